@@ -1,0 +1,221 @@
+"""Deterministic "Silesia-like" synthetic corpus -- test/bench infrastructure.
+
+Every byte is a pure function of (seed, frame index, position) through a 32-bit integer hash evaluated with
+int64 tensor ops, so the same frames come out of torch-on-CPU (tests, here) and torch-on-GPU (bench.py generates
+the 65 536 x 128 KiB workload directly in HBM).  Classes per 128 KiB slice, by frame index hash:
+
+  text    40 %  Zipf-distributed words from an 8 Ki-word vocabulary            (ratio ~3,   dickens/webster-like)
+  record  22 %  JSON/XML-ish records: fixed key tokens + variable value tokens (ratio ~6-9, xml/nci-like)
+  binary  14 %  16-byte little-endian records with small deltas                (ratio ~2,   sao/x-ray/mr-like)
+  exe     14 %  opcode-ish snippets from a binary vocabulary + random operands (ratio ~2,   mozilla/ooffice-like)
+  random   5 %  incompressible                                                 (raw-block path)
+  runs     5 %  long byte runs with occasional breaks                          (RLE-ish / tiny frames)
+"""
+import torch
+
+M32 = 0xFFFFFFFF
+CLASS_NAMES = ("text", "record", "binary", "exe", "random", "runs")
+_CLASS_CUM = (40, 62, 76, 90, 95, 100)
+
+
+def _mix(x):
+    """murmur3 finalizer on int64 tensors holding 32-bit values."""
+    x = x & M32
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _h(seed, a, b=0):
+    """hash of (seed, a, b) -> 32-bit value (int64 tensor, broadcasting)."""
+    return _mix(_mix(a * 0x9E3779B1 + seed) ^ (b * 0x7FEB352D + 0x165667B1))
+
+
+def _vocab(seed, n_words, min_len, max_len, alphabet, device):
+    """flat byte table + starts + lengths for n_words pseudo-words over `alphabet` (uint8 tensor)."""
+    w = torch.arange(n_words, dtype=torch.int64, device=device)
+    lens = min_len + _h(seed, w, 1) % (max_len - min_len + 1)
+    starts = torch.cumsum(lens, 0) - lens
+    total = int(lens.sum())
+    pos = torch.arange(total, dtype=torch.int64, device=device)
+    word_of = torch.repeat_interleave(w, lens)
+    off = pos - starts[word_of]
+    # skewed letter choice: square of a uniform picks early alphabet entries more often
+    u = _h(seed + 7, word_of, off) % 4096
+    idx = (u * u * alphabet.numel()) >> 24
+    table = alphabet[idx]
+    return table, starts, lens
+
+
+class Corpus:
+    def __init__(self, seed=20260924, frame_size=131072, device="cpu"):
+        self.seed = seed
+        self.n = frame_size
+        self.dev = torch.device(device)
+        d = self.dev
+        letters = torch.tensor(list(b"etaoinshrdlcumwfgypbvkjxqz"), dtype=torch.uint8, device=d)
+        tbl, st, ln = _vocab(seed + 11, 8192, 2, 10, letters, d)
+        # append separators: every word carries a trailing space (or ", " / ".\n" for a few ids)
+        self.text_vocab = self._with_suffix(tbl, st, ln, [b" "] * 13 + [b", ", b". ", b".\n"])
+        digits = torch.tensor(list(b"0123456789abcdef-_"), dtype=torch.uint8, device=d)
+        tbl, st, ln = _vocab(seed + 13, 4096, 1, 8, digits, d)
+        self.val_vocab = (tbl, st, ln)
+        keys = [b'{"id": ', b', "name": "', b'", "kind": "', b'", "value": ', b', "ts": ', b', "tags": ["',
+                b'", "', b'"], "ok": ', b"}\n", b"<item key=\"", b"\">", b"</item>\n"]
+        self.key_vocab = self._literal_vocab(keys)
+        ops = torch.arange(256, dtype=torch.int64, device=d)
+        ops = ((ops * 167 + 13) & 255).to(torch.uint8)
+        tbl, st, ln = _vocab(seed + 17, 2048, 2, 9, ops, d)
+        self.exe_vocab = (tbl, st, ln)
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _literal_vocab(self, items):
+        d = self.dev
+        tbl = torch.tensor(list(b"".join(items)), dtype=torch.uint8, device=d)
+        ln = torch.tensor([len(i) for i in items], dtype=torch.int64, device=d)
+        st = torch.cumsum(ln, 0) - ln
+        return tbl, st, ln
+
+    def _with_suffix(self, tbl, st, ln, suffixes):
+        d = self.dev
+        n = ln.numel()
+        suf_tbl, suf_st, suf_ln = self._literal_vocab(suffixes)
+        which = torch.arange(n, dtype=torch.int64, device=d) % len(suffixes)
+        new_ln = ln + suf_ln[which]
+        new_st = torch.cumsum(new_ln, 0) - new_ln
+        total = int(new_ln.sum())
+        pos = torch.arange(total, dtype=torch.int64, device=d)
+        word_of = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=d), new_ln)
+        off = pos - new_st[word_of]
+        in_word = off < ln[word_of]
+        a = tbl[(st[word_of] + off).clamp(max=tbl.numel() - 1)]
+        b = suf_tbl[(suf_st[which[word_of]] + (off - ln[word_of]).clamp(min=0)).clamp(max=suf_tbl.numel() - 1)]
+        return torch.where(in_word, a, b), new_st, new_ln
+
+    def _tokens_to_bytes(self, tok_tbl_id, tok_idx, vocabs):
+        """tok_idx [B, W] token ids into vocab `tok_tbl_id[B, W]` (index into vocabs) -> bytes [B, n]."""
+        B, W = tok_idx.shape
+        d = self.dev
+        lens = torch.zeros_like(tok_idx)
+        starts = torch.zeros_like(tok_idx)
+        base = 0
+        tables = []
+        for k, (tbl, st, ln) in enumerate(vocabs):
+            m = tok_tbl_id == k
+            idx = tok_idx.clamp(max=ln.numel() - 1)
+            lens = torch.where(m, ln[idx], lens)
+            starts = torch.where(m, st[idx] + base, starts)
+            tables.append(tbl)
+            base += tbl.numel()
+        table = torch.cat(tables)
+        ends = torch.cumsum(lens, 1)
+        pos = torch.arange(self.n, dtype=torch.int64, device=d).expand(B, self.n).contiguous()
+        w = torch.searchsorted(ends, pos, right=True).clamp(max=W - 1)
+        off = pos - (torch.gather(ends, 1, w) - torch.gather(lens, 1, w))
+        src = (torch.gather(starts, 1, w) + off).clamp(min=0, max=table.numel() - 1)
+        return table[src]
+
+    # -- classes ---------------------------------------------------------------------------------------
+    def classes(self, idx):
+        r = _h(self.seed + 1, idx) % 100
+        c = torch.zeros_like(idx)
+        for k, cum in enumerate(_CLASS_CUM[:-1]):
+            c = c + (r >= cum).to(torch.int64)
+        return c
+
+    def _gen_text(self, fi):
+        B = fi.numel(); W = self.n // 3 + 8
+        w = torch.arange(W, dtype=torch.int64, device=self.dev)
+        u = _h(self.seed + 2, fi[:, None], w[None, :]) % 65536
+        # Zipf-ish: cube of a uniform -> heavy head; plus per-frame topic offset so frames differ
+        z = (u * u * u) >> 35           # 0 .. 8191
+        topic = (_h(self.seed + 3, fi) % 8192)[:, None]
+        tok = torch.where((u & 7) == 0, (z + topic) % 8192, z)
+        # a third of the 8-word groups are stock phrases out of a per-topic set of 256 (long matches)
+        grp = _h(self.seed + 22, fi[:, None], w[None, :] >> 3)
+        phrase = _h(self.seed + 23, (grp >> 8) % 256 + (topic & 0xF00), w[None, :] & 7) % 8192
+        tok = torch.where(grp % 3 == 0, (phrase * phrase) >> 13, tok)
+        return self._tokens_to_bytes(torch.zeros_like(tok), tok, [self.text_vocab])
+
+    def _gen_record(self, fi):
+        B = fi.numel(); W = self.n // 3 + 16
+        w = torch.arange(W, dtype=torch.int64, device=self.dev)
+        style = (_h(self.seed + 4, fi) & 1)[:, None]           # json-ish or xml-ish
+        slot = w[None, :] % 18
+        is_key = (slot & 1) == 0
+        json_key = (slot >> 1) % 9
+        xml_key = 9 + (slot >> 1) % 3
+        key = torch.where(style == 0, json_key, xml_key)
+        u = _h(self.seed + 5, fi[:, None], w[None, :])
+        val = ((u % 4096) * (u % 4096)) >> 12                  # skewed values
+        val = torch.where((u >> 13) % 4 != 0, (val * val) >> 14, val)
+        rec = w[None, :] // 18
+        val = torch.where(slot == 1, rec % 4096, val)          # incrementing ids
+        tok = torch.where(is_key, key, val)
+        tid = torch.where(is_key, torch.zeros_like(tok), torch.ones_like(tok))
+        return self._tokens_to_bytes(tid, tok, [self.key_vocab, self.val_vocab])
+
+    def _gen_binary(self, fi):
+        n = self.n
+        p = torch.arange(n, dtype=torch.int64, device=self.dev)[None, :]
+        rec, field, byte = p >> 4, (p >> 2) & 3, p & 3
+        f = fi[:, None]
+        noise = _h(self.seed + 6, f, rec * 4 + field)
+        counter = rec * 3 + (_h(self.seed + 8, f) & 0xFFFF)
+        wave = ((rec * (1 + (f & 7))) & 1023) * 37 + (noise & 15) + 0x3F800000
+        small = (noise >> 8) & 0xFF
+        sel = (noise >> 20) & 0xFFF
+        v = torch.where(field == 0, counter, torch.where(field == 1, wave, torch.where(field == 2, small, sel)))
+        return ((v >> (8 * byte)) & 255).to(torch.uint8)
+
+    def _gen_exe(self, fi):
+        B = fi.numel(); W = self.n // 2 + 8
+        w = torch.arange(W, dtype=torch.int64, device=self.dev)
+        u = _h(self.seed + 9, fi[:, None], w[None, :])
+        z = ((u % 2048) * (u % 2048)) >> 11
+        local = (_h(self.seed + 10, fi[:, None], w[None, :] >> 6) % 2048)   # local working set of snippets
+        tok = torch.where((u >> 12) % 3 == 0, local, z)
+        # every 4th token is a 1-token "operand" from the value vocab (higher entropy)
+        is_op = (w[None, :] & 3) == 3
+        tok = torch.where(is_op, (u >> 7) % 4096, tok)
+        tid = is_op.to(torch.int64).expand_as(tok)
+        return self._tokens_to_bytes(tid, tok, [self.exe_vocab, self.val_vocab])
+
+    def _gen_random(self, fi):
+        p = torch.arange(self.n, dtype=torch.int64, device=self.dev)[None, :]
+        v = _h(self.seed + 12, fi[:, None], p >> 2)
+        return ((v >> (8 * (p & 3))) & 255).to(torch.uint8)
+
+    def _gen_runs(self, fi):
+        p = torch.arange(self.n, dtype=torch.int64, device=self.dev)[None, :]
+        f = fi[:, None]
+        shift = 6 + (_h(self.seed + 14, f) % 9)               # run length 64 .. 16384
+        run = p >> shift
+        v = _h(self.seed + 15, f, run) & 255
+        glitch = (_h(self.seed + 16, f, p) % 997) == 0
+        v = torch.where(glitch, _h(self.seed + 18, f, p) & 255, v)
+        whole = (_h(self.seed + 19, f) % 4) == 0              # a quarter of them: one single byte value
+        v = torch.where(whole, (_h(self.seed + 21, f) & 255).expand_as(v), v)
+        return v.to(torch.uint8)
+
+    # -- public ----------------------------------------------------------------------------------------
+    def frames(self, start, count, chunk=64):
+        """uint8 tensor [count, frame_size] holding frames start .. start+count-1."""
+        out = torch.empty((count, self.n), dtype=torch.uint8, device=self.dev)
+        gens = (self._gen_text, self._gen_record, self._gen_binary, self._gen_exe, self._gen_random, self._gen_runs)
+        for c0 in range(0, count, chunk):
+            c1 = min(count, c0 + chunk)
+            fi = torch.arange(start + c0, start + c1, dtype=torch.int64, device=self.dev)
+            cls = self.classes(fi)
+            for k, g in enumerate(gens):
+                m = cls == k
+                if bool(m.any()):
+                    sel = torch.nonzero(m).flatten()
+                    out[c0 + sel] = g(fi[sel])
+        return out
+
+    def frame_bytes(self, i):
+        return self.frames(i, 1)[0].cpu().numpy().tobytes()
