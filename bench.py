@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): multi_decompress_to_buffer over 65 536 pre-compressed level-3 frames of
+128 KiB "Silesia-like" slices per GPU, inputs and outputs resident in HBM. A step = one pass over all frames.
+value = uncompressed GB/s (1e9) over all ranks; roofline = (compressed + uncompressed bytes) / kernel time vs HBM peak.
+cpu_baseline = the reference libzstd 1.5.7 (oracle/_ref) decoding a bounded sample of the same frames on host cores.
+
+  python bench.py [--gpus N --steps K --warmup W --frames F]
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FRAME = 131072
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _ref_lib():
+    """libzstd 1.5.7 as the input generator and CPU baseline: the reference build, else the copy inside the image."""
+    from tests import reflib
+    if reflib.have_ref():
+        return reflib.RefZstd(), "reference"
+    import glob
+    cands = glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd-*.so.1.5.7")
+    if cands:
+        reflib.REF_SO = cands[0]
+        return reflib.RefZstd(), "reference"
+    raise RuntimeError("no libzstd 1.5.7 available to prepare the bench input")
+
+
+def _threads():
+    return max(1, min(os.cpu_count() or 1, 64))
+
+
+def compress_on_host(ref, raw_np, nthreads):
+    """level-3 frames of every row of raw_np [F, FRAME] with the reference library, contiguous partition by bytes."""
+    F = raw_np.shape[0]
+    bound = ref.lib.ZSTD_compressBound(FRAME)
+    outs = [None] * F
+    base = raw_np.ctypes.data
+
+    def work(lo, hi):
+        buf = C.create_string_buffer(bound)
+        for i in range(lo, hi):
+            n = ref.compress_into(C.addressof(buf), bound, base + i * FRAME, FRAME)
+            outs[i] = buf.raw[:n]
+
+    step = (F + nthreads - 1) // nthreads
+    ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    return outs
+
+
+def cpu_decompress_baseline(ref, frames, nthreads, budget_s=8.0):
+    """reference ZSTD_decompressStream on a bounded sample, one DCtx per thread (decompress_worker's loop)."""
+    F = len(frames)
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    offs = np.zeros(F + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(f) for f in frames])
+    base = blob.ctypes.data
+
+    def work(lo, hi):
+        dctx = ref.lib.ZSTD_createDCtx()
+        dst = C.create_string_buffer(FRAME)
+        for i in range(lo, hi):
+            ref.decompress_into(dctx, C.addressof(dst), FRAME, base + int(offs[i]), int(offs[i + 1] - offs[i]))
+        ref.lib.ZSTD_freeDCtx(dctx)
+
+    step = (F + nthreads - 1) // nthreads
+    best, reps, t_start = None, 0, time.time()
+    while reps < 3 or (time.time() - t_start < budget_s and reps < 50):
+        ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
+        t0 = time.time()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+        if time.time() - t_start > budget_s:
+            break
+    return F * FRAME / best / 1e9, reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (BASELINE config: 65536)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import zstandard_amd as zstd
+    from zstandard_amd.device import DeviceBatchContext
+    from tests.corpus import Corpus
+
+    F = args.frames
+    t0 = time.time()
+    corpus = Corpus(device=dev)
+    raw = corpus.frames(rank * F, F, chunk=256)                      # [F, FRAME] uint8 in HBM (this rank's shard)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    ref, ref_kind = _ref_lib()
+    nthreads = _threads()
+    t0 = time.time()
+    raw_np = raw.cpu().numpy()
+    frames = compress_on_host(ref, raw_np, nthreads)
+    t_comp = time.time() - t0
+    csizes = np.array([len(f) for f in frames], dtype=np.int64)
+    ctotal = int(csizes.sum())
+    src_segs_np = np.zeros((F, 2), dtype=np.int64)
+    src_segs_np[:, 1] = csizes
+    src_segs_np[1:, 0] = np.cumsum(csizes)[:-1]
+    dst_segs_np = np.zeros((F, 2), dtype=np.int64)
+    dst_segs_np[:, 0] = np.arange(F, dtype=np.int64) * FRAME
+    dst_segs_np[:, 1] = FRAME
+    src = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).to(dev)
+    src_segs = torch.from_numpy(src_segs_np).to(dev)
+    dst_segs = torch.from_numpy(dst_segs_np).to(dev)
+    dst = torch.zeros(F * FRAME, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    status = torch.zeros(F, dtype=torch.int32, device=dev)
+
+    ctx = DeviceBatchContext()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
+    barrier()
+    ctx.kernel_time(0)                                               # reset the per-kernel timers
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.kernel_time(0)
+
+    # correctness gate at full size: every frame decoded, every byte equals the original input
+    assert int(status.abs().max().item()) == 0, "a frame failed to decode"
+    assert bool((out_sizes == FRAME).all().item())
+    assert torch.equal(dst.view(F, FRAME), raw), "round-trip mismatch"
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only cross-rank exchange the path needs: the segment table of the sharded result (payload stays per GPU)
+        gathered = [torch.zeros_like(out_sizes) for _ in range(world)]
+        dist.all_gather(gathered, out_sizes)
+
+    total_unc = world * F * FRAME
+    value = total_unc * args.steps / elapsed / 1e9
+    line = {
+        "metric": "GB/s uncompressed throughput, batch decompress of 128 KiB level-3 frames",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "multi_decompress_to_buffer (device-resident): %d x 128 KiB Silesia-like frames per GPU, "
+                               "level 3, frames compressed by libzstd 1.5.7" % F,
+                   "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3,
+                   "compression_ratio": round(F * FRAME / ctotal, 3), "parallelism": "frames sharded by rank, no data-path collective"},
+    }
+    if rank == 0:
+        algo_bytes = F * FRAME + ctotal                              # per launch: compressed read + uncompressed written
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(0), "achieved": round(achieved, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                            "traffic": None, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                            "algorithmic_bytes_per_launch": int(algo_bytes)}
+        if world == 1 and not args.no_cpu_baseline:
+            sample = min(F, 4096)
+            v, reps = cpu_decompress_baseline(ref, frames[:sample], nthreads)
+            line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
+                                    "sample": "libzstd 1.5.7 ZSTD_decompressStream over the first %d frames of the same "
+                                              "workload, %d threads (host has %d cores), best of %d passes"
+                                              % (sample, nthreads, os.cpu_count() or 0, reps)}
+        line["setup_s"] = {"generate": round(t_gen, 1), "host_compress": round(t_comp, 1)}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,123 @@
+/* include/zstd_hip.h -- C ABI of libzstd_hip.so, the MI355X (gfx950) backend for python-zstandard's
+ * batch / one-shot frame hot path.
+ *
+ * Plain C, plain pointers and sizes, no torch / Python types. These entry points are what the reference's
+ * C extension would bind in place of its file-local batch workers:
+ *
+ *   zhip_compress_batch    replaces  compress_from_datasources()   c-ext/compressor.c:1083-1336
+ *                                    + compress_worker()           c-ext/compressor.c:856-1076
+ *   zhip_decompress_batch  replaces  decompress_from_framesources() c-ext/decompressor.c:1185-1455
+ *                                    + decompress_worker()          c-ext/decompressor.c:944-1181
+ *   zhip_item              ==        DataSource / FramePointer      c-ext/compressor.c:805-808, decompressor.c:892-896
+ *   zhip_segment           ==        BufferSegment                  c-ext/python-zstandard.h:307-313
+ *   zhip_outbuf            ==        CompressorDestBuffer / DecompressorDestBuffer (compressor.c:816-821,
+ *                                    decompressor.c:904-909): malloc()ed by the callee, ownership passes to the
+ *                                    caller exactly like BufferWithSegments_FromMemory(useFree=1) expects
+ *                                    (c-ext/bufferutil.c:107-148).
+ *   error classes          ==        CompressorWorkerError / DecompressorWorkerError (compressor.c:823-828,
+ *                                    decompressor.c:911-917) + first failing item index + zstd error code
+ *                                    (numeric values of zstd/zstd_errors.h:61-97).
+ *
+ * The *_device entry points are the same operations with every buffer already resident in HBM
+ * (what bench.py times and what a multi-GPU caller shards); the host-buffer entry points wrap them with
+ * H2D / D2H copies. INTEGRATION.md shows the reference-side stub.
+ */
+#ifndef ZSTD_HIP_H
+#define ZSTD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZHIP_ABI_VERSION 1
+
+typedef struct { uint64_t offset, length; } zhip_segment;             /* BufferSegment */
+typedef struct { const void* src; size_t srcSize; size_t dstSize; } zhip_item; /* dstSize: decompress only (0 = unknown) */
+typedef struct { void* data; size_t dataSize; zhip_segment* segs; size_t nSegs; } zhip_outbuf;
+
+/* worker error classes (values follow the reference enums) */
+enum {
+    ZHIP_ERR_NONE = 0,
+    ZHIP_ERR_ZSTD = 1,          /* zstdErr holds the zstd error code */
+    ZHIP_ERR_NO_MEMORY = 2,
+    ZHIP_ERR_SIZE_MISMATCH = 3, /* decompress: produced != expected (errDetail = produced, expected) ; compress: nospace */
+    ZHIP_ERR_UNKNOWN_SIZE = 4,  /* decompress: frame has no content size and none supplied */
+    ZHIP_ERR_HIP = 5,           /* HIP runtime failure; zhip_last_error() has the text */
+    ZHIP_ERR_UNSUPPORTED = 6    /* parameter combination not implemented by this backend (fails loudly) */
+};
+
+typedef struct {
+    int kind;            /* ZHIP_ERR_* */
+    int zstdErr;         /* zstd error code when kind == ZHIP_ERR_ZSTD */
+    size_t index;        /* first failing item */
+    uint64_t detail[2];  /* size mismatch: produced, expected */
+} zhip_error;
+
+/* compression parameters the hot path reads (the reference keeps them in ZSTD_CCtx_params,
+ * c-ext/compressor.c:209-233; defaults there: contentSize=1, checksum=0, dictID=1). */
+typedef struct {
+    int level;
+    int contentSizeFlag, checksumFlag, dictIDFlag;
+    const void* dict; size_t dictSize;      /* raw bytes of a ZstdCompressionDict (or NULL) */
+} zhip_cparams;
+
+typedef struct {
+    const void* dict; size_t dictSize;      /* raw bytes of a ZstdCompressionDict (or NULL) */
+    uint64_t maxWindowSize;                 /* 0 = default (1 << 27) */
+} zhip_dparams;
+
+/* ---- library / device ---- */
+int         zhip_abi_version(void);
+int         zhip_device_count(void);
+int         zhip_set_device(int device);
+const char* zhip_last_error(void);                  /* thread-local text of the last ZHIP_ERR_HIP */
+const char* zhip_error_name(int zstdErr);            /* same strings as ZSTD_getErrorName (zstd.c:3580-3616) */
+size_t      zhip_compress_bound(size_t srcSize);     /* ZSTD_compressBound, zstd.h:249 */
+
+/* ---- frame inspection (host, no GPU): ZSTD_getFrameContentSize zstd.c:43790, ZSTD_findFrameCompressedSize :44022 */
+#define ZHIP_CONTENTSIZE_UNKNOWN ((uint64_t)-1)
+#define ZHIP_CONTENTSIZE_ERROR   ((uint64_t)-2)
+uint64_t zhip_frame_content_size(const void* src, size_t srcSize);
+int64_t  zhip_find_frame_compressed_size(const void* src, size_t srcSize);  /* <0: -(zstd error code) */
+
+/* ---- host-buffer batch API (drop-in for the reference's workers) ----
+ * items are borrowed; *out is an array of *nOut malloc()ed buffers the caller owns (free each data/segs, then the
+ * array with zhip_free_outbufs or free()). Returns ZHIP_ERR_NONE or fills *err. Re-entrant; call with the GIL released. */
+int  zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, size_t n,
+                         zhip_outbuf** out, size_t* nOut, zhip_error* err);
+int  zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
+                           zhip_outbuf** out, size_t* nOut, zhip_error* err);
+void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload);
+
+/* ---- device-resident batch API (all pointers are HBM addresses on the current device) ----
+ * A context owns the per-launch scratch (literal buffers, hash tables, work counters, status words) so repeated
+ * calls allocate nothing. `stream` is a hipStream_t passed as void* (NULL = default stream). Calls are asynchronous;
+ * zhip_ctx_sync() waits and returns the first failing frame (lowest index) like the reference's workers do. */
+typedef struct zhip_ctx zhip_ctx;
+zhip_ctx* zhip_ctx_create(void);
+void      zhip_ctx_destroy(zhip_ctx*);
+int       zhip_ctx_set_ddict(zhip_ctx*, const void* hostDict, size_t dictSize);   /* parses + uploads; NULL clears */
+int       zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams* params);            /* uploads dict / tables */
+
+/* d_src: concatenated frames; d_srcSegs[i] = (offset,length) of frame i in d_src.
+ * d_dst: output arena;        d_dstSegs[i] = (offset, capacity) where frame i must be written.
+ * d_outSizes[i] receives the produced size, d_status[i] 0 or a zstd error code. */
+int zhip_decompress_batch_device(zhip_ctx*, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
+                                 void* d_dst, const zhip_segment* d_dstSegs,
+                                 uint64_t* d_outSizes, int32_t* d_status, void* stream);
+/* d_dstSegs[i].length must be >= zhip_compress_bound(d_srcSegs[i].length). */
+int zhip_compress_batch_device(zhip_ctx*, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
+                               void* d_dst, const zhip_segment* d_dstSegs,
+                               uint64_t* d_outSizes, int32_t* d_status, void* stream);
+int zhip_ctx_sync(zhip_ctx*, void* stream, const int32_t* d_status, size_t n, zhip_error* err);
+
+/* name of the dominant kernel of each direction as it appears in rocprofv3 traces, and its average duration (ms)
+ * over the launches since the last call, measured with HIP events on the launch stream (for bench.py's roofline). */
+const char* zhip_kernel_name(int direction /*0 decompress, 1 compress*/);
+int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,110 @@
+// zhip_device.hpp -- the few wave-level primitives the kernels are written against.
+//
+// Product build (hipcc, gfx950): thin inline wrappers over HIP/AMDGCN builtins. 64-lane wavefronts,
+// one wavefront per workgroup (blockDim.x == 64), so __syncthreads() is a wave-local LDS fence.
+//
+// ZHIP_EMU build (g++, tests/emu only): the same kernel source runs on the host with each lane as a
+// ucontext fiber and every collective implemented as a rendezvous. It exists so kernel LOGIC can be
+// debugged in a container without a GPU; it is compiled only by tests/emu/build.sh into tests/emu/,
+// is never part of libzstd_hip.so and is not reachable from the python package.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifndef ZHIP_EMU
+// =====================================================================================  device
+#include <hip/hip_runtime.h>
+#define ZH_DEV __device__ __forceinline__
+#define ZH_DEVFN __device__
+#define ZH_GLOBAL extern "C" __global__
+#define ZH_SHARED __shared__
+#define ZH_CONST __device__ const
+
+ZH_DEV uint32_t zh_lane() { return threadIdx.x; }
+ZH_DEV uint32_t zh_block() { return blockIdx.x; }
+ZH_DEV uint32_t zh_nblocks() { return gridDim.x; }
+ZH_DEV void zh_sync() { __syncthreads(); }
+ZH_DEV uint64_t zh_ballot(bool p) { return __ballot(p); }
+ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl((int)v, (int)srcLane, 64); }
+ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }
+ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
+ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
+ZH_DEV int zh_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }   // v != 0
+ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
+
+#else
+// =====================================================================================  emulation
+#include <string.h>
+#define ZH_DEV static inline
+#define ZH_DEVFN
+#define ZH_GLOBAL extern "C"
+#define ZH_SHARED static
+#define ZH_CONST static const
+
+namespace zhemu {
+void collective_wait();                 // rendezvous of all live lanes of the current wave
+extern thread_local uint32_t lane, block, nblocks;
+extern thread_local uint64_t slot[64];  // per-lane exchange slots
+extern thread_local uint64_t result;
+typedef void (*lane_fn)(void*);
+void run_grid(uint32_t nBlocks, lane_fn fn, void* arg);   // runs fn(arg) on 64 fibers per block
+}
+ZH_DEV uint32_t zh_lane() { return zhemu::lane; }
+ZH_DEV uint32_t zh_block() { return zhemu::block; }
+ZH_DEV uint32_t zh_nblocks() { return zhemu::nblocks; }
+ZH_DEV void zh_sync() { zhemu::collective_wait(); }
+ZH_DEV uint64_t zh_ballot(bool p)
+{
+    zhemu::slot[zhemu::lane] = p ? 1 : 0;
+    zhemu::collective_wait();
+    uint64_t m = 0;
+    for (int i = 0; i < 64; i++) m |= (uint64_t)(zhemu::slot[i] & 1) << i;
+    zhemu::collective_wait();
+    return m;
+}
+ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane)
+{
+    zhemu::slot[zhemu::lane] = v;
+    zhemu::collective_wait();
+    uint32_t r = (uint32_t)zhemu::slot[srcLane & 63];
+    zhemu::collective_wait();
+    return r;
+}
+ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d)
+{
+    zhemu::slot[zhemu::lane] = v;
+    zhemu::collective_wait();
+    uint32_t r = zhemu::lane >= d ? (uint32_t)zhemu::slot[zhemu::lane - d] : v;
+    zhemu::collective_wait();
+    return r;
+}
+ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
+ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }
+ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
+ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
+#endif
+
+// ------------------------------------------------------------------------------------- common helpers
+typedef uint64_t __attribute__((aligned(1))) zh_u64u;
+typedef uint32_t __attribute__((aligned(1))) zh_u32u;
+typedef uint16_t __attribute__((aligned(1))) zh_u16u;
+ZH_DEV uint64_t zh_ld64(const uint8_t* p) { return *(const zh_u64u*)p; }
+ZH_DEV uint32_t zh_ld32(const uint8_t* p) { return *(const zh_u32u*)p; }
+ZH_DEV uint32_t zh_ld16(const uint8_t* p) { return *(const zh_u16u*)p; }
+ZH_DEV uint32_t zh_ld24(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+ZH_DEV void zh_st64(uint8_t* p, uint64_t v) { *(zh_u64u*)p = v; }
+ZH_DEV void zh_st32(uint8_t* p, uint32_t v) { *(zh_u32u*)p = v; }
+ZH_DEV void zh_st16(uint8_t* p, uint16_t v) { *(zh_u16u*)p = v; }
+ZH_DEV uint64_t zh_lt_mask() { return (1ull << zh_lane()) - 1; }
+
+// inclusive wave prefix sum (all 64 lanes must call)
+ZH_DEV uint32_t zh_scan_add(uint32_t v)
+{
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t t = zh_shfl_up(v, d);
+        if (zh_lane() >= d) v += t;
+    }
+    return v;
+}

@@ -1,0 +1,55 @@
+// zhip_format.hpp -- zstd format constants (RFC 8878) and error codes shared by host and device code.
+#pragma once
+#include <stdint.h>
+
+// numeric values = the reference's public enum (zstd/zstd_errors.h:61-97)
+enum {
+    ZE_OK = 0, ZE_GENERIC = 1, ZE_PREFIX_UNKNOWN = 10, ZE_FRAMEPARAM_UNSUPPORTED = 14, ZE_WINDOW_TOO_LARGE = 16,
+    ZE_CORRUPTION = 20, ZE_CHECKSUM_WRONG = 22, ZE_LITERALS_HEADER_WRONG = 24, ZE_DICT_CORRUPTED = 30,
+    ZE_DICT_WRONG = 32, ZE_PARAM_UNSUPPORTED = 40, ZE_TABLELOG_TOO_LARGE = 44, ZE_MAXSYMBOL_TOO_LARGE = 46,
+    ZE_MAXSYMBOL_TOO_SMALL = 48, ZE_MEMORY = 64, ZE_DST_TOO_SMALL = 70, ZE_SRC_SIZE_WRONG = 72
+};
+
+#define ZF_MAGIC 0xFD2FB528u
+#define ZF_DICT_MAGIC 0xEC30A437u
+#define ZF_BLOCK_MAX (1u << 17)
+#define ZF_MAXLL 35
+#define ZF_MAXML 52
+#define ZF_MAXOFF 31
+#define ZF_LL_LOGMAX 9
+#define ZF_ML_LOGMAX 9
+#define ZF_OF_LOGMAX 8
+
+// literal scratch per resident wave: one block's literals (<=128 KiB) + slack for wide stores
+#define ZHIP_LIT_STRIDE (ZF_BLOCK_MAX + 256)
+
+// Parsed dictionary entropy section, uploaded once per context (decode side).
+// Mirrors what ZSTD_loadDEntropy (zstd.c:44673) extracts: a Huffman table, three FSE distributions, three repcodes.
+struct ZhipDictEntropy {
+    uint8_t  hufWeights[256];
+    uint32_t hufCount;          // number of weights including the implied last one (0 = no entropy tables: raw dict)
+    int16_t  ofNorm[32]; uint32_t ofMax, ofLog;
+    int16_t  mlNorm[53]; uint32_t mlMax, mlLog;
+    int16_t  llNorm[36]; uint32_t llMax, llLog;
+    uint32_t rep[3];
+    uint32_t contentOffset;     // byte offset of the raw content inside the dictionary blob
+    uint32_t dictID;
+    int32_t  status;            // 0 or a zstd error code (ZE_DICT_CORRUPTED)
+};
+
+struct ZhipDecodeArgs {
+    const uint8_t* src;             // all frames
+    const uint64_t* srcSegs;        // n x (offset, length)
+    uint8_t* dst;
+    const uint64_t* dstSegs;        // n x (offset, capacity)
+    uint64_t* outSizes;             // n
+    int32_t* status;                // n
+    uint8_t* scratch;               // gridDim.x * ZHIP_LIT_STRIDE
+    uint32_t* counter;              // work-stealing counter, zeroed before launch
+    uint32_t n;
+    uint32_t dictID;
+    const uint8_t* dictContent;     // may be null
+    uint32_t dictContentSize;
+    const ZhipDictEntropy* dictEntropy; // null when no dictionary or raw-content dictionary
+    uint64_t maxWindowSize;
+};

@@ -1,0 +1,368 @@
+// zhip_lib.hip -- libzstd_hip.so: C ABI (include/zstd_hip.h) + kernel entry points, compiled for gfx950 only.
+//
+// Host side = the batch dispatcher that replaces compress_from_datasources / decompress_from_framesources
+// (c-ext/compressor.c:1083, c-ext/decompressor.c:1185): instead of partitioning frames over a pthread pool
+// (POOL_*, zstd.c:7537-7975) it stages them in HBM and launches persistent one-wave workgroups that pull frame
+// indices from an atomic counter.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/zstd_hip.h"
+#include "zhip_decode_kernel.hpp"
+
+// ------------------------------------------------------------------------------------------ kernels
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
+{
+    __shared__ ZdLDS L;
+    zd_kernel_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_parse_dict_kernel(const uint8_t* dict, uint32_t dictSize, ZhipDictEntropy* de)
+{
+    __shared__ ZdLDS L;
+    zd_dict_body(dict, dictSize, de, L);
+}
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_lastError;
+static int hip_fail(hipError_t e, const char* what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    g_lastError = buf;
+    return ZHIP_ERR_HIP;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+extern "C" const char* zhip_last_error(void) { return g_lastError.c_str(); }
+extern "C" int zhip_abi_version(void) { return ZHIP_ABI_VERSION; }
+extern "C" int zhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int zhip_set_device(int d) { HIP_TRY(hipSetDevice(d)); return 0; }
+extern "C" size_t zhip_compress_bound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
+
+extern "C" const char* zhip_error_name(int code)
+{
+    switch (code) {   // strings of ERR_getErrorString, zstd.c:3580-3616
+    case ZE_OK: return "No error detected";
+    case ZE_GENERIC: return "Error (generic)";
+    case ZE_PREFIX_UNKNOWN: return "Unknown frame descriptor";
+    case ZE_FRAMEPARAM_UNSUPPORTED: return "Unsupported frame parameter";
+    case ZE_WINDOW_TOO_LARGE: return "Frame requires too much memory for decoding";
+    case ZE_CORRUPTION: return "Data corruption detected";
+    case ZE_CHECKSUM_WRONG: return "Restored data doesn't match checksum";
+    case ZE_LITERALS_HEADER_WRONG: return "Header of Literals' block doesn't respect format specification";
+    case ZE_DICT_CORRUPTED: return "Dictionary is corrupted";
+    case ZE_DICT_WRONG: return "Dictionary mismatch";
+    case ZE_PARAM_UNSUPPORTED: return "Unsupported parameter";
+    case ZE_TABLELOG_TOO_LARGE: return "tableLog requires too much memory : unsupported";
+    case ZE_MAXSYMBOL_TOO_LARGE: return "Unsupported max Symbol Value : too large";
+    case ZE_MAXSYMBOL_TOO_SMALL: return "Specified maxSymbolValue is too small";
+    case ZE_MEMORY: return "Allocation error : not enough memory";
+    case ZE_DST_TOO_SMALL: return "Destination buffer is too small";
+    case ZE_SRC_SIZE_WRONG: return "Src size is incorrect";
+    default: return "Unspecified error code";
+    }
+}
+
+// ------------------------------------------------------------------------------------------ frame inspection (host)
+static inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+static inline uint32_t rd24(const uint8_t* p) { return rd16(p) | ((uint32_t)p[2] << 16); }
+static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+struct HostFrameHeader { uint64_t contentSize; uint32_t headerSize; uint32_t hasChecksum; };
+// RFC 8878 3.1.1.1; restates ZSTD_getFrameHeader_advanced (zstd.c:43668) for the fields the dispatcher needs.
+static int host_frame_header(HostFrameHeader* h, const uint8_t* src, size_t n)
+{
+    if (n < 5) return -ZE_SRC_SIZE_WRONG;
+    if (rd32(src) != ZF_MAGIC) return -ZE_PREFIX_UNKNOWN;
+    uint32_t fhd = src[4], dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
+    uint32_t dictBytes = dictCode == 3 ? 4 : dictCode, fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
+    uint32_t hs = 5 + (single ? 0 : 1) + dictBytes + fcsBytes;
+    if (fhd & 8) return -ZE_FRAMEPARAM_UNSUPPORTED;
+    if (n < hs) return -ZE_SRC_SIZE_WRONG;
+    const uint8_t* p = src + 5 + (single ? 0 : 1) + dictBytes;
+    h->contentSize = ZHIP_CONTENTSIZE_UNKNOWN;
+    if (fcsCode == 0) { if (single) h->contentSize = p[0]; }
+    else if (fcsCode == 1) h->contentSize = (uint64_t)rd16(p) + 256;
+    else if (fcsCode == 2) h->contentSize = rd32(p);
+    else h->contentSize = rd64(p);
+    h->headerSize = hs; h->hasChecksum = (fhd >> 2) & 1;
+    return 0;
+}
+extern "C" uint64_t zhip_frame_content_size(const void* src, size_t n)
+{
+    HostFrameHeader h;
+    if (host_frame_header(&h, (const uint8_t*)src, n) < 0) return ZHIP_CONTENTSIZE_ERROR;
+    return h.contentSize;
+}
+extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
+{
+    const uint8_t* src = (const uint8_t*)srcv;
+    HostFrameHeader h; int e = host_frame_header(&h, src, n); if (e < 0) return e;
+    size_t pos = h.headerSize;
+    for (;;) {
+        if (pos + 3 > n) return -ZE_SRC_SIZE_WRONG;
+        uint32_t bh = rd24(src + pos); pos += 3;
+        uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+        if (type == 3) return -ZE_CORRUPTION;
+        size_t c = type == 1 ? 1 : bs;
+        if (pos + c > n) return -ZE_SRC_SIZE_WRONG;
+        pos += c;
+        if (bh & 1) break;
+    }
+    if (h.hasChecksum) { if (pos + 4 > n) return -ZE_SRC_SIZE_WRONG; pos += 4; }
+    return (int64_t)pos;
+}
+
+// ------------------------------------------------------------------------------------------ context
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 3) + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct KTimer { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; double totalMs = 0; uint64_t launches = 0; };
+
+struct zhip_ctx {
+    int device = 0;
+    int numCU = 0;
+    int decBlocksPerCU = 0;
+    DevBuf scratch, counter;
+    // dictionary (decode side)
+    DevBuf dictBlob, dictEntropy;
+    uint32_t dictSize = 0, dictID = 0, dictContentOffset = 0; bool dictHasEntropy = false;
+    uint64_t maxWindowSize = (1ull << 27) + 1;
+    // host-API staging
+    DevBuf hSrc, hDst, hSegs, hStatus;
+    void* pinned = nullptr; size_t pinnedCap = 0;
+    KTimer timer[2];
+};
+
+extern "C" zhip_ctx* zhip_ctx_create(void)
+{
+    zhip_ctx* c = new zhip_ctx();
+    if (hipGetDevice(&c->device) != hipSuccess) { g_lastError = "hipGetDevice failed (no GPU?)"; delete c; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { g_lastError = "hipGetDeviceProperties failed"; delete c; return nullptr; }
+    c->numCU = prop.multiProcessorCount;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 8;
+    c->decBlocksPerCU = nb;
+    return c;
+}
+static void drain_timer(KTimer& t)
+{
+    for (auto& pr : t.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.totalMs += ms; t.launches++; }
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    t.pending.clear();
+}
+extern "C" void zhip_ctx_destroy(zhip_ctx* c)
+{
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    drain_timer(c->timer[0]); drain_timer(c->timer[1]);
+    c->scratch.release(); c->counter.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+}
+extern "C" const char* zhip_kernel_name(int direction) { return direction == 0 ? "zhip_decode_frames_kernel" : "zhip_encode_frames_kernel"; }
+extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
+{
+    if (!c || direction < 0 || direction > 1) return ZHIP_ERR_UNSUPPORTED;
+    HIP_TRY(hipDeviceSynchronize());
+    KTimer& t = c->timer[direction];
+    drain_timer(t);
+    if (avgMs) *avgMs = t.launches ? t.totalMs / (double)t.launches : 0.0;
+    if (launches) *launches = t.launches;
+    t.totalMs = 0; t.launches = 0;
+    return 0;
+}
+
+extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dictSize)
+{
+    c->dictSize = 0; c->dictID = 0; c->dictContentOffset = 0; c->dictHasEntropy = false;
+    if (!hostDict || !dictSize) return 0;
+    if (dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; return ZHIP_ERR_UNSUPPORTED; }
+    if (c->dictBlob.reserve(dictSize + 16)) return ZHIP_ERR_HIP;
+    if (c->dictEntropy.reserve(sizeof(ZhipDictEntropy))) return ZHIP_ERR_HIP;
+    HIP_TRY(hipMemcpy(c->dictBlob.p, hostDict, dictSize, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->dictEntropy.p, 0, sizeof(ZhipDictEntropy)));
+    hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->dictBlob.p, (uint32_t)dictSize,
+                       (ZhipDictEntropy*)c->dictEntropy.p);
+    HIP_TRY(hipGetLastError());
+    ZhipDictEntropy de;
+    HIP_TRY(hipMemcpy(&de, c->dictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
+    if (de.status) return -de.status;            // negative zstd error code: dictionary corrupted
+    c->dictSize = (uint32_t)dictSize; c->dictID = de.dictID; c->dictContentOffset = de.contentOffset;
+    c->dictHasEntropy = de.hufCount != 0;
+    return 0;
+}
+extern "C" int zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams*) { g_lastError = "compress path not built yet"; return ZHIP_ERR_UNSUPPORTED; }
+
+// ------------------------------------------------------------------------------------------ device-resident decode
+extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
+                                            void* d_dst, const zhip_segment* d_dstSegs, uint64_t* d_outSizes,
+                                            int32_t* d_status, void* streamv)
+{
+    if (!c) return ZHIP_ERR_UNSUPPORTED;
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFu) { g_lastError = "too many frames in one launch"; return ZHIP_ERR_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)streamv;
+    size_t maxBlocks = (size_t)c->numCU * (size_t)c->decBlocksPerCU;
+    uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
+    if (c->scratch.reserve((size_t)grid * ZHIP_LIT_STRIDE)) return ZHIP_ERR_HIP;
+    if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
+    ZhipDecodeArgs a; memset(&a, 0, sizeof a);
+    a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
+    a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
+    a.scratch = (uint8_t*)c->scratch.p; a.counter = (uint32_t*)c->counter.p; a.n = (uint32_t)n;
+    a.maxWindowSize = c->maxWindowSize;
+    if (c->dictSize) {
+        a.dictID = c->dictID;
+        a.dictContent = (const uint8_t*)c->dictBlob.p + c->dictContentOffset;
+        a.dictContentSize = c->dictSize - c->dictContentOffset;
+        a.dictEntropy = c->dictHasEntropy ? (const ZhipDictEntropy*)c->dictEntropy.p : nullptr;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(zhip_decode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, stream));
+    c->timer[0].pending.emplace_back(e0, e1);
+    if (c->timer[0].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[0]); }
+    return 0;
+}
+extern "C" int zhip_compress_batch_device(zhip_ctx*, const void*, const zhip_segment*, size_t, void*, const zhip_segment*,
+                                          uint64_t*, int32_t*, void*)
+{
+    g_lastError = "compress path not built yet"; return ZHIP_ERR_UNSUPPORTED;
+}
+
+extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status, size_t n, zhip_error* err)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)streamv));
+    if (err) memset(err, 0, sizeof *err);
+    if (!d_status || !n) return 0;
+    std::vector<int32_t> st(n);
+    HIP_TRY(hipMemcpy(st.data(), d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) if (st[i]) {
+        if (err) { err->kind = ZHIP_ERR_ZSTD; err->zstdErr = st[i]; err->index = i; }
+        return ZHIP_ERR_ZSTD;
+    }
+    (void)c;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ host-buffer batch API
+static int ensure_pinned(zhip_ctx* c, size_t n)
+{
+    if (n <= c->pinnedCap) return 0;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinnedCap = 0;
+    size_t want = n + (n >> 2) + 4096;
+    HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinnedCap = want;
+    return 0;
+}
+static thread_local zhip_ctx* g_tlsCtx = nullptr;   // one lazily created context per calling thread
+static zhip_ctx* tls_ctx()
+{
+    if (!g_tlsCtx) g_tlsCtx = zhip_ctx_create();
+    return g_tlsCtx;
+}
+static int set_err(zhip_error* err, int kind, size_t index, int zerr, uint64_t d0 = 0, uint64_t d1 = 0)
+{
+    if (err) { err->kind = kind; err->index = index; err->zstdErr = zerr; err->detail[0] = d0; err->detail[1] = d1; }
+    return kind;
+}
+
+extern "C" void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload)
+{
+    if (!bufs) return;
+    if (freePayload) for (size_t i = 0; i < n; i++) { free(bufs[i].data); free(bufs[i].segs); }
+    free(bufs);
+}
+
+extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
+                                     zhip_outbuf** out, size_t* nOut, zhip_error* err)
+{
+    const bool allowShort = (requireSizes & 2) != 0;   // dstSize is a capacity (one-shot decompress with max_output_size)
+    if (err) memset(err, 0, sizeof *err);
+    *out = nullptr; *nOut = 0;
+    zhip_ctx* c = tls_ctx();
+    if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    // pass 1 (decompress_worker pass 1, decompressor.c:981-1014): every frame needs a known decompressed size
+    std::vector<zhip_segment> segs(2 * n);           // [0,n) source, [n,2n) destination
+    uint64_t srcTotal = 0, dstTotal = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t ds = items[i].dstSize;
+        if (ds == 0) {
+            uint64_t fcs = zhip_frame_content_size(items[i].src, items[i].srcSize);
+            if (fcs == ZHIP_CONTENTSIZE_ERROR || fcs == ZHIP_CONTENTSIZE_UNKNOWN) return set_err(err, ZHIP_ERR_UNKNOWN_SIZE, i, 0);
+            ds = fcs;
+        }
+        segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;
+        segs[n + i].offset = dstTotal; segs[n + i].length = ds; dstTotal += ds;
+    }
+    c->maxWindowSize = (params && params->maxWindowSize) ? params->maxWindowSize : ((1ull << 27) + 1);
+    int r = zhip_ctx_set_ddict(c, params ? params->dict : nullptr, params ? params->dictSize : 0);
+    if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
+    if (r) return set_err(err, r, 0, 0);
+    // stage: pack the frames into one pinned buffer, one H2D copy
+    if (ensure_pinned(c, srcTotal + 8)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
+    if (c->hSrc.reserve(srcTotal + 8) || c->hDst.reserve(dstTotal + 8) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
+        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    if (hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess && srcTotal) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    uint64_t* dSizes = (uint64_t*)c->hStatus.p;
+    int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
+    r = zhip_decompress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
+                                     (const zhip_segment*)c->hSegs.p + n, dSizes, dStatus, nullptr);
+    if (r) return set_err(err, r, 0, 0);
+    std::vector<uint64_t> sizes(n); std::vector<int32_t> status(n);
+    if (hipMemcpy(sizes.data(), dSizes, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(status.data(), dStatus, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        hip_fail(hipGetLastError(), "decode kernel / status copy"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (status[i]) return set_err(err, ZHIP_ERR_ZSTD, i, status[i]);
+        if (sizes[i] != segs[n + i].length && !(allowShort && sizes[i] < segs[n + i].length))
+            return set_err(err, ZHIP_ERR_SIZE_MISMATCH, i, 0, sizes[i], segs[n + i].length);
+        segs[n + i].length = sizes[i];
+    }
+    // results: one malloc()ed payload + segment table handed to the caller (BufferWithSegments_FromMemory semantics)
+    zhip_outbuf* ob = (zhip_outbuf*)calloc(1, sizeof(zhip_outbuf));
+    void* payload = malloc(dstTotal ? dstTotal : 1);
+    zhip_segment* osegs = (zhip_segment*)malloc((n ? n : 1) * sizeof(zhip_segment));
+    if (!ob || !payload || !osegs) { free(ob); free(payload); free(osegs); return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0); }
+    if (dstTotal && hipMemcpy(payload, c->hDst.p, dstTotal, hipMemcpyDeviceToHost) != hipSuccess) {
+        free(ob); free(payload); free(osegs); hip_fail(hipGetLastError(), "D2H"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    }
+    memcpy(osegs, segs.data() + n, n * sizeof(zhip_segment));
+    ob->data = payload; ob->dataSize = dstTotal; ob->segs = osegs; ob->nSegs = n;
+    *out = ob; *nOut = 1;
+    return ZHIP_ERR_NONE;
+}
+
+extern "C" int zhip_compress_batch(const zhip_cparams*, const zhip_item*, size_t, zhip_outbuf** out, size_t* nOut, zhip_error* err)
+{
+    *out = nullptr; *nOut = 0;
+    g_lastError = "compress path not built yet";
+    return set_err(err, ZHIP_ERR_UNSUPPORTED, 0, 0);
+}

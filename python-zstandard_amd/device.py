@@ -1,0 +1,75 @@
+"""Device-resident batch API: frames already in HBM in, frames in HBM out (torch tensors only carry the memory).
+
+This is the same hot path as ``multi_*_to_buffer`` without the PCIe hops, and it is what shards across GPUs:
+each rank owns a contiguous range of frames (the reference's partition rule, c-ext/compressor.c:1127-1216) and
+results stay resident per GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .common import ZstdError
+
+
+class DeviceBatchContext:
+    """Owns the native context (scratch, dictionary tables, kernel timers) for one GPU / one stream."""
+
+    def __init__(self, dict_data=None):
+        self.L = _lib.lib()
+        self.ctx = self.L.zhip_ctx_create()
+        if not self.ctx:
+            raise ZstdError("HIP backend failure: %s" % _lib.last_error())
+        if dict_data is not None:
+            raw = dict_data.as_bytes()
+            buf = C.create_string_buffer(raw, len(raw))
+            rc = self.L.zhip_ctx_set_ddict(self.ctx, C.cast(buf, C.c_void_p), len(raw))
+            if rc:
+                raise ZstdError("could not load dictionary: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
+
+    def close(self):
+        if self.ctx:
+            self.L.zhip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _check(t, dtype):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, "expected a contiguous CUDA tensor of %s" % dtype
+
+    def decompress(self, src, src_segs, dst, dst_segs, out_sizes, status, stream=None):
+        """Asynchronous. src/dst: uint8 arenas; *_segs: int64 [n,2] (offset,length|capacity); out_sizes int64[n]; status int32[n]."""
+        self._check(src, torch.uint8); self._check(dst, torch.uint8)
+        self._check(src_segs, torch.int64); self._check(dst_segs, torch.int64)
+        self._check(out_sizes, torch.int64); self._check(status, torch.int32)
+        n = src_segs.shape[0]
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = self.L.zhip_decompress_batch_device(self.ctx, src.data_ptr(), src_segs.data_ptr(), n, dst.data_ptr(),
+                                                 dst_segs.data_ptr(), out_sizes.data_ptr(), status.data_ptr(),
+                                                 s.cuda_stream)
+        if rc:
+            raise ZstdError("HIP backend failure: %s" % _lib.last_error())
+
+    def compress(self, src, src_segs, dst, dst_segs, out_sizes, status, stream=None):
+        self._check(src, torch.uint8); self._check(dst, torch.uint8)
+        n = src_segs.shape[0]
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = self.L.zhip_compress_batch_device(self.ctx, src.data_ptr(), src_segs.data_ptr(), n, dst.data_ptr(),
+                                               dst_segs.data_ptr(), out_sizes.data_ptr(), status.data_ptr(),
+                                               s.cuda_stream)
+        if rc:
+            raise ZstdError("HIP backend failure: %s" % _lib.last_error())
+
+    def kernel_time(self, direction):
+        """(average ms per launch, launches) of the dominant kernel since the last call, from HIP events on the launch stream."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self.L.zhip_ctx_kernel_time(self.ctx, direction, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def kernel_name(self, direction):
+        return self.L.zhip_kernel_name(direction).decode()

@@ -1,0 +1,27 @@
+// tests/emu/emu_kernels.cpp -- compiles the PRODUCT kernel sources for the host wave emulator (ZHIP_EMU).
+// Test infrastructure only: lets tests/test_emu_*.py exercise kernel logic without a GPU. Never shipped.
+#define ZHIP_EMU 1
+#include "../../python-zstandard_amd/csrc/zhip_decode_kernel.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+static ZdLDS g_lds;
+struct DecLaunch { const ZhipDecodeArgs* a; };
+static void dec_lane(void* p) { zd_kernel_body(*((DecLaunch*)p)->a, g_lds); }
+
+extern "C" int emu_decompress_batch(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst,
+                                    const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status,
+                                    const uint8_t* dictContent, uint32_t dictContentSize, uint32_t dictID,
+                                    const ZhipDictEntropy* de, uint32_t nBlocks)
+{
+    ZhipDecodeArgs a; memset(&a, 0, sizeof(a));
+    uint32_t counter = 0;
+    a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
+    a.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
+    a.counter = &counter; a.n = n; a.dictID = dictID; a.dictContent = dictContent; a.dictContentSize = dictContentSize;
+    a.dictEntropy = de; a.maxWindowSize = (1ull << 27) + 1;
+    DecLaunch l = { &a };
+    zhemu::run_grid(nBlocks, dec_lane, &l);
+    free(a.scratch);
+    return 0;
+}

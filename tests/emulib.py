@@ -1,0 +1,47 @@
+"""ctypes binding of tests/emu/libzhip_emu.so (product kernels compiled for the host wave emulator)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+EMU_SO = os.path.join(_DIR, "libzhip_emu.so")
+
+
+def build():
+    subprocess.check_call(["sh", os.path.join(_DIR, "build.sh")])
+
+
+class Emu:
+    def __init__(self):
+        if not os.path.exists(EMU_SO):
+            build()
+        self.lib = C.CDLL(EMU_SO)
+
+    def decompress_batch(self, frames, sizes, n_blocks=2, dict_content=None, dict_id=0, dict_entropy=None):
+        n = len(frames)
+        src = np.frombuffer(b"".join(frames) + b"\0" * 0, dtype=np.uint8).copy()
+        src_segs = np.zeros((n, 2), dtype=np.uint64)
+        o = 0
+        for i, f in enumerate(frames):
+            src_segs[i] = (o, len(f)); o += len(f)
+        dst_segs = np.zeros((n, 2), dtype=np.uint64)
+        o = 0
+        for i, s in enumerate(sizes):
+            dst_segs[i] = (o, s); o += s
+        dst = np.zeros(max(o, 1), dtype=np.uint8)
+        out_sizes = np.zeros(n, dtype=np.uint64)
+        status = np.full(n, -1, dtype=np.int32)
+        dc = np.frombuffer(dict_content, dtype=np.uint8).copy() if dict_content else None
+        self.lib.emu_decompress_batch(
+            src.ctypes.data_as(C.c_void_p), src_segs.ctypes.data_as(C.c_void_p), C.c_uint32(n),
+            dst.ctypes.data_as(C.c_void_p), dst_segs.ctypes.data_as(C.c_void_p),
+            out_sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+            dc.ctypes.data_as(C.c_void_p) if dc is not None else None, C.c_uint32(len(dc) if dc is not None else 0),
+            C.c_uint32(dict_id), dict_entropy, C.c_uint32(n_blocks))
+        outs = []
+        for i in range(n):
+            a = int(dst_segs[i][0])
+            outs.append(dst[a:a + int(out_sizes[i])].tobytes())
+        return outs, status.tolist()

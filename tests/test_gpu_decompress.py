@@ -1,0 +1,105 @@
+"""GPU parity tests for the decode path: HIP kernels (through the C ABI) vs the CPU oracle and the originals."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zstd():
+    import zstandard_amd
+    assert zstandard_amd._lib.lib().zhip_device_count() >= 1, "no GPU visible"
+    return zstandard_amd
+
+
+def _enc():
+    from tests import reflib
+    return reflib.RefZstd() if reflib.have_ref() else reflib.Oracle()
+
+
+def test_small_and_edge_frames(zstd, oracle):
+    enc = _enc()
+    raws = [b"", b"foo", b"foo" * 4, b"bar" * 6, b"a" * 1000, b"a" * 131072, bytes(range(256)) * 40,
+            b"hello world, hello world, hello there world! " * 500, np.random.default_rng(1).bytes(1 << 17)]
+    frames = [enc.compress(r) for r in raws]
+    res = zstd.ZstdDecompressor().multi_decompress_to_buffer(frames)
+    assert len(res) == len(raws)
+    assert res.size() == sum(map(len, raws))
+    for i, r in enumerate(raws):
+        assert res[i].tobytes() == r == oracle.decompress(frames[i], len(r))
+    assert res[0].offset == 0
+
+
+def test_corpus_frames_match_oracle(zstd, oracle, corpus):
+    enc = _enc()
+    n = 96
+    raws = [corpus.frame_bytes(i) for i in range(n)]
+    # ragged sizes as well
+    raws += [corpus.frame_bytes(100 + i)[: 1000 * (i + 1) + i] for i in range(32)]
+    frames = [enc.compress(r) for r in raws]
+    res = zstd.ZstdDecompressor().multi_decompress_to_buffer(frames)
+    for i, r in enumerate(raws):
+        got = res[i].tobytes()
+        assert got == r, "frame %d" % i
+    for i in range(0, len(raws), 7):
+        assert res[i].tobytes() == oracle.decompress(frames[i], len(raws[i]))
+
+
+def test_multi_block_and_levels(zstd):
+    from tests import reflib
+    if not reflib.have_ref():
+        pytest.skip("needs reference libzstd for other levels")
+    ref = reflib.RefZstd()
+    from tests.corpus import Corpus
+    c = Corpus()
+    big = b"".join(c.frame_bytes(i) for i in range(5))       # 640 KiB: 5 blocks, repeat modes, window carry
+    for level in (1, 3, 5, 9, 19):
+        for flags in (reflib.DEFAULT_FLAGS, reflib.F_DICTID, reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM):
+            frame = ref.compress(big, level=level, flags=flags)
+            sizes = struct.pack("=Q", len(big))
+            res = zstd.ZstdDecompressor().multi_decompress_to_buffer([frame], decompressed_sizes=sizes)
+            assert res[0].tobytes() == big, (level, flags)
+
+
+def test_one_shot_decompress(zstd):
+    enc = _enc()
+    d = zstd.ZstdDecompressor()
+    for raw in (b"foobar" * 256, b"", b"x"):
+        assert d.decompress(enc.compress(raw)) == raw
+    with pytest.raises(zstd.ZstdError, match="error determining content size from frame header"):
+        d.decompress(b"foobar")
+
+
+def test_item_failure_reports_first_bad_frame(zstd):
+    enc = _enc()
+    frames = [enc.compress(b"x" * 128), enc.compress(b"y" * 128)]
+    frames[1] = frames[1][0:15] + b"extra" + frames[1][15:]
+    with pytest.raises(zstd.ZstdError, match="error decompressing item 1: (Data corruption detected|Destination buffer is too small)"):
+        zstd.ZstdDecompressor().multi_decompress_to_buffer(frames)
+    with pytest.raises(ValueError, match="could not determine decompressed size of item 0"):
+        zstd.ZstdDecompressor().multi_decompress_to_buffer([b"foobarbaz"])
+
+
+def test_truncated_and_corrupt_frames_do_not_crash(zstd, corpus):
+    enc = _enc()
+    raw = corpus.frame_bytes(3)
+    frame = enc.compress(raw)
+    rng = np.random.default_rng(7)
+    bad = []
+    for k in range(40):
+        b = bytearray(frame)
+        if k % 2:
+            del b[len(b) // 2 + k:]
+        else:
+            for _ in range(3):
+                b[int(rng.integers(9, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(b))
+    sizes = struct.pack("=%dQ" % len(bad), *([len(raw)] * len(bad)))
+    d = zstd.ZstdDecompressor()
+    for b in bad:   # each either errors cleanly or (rare harmless flips) decodes to something of the right size
+        try:
+            d.multi_decompress_to_buffer([b], decompressed_sizes=sizes[:8])
+        except zstd.ZstdError:
+            pass
