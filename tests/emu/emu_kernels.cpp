@@ -25,3 +25,14 @@ extern "C" int emu_decompress_batch(const uint8_t* src, const uint64_t* srcSegs,
     free(a.scratch);
     return 0;
 }
+
+struct DictLaunch { const uint8_t* dict; uint32_t size; ZhipDictEntropy* de; };
+static void dict_lane(void* p) { DictLaunch* l = (DictLaunch*)p; zd_dict_body(l->dict, l->size, l->de, g_lds); }
+extern "C" int emu_parse_dict(const uint8_t* dict, uint32_t size, ZhipDictEntropy* de)
+{
+    memset(de, 0, sizeof *de);
+    DictLaunch l = { dict, size, de };
+    zhemu::run_grid(1, dict_lane, &l);
+    return de->status;
+}
+extern "C" uint32_t emu_dict_entropy_size(void) { return (uint32_t)sizeof(ZhipDictEntropy); }

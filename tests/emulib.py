@@ -19,6 +19,19 @@ class Emu:
             build()
         self.lib = C.CDLL(EMU_SO)
 
+    def parse_dict(self, dict_bytes):
+        """returns (entropy blob or None, content bytes, dictID) using the device dictionary parser under emulation"""
+        import struct
+        size = self.lib.emu_dict_entropy_size()
+        blob = C.create_string_buffer(size)
+        d = np.frombuffer(dict_bytes, dtype=np.uint8).copy()
+        st = self.lib.emu_parse_dict(d.ctypes.data_as(C.c_void_p), C.c_uint32(len(d)), blob)
+        if st:
+            raise RuntimeError("dict parse error %d" % st)
+        content_off, dict_id, status = struct.unpack_from("<IIi", blob.raw, size - 12)
+        huf_count = struct.unpack_from("<I", blob.raw, 256)[0]
+        return (blob if huf_count else None), dict_bytes[content_off:], dict_id
+
     def decompress_batch(self, frames, sizes, n_blocks=2, dict_content=None, dict_id=0, dict_entropy=None):
         n = len(frames)
         src = np.frombuffer(b"".join(frames) + b"\0" * 0, dtype=np.uint8).copy()
