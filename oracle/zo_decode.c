@@ -126,6 +126,7 @@ int zo_fse_read_ncount(int16_t* norm, unsigned* maxSymbol, unsigned* tableLog, c
         }
         count--;
         remaining -= count < 0 ? -count : count;
+        if (remaining < 1) return -ZO_E_CORRUPTION;
         norm[sym++] = (int16_t)count;
         prev0 = (count == 0);
         while (remaining < threshold) { nbBits--; threshold >>= 1; }

@@ -51,6 +51,12 @@ def lib():
         raise ImportError(
             "libzstd_hip.so is not built (%s). Run `python __graft_entry__.py` / "
             "`python-zstandard_amd/csrc/build.sh`; this backend has no CPU fallback." % LIB_PATH)
+    try:
+        # torch bundles its own libamdhip64.so.7; loading it first makes this library bind to the SAME HIP runtime
+        # instance, which is required for torch streams / device pointers to be meaningful to our launches.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     protos = {

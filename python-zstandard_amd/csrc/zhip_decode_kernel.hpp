@@ -138,6 +138,7 @@ ZH_DEVFN int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, ui
         }
         count--;
         remaining -= count < 0 ? -count : count;
+        if (remaining < 1) return -ZE_CORRUPTION;
         L.norm[sym++] = (int16_t)count;
         prev0 = (count == 0);
         while (remaining < threshold) { nbBits--; threshold >>= 1; }

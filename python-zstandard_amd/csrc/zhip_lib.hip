@@ -38,7 +38,13 @@ static int hip_fail(hipError_t e, const char* what)
 
 extern "C" const char* zhip_last_error(void) { return g_lastError.c_str(); }
 extern "C" int zhip_abi_version(void) { return ZHIP_ABI_VERSION; }
-extern "C" int zhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int zhip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { hip_fail(e, "hipGetDeviceCount"); return 0; }
+    return n;
+}
 extern "C" int zhip_set_device(int d) { HIP_TRY(hipSetDevice(d)); return 0; }
 extern "C" size_t zhip_compress_bound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
 
