@@ -73,6 +73,7 @@ int         zhip_device_count(void);
 int         zhip_set_device(int device);
 const char* zhip_last_error(void);                  /* thread-local text of the last ZHIP_ERR_HIP */
 const char* zhip_error_name(int zstdErr);            /* same strings as ZSTD_getErrorName (zstd.c:3580-3616) */
+int         zhip_selftest(void);                     /* 0 = the wave primitives behave on this GPU */
 size_t      zhip_compress_bound(size_t srcSize);     /* ZSTD_compressBound, zstd.h:249 */
 
 /* ---- frame inspection (host, no GPU): ZSTD_getFrameContentSize zstd.c:43790, ZSTD_findFrameCompressedSize :44022 */

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libzstd_hip.so")
+LIB_PATH = os.environ.get("ZHIP_LIB") or os.path.join(_HERE, "csrc", "libzstd_hip.so")
 
 ERR_NONE, ERR_ZSTD, ERR_NO_MEMORY, ERR_SIZE_MISMATCH, ERR_UNKNOWN_SIZE, ERR_HIP, ERR_UNSUPPORTED = range(7)
 CONTENTSIZE_UNKNOWN = 2**64 - 1
@@ -65,6 +65,7 @@ def lib():
         "zhip_set_device": (C.c_int, [C.c_int]),
         "zhip_last_error": (C.c_char_p, []),
         "zhip_error_name": (C.c_char_p, [C.c_int]),
+        "zhip_selftest": (C.c_int, []),
         "zhip_compress_bound": (sz, [sz]),
         "zhip_frame_content_size": (u64, [vp, sz]),
         "zhip_find_frame_compressed_size": (C.c_int64, [vp, sz]),
@@ -94,7 +95,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "zhip_abi_version", "zhip_device_count", "zhip_set_device", "zhip_last_error", "zhip_error_name",
-    "zhip_compress_bound", "zhip_frame_content_size", "zhip_find_frame_compressed_size", "zhip_compress_batch",
+    "zhip_selftest", "zhip_compress_bound", "zhip_frame_content_size", "zhip_find_frame_compressed_size", "zhip_compress_batch",
     "zhip_decompress_batch", "zhip_free_outbufs", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
     "zhip_kernel_name", "zhip_ctx_kernel_time",

@@ -571,7 +571,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
             else {
                 uint64_t c = 0;
                 for (uint32_t i = 0; i < ssize; i++) c |= (uint64_t)p[i] << (8 * i);
-                V = 8 * ssize - pad; w = c << (64 - V); q = 0;
+                V = 8 * ssize - pad; w = V ? c << (64 - V) : 0; q = 0;
             }
         }
         uint32_t sL = 0, sM = 0, sO = 0, done = 0;
@@ -636,7 +636,8 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                     cnt++;
                     if ((int64_t)q * 8 + (int64_t)V < 0) { bad = 1; break; }
                 }
-                L.misc[0] = cnt; L.misc[1] = (uint32_t)bad;
+                L.misc[0] = cnt; L.misc[1] = (uint32_t)bad; L.misc[2] = (uint32_t)q; L.misc[3] = V;
+                L.misc[4] = rep0; L.misc[5] = rep1; L.misc[6] = rep2;
 #undef ZD_TAKE
 #undef ZD_REFILL
             }
@@ -644,7 +645,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
             zh_sync();
             const uint32_t cnt = L.misc[0];
             if (L.misc[1]) return -ZE_CORRUPTION;
-            q = (int32_t)zh_first((uint32_t)q);
+            q = (int32_t)zh_first(L.misc[2]);
             if (cnt == 0) continue;              // window had run dry: restage lower and retry
             // ---- execute the batch with the whole wave
             const bool act = lane < cnt;
@@ -698,10 +699,11 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
         }
         // the bitstream must be consumed exactly
         {
-            uint32_t Vu = zh_first(V);
+            uint32_t Vu = zh_first(L.misc[3]);
             if ((int64_t)q * 8 + (int64_t)Vu != 0) return -ZE_CORRUPTION;
         }
-        st.rep0 = zh_first(rep0); st.rep1 = zh_first(rep1); st.rep2 = zh_first(rep2);
+        st.rep0 = zh_first(L.misc[4]); st.rep1 = zh_first(L.misc[5]); st.rep2 = zh_first(L.misc[6]);
+        zh_sync();
     }
     // last literals
     uint32_t rest = st.litSize - lp;
@@ -817,23 +819,38 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
     return ZE_OK;
 }
 
+#if !defined(ZHIP_EMU) && !defined(ZD_NO_DBG)
+#define ZD_DBG(slot, val) do { if (a.dbg && zh_block() == 0) { a.dbg[slot] = (uint32_t)(val); __threadfence_system(); } } while (0)
+#else
+#define ZD_DBG(slot, val) do { } while (0)
+#endif
+
 ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
+    ZD_DBG(0, 1);
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
+    ZD_DBG(0, 2);
     uint8_t* lit = a.scratch + (size_t)zh_block() * ZHIP_LIT_STRIDE;
     for (;;) {
-        uint32_t f = 0;
-        if (lane == 0) f = zh_atomic_inc(a.counter);
-        f = zh_first(f);
+        // NOTE (compiler hazard, found on hardware): never write `x = c; if (lane == 0) x = ...; x = readfirstlane(x)`.
+        // LLVM threads the constant arm of that phi through the convergent readfirstlane and the non-zero lanes end up
+        // in their own loop. Lane-0 results are always published through LDS + barrier instead.
+        if (lane == 0) L.misc[7] = zh_atomic_inc(a.counter);
+        zh_sync();
+        const uint32_t f = zh_first(L.misc[7]);
+        zh_sync();
+        ZD_DBG(2, 0x200 + f);
         if (f >= a.n) break;
         uint64_t produced = 0;
         int err = zd_frame(a, L, f, lit, &produced);
+        ZD_DBG(3, 0x300 + err);
         zh_sync();
         if (lane == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }
+    ZD_DBG(0, 9);
 }
 
 // Parses the entropy section of a zstd-format dictionary (magic, dictID, Huffman table, OF/ML/LL distributions,

@@ -15,7 +15,11 @@
 // =====================================================================================  device
 #include <hip/hip_runtime.h>
 #define ZH_DEV __device__ __forceinline__
+#ifdef ZD_NOINLINE
+#define ZH_DEVFN __device__ __attribute__((noinline))
+#else
 #define ZH_DEVFN __device__
+#endif
 #define ZH_GLOBAL extern "C" __global__
 #define ZH_SHARED __shared__
 #define ZH_CONST __device__ const

@@ -52,4 +52,5 @@ struct ZhipDecodeArgs {
     uint32_t dictContentSize;
     const ZhipDictEntropy* dictEntropy; // null when no dictionary or raw-content dictionary
     uint64_t maxWindowSize;
+    volatile uint32_t* dbg;         // optional host-visible progress words (ZHIP_DEBUG bring-up aid), else null
 };

@@ -6,6 +6,7 @@
 // indices from an atomic counter.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -18,6 +19,12 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
 {
     __shared__ ZdLDS L;
     zd_kernel_body(a, L);
+}
+ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
+{
+    uint32_t v = zh_scan_add(zh_lane());                  // 0+1+..+lane
+    uint64_t m = zh_ballot((zh_lane() & 1) != 0);
+    out[zh_lane()] = v + (uint32_t)zh_popc64(m) + zh_shfl(zh_lane(), 63) + zh_first(zh_lane() + 7);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_parse_dict_kernel(const uint8_t* dict, uint32_t dictSize, ZhipDictEntropy* de)
 {
@@ -216,6 +223,18 @@ extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dict
     c->dictHasEntropy = de.hufCount != 0;
     return 0;
 }
+// bring-up probe: launches a 64-lane kernel exercising every wave primitive the codec uses; returns 0 when correct
+extern "C" int zhip_selftest(void)
+{
+    uint32_t* d = nullptr; uint32_t h[64];
+    HIP_TRY(hipMalloc((void**)&d, sizeof h));
+    hipLaunchKernelGGL(zhip_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    for (uint32_t l = 0; l < 64; l++) if (h[l] != l * (l + 1) / 2 + 32 + 63 + 7) { g_lastError = "selftest mismatch"; return 1; }
+    return 0;
+}
 extern "C" int zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams*) { g_lastError = "compress path not built yet"; return ZHIP_ERR_UNSUPPORTED; }
 
 // ------------------------------------------------------------------------------------------ device-resident decode
@@ -243,12 +262,37 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         a.dictContentSize = c->dictSize - c->dictContentOffset;
         a.dictEntropy = c->dictHasEntropy ? (const ZhipDictEntropy*)c->dictEntropy.p : nullptr;
     }
+    const bool debug = getenv("ZHIP_DEBUG") != nullptr;
+    const bool watchdog = getenv("ZHIP_WATCHDOG") != nullptr;
+    uint32_t* dbg = nullptr;
+    if (debug) {
+        HIP_TRY(hipHostMalloc((void**)&dbg, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(dbg, 0, 64);
+        a.dbg = dbg;
+        fprintf(stderr, "[zhip] launch decode grid=%u n=%u scratch=%p counter=%p\n", grid, a.n, (void*)a.scratch, (void*)a.counter);
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(zhip_decode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, stream));
+    if (watchdog && !debug) {
+        for (int it = 0; it < 100; it++) {
+            if (hipStreamQuery(stream) == hipSuccess) break;
+            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
+            if (it == 99) { fprintf(stderr, "[zhip] WATCHDOG: kernel did not finish in 5 s; aborting process\n"); abort(); }
+        }
+    }
+    if (debug) {
+        for (int it = 0; it < 12; it++) {
+            hipError_t q = hipStreamQuery(stream);
+            fprintf(stderr, "[zhip] t=%dms query=%d dbg=%x %x %x %x %x %x %x\n", it * 50, (int)q, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+            if (q == hipSuccess) break;
+            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
+            if (it == 11) { fprintf(stderr, "[zhip] kernel did not finish in 5 s; aborting process\n"); abort(); }
+        }
+    }
     c->timer[0].pending.emplace_back(e0, e1);
     if (c->timer[0].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[0]); }
     return 0;

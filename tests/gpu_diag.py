@@ -19,6 +19,7 @@ say("torch", torch.__version__, "cuda available:", torch.cuda.is_available())
 import zstandard_amd as zstd
 L = zstd._lib.lib()
 say("lib loaded; device count:", L.zhip_device_count(), "last error:", zstd._lib.last_error())
+say("selftest:", L.zhip_selftest(), zstd._lib.last_error())
 from tests import reflib
 enc = reflib.RefZstd() if reflib.have_ref() else reflib.Oracle()
 say("encoder:", type(enc).__name__)
