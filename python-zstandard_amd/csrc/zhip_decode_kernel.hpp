@@ -20,6 +20,15 @@
 #include "zhip_device.hpp"
 #include "zhip_format.hpp"
 
+#if defined(ZHIP_EMU) && defined(ZD_TRACE)
+#include <stdio.h>
+extern "C" { extern long zd_trace_pos; extern long zd_cur_frame; }
+#define ZD_TRR(lo, n, what, a1, a2) do { if (zh_lane() == 0 && zd_trace_pos + 40 >= (long)(lo) && zd_trace_pos < (long)(lo) + (long)(n) + 40) fprintf(stderr, "[trace] f%ld range [%ld,+%ld) %s %ld %ld\n", zd_cur_frame, (long)(lo), (long)(n), what, (long)(a1), (long)(a2)); } while (0)
+#define ZD_TR(pos, what, a1, a2, a3) do { if ((long)(pos) == zd_trace_pos) fprintf(stderr, "[trace] f%ld pos=%ld %s lane=%u %ld %ld %ld\n", zd_cur_frame, (long)(pos), what, zh_lane(), (long)(a1), (long)(a2), (long)(a3)); } while (0)
+#else
+#define ZD_TR(pos, what, a1, a2, a3) do { } while (0)
+#define ZD_TRR(lo, n, what, a1, a2) do { } while (0)
+#endif
 #define ZD_STAGE_BYTES 512
 #define ZD_COOP_LEN 32          // copies longer than this are done by the whole wave
 
@@ -92,7 +101,7 @@ ZH_DEV void zd_fill_wave(uint8_t* dst, uint32_t byte, uint32_t len)
 #ifndef ZHIP_EMU
 ZH_DEV void zd_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 #else
-ZH_DEV void zd_fence() {}
+ZH_DEV void zd_fence() { zhemu::collective_wait(); }   // emulated lanes are not lockstep: a fence orders them like the hardware's in-order wave does
 #endif
 
 // ------------------------------------------------------------------------------------------ FSE tables
@@ -525,7 +534,7 @@ ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst,
     if (off >= 64) {
         for (uint32_t c = 0; c < ml; c += 64) {
             uint32_t j = c + lane;
-            if (j < ml) dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j);
+            if (j < ml) { ZD_TR(mdst + j, "wave-match", sbeg + (int32_t)j, zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j), off); dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j); }
             if (off < ml) zd_fence();       // later chunks read what this chunk wrote
         }
     } else {                                 // period `off` pattern: every source byte precedes mdst
@@ -588,11 +597,11 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                     L.u.q.stage[1 + lane * 2] = (uint32_t)v;
                     L.u.q.stage[2 + lane * 2] = (uint32_t)(v >> 32);
                 }
-                if (lane == 0) L.u.q.stage[0] = 0;
+                if (zh_opaque(lane) == 0) L.u.q.stage[0] = 0;
             }
             zh_sync();
             // ---- lane 0: decode up to 64 sequences
-            if (lane == 0) {
+            if (zh_opaque(lane) == 0) {
                 const uint8_t* sb = (const uint8_t*)L.u.q.stage;
 #define ZD_REFILL() do { uint32_t x_ = 0; if (q > 0) { uint32_t ix_ = (uint32_t)(q - stageLo); \
                         uint64_t t_ = ((uint64_t)L.u.q.stage[(ix_ >> 2) + 1] << 32) | L.u.q.stage[ix_ >> 2]; \
@@ -658,17 +667,19 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
             uint32_t litStart = lp + incL - myLL;
             uint32_t outStart = op + incT - (myLL + myML);
             uint32_t mdst = outStart + myLL;
+            if (act) ZD_TRR(outStart, myLL + myML, "seq", myLL, myOF);
             if (zh_ballot(act && (uint64_t)myOF > (uint64_t)mdst + dictSize)) return -ZE_CORRUPTION;
             // literals: every lane copies its own run; long runs go wave-wide
             if (st.litRLE) {
                 for (uint32_t j = 0; j < myLL && myLL <= ZD_COOP_LEN; j++) dst[outStart + j] = (uint8_t)st.rleByte;
             } else {
                 const uint8_t* lsrc = st.litPtr + litStart;
-                for (uint32_t j = 0; j < myLL && myLL <= ZD_COOP_LEN; j++) dst[outStart + j] = lsrc[j];
+                for (uint32_t j = 0; j < myLL && myLL <= ZD_COOP_LEN; j++) { ZD_TR(outStart + j, "lit", litStart + j, lsrc[j], myLL); dst[outStart + j] = lsrc[j]; }
             }
             for (uint64_t big = zh_ballot(myLL > ZD_COOP_LEN); big; big &= big - 1) {
                 uint32_t l = (uint32_t)zh_ctz64(big);
                 uint32_t d = zh_shfl(outStart, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
+                ZD_TRR(d, n, "biglit", s, l);
                 if (st.litRLE) zd_fill_wave(dst + d, st.rleByte, n);
                 else zd_copy_wave(dst + d, st.litPtr + s, n);
             }
@@ -682,14 +693,17 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 if (!pend) break;
                 uint32_t f = (uint32_t)zh_ctz64(pend);
                 uint32_t F = zh_shfl(mdst, f), fml = zh_shfl(myML, f), fof = zh_shfl(myOF, f);
+                ZD_TRR(F, fml, "round-first", fof, f);
                 if (fml > ZD_COOP_LEN) {
                     zd_match_wave(dst, dictEnd, F, fof, fml);
                     if (lane == f) pending = false;
                 } else {
                     bool ready = pending && myML <= ZD_COOP_LEN && (lane == f || send <= (int32_t)F);
                     if (ready) {
-                        for (uint32_t j = 0; j < myML; j++)
+                        for (uint32_t j = 0; j < myML; j++) {
+                            ZD_TR(mdst + j, "match", sbeg + (int32_t)j, myOF, myML);
                             dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j);
+                        }
                         pending = false;
                     }
                 }
@@ -709,6 +723,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
     uint32_t rest = st.litSize - lp;
     if ((uint64_t)op + rest > cap) return -ZE_DST_TOO_SMALL;
     if (op + rest - blockStart > blockMax) return -ZE_CORRUPTION;
+    ZD_TRR(op, rest, "lastlit", lp, 0);
     if (st.litRLE) zd_fill_wave(dst + op, st.rleByte, rest);
     else zd_copy_wave(dst + op, st.litPtr + lp, rest);
     zd_fence();
@@ -720,6 +735,9 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
 ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* lit, uint64_t* produced)
 {
     const uint32_t lane = zh_lane();
+#if defined(ZHIP_EMU) && defined(ZD_TRACE)
+    zd_cur_frame = f;
+#endif
     *produced = 0;
     const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
@@ -838,7 +856,11 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
         // NOTE (compiler hazard, found on hardware): never write `x = c; if (lane == 0) x = ...; x = readfirstlane(x)`.
         // LLVM threads the constant arm of that phi through the convergent readfirstlane and the non-zero lanes end up
         // in their own loop. Lane-0 results are always published through LDS + barrier instead.
-        if (lane == 0) L.misc[7] = zh_atomic_inc(a.counter);
+        // and never put a lane-invariant branch (`if (lane == 0)`) first in a loop body: LLVM splits the back edge per
+        // lane class, StructurizeCFG nests the two loops, and lanes != 0 spin forever waiting for lane 0 (SIMT deadlock).
+        // The work-stealing fetch is therefore branch-free: every lane issues the add, only lane 0 adds 1.
+        const uint32_t got = zh_atomic_add(a.counter, lane == 0 ? 1u : 0u);
+        if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
         const uint32_t f = zh_first(L.misc[7]);
         zh_sync();
@@ -848,7 +870,7 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
         int err = zd_frame(a, L, f, lit, &produced);
         ZD_DBG(3, 0x300 + err);
         zh_sync();
-        if (lane == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
+        if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }
     ZD_DBG(0, 9);
 }
@@ -877,7 +899,7 @@ ZH_DEVFN void zd_dict_body(const uint8_t* dict, uint32_t dictSize, ZhipDictEntro
                 uint32_t lim = t == 0 ? ZF_MAXOFF : t == 1 ? ZF_MAXML : ZF_MAXLL;
                 uint32_t maxLog = t == 0 ? ZF_OF_LOGMAX : ZF_ML_LOGMAX;
                 zh_sync();
-                if (lane == 0) {
+                if (zh_opaque(lane) == 0) {
                     uint32_t ms = lim, tl = 0;
                     int rr = zd_read_ncount(L, p, end, &ms, &tl);
                     L.misc[0] = (uint32_t)rr; L.misc[1] = ms; L.misc[2] = tl;

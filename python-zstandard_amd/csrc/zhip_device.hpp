@@ -33,6 +33,9 @@ ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl(
 ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }
 ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
+ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+// hides a value's provenance from the optimizer (used so `lane == 0` is not provably loop-invariant)
+ZH_DEV uint32_t zh_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }   // v != 0
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
@@ -85,6 +88,8 @@ ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d)
 }
 ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }
+ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
+ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
