@@ -22,14 +22,17 @@
 
 #if defined(ZHIP_EMU) && defined(ZD_TRACE)
 #include <stdio.h>
-extern "C" { extern long zd_trace_pos; extern long zd_cur_frame; }
+extern "C" { extern long zd_trace_pos; extern long zd_cur_frame; extern long zd_stat[16]; }
+#define ZD_STAT(i, v) do { if (zh_lane() == 0) zd_stat[i] += (v); } while (0)
 #define ZD_TRR(lo, n, what, a1, a2) do { if (zh_lane() == 0 && zd_trace_pos + 40 >= (long)(lo) && zd_trace_pos < (long)(lo) + (long)(n) + 40) fprintf(stderr, "[trace] f%ld range [%ld,+%ld) %s %ld %ld\n", zd_cur_frame, (long)(lo), (long)(n), what, (long)(a1), (long)(a2)); } while (0)
 #define ZD_TR(pos, what, a1, a2, a3) do { if ((long)(pos) == zd_trace_pos) fprintf(stderr, "[trace] f%ld pos=%ld %s lane=%u %ld %ld %ld\n", zd_cur_frame, (long)(pos), what, zh_lane(), (long)(a1), (long)(a2), (long)(a3)); } while (0)
 #else
 #define ZD_TR(pos, what, a1, a2, a3) do { } while (0)
 #define ZD_TRR(lo, n, what, a1, a2) do { } while (0)
+#define ZD_STAT(i, v) do { } while (0)
 #endif
 #define ZD_STAGE_BYTES 512
+#define ZD_ASM_BYTES 4096       // output bytes assembled in LDS per batch before the coalesced flush
 #define ZD_COOP_LEN 32          // copies longer than this are done by the whole wave
 
 ZH_CONST uint32_t zc_llBase[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,
@@ -57,6 +60,7 @@ struct ZdLDS {
         uint16_t huf[4096];
         struct { uint32_t stage[ZD_STAGE_BYTES / 4 + 4]; uint32_t ll[64], ml[64], of[64]; } q;
         struct { uint32_t wfse[64]; uint8_t pad[2048 - 256]; uint8_t symAt[512]; } b;
+        struct { uint8_t pad[2048]; uint8_t asmb[ZD_ASM_BYTES + 64]; } a;   // batch output assembly buffer
     } u;
     uint32_t llBase[36];
     uint32_t mlBase[53];
@@ -526,7 +530,8 @@ ZH_DEV uint32_t zd_hist_byte(const uint8_t* dst, const uint8_t* dictEnd, int32_t
     return pos >= 0 ? dst[pos] : dictEnd[pos];
 }
 
-// whole-wave match copy for one long / self-overlapping match. All lanes call with uniform arguments.
+// whole-wave match copy straight in global memory, for matches too long for the LDS assembly buffer.
+// All lanes call with uniform arguments.
 ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst, uint32_t off, uint32_t ml)
 {
     const uint32_t lane = zh_lane();
@@ -534,7 +539,7 @@ ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst,
     if (off >= 64) {
         for (uint32_t c = 0; c < ml; c += 64) {
             uint32_t j = c + lane;
-            if (j < ml) { ZD_TR(mdst + j, "wave-match", sbeg + (int32_t)j, zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j), off); dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j); }
+            if (j < ml) dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j);
             if (off < ml) zd_fence();       // later chunks read what this chunk wrote
         }
     } else {                                 // period `off` pattern: every source byte precedes mdst
@@ -546,7 +551,41 @@ ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst,
     }
 }
 
+// ---- up-to-32-byte moves through 4 registers: all loads are issued before any store (one memory latency per move)
+ZH_DEV void zd_ld32(const uint8_t* p, uint32_t len, uint64_t r[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        r[k] = 0;
+        if (len >= 8u * k + 8) r[k] = zh_ld64(p + 8 * k);
+        else if (len > 8u * k) {
+            uint64_t v = 0;
+            for (uint32_t i = 8u * k; i < len; i++) v |= (uint64_t)p[i] << (8 * (i - 8u * k));
+            r[k] = v;
+        }
+    }
+}
+ZH_DEV void zd_st32(uint8_t* q, uint32_t len, const uint64_t r[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (len >= 8u * k + 8) zh_st64(q + 8 * k, r[k]);
+        else if (len > 8u * k) {
+            uint64_t v = r[k];
+            for (uint32_t i = 8u * k; i < len; i++) { q[i] = (uint8_t)v; v >>= 8; }
+        }
+    }
+}
+
+struct ZdPack16 { uint32_t a, b, c, d; } __attribute__((packed, aligned(1)));
+
 // Sequences section + execution for one compressed block. All lanes call. Returns 0 or -err; *pOp advanced.
+//
+// Execution model: the output of one batch of <=64 sequences (<= ZD_ASM_BYTES bytes) is ASSEMBLED IN LDS and then
+// flushed to HBM with wide coalesced stores. Everything a batch reads from global memory (its literals, and matches
+// whose source lies before the batch) is independent of the batch itself, so those loads are issued together and
+// cost one memory latency; matches that read the batch's own output are resolved in dependency rounds at LDS
+// latency. Sequences too large for the buffer take the direct global path.
 ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t* end, uint8_t* dst, uint32_t cap,
                           uint32_t* pOp, uint32_t blockMax, const uint8_t* dictEnd, uint32_t dictSize)
 {
@@ -585,7 +624,9 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
         }
         uint32_t sL = 0, sM = 0, sO = 0, done = 0;
         uint32_t rep0 = st.rep0, rep1 = st.rep1, rep2 = st.rep2;
+        uint32_t carry = 0, cLL = 0, cML = 0, cOF = 0;          // lane 0: a decoded sequence that did not fit the last batch
         bool first = true;
+        uint8_t* const asmb = L.u.a.asmb;
         while (done < nbSeq) {
             // ---- stage the next <=512 bytes of the backward stream into LDS (coalesced 8-byte loads)
             zh_sync();
@@ -600,22 +641,25 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 if (zh_opaque(lane) == 0) L.u.q.stage[0] = 0;
             }
             zh_sync();
-            // ---- lane 0: decode up to 64 sequences
+            // ---- lane 0: decode up to 64 sequences / ZD_ASM_BYTES of output
             if (zh_opaque(lane) == 0) {
-                const uint8_t* sb = (const uint8_t*)L.u.q.stage;
 #define ZD_REFILL() do { uint32_t x_ = 0; if (q > 0) { uint32_t ix_ = (uint32_t)(q - stageLo); \
                         uint64_t t_ = ((uint64_t)L.u.q.stage[(ix_ >> 2) + 1] << 32) | L.u.q.stage[ix_ >> 2]; \
                         x_ = (uint32_t)(t_ >> (8 * (ix_ & 3))); } \
                         w |= (uint64_t)x_ << (32 - V); V += 32; q -= 4; } while (0)
 #define ZD_TAKE(dstv, n) do { uint32_t n_ = (n); if (V < n_) ZD_REFILL(); \
                         dstv = (uint32_t)((w >> 1) >> (63 - n_)); w <<= n_; V -= n_; } while (0)
-                (void)sb;
                 if (first) {
                     ZD_TAKE(sL, st.llLog); ZD_TAKE(sO, st.ofLog); ZD_TAKE(sM, st.mlLog);
                 }
-                uint32_t cnt = 0;
+                uint32_t cnt = 0, outAcc = 0, big = 0;
                 int bad = 0;
-                while (cnt < 64 && done + cnt < nbSeq && (stageLo == 0 || q - stageLo >= 16)) {
+                if (carry) {
+                    L.u.q.ll[0] = cLL; L.u.q.ml[0] = cML; L.u.q.of[0] = cOF;
+                    outAcc = cLL + cML; cnt = 1; carry = 0;
+                    if (outAcc > ZD_ASM_BYTES) big = 1;
+                }
+                while (!big && cnt < 64 && done + cnt < nbSeq && (stageLo == 0 || q - stageLo >= 16)) {
                     uint32_t eL = L.fse[ZD_FSE_LL + sL], eM = L.fse[ZD_FSE_ML + sM], eO = L.fse[ZD_FSE_OF + sO];
                     uint32_t ofBits = (eO >> 14) & 31, mlBits = (eM >> 14) & 31, llBits = (eL >> 14) & 31;
                     uint32_t xo, xm, xl;
@@ -641,12 +685,19 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                         ZD_TAKE(t, (eM >> 10) & 15); sM = (eM & 1023) + t;
                         ZD_TAKE(t, (eO >> 10) & 15); sO = (eO & 1023) + t;
                     }
-                    L.u.q.ll[cnt] = llv; L.u.q.ml[cnt] = mlv; L.u.q.of[cnt] = offset;
-                    cnt++;
                     if ((int64_t)q * 8 + (int64_t)V < 0) { bad = 1; break; }
+                    if (outAcc + llv + mlv > ZD_ASM_BYTES) {
+                        if (cnt == 0) { L.u.q.ll[0] = llv; L.u.q.ml[0] = mlv; L.u.q.of[0] = offset; cnt = 1; big = 1; }
+                        else { carry = 1; cLL = llv; cML = mlv; cOF = offset; }
+                        break;
+                    }
+                    L.u.q.ll[cnt] = llv; L.u.q.ml[cnt] = mlv; L.u.q.of[cnt] = offset;
+                    outAcc += llv + mlv;
+                    cnt++;
                 }
+                // a carried sequence is not counted as done yet, so the stream-position bookkeeping stays simple
                 L.misc[0] = cnt; L.misc[1] = (uint32_t)bad; L.misc[2] = (uint32_t)q; L.misc[3] = V;
-                L.misc[4] = rep0; L.misc[5] = rep1; L.misc[6] = rep2;
+                L.misc[4] = rep0; L.misc[5] = rep1; L.misc[6] = rep2; L.misc[7] = big | (carry << 1);
 #undef ZD_TAKE
 #undef ZD_REFILL
             }
@@ -655,59 +706,118 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
             const uint32_t cnt = L.misc[0];
             if (L.misc[1]) return -ZE_CORRUPTION;
             q = (int32_t)zh_first(L.misc[2]);
-            if (cnt == 0) continue;              // window had run dry: restage lower and retry
-            // ---- execute the batch with the whole wave
+            const uint32_t big = L.misc[7] & 1, carried = L.misc[7] >> 1;
+            if (cnt == 0) { if (carried) return -ZE_CORRUPTION; continue; }   // window had run dry: restage lower and retry
             const bool act = lane < cnt;
-            uint32_t myLL = act ? L.u.q.ll[lane] : 0, myML = act ? L.u.q.ml[lane] : 0, myOF = act ? L.u.q.of[lane] : 1;
-            uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
-            uint32_t totL = zh_shfl(incL, 63), totT = zh_shfl(incT, 63);
+            const uint32_t myLL = act ? L.u.q.ll[lane] : 0, myML = act ? L.u.q.ml[lane] : 0, myOF = act ? L.u.q.of[lane] : 1;
+            const uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
+            const uint32_t totL = zh_shfl(incL, 63), totT = zh_shfl(incT, 63);
             if (lp + totL > st.litSize) return -ZE_CORRUPTION;
             if ((uint64_t)op + totT > cap) return -ZE_DST_TOO_SMALL;
             if (op + totT - blockStart > blockMax) return -ZE_CORRUPTION;
-            uint32_t litStart = lp + incL - myLL;
-            uint32_t outStart = op + incT - (myLL + myML);
-            uint32_t mdst = outStart + myLL;
-            if (act) ZD_TRR(outStart, myLL + myML, "seq", myLL, myOF);
-            if (zh_ballot(act && (uint64_t)myOF > (uint64_t)mdst + dictSize)) return -ZE_CORRUPTION;
-            // literals: every lane copies its own run; long runs go wave-wide
-            if (st.litRLE) {
-                for (uint32_t j = 0; j < myLL && myLL <= ZD_COOP_LEN; j++) dst[outStart + j] = (uint8_t)st.rleByte;
-            } else {
-                const uint8_t* lsrc = st.litPtr + litStart;
-                for (uint32_t j = 0; j < myLL && myLL <= ZD_COOP_LEN; j++) { ZD_TR(outStart + j, "lit", litStart + j, lsrc[j], myLL); dst[outStart + j] = lsrc[j]; }
+            const uint32_t litStart = lp + incL - myLL;
+            const uint32_t oRel = incT - (myLL + myML);          // batch-relative output start of my sequence
+            const uint32_t mRel = oRel + myLL;                   // batch-relative start of my match
+            if (zh_ballot(act && (uint64_t)myOF > (uint64_t)op + mRel + dictSize)) return -ZE_CORRUPTION;
+            if (big) {
+                // one sequence larger than the assembly buffer: straight global copies
+                const uint32_t bll = zh_shfl(myLL, 0), bml = zh_shfl(myML, 0), bof = zh_shfl(myOF, 0);
+                if (st.litRLE) zd_fill_wave(dst + op, st.rleByte, bll);
+                else zd_copy_wave(dst + op, st.litPtr + lp, bll);
+                zd_fence();
+                zd_match_wave(dst, dictEnd, op + bll, bof, bml);
+                zd_fence();
+                op += totT; lp += totL; done += cnt;
+                continue;
             }
-            for (uint64_t big = zh_ballot(myLL > ZD_COOP_LEN); big; big &= big - 1) {
-                uint32_t l = (uint32_t)zh_ctz64(big);
-                uint32_t d = zh_shfl(outStart, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
-                ZD_TRR(d, n, "biglit", s, l);
-                if (st.litRLE) zd_fill_wave(dst + d, st.rleByte, n);
-                else zd_copy_wave(dst + d, st.litPtr + s, n);
+            // ---- phase 1: everything that comes from global memory (literals + matches older than this batch)
+            const int32_t sAbs = (int32_t)(op + mRel) - (int32_t)myOF;       // frame-relative match source (negative: dictionary)
+            const bool hasM = act && myML > 0;
+            const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)op && (sAbs >= 0 || sAbs + (int32_t)myML <= 0);
+            {
+                uint64_t rl[4], rm[4];
+                const bool shortL = act && myLL > 0 && myLL <= ZD_COOP_LEN;
+                const bool shortFar = farM && myML <= ZD_COOP_LEN;
+                if (shortL && !st.litRLE) zd_ld32(st.litPtr + litStart, myLL, rl);
+                if (shortFar) zd_ld32(sAbs >= 0 ? dst + sAbs : dictEnd + sAbs, myML, rm);
+                if (shortL) {
+                    if (st.litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * st.rleByte; }
+                    zd_st32(asmb + oRel, myLL, rl);
+                }
+                if (shortFar) zd_st32(asmb + mRel, myML, rm);
             }
-            zd_fence();
-            // matches: dependency rounds
-            bool pending = act && myML > 0;
-            const int32_t sbeg = (int32_t)mdst - (int32_t)myOF;
-            int32_t send = sbeg + (int32_t)myML; if (send > (int32_t)mdst) send = (int32_t)mdst;
+            for (uint64_t m = zh_ballot(act && myLL > ZD_COOP_LEN); m; m &= m - 1) {       // long literal runs: whole wave
+                const uint32_t l = (uint32_t)zh_ctz64(m);
+                const uint32_t d = zh_shfl(oRel, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
+                if (st.litRLE) { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)st.rleByte; }
+                else { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = st.litPtr[s + j]; }
+            }
+            for (uint64_t m = zh_ballot(farM && myML > ZD_COOP_LEN); m; m &= m - 1) {      // long far matches: whole wave
+                const uint32_t l = (uint32_t)zh_ctz64(m);
+                const uint32_t d = zh_shfl(mRel, l), n = zh_shfl(myML, l);
+                const int32_t s = (int32_t)zh_shfl((uint32_t)sAbs, l);
+                for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)zd_hist_byte(dst, dictEnd, s + (int32_t)j);
+            }
+            zh_sync();
+            // ---- phase 2: matches that read this batch's own output, in dependency rounds at LDS speed
+            bool pending = hasM && !farM;
+            int32_t send = sAbs + (int32_t)myML; if (send > (int32_t)(op + mRel)) send = (int32_t)(op + mRel);
             for (;;) {
-                uint64_t pend = zh_ballot(pending);
+                const uint64_t pend = zh_ballot(pending);
                 if (!pend) break;
-                uint32_t f = (uint32_t)zh_ctz64(pend);
-                uint32_t F = zh_shfl(mdst, f), fml = zh_shfl(myML, f), fof = zh_shfl(myOF, f);
-                ZD_TRR(F, fml, "round-first", fof, f);
+                const uint32_t f = (uint32_t)zh_ctz64(pend);
+                const uint32_t Frel = zh_shfl(mRel, f), fml = zh_shfl(myML, f), fof = zh_shfl(myOF, f);
                 if (fml > ZD_COOP_LEN) {
-                    zd_match_wave(dst, dictEnd, F, fof, fml);
+                    // whole wave copies one long match; every source byte is final (older than Frel)
+                    const int32_t fs = (int32_t)(op + Frel) - (int32_t)fof;
+                    if (fof >= 64) {
+                        for (uint32_t c = 0; c < fml; c += 64) {
+                            const uint32_t j = c + lane;
+                            if (j < fml) {
+                                const int32_t sp = fs + (int32_t)j;
+                                asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
+                            }
+                            if (fof < fml) zh_sync();
+                        }
+                    } else {
+                        uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
+                        for (uint32_t j = lane; j < fml; j += 64) {
+                            const int32_t sp = fs + (int32_t)idx;
+                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
+                            idx += adv; if (idx >= fof) idx -= fof;
+                        }
+                    }
                     if (lane == f) pending = false;
                 } else {
-                    bool ready = pending && myML <= ZD_COOP_LEN && (lane == f || send <= (int32_t)F);
+                    const bool ready = pending && myML <= ZD_COOP_LEN && (lane == f || send <= (int32_t)(op + Frel));
                     if (ready) {
-                        for (uint32_t j = 0; j < myML; j++) {
-                            ZD_TR(mdst + j, "match", sbeg + (int32_t)j, myOF, myML);
-                            dst[mdst + j] = (uint8_t)zd_hist_byte(dst, dictEnd, sbeg + (int32_t)j);
+                        if (sAbs >= (int32_t)op && myOF >= myML) {            // entirely inside the buffer, no self-overlap
+                            uint64_t rr[4];
+                            zd_ld32(asmb + (sAbs - (int32_t)op), myML, rr);
+                            zd_st32(asmb + mRel, myML, rr);
+                        } else {                                               // self-overlapping or straddling: byte serial
+                            for (uint32_t j = 0; j < myML; j++) {
+                                const int32_t sp = sAbs + (int32_t)j;
+                                asmb[mRel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
+                            }
                         }
                         pending = false;
                     }
                 }
-                zd_fence();
+                zh_sync();
+            }
+            // ---- phase 3: flush the assembled bytes to HBM, 16 bytes per lane per store
+            {
+                uint8_t* out = dst + op;
+                for (uint32_t j = lane * 16; j < totT; j += 1024) {
+                    if (j + 16 <= totT) {
+                        const uint32_t* s4 = (const uint32_t*)(asmb + j);
+                        ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
+                        *(ZdPack16*)(out + j) = v;
+                    } else {
+                        for (uint32_t k = j; k < totT; k++) out[k] = asmb[k];
+                    }
+                }
             }
             op += totT; lp += totL; done += cnt;
         }
@@ -723,7 +833,6 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
     uint32_t rest = st.litSize - lp;
     if ((uint64_t)op + rest > cap) return -ZE_DST_TOO_SMALL;
     if (op + rest - blockStart > blockMax) return -ZE_CORRUPTION;
-    ZD_TRR(op, rest, "lastlit", lp, 0);
     if (st.litRLE) zd_fill_wave(dst + op, st.rleByte, rest);
     else zd_copy_wave(dst + op, st.litPtr + lp, rest);
     zd_fence();

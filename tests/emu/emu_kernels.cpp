@@ -1,7 +1,7 @@
 // tests/emu/emu_kernels.cpp -- compiles the PRODUCT kernel sources for the host wave emulator (ZHIP_EMU).
 // Test infrastructure only: lets tests/test_emu_*.py exercise kernel logic without a GPU. Never shipped.
 #define ZHIP_EMU 1
-extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; }
+extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; long zd_stat[16]; }
 #include "../../python-zstandard_amd/csrc/zhip_decode_kernel.hpp"
 #include <stdlib.h>
 #include <string.h>
