@@ -84,6 +84,16 @@ struct ZdState {
     uint32_t rleByte;
 };
 
+// ------------------------------------------------------------------------------------------ phase timers (tuning aid)
+enum { ZP_HEADER = 0, ZP_HUFTAB, ZP_HUFDEC, ZP_SEQTAB, ZP_STAGE, ZP_SEQDEC, ZP_EXEC1, ZP_EXEC2, ZP_FLUSH, ZP_RAW, ZP_N };
+struct ZdProf { bool on; uint64_t t0; uint64_t acc[ZP_N]; };
+#ifndef ZHIP_EMU
+ZH_DEV uint64_t zd_clock() { return __builtin_readcyclecounter(); }
+#else
+ZH_DEV uint64_t zd_clock() { return 0; }
+#endif
+#define ZD_T(P, i) do { if ((P).on) { uint64_t t1_ = zd_clock(); (P).acc[i] += t1_ - (P).t0; (P).t0 = t1_; } } while (0)
+
 // ------------------------------------------------------------------------------------------ small helpers
 ZH_DEV uint64_t zd_ld64_bounded(const uint8_t* p, const uint8_t* end)
 {
@@ -412,7 +422,7 @@ ZH_DEVFN bool zd_huf_stream(const uint16_t* huf, uint32_t log, const uint8_t* sr
 }
 
 // Literals section (RFC 8878 3.1.1.3.1). All lanes call. Returns bytes consumed or -err.
-ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t srcSize, uint8_t* lit, uint32_t blockMax)
+ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t srcSize, uint8_t* lit, uint32_t blockMax, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
     if (srcSize < 1) return -ZE_CORRUPTION;
@@ -454,6 +464,7 @@ ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t src
     }
     int lg = zd_build_huf(L, st.hufCount);
     if (lg < 0) return -ZE_CORRUPTION;
+    ZD_T(P, ZP_HUFTAB);
     bool ok = true;
     if (!four) {
         if (lane == 0) ok = zd_huf_stream(L.u.huf, (uint32_t)lg, p, left, lit, regen);
@@ -473,6 +484,7 @@ ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t src
     }
     if (zh_ballot(!ok)) return -ZE_CORRUPTION;
     zd_fence();
+    ZD_T(P, ZP_HUFDEC);
     st.litPtr = lit; st.litSize = regen;
     return (int)(hdr + csize);
 }
@@ -587,7 +599,7 @@ struct ZdPack16 { uint32_t a, b, c, d; } __attribute__((packed, aligned(1)));
 // cost one memory latency; matches that read the batch's own output are resolved in dependency rounds at LDS
 // latency. Sequences too large for the buffer take the direct global path.
 ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t* end, uint8_t* dst, uint32_t cap,
-                          uint32_t* pOp, uint32_t blockMax, const uint8_t* dictEnd, uint32_t dictSize)
+                          uint32_t* pOp, uint32_t blockMax, const uint8_t* dictEnd, uint32_t dictSize, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
     const uint32_t blockStart = *pOp;
@@ -608,6 +620,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
         r = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, p, end); if (r < 0) return r; p += r;
         r = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, p, end); if (r < 0) return r; p += r;
         if (p >= end) return -ZE_CORRUPTION;
+        ZD_T(P, ZP_SEQTAB);
         const uint32_t ssize = (uint32_t)(end - p);
         const uint32_t last = p[ssize - 1];
         if (last == 0) return -ZE_CORRUPTION;
@@ -641,6 +654,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 if (zh_opaque(lane) == 0) L.u.q.stage[0] = 0;
             }
             zh_sync();
+            ZD_T(P, ZP_STAGE);
             // ---- lane 0: decode up to 64 sequences / ZD_ASM_BYTES of output
             if (zh_opaque(lane) == 0) {
 #define ZD_REFILL() do { uint32_t x_ = 0; if (q > 0) { uint32_t ix_ = (uint32_t)(q - stageLo); \
@@ -703,6 +717,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
             }
             first = false;
             zh_sync();
+            ZD_T(P, ZP_SEQDEC);
             const uint32_t cnt = L.misc[0];
             if (L.misc[1]) return -ZE_CORRUPTION;
             q = (int32_t)zh_first(L.misc[2]);
@@ -759,6 +774,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)zd_hist_byte(dst, dictEnd, s + (int32_t)j);
             }
             zh_sync();
+            ZD_T(P, ZP_EXEC1);
             // ---- phase 2: matches that read this batch's own output, in dependency rounds at LDS speed
             bool pending = hasM && !farM;
             int32_t send = sAbs + (int32_t)myML; if (send > (int32_t)(op + mRel)) send = (int32_t)(op + mRel);
@@ -806,6 +822,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 }
                 zh_sync();
             }
+            ZD_T(P, ZP_EXEC2);
             // ---- phase 3: flush the assembled bytes to HBM, 16 bytes per lane per store
             {
                 uint8_t* out = dst + op;
@@ -820,6 +837,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 }
             }
             op += totT; lp += totL; done += cnt;
+            ZD_T(P, ZP_FLUSH);
         }
         // the bitstream must be consumed exactly
         {
@@ -836,12 +854,13 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
     if (st.litRLE) zd_fill_wave(dst + op, st.rleByte, rest);
     else zd_copy_wave(dst + op, st.litPtr + lp, rest);
     zd_fence();
+    ZD_T(P, ZP_RAW);
     *pOp = op + rest;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------ frame
-ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* lit, uint64_t* produced)
+ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* lit, uint64_t* produced, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
 #if defined(ZHIP_EMU) && defined(ZD_TRACE)
@@ -921,6 +940,7 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
             if ((uint64_t)op + bs > cap) return ZE_DST_TOO_SMALL;
             zd_copy_wave(dst + op, src + pos, bs);
             zd_fence();
+            ZD_T(P, ZP_RAW);
             op += bs; pos += bs;
         } else if (type == 1) {
             if (pos + 1 > srcSize) return ZE_SRC_SIZE_WRONG;
@@ -932,9 +952,10 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
         } else {
             if (pos + bs > srcSize) return ZE_SRC_SIZE_WRONG;
             if (bs > ZF_BLOCK_MAX || bs < 2) return ZE_CORRUPTION;
-            int r = zd_literals(L, st, src + pos, bs, lit, blockMax);
+            ZD_T(P, ZP_HEADER);
+            int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P);
             if (r < 0) return -r;
-            int e = zd_sequences(L, st, src + pos + r, src + pos + bs, dst, cap, &op, blockMax, dictEnd, dictSize);
+            int e = zd_sequences(L, st, src + pos + r, src + pos + bs, dst, cap, &op, blockMax, dictEnd, dictSize, P);
             if (e < 0) return -e;
             pos += bs;
         }
@@ -976,7 +997,13 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
         ZD_DBG(2, 0x200 + f);
         if (f >= a.n) break;
         uint64_t produced = 0;
-        int err = zd_frame(a, L, f, lit, &produced);
+        ZdProf P; P.on = a.prof != nullptr;
+        if (P.on) { for (int i = 0; i < ZP_N; i++) P.acc[i] = 0; P.t0 = zd_clock(); }
+        int err = zd_frame(a, L, f, lit, &produced, P);
+        if (P.on) {
+            ZD_T(P, ZP_HEADER);
+            if (zh_opaque(lane) == 0) for (int i = 0; i < ZP_N; i++) zh_atomic_add64(a.prof + i, (unsigned long long)P.acc[i]);
+        }
         ZD_DBG(3, 0x300 + err);
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }

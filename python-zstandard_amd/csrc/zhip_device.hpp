@@ -34,6 +34,7 @@ ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up(
 ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 // hides a value's provenance from the optimizer (used so `lane == 0` is not provably loop-invariant)
 ZH_DEV uint32_t zh_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
@@ -89,6 +90,7 @@ ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d)
 ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
+ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __sync_fetch_and_add(p, v); }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }

@@ -52,5 +52,6 @@ struct ZhipDecodeArgs {
     uint32_t dictContentSize;
     const ZhipDictEntropy* dictEntropy; // null when no dictionary or raw-content dictionary
     uint64_t maxWindowSize;
+    unsigned long long* prof;       // optional: per-phase cycle totals (ZHIP_PROF bring-up / tuning aid), else null
     volatile uint32_t* dbg;         // optional host-visible progress words (ZHIP_DEBUG bring-up aid), else null
 };

@@ -264,6 +264,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     }
     const bool debug = getenv("ZHIP_DEBUG") != nullptr;
     const bool watchdog = getenv("ZHIP_WATCHDOG") != nullptr;
+    const bool prof = getenv("ZHIP_PROF") != nullptr;
+    static unsigned long long* d_prof = nullptr;
+    if (prof) {
+        if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, ZP_N * 8));
+        HIP_TRY(hipMemsetAsync(d_prof, 0, ZP_N * 8, stream));
+        a.prof = d_prof;
+    }
     uint32_t* dbg = nullptr;
     if (debug) {
         HIP_TRY(hipHostMalloc((void**)&dbg, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -294,6 +301,14 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         }
     }
     c->timer[0].pending.emplace_back(e0, e1);
+    if (prof) {
+        unsigned long long h[ZP_N];
+        HIP_TRY(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+        static const char* names[ZP_N] = {"header/misc", "huf-table", "huf-decode", "seq-tables", "stage", "seq-decode(lane0)", "exec1(global->lds)", "exec2(lds rounds)", "flush", "raw/lastlit"};
+        unsigned long long tot = 0; for (int i = 0; i < ZP_N; i++) tot += h[i];
+        fprintf(stderr, "[zhip-prof] grid=%u (CUs %d x %d blocks) frames=%u wave-cycles total=%.3e (%.0f per frame)\n", grid, c->numCU, c->decBlocksPerCU, a.n, (double)tot, (double)tot / a.n);
+        for (int i = 0; i < ZP_N; i++) fprintf(stderr, "[zhip-prof]   %-22s %6.2f%%  %10.0f cyc/frame\n", names[i], 100.0 * h[i] / (tot ? tot : 1), (double)h[i] / a.n);
+    }
     if (c->timer[0].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[0]); }
     return 0;
 }
