@@ -15,7 +15,7 @@
 #include "zhip_decode_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
-ZH_GLOBAL __launch_bounds__(64, 3) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
+ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
 {
     __shared__ ZdLDS L;
     zd_kernel_body(a, L);
