@@ -94,6 +94,68 @@ def cpu_decompress_baseline(ref, frames, nthreads, budget_s=8.0):
     return F * FRAME / best / 1e9, reps
 
 
+def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F):
+    """multi_compress_to_buffer direction: same inputs, frames must be bit-identical to libzstd's (all of them)."""
+    bound = FRAME + (FRAME >> 8)
+    bound = (bound + 15) & ~15
+    src_segs = torch.zeros((F, 2), dtype=torch.int64, device=dev)
+    src_segs[:, 0] = torch.arange(F, device=dev, dtype=torch.int64) * FRAME
+    src_segs[:, 1] = FRAME
+    dst_segs = torch.zeros((F, 2), dtype=torch.int64, device=dev)
+    dst_segs[:, 0] = torch.arange(F, device=dev, dtype=torch.int64) * bound
+    dst_segs[:, 1] = bound
+    dst = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    status = torch.zeros(F, dtype=torch.int32, device=dev)
+    src = raw.reshape(-1)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
+    barrier()
+    ctx.kernel_time(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.kernel_time(1)
+    assert int(status.abs().max().item()) == 0, "a frame failed to compress"
+    sizes = out_sizes.cpu().numpy()
+    out = dst.view(F, bound).cpu().numpy()
+    for i in range(F):                                              # bit-exactness gate over every frame
+        assert out[i, : sizes[i]].tobytes() == frames[i], "frame %d differs from libzstd 1.5.7" % i
+    ctotal = int(sizes.sum())
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * F * FRAME * args.steps / elapsed / 1e9
+    line = {
+        "metric": "GB/s uncompressed throughput, batch compress of 128 KiB inputs at level 3 (bit-exact vs libzstd 1.5.7)",
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "multi_compress_to_buffer (device-resident): %d x 128 KiB Silesia-like inputs per GPU, level 3" % F,
+                   "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3, "compression_ratio": round(F * FRAME / ctotal, 3),
+                   "parallelism": "frames sharded by rank, no data-path collective"},
+    }
+    if rank == 0:
+        algo_bytes = F * FRAME + ctotal
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(1), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "kernel_ms": round(kernel_ms, 3), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes)}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (BASELINE config: 65536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direction", choices=["decompress", "compress"], default="decompress",
+                    help="decompress is the BASELINE.json headline; compress times multi_compress_to_buffer on the same inputs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +211,8 @@ def main():
     status = torch.zeros(F, dtype=torch.int32, device=dev)
 
     ctx = DeviceBatchContext()
+    if args.direction == "compress":
+        return bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F)
 
     def barrier():
         if world > 1:

@@ -35,6 +35,9 @@ ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfir
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { atomicAdd(p, 1u); }
+ZH_DEV uint32_t zh_wave_max(uint32_t v) { for (int d = 32; d; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; } return v; }
+ZH_DEV void ze_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 // hides a value's provenance from the optimizer (used so `lane == 0` is not provably loop-invariant)
 ZH_DEV uint32_t zh_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
@@ -92,6 +95,17 @@ ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u);
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __sync_fetch_and_add(p, v); }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
+ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { (*p)++; }
+ZH_DEV uint32_t zh_wave_max(uint32_t v)
+{
+    zhemu::slot[zhemu::lane] = v;
+    zhemu::collective_wait();
+    uint32_t m = 0;
+    for (int i = 0; i < 64; i++) if ((uint32_t)zhemu::slot[i] > m) m = (uint32_t)zhemu::slot[i];
+    zhemu::collective_wait();
+    return m;
+}
+ZH_DEV void ze_fence() { zhemu::collective_wait(); }
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __builtin_clz(v); }

@@ -1,0 +1,918 @@
+// zhip_encode_kernel.hpp -- batch zstd frame encoder, one wavefront per frame, frames bit-identical to libzstd 1.5.7
+// at the same level (double-fast strategy: level 3 for every size class, and the other dfast rows of the level table).
+//
+// Replaces the arithmetic under compress_worker() (c-ext/compressor.c:856-1076): ZSTD_compressStream2(e_end) ->
+// ZSTD_compress_frameChunk -> ZSTD_compressBlock_internal (zstd.c:29401, :27545, :27337) for single-block frames
+// (<= 128 KiB, every batch configuration of BASELINE.json). SURVEY.md 8(a) rows C1-C13 / Appendix A list the
+// behaviours that decide output bytes; each routine below names the reference routine it restates.
+//
+// Round-1 shape (correctness first, see DESIGN.md for the plan): the double-fast search is a serial dependency chain
+// (every step reads two hash tables the previous step wrote), so lane 0 drives it with the tables in a per-wave HBM
+// workspace; the wave zeroes tables, builds histograms and symbol codes in parallel; entropy-table construction is
+// small and serial; literals are Huffman-coded by four lanes (one per stream); the tANS sequence stream is emitted by
+// lane 0. Lane-0 results are published through LDS + barrier (see the compiler-hazard note in zhip_decode_kernel.hpp).
+#pragma once
+#include "zhip_device.hpp"
+#include "zhip_format.hpp"
+
+ZH_CONST uint32_t ze_llBase[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,
+                                   1024,2048,4096,8192,16384,32768,65536};
+ZH_CONST uint8_t ze_llBits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+ZH_CONST uint32_t ze_mlBase[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,
+                                   33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+ZH_CONST uint8_t ze_mlBits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                  1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+ZH_CONST int16_t ze_llDef[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+ZH_CONST int16_t ze_mlDef[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                 1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+ZH_CONST int16_t ze_ofDef[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+// level rows 1..4 of the four source-size classes (zstd.c:30650-30755): wlog clog hlog slog mml tlen strategy
+ZH_CONST int8_t ze_rows[4][5][7] = {
+    {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2}},
+    {{18,12,13,1,5,1,1},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,3,5,2,3}},
+    {{17,12,12,1,5,1,1},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2}},
+    {{14,12,13,1,5,1,1},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3}},
+};
+
+struct ZeCTab {                 // FSE encoding table: per symbol, its cells in table order
+    int32_t log;
+    uint32_t maxSym;
+    int16_t norm[64];
+    uint16_t cellOf[66];
+    uint16_t next[512];
+};
+struct ZeNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
+
+struct ZeLDS {
+    uint32_t hist[256];
+    ZeNode node[2 * 256 + 2];
+    uint8_t hufBits[256];
+    uint16_t hufCode[256];
+    ZeCTab tab[3];              // LL, OF, ML
+    uint32_t cnt[3][64];        // code histograms
+    uint8_t cellSym[512];
+    uint8_t weights[256];
+    uint32_t misc[16];
+    uint32_t stack[64];
+};
+
+struct ZePar { int wlog, clog, hlog, mml, strat; };
+
+// ------------------------------------------------------------------------------------------ LSB-first bit writer (one lane)
+struct ZeBits { uint8_t* p; uint32_t cap; uint64_t acc; uint32_t n; uint32_t pos; };
+ZH_DEV void ze_bw_init(ZeBits& b, uint8_t* p, uint32_t cap) { b.p = p; b.cap = cap; b.acc = 0; b.n = 0; b.pos = 0; }
+ZH_DEV void ze_bw_add(ZeBits& b, uint32_t v, uint32_t nb)
+{
+    if (nb == 0) return;
+    b.acc |= ((uint64_t)v & ((1ull << nb) - 1)) << b.n;
+    b.n += nb;
+    while (b.n >= 8) {
+        if (b.pos < b.cap) b.p[b.pos] = (uint8_t)b.acc;
+        b.pos++; b.acc >>= 8; b.n -= 8;
+    }
+}
+ZH_DEV uint32_t ze_bw_close(ZeBits& b)      // end mark + padding; 0 on overflow
+{
+    ze_bw_add(b, 1, 1);
+    if (b.n) { if (b.pos < b.cap) b.p[b.pos] = (uint8_t)b.acc; b.pos++; }
+    return b.pos > b.cap ? 0 : b.pos;
+}
+
+// ------------------------------------------------------------------------------------------ FSE, compression side (lane 0)
+// FSE_optimalTableLog_internal, zstd.c:16294
+ZH_DEV uint32_t ze_fse_optimal_log(uint32_t maxLog, uint32_t n, uint32_t maxSym, uint32_t minus)
+{
+    uint32_t maxBitsSrc = (uint32_t)zh_highbit32(n - 1) - minus;
+    uint32_t minBitsSrc = (uint32_t)zh_highbit32(n) + 1, minBitsSym = (uint32_t)zh_highbit32(maxSym) + 2;
+    uint32_t minBits = minBitsSrc < minBitsSym ? minBitsSrc : minBitsSym;
+    uint32_t lg = maxLog;
+    if (maxBitsSrc < lg) lg = maxBitsSrc;
+    if (minBits > lg) lg = minBits;
+    if (lg < 5) lg = 5;
+    if (lg > 12) lg = 12;
+    return lg;
+}
+
+// FSE_normalizeM2, zstd.c:16316
+ZH_DEVFN int ze_fse_normalize_m2(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, int lowProb)
+{
+    const int16_t UNSET = -2;
+    uint32_t distributed = 0;
+    uint32_t lowThreshold = total >> lg;
+    uint32_t lowOne = (uint32_t)(((uint64_t)total * 3) >> (lg + 1));
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = (int16_t)lowProb; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = UNSET;
+    }
+    uint32_t toDistribute = (1u << lg) - distributed;
+    if (toDistribute == 0) return 0;
+    if ((total / toDistribute) > lowOne) {
+        lowOne = (uint32_t)(((uint64_t)total * 3) / (toDistribute * 2));
+        for (uint32_t s = 0; s <= maxSym; s++)
+            if (norm[s] == UNSET && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        toDistribute = (1u << lg) - distributed;
+    }
+    if (distributed == maxSym + 1) {
+        uint32_t maxV = 0, maxC = 0;
+        for (uint32_t s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] = (int16_t)(norm[maxV] + (int16_t)toDistribute);
+        return 0;
+    }
+    if (total == 0) {
+        for (uint32_t s = 0; toDistribute > 0; s = (s + 1) % (maxSym + 1))
+            if (norm[s] > 0) { toDistribute--; norm[s]++; }
+        return 0;
+    }
+    {
+        const uint64_t vStepLog = 62 - lg, mid = (1ull << (vStepLog - 1)) - 1;
+        const uint64_t rStep = (((1ull << vStepLog) * toDistribute) + mid) / total;
+        uint64_t tmpTotal = mid;
+        for (uint32_t s = 0; s <= maxSym; s++) if (norm[s] == UNSET) {
+            uint64_t end = tmpTotal + (uint64_t)count[s] * rStep;
+            uint32_t weight = (uint32_t)(end >> vStepLog) - (uint32_t)(tmpTotal >> vStepLog);
+            if (weight < 1) return -1;
+            norm[s] = (int16_t)weight;
+            tmpTotal = end;
+        }
+    }
+    return 0;
+}
+
+// FSE_normalizeCount, zstd.c:16402
+ZH_DEVFN int ze_fse_normalize(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, int useLowProb)
+{
+    const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+    const int lowProb = useLowProb ? -1 : 1;
+    const uint64_t scale = 62 - lg, step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
+    int still = 1 << lg;
+    uint32_t largest = 0; int16_t largestP = 0;
+    const uint32_t lowThreshold = total >> lg;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = (int16_t)lowProb; still--; }
+        else {
+            int16_t proba = (int16_t)(((uint64_t)count[s] * step) >> scale);
+            if (proba < 8) {
+                uint64_t restToBeat = vStep * rtb[proba];
+                proba = (int16_t)(proba + ((((uint64_t)count[s] * step) - ((uint64_t)proba << scale)) > restToBeat));
+            }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba; still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) return ze_fse_normalize_m2(norm, lg, count, total, maxSym, lowProb);
+    norm[largest] = (int16_t)(norm[largest] + (int16_t)still);
+    return 0;
+}
+
+// FSE_writeNCount_generic, zstd.c:16170. Returns bytes written.
+ZH_DEVFN uint32_t ze_fse_write_ncount(uint8_t* out, const int16_t* norm, uint32_t maxSym, uint32_t lg)
+{
+    ZeBits b; ze_bw_init(b, out, 512);
+    const uint32_t alphabet = maxSym + 1;
+    int remaining = (1 << lg) + 1, threshold = 1 << lg, nbBits = (int)lg + 1;
+    uint32_t sym = 0; int prev0 = 0;
+    ze_bw_add(b, lg - 5, 4);
+    while (sym < alphabet && remaining > 1) {
+        if (prev0) {
+            uint32_t start = sym;
+            while (sym < alphabet && !norm[sym]) sym++;
+            if (sym == alphabet) break;
+            while (sym >= start + 24) { start += 24; ze_bw_add(b, 0xFFFF, 16); }
+            while (sym >= start + 3) { start += 3; ze_bw_add(b, 3, 2); }
+            ze_bw_add(b, sym - start, 2);
+        }
+        {
+            int count = norm[sym++];
+            int max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            ze_bw_add(b, (uint32_t)count, (uint32_t)(nbBits - (count < max)));
+            prev0 = (count == 1);
+            if (remaining < 1) break;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+    }
+    if (b.n) { b.p[b.pos++] = (uint8_t)b.acc; }
+    return b.pos;
+}
+
+// FSE_buildCTable_wksp, zstd.c:16005 (same symbol spread as the decoding table; per symbol the sorted cell list)
+ZH_DEVFN void ze_fse_build_ctab(ZeCTab& t, uint8_t* cellSym, const int16_t* norm, uint32_t maxSym, uint32_t lg)
+{
+    const uint32_t size = 1u << lg, step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    uint32_t high = size - 1, pos = 0;
+    t.log = (int32_t)lg; t.maxSym = maxSym;
+    for (uint32_t s = 0; s <= maxSym; s++) { t.norm[s] = norm[s]; if (norm[s] == -1) cellSym[high--] = (uint8_t)s; }
+    for (uint32_t s = 0; s <= maxSym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            cellSym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    uint32_t cum = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) { t.cellOf[s] = (uint16_t)cum; cum += norm[s] == -1 ? 1u : (uint32_t)norm[s]; }
+    t.cellOf[maxSym + 1] = (uint16_t)cum;
+    // second pass needs a running fill pointer per symbol: reuse cellOf by walking cells in order per symbol
+    for (uint32_t u = 0, filled = 0; filled < size && u < 1; u++) { (void)filled; }
+    uint16_t fill[64];
+    for (uint32_t s = 0; s <= maxSym; s++) fill[s] = t.cellOf[s];
+    for (uint32_t u = 0; u < size; u++) { uint32_t s = cellSym[u]; t.next[fill[s]++] = (uint16_t)(size + u); }
+}
+ZH_DEV void ze_fse_build_rle(ZeCTab& t, uint32_t sym)      // FSE_buildCTable_rle, zstd.c:16465
+{
+    t.log = 0; t.maxSym = sym;
+    for (uint32_t s = 0; s <= sym; s++) { t.norm[s] = 0; t.cellOf[s] = 0; }
+    t.norm[sym] = 1; t.cellOf[sym + 1] = 1; t.next[0] = 1;
+}
+// FSE_initCState2 (zstd.c:2774): the virtual start state that lands on one of the symbol's first cells
+ZH_DEV uint32_t ze_fse_first_state(const ZeCTab& t, uint32_t s)
+{
+    if (t.log == 0) return 1;
+    const uint32_t c = t.norm[s] == -1 ? 1u : (uint32_t)t.norm[s];
+    const uint32_t nb = c > 1 ? (uint32_t)t.log - (uint32_t)zh_highbit32(c - 1) : (uint32_t)t.log;
+    const uint32_t delta = (nb << 16) - (c << nb);
+    const uint32_t nbOut = (delta + (1u << 15)) >> 16;
+    const uint32_t value = (nbOut << 16) - delta;
+    return t.next[t.cellOf[s] + (value >> nbOut) - c];
+}
+// FSE_encodeSymbol (zstd.c:2785)
+ZH_DEV uint32_t ze_fse_encode(const ZeCTab& t, ZeBits& b, uint32_t v, uint32_t s)
+{
+    if (t.log == 0) return v;
+    const uint32_t c = t.norm[s] == -1 ? 1u : (uint32_t)t.norm[s];
+    uint32_t nb;
+    if (c == 1) nb = (uint32_t)t.log;
+    else { const uint32_t maxBits = (uint32_t)t.log - (uint32_t)zh_highbit32(c - 1); nb = v >= (c << maxBits) ? maxBits : maxBits - 1; }
+    ze_bw_add(b, v, nb);
+    return t.next[t.cellOf[s] + (v >> nb) - c];
+}
+
+// ------------------------------------------------------------------------------------------ Huffman, compression side (lane 0)
+ZH_DEV uint32_t ze_huf_bucket(uint32_t c) { return c < 166 ? c : (uint32_t)zh_highbit32(c) + 158; }
+
+ZH_DEVFN void ze_huf_insertion(ZeNode* a, int n)        // HUF_insertionSort, zstd.c:17312
+{
+    for (int i = 1; i < n; i++) {
+        ZeNode key = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+ZH_DEVFN int ze_huf_partition(ZeNode* a, int low, int high)   // HUF_quickSortPartition, zstd.c:17328
+{
+    const uint32_t pivot = a[high].count; int i = low - 1;
+    for (int j = low; j < high; j++) if (a[j].count > pivot) { i++; ZeNode t = a[i]; a[i] = a[j]; a[j] = t; }
+    ZeNode t = a[i + 1]; a[i + 1] = a[high]; a[high] = t;
+    return i + 1;
+}
+// HUF_simpleQuickSort (zstd.c:17345) without recursion: frames are (low, high, isCall). A "call" on fewer than 8
+// elements is an insertion sort; a continued loop always partitions, exactly like the reference.
+ZH_DEVFN void ze_huf_quicksort(ZeNode* a, int low0, int high0, uint32_t* stack)
+{
+    int sp = 0;
+    stack[sp++] = (uint32_t)low0 | ((uint32_t)high0 << 10) | (1u << 20);
+    while (sp > 0) {
+        const uint32_t f = stack[--sp];
+        int low = (int)(f & 1023), high = (int)((f >> 10) & 1023); const bool call = (f >> 20) & 1;
+        if (high >= 1000) high -= 1024;          // -1 encoded
+        if (call && high - low < 8) { ze_huf_insertion(a + low, high - low + 1); continue; }
+        if (!(low < high)) continue;
+        const int idx = ze_huf_partition(a, low, high);
+        if (idx - low < high - idx) {
+            stack[sp++] = (uint32_t)(idx + 1) | ((uint32_t)(high & 1023) << 10);                 // continue loop on the right
+            stack[sp++] = (uint32_t)low | ((uint32_t)((idx - 1) & 1023) << 10) | (1u << 20);     // call on the left
+        } else {
+            stack[sp++] = (uint32_t)low | ((uint32_t)((idx - 1) & 1023) << 10);
+            stack[sp++] = (uint32_t)(idx + 1) | ((uint32_t)(high & 1023) << 10) | (1u << 20);
+        }
+    }
+}
+
+// HUF_buildCTable_wksp (zstd.c:17513): HUF_sort :17377, HUF_buildTree :17438, HUF_setMaxHeight :17133,
+// HUF_buildCTableFromTree :17487. counts in L.hist -> L.hufBits / L.hufCode. Returns the maximum code length.
+ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
+{
+    ZeNode* const tbl = L.node;
+    for (uint32_t i = 0; i < 2 * 256 + 2; i++) { tbl[i].count = 0; tbl[i].parent = 0; tbl[i].byte = 0; tbl[i].nbBits = 0; }
+    ZeNode* const node = tbl + 1;
+    const uint32_t* count = L.hist;
+    {   // bucket sort by decreasing count; L.cnt doubles as the 193-entry base/cur arrays
+        uint32_t* base = &L.cnt[0][0];          // 192 entries available (3 x 64)
+        uint16_t* cur = L.tab[2].next;          // scratch: free until the sequence tables are built
+        for (int n = 0; n < 192; n++) base[n] = 0;
+        const uint32_t n1 = maxSym + 1;
+        for (uint32_t n = 0; n < n1; n++) base[ze_huf_bucket(count[n])]++;
+        for (int n = 191; n > 0; n--) base[n - 1] += base[n];
+        for (int n = 0; n < 192; n++) cur[n] = (uint16_t)base[n];
+        cur[192] = 0;
+        for (uint32_t n = 0; n < n1; n++) {
+            const uint32_t r = ze_huf_bucket(count[n]) + 1;
+            const uint32_t pos = r < 192 ? cur[r]++ : 0;
+            node[pos].count = count[n]; node[pos].byte = (uint8_t)n;
+        }
+        for (uint32_t r = 166; r < 191; r++) {
+            const int bsize = (int)cur[r] - (int)base[r];
+            if (bsize > 1) ze_huf_quicksort(node + base[r], 0, bsize - 1, L.stack);
+        }
+    }
+    int last = (int)maxSym;
+    while (node[last].count == 0) last--;
+    int lowS = last, nodeNb = 256, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
+    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+    node[lowS].parent = node[lowS - 1].parent = (uint16_t)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+    node[-1].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        const int n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        const int n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        node[nodeNb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (uint16_t)nodeNb;
+        nodeNb++;
+    }
+    node[nodeRoot].nbBits = 0;
+    for (int n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = (uint8_t)(node[node[n].parent].nbBits + 1);
+    for (int n = 0; n <= last; n++) node[n].nbBits = (uint8_t)(node[node[n].parent].nbBits + 1);
+    uint32_t largest = node[last].nbBits;
+    if (largest > maxBits) {
+        int totalCost = 0; const uint32_t baseCost = 1u << (largest - maxBits);
+        int n = last;
+        while (node[n].nbBits > maxBits) { totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits))); node[n].nbBits = (uint8_t)maxBits; n--; }
+        while (node[n].nbBits == maxBits) --n;
+        totalCost >>= (largest - maxBits);
+        const uint32_t none = 0xF0F0F0F0u; uint32_t rankLast[14];
+        for (int i = 0; i < 14; i++) rankLast[i] = none;
+        {   uint32_t curBits = maxBits;
+            for (int pos = n; pos >= 0; pos--) { if (node[pos].nbBits >= curBits) continue; curBits = node[pos].nbBits; rankLast[maxBits - curBits] = (uint32_t)pos; } }
+        while (totalCost > 0) {
+            uint32_t dec = (uint32_t)zh_highbit32((uint32_t)totalCost) + 1;
+            for (; dec > 1; dec--) {
+                const uint32_t highPos = rankLast[dec], lowPos = rankLast[dec - 1];
+                if (highPos == none) continue;
+                if (lowPos == none) break;
+                if (node[highPos].count <= 2 * node[lowPos].count) break;
+            }
+            while (dec <= 12 && rankLast[dec] == none) dec++;
+            totalCost -= 1 << (dec - 1);
+            node[rankLast[dec]].nbBits++;
+            if (rankLast[dec - 1] == none) rankLast[dec - 1] = rankLast[dec];
+            if (rankLast[dec] == 0) rankLast[dec] = none;
+            else { rankLast[dec]--; if (node[rankLast[dec]].nbBits != maxBits - dec) rankLast[dec] = none; }
+        }
+        while (totalCost < 0) {
+            if (rankLast[1] == none) {
+                while (node[n].nbBits == maxBits) n--;
+                node[n + 1].nbBits--; rankLast[1] = (uint32_t)(n + 1); totalCost++;
+                continue;
+            }
+            node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+        }
+        largest = maxBits;
+    }
+    uint16_t perRank[14], start[14];
+    for (int i = 0; i < 14; i++) { perRank[i] = 0; start[i] = 0; }
+    for (int n = 0; n <= last; n++) perRank[node[n].nbBits]++;
+    {   uint16_t mn = 0; for (int r = (int)largest; r > 0; r--) { start[r] = mn; mn = (uint16_t)((mn + perRank[r]) >> 1); } }
+    for (uint32_t s = 0; s < 256; s++) { L.hufBits[s] = 0; L.hufCode[s] = 0; }
+    for (uint32_t n = 0; n <= maxSym; n++) L.hufBits[node[n].byte] = node[n].nbBits;
+    for (uint32_t s = 0; s <= maxSym; s++) { const uint32_t nb = L.hufBits[s]; L.hufCode[s] = nb ? start[nb]++ : (uint16_t)0; }
+    return largest;
+}
+
+// HUF_compressWeights (zstd.c:16904) + FSE_compress_usingCTable_generic (:16488). 0 = not compressible, 1 = one symbol.
+ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t* w, uint32_t n)
+{
+    uint32_t count[13]; uint32_t maxSym = 0, maxCount = 0;
+    if (n <= 1) return 0;
+    for (int s = 0; s < 13; s++) count[s] = 0;
+    for (uint32_t i = 0; i < n; i++) count[w[i]]++;
+    for (uint32_t s = 0; s <= 12; s++) { if (count[s]) maxSym = s; if (count[s] > maxCount) maxCount = count[s]; }
+    if (maxCount == n) return 1;
+    if (maxCount == 1) return 0;
+    const uint32_t lg = ze_fse_optimal_log(6, n, maxSym, 2);
+    int16_t norm[13];
+    if (ze_fse_normalize(norm, lg, count, n, maxSym, 0) < 0) return 0;
+    const uint32_t h = ze_fse_write_ncount(out, norm, maxSym, lg);
+    ZeCTab& t = L.tab[0];
+    ze_fse_build_ctab(t, L.cellSym, norm, maxSym, lg);
+    if (n <= 2) return 0;
+    ZeBits b; ze_bw_init(b, out + h, 512);
+    uint32_t ip = n, s1, s2;
+    if (n & 1) { s1 = ze_fse_first_state(t, w[--ip]); s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_encode(t, b, s1, w[--ip]); }
+    else { s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_first_state(t, w[--ip]); }
+    while (ip > 0) {
+        s2 = ze_fse_encode(t, b, s2, w[--ip]);
+        s1 = ze_fse_encode(t, b, s1, w[--ip]);
+    }
+    ze_bw_add(b, s2, lg); ze_bw_add(b, s1, lg);
+    const uint32_t c = ze_bw_close(b);
+    return c ? h + c : 0;
+}
+
+// HUF_writeCTable_wksp (zstd.c:17005). 0 = cannot be described.
+ZH_DEVFN uint32_t ze_huf_write_table(ZeLDS& L, uint8_t* out, uint32_t maxSym, uint32_t lg)
+{
+    uint8_t* w = L.weights;
+    for (uint32_t n = 0; n < maxSym; n++) w[n] = L.hufBits[n] ? (uint8_t)(lg + 1 - L.hufBits[n]) : (uint8_t)0;
+    const uint32_t h = ze_huf_compress_weights(L, out + 1, w, maxSym);
+    if (h > 1 && h < maxSym / 2) { out[0] = (uint8_t)h; return h + 1; }
+    if (maxSym > 128) return 0;
+    out[0] = (uint8_t)(128 + (maxSym - 1));
+    w[maxSym] = 0;
+    for (uint32_t n = 0; n < maxSym; n += 2) out[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
+    return (maxSym + 1) / 2 + 1;
+}
+
+// one Huffman stream, last symbol first (HUF_compress1X_usingCTable_internal_body, zstd.c:17813). One lane.
+ZH_DEVFN uint32_t ze_huf_encode_1x(const ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t n)
+{
+    ZeBits b; ze_bw_init(b, out, cap);
+    for (uint32_t i = n; i-- > 0;) { const uint32_t s = src[i]; ze_bw_add(b, L.hufCode[s], L.hufBits[s]); }
+    return ze_bw_close(b);
+}
+
+// literals header for raw / rle sections (ZSTD_noCompressLiterals :20842, ZSTD_compressRleLiteralsBlock :20884). lane 0.
+ZH_DEVFN uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n, uint32_t type, bool rle)
+{
+    const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) out[0] = (uint8_t)(type + (n << 3));
+    else if (fl == 2) zh_st16(out, (uint16_t)(type + (1 << 2) + (n << 4)));
+    else zh_st32(out, type + (3u << 2) + (n << 4));
+    if (rle) { out[fl] = lit[0]; return fl + 1; }
+    for (uint32_t i = 0; i < n; i++) out[fl + i] = lit[i];
+    return fl + n;
+}
+
+// ZSTD_compressLiterals (zstd.c:20932) + HUF_compress_internal (:18089) on a first block (no previous table).
+// All lanes call; returns the literals-section size (uniform).
+ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t lh = 3 + (n >= 1024) + (n >= 16384);
+    const bool single = n < 256;
+    // decision: 0 raw, 1 rle, 2 try Huffman
+    uint32_t decision = 2;
+    if (n < 64) decision = 0;
+    const bool suspect = (nbSeq == 0) || (n / nbSeq >= 20);
+    zh_sync();
+    for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
+    zh_sync();
+    if (decision == 2 && suspect && n >= 4096 * 10) {
+        // two 4 KiB samples (HUF_flags_suspectUncompressible)
+        uint32_t total = 0;
+        for (int part = 0; part < 2; part++) {
+            const uint8_t* p = part ? lit + n - 4096 : lit;
+            for (uint32_t i = lane; i < 4096; i += 64) zh_lds_atomic_inc(&L.hist[p[i]]);
+            zh_sync();
+            uint32_t m = 0;
+            for (uint32_t i = lane; i < 256; i += 64) { if (L.hist[i] > m) m = L.hist[i]; }
+            m = zh_wave_max(m);
+            total += m;
+            zh_sync();
+            for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
+            zh_sync();
+        }
+        if (total <= ((2 * 4096) >> 7) + 4) decision = 0;
+    }
+    uint32_t maxSym = 0, largest = 0;
+    if (decision == 2) {
+        for (uint32_t i = lane; i < n; i += 64) zh_lds_atomic_inc(&L.hist[lit[i]]);
+        zh_sync();
+        uint32_t m = 0, ms = 0;
+        for (uint32_t i = lane; i < 256; i += 64) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) ms = i; }
+        largest = zh_wave_max(m); maxSym = zh_wave_max(ms);
+        if (largest == n) decision = 1;
+        else if (largest <= (n >> 7) + 4) decision = 0;
+    }
+    zh_sync();
+    if (decision == 2) {
+        uint32_t lg = 0, h = 0;
+        if (zh_opaque(lane) == 0) {
+            lg = ze_fse_optimal_log(11, n, maxSym, 1);
+            lg = ze_huf_build(L, maxSym, lg);
+            h = ze_huf_write_table(L, out + lh, maxSym, lg);
+            L.misc[0] = h;
+        }
+        zh_sync();
+        h = zh_first(L.misc[0]);
+        zh_sync();
+        if (h == 0 || h + 12 >= n) decision = 0;
+        else {
+            uint8_t* body = out + lh + h;
+            const uint32_t bcap = cap - lh - h;
+            uint32_t total = 0;
+            if (single) {
+                if (zh_opaque(lane) == 0) L.misc[0] = ze_huf_encode_1x(L, body, bcap, lit, n);
+                zh_sync();
+                total = zh_first(L.misc[0]);
+                zh_sync();
+            } else {
+                // 4 streams (HUF_compress4X_usingCTable_internal, zstd.c:17925): 6-byte jump table + 4 bodies. The bodies
+                // must be contiguous, so every lane first measures its stream, then writes it at its final offset.
+                const uint32_t seg = (n + 3) / 4;
+                uint32_t bits = 0;
+                if (lane < 4) {
+                    const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
+                    for (uint32_t i = 0; i < len; i++) bits += L.hufBits[lit[s0 + i]];
+                }
+                const uint32_t mySize = (bits + 1 + 7) / 8;
+                const uint32_t z1 = zh_shfl(mySize, 0), z2 = zh_shfl(mySize, 1), z3 = zh_shfl(mySize, 2), z4 = zh_shfl(mySize, 3);
+                bool ok = !(z1 > 65535 || z2 > 65535 || z3 > 65535 || z4 > 65535) && n >= 12 && (6 + z1 + z2 + z3 + z4 <= bcap);
+                if (ok) {
+                    if (lane < 4) {
+                        const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
+                        const uint32_t off = 6 + (lane > 0 ? z1 : 0) + (lane > 1 ? z2 : 0) + (lane > 2 ? z3 : 0);
+                        (void)ze_huf_encode_1x(L, body + off, mySize, lit + s0, len);
+                        if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)mySize);
+                    }
+                    total = 6 + z1 + z2 + z3 + z4;
+                }
+                zh_sync();
+            }
+            uint32_t cl = total ? h + total : 0;
+            if (cl >= n - 1) cl = 0;
+            if (cl == 0 || cl >= n - ((n >> 6) + 2)) decision = 0;
+            else {
+                if (zh_opaque(lane) == 0) {
+                    if (lh == 3) { const uint32_t v = 2 + ((uint32_t)(!single) << 2) + (n << 4) + (cl << 14); out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16); }
+                    else if (lh == 4) zh_st32(out, 2 + (2u << 2) + (n << 4) + (cl << 18));
+                    else { zh_st32(out, 2 + (3u << 2) + (n << 4) + (cl << 22)); out[4] = (uint8_t)(cl >> 10); }
+                }
+                zh_sync();
+                return lh + cl;
+            }
+        }
+    }
+    // raw or rle literals
+    if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lit, n, decision == 1 ? 1u : 0u, decision == 1);
+    zh_sync();
+    const uint32_t r = zh_first(L.misc[0]);
+    zh_sync();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ double-fast match finder (lane 0)
+ZH_DEV uint32_t ze_hash(const uint8_t* p, int hbits, int mls)      // ZSTD_hashPtr, zstd.c:20084
+{
+    const uint64_t u = zh_ld64(p);
+    switch (mls) {
+    case 5: return (uint32_t)(((u << 24) * 889523592379ull) >> (64 - hbits));
+    case 6: return (uint32_t)(((u << 16) * 227718039650203ull) >> (64 - hbits));
+    case 7: return (uint32_t)(((u << 8) * 58295818150454627ull) >> (64 - hbits));
+    case 8: return (uint32_t)((u * 0xCF1BBCDCB7A56463ull) >> (64 - hbits));
+    default: return (uint32_t)(((uint32_t)u * 2654435761u) >> (32 - hbits));
+    }
+}
+ZH_DEV uint32_t ze_common_len(const uint8_t* a, const uint8_t* b, const uint8_t* aend)     // ZSTD_count, zstd.c:20008
+{
+    const uint8_t* s = a;
+    while (a + 8 <= aend) {
+        const uint64_t d = zh_ld64(a) ^ zh_ld64(b);
+        if (d) return (uint32_t)(a - s) + (uint32_t)(zh_ctz64(d) >> 3);
+        a += 8; b += 8;
+    }
+    while (a < aend && *a == *b) { a++; b++; }
+    return (uint32_t)(a - s);
+}
+
+// ZSTD_compressBlock_doubleFast_noDict_generic (zstd.c:31039) for a block that is the whole frame. Table cells hold
+// position + 2 (0 = empty), so the reference's index comparisons keep their meaning with lowest == 2. lane 0 only.
+// seqs: triples (offBase, litLength, matchLength). Returns nbSeq; *pLit = literal count.
+ZH_DEVFN uint32_t ze_dfast(uint32_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                           uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const int hl = cp.hlog, hs = cp.clog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t LOW = 2;
+    const uint8_t* const base = src - 2;
+    const uint8_t* const iend = src + srcSize;
+    const uint8_t* const ilimit = iend - 8;
+    const uint8_t* anchor = src;
+    const uint8_t* ip = src + 1;
+    uint32_t off1 = 1, off2 = 0;            // {1,4,8} clipped to maxRep == 1 at the frame start (zstd.c:31091-31098)
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
+        seqs[3 * nseq] = (OFFBASE); seqs[3 * nseq + 1] = ll_; seqs[3 * nseq + 2] = (uint32_t)(ML); nseq++; } while (0)
+    for (;;) {
+        uint32_t step = 1; const uint8_t* nextStep = ip + 256; const uint8_t* ip1 = ip + step;
+        uint32_t mLength = 0, offset = 0, curr = 0;
+        if (ip1 > ilimit) break;
+        uint32_t hl0 = ze_hash(ip, hl, 8), idxl0 = hashLong[hl0];
+        uint32_t hl1 = 0, idxl1 = 0;
+        int found = 0;
+        do {
+            const uint32_t hs0 = ze_hash(ip, hs, mls), idxs0 = hashSmall[hs0];
+            curr = (uint32_t)(ip - base);
+            hashLong[hl0] = curr; hashSmall[hs0] = curr;
+            if (off1 > 0 && zh_ld32(ip + 1 - off1) == zh_ld32(ip + 1)) {
+                mLength = ze_common_len(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+                ip++;
+                ZE_STORE(ip - anchor, 1, mLength);
+                found = 1; break;
+            }
+            hl1 = ze_hash(ip1, hl, 8);
+            if (idxl0 >= LOW && zh_ld64(base + idxl0) == zh_ld64(ip)) {
+                const uint8_t* m = base + idxl0;
+                mLength = ze_common_len(ip + 8, m + 8, iend) + 8;
+                offset = (uint32_t)(ip - m);
+                while (ip > anchor && m > base + LOW && ip[-1] == m[-1]) { ip--; m--; mLength++; }
+                found = 2; break;
+            }
+            idxl1 = hashLong[hl1];
+            if (idxs0 >= LOW && zh_ld32(base + idxs0) == zh_ld32(ip)) {
+                const uint8_t* m = base + idxs0;
+                mLength = ze_common_len(ip + 4, m + 4, iend) + 4;
+                offset = (uint32_t)(ip - m);
+                if (idxl1 > LOW && zh_ld64(base + idxl1) == zh_ld64(ip1)) {
+                    const uint8_t* m1 = base + idxl1;
+                    const uint32_t l1 = ze_common_len(ip1 + 8, m1 + 8, iend) + 8;
+                    if (l1 > mLength) { ip = ip1; mLength = l1; offset = (uint32_t)(ip - m1); m = m1; }
+                }
+                while (ip > anchor && m > base + LOW && ip[-1] == m[-1]) { ip--; m--; mLength++; }
+                found = 2; break;
+            }
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1;
+        } while (ip1 <= ilimit);
+        if (!found) break;
+        if (found == 2) {
+            off2 = off1; off1 = offset;
+            if (step < 4) hashLong[hl1] = (uint32_t)(ip1 - base);
+            ZE_STORE(ip - anchor, offset + 3, mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            const uint32_t ins = curr + 2;
+            hashLong[ze_hash(base + ins, hl, 8)] = ins;
+            hashLong[ze_hash(ip - 2, hl, 8)] = (uint32_t)(ip - 2 - base);
+            hashSmall[ze_hash(base + ins, hs, mls)] = ins;
+            hashSmall[ze_hash(ip - 1, hs, mls)] = (uint32_t)(ip - 1 - base);
+            while (ip <= ilimit && off2 > 0 && zh_ld32(ip) == zh_ld32(ip - off2)) {
+                const uint32_t r = ze_common_len(ip + 4, ip + 4 - off2, iend) + 4;
+                const uint32_t t = off2; off2 = off1; off1 = t;
+                hashSmall[ze_hash(ip, hs, mls)] = (uint32_t)(ip - base);
+                hashLong[ze_hash(ip, hl, 8)] = (uint32_t)(ip - base);
+                ZE_STORE(0, 1, r);
+                ip += r; anchor = ip;
+            }
+        }
+    }
+#undef ZE_STORE
+    {   const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+
+// ------------------------------------------------------------------------------------------ sequences section
+// ZSTD_selectEncodingType (zstd.c:21252), strategy below "lazy", first block: 0 basic, 1 rle, 2 compressed
+ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog, bool defaultAllowed)
+{
+    if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+    if (defaultAllowed) {
+        const uint32_t dynMin = ((1u << defLog) * 8) >> 3;
+        if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) return 0;
+    }
+    return 2;
+}
+// ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq)
+{
+    const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
+    const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
+    const int16_t* defNorm = which == 0 ? ze_llDef : which == 1 ? ze_ofDef : ze_mlDef;
+    uint32_t* count = L.cnt[which];
+    uint32_t max = 0, most = 0;
+    for (uint32_t s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
+    const bool defaultAllowed = which != 1 || max <= 28;
+    *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed);
+    ZeCTab& t = L.tab[which];
+    if (*mode == 1) { ze_fse_build_rle(t, codes[0]); out[0] = codes[0]; return 1; }
+    if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, L.cellSym, nrm, defMax, defLog); return 0; }
+    const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
+    uint32_t n1 = nbSeq;
+    const uint32_t lastCode = codes[nbSeq - 1];
+    if (count[lastCode] > 1) { count[lastCode]--; n1--; }
+    int16_t norm[53];
+    ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
+    const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
+    ze_fse_build_ctab(t, L.cellSym, norm, max, lg);
+    return h;
+}
+ZH_DEV uint32_t ze_ll_code(uint32_t v) { uint32_t c = 35; while (ze_llBase[c] > v) c--; return c; }
+ZH_DEV uint32_t ze_ml_code(uint32_t ml) { uint32_t c = 52; while (ze_mlBase[c] > ml) c--; return c; }
+
+// ZSTD_compressBlock_internal (zstd.c:27337) for the first-and-only block. All lanes call. Returns body size, 0 = store raw.
+ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws)
+{
+    const uint32_t lane = zh_lane();
+    if (srcSize < 7) return 0;
+    uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
+    uint32_t* hashSmall = (uint32_t*)(ws + ZE_WS_HASHS);
+    uint32_t* seqs = (uint32_t*)(ws + ZE_WS_SEQ);
+    uint8_t* lits = ws + ZE_WS_LIT;
+    uint8_t* codes = ws + ZE_WS_CODES;
+    // fresh tables: the wave zeroes them with coalesced 8-byte stores
+    {
+        uint64_t* a = (uint64_t*)hashLong; const uint32_t na = (1u << cp.hlog) / 2;
+        for (uint32_t i = lane; i < na; i += 64) a[i] = 0;
+        uint64_t* b = (uint64_t*)hashSmall; const uint32_t nb = (1u << cp.clog) / 2;
+        for (uint32_t i = lane; i < nb; i += 64) b[i] = 0;
+    }
+    ze_fence();
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        uint32_t litSize = 0;
+        const uint32_t nbSeq = ze_dfast(seqs, lits, &litSize, src, srcSize, cp, hashLong, hashSmall);
+        L.misc[1] = nbSeq; L.misc[2] = litSize;
+    }
+    ze_fence();
+    zh_sync();
+    const uint32_t nbSeq = zh_first(L.misc[1]), litSize = zh_first(L.misc[2]);
+    zh_sync();
+    uint32_t pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq);
+    // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
+    uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
+    zh_sync();
+    for (uint32_t i = lane; i < 192; i += 64) (&L.cnt[0][0])[i] = 0;
+    zh_sync();
+    for (uint32_t i = lane; i < nbSeq; i += 64) {
+        const uint32_t a = ze_ll_code(seqs[3 * i + 1]), o = (uint32_t)zh_highbit32(seqs[3 * i]), m = ze_ml_code(seqs[3 * i + 2]);
+        llc[i] = (uint8_t)a; ofc[i] = (uint8_t)o; mlc[i] = (uint8_t)m;
+        zh_lds_atomic_inc(&L.cnt[0][a]); zh_lds_atomic_inc(&L.cnt[1][o]); zh_lds_atomic_inc(&L.cnt[2][m]);
+    }
+    ze_fence();
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        uint8_t* op = out + pos;
+        uint32_t result = 1;
+        if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
+        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
+        else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
+        if (nbSeq) {
+            uint8_t* seqHead = op++;
+            int mLL, mOF, mML; uint32_t lastCount = 0, h;
+            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq); if (mML == 2) lastCount = h; op += h;
+            *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
+            // ZSTD_encodeSequences_body (zstd.c:21386): last sequence first; per sequence OF, ML, LL state updates,
+            // then the LL, ML, OF extra bits
+            ZeBits b; ze_bw_init(b, op, cap - (uint32_t)(op - out));
+            uint32_t n = nbSeq - 1;
+            uint32_t sML = ze_fse_first_state(L.tab[2], mlc[n]), sOF = ze_fse_first_state(L.tab[1], ofc[n]), sLL = ze_fse_first_state(L.tab[0], llc[n]);
+            ze_bw_add(b, seqs[3 * n + 1], ze_llBits[llc[n]]);
+            ze_bw_add(b, seqs[3 * n + 2] - 3, ze_mlBits[mlc[n]]);
+            ze_bw_add(b, seqs[3 * n], ofc[n]);
+            while (n-- > 0) {
+                sOF = ze_fse_encode(L.tab[1], b, sOF, ofc[n]);
+                sML = ze_fse_encode(L.tab[2], b, sML, mlc[n]);
+                sLL = ze_fse_encode(L.tab[0], b, sLL, llc[n]);
+                ze_bw_add(b, seqs[3 * n + 1], ze_llBits[llc[n]]);
+                ze_bw_add(b, seqs[3 * n + 2] - 3, ze_mlBits[mlc[n]]);
+                ze_bw_add(b, seqs[3 * n], ofc[n]);
+            }
+            ze_bw_add(b, sML, (uint32_t)L.tab[2].log); ze_bw_add(b, sOF, (uint32_t)L.tab[1].log); ze_bw_add(b, sLL, (uint32_t)L.tab[0].log);
+            const uint32_t bs = ze_bw_close(b);
+            if (bs == 0) result = 0;
+            op += bs;
+            if (lastCount && lastCount + bs < 4) result = 0;
+        }
+        const uint32_t cSize = (uint32_t)(op - out);
+        if (cSize >= srcSize - ((srcSize >> 6) + 2)) result = 0;           // ZSTD_minGain, zstd.c:19831
+        L.misc[3] = result ? cSize : 0;
+    }
+    ze_fence();
+    zh_sync();
+    const uint32_t r = zh_first(L.misc[3]);
+    zh_sync();
+    return r;
+}
+
+// XXH64 of the content for the optional frame checksum (public algorithm; zstd.c:28325 stores its low 32 bits). lane 0.
+ZH_DEVFN uint64_t ze_xxh64(const uint8_t* p, uint32_t len)
+{
+    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+#define ZE_ROTL(x, r) (((x) << (r)) | ((x) >> (64 - (r))))
+#define ZE_ROUND(acc, in) (ZE_ROTL((acc) + (in) * P2, 31) * P1)
+    const uint8_t* const end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+        do {
+            v1 = ZE_ROUND(v1, zh_ld64(p)); v2 = ZE_ROUND(v2, zh_ld64(p + 8)); v3 = ZE_ROUND(v3, zh_ld64(p + 16)); v4 = ZE_ROUND(v4, zh_ld64(p + 24));
+            p += 32;
+        } while (p + 32 <= end);
+        h = ZE_ROTL(v1, 1) + ZE_ROTL(v2, 7) + ZE_ROTL(v3, 12) + ZE_ROTL(v4, 18);
+        h = (h ^ ZE_ROUND(0, v1)) * P1 + P4; h = (h ^ ZE_ROUND(0, v2)) * P1 + P4;
+        h = (h ^ ZE_ROUND(0, v3)) * P1 + P4; h = (h ^ ZE_ROUND(0, v4)) * P1 + P4;
+    } else h = P5;
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= ZE_ROUND(0, zh_ld64(p)); h = ZE_ROTL(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)zh_ld32(p) * P1; h = ZE_ROTL(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (*p++) * P5; h = ZE_ROTL(h, 11) * P1; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+#undef ZE_ROUND
+#undef ZE_ROTL
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------ frame
+// ZSTD_getCParams_internal + ZSTD_adjustCParams_internal (zstd.c:30848, :24426) for a known source size, no dictionary
+ZH_DEV int ze_get_cparams(ZePar& out, int level, uint32_t srcSize)
+{
+    if (level == 0) level = 3;
+    if (level < 1 || level > 4) return ZE_PARAM_UNSUPPORTED;
+    const uint32_t tableID = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
+    int w = ze_rows[tableID][level][0], c = ze_rows[tableID][level][1], h = ze_rows[tableID][level][2];
+    const int srcLog = srcSize < 64 ? 6 : zh_highbit32(srcSize - 1) + 1;
+    if (w > srcLog) w = srcLog;
+    if (h > w + 1) h = w + 1;
+    if (c > w) c = w;
+    if (w < 10) w = 10;
+    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][level][4]; out.strat = ze_rows[tableID][level][6];
+    return 0;
+}
+
+// one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
+ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced)
+{
+    const uint32_t lane = zh_lane();
+    *produced = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
+    const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
+    if (srcSize64 > ZF_BLOCK_MAX) return ZE_PARAM_UNSUPPORTED;           // multi-block frames: next round
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    const uint32_t bound = srcSize + (srcSize >> 8) + (srcSize < (128u << 10) ? (((128u << 10) - srcSize) >> 11) : 0);
+    if (cap64 < bound) return ZE_DST_TOO_SMALL;
+    const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
+    ZePar cp;
+    const int e = ze_get_cparams(cp, a.level, srcSize);
+    if (e) return e;
+    if (cp.strat != 2 || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
+    uint32_t pos = 0;
+    const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
+    const uint32_t windowSize = 1u << cp.wlog;
+    const uint32_t single = contentSize && windowSize >= srcSize;
+    const uint32_t fcsCode = contentSize ? (srcSize >= 256) + (srcSize >= 65536 + 256) : 0;
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        zh_st32(dst, ZF_MAGIC); pos = 4;
+        dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+        if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
+        if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
+        else if (fcsCode == 1) { zh_st16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
+        else { zh_st32(dst + pos, srcSize); pos += 4; }
+        L.misc[4] = pos;
+    }
+    zh_sync();
+    pos = zh_first(L.misc[4]);
+    zh_sync();
+    if (srcSize == 0) {
+        if (zh_opaque(lane) == 0) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; }
+        pos += 3;
+    } else {
+        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws);
+        if (c == 0) {
+            const uint32_t bh = 1 + (0u << 1) + (srcSize << 3);
+            if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
+            for (uint32_t i = lane; i < srcSize; i += 64) dst[pos + 3 + i] = src[i];
+            pos += 3 + srcSize;
+        } else {
+            const uint32_t bh = 1 + (2u << 1) + (c << 3);
+            if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
+            pos += 3 + c;
+        }
+    }
+    if (checksum) {
+        if (zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));
+        pos += 4;
+    }
+    ze_fence();
+    *produced = pos;
+    return ZE_OK;
+}
+
+ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    uint8_t* ws = a.workspace + (size_t)zh_block() * ZHIP_ENC_STRIDE;
+    for (;;) {
+        const uint32_t got = zh_atomic_add(a.counter, lane == 0 ? 1u : 0u);     // branch-free fetch (see decoder note)
+        if (zh_opaque(lane) == 0) L.misc[15] = got;
+        zh_sync();
+        const uint32_t f = zh_first(L.misc[15]);
+        zh_sync();
+        if (f >= a.n) break;
+        uint64_t produced = 0;
+        const int err = ze_frame(a, L, f, ws, &produced);
+        zh_sync();
+        if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
+    }
+}

@@ -55,3 +55,29 @@ struct ZhipDecodeArgs {
     unsigned long long* prof;       // optional: per-phase cycle totals (ZHIP_PROF bring-up / tuning aid), else null
     volatile uint32_t* dbg;         // optional host-visible progress words (ZHIP_DEBUG bring-up aid), else null
 };
+
+// ------------------------------------------------------------------------------------------------ encode side
+// per-resident-wave workspace in HBM (hash tables, sequence store, literal buffer, symbol codes)
+#define ZE_MAX_HLOG 17
+#define ZE_MAX_SEQ 32768
+#define ZE_WS_HASHL 0
+#define ZE_WS_HASHS (ZE_WS_HASHL + (4u << ZE_MAX_HLOG))
+#define ZE_WS_SEQ   (ZE_WS_HASHS + (4u << ZE_MAX_HLOG))
+#define ZE_WS_LIT   (ZE_WS_SEQ + 12u * (ZE_MAX_SEQ + 8))
+#define ZE_WS_CODES (ZE_WS_LIT + ZF_BLOCK_MAX + 256)
+#define ZHIP_ENC_STRIDE (ZE_WS_CODES + 3u * (ZE_MAX_SEQ + 8) + 256)
+
+struct ZhipEncodeArgs {
+    const uint8_t* src;             // all inputs
+    const uint64_t* srcSegs;        // n x (offset, length)
+    uint8_t* dst;
+    const uint64_t* dstSegs;        // n x (offset, capacity >= compressBound(length))
+    uint64_t* outSizes;             // n: frame sizes
+    int32_t* status;                // n: 0 or a zstd error code
+    uint8_t* workspace;             // gridDim.x * ZHIP_ENC_STRIDE
+    uint32_t* counter;              // work-stealing counter, zeroed before launch
+    uint32_t n;
+    int32_t level;
+    uint32_t contentSizeFlag, checksumFlag, dictIDFlag;
+    unsigned long long* prof;
+};

@@ -13,12 +13,18 @@
 #include <vector>
 #include "../../include/zstd_hip.h"
 #include "zhip_decode_kernel.hpp"
+#include "zhip_encode_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
 ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
 {
     __shared__ ZdLDS L;
     zd_kernel_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
+{
+    __shared__ ZeLDS L;
+    ze_kernel_body(a, L);
 }
 ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
 {
@@ -149,6 +155,9 @@ struct zhip_ctx {
     int device = 0;
     int numCU = 0;
     int decBlocksPerCU = 0;
+    int encBlocksPerCU = 0;
+    DevBuf encWorkspace;
+    zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy;
@@ -170,6 +179,9 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 8;
     c->decBlocksPerCU = nb;
+    nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_encode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 4;
+    c->encBlocksPerCU = nb;
     return c;
 }
 static void drain_timer(KTimer& t)
@@ -186,7 +198,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     if (!c) return;
     (void)hipDeviceSynchronize();
     drain_timer(c->timer[0]); drain_timer(c->timer[1]);
-    c->scratch.release(); c->counter.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -235,7 +247,15 @@ extern "C" int zhip_selftest(void)
     for (uint32_t l = 0; l < 64; l++) if (h[l] != l * (l + 1) / 2 + 32 + 63 + 7) { g_lastError = "selftest mismatch"; return 1; }
     return 0;
 }
-extern "C" int zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams*) { g_lastError = "compress path not built yet"; return ZHIP_ERR_UNSUPPORTED; }
+extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
+{
+    if (!c || !p) return ZHIP_ERR_UNSUPPORTED;
+    if (p->dict && p->dictSize) { g_lastError = "dictionary compression is not implemented in the HIP backend yet"; return ZHIP_ERR_UNSUPPORTED; }
+    int level = p->level == 0 ? 3 : p->level;
+    if (level < 1 || level > 4) { g_lastError = "HIP backend compresses with the double-fast strategy only (level 3; level 2/4 for some sizes)"; return ZHIP_ERR_UNSUPPORTED; }
+    c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------ device-resident decode
 extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
@@ -312,10 +332,41 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->timer[0].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[0]); }
     return 0;
 }
-extern "C" int zhip_compress_batch_device(zhip_ctx*, const void*, const zhip_segment*, size_t, void*, const zhip_segment*,
-                                          uint64_t*, int32_t*, void*)
+extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
+                                          void* d_dst, const zhip_segment* d_dstSegs, uint64_t* d_outSizes,
+                                          int32_t* d_status, void* streamv)
 {
-    g_lastError = "compress path not built yet"; return ZHIP_ERR_UNSUPPORTED;
+    if (!c) return ZHIP_ERR_UNSUPPORTED;
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFu) { g_lastError = "too many frames in one launch"; return ZHIP_ERR_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)streamv;
+    size_t maxBlocks = (size_t)c->numCU * (size_t)c->encBlocksPerCU;
+    uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
+    if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+    if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
+    HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 4, stream));
+    ZhipEncodeArgs a; memset(&a, 0, sizeof a);
+    a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
+    a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
+    a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)((uint8_t*)c->counter.p + 8); a.n = (uint32_t)n;
+    a.level = c->cparams.level == 0 ? 3 : c->cparams.level;
+    a.contentSizeFlag = c->cparams.contentSizeFlag != 0; a.checksumFlag = c->cparams.checksumFlag != 0; a.dictIDFlag = c->cparams.dictIDFlag != 0;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, stream));
+    c->timer[1].pending.emplace_back(e0, e1);
+    if (getenv("ZHIP_WATCHDOG")) {
+        for (int it = 0; it < 1200; it++) {
+            if (hipStreamQuery(stream) == hipSuccess) break;
+            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
+            if (it == 1199) { fprintf(stderr, "[zhip] WATCHDOG: encode kernel did not finish in 60 s; aborting process\n"); abort(); }
+        }
+    }
+    if (c->timer[1].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[1]); }
+    return 0;
 }
 
 extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status, size_t n, zhip_error* err)
@@ -425,9 +476,63 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     return ZHIP_ERR_NONE;
 }
 
-extern "C" int zhip_compress_batch(const zhip_cparams*, const zhip_item*, size_t, zhip_outbuf** out, size_t* nOut, zhip_error* err)
+extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, size_t n, zhip_outbuf** out, size_t* nOut, zhip_error* err)
 {
+    if (err) memset(err, 0, sizeof *err);
     *out = nullptr; *nOut = 0;
-    g_lastError = "compress path not built yet";
-    return set_err(err, ZHIP_ERR_UNSUPPORTED, 0, 0);
+    zhip_ctx* c = tls_ctx();
+    if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    zhip_cparams defaults = {3, 1, 0, 1, nullptr, 0};
+    int r = zhip_ctx_set_cparams(c, params ? params : &defaults);
+    if (r) return set_err(err, r, 0, 0);
+    // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are
+    // compacted into one payload afterwards
+    std::vector<zhip_segment> segs(2 * n);
+    uint64_t srcTotal = 0, dstTotal = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (items[i].srcSize > ZF_BLOCK_MAX) {
+            g_lastError = "inputs larger than 128 KiB (multi-block frames) are not implemented in the HIP backend yet";
+            return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
+        }
+        segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;
+        uint64_t b = zhip_compress_bound(items[i].srcSize);
+        b = (b + 15) & ~(uint64_t)15;
+        segs[n + i].offset = dstTotal; segs[n + i].length = b; dstTotal += b;
+    }
+    if (ensure_pinned(c, (srcTotal > dstTotal ? srcTotal : dstTotal) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
+    if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
+        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    if (srcTotal && hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    uint64_t* dSizes = (uint64_t*)c->hStatus.p;
+    int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
+    r = zhip_compress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
+                                   (const zhip_segment*)c->hSegs.p + n, dSizes, dStatus, nullptr);
+    if (r) return set_err(err, r, 0, 0);
+    std::vector<uint64_t> sizes(n); std::vector<int32_t> status(n);
+    if (hipMemcpy(sizes.data(), dSizes, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(status.data(), dStatus, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        hip_fail(hipGetLastError(), "encode kernel / status copy"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    }
+    uint64_t outTotal = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (status[i]) return set_err(err, ZHIP_ERR_ZSTD, i, status[i]);
+        outTotal += sizes[i];
+    }
+    if (dstTotal && hipMemcpy(c->pinned, c->hDst.p, dstTotal, hipMemcpyDeviceToHost) != hipSuccess) {
+        hip_fail(hipGetLastError(), "D2H"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    }
+    zhip_outbuf* ob = (zhip_outbuf*)calloc(1, sizeof(zhip_outbuf));
+    uint8_t* payload = (uint8_t*)malloc(outTotal ? outTotal : 1);
+    zhip_segment* osegs = (zhip_segment*)malloc((n ? n : 1) * sizeof(zhip_segment));
+    if (!ob || !payload || !osegs) { free(ob); free(payload); free(osegs); return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0); }
+    uint64_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        memcpy(payload + o, (const uint8_t*)c->pinned + segs[n + i].offset, sizes[i]);
+        osegs[i].offset = o; osegs[i].length = sizes[i]; o += sizes[i];
+    }
+    ob->data = payload; ob->dataSize = outTotal; ob->segs = osegs; ob->nSegs = n;
+    *out = ob; *nOut = 1;
+    return ZHIP_ERR_NONE;
 }

@@ -3,6 +3,7 @@
 #define ZHIP_EMU 1
 extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; long zd_stat[16]; }
 #include "../../python-zstandard_amd/csrc/zhip_decode_kernel.hpp"
+#include "../../python-zstandard_amd/csrc/zhip_encode_kernel.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -37,3 +38,21 @@ extern "C" int emu_parse_dict(const uint8_t* dict, uint32_t size, ZhipDictEntrop
     return de->status;
 }
 extern "C" uint32_t emu_dict_entropy_size(void) { return (uint32_t)sizeof(ZhipDictEntropy); }
+
+static ZeLDS g_elds;
+struct EncLaunch { const ZhipEncodeArgs* a; };
+static void enc_lane(void* p) { ze_kernel_body(*((EncLaunch*)p)->a, g_elds); }
+extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
+                                  uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks)
+{
+    ZhipEncodeArgs a; memset(&a, 0, sizeof(a));
+    uint32_t counter = 0;
+    a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
+    a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
+    a.counter = &counter; a.n = n; a.level = level;
+    a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
+    EncLaunch l = { &a };
+    zhemu::run_grid(nBlocks, enc_lane, &l);
+    free(a.workspace);
+    return 0;
+}
