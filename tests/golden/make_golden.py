@@ -1,0 +1,80 @@
+"""Generates tests/golden/golden.json + frames_*.bin from the REFERENCE libzstd 1.5.7 (oracle/_ref/libzstd_ref.so, built
+from /root/reference/zstd/zstd.c). Run in the authoring container only:  python tests/golden/make_golden.py
+
+Inputs are deterministic (tests/corpus.py seeds or literals below), so only the reference's OUTPUT is stored:
+small frames verbatim (hex), large ones as sha256 + size, plus a handful of full frames for decoder-only tests.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np
+
+from tests.corpus import Corpus
+from tests import reflib
+
+
+def inputs(corpus):
+    rng = np.random.default_rng(20260924)
+    cases = {
+        "empty": b"", "foo": b"foo", "foo4": b"foo" * 4, "bar6": b"bar" * 6, "x6": b"x" * 6, "x7": b"x" * 7, "x8": b"x" * 8,
+        "a1000": b"a" * 1000, "a131072": b"a" * 131072, "bytes256x40": bytes(range(256)) * 40,
+        "hello500": b"hello world, hello world, hello there world! " * 500,
+        "random128k": rng.bytes(1 << 17), "random300": rng.bytes(300),
+        "quat70000": bytes(rng.integers(0, 4, 70000, dtype=np.uint8)),
+    }
+    for i in range(16):
+        cases["corpus%d" % i] = corpus.frame_bytes(i)
+    for i in range(16):
+        cases["corpus%d_cut" % (100 + i)] = corpus.frame_bytes(100 + i)[: 997 * (i + 1)]
+    return cases
+
+
+def main():
+    ref = reflib.RefZstd()
+    corpus = Corpus()
+    out = {"libzstd": "1.5.7", "source": "/root/reference/zstd/zstd.c via oracle/Makefile", "level": 3, "cases": []}
+    blob = bytearray()
+    for name, data in inputs(corpus).items():
+        entry = {"name": name, "size": len(data), "input_sha256": hashlib.sha256(data).hexdigest(), "frames": {}}
+        for tag, flags in (("default", reflib.DEFAULT_FLAGS), ("checksum", reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM),
+                           ("nosize", reflib.F_DICTID)):
+            frame = ref.compress(data, level=3, flags=flags)
+            rec = {"size": len(frame), "sha256": hashlib.sha256(frame).hexdigest()}
+            if len(frame) <= 64:
+                rec["hex"] = frame.hex()
+            if tag == "default" and (name in ("corpus0", "corpus1", "corpus2", "corpus3", "corpus4", "corpus5", "hello500", "quat70000")
+                                     or name.endswith("_cut")):
+                rec["blob_offset"] = len(blob)
+                blob += frame
+            entry["frames"][tag] = rec
+        out["cases"].append(entry)
+    # a level-19 multi-block frame and a dictionary frame for decoder coverage
+    big = b"".join(corpus.frame_bytes(300 + i) for i in range(3))
+    f19 = ref.compress(big, level=19)
+    out["multiblock_level19"] = {"input": "corpus frames 300..302 concatenated", "size": len(big), "blob_offset": len(blob),
+                                 "frame_size": len(f19), "input_sha256": hashlib.sha256(big).hexdigest()}
+    blob += f19
+    samples = [corpus.frame_bytes(40 + i)[: 2000 + 37 * i] for i in range(200)]
+    d = ref.train_dictionary(16384, samples)
+    dict_frames = [ref.compress(s, dict_data=d) for s in samples[:8]]
+    out["dictionary"] = {"dict_blob_offset": len(blob), "dict_size": len(d), "samples": "corpus frames 40..47 cut to 2000+37*i",
+                         "frames": []}
+    blob += d
+    for s, fr in zip(samples[:8], dict_frames):
+        out["dictionary"]["frames"].append({"blob_offset": len(blob), "size": len(fr), "input_sha256": hashlib.sha256(s).hexdigest(),
+                                            "input_size": len(s)})
+        blob += fr
+    with open(os.path.join(HERE, "golden.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    with open(os.path.join(HERE, "frames.bin"), "wb") as fh:
+        fh.write(blob)
+    print("cases", len(out["cases"]), "blob bytes", len(blob))
+
+
+if __name__ == "__main__":
+    main()

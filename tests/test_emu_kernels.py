@@ -1,0 +1,45 @@
+"""Kernel LOGIC on the host: the product kernel sources compiled for the wave emulator (tests/emu) against the oracle.
+Small inputs only -- the emulator runs each of the 64 lanes as a fiber. The real parity tests are the -m gpu ones."""
+import pytest
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests import emulib
+    emulib.build()
+    return emulib.Emu()
+
+
+def test_emulated_encoder_is_bit_exact(emu, oracle, corpus):
+    raws = [b"", b"foo", b"x" * 7, b"a" * 1000, b"hello world, hello there world! " * 40, bytes(range(256)) * 3]
+    raws += [corpus.frame_bytes(i)[: 9000 + 1111 * i] for i in range(6)]
+    for flags in (5, 7, 4):
+        outs, st = emu.compress_batch(raws, level=3, flags=flags, n_blocks=2)
+        assert not any(st)
+        for r, o in zip(raws, outs):
+            assert o == oracle.compress(r, level=3, flags=flags)
+
+
+def test_emulated_decoder_matches_oracle(emu, oracle, corpus):
+    raws = [b"foo", b"a" * 5000, b"abcabcabcabcabcabcabcabcabc" * 30] + [corpus.frame_bytes(i)[: 20000 + 999 * i] for i in range(6)]
+    frames = [oracle.compress(r) for r in raws]
+    outs, st = emu.decompress_batch(frames, [len(r) for r in raws], n_blocks=2)
+    assert not any(st)
+    assert outs == raws
+    # a truncated and a bit-flipped frame fail cleanly, the good neighbour still decodes
+    bad = [frames[4][: len(frames[4]) // 2], frames[5][:30] + bytes([frames[5][30] ^ 0x40]) + frames[5][31:], frames[3]]
+    outs, st = emu.decompress_batch(bad, [len(raws[4]), len(raws[5]), len(raws[3])], n_blocks=1)
+    assert st[0] != 0 and st[2] == 0 and outs[2] == raws[3]
+
+
+def test_emulated_decoder_on_golden_libzstd_frames(emu):
+    import hashlib
+    from tests.test_oracle_vs_golden import GOLD, BLOB
+    frames, sizes, shas = [], [], []
+    for case in GOLD["cases"]:
+        rec = case["frames"]["default"]
+        if "blob_offset" in rec and case["size"] <= 20000:
+            frames.append(BLOB[rec["blob_offset"]: rec["blob_offset"] + rec["size"]]); sizes.append(case["size"]); shas.append(case["input_sha256"])
+    outs, st = emu.decompress_batch(frames, sizes, n_blocks=2)
+    assert not any(st) and len(frames) >= 8
+    assert [hashlib.sha256(o).hexdigest() for o in outs] == shas

@@ -1,0 +1,135 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/zstd_hip.h declares,
+the host-side mirror validates arguments like the reference (no compute calls here: there is no GPU and no fallback)."""
+import os
+import re
+import struct
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ss = struct.Struct("=QQ")
+
+
+@pytest.fixture(scope="module")
+def zstd():
+    import zstandard_amd
+    return zstandard_amd
+
+
+def test_library_exports_every_declared_symbol(zstd):
+    header = open(os.path.join(ROOT, "include", "zstd_hip.h")).read()
+    declared = set(re.findall(r"\b(zhip_[a-z0-9_]+)\s*\(", header))
+    lib = zstd._lib.lib()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libzstd_hip.so does not export %s" % name
+    assert set(zstd._lib.EXPORTED_SYMBOLS) <= declared
+    assert lib.zhip_abi_version() == 1
+    assert lib.zhip_compress_bound(131072) == 131072 + 512
+    assert lib.zhip_compress_bound(0) == 64
+
+
+def test_frame_inspection_entry_points(zstd):
+    import ctypes as C
+    lib = zstd._lib.lib()
+    f = bytes.fromhex("28b52ffd2000010000")
+    buf = C.create_string_buffer(f, len(f))
+    assert lib.zhip_frame_content_size(C.cast(buf, C.c_void_p), len(f)) == 0
+    assert lib.zhip_find_frame_compressed_size(C.cast(buf, C.c_void_p), len(f)) == len(f)
+    bad = C.create_string_buffer(b"foobarbaz", 9)
+    assert lib.zhip_frame_content_size(C.cast(bad, C.c_void_p), 9) == zstd._lib.CONTENTSIZE_ERROR
+    assert lib.zhip_error_name(20) == b"Data corruption detected"
+    assert lib.zhip_error_name(70) == b"Destination buffer is too small"
+
+
+def test_backend_surface(zstd):
+    assert zstd.backend_features >= {"buffer_types", "multi_compress_to_buffer", "multi_decompress_to_buffer"}
+    for name in ("ZstdCompressor", "ZstdDecompressor", "BufferWithSegments", "BufferWithSegmentsCollection", "BufferSegment",
+                 "BufferSegments", "ZstdCompressionDict", "ZstdError"):
+        assert hasattr(zstd, name)
+
+
+# ---- mirrors of the reference's tests/test_buffer_util.py
+def test_buffer_with_segments(zstd):
+    with pytest.raises(TypeError):
+        zstd.BufferWithSegments()
+    with pytest.raises(TypeError):
+        zstd.BufferWithSegments(b"foo")
+    with pytest.raises(ValueError, match="segments array size is not a multiple of 16"):
+        zstd.BufferWithSegments(b"foo", b"\x00\x00")
+    with pytest.raises(ValueError, match="offset within segments array references memory"):
+        zstd.BufferWithSegments(b"foo", ss.pack(0, 4))
+    b = zstd.BufferWithSegments(b"foo", ss.pack(0, 3))
+    with pytest.raises(IndexError, match="offset must be non-negative"):
+        b[-10]
+    with pytest.raises(IndexError, match="offset must be less than 1"):
+        b[1]
+    assert len(b) == 1 and b.size == 3 and b.tobytes() == b"foo"
+    assert len(b[0]) == 3 and b[0].offset == 0 and b[0].tobytes() == b"foo"
+    b = zstd.BufferWithSegments(b"foofooxfooxy", b"".join([ss.pack(0, 3), ss.pack(3, 4), ss.pack(7, 5)]))
+    assert len(b) == 3 and b.size == 12
+    assert [b[i].tobytes() for i in range(3)] == [b"foo", b"foox", b"fooxy"]
+    assert b.segments().tobytes() == b"".join([ss.pack(0, 3), ss.pack(3, 4), ss.pack(7, 5)])
+
+
+def test_buffer_with_segments_collection(zstd):
+    with pytest.raises(ValueError, match="must pass at least 1 argument"):
+        zstd.BufferWithSegmentsCollection()
+    with pytest.raises(TypeError, match="arguments must be BufferWithSegments"):
+        zstd.BufferWithSegmentsCollection(None)
+    with pytest.raises(ValueError, match="ZstdBufferWithSegments cannot be empty"):
+        zstd.BufferWithSegmentsCollection(zstd.BufferWithSegments(b"", b""))
+    b1 = zstd.BufferWithSegments(b"foo", ss.pack(0, 3))
+    b2 = zstd.BufferWithSegments(b"barbaz", b"".join([ss.pack(0, 3), ss.pack(3, 3)]))
+    c = zstd.BufferWithSegmentsCollection(b1, b2)
+    assert len(c) == 3 and c.size() == 9
+    with pytest.raises(IndexError, match="offset must be less than 3"):
+        c[3]
+    assert [c[i].tobytes() for i in range(3)] == [b"foo", b"bar", b"baz"]
+
+
+# ---- argument validation of the hot-path entry points (reference: compressor.c:88-246, 1340-1503; decompressor.c:1459-1710)
+def test_compressor_argument_validation(zstd):
+    with pytest.raises(ValueError, match="level must be less than 23"):
+        zstd.ZstdCompressor(level=23)
+    with pytest.raises(TypeError):
+        zstd.ZstdCompressor(dict_data=b"raw bytes")
+    c = zstd.ZstdCompressor()
+    with pytest.raises(TypeError, match="argument must be list of BufferWithSegments"):
+        c.multi_compress_to_buffer(True)
+    with pytest.raises(ValueError, match="no source elements found"):
+        c.multi_compress_to_buffer([])
+    with pytest.raises(ValueError, match="source elements are empty"):
+        c.multi_compress_to_buffer([b"", b""])
+    with pytest.raises(TypeError, match="item 1 not a bytes like object"):
+        c.multi_compress_to_buffer([b"ok", 7])
+
+
+def test_decompressor_argument_validation(zstd):
+    d = zstd.ZstdDecompressor()
+    with pytest.raises(TypeError):
+        d.multi_decompress_to_buffer(True)
+    with pytest.raises(TypeError):
+        d.multi_decompress_to_buffer((1, 2))
+    with pytest.raises(TypeError, match="item 0 not a bytes like object"):
+        d.multi_decompress_to_buffer(["foo"])
+    with pytest.raises(ValueError, match="decompressed_sizes size mismatch; expected 16, got 8"):
+        d.multi_decompress_to_buffer([b"a", b"b"], decompressed_sizes=struct.pack("=Q", 1))
+    with pytest.raises(zstd.ZstdError, match="read_across_frames=True is not yet implemented"):
+        d.decompress(b"whatever", read_across_frames=True)
+    with pytest.raises(zstd.ZstdError, match="error determining content size from frame header"):
+        d.decompress(b"")
+    assert zstd.ZstdCompressionDict(b"\x37\xa4\x30\xec" + struct.pack("<I", 1234) + b"x" * 100).dict_id() == 1234
+    assert zstd.ZstdCompressionDict(b"plain content").dict_id() == 0
+
+
+def test_partition_by_bytes_matches_reference_rule():
+    import importlib
+    par = importlib.import_module("python-zstandard_amd.parallel")
+    sizes = [10] * 10
+    assert par.partition_by_bytes(sizes, 2) == [(0, 5), (5, 10)]
+    assert par.partition_by_bytes(sizes, 3) == [(0, 4), (4, 8), (8, 10)]          # cut once a worker reaches total/workers
+    assert par.partition_by_bytes([100, 1, 1, 1], 2) == [(0, 1), (1, 4)]
+    assert par.partition_by_bytes([5], 4) == [(0, 1)]
+    bounds = par.partition_by_bytes(list(range(1, 100)), 8)
+    assert bounds[0][0] == 0 and bounds[-1][1] == 99 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
