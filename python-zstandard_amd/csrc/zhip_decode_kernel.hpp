@@ -992,10 +992,12 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
         const uint32_t got = zh_atomic_add(a.counter, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
-        const uint32_t f = zh_first(L.misc[7]);
+        uint32_t f = zh_first(L.misc[7]);
         zh_sync();
         ZD_DBG(2, 0x200 + f);
-        if (f >= a.n) break;
+        const uint32_t limit = a.listCount ? *a.listCount : a.n;
+        if (f >= limit) break;
+        if (a.frameList) f = a.frameList[f];
         uint64_t produced = 0;
         ZdProf P; P.on = a.prof != nullptr;
         if (P.on) { for (int i = 0; i < ZP_N; i++) P.acc[i] = 0; P.t0 = zd_clock(); }

@@ -52,6 +52,8 @@ struct ZhipDecodeArgs {
     uint32_t dictContentSize;
     const ZhipDictEntropy* dictEntropy; // null when no dictionary or raw-content dictionary
     uint64_t maxWindowSize;
+    const uint32_t* frameList;      // optional indirection: process frameList[0 .. *listCount) instead of 0 .. n (pipeline fallback)
+    const uint32_t* listCount;
     unsigned long long* prof;       // optional: per-phase cycle totals (ZHIP_PROF bring-up / tuning aid), else null
     volatile uint32_t* dbg;         // optional host-visible progress words (ZHIP_DEBUG bring-up aid), else null
 };
@@ -80,4 +82,39 @@ struct ZhipEncodeArgs {
     int32_t level;
     uint32_t contentSizeFlag, checksumFlag, dictIDFlag;
     unsigned long long* prof;
+};
+
+// ------------------------------------------------------------------------------------------------ phase-split decode pipeline
+// per-frame record handed from kernel to kernel (HBM)
+struct ZdMeta {
+    int32_t  status;        // 0 or a zstd error code
+    uint32_t path;          // 0: finished in K1 (raw / RLE / empty, or failed), 1: fast path (K2 + K3), 2: generic fused kernel
+    uint32_t seqOff;        // sequences section [seqOff, seqEnd) inside the frame
+    uint32_t seqEnd;
+    uint32_t litSize;
+    uint32_t litMode;       // 0: literals sit in the frame at litOff, 1: in this frame's literal slot, 2: RLE (litOff = byte)
+    uint32_t litOff;
+    uint32_t nbSeq;         // filled by K2
+    uint32_t blockMax;
+    uint32_t fcsLo, fcsHi;  // frame content size (0xFFFFFFFF/0xFFFFFFFF when absent)
+    uint32_t produced;
+    uint32_t pad[4];
+};
+#define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
+#define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)
+#define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
+#define ZP_K2_LANES 16                                  // frames decoded per wave in K2 (one lane each)
+#define ZP_K2_LANE_LDS 2820                             // bytes of LDS per K2 lane (odd dword stride: no bank aliasing)
+
+struct ZhipPipeArgs {
+    const uint8_t* src; const uint64_t* srcSegs;
+    uint8_t* dst; const uint64_t* dstSegs;
+    uint64_t* outSizes; int32_t* status;
+    ZdMeta* meta;               // chunk-local
+    uint8_t* litArena;          // chunk x ZP_LIT_STRIDE
+    uint64_t* seqArena;         // chunk x ZP_SEQ_CAP
+    uint32_t* counters;         // [0] K1 work, [1] K2 work, [2] K3 work, [3] fallback list length
+    uint32_t* fallbackList;     // frame indices for the generic kernel
+    uint32_t first, count;      // frames [first, first + count) of the batch are this chunk
+    uint64_t maxWindowSize;
 };

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 #include "../../include/zstd_hip.h"
-#include "zhip_decode_kernel.hpp"
+#include "zhip_decode_pipeline.hpp"
 #include "zhip_encode_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -20,6 +20,23 @@ ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs
 {
     __shared__ ZdLDS L;
     zd_kernel_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZdLDS L;
+    zp_lit_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ZP_K2_LANES * ZP_K2_LANE_LDS];
+    __shared__ uint32_t llBase[36], mlBase[53];
+    __shared__ uint8_t llBits[36], mlBits[56];
+    zp_seq_body(a, lds, llBase, mlBase, llBits, mlBits);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_exec_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpExecLDS L;
+    zp_exec_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
@@ -149,13 +166,19 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-struct KTimer { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; double totalMs = 0; uint64_t launches = 0; };
+struct KTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
+    double totalMs = 0; uint64_t launches = 0;
+};
 
 struct zhip_ctx {
     int device = 0;
     int numCU = 0;
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
+    int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
+    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback;
     DevBuf encWorkspace;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
@@ -166,7 +189,7 @@ struct zhip_ctx {
     // host-API staging
     DevBuf hSrc, hDst, hSegs, hStatus;
     void* pinned = nullptr; size_t pinnedCap = 0;
-    KTimer timer[2];
+    KTimer timer[5];     // 0 fused decode, 1 encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution
 };
 
 extern "C" zhip_ctx* zhip_ctx_create(void)
@@ -182,10 +205,25 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_encode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 4;
     c->encBlocksPerCU = nb;
+    nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_lit_kernel, 64, 0) != hipSuccess || nb < 1) nb = 8;
+    c->k1PerCU = nb;
+    nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_seq_kernel, 64, 0) != hipSuccess || nb < 1) nb = 3;
+    c->k2PerCU = nb;
+    nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_exec_kernel, 64, 0) != hipSuccess || nb < 1) nb = 16;
+    c->k3PerCU = nb;
     return c;
+}
+static void drain_shared(KTimer& t)
+{
+    for (auto& pr : t.shared) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.totalMs += ms; t.launches++; }
+    }
+    t.shared.clear();
 }
 static void drain_timer(KTimer& t)
 {
+    drain_shared(t);
     for (auto& pr : t.pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.totalMs += ms; t.launches++; }
@@ -197,17 +235,25 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    drain_timer(c->timer[0]); drain_timer(c->timer[1]);
+    for (int i = 0; i < 5; i++) drain_shared(c->timer[i]);
+    for (int i = 0; i < 5; i++) drain_timer(c->timer[i]);
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
-extern "C" const char* zhip_kernel_name(int direction) { return direction == 0 ? "zhip_decode_frames_kernel" : "zhip_encode_frames_kernel"; }
+extern "C" const char* zhip_kernel_name(int k)
+{
+    static const char* names[5] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
+                                   "zhip_decode_seq_kernel", "zhip_decode_exec_kernel"};
+    return k >= 0 && k < 5 ? names[k] : "";
+}
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
 {
-    if (!c || direction < 0 || direction > 1) return ZHIP_ERR_UNSUPPORTED;
+    if (!c || direction < 0 || direction > 4) return ZHIP_ERR_UNSUPPORTED;
     HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 5; i++) drain_shared(c->timer[i]);
     KTimer& t = c->timer[direction];
     drain_timer(t);
     if (avgMs) *avgMs = t.launches ? t.totalMs / (double)t.launches : 0.0;
@@ -271,11 +317,54 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->scratch.reserve((size_t)grid * ZHIP_LIT_STRIDE)) return ZHIP_ERR_HIP;
     if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
     HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
+    const uint32_t* d_fallbackList = nullptr; const uint32_t* d_fallbackCount = nullptr;
+    const bool usePipeline = c->dictSize == 0 && getenv("ZHIP_NO_PIPELINE") == nullptr;
+    if (usePipeline) {
+        // phase-split fast path for single-block, dictionary-less frames (zhip_decode_pipeline.hpp); everything it declines
+        // lands in the fallback list consumed by the generic kernel below.
+        const size_t chunkMax = 16384;
+        const size_t chunk = n < chunkMax ? n : chunkMax;
+        if (c->pipeMeta.reserve(chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(chunk * ZP_LIT_STRIDE) || c->pipeSeq.reserve(chunk * ZP_SEQ_STRIDE) ||
+            c->pipeCounters.reserve(64) || c->pipeFallback.reserve(n * 4 + 16)) return ZHIP_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 16, stream));
+        ZhipPipeArgs pa; memset(&pa, 0, sizeof pa);
+        pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
+        pa.outSizes = d_outSizes; pa.status = d_status; pa.meta = (ZdMeta*)c->pipeMeta.p; pa.litArena = (uint8_t*)c->pipeLit.p;
+        pa.seqArena = (uint64_t*)c->pipeSeq.p; pa.counters = (uint32_t*)c->pipeCounters.p; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
+        pa.maxWindowSize = c->maxWindowSize;
+        for (size_t first = 0; first < n; first += chunk) {
+            const size_t cnt = n - first < chunk ? n - first : chunk;
+            pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
+            if (first) HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 12, stream));
+            const size_t g1m = (size_t)c->numCU * c->k1PerCU, g2m = (size_t)c->numCU * c->k2PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
+            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;
+            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
+            hipEvent_t ev[4];
+            for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));
+            HIP_TRY(hipEventRecord(ev[0], stream));
+            hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, stream, pa);
+            HIP_TRY(hipEventRecord(ev[1], stream));
+            hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, stream, pa);
+            HIP_TRY(hipEventRecord(ev[2], stream));
+            hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, stream, pa);
+            HIP_TRY(hipEventRecord(ev[3], stream));
+            HIP_TRY(hipGetLastError());
+            // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
+            // ev[0..1], K3's owns ev[2..3]; K2's pair (ev[1], ev[2]) is borrowed and always drained before any destroy.
+            c->timer[2].pending.emplace_back(ev[0], ev[1]);
+            c->timer[3].shared.emplace_back(ev[1], ev[2]);
+            c->timer[4].pending.emplace_back(ev[2], ev[3]);
+        }
+        d_fallbackList = (const uint32_t*)c->pipeFallback.p; d_fallbackCount = (const uint32_t*)c->pipeCounters.p + 3;
+        // the generic kernel only sees the (usually empty) fallback list: a small grid is enough
+        if (grid > 1024) grid = 1024;
+    }
     ZhipDecodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
     a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
     a.scratch = (uint8_t*)c->scratch.p; a.counter = (uint32_t*)c->counter.p; a.n = (uint32_t)n;
     a.maxWindowSize = c->maxWindowSize;
+    a.frameList = d_fallbackList; a.listCount = d_fallbackCount;
     if (c->dictSize) {
         a.dictID = c->dictID;
         a.dictContent = (const uint8_t*)c->dictBlob.p + c->dictContentOffset;
@@ -329,7 +418,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         fprintf(stderr, "[zhip-prof] grid=%u (CUs %d x %d blocks) frames=%u wave-cycles total=%.3e (%.0f per frame)\n", grid, c->numCU, c->decBlocksPerCU, a.n, (double)tot, (double)tot / a.n);
         for (int i = 0; i < ZP_N; i++) fprintf(stderr, "[zhip-prof]   %-22s %6.2f%%  %10.0f cyc/frame\n", names[i], 100.0 * h[i] / (tot ? tot : 1), (double)h[i] / a.n);
     }
-    if (c->timer[0].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[0]); }
+    if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < 5; i++) drain_shared(c->timer[i]); for (int i = 0; i < 5; i++) drain_timer(c->timer[i]); }
     return 0;
 }
 extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,

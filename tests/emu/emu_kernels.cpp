@@ -2,7 +2,7 @@
 // Test infrastructure only: lets tests/test_emu_*.py exercise kernel logic without a GPU. Never shipped.
 #define ZHIP_EMU 1
 extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; long zd_stat[16]; }
-#include "../../python-zstandard_amd/csrc/zhip_decode_kernel.hpp"
+#include "../../python-zstandard_amd/csrc/zhip_decode_pipeline.hpp"
 #include "../../python-zstandard_amd/csrc/zhip_encode_kernel.hpp"
 #include <stdlib.h>
 #include <string.h>
@@ -55,4 +55,43 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
     zhemu::run_grid(nBlocks, enc_lane, &l);
     free(a.workspace);
     return 0;
+}
+
+// ---- phase-split decode pipeline under emulation
+static ZpExecLDS g_xlds;
+static uint8_t g_k2lds[ZP_K2_LANES * ZP_K2_LANE_LDS + 64];
+static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBits[56];
+static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
+static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_k2lds, g_llBase, g_mlBase, g_llBits, g_mlBits); }
+static void k3_lane(void* p) { zp_exec_body(*(const ZhipPipeArgs*)p, g_xlds); }
+extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst,
+                                       const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status, uint32_t nBlocks, uint32_t chunk)
+{
+    ZhipPipeArgs a; memset(&a, 0, sizeof(a));
+    uint32_t counters[4] = {0, 0, 0, 0};
+    if (chunk == 0 || chunk > n) chunk = n ? n : 1;
+    a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
+    a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
+    a.litArena = (uint8_t*)malloc((size_t)chunk * ZP_LIT_STRIDE);
+    a.seqArena = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE);
+    a.counters = counters; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
+    a.maxWindowSize = (1ull << 27) + 1;
+    for (uint32_t first = 0; first < n; first += chunk) {
+        a.first = first; a.count = n - first < chunk ? n - first : chunk;
+        counters[0] = counters[1] = counters[2] = 0;
+        zhemu::run_grid(nBlocks, k1_lane, &a);
+        zhemu::run_grid(nBlocks, k2_lane, &a);
+        zhemu::run_grid(nBlocks, k3_lane, &a);
+    }
+    // generic kernel for everything the fast path declined
+    ZhipDecodeArgs g; memset(&g, 0, sizeof(g));
+    uint32_t counter = 0;
+    g.src = src; g.srcSegs = srcSegs; g.dst = dst; g.dstSegs = dstSegs; g.outSizes = outSizes; g.status = status;
+    g.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
+    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.frameList = a.fallbackList; g.listCount = &counters[3];
+    DecLaunch l = { &g };
+    zhemu::run_grid(nBlocks, dec_lane, &l);
+    int nfb = (int)counters[3];
+    free(g.scratch); free(a.meta); free(a.litArena); free(a.seqArena); free(a.fallbackList);
+    return nfb;
 }

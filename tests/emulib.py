@@ -82,3 +82,28 @@ def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2):
 
 
 Emu.compress_batch = _emu_compress_batch
+
+
+def _emu_decompress_pipeline(self, frames, sizes, n_blocks=2, chunk=0):
+    n = len(frames)
+    src = np.frombuffer(b"".join(frames) + b"\0" * 16, dtype=np.uint8).copy()
+    src_segs = np.zeros((n, 2), dtype=np.uint64)
+    o = 0
+    for i, f in enumerate(frames):
+        src_segs[i] = (o, len(f)); o += len(f)
+    dst_segs = np.zeros((n, 2), dtype=np.uint64)
+    o = 0
+    for i, s in enumerate(sizes):
+        dst_segs[i] = (o, s); o += s
+    dst = np.zeros(max(o, 1) + 16, dtype=np.uint8)
+    out_sizes = np.zeros(n, dtype=np.uint64)
+    status = np.full(n, -1, dtype=np.int32)
+    nfb = self.lib.emu_decompress_pipeline(src.ctypes.data_as(C.c_void_p), src_segs.ctypes.data_as(C.c_void_p), C.c_uint32(n),
+                                           dst.ctypes.data_as(C.c_void_p), dst_segs.ctypes.data_as(C.c_void_p),
+                                           out_sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+                                           C.c_uint32(n_blocks), C.c_uint32(chunk))
+    outs = [dst[int(dst_segs[i][0]):int(dst_segs[i][0]) + int(out_sizes[i])].tobytes() for i in range(n)]
+    return outs, status.tolist(), nfb
+
+
+Emu.decompress_pipeline = _emu_decompress_pipeline
