@@ -267,6 +267,49 @@ ZH_DEV uint32_t zd_bits_peek(const ZdBits& b, uint32_t n)   // 1 <= n <= 32
 }
 ZH_DEV bool zd_bits_done(const ZdBits& b) { return b.ptr == b.start && b.used == 64; }
 
+// ------------------------------------------------------------------------------------------ prefetching backward reader
+// Same stream convention as ZdBits, but the NEXT 8 bytes below the window are always already in flight (`d`), so the
+// per-symbol / per-sequence critical path never waits for global memory: renormalisation is a funnel shift of (c, d)
+// followed by issuing the load that will only be needed one renormalisation later.
+struct ZdPBits { const uint8_t* start; const uint8_t* end; const uint8_t* ptr; uint64_t c, d; uint32_t used; };
+ZH_DEV uint64_t zd_pb_below(const ZdPBits& b)           // bytes at [ptr-8, ptr), zeros below the stream start
+{
+    const uint32_t k = (uint32_t)(b.ptr - b.start);
+    if (k >= 8) return zh_ld64(b.ptr - 8);
+    if (k == 0) return 0;
+    return zd_ld64_bounded(b.start, b.end) << (8 * (8 - k));
+}
+ZH_DEV bool zd_pb_init(ZdPBits& b, const uint8_t* src, uint32_t size)
+{
+    b.start = src; b.end = src + size; b.ptr = src; b.c = 0; b.d = 0; b.used = 64;
+    if (size == 0) return false;
+    const uint32_t last = src[size - 1];
+    if (last == 0) return false;
+    const uint32_t pad = 8 - (uint32_t)zh_highbit32(last);
+    if (size >= 8) { b.ptr = src + size - 8; b.c = zh_ld64(b.ptr); b.used = pad; }
+    else {
+        uint64_t c = 0;
+        for (uint32_t i = 0; i < size; i++) c |= (uint64_t)src[i] << (8 * i);
+        b.c = c; b.used = pad + (8 - size) * 8;
+    }
+    b.d = zd_pb_below(b);
+    return true;
+}
+ZH_DEV void zd_pb_norm(ZdPBits& b)
+{
+    uint32_t nb = b.used >> 3;
+    const uint32_t room = (uint32_t)(b.ptr - b.start);
+    if (nb > room) nb = room;
+    if (nb > 8) nb = 8;
+    if (nb) {
+        b.c = nb == 8 ? b.d : ((b.c << (8 * nb)) | (b.d >> (64 - 8 * nb)));
+        b.ptr -= nb; b.used -= nb * 8;
+        b.d = zd_pb_below(b);
+    }
+}
+ZH_DEV uint32_t zd_pb_peek(const ZdPBits& b, uint32_t n) { return (uint32_t)((b.c << (b.used & 63)) >> (64 - n)); }   // 1 <= n <= 32
+ZH_DEV bool zd_pb_done(const ZdPBits& b) { return b.ptr == b.start && b.used == 64; }
+
 // ------------------------------------------------------------------------------------------ Huffman
 // Reads a tree description into L.weights (all lanes call). Returns bytes used or -err; *pCount = #weights incl. last.
 ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize, uint32_t* pCount, uint32_t* pLog)
@@ -398,27 +441,27 @@ ZH_DEVFN int zd_build_huf(ZdLDS& L, uint32_t count)
 // one Huffman stream, one lane. Writes `count` symbols to out. Returns true when the stream was consumed exactly.
 ZH_DEVFN bool zd_huf_stream(const uint16_t* huf, uint32_t log, const uint8_t* src, uint32_t srcSize, uint8_t* out, uint32_t count)
 {
-    ZdBits b;
-    if (!zd_bits_init(b, src, srcSize)) return false;
+    ZdPBits b;
+    if (!zd_pb_init(b, src, srcSize)) return false;
     uint32_t i = 0;
+    zd_pb_norm(b);
     while (i + 4 <= count) {
-        zd_bits_reload(b);
-        uint32_t e0 = huf[zd_bits_peek(b, log)]; b.used += e0 >> 8;
-        uint32_t e1 = huf[zd_bits_peek(b, log)]; b.used += e1 >> 8;
-        uint32_t e2 = huf[zd_bits_peek(b, log)]; b.used += e2 >> 8;
-        uint32_t e3 = huf[zd_bits_peek(b, log)]; b.used += e3 >> 8;
+        uint32_t e0 = huf[zd_pb_peek(b, log)]; b.used += e0 >> 8;
+        uint32_t e1 = huf[zd_pb_peek(b, log)]; b.used += e1 >> 8;
+        uint32_t e2 = huf[zd_pb_peek(b, log)]; b.used += e2 >> 8;
+        uint32_t e3 = huf[zd_pb_peek(b, log)]; b.used += e3 >> 8;
         if (b.used > 64) return false;
         zh_st32(out + i, (e0 & 255) | ((e1 & 255) << 8) | ((e2 & 255) << 16) | ((e3 & 255) << 24));
         i += 4;
+        zd_pb_norm(b);
     }
-    zd_bits_reload(b);
     while (i < count) {
-        uint32_t e = huf[zd_bits_peek(b, log)]; b.used += e >> 8;
+        uint32_t e = huf[zd_pb_peek(b, log)]; b.used += e >> 8;
         if (b.used > 64) return false;
         out[i++] = (uint8_t)e;
     }
-    zd_bits_reload(b);
-    return zd_bits_done(b);
+    zd_pb_norm(b);
+    return zd_pb_done(b);
 }
 
 // Literals section (RFC 8878 3.1.1.3.1). All lanes call. Returns bytes consumed or -err.

@@ -225,22 +225,31 @@ ZH_DEVFN int zp_decode_sequences(const uint8_t* p, const uint8_t* end, ZpLaneLDS
     r = zp_seq_table(Ll->of, Ll, (modes >> 4) & 3, ZD_KIND_OF, &ofLog, p, end); if (r < 0) return -r; p += r;
     r = zp_seq_table(Ll->ml, Ll, (modes >> 2) & 3, ZD_KIND_ML, &mlLog, p, end); if (r < 0) return -r; p += r;
     if (p >= end) return ZE_CORRUPTION;
-    ZdBits b;
-    if (!zd_bits_init(b, p, (uint32_t)(end - p))) return ZE_CORRUPTION;
-    // a take of n <= 32 bits with reload; remaining-bit accounting detects over-reads
+    ZdPBits b;
+    if (!zd_pb_init(b, p, (uint32_t)(end - p))) return ZE_CORRUPTION;
     int64_t left = ((end - p) >= 8) ? (int64_t)(end - p) * 8 - (int64_t)b.used : 64 - (int64_t)b.used;
-#define ZP_TAKE(dstv, n) do { const uint32_t n_ = (n); if (b.used + n_ > 64) zd_bits_reload(b); \
-        dstv = n_ ? (uint32_t)((b.c << (b.used & 63)) >> (64 - n_)) : 0u; b.used += n_; left -= n_; } while (0)
+    // extra-bit counts computed arithmetically (nibble tables for codes 16..31 / 32..47) keep the bit-consumption chain
+    // free of a second dependent LDS lookup
+    const uint64_t kLL = 0xCBA9876433221111ull;    // LL_bits[16..31] = 1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12
+    const uint64_t kML = 0xBA98754433221111ull;    // ML_bits[32..47] = 1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11
+#define ZP_TAKE(dstv, n) do { const uint32_t n_ = (n); dstv = n_ ? (uint32_t)((b.c << (b.used & 63)) >> (64 - n_)) : 0u; b.used += n_; left -= n_; } while (0)
     uint32_t sL, sO, sM;
+    zd_pb_norm(b);
     ZP_TAKE(sL, llLog); ZP_TAKE(sO, ofLog); ZP_TAKE(sM, mlLog);
+    zd_pb_norm(b);
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     const uint32_t sizeL = 1u << llLog, sizeO = 1u << ofLog, sizeM = 1u << mlLog;
     for (uint32_t n = 0; n < nbSeq; n++) {
         const uint32_t cL = Ll->ll[sL], cM = Ll->ml[sM], cO = Ll->of[sO];
         const uint32_t symL = cL >> 10, symM = cM >> 10, symO = cO >> 10;
-        if (symO > ZF_MAXOFF) return ZE_CORRUPTION;
+        if (symO > ZF_MAXOFF || symL > ZF_MAXLL || symM > ZF_MAXML) return ZE_CORRUPTION;
+        const uint32_t bitsL = symL < 16 ? 0u : symL < 32 ? (uint32_t)(kLL >> (4 * (symL - 16))) & 15u : symL - 19;
+        const uint32_t bitsM = symM < 32 ? 0u : symM < 48 ? (uint32_t)(kML >> (4 * (symM - 32))) & 15u : symM - 36;
         uint32_t xo, xm, xl;
-        ZP_TAKE(xo, symO); ZP_TAKE(xm, mlBits[symM]); ZP_TAKE(xl, llBits[symL]);
+        ZP_TAKE(xo, symO);
+        if (b.used + bitsM + bitsL > 64) zd_pb_norm(b);  // only for very long extra-bit fields
+        ZP_TAKE(xm, bitsM); ZP_TAKE(xl, bitsL);
+        if (b.used > 38) zd_pb_norm(b);                 // rare: the three state updates below need up to 26 bits
         const uint32_t ofv = (1u << symO) + xo;
         const uint32_t mlv = mlBase[symM] + xm;
         const uint32_t llv = llBase[symL] + xl;
@@ -262,6 +271,7 @@ ZH_DEVFN int zp_decode_sequences(const uint8_t* p, const uint8_t* end, ZpLaneLDS
             { const uint32_t x = cM & 1023, nb = mlLog - (uint32_t)zh_highbit32(x); ZP_TAKE(t, nb); sM = (x << nb) - sizeM + t; }
             { const uint32_t x = cO & 1023, nb = ofLog - (uint32_t)zh_highbit32(x); ZP_TAKE(t, nb); sO = (x << nb) - sizeO + t; }
         }
+        zd_pb_norm(b);                                   // funnel shift; the load it issues is consumed one iteration later
         if (left < 0) return ZE_CORRUPTION;
         if (offset >= (1u << 30)) return ZE_PARAM_UNSUPPORTED;     // does not fit the packed form (windows > 1 GiB)
         out[n] = (uint64_t)llv | ((uint64_t)mlv << 17) | ((uint64_t)offset << 34);
@@ -299,7 +309,7 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, uint8_t* ldsBase, uint32_t* llB
 }
 
 // ------------------------------------------------------------------------------------------ K3 (one wave per frame)
-struct ZpExecLDS { uint8_t asmb[ZD_ASM_BYTES + 64]; uint32_t misc[8]; };
+struct ZpExecLDS { uint8_t asmb[ZD_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8]; };
 
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced)
 {
@@ -373,15 +383,34 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const uint32_t s = zh_shfl((uint32_t)sAbs, l);
             for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = dst[s + j];
         }
+        // ---- matches that read this batch's own output. A match may start as soon as every near match whose output
+        // it reads is done: `need` = the set of those sequences (contiguous index range found by binary search over the
+        // batch-relative match extents), so the number of rounds is the dependency depth, not the batch length.
+        L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
         zh_sync();
         bool pending = hasM && !farM;
-        int32_t send = sAbs + (int32_t)myML; if (send > (int32_t)(op + mRel)) send = (int32_t)(op + mRel);
+        uint64_t need = 0;
+        if (pending) {
+            const uint32_t a0 = sAbs > (int32_t)op ? (uint32_t)(sAbs - (int32_t)op) : 0;          // first batch byte I read
+            uint32_t b0 = (uint32_t)(sAbs + (int32_t)myML - (int32_t)op);                          // one past the last byte I read
+            if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
+            uint32_t lo = 0, hi = 0;            // lo = first j with mEnd[j] > a0 ; hi = first j with mBeg[j] >= b0
+            for (uint32_t stp = 32; stp; stp >>= 1) { if (lo + stp <= 64 && L.mEnd[lo + stp - 1] <= a0) lo += stp; }
+            for (uint32_t stp = 32; stp; stp >>= 1) { if (hi + stp <= 64 && L.mBeg[hi + stp - 1] < b0) hi += stp; }
+            if (hi > lane) hi = lane;           // only earlier sequences can feed me
+            if (lo < hi) need = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
+        }
+        const uint64_t nearMask = zh_ballot(pending);
+        need &= nearMask;                       // literals and far matches are already in the buffer
+        uint64_t doneMask = ~nearMask;
         for (;;) {
             const uint64_t pend = zh_ballot(pending);
             if (!pend) break;
-            const uint32_t pf = (uint32_t)zh_ctz64(pend);
-            const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
-            if (fml > ZD_COOP_LEN) {
+            const uint64_t longReady = zh_ballot(pending && myML > ZD_COOP_LEN && (need & ~doneMask) == 0);
+            if (longReady) {
+                // whole wave copies one long ready match
+                const uint32_t pf = (uint32_t)zh_ctz64(longReady);
+                const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
                 const int32_t fs = (int32_t)(op + Frel) - (int32_t)fof;
                 if (fof >= 64) {
                     for (uint32_t c = 0; c < fml; c += 64) {
@@ -398,8 +427,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     }
                 }
                 if (lane == pf) pending = false;
+                doneMask |= 1ull << pf;
             } else {
-                const bool ready = pending && myML <= ZD_COOP_LEN && (lane == pf || send <= (int32_t)(op + Frel));
+                const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
                 if (ready) {
                     if (sAbs >= (int32_t)op && myOF >= myML) {
                         uint64_t rr[4];
@@ -413,6 +443,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     }
                     pending = false;
                 }
+                doneMask |= zh_ballot(ready);
             }
             zh_sync();
         }
