@@ -227,56 +227,79 @@ ZH_DEVFN int zp_decode_sequences(const uint8_t* p, const uint8_t* end, ZpLaneLDS
     if (p >= end) return ZE_CORRUPTION;
     ZdPBits b;
     if (!zd_pb_init(b, p, (uint32_t)(end - p))) return ZE_CORRUPTION;
-    int64_t left = ((end - p) >= 8) ? (int64_t)(end - p) * 8 - (int64_t)b.used : 64 - (int64_t)b.used;
-    // extra-bit counts computed arithmetically (nibble tables for codes 16..31 / 32..47) keep the bit-consumption chain
-    // free of a second dependent LDS lookup
+    int32_t left = ((end - p) >= 8) ? (int32_t)(end - p) * 8 - (int32_t)b.used : 64 - (int32_t)b.used;
+    // The loop below is the hot serial chain of the whole decoder, so it is written branch-lean: reads of n in [0,32]
+    // bits never branch on n, renormalisation is a funnel shift of (c, d) with the next load already issued, extra-bit
+    // counts come from nibble tables instead of a second dependent LDS lookup, repcode handling is select-based, and the
+    // rare sequence with more than 31 extra bits takes a side path.
     const uint64_t kLL = 0xCBA9876433221111ull;    // LL_bits[16..31] = 1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12
     const uint64_t kML = 0xBA98754433221111ull;    // ML_bits[32..47] = 1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11
-#define ZP_TAKE(dstv, n) do { const uint32_t n_ = (n); dstv = n_ ? (uint32_t)((b.c << (b.used & 63)) >> (64 - n_)) : 0u; b.used += n_; left -= n_; } while (0)
+    const uint8_t* const start = b.start;
+    const uint8_t* ptr = b.ptr;
+    uint64_t c = b.c, d = b.d;
+    uint32_t used = b.used;
+    const bool tiny = (end - p) < 8;                 // whole stream already sits in c; d stays 0
+#define ZP_PEEK(n) ((uint32_t)(((c << (used & 63)) >> 1) >> (63 - (n))))
+#define ZP_NORM() do { uint32_t nb_ = used >> 3; if (nb_ > 7) nb_ = 7; const uint32_t room_ = (uint32_t)(ptr - start); if (nb_ > room_) nb_ = room_; \
+        c = (c << (8 * nb_)) | ((d >> 1) >> (63 - 8 * nb_)); ptr -= nb_; used -= 8 * nb_; \
+        const uint32_t r2_ = room_ - nb_; \
+        if (r2_ >= 8) d = zh_ld64(ptr - 8); else d = (tiny || r2_ == 0) ? 0ull : (zh_ld64(start) << (8 * (8 - r2_))); } while (0)
     uint32_t sL, sO, sM;
-    zd_pb_norm(b);
-    ZP_TAKE(sL, llLog); ZP_TAKE(sO, ofLog); ZP_TAKE(sM, mlLog);
-    zd_pb_norm(b);
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    ZP_NORM();
+    sL = ZP_PEEK(llLog); used += llLog; sO = ZP_PEEK(ofLog); used += ofLog; sM = ZP_PEEK(mlLog); used += mlLog;
+    left -= (int32_t)(llLog + ofLog + mlLog);
+    ZP_NORM();
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8, bad = 0;
     const uint32_t sizeL = 1u << llLog, sizeO = 1u << ofLog, sizeM = 1u << mlLog;
     for (uint32_t n = 0; n < nbSeq; n++) {
         const uint32_t cL = Ll->ll[sL], cM = Ll->ml[sM], cO = Ll->of[sO];
         const uint32_t symL = cL >> 10, symM = cM >> 10, symO = cO >> 10;
-        if (symO > ZF_MAXOFF || symL > ZF_MAXLL || symM > ZF_MAXML) return ZE_CORRUPTION;
-        const uint32_t bitsL = symL < 16 ? 0u : symL < 32 ? (uint32_t)(kLL >> (4 * (symL - 16))) & 15u : symL - 19;
-        const uint32_t bitsM = symM < 32 ? 0u : symM < 48 ? (uint32_t)(kML >> (4 * (symM - 32))) & 15u : symM - 36;
+        const uint32_t nibL = (uint32_t)(kLL >> ((4 * symL) & 63)) & 15u, nibM = (uint32_t)(kML >> ((4 * symM) & 63)) & 15u;
+        const uint32_t bitsL = symL < 16 ? 0u : (symL < 32 ? nibL : symL - 19);
+        const uint32_t bitsM = symM < 32 ? 0u : (symM < 48 ? nibM : symM - 36);
+        const uint32_t extra = symO + bitsM + bitsL;
         uint32_t xo, xm, xl;
-        ZP_TAKE(xo, symO);
-        if (b.used + bitsM + bitsL > 64) zd_pb_norm(b);  // only for very long extra-bit fields
-        ZP_TAKE(xm, bitsM); ZP_TAKE(xl, bitsL);
-        if (b.used > 38) zd_pb_norm(b);                 // rare: the three state updates below need up to 26 bits
+        if (extra > 31) {                               // rare: long offsets plus long lengths
+            xo = ZP_PEEK(symO); used += symO; ZP_NORM();
+            xm = ZP_PEEK(bitsM); used += bitsM; xl = ZP_PEEK(bitsL); used += bitsL; ZP_NORM();
+        } else {
+            xo = ZP_PEEK(symO); used += symO; xm = ZP_PEEK(bitsM); used += bitsM; xl = ZP_PEEK(bitsL); used += bitsL;
+        }
         const uint32_t ofv = (1u << symO) + xo;
         const uint32_t mlv = mlBase[symM] + xm;
         const uint32_t llv = llBase[symL] + xl;
-        uint32_t offset;
-        if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-        else {
-            const uint32_t idx = ofv - 1 + (llv == 0);
-            if (idx == 0) offset = rep0;
-            else {
-                offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                if (offset == 0) offset = 1;
-                if (idx != 1) rep2 = rep1;
-                rep1 = rep0; rep0 = offset;
-            }
-        }
-        if (n + 1 < nbSeq) {
-            uint32_t t;
-            { const uint32_t x = cL & 1023, nb = llLog - (uint32_t)zh_highbit32(x); ZP_TAKE(t, nb); sL = (x << nb) - sizeL + t; }
-            { const uint32_t x = cM & 1023, nb = mlLog - (uint32_t)zh_highbit32(x); ZP_TAKE(t, nb); sM = (x << nb) - sizeM + t; }
-            { const uint32_t x = cO & 1023, nb = ofLog - (uint32_t)zh_highbit32(x); ZP_TAKE(t, nb); sO = (x << nb) - sizeO + t; }
-        }
-        zd_pb_norm(b);                                   // funnel shift; the load it issues is consumed one iteration later
-        if (left < 0) return ZE_CORRUPTION;
-        if (offset >= (1u << 30)) return ZE_PARAM_UNSUPPORTED;     // does not fit the packed form (windows > 1 GiB)
+        // repcode resolution (RFC 8878 3.1.1.5) with selects
+        const uint32_t idx = ofv - 1 + (llv == 0);           // meaningful when ofv <= 3
+        uint32_t ro = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+        if (ro == 0) ro = 1;
+        const bool isRep = ofv <= 3;
+        const uint32_t offset = isRep ? ro : ofv - 3;
+        const bool shift3 = !isRep || idx >= 2;               // rep2 <- rep1
+        const bool shift2 = !isRep || idx >= 1;               // rep1 <- rep0, rep0 <- offset
+        rep2 = shift3 ? rep1 : rep2;
+        rep1 = shift2 ? rep0 : rep1;
+        rep0 = shift2 ? offset : rep0;
+        // state updates (skipped bit-wise for the last sequence by zeroing the widths)
+        const uint32_t live = n + 1 < nbSeq;
+        const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
+        const uint32_t nbL = live ? llLog - (uint32_t)zh_highbit32(xL) : 0u;
+        const uint32_t nbM = live ? mlLog - (uint32_t)zh_highbit32(xM) : 0u;
+        const uint32_t nbO = live ? ofLog - (uint32_t)zh_highbit32(xO) : 0u;
+        const uint32_t tL = ZP_PEEK(nbL); used += nbL;
+        const uint32_t tM = ZP_PEEK(nbM); used += nbM;
+        const uint32_t tO = ZP_PEEK(nbO); used += nbO;
+        sL = ((xL << nbL) - sizeL + tL) & (sizeL - 1);
+        sM = ((xM << nbM) - sizeM + tM) & (sizeM - 1);
+        sO = ((xO << nbO) - sizeO + tO) & (sizeO - 1);
+        left -= (int32_t)(extra + nbL + nbM + nbO);
+        ZP_NORM();                                       // the load it issues is consumed one iteration later
+        bad |= (uint32_t)(left < 0) | ((offset >> 30) << 1);
         out[n] = (uint64_t)llv | ((uint64_t)mlv << 17) | ((uint64_t)offset << 34);
     }
-#undef ZP_TAKE
+#undef ZP_PEEK
+#undef ZP_NORM
+    if (bad & 2) return ZE_PARAM_UNSUPPORTED;           // an offset does not fit the packed form (window > 1 GiB)
+    if (bad & 1) return ZE_CORRUPTION;
     if (left != 0) return ZE_CORRUPTION;
     *pNbSeq = nbSeq;
     return 0;
