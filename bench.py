@@ -266,9 +266,17 @@ def main():
         algo_bytes = (F * FRAME + ctotal) // launches_per_step
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line["kernels"] = {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
+        traffic = None
+        try:                                                         # PMC passes are separate runs (profiles/README.md); scaled per launch
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            per_frame = tj["bytes_per_frame"].get(ctx.kernel_name(kdom))
+            if per_frame:
+                traffic = int(per_frame * F / launches_per_step)
+        except (OSError, ValueError, KeyError):
+            pass
         line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                            "traffic": None, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
+                            "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
                             "algorithmic_bytes_per_launch": int(algo_bytes)}
         if world == 1 and not args.no_cpu_baseline:
             sample = min(F, 4096)
