@@ -581,8 +581,8 @@ ZH_DEV uint32_t ze_common_len(const uint8_t* a, const uint8_t* b, const uint8_t*
 
 // ZSTD_compressBlock_doubleFast_noDict_generic (zstd.c:31039) for a block that is the whole frame. Table cells hold
 // position + 2 (0 = empty), so the reference's index comparisons keep their meaning with lowest == 2. lane 0 only.
-// seqs: triples (offBase, litLength, matchLength). Returns nbSeq; *pLit = literal count.
-ZH_DEVFN uint32_t ze_dfast(uint32_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+// seqs: packed (offBase | litLength << 20 | matchLength << 42). Returns nbSeq; *pLit = literal count.
+ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
                            uint32_t* hashLong, uint32_t* hashSmall)
 {
     const int hl = cp.hlog, hs = cp.clog;
@@ -596,7 +596,7 @@ ZH_DEVFN uint32_t ze_dfast(uint32_t* seqs, uint8_t* lits, uint32_t* pLit, const 
     uint32_t off1 = 1, off2 = 0;            // {1,4,8} clipped to maxRep == 1 at the frame start (zstd.c:31091-31098)
     uint32_t nseq = 0; uint8_t* lp = lits;
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
-        seqs[3 * nseq] = (OFFBASE); seqs[3 * nseq + 1] = ll_; seqs[3 * nseq + 2] = (uint32_t)(ML); nseq++; } while (0)
+        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
     for (;;) {
         uint32_t step = 1; const uint8_t* nextStep = ip + 256; const uint8_t* ip1 = ip + step;
         uint32_t mLength = 0, offset = 0, curr = 0;
@@ -707,15 +707,21 @@ ZH_DEV uint32_t ze_ll_code(uint32_t v) { uint32_t c = 35; while (ze_llBase[c] > 
 ZH_DEV uint32_t ze_ml_code(uint32_t ml) { uint32_t c = 52; while (ze_mlBase[c] > ml) c--; return c; }
 
 // ZSTD_compressBlock_internal (zstd.c:27337) for the first-and-only block. All lanes call. Returns body size, 0 = store raw.
-ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws)
+struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
+
+ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
+                                    const ZePre* pre)
 {
     const uint32_t lane = zh_lane();
     if (srcSize < 7) return 0;
     uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
     uint32_t* hashSmall = (uint32_t*)(ws + ZE_WS_HASHS);
-    uint32_t* seqs = (uint32_t*)(ws + ZE_WS_SEQ);
-    uint8_t* lits = ws + ZE_WS_LIT;
+    const uint64_t* seqs = pre ? pre->seqs : (const uint64_t*)(ws + ZE_WS_SEQ);
+    const uint8_t* lits = pre ? pre->lits : ws + ZE_WS_LIT;
     uint8_t* codes = ws + ZE_WS_CODES;
+    uint32_t nbSeq, litSize;
+    if (pre) { nbSeq = pre->nbSeq; litSize = pre->litSize; }
+    else {
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
     {
         uint64_t* a = (uint64_t*)hashLong; const uint32_t na = (1u << cp.hlog) / 2;
@@ -726,14 +732,15 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     ze_fence();
     zh_sync();
     if (zh_opaque(lane) == 0) {
-        uint32_t litSize = 0;
-        const uint32_t nbSeq = ze_dfast(seqs, lits, &litSize, src, srcSize, cp, hashLong, hashSmall);
-        L.misc[1] = nbSeq; L.misc[2] = litSize;
+        uint32_t ls = 0;
+        const uint32_t ns = ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
+        L.misc[1] = ns; L.misc[2] = ls;
     }
     ze_fence();
     zh_sync();
-    const uint32_t nbSeq = zh_first(L.misc[1]), litSize = zh_first(L.misc[2]);
+    nbSeq = zh_first(L.misc[1]); litSize = zh_first(L.misc[2]);
     zh_sync();
+    }
     uint32_t pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq);
     // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
     uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
@@ -741,7 +748,8 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     for (uint32_t i = lane; i < 192; i += 64) (&L.cnt[0][0])[i] = 0;
     zh_sync();
     for (uint32_t i = lane; i < nbSeq; i += 64) {
-        const uint32_t a = ze_ll_code(seqs[3 * i + 1]), o = (uint32_t)zh_highbit32(seqs[3 * i]), m = ze_ml_code(seqs[3 * i + 2]);
+        const uint64_t q = seqs[i];
+        const uint32_t a = ze_ll_code((uint32_t)(q >> 20) & 0x3FFFFF), o = (uint32_t)zh_highbit32((uint32_t)q & 0xFFFFF), m = ze_ml_code((uint32_t)(q >> 42));
         llc[i] = (uint8_t)a; ofc[i] = (uint8_t)o; mlc[i] = (uint8_t)m;
         zh_lds_atomic_inc(&L.cnt[0][a]); zh_lds_atomic_inc(&L.cnt[1][o]); zh_lds_atomic_inc(&L.cnt[2][m]);
     }
@@ -765,16 +773,21 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
             ZeBits b; ze_bw_init(b, op, cap - (uint32_t)(op - out));
             uint32_t n = nbSeq - 1;
             uint32_t sML = ze_fse_first_state(L.tab[2], mlc[n]), sOF = ze_fse_first_state(L.tab[1], ofc[n]), sLL = ze_fse_first_state(L.tab[0], llc[n]);
-            ze_bw_add(b, seqs[3 * n + 1], ze_llBits[llc[n]]);
-            ze_bw_add(b, seqs[3 * n + 2] - 3, ze_mlBits[mlc[n]]);
-            ze_bw_add(b, seqs[3 * n], ofc[n]);
+#define ZE_SQ_OFF(q) ((uint32_t)(q) & 0xFFFFF)
+#define ZE_SQ_LL(q) ((uint32_t)((q) >> 20) & 0x3FFFFF)
+#define ZE_SQ_ML(q) ((uint32_t)((q) >> 42))
+            { const uint64_t q = seqs[n];
+              ze_bw_add(b, ZE_SQ_LL(q), ze_llBits[llc[n]]);
+              ze_bw_add(b, ZE_SQ_ML(q) - 3, ze_mlBits[mlc[n]]);
+              ze_bw_add(b, ZE_SQ_OFF(q), ofc[n]); }
             while (n-- > 0) {
                 sOF = ze_fse_encode(L.tab[1], b, sOF, ofc[n]);
                 sML = ze_fse_encode(L.tab[2], b, sML, mlc[n]);
                 sLL = ze_fse_encode(L.tab[0], b, sLL, llc[n]);
-                ze_bw_add(b, seqs[3 * n + 1], ze_llBits[llc[n]]);
-                ze_bw_add(b, seqs[3 * n + 2] - 3, ze_mlBits[mlc[n]]);
-                ze_bw_add(b, seqs[3 * n], ofc[n]);
+                const uint64_t q = seqs[n];
+                ze_bw_add(b, ZE_SQ_LL(q), ze_llBits[llc[n]]);
+                ze_bw_add(b, ZE_SQ_ML(q) - 3, ze_mlBits[mlc[n]]);
+                ze_bw_add(b, ZE_SQ_OFF(q), ofc[n]);
             }
             ze_bw_add(b, sML, (uint32_t)L.tab[2].log); ze_bw_add(b, sOF, (uint32_t)L.tab[1].log); ze_bw_add(b, sLL, (uint32_t)L.tab[0].log);
             const uint32_t bs = ze_bw_close(b);
@@ -839,7 +852,7 @@ ZH_DEV int ze_get_cparams(ZePar& out, int level, uint32_t srcSize)
 }
 
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
-ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced)
+ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre)
 {
     const uint32_t lane = zh_lane();
     *produced = 0;
@@ -878,7 +891,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
         if (zh_opaque(lane) == 0) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; }
         pos += 3;
     } else {
-        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws);
+        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre);
         if (c == 0) {
             const uint32_t bh = 1 + (0u << 1) + (srcSize << 3);
             if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
@@ -911,7 +924,63 @@ ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
         zh_sync();
         if (f >= a.n) break;
         uint64_t produced = 0;
-        const int err = ze_frame(a, L, f, ws, &produced);
+        const int err = ze_frame(a, L, f, ws, &produced, nullptr);
+        zh_sync();
+        if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ two-kernel form
+// E1: double-fast search with one LANE per frame. The search is a chain of dependent global-memory probes (hash table,
+// candidate bytes), so the way to throughput is frames in flight: every lane of the wave runs the serial search of its own
+// frame against its own tables; nothing is shared between lanes and no cross-lane operation is needed.
+ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
+{
+    const uint32_t lane = zh_lane();
+    if (lane >= ZE_E1_LANES) return;
+    uint8_t* tables = a.laneTables + ((size_t)zh_block() * ZE_E1_LANES + lane) * a.tableStride;
+    for (;;) {
+        const uint32_t i = zh_atomic_add(a.counter, 1u);
+        if (i >= a.count) break;
+        const uint32_t f = a.first + i;
+        ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
+        const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+        const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+        ZePar cp;
+        if (srcSize64 > ZF_BLOCK_MAX || ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || cp.strat != 2 ||
+            (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
+        const uint32_t srcSize = (uint32_t)srcSize64;
+        if (srcSize < 7) { m.mode = 1; a.meta[i] = m; continue; }
+        uint32_t* hashLong = (uint32_t*)tables;
+        uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
+        { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (4u << cp.clog)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
+        uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
+        uint32_t litSize = 0;
+        m.nbSeq = ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
+        m.litSize = litSize;
+        a.meta[i] = m;
+    }
+}
+
+// E2: everything after the search (entropy coding + frame assembly), one wave per frame
+ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    // only the symbol-code region of the fused kernel's workspace layout is used here; bias the base so it lands in our slot
+    uint8_t* ws = a.workspace + (size_t)zh_block() * ZE_CODES_STRIDE - ZE_WS_CODES;
+    for (;;) {
+        const uint32_t got = zh_atomic_add(a.counter + 1, lane == 0 ? 1u : 0u);
+        if (zh_opaque(lane) == 0) L.misc[15] = got;
+        zh_sync();
+        const uint32_t i = zh_first(L.misc[15]);
+        zh_sync();
+        if (i >= a.count) break;
+        const uint32_t f = a.first + i;
+        const ZeMeta m = a.meta[i];
+        const uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
+        ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
+        uint64_t produced = 0;
+        const int err = ze_frame(a, L, f, ws, &produced, m.mode == 0 ? &pre : nullptr);   // modes 1/2 never reach the search inside
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }

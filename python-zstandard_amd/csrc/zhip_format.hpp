@@ -61,11 +61,13 @@ struct ZhipDecodeArgs {
 // ------------------------------------------------------------------------------------------------ encode side
 // per-resident-wave workspace in HBM (hash tables, sequence store, literal buffer, symbol codes)
 #define ZE_MAX_HLOG 17
-#define ZE_MAX_SEQ 32768
+#define ZE_MAX_SEQ 43704                                 // >= 131072 / 3 sequences per block
+#define ZE_SEQ_CAP ZE_MAX_SEQ
+// packed sequence: offBase[0:20) litLength[20:42) matchLength[42:64)
 #define ZE_WS_HASHL 0
 #define ZE_WS_HASHS (ZE_WS_HASHL + (4u << ZE_MAX_HLOG))
 #define ZE_WS_SEQ   (ZE_WS_HASHS + (4u << ZE_MAX_HLOG))
-#define ZE_WS_LIT   (ZE_WS_SEQ + 12u * (ZE_MAX_SEQ + 8))
+#define ZE_WS_LIT   (ZE_WS_SEQ + 8u * (ZE_SEQ_CAP + 8))
 #define ZE_WS_CODES (ZE_WS_LIT + ZF_BLOCK_MAX + 256)
 #define ZHIP_ENC_STRIDE (ZE_WS_CODES + 3u * (ZE_MAX_SEQ + 8) + 256)
 
@@ -82,7 +84,19 @@ struct ZhipEncodeArgs {
     int32_t level;
     uint32_t contentSizeFlag, checksumFlag, dictIDFlag;
     unsigned long long* prof;
+    // two-kernel form (match finding with one LANE per frame, then entropy coding with one wave per frame)
+    struct ZeMeta* meta;            // chunk-local per-frame record
+    uint8_t* arena;                 // chunk x ZE_ARENA_STRIDE : packed sequences + literals of each frame
+    uint8_t* laneTables;            // (gridDim.x * ZE_E1_LANES) x tableStride : hash tables of the frames being searched
+    uint32_t tableStride;
+    uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
 };
+struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched; 1: store raw (too small); 2: error in status
+#define ZE_ARENA_SEQ 0
+#define ZE_ARENA_LIT (8u * (ZE_SEQ_CAP + 8))
+#define ZE_ARENA_STRIDE ((size_t)ZE_ARENA_LIT + ZF_BLOCK_MAX + 256)
+#define ZE_E1_LANES 32
+#define ZE_CODES_STRIDE ((size_t)3 * (ZE_MAX_SEQ + 8) + 256)   // E2 only needs the symbol-code scratch per wave
 
 // ------------------------------------------------------------------------------------------------ phase-split decode pipeline
 // per-frame record handed from kernel to kernel (HBM)

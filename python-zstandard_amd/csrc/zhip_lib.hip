@@ -43,6 +43,12 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
     __shared__ ZeLDS L;
     ze_kernel_body(a, L);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
+{
+    __shared__ ZeLDS L;
+    ze_entropy_body(a, L);
+}
 ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
 {
     uint32_t v = zh_scan_add(zh_lane());                  // 0+1+..+lane
@@ -179,7 +185,8 @@ struct zhip_ctx {
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback;
-    DevBuf encWorkspace;
+    DevBuf encWorkspace, encMeta, encArena, encTables;
+    int e1PerCU = 0, e2PerCU = 0;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
     // dictionary (decode side)
@@ -189,7 +196,7 @@ struct zhip_ctx {
     // host-API staging
     DevBuf hSrc, hDst, hSegs, hStatus;
     void* pinned = nullptr; size_t pinnedCap = 0;
-    KTimer timer[5];     // 0 fused decode, 1 encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution
+    KTimer timer[7];     // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy
 };
 
 extern "C" zhip_ctx* zhip_ctx_create(void)
@@ -211,6 +218,10 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     c->k2PerCU = nb;
     nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_exec_kernel, 64, 0) != hipSuccess || nb < 1) nb = 16;
     c->k3PerCU = nb;
+    nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_encode_match_kernel, 64, 0) != hipSuccess || nb < 1) nb = 4;
+    c->e1PerCU = nb;
+    nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_encode_entropy_kernel, 64, 0) != hipSuccess || nb < 1) nb = 4;
+    c->e2PerCU = nb;
     return c;
 }
 static void drain_shared(KTimer& t)
@@ -235,25 +246,26 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 5; i++) drain_shared(c->timer[i]);
-    for (int i = 0; i < 5; i++) drain_timer(c->timer[i]);
+    for (int i = 0; i < 7; i++) drain_shared(c->timer[i]);
+    for (int i = 0; i < 7; i++) drain_timer(c->timer[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
 }
 extern "C" const char* zhip_kernel_name(int k)
 {
-    static const char* names[5] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
-                                   "zhip_decode_seq_kernel", "zhip_decode_exec_kernel"};
-    return k >= 0 && k < 5 ? names[k] : "";
+    static const char* names[7] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
+                                   "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
+                                   "zhip_encode_entropy_kernel"};
+    return k >= 0 && k < 7 ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
 {
-    if (!c || direction < 0 || direction > 4) return ZHIP_ERR_UNSUPPORTED;
+    if (!c || direction < 0 || direction > 6) return ZHIP_ERR_UNSUPPORTED;
     HIP_TRY(hipDeviceSynchronize());
-    for (int i = 0; i < 5; i++) drain_shared(c->timer[i]);
+    for (int i = 0; i < 7; i++) drain_shared(c->timer[i]);
     KTimer& t = c->timer[direction];
     drain_timer(t);
     if (avgMs) *avgMs = t.launches ? t.totalMs / (double)t.launches : 0.0;
@@ -418,7 +430,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         fprintf(stderr, "[zhip-prof] grid=%u (CUs %d x %d blocks) frames=%u wave-cycles total=%.3e (%.0f per frame)\n", grid, c->numCU, c->decBlocksPerCU, a.n, (double)tot, (double)tot / a.n);
         for (int i = 0; i < ZP_N; i++) fprintf(stderr, "[zhip-prof]   %-22s %6.2f%%  %10.0f cyc/frame\n", names[i], 100.0 * h[i] / (tot ? tot : 1), (double)h[i] / a.n);
     }
-    if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < 5; i++) drain_shared(c->timer[i]); for (int i = 0; i < 5; i++) drain_timer(c->timer[i]); }
+    if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < 7; i++) drain_shared(c->timer[i]); for (int i = 0; i < 7; i++) drain_timer(c->timer[i]); }
     return 0;
 }
 extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
@@ -440,6 +452,48 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)((uint8_t*)c->counter.p + 8); a.n = (uint32_t)n;
     a.level = c->cparams.level == 0 ? 3 : c->cparams.level;
     a.contentSizeFlag = c->cparams.contentSizeFlag != 0; a.checksumFlag = c->cparams.checksumFlag != 0; a.dictIDFlag = c->cparams.dictIDFlag != 0;
+    if (getenv("ZHIP_NO_PIPELINE") == nullptr) {
+        // two kernels: E1 searches with one LANE per frame (frames in flight hide the probe latency), E2 entropy-codes with one
+        // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
+        const int level = a.level;
+        a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));        // largest dfast tables for inputs <= 128 KiB
+        const size_t chunkMax = 32768;
+        const size_t chunk = n < chunkMax ? n : chunkMax;
+        size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max > 1024) g1max = 1024;
+        const size_t w1 = (chunk + ZE_E1_LANES - 1) / ZE_E1_LANES;
+        const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
+        size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
+        const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
+        if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
+            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+        a.workspace = (uint8_t*)c->encWorkspace.p;
+        a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
+        for (size_t first = 0; first < n; first += chunk) {
+            const size_t cnt = n - first < chunk ? n - first : chunk;
+            a.first = (uint32_t)first; a.count = (uint32_t)cnt;
+            HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 8, stream));
+            hipEvent_t ev[3];
+            for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ev[i]));
+            HIP_TRY(hipEventRecord(ev[0], stream));
+            hipLaunchKernelGGL(zhip_encode_match_kernel, dim3(g1), dim3(64), 0, stream, a);
+            HIP_TRY(hipEventRecord(ev[1], stream));
+            hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
+            HIP_TRY(hipEventRecord(ev[2], stream));
+            HIP_TRY(hipGetLastError());
+            c->timer[5].pending.emplace_back(ev[0], ev[1]);
+            hipEvent_t dup; HIP_TRY(hipEventCreate(&dup)); HIP_TRY(hipEventRecord(dup, stream));
+            c->timer[6].shared.emplace_back(ev[1], ev[2]);
+            c->timer[1].pending.emplace_back(ev[2], dup);      // owns ev[2]; measures ~0
+        }
+        if (getenv("ZHIP_WATCHDOG")) {
+            for (int it = 0; it < 2400; it++) {
+                if (hipStreamQuery(stream) == hipSuccess) break;
+                struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
+                if (it == 2399) { fprintf(stderr, "[zhip] WATCHDOG: encode kernels did not finish in 120 s; aborting process\n"); abort(); }
+            }
+        }
+        return 0;
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));

@@ -95,3 +95,31 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     free(g.scratch); free(a.meta); free(a.litArena); free(a.seqArena); free(a.fallbackList);
     return nfb;
 }
+
+// ---- two-kernel encoder under emulation
+static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
+static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
+extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
+                                     uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks, uint32_t chunk)
+{
+    ZhipEncodeArgs a; memset(&a, 0, sizeof(a));
+    uint32_t counters[2] = {0, 0};
+    if (chunk == 0 || chunk > n) chunk = n ? n : 1;
+    a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
+    a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
+    a.counter = counters; a.n = n; a.level = level;
+    a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
+    free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE);
+    a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));
+    a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
+    a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
+    a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
+    for (uint32_t first = 0; first < n; first += chunk) {
+        a.first = first; a.count = n - first < chunk ? n - first : chunk;
+        counters[0] = counters[1] = 0;
+        zhemu::run_grid(nBlocks, e1_lane, &a);
+        zhemu::run_grid(nBlocks, e2_lane, &a);
+    }
+    free(a.workspace); free(a.laneTables); free(a.meta); free(a.arena);
+    return 0;
+}

@@ -60,7 +60,7 @@ class Emu:
         return outs, status.tolist()
 
 
-def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2):
+def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2, pipeline=False, chunk=0):
     n = len(raws)
     src = np.frombuffer(b"".join(raws) + b"\0" * 16, dtype=np.uint8).copy()
     src_segs = np.zeros((n, 2), dtype=np.uint64)
@@ -73,10 +73,14 @@ def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2):
     dst = np.zeros(max(d, 1) + 16, dtype=np.uint8)
     out_sizes = np.zeros(n, dtype=np.uint64)
     status = np.full(n, -1, dtype=np.int32)
-    self.lib.emu_compress_batch(src.ctypes.data_as(C.c_void_p), src_segs.ctypes.data_as(C.c_void_p), C.c_uint32(n),
-                                dst.ctypes.data_as(C.c_void_p), dst_segs.ctypes.data_as(C.c_void_p),
-                                out_sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
-                                C.c_int(level), C.c_uint32(flags), C.c_uint32(n_blocks))
+    args = [src.ctypes.data_as(C.c_void_p), src_segs.ctypes.data_as(C.c_void_p), C.c_uint32(n),
+            dst.ctypes.data_as(C.c_void_p), dst_segs.ctypes.data_as(C.c_void_p),
+            out_sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+            C.c_int(level), C.c_uint32(flags), C.c_uint32(n_blocks)]
+    if pipeline:
+        self.lib.emu_compress_pipeline(*args, C.c_uint32(chunk))
+    else:
+        self.lib.emu_compress_batch(*args)
     outs = [dst[int(dst_segs[i][0]):int(dst_segs[i][0]) + int(out_sizes[i])].tobytes() for i in range(n)]
     return outs, status.tolist()
 
