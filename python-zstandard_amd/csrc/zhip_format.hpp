@@ -95,7 +95,9 @@ struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched;
 #define ZE_ARENA_SEQ 0
 #define ZE_ARENA_LIT (8u * (ZE_SEQ_CAP + 8))
 #define ZE_ARENA_STRIDE ((size_t)ZE_ARENA_LIT + ZF_BLOCK_MAX + 256)
-#define ZE_E1_LANES 32
+#ifndef ZE_E1_LANES
+#define ZE_E1_LANES 8
+#endif
 #define ZE_CODES_STRIDE ((size_t)3 * (ZE_MAX_SEQ + 8) + 256)   // E2 only needs the symbol-code scratch per wave
 
 // ------------------------------------------------------------------------------------------------ phase-split decode pipeline

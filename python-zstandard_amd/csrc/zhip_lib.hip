@@ -443,7 +443,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     hipStream_t stream = (hipStream_t)streamv;
     size_t maxBlocks = (size_t)c->numCU * (size_t)c->encBlocksPerCU;
     uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
-    if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
     if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
     HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 4, stream));
     ZhipEncodeArgs a; memset(&a, 0, sizeof a);
@@ -459,7 +458,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));        // largest dfast tables for inputs <= 128 KiB
         const size_t chunkMax = 32768;
         const size_t chunk = n < chunkMax ? n : chunkMax;
-        size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max > 1024) g1max = 1024;
+        size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * ZE_E1_LANES > 32768) g1max = 32768 / ZE_E1_LANES;
         const size_t w1 = (chunk + ZE_E1_LANES - 1) / ZE_E1_LANES;
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
@@ -494,6 +493,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         return 0;
     }
+    if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+    a.workspace = (uint8_t*)c->encWorkspace.p;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
