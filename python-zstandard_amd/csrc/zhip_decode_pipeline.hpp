@@ -102,7 +102,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         zh_sync();
         if (zh_opaque(lane) == 0) {
             a.meta[i] = m;
-            if (m.path == 2) { const uint32_t k = zh_atomic_add(a.counters + 3, 1u); a.fallbackList[k] = f; }
+            if (m.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
         }
         zd_fence();
@@ -325,7 +325,7 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, uint8_t* ldsBase, uint32_t* llB
                                             a.seqArena + (size_t)i * ZP_SEQ_CAP, &nbSeq);
         if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
             m->path = 2;
-            const uint32_t k = zh_atomic_add(a.counters + 3, 1u); a.fallbackList[k] = f;
+            const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f;
         } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
         else m->nbSeq = nbSeq;
     }

@@ -129,7 +129,8 @@ struct ZhipPipeArgs {
     ZdMeta* meta;               // chunk-local
     uint8_t* litArena;          // chunk x ZP_LIT_STRIDE
     uint64_t* seqArena;         // chunk x ZP_SEQ_CAP
-    uint32_t* counters;         // [0] K1 work, [1] K2 work, [2] K3 work, [3] fallback list length
+    uint32_t* counters;         // [0] K1 work, [1] K2 work, [2] K3 work (per chunk slot)
+    uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk
     uint64_t maxWindowSize;

@@ -160,6 +160,7 @@ extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------ context
+#define ZHIP_NSLOT 3
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t n) {
@@ -185,6 +186,7 @@ struct zhip_ctx {
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback;
+    hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables;
     int e1PerCU = 0, e2PerCU = 0;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
@@ -248,6 +250,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 7; i++) drain_shared(c->timer[i]);
     for (int i = 0; i < 7; i++) drain_timer(c->timer[i]);
+    for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
@@ -334,32 +337,50 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (usePipeline) {
         // phase-split fast path for single-block, dictionary-less frames (zhip_decode_pipeline.hpp); everything it declines
         // lands in the fallback list consumed by the generic kernel below.
-        const size_t chunkMax = 16384;
+        // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
+        // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
+        // slots, and their LDS footprints differ, which is exactly when co-residency pays.
+        const size_t chunkMax = 8192;
         const size_t chunk = n < chunkMax ? n : chunkMax;
-        if (c->pipeMeta.reserve(chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(chunk * ZP_LIT_STRIDE) || c->pipeSeq.reserve(chunk * ZP_SEQ_STRIDE) ||
-            c->pipeCounters.reserve(64) || c->pipeFallback.reserve(n * 4 + 16)) return ZHIP_ERR_HIP;
-        HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 16, stream));
+        const size_t nChunks = (n + chunk - 1) / chunk;
+        const int nslot = (int)(nChunks < ZHIP_NSLOT ? nChunks : ZHIP_NSLOT);
+        if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
+            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16)) return ZHIP_ERR_HIP;
+        for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
+        HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 256, stream));
+        hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(evStart, stream));
+        for (int sidx = 0; sidx < nslot; sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
+        (void)hipEventDestroy(evStart);
         ZhipPipeArgs pa; memset(&pa, 0, sizeof pa);
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
-        pa.outSizes = d_outSizes; pa.status = d_status; pa.meta = (ZdMeta*)c->pipeMeta.p; pa.litArena = (uint8_t*)c->pipeLit.p;
-        pa.seqArena = (uint64_t*)c->pipeSeq.p; pa.counters = (uint32_t*)c->pipeCounters.p; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
+        pa.outSizes = d_outSizes; pa.status = d_status; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
         pa.maxWindowSize = c->maxWindowSize;
-        for (size_t first = 0; first < n; first += chunk) {
+        uint32_t* counters = (uint32_t*)c->pipeCounters.p;        // [0] = fallback length, then 4 words per slot
+        pa.fallbackCount = counters;
+        size_t ci = 0;
+        for (size_t first = 0; first < n; first += chunk, ci++) {
+            const int sidx = (int)(ci % nslot);
+            hipStream_t ss = c->slotStream[sidx];
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
-            if (first) HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 12, stream));
+            pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * chunk;
+            pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * chunk * ZP_LIT_STRIDE;
+            pa.seqArena = (uint64_t*)c->pipeSeq.p + (size_t)sidx * chunk * ZP_SEQ_CAP;
+            pa.counters = counters + 4 + 4 * sidx;
+            if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 16, ss));
             const size_t g1m = (size_t)c->numCU * c->k1PerCU, g2m = (size_t)c->numCU * c->k2PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
             const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             hipEvent_t ev[4];
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));
-            HIP_TRY(hipEventRecord(ev[0], stream));
-            hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, stream, pa);
-            HIP_TRY(hipEventRecord(ev[1], stream));
-            hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, stream, pa);
-            HIP_TRY(hipEventRecord(ev[2], stream));
-            hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, stream, pa);
-            HIP_TRY(hipEventRecord(ev[3], stream));
+            HIP_TRY(hipEventRecord(ev[0], ss));
+            hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            HIP_TRY(hipEventRecord(ev[1], ss));
+            hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            HIP_TRY(hipEventRecord(ev[2], ss));
+            hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
             // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
             // ev[0..1], K3's owns ev[2..3]; K2's pair (ev[1], ev[2]) is borrowed and always drained before any destroy.
@@ -367,7 +388,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             c->timer[3].shared.emplace_back(ev[1], ev[2]);
             c->timer[4].pending.emplace_back(ev[2], ev[3]);
         }
-        d_fallbackList = (const uint32_t*)c->pipeFallback.p; d_fallbackCount = (const uint32_t*)c->pipeCounters.p + 3;
+        for (int sidx = 0; sidx < nslot; sidx++) {                 // the caller's stream continues after every slot has drained
+            hipEvent_t evEnd; HIP_TRY(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(evEnd, c->slotStream[sidx]));
+            HIP_TRY(hipStreamWaitEvent(stream, evEnd, 0));
+            (void)hipEventDestroy(evEnd);
+        }
+        d_fallbackList = (const uint32_t*)c->pipeFallback.p; d_fallbackCount = (const uint32_t*)c->pipeCounters.p;
         // the generic kernel only sees the (usually empty) fallback list: a small grid is enough
         if (grid > 1024) grid = 1024;
     }

@@ -74,7 +74,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
     a.litArena = (uint8_t*)malloc((size_t)chunk * ZP_LIT_STRIDE);
     a.seqArena = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE);
-    a.counters = counters; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
+    a.counters = counters; a.fallbackCount = &counters[3]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
