@@ -606,29 +606,38 @@ ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst,
     }
 }
 
-// ---- up-to-32-byte moves through 4 registers: all loads are issued before any store (one memory latency per move)
+// ---- up-to-32-byte moves through 4 registers: all loads are issued before any store (one memory latency per move).
+// Branch-lean: full 8-byte words for the body, and for the tail either an overlapping 8-byte word ending exactly at
+// `len` (len >= 8) or a 4/2/1 cascade (len < 8) -- no byte loops, since a divergent loop costs its longest lane.
+// r[0..2] hold bytes [0,8) [8,16) [16,24); r[3] holds the LAST 8 bytes (overlapping) when len >= 8, else the whole run.
 ZH_DEV void zd_ld32(const uint8_t* p, uint32_t len, uint64_t r[4])
 {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        r[k] = 0;
-        if (len >= 8u * k + 8) r[k] = zh_ld64(p + 8 * k);
-        else if (len > 8u * k) {
-            uint64_t v = 0;
-            for (uint32_t i = 8u * k; i < len; i++) v |= (uint64_t)p[i] << (8 * (i - 8u * k));
-            r[k] = v;
-        }
+    r[0] = r[1] = r[2] = r[3] = 0;
+    if (len >= 8) {
+        r[0] = zh_ld64(p);
+        if (len > 16) r[1] = zh_ld64(p + 8);
+        if (len > 24) r[2] = zh_ld64(p + 16);
+        r[3] = zh_ld64(p + len - 8);
+    } else {
+        uint64_t v = 0; uint32_t o = 0;
+        if (len & 4) { v = zh_ld32(p); o = 4; }
+        if (len & 2) { v |= (uint64_t)zh_ld16(p + o) << (8 * o); o += 2; }
+        if (len & 1) { v |= (uint64_t)p[o] << (8 * o); }
+        r[3] = v;
     }
 }
 ZH_DEV void zd_st32(uint8_t* q, uint32_t len, const uint64_t r[4])
 {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (len >= 8u * k + 8) zh_st64(q + 8 * k, r[k]);
-        else if (len > 8u * k) {
-            uint64_t v = r[k];
-            for (uint32_t i = 8u * k; i < len; i++) { q[i] = (uint8_t)v; v >>= 8; }
-        }
+    if (len >= 8) {
+        zh_st64(q, r[0]);
+        if (len > 16) zh_st64(q + 8, r[1]);
+        if (len > 24) zh_st64(q + 16, r[2]);
+        zh_st64(q + len - 8, r[3]);
+    } else {
+        uint64_t v = r[3]; uint32_t o = 0;
+        if (len & 4) { zh_st32(q, (uint32_t)v); v >>= 32; o = 4; }
+        if (len & 2) { zh_st16(q + o, (uint16_t)v); v >>= 16; o += 2; }
+        if (len & 1) { q[o] = (uint8_t)v; }
     }
 }
 

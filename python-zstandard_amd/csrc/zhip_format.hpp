@@ -119,7 +119,10 @@ struct ZdMeta {
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
 #define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)
 #define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
-#define ZP_K2_LANES 16                                  // frames decoded per wave in K2 (one lane each)
+#ifndef ZP_K2_LANES
+#define ZP_K2_LANES 16
+#endif
+//                                // frames decoded per wave in K2 (one lane each)
 #define ZP_K2_LANE_LDS 2820                             // bytes of LDS per K2 lane (odd dword stride: no bank aliasing)
 
 struct ZhipPipeArgs {

@@ -160,7 +160,12 @@ extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
 }
 
 // ------------------------------------------------------------------------------------------ context
+#ifndef ZHIP_NSLOT
 #define ZHIP_NSLOT 3
+#endif
+#ifndef ZHIP_DCHUNK
+#define ZHIP_DCHUNK 8192
+#endif
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t n) {
@@ -340,7 +345,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        const size_t chunkMax = 8192;
+        const size_t chunkMax = ZHIP_DCHUNK;
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < ZHIP_NSLOT ? nChunks : ZHIP_NSLOT);
