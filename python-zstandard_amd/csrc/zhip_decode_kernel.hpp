@@ -19,6 +19,7 @@
 #pragma once
 #include "zhip_device.hpp"
 #include "zhip_format.hpp"
+#include "zhip_xxh64.hpp"
 
 #if defined(ZHIP_EMU) && defined(ZD_TRACE)
 #include <stdio.h>
@@ -1014,7 +1015,17 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
         if (lastBlock) break;
     }
     if (fcs != ~0ull && fcs != op) return ZE_CORRUPTION;
-    if (hasChecksum) { if (pos + 4 > srcSize) return ZE_CHECKSUM_WRONG; }
+    if (hasChecksum) {
+        // content checksum (zstd.c:44270-44277): low 32 bits of XXH64 over everything this frame produced
+        if (pos + 4 > srcSize) return ZE_CHECKSUM_WRONG;
+        zd_fence();
+        zh_sync();
+        if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, op);
+        zh_sync();
+        const uint32_t digest = zh_first(L.misc[0]);
+        zh_sync();
+        if (digest != zh_ld32(src + pos)) return ZE_CHECKSUM_WRONG;
+    }
     *produced = op;
     return ZE_OK;
 }

@@ -30,7 +30,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         const uint32_t f = a.first + i;
         ZdMeta m;
         m.status = 0; m.path = 0; m.seqOff = m.seqEnd = 0; m.litSize = 0; m.litMode = 0; m.litOff = 0; m.nbSeq = 0;
-        m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0;
+        m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0;
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
         uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
@@ -43,7 +43,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (srcSize < 5) { err = ZE_SRC_SIZE_WRONG; break; }
             if (zh_ld32(src) != ZF_MAGIC) { err = ZE_PREFIX_UNKNOWN; break; }
             const uint32_t fhd = src[4];
-            const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
+            const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6, hasChecksum = (fhd >> 2) & 1;
             const uint32_t dictBytes = dictCode == 3 ? 4 : dictCode;
             const uint32_t fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
             const uint32_t hs = 5 + (single ? 0 : 1) + dictBytes + fcsBytes;
@@ -79,6 +79,17 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 if (type == 0) zd_copy_wave(dst, src + pos, bs); else zd_fill_wave(dst, src[pos], bs);
                 if (fcs != ~0ull && fcs != bs) { err = ZE_CORRUPTION; break; }
                 m.produced = bs;
+                if (hasChecksum) {
+                    const uint32_t cpos = pos + (type == 0 ? bs : 1);
+                    if (cpos + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
+                    zd_fence();
+                    zh_sync();
+                    if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, bs);
+                    zh_sync();
+                    const uint32_t digest = zh_first(L.misc[0]);
+                    zh_sync();
+                    if (digest != zh_ld32(src + cpos)) { err = ZE_CHECKSUM_WRONG; break; }
+                }
                 break;
             }
             if (pos + bs > srcSize) { err = ZE_SRC_SIZE_WRONG; break; }
@@ -95,6 +106,10 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             else if (st.litPtr == lit) { m.litMode = 1; m.litOff = 0; }
             else { m.litMode = 0; m.litOff = (uint32_t)(st.litPtr - src); }
             m.seqOff = pos + (uint32_t)r; m.seqEnd = pos + bs;
+            if (hasChecksum) {
+                if (pos + bs + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
+                m.hasChecksum = 1; m.checksum = zh_ld32(src + pos + bs);
+            }
             m.path = 1;
         } while (false);
         if (fallback) { m.path = 2; }
@@ -492,6 +507,15 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     op += rest;
     const uint64_t fcs = (uint64_t)m.fcsLo | ((uint64_t)m.fcsHi << 32);
     if (fcs != ~0ull && fcs != op) return ZE_CORRUPTION;
+    if (m.hasChecksum) {
+        zd_fence();
+        zh_sync();
+        if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, op);
+        zh_sync();
+        const uint32_t digest = zh_first(L.misc[0]);
+        zh_sync();
+        if (digest != m.checksum) return ZE_CHECKSUM_WRONG;
+    }
     *pProduced = op;
     return 0;
 }

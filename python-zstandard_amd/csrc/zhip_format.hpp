@@ -114,7 +114,8 @@ struct ZdMeta {
     uint32_t blockMax;
     uint32_t fcsLo, fcsHi;  // frame content size (0xFFFFFFFF/0xFFFFFFFF when absent)
     uint32_t produced;
-    uint32_t pad[4];
+    uint32_t hasChecksum, checksum;   // content checksum to verify after execution
+    uint32_t pad[2];
 };
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
 #define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)

@@ -103,3 +103,21 @@ def test_truncated_and_corrupt_frames_do_not_crash(zstd, corpus):
             d.multi_decompress_to_buffer([b], decompressed_sizes=sizes[:8])
         except zstd.ZstdError:
             pass
+
+
+def test_content_checksum_is_verified(zstd):
+    from tests import reflib
+    if not reflib.have_ref():
+        pytest.skip("needs reference libzstd for checksum frames")
+    ref = reflib.RefZstd()
+    from tests.corpus import Corpus
+    c = Corpus()
+    raws = [b"a" * 1000, c.frame_bytes(7), c.frame_bytes(8)[:5000], b"".join(c.frame_bytes(i) for i in range(2))]
+    frames = [ref.compress(r, flags=reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM) for r in raws]
+    res = zstd.ZstdDecompressor().multi_decompress_to_buffer(frames)
+    assert [res[i].tobytes() for i in range(len(raws))] == raws
+    for k in range(len(frames)):
+        bad = list(frames)
+        bad[k] = bad[k][:-2] + bytes([bad[k][-2] ^ 0x20]) + bad[k][-1:]
+        with pytest.raises(zstd.ZstdError, match="error decompressing item %d: Restored data doesn't match checksum" % k):
+            zstd.ZstdDecompressor().multi_decompress_to_buffer(bad)
