@@ -77,4 +77,6 @@ uint64_t zo_xxh64(const void* data, size_t len, uint64_t seed);
 int zo_fse_read_ncount(int16_t* norm, unsigned* maxSymbol, unsigned* tableLog,
                        const uint8_t* src, size_t srcSize);
 
+int zo_huf_read_weights(uint8_t* w, unsigned* count, unsigned* log, const uint8_t* src, size_t srcSize);
+
 #endif

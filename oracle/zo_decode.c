@@ -251,6 +251,24 @@ static int huf_read_table(huf_dtable* ht, const uint8_t* src, size_t srcSize)
     return (int)used;
 }
 
+/* tree description -> complete weight list (implied last weight included); shared with the encoder's dictionary loader.
+ * Returns bytes consumed; *count = number of symbols, *log = table log. */
+int zo_huf_read_weights(uint8_t* w, unsigned* count, unsigned* log, const uint8_t* src, size_t srcSize)
+{
+    huf_dtable* ht = (huf_dtable*)malloc(sizeof(huf_dtable));
+    if (!ht) return -ZO_E_MEMORY;
+    int r = huf_read_table(ht, src, srcSize);
+    if (r >= 0) {
+        /* recover weights from the decode table: nb = log + 1 - weight for every symbol present */
+        unsigned maxSym = 0;
+        memset(w, 0, 256);
+        for (unsigned i = 0; i < (1u << ht->log); i++) { unsigned s = ht->cell[i].sym; w[s] = (uint8_t)(ht->log + 1 - ht->cell[i].nb); if (s > maxSym) maxSym = s; }
+        *count = maxSym + 1; *log = (unsigned)ht->log;
+    }
+    free(ht);
+    return r;
+}
+
 static int huf_decode_stream(uint8_t* dst, size_t n, const uint8_t* src, size_t srcSize, const huf_dtable* ht)
 {
     bwd_bits b; int e = bwd_init(&b, src, srcSize); if (e < 0) return -ZO_E_CORRUPTION;

@@ -454,8 +454,98 @@ static size_t zo_raw_literals(uint8_t* out, const uint8_t* lit, size_t n, unsign
     return fl + n;
 }
 
-static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit, size_t n, size_t nbSeq)
+/* entropy tables inherited from a dictionary (the only "previous block" a single-block frame can have):
+ * repeat modes follow libzstd: 0 none, 1 check (usable if it covers the data), 2 valid (zstd.c:3097-3101, FSE_repeat) */
+typedef struct { huf_ctab huf; int hufRepeat; fse_ctab ll, of, ml; int llRepeat, ofRepeat, mlRepeat; } zo_entropy;
+
+static size_t huf_estimate(const huf_ctab* ct, const unsigned* count, unsigned maxSym)
 {
+    size_t bits = 0;
+    for (unsigned s = 0; s <= maxSym; s++) bits += (size_t)ct->nbBits[s] * count[s];
+    return bits >> 3;
+}
+static int huf_validate(const huf_ctab* ct, const unsigned* count, unsigned maxSym)
+{
+    if (ct->maxSym < maxSym) return 0;
+    for (unsigned s = 0; s <= maxSym; s++) if (count[s] && !ct->nbBits[s]) return 0;
+    return 1;
+}
+
+static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit, size_t n, size_t nbSeq, const zo_entropy* prev)
+{
+    if (prev && prev->hufRepeat) {
+        /* ZSTD_compressLiterals + HUF_compress_internal with a candidate previous table (zstd.c:20932, :18089) */
+        const size_t lh = 3 + (n >= 1024) + (n >= 16384);
+        int single = n < 256;
+        int repeat = prev->hufRepeat;
+        const size_t minLits = repeat == 2 ? 6 : 64;
+        if (n < minLits) return zo_raw_literals(out, lit, n, 0, 0);
+        const int suspect = (nbSeq == 0) || (n / nbSeq >= 20);
+        const int preferRepeat = n <= 1024;
+        if (repeat == 2 && lh == 3) single = 1;
+        uint8_t* body = out + lh;
+        const size_t bcap = cap - lh;
+        size_t cl = 0; int useOld = 0, done = 0, rle = 0;
+        huf_ctab nt; size_t h = 0;
+        unsigned count[256]; unsigned maxSym = 0, largest = 0;
+        if (preferRepeat && repeat == 2) { useOld = 1; }
+        else {
+            if (suspect && n >= 4096 * 10) {
+                unsigned a = 0, b = 0; unsigned c[256];
+                memset(c, 0, sizeof c); for (size_t i = 0; i < 4096; i++) c[lit[i]]++;
+                for (int s2 = 0; s2 < 256; s2++) if (c[s2] > a) a = c[s2];
+                memset(c, 0, sizeof c); for (size_t i = n - 4096; i < n; i++) c[lit[i]]++;
+                for (int s2 = 0; s2 < 256; s2++) if (c[s2] > b) b = c[s2];
+                if (a + b <= ((2 * 4096) >> 7) + 4) { done = 1; cl = 0; }
+            }
+            if (!done) {
+                memset(count, 0, sizeof count);
+                for (size_t i = 0; i < n; i++) count[lit[i]]++;
+                for (unsigned s2 = 0; s2 < 256; s2++) { if (count[s2]) maxSym = s2; if (count[s2] > largest) largest = count[s2]; }
+                if (largest == n) { done = 1; rle = 1; }
+                else if (largest <= (n >> 7) + 4) { done = 1; cl = 0; }
+            }
+            if (!done) {
+                if (repeat == 1 && !huf_validate(&prev->huf, count, maxSym)) repeat = 0;
+                if (preferRepeat && repeat != 0) useOld = 1;
+                else {
+                    unsigned log = fse_optimal_log(11, n, maxSym, 1);
+                    huf_build(&nt, count, maxSym, log);
+                    h = huf_write_table(body, &nt);
+                    if (h == 0) { done = 1; cl = 0; }       /* table cannot be described: error -> raw literals */
+                    else if (repeat != 0) {
+                        size_t oldSize = huf_estimate(&prev->huf, count, maxSym), newSize = huf_estimate(&nt, count, maxSym);
+                        if (oldSize <= h + newSize || h + 12 >= n) useOld = 1;
+                    }
+                    if (!done && !useOld) {
+                        if (h + 12 >= n) { done = 1; cl = 0; }
+                        else {
+                            repeat = 0;
+                            size_t c = single ? huf_encode_1x(body + h, bcap - h, lit, n, &nt) : huf_encode_4x(body + h, bcap - h, lit, n, &nt);
+                            cl = c ? h + c : 0; if (cl >= n - 1) cl = 0;
+                            done = 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (!done && useOld) {
+            size_t c = single ? huf_encode_1x(body, bcap, lit, n, &prev->huf) : huf_encode_4x(body, bcap, lit, n, &prev->huf);
+            cl = c; if (cl >= n - 1) cl = 0;
+        }
+        if (rle) return zo_raw_literals(out, lit, n, 1, 1);
+        if (cl == 0 || cl >= n - ((n >> 6) + 2)) return zo_raw_literals(out, lit, n, 0, 0);
+        if (cl == 1) {
+            int same = 1; for (size_t i = 1; i < n; i++) if (lit[i] != lit[0]) { same = 0; break; }
+            if (n >= 8 || same) return zo_raw_literals(out, lit, n, 1, 1);
+        }
+        const unsigned hType = repeat != 0 ? 3u : 2u;
+        if (lh == 3) { uint32_t v = hType + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 14); zo_wr24(out, v); }
+        else if (lh == 4) { zo_wr32(out, hType + (2u << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 18)); }
+        else { zo_wr32(out, hType + (3u << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 22)); out[4] = (uint8_t)(cl >> 10); }
+        return lh + cl;
+    }
+
     const size_t lh = 3 + (n >= 1024) + (n >= 16384);
     const int single = n < 256;
     if (n < 64) return zo_raw_literals(out, lit, n, 0, 0);           /* dfast, no previous table: 8 << 3 */
@@ -605,30 +695,302 @@ static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8
     return nseq;
 }
 
+
+/* ------------------------------------------------------------------ dictionary (attached CDict, sources <= 16 KiB) */
+/* Restates: ZSTD_createCDict_advanced2 (zstd.c:28614) parameters, ZSTD_loadCEntropy (:28015), ZSTD_loadDictionaryContent (:27895),
+ * ZSTD_fillDoubleHashTableForCDict (:30952, tagged cells :20636), ZSTD_resetCCtx_byAttachingCDict (:25279) and
+ * ZSTD_compressBlock_doubleFast_dictMatchState_generic (:31262). Index space: dictionary content byte k has index 2 + k, the
+ * source starts right after it (index CE = 2 + contentSize), so offsets are plain index differences. */
+typedef struct {
+    zo_cpar cp;                                  /* parameters the CDict tables were built with */
+    uint32_t* hashLong; uint32_t* hashSmall;     /* cell = index << 8 | tag */
+    const uint8_t* content; size_t contentSize;
+    uint32_t dictID;
+    uint32_t rep[3];
+    zo_entropy ent;                              /* hufRepeat == 0 and *Repeat == 0 for raw-content dictionaries */
+} zo_cdict;
+
+static void zo_cdict_free(zo_cdict* d) { if (d) { free(d->hashLong); free(d->hashSmall); free(d); } }
+
+static int zo_cdict_params(zo_cpar* out, int level, size_t dictSize)
+{
+    if (level == 0) level = 3;
+    if (level < 1 || level > 4) return -ZO_E_PARAM_UNSUPPORTED;
+    uint64_t rSize = (uint64_t)dictSize + 499;                  /* unknown source size: "size hint" wraps to dictSize + 499 */
+    unsigned tableID = (rSize <= 256u * 1024) + (rSize <= 128u * 1024) + (rSize <= 16u * 1024);
+    zo_cpar c = zo_rows[tableID][level];
+    const uint64_t srcSize = 513;                               /* createCDict mode assumes a small source */
+    uint32_t t = (uint32_t)(srcSize + dictSize);
+    int srcLog = (t < 64) ? 6 : zo_highbit(t - 1) + 1;
+    if (c.wlog > srcLog) c.wlog = srcLog;
+    {   uint64_t windowSize = 1ull << c.wlog;
+        int dawl = c.wlog;
+        if (windowSize < dictSize + srcSize) { uint64_t dw = dictSize + windowSize; dawl = dw >= (1ull << 31) ? 31 : zo_highbit((uint32_t)dw - 1) + 1; }
+        if (c.hlog > dawl + 1) c.hlog = dawl + 1;
+        if (c.clog > dawl) c.clog = dawl;
+    }
+    if (c.wlog < 10) c.wlog = 10;
+    if (c.hlog > 24) c.hlog = 24;
+    if (c.clog > 24) c.clog = 24;
+    *out = c;
+    return 0;
+}
+
+static void huf_ctab_from_weights(huf_ctab* ct, const uint8_t* w, unsigned count, unsigned log)
+{
+    /* HUF_readCTable (zstd.c:17048): lengths from weights, canonical values per rank in symbol order */
+    uint16_t perRank[16] = {0}, start[16] = {0};
+    memset(ct->nbBits, 0, sizeof ct->nbBits); memset(ct->code, 0, sizeof ct->code);
+    for (unsigned s = 0; s < count; s++) { ct->nbBits[s] = w[s] ? (uint8_t)(log + 1 - w[s]) : 0; perRank[ct->nbBits[s]]++; }
+    { uint16_t min = 0; for (int r = (int)log; r > 0; r--) { start[r] = min; min = (uint16_t)((min + perRank[r]) >> 1); } }
+    for (unsigned s = 0; s < count; s++) ct->code[s] = ct->nbBits[s] ? start[ct->nbBits[s]]++ : 0;
+    ct->maxSym = count - 1; ct->log = log;
+}
+
+static int ncount_repeat(const int16_t* norm, unsigned dictMax, unsigned needMax)
+{
+    if (dictMax < needMax) return 1;
+    for (unsigned s = 0; s <= needMax; s++) if (norm[s] == 0) return 1;
+    return 2;
+}
+
+static zo_cdict* zo_cdict_create(const uint8_t* dict, size_t dictSize, int level, int* err)
+{
+    zo_cdict* d = (zo_cdict*)calloc(1, sizeof(zo_cdict));
+    if (!d) { *err = -ZO_E_MEMORY; return NULL; }
+    *err = zo_cdict_params(&d->cp, level, dictSize);
+    if (*err < 0 || d->cp.strat != 2) { if (*err >= 0) *err = -ZO_E_PARAM_UNSUPPORTED; free(d); return NULL; }
+    d->rep[0] = 1; d->rep[1] = 4; d->rep[2] = 8;
+    const uint8_t* p = dict; const uint8_t* end = dict + dictSize;
+    if (dictSize >= 8 && zo_rd32(dict) == ZO_DICT_MAGIC) {
+        d->dictID = zo_rd32(dict + 4);
+        p += 8;
+        uint8_t w[256]; unsigned cnt, log;
+        int r = zo_huf_read_weights(w, &cnt, &log, p, (size_t)(end - p));
+        if (r < 0 || log > 12) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; }
+        huf_ctab_from_weights(&d->ent.huf, w, cnt, log);
+        { int zero = 0; for (unsigned s2 = 0; s2 < cnt; s2++) zero |= (w[s2] == 0); d->ent.hufRepeat = (!zero && cnt == 256) ? 2 : 1; }
+        p += r;
+        int16_t ofN[64], mlN[64], llN[64]; unsigned ofMax = ZO_MAXOFF, mlMax = ZO_MAXML, llMax = ZO_MAXLL, ofLog, mlLog, llLog;
+        memset(ofN, 0, sizeof ofN); memset(mlN, 0, sizeof mlN); memset(llN, 0, sizeof llN);
+        r = zo_fse_read_ncount(ofN, &ofMax, &ofLog, p, (size_t)(end - p)); if (r < 0 || ofLog > 8) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; } p += r;
+        fse_build_ctab(&d->ent.of, ofN, ZO_MAXOFF, ofLog);              /* all offset symbols, like the reference */
+        r = zo_fse_read_ncount(mlN, &mlMax, &mlLog, p, (size_t)(end - p)); if (r < 0 || mlLog > 9) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; } p += r;
+        fse_build_ctab(&d->ent.ml, mlN, mlMax, mlLog);
+        d->ent.mlRepeat = ncount_repeat(mlN, mlMax, ZO_MAXML);
+        r = zo_fse_read_ncount(llN, &llMax, &llLog, p, (size_t)(end - p)); if (r < 0 || llLog > 9) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; } p += r;
+        fse_build_ctab(&d->ent.ll, llN, llMax, llLog);
+        d->ent.llRepeat = ncount_repeat(llN, llMax, ZO_MAXLL);
+        if (p + 12 > end) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; }
+        for (int i = 0; i < 3; i++) d->rep[i] = zo_rd32(p + 4 * i);
+        p += 12;
+        size_t cs = (size_t)(end - p);
+        { unsigned offcodeMax = ZO_MAXOFF; uint32_t maxOffset = (uint32_t)cs + 128 * 1024; offcodeMax = (unsigned)zo_highbit(maxOffset);
+          d->ent.ofRepeat = ncount_repeat(ofN, ofMax, offcodeMax < ZO_MAXOFF ? offcodeMax : ZO_MAXOFF); }
+        for (int i = 0; i < 3; i++) if (d->rep[i] == 0 || d->rep[i] > cs) { *err = -ZO_E_DICT_CORRUPTED; free(d); return NULL; }
+    }
+    d->content = p; d->contentSize = (size_t)(end - p);
+    d->hashLong = (uint32_t*)calloc((size_t)1 << d->cp.hlog, 4);
+    d->hashSmall = (uint32_t*)calloc((size_t)1 << d->cp.clog, 4);
+    if (!d->hashLong || !d->hashSmall) { *err = -ZO_E_MEMORY; zo_cdict_free(d); return NULL; }
+    /* index only the tail the tables can reasonably address; every third position into both tables, the two in between
+     * into the long table when its cell is still empty */
+    {   size_t cs = d->contentSize, startOff = 0;
+        int mx = d->cp.hlog + 3 > d->cp.clog + 1 ? d->cp.hlog + 3 : d->cp.clog + 1; if (mx > 31) mx = 31;
+        size_t maxDict = (size_t)1 << mx;
+        if (cs > maxDict) startOff = cs - maxDict;
+        if (cs - startOff > 8) {
+            const uint8_t* base = d->content - 2;
+            const int mls = d->cp.mml <= 4 ? 4 : d->cp.mml >= 7 ? 7 : d->cp.mml;
+            const uint8_t* ip = d->content + startOff; const uint8_t* iend = d->content + cs - 8;
+            for (; ip + 2 <= iend; ip += 3) {
+                uint32_t curr = (uint32_t)(ip - base);
+                for (uint32_t i = 0; i < 3; i++) {
+                    uint32_t sm = hash_n(ip + i, d->cp.clog + 8, mls), lg = hash_n(ip + i, d->cp.hlog + 8, 8);
+                    if (i == 0) d->hashSmall[sm >> 8] = ((curr + i) << 8) | (sm & 255);
+                    if (i == 0 || d->hashLong[lg >> 8] == 0) d->hashLong[lg >> 8] = ((curr + i) << 8) | (lg & 255);
+                }
+            }
+        }
+    }
+    return d;
+}
+
+/* byte at unified index i (dictionary content below CE, source at and above it) */
+typedef struct { const uint8_t* content; const uint8_t* src; uint32_t CE; uint32_t end; } zo_space;
+static inline uint8_t sp_byte(const zo_space* sp, uint32_t i) { return i < sp->CE ? sp->content[i - 2] : sp->src[i - sp->CE]; }
+static inline uint32_t sp_rd32(const zo_space* sp, uint32_t i)
+{
+    if (i >= sp->CE) return zo_rd32(sp->src + (i - sp->CE));
+    if (i + 4 <= sp->CE) return zo_rd32(sp->content + (i - 2));
+    uint32_t v = 0; for (int k = 0; k < 4; k++) v |= (uint32_t)sp_byte(sp, i + k) << (8 * k); return v;
+}
+static inline uint64_t sp_rd64(const zo_space* sp, uint32_t i)
+{
+    if (i >= sp->CE) return zo_rd64(sp->src + (i - sp->CE));
+    if (i + 8 <= sp->CE) return zo_rd64(sp->content + (i - 2));
+    uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)sp_byte(sp, i + k) << (8 * k); return v;
+}
+/* common length of source position ip (index) and match index m, the match continuing from the dictionary end into the
+ * source start (ZSTD_count_2segments, zstd.c:20034) */
+static uint32_t sp_count(const zo_space* sp, uint32_t ip, uint32_t m)
+{
+    uint32_t n = 0;
+    while (ip + n < sp->end && sp_byte(sp, ip + n) == sp_byte(sp, m + n)) n++;
+    return n;
+}
+
+static size_t zo_dfast_dict(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
+                            const zo_cdict* d, uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const int hl = cp->hlog, hs = cp->clog;
+    const int mls = cp->mml <= 4 ? 4 : cp->mml >= 7 ? 7 : cp->mml;
+    const uint32_t CE = 2 + (uint32_t)d->contentSize;          /* prefixLowestIndex == first source index */
+    const uint32_t dictStart = 2;
+    zo_space sp = { d->content, src, CE, CE + (uint32_t)srcSize };
+    const int dhl = d->cp.hlog + 8, dhs = d->cp.clog + 8;
+    const uint32_t iend = CE + (uint32_t)srcSize;
+    uint32_t ip = CE, anchor = CE;
+    uint32_t off1 = d->rep[0], off2 = d->rep[1];
+    size_t nseq = 0; uint8_t* lp = lits;
+    memset(hashLong, 0, sizeof(uint32_t) << hl);
+    memset(hashSmall, 0, sizeof(uint32_t) << hs);
+    if (srcSize < 8) { memcpy(lp, src, srcSize); *litSize = srcSize; return 0; }
+    const uint32_t ilimit = iend - 8;
+#define SRC(i) (src + ((i) - CE))
+#define STORE(LL, OFFBASE, ML) do { size_t ll_ = (LL); memcpy(lp, SRC(anchor), ll_); lp += ll_; \
+        seqs[nseq].litLength = (uint32_t)ll_; seqs[nseq].offBase = (OFFBASE); seqs[nseq].matchLength = (uint32_t)(ML); nseq++; } while (0)
+    while (ip < ilimit) {
+        uint32_t mLength = 0, offset = 0;
+        const uint32_t h2 = hash_n(SRC(ip), hl, 8), h = hash_n(SRC(ip), hs, mls);
+        const uint32_t dTagL = hash_n(SRC(ip), dhl, 8), dTagS = hash_n(SRC(ip), dhs, mls);
+        const uint32_t dEntL = d->hashLong[dTagL >> 8], dEntS = d->hashSmall[dTagS >> 8];
+        const int tagL = (dEntL & 255) == (dTagL & 255), tagS = (dEntS & 255) == (dTagS & 255);
+        const uint32_t curr = ip;
+        const uint32_t mIdxL = hashLong[h2]; uint32_t mIdxS = hashSmall[h];
+        const uint32_t repIndex = curr + 1 - off1;
+        hashLong[h2] = hashSmall[h] = curr;
+        int found = 0;          /* 1 repcode stored, 2 offset match */
+        if (((uint32_t)((CE - 1) - repIndex) >= 3) && sp_rd32(&sp, repIndex) == zo_rd32(SRC(ip + 1))) {
+            mLength = sp_count(&sp, ip + 1 + 4, repIndex + 4) + 4;
+            ip++;
+            STORE(ip - anchor, 1, mLength);
+            found = 1;
+        } else {
+            int shortCand = 0; uint32_t match = 0;
+            if (mIdxL >= CE && zo_rd64(SRC(mIdxL)) == zo_rd64(SRC(ip))) {
+                uint32_t m = mIdxL;
+                mLength = sp_count(&sp, ip + 8, m + 8) + 8;
+                offset = ip - m;
+                while (ip > anchor && m > CE && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; }
+                found = 2;
+            } else if (tagL) {
+                uint32_t m = dEntL >> 8;
+                if (m > dictStart && sp_rd64(&sp, m) == zo_rd64(SRC(ip))) {
+                    mLength = sp_count(&sp, ip + 8, m + 8) + 8;
+                    offset = curr - m;
+                    while (ip > anchor && m > dictStart && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; }
+                    found = 2;
+                }
+            }
+            if (!found) {
+                if (mIdxS > CE) { if (zo_rd32(SRC(mIdxS)) == zo_rd32(SRC(ip))) { shortCand = 1; match = mIdxS; } }
+                else if (tagS) {
+                    match = dEntS >> 8; mIdxS = match;
+                    if (match > dictStart && sp_rd32(&sp, match) == zo_rd32(SRC(ip))) shortCand = 1;
+                }
+                if (!shortCand) { ip += ((ip - anchor) >> 8) + 1; continue; }
+                /* a short match exists: first try a long match one position later */
+                {   const uint32_t hl3 = hash_n(SRC(ip + 1), hl, 8), dTagL3 = hash_n(SRC(ip + 1), dhl, 8);
+                    const uint32_t mIdxL3 = hashLong[hl3], dEntL3 = d->hashLong[dTagL3 >> 8];
+                    const int tagL3 = (dEntL3 & 255) == (dTagL3 & 255);
+                    hashLong[hl3] = curr + 1;
+                    if (mIdxL3 >= CE && zo_rd64(SRC(mIdxL3)) == zo_rd64(SRC(ip + 1))) {
+                        uint32_t m = mIdxL3;
+                        mLength = sp_count(&sp, ip + 9, m + 8) + 8;
+                        ip++;
+                        offset = ip - m;
+                        while (ip > anchor && m > CE && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; }
+                        found = 2;
+                    } else if (tagL3) {
+                        uint32_t m = dEntL3 >> 8;
+                        if (m > dictStart && sp_rd64(&sp, m) == zo_rd64(SRC(ip + 1))) {
+                            mLength = sp_count(&sp, ip + 1 + 8, m + 8) + 8;
+                            ip++;
+                            offset = curr + 1 - m;
+                            while (ip > anchor && m > dictStart && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; }
+                            found = 2;
+                        }
+                    }
+                }
+                if (!found) {
+                    uint32_t m = match;
+                    mLength = sp_count(&sp, ip + 4, m + 4) + 4;
+                    offset = curr - mIdxS;
+                    if (mIdxS < CE) { while (ip > anchor && m > dictStart && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; } }
+                    else { while (ip > anchor && m > CE && sp_byte(&sp, ip - 1) == sp_byte(&sp, m - 1)) { ip--; m--; mLength++; } }
+                    found = 2;
+                }
+            }
+            off2 = off1; off1 = offset;
+            STORE(ip - anchor, offset + 3, mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            const uint32_t ins = curr + 2;
+            hashLong[hash_n(SRC(ins), hl, 8)] = ins;
+            hashLong[hash_n(SRC(ip - 2), hl, 8)] = ip - 2;
+            hashSmall[hash_n(SRC(ins), hs, mls)] = ins;
+            hashSmall[hash_n(SRC(ip - 1), hs, mls)] = ip - 1;
+            while (ip <= ilimit) {
+                const uint32_t rep2 = ip - off2;
+                if (((uint32_t)((CE - 1) - rep2) >= 3) && sp_rd32(&sp, rep2) == zo_rd32(SRC(ip))) {
+                    const uint32_t r = sp_count(&sp, ip + 4, rep2 + 4) + 4;
+                    uint32_t t = off2; off2 = off1; off1 = t;
+                    STORE(0, 1, r);
+                    hashSmall[hash_n(SRC(ip), hs, mls)] = ip;
+                    hashLong[hash_n(SRC(ip), hl, 8)] = ip;
+                    ip += r; anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+#undef STORE
+    { size_t last = (size_t)(iend - anchor); memcpy(lp, SRC(anchor), last); lp += last; }
+#undef SRC
+    *litSize = (size_t)(lp - lits);
+    return nseq;
+}
+
 /* ------------------------------------------------------------------ sequences section */
 static unsigned ll_code(uint32_t v) { unsigned c = 35; while (zo_ll_base[c] > v) c--; return c; }
 static unsigned ml_code(uint32_t ml) { unsigned c = 52; while (zo_ml_base[c] > ml) c--; return c; }
 
 /* picks basic / rle / compressed exactly like the reference does for strategies below "lazy" on a first block */
-static int select_mode(const unsigned* count, unsigned max, unsigned mostFrequent, size_t nbSeq, unsigned defLog, int defaultAllowed)
+static int select_mode(const unsigned* count, unsigned max, unsigned mostFrequent, size_t nbSeq, unsigned defLog, int defaultAllowed, int repeatMode)
 {
     (void)count; (void)max;
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
         size_t dynMin = (((size_t)1 << defLog) * 8) >> 3;     /* mult = 10 - strategy(2) */
+        if (repeatMode == 2 && nbSeq < 1000) return 3;         /* set_repeat: the dictionary's table is known to cover everything */
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) return 0;
     }
     return 2;
 }
 
 static size_t build_seq_table(fse_ctab* t, uint8_t* out, int* mode, const uint8_t* codes, size_t nbSeq, unsigned maxCode,
-                              unsigned fseLog, const int16_t* defNorm, unsigned defLog, unsigned defMax, int allowDefaultIfMaxLE)
+                              unsigned fseLog, const int16_t* defNorm, unsigned defLog, unsigned defMax, int allowDefaultIfMaxLE,
+                              const fse_ctab* prevTab, int prevRepeat)
 {
     unsigned count[64] = {0}, max = 0, most = 0;
     for (size_t i = 0; i < nbSeq; i++) count[codes[i]]++;
     for (unsigned s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
     int defaultAllowed = allowDefaultIfMaxLE < 0 ? 1 : (max <= (unsigned)allowDefaultIfMaxLE);
-    *mode = select_mode(count, max, most, nbSeq, defLog, defaultAllowed);
+    *mode = select_mode(count, max, most, nbSeq, defLog, defaultAllowed, prevTab ? prevRepeat : 0);
+    if (*mode == 3) { *t = *prevTab; return 0; }
     if (*mode == 1) { fse_build_rle(t, codes[0]); out[0] = codes[0]; return 1; }
     if (*mode == 0) { fse_build_ctab(t, defNorm, defMax, defLog); return 0; }
     unsigned log = fse_optimal_log(fseLog, nbSeq, max, 2);
@@ -643,8 +1005,9 @@ static size_t build_seq_table(fse_ctab* t, uint8_t* out, int* mode, const uint8_
 
 /* ------------------------------------------------------------------ one block */
 /* returns compressed body size, or 0 when the block must be stored raw */
-static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, size_t srcSize, const zo_cpar* cp)
+static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, size_t srcSize, const zo_cpar* cp, const zo_cdict* cd)
 {
+    const zo_entropy* prev = cd ? &cd->ent : NULL;
     if (srcSize < 7) return 0;
     size_t result = 0;
     zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (srcSize / 3 + 8));
@@ -656,9 +1019,10 @@ static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, si
     if (!seqs || !lits || !codes || !hashLong || !hashSmall || !tabs) goto done;
     {
         size_t litSize = 0;
-        size_t nbSeq = zo_dfast(seqs, lits, &litSize, src, srcSize, cp, hashLong, hashSmall);
+        size_t nbSeq = cd ? zo_dfast_dict(seqs, lits, &litSize, src, srcSize, cp, cd, hashLong, hashSmall)
+                          : zo_dfast(seqs, lits, &litSize, src, srcSize, cp, hashLong, hashSmall);
         uint8_t* op = out;
-        op += zo_compress_literals(op, cap, lits, litSize, nbSeq);
+        op += zo_compress_literals(op, cap, lits, litSize, nbSeq, prev);
         if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
         else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
         else { op[0] = 0xFF; zo_wr16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
@@ -671,9 +1035,9 @@ static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, si
             }
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; size_t lastCount = 0, h;
-            h = build_seq_table(&tabs[0], op, &mLL, llc, nbSeq, 35, 9, zo_ll_defnorm, 6, 35, -1); if (mLL == 2) lastCount = h; op += h;
-            h = build_seq_table(&tabs[1], op, &mOF, ofc, nbSeq, 31, 8, zo_of_defnorm, 5, 28, 28); if (mOF == 2) lastCount = h; op += h;
-            h = build_seq_table(&tabs[2], op, &mML, mlc, nbSeq, 52, 9, zo_ml_defnorm, 6, 52, -1); if (mML == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[0], op, &mLL, llc, nbSeq, 35, 9, zo_ll_defnorm, 6, 35, -1, prev ? &prev->ll : NULL, prev ? prev->llRepeat : 0); if (mLL == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[1], op, &mOF, ofc, nbSeq, 31, 8, zo_of_defnorm, 5, 28, 28, prev ? &prev->of : NULL, prev ? prev->ofRepeat : 0); if (mOF == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[2], op, &mML, mlc, nbSeq, 52, 9, zo_ml_defnorm, 6, 52, -1, prev ? &prev->ml : NULL, prev ? prev->mlRepeat : 0); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
             /* three interleaved states, sequences visited last to first; per sequence OF state, ML state, LL state,
              * then LL, ML, OF extra bits (the decoder reads them in the opposite order) */
@@ -713,11 +1077,25 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
                           const void* dict, size_t dictSize)
 {
     uint8_t* dst = (uint8_t*)dstv; const uint8_t* src = (const uint8_t*)srcv;
-    if (dict && dictSize) return -ZO_E_PARAM_UNSUPPORTED;
     if (srcSize > ZO_BLOCK_MAX) return -ZO_E_PARAM_UNSUPPORTED;
     if (dstCap < zo_compress_bound(srcSize)) return -ZO_E_DST_TOO_SMALL;
     zo_cpar cp; int e = zo_get_cparams(&cp, level, srcSize); if (e < 0) return e;
-    if (cp.strat != 2) return -ZO_E_PARAM_UNSUPPORTED;
+    zo_cdict* cd = NULL;
+    if (dict && dictSize) {
+        /* only the attached-CDict mode (sources <= 16 KiB for double-fast, zstd.c:25235-25276) is restated */
+        if (dictSize < 8 || srcSize > 16 * 1024) return -ZO_E_PARAM_UNSUPPORTED;
+        cd = zo_cdict_create((const uint8_t*)dict, dictSize, level, &e);
+        if (!cd) return e;
+        /* working tables: the CDict's parameters shrunk to the source; the frame keeps the window log chosen for the source */
+        zo_cpar w = cd->cp;
+        uint32_t t = (uint32_t)srcSize; int srcLog = (t < 64) ? 6 : zo_highbit(t - 1) + 1;
+        if (w.wlog > srcLog) w.wlog = srcLog;
+        if (w.hlog > w.wlog + 1) w.hlog = w.wlog + 1;
+        if (w.clog > w.wlog) w.clog = w.wlog;
+        w.wlog = cp.wlog;
+        cp = w;
+    }
+    if (cp.strat != 2) { zo_cdict_free(cd); return -ZO_E_PARAM_UNSUPPORTED; }
     /* frame header */
     size_t pos = 0;
     const int contentSize = (flags & ZO_F_CONTENTSIZE) != 0, checksum = (flags & ZO_F_CHECKSUM) != 0;
@@ -725,8 +1103,13 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
     const int single = contentSize && windowSize >= srcSize;
     const unsigned fcsCode = contentSize ? (srcSize >= 256) + (srcSize >= 65536 + 256) + (srcSize >= 0xFFFFFFFFu) : 0;
     zo_wr32(dst, ZO_MAGIC); pos = 4;
-    dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+    const uint32_t dictID = (cd && (flags & ZO_F_DICTID)) ? cd->dictID : 0;
+    const unsigned dictCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
+    dst[pos++] = (uint8_t)(dictCode + (checksum << 2) + (single << 5) + (fcsCode << 6));
     if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
+    if (dictCode == 1) dst[pos++] = (uint8_t)dictID;
+    else if (dictCode == 2) { zo_wr16(dst + pos, (uint16_t)dictID); pos += 2; }
+    else if (dictCode == 3) { zo_wr32(dst + pos, dictID); pos += 4; }
     if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
     else if (fcsCode == 1) { zo_wr16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
     else if (fcsCode == 2) { zo_wr32(dst + pos, (uint32_t)srcSize); pos += 4; }
@@ -734,10 +1117,11 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
     /* the single block (or the empty last block of an empty frame) */
     if (srcSize == 0) { zo_wr24(dst + pos, 1); pos += 3; }
     else {
-        size_t c = zo_compress_block(dst + pos + 3, dstCap - pos - 3, src, srcSize, &cp);
+        size_t c = zo_compress_block(dst + pos + 3, dstCap - pos - 3, src, srcSize, &cp, cd);
         if (c == 0) { zo_wr24(dst + pos, 1 + (0 << 1) + ((uint32_t)srcSize << 3)); memcpy(dst + pos + 3, src, srcSize); pos += 3 + srcSize; }
         else { zo_wr24(dst + pos, 1 + (2 << 1) + ((uint32_t)c << 3)); pos += 3 + c; }
     }
     if (checksum) { zo_wr32(dst + pos, (uint32_t)zo_xxh64(src, srcSize, 0)); pos += 4; }
+    zo_cdict_free(cd);
     return (int64_t)pos;
 }
