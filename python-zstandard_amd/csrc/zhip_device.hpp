@@ -35,6 +35,7 @@ ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfir
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_wave_max(uint32_t v) { for (int d = 32; d; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; } return v; }
 ZH_DEV void ze_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -94,6 +95,7 @@ ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __sync_fetch_and_add(p, v); }
+ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { (*p)++; }
 ZH_DEV uint32_t zh_wave_max(uint32_t v)

@@ -35,13 +35,6 @@ ZH_CONST int8_t ze_rows[4][5][7] = {
     {{14,12,13,1,5,1,1},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3}},
 };
 
-struct ZeCTab {                 // FSE encoding table: per symbol, its cells in table order
-    int32_t log;
-    uint32_t maxSym;
-    int16_t norm[64];
-    uint16_t cellOf[66];
-    uint16_t next[512];
-};
 struct ZeNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
 
 struct ZeLDS {
@@ -448,104 +441,139 @@ ZH_DEVFN uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n
     return fl + n;
 }
 
-// ZSTD_compressLiterals (zstd.c:20932) + HUF_compress_internal (:18089) on a first block (no previous table).
+// ZSTD_compressLiterals (zstd.c:20932) + HUF_compress_internal (:18089). The only "previous" Huffman table a single-block
+// frame can have is the dictionary's (cd, may be null): repeat 0 none, 1 usable after validation, 2 valid.
 // All lanes call; returns the literals-section size (uniform).
-ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq)
+ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq, const ZeCDict* cd)
 {
     const uint32_t lane = zh_lane();
     const uint32_t lh = 3 + (n >= 1024) + (n >= 16384);
-    const bool single = n < 256;
+    uint32_t repeat = cd ? cd->hufRepeat : 0;
+    bool single = n < 256;
+    if (repeat == 2 && lh == 3) single = true;
+    const bool preferRepeat = n <= 1024;
+    const uint32_t minLits = repeat == 2 ? 6 : 64;
     // decision: 0 raw, 1 rle, 2 try Huffman
     uint32_t decision = 2;
-    if (n < 64) decision = 0;
+    bool useOld = false;
+    if (n < minLits) decision = 0;
     const bool suspect = (nbSeq == 0) || (n / nbSeq >= 20);
     zh_sync();
     for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
     zh_sync();
-    if (decision == 2 && suspect && n >= 4096 * 10) {
-        // two 4 KiB samples (HUF_flags_suspectUncompressible)
-        uint32_t total = 0;
-        for (int part = 0; part < 2; part++) {
-            const uint8_t* p = part ? lit + n - 4096 : lit;
-            for (uint32_t i = lane; i < 4096; i += 64) zh_lds_atomic_inc(&L.hist[p[i]]);
-            zh_sync();
-            uint32_t m = 0;
-            for (uint32_t i = lane; i < 256; i += 64) { if (L.hist[i] > m) m = L.hist[i]; }
-            m = zh_wave_max(m);
-            total += m;
-            zh_sync();
-            for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
-            zh_sync();
-        }
-        if (total <= ((2 * 4096) >> 7) + 4) decision = 0;
-    }
-    uint32_t maxSym = 0, largest = 0;
-    if (decision == 2) {
-        for (uint32_t i = lane; i < n; i += 64) zh_lds_atomic_inc(&L.hist[lit[i]]);
-        zh_sync();
-        uint32_t m = 0, ms = 0;
-        for (uint32_t i = lane; i < 256; i += 64) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) ms = i; }
-        largest = zh_wave_max(m); maxSym = zh_wave_max(ms);
-        if (largest == n) decision = 1;
-        else if (largest <= (n >> 7) + 4) decision = 0;
-    }
-    zh_sync();
-    if (decision == 2) {
-        uint32_t lg = 0, h = 0;
-        if (zh_opaque(lane) == 0) {
-            lg = ze_fse_optimal_log(11, n, maxSym, 1);
-            lg = ze_huf_build(L, maxSym, lg);
-            h = ze_huf_write_table(L, out + lh, maxSym, lg);
-            L.misc[0] = h;
-        }
-        zh_sync();
-        h = zh_first(L.misc[0]);
-        zh_sync();
-        if (h == 0 || h + 12 >= n) decision = 0;
-        else {
-            uint8_t* body = out + lh + h;
-            const uint32_t bcap = cap - lh - h;
+    uint32_t h = 0;
+    if (decision == 2 && preferRepeat && repeat == 2) useOld = true;          // no statistics needed
+    else if (decision == 2) {
+        if (suspect && n >= 4096 * 10) {
+            // two 4 KiB samples (HUF_flags_suspectUncompressible)
             uint32_t total = 0;
-            if (single) {
-                if (zh_opaque(lane) == 0) L.misc[0] = ze_huf_encode_1x(L, body, bcap, lit, n);
+            for (int part = 0; part < 2; part++) {
+                const uint8_t* p = part ? lit + n - 4096 : lit;
+                for (uint32_t i = lane; i < 4096; i += 64) zh_lds_atomic_inc(&L.hist[p[i]]);
                 zh_sync();
-                total = zh_first(L.misc[0]);
+                uint32_t m = 0;
+                for (uint32_t i = lane; i < 256; i += 64) { if (L.hist[i] > m) m = L.hist[i]; }
+                m = zh_wave_max(m);
+                total += m;
                 zh_sync();
-            } else {
-                // 4 streams (HUF_compress4X_usingCTable_internal, zstd.c:17925): 6-byte jump table + 4 bodies. The bodies
-                // must be contiguous, so every lane first measures its stream, then writes it at its final offset.
-                const uint32_t seg = (n + 3) / 4;
-                uint32_t bits = 0;
+                for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
+                zh_sync();
+            }
+            if (total <= ((2 * 4096) >> 7) + 4) decision = 0;
+        }
+        uint32_t maxSym = 0, largest = 0;
+        if (decision == 2) {
+            for (uint32_t i = lane; i < n; i += 64) zh_lds_atomic_inc(&L.hist[lit[i]]);
+            zh_sync();
+            uint32_t m = 0, ms = 0;
+            for (uint32_t i = lane; i < 256; i += 64) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) ms = i; }
+            largest = zh_wave_max(m); maxSym = zh_wave_max(ms);
+            if (largest == n) decision = 1;
+            else if (largest <= (n >> 7) + 4) decision = 0;
+        }
+        zh_sync();
+        if (decision == 2 && repeat == 1) {
+            // HUF_validateCTable (zstd.c:17693): every present symbol needs a code in the old table
+            uint32_t bad = cd->hufMaxSym < maxSym ? 1u : 0u;
+            for (uint32_t i = lane; i <= maxSym; i += 64) if (L.hist[i] && !cd->hufBits[i]) bad = 1;
+            if (zh_wave_max(bad)) repeat = 0;
+        }
+        if (decision == 2 && preferRepeat && repeat != 0) useOld = true;
+        else if (decision == 2) {
+            uint32_t lg = 0;
+            if (zh_opaque(lane) == 0) {
+                lg = ze_fse_optimal_log(11, n, maxSym, 1);
+                lg = ze_huf_build(L, maxSym, lg);
+                L.misc[0] = ze_huf_write_table(L, out + lh, maxSym, lg);
+            }
+            zh_sync();
+            h = zh_first(L.misc[0]);
+            zh_sync();
+            if (h == 0) decision = 0;
+            else if (repeat != 0) {
+                // HUF_estimateCompressedSize (zstd.c:17681) of both tables on this histogram
+                uint32_t ob = 0, nb = 0;
+                for (uint32_t i = lane; i <= maxSym; i += 64) { ob += (uint32_t)cd->hufBits[i] * L.hist[i]; nb += (uint32_t)L.hufBits[i] * L.hist[i]; }
+                ob = zh_scan_add(ob); nb = zh_scan_add(nb);
+                const uint32_t oldSize = zh_shfl(ob, 63) >> 3, newSize = zh_shfl(nb, 63) >> 3;
+                if (oldSize <= h + newSize || h + 12 >= n) useOld = true;
+            }
+            if (decision == 2 && !useOld) {
+                if (h + 12 >= n) decision = 0;
+                else repeat = 0;
+            }
+        }
+    }
+    if (decision == 2) {
+        if (useOld) {
+            zh_sync();
+            for (uint32_t i = lane; i < 256; i += 64) { L.hufBits[i] = cd->hufBits[i]; L.hufCode[i] = cd->hufCode[i]; }
+            zh_sync();
+            h = 0;
+        }
+        uint8_t* body = out + lh + h;
+        const uint32_t bcap = cap - lh - h;
+        uint32_t total = 0;
+        if (single) {
+            if (zh_opaque(lane) == 0) L.misc[0] = ze_huf_encode_1x(L, body, bcap, lit, n);
+            zh_sync();
+            total = zh_first(L.misc[0]);
+            zh_sync();
+        } else {
+            // 4 streams (HUF_compress4X_usingCTable_internal, zstd.c:17925): 6-byte jump table + 4 bodies. The bodies
+            // must be contiguous, so every lane first measures its stream, then writes it at its final offset.
+            const uint32_t seg = (n + 3) / 4;
+            uint32_t bits = 0;
+            if (lane < 4) {
+                const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
+                for (uint32_t i = 0; i < len; i++) bits += L.hufBits[lit[s0 + i]];
+            }
+            const uint32_t mySize = (bits + 1 + 7) / 8;
+            const uint32_t z1 = zh_shfl(mySize, 0), z2 = zh_shfl(mySize, 1), z3 = zh_shfl(mySize, 2), z4 = zh_shfl(mySize, 3);
+            bool ok = !(z1 > 65535 || z2 > 65535 || z3 > 65535 || z4 > 65535) && n >= 12 && (6 + z1 + z2 + z3 + z4 <= bcap);
+            if (ok) {
                 if (lane < 4) {
                     const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
-                    for (uint32_t i = 0; i < len; i++) bits += L.hufBits[lit[s0 + i]];
+                    const uint32_t off = 6 + (lane > 0 ? z1 : 0) + (lane > 1 ? z2 : 0) + (lane > 2 ? z3 : 0);
+                    (void)ze_huf_encode_1x(L, body + off, mySize, lit + s0, len);
+                    if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)mySize);
                 }
-                const uint32_t mySize = (bits + 1 + 7) / 8;
-                const uint32_t z1 = zh_shfl(mySize, 0), z2 = zh_shfl(mySize, 1), z3 = zh_shfl(mySize, 2), z4 = zh_shfl(mySize, 3);
-                bool ok = !(z1 > 65535 || z2 > 65535 || z3 > 65535 || z4 > 65535) && n >= 12 && (6 + z1 + z2 + z3 + z4 <= bcap);
-                if (ok) {
-                    if (lane < 4) {
-                        const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
-                        const uint32_t off = 6 + (lane > 0 ? z1 : 0) + (lane > 1 ? z2 : 0) + (lane > 2 ? z3 : 0);
-                        (void)ze_huf_encode_1x(L, body + off, mySize, lit + s0, len);
-                        if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)mySize);
-                    }
-                    total = 6 + z1 + z2 + z3 + z4;
-                }
-                zh_sync();
+                total = 6 + z1 + z2 + z3 + z4;
             }
-            uint32_t cl = total ? h + total : 0;
-            if (cl >= n - 1) cl = 0;
-            if (cl == 0 || cl >= n - ((n >> 6) + 2)) decision = 0;
-            else {
-                if (zh_opaque(lane) == 0) {
-                    if (lh == 3) { const uint32_t v = 2 + ((uint32_t)(!single) << 2) + (n << 4) + (cl << 14); out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16); }
-                    else if (lh == 4) zh_st32(out, 2 + (2u << 2) + (n << 4) + (cl << 18));
-                    else { zh_st32(out, 2 + (3u << 2) + (n << 4) + (cl << 22)); out[4] = (uint8_t)(cl >> 10); }
-                }
-                zh_sync();
-                return lh + cl;
+            zh_sync();
+        }
+        uint32_t cl = total ? h + total : 0;
+        if (cl >= n - 1) cl = 0;
+        if (cl == 0 || cl >= n - ((n >> 6) + 2)) decision = 0;
+        else {
+            const uint32_t hType = repeat != 0 ? 3u : 2u;
+            if (zh_opaque(lane) == 0) {
+                if (lh == 3) { const uint32_t v = hType + ((uint32_t)(!single) << 2) + (n << 4) + (cl << 14); out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16); }
+                else if (lh == 4) zh_st32(out, hType + (2u << 2) + (n << 4) + (cl << 18));
+                else { zh_st32(out, hType + (3u << 2) + (n << 4) + (cl << 22)); out[4] = (uint8_t)(cl >> 10); }
             }
+            zh_sync();
+            return lh + cl;
         }
     }
     // raw or rle literals
@@ -669,19 +697,187 @@ ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const 
     return nseq;
 }
 
+
+// ------------------------------------------------------------------------------------------ double-fast search against an attached dictionary
+// ZSTD_compressBlock_doubleFast_dictMatchState_generic (zstd.c:31262) for a frame of one block. One index space: dictionary
+// content byte k is index 2 + k, the source follows at CE = 2 + contentSize, so offsets are index differences. The frame's own
+// tables hold plain indices; the dictionary's hold (index << 8 | tag) (ZSTD_writeTaggedIndex, zstd.c:20636). One lane.
+struct ZeSpace { const uint8_t* content; const uint8_t* src; uint32_t CE, end; };
+ZH_DEV uint32_t ze_sp_byte(const ZeSpace& sp, uint32_t i) { return i < sp.CE ? sp.content[i - 2] : sp.src[i - sp.CE]; }
+ZH_DEV uint32_t ze_sp_rd32(const ZeSpace& sp, uint32_t i)
+{
+    if (i >= sp.CE) return zh_ld32(sp.src + (i - sp.CE));
+    if (i + 4 <= sp.CE) return zh_ld32(sp.content + (i - 2));
+    uint32_t v = 0; for (uint32_t k = 0; k < 4; k++) v |= ze_sp_byte(sp, i + k) << (8 * k);
+    return v;
+}
+ZH_DEV uint64_t ze_sp_rd64(const ZeSpace& sp, uint32_t i)
+{
+    if (i >= sp.CE) return zh_ld64(sp.src + (i - sp.CE));
+    if (i + 8 <= sp.CE) return zh_ld64(sp.content + (i - 2));
+    uint64_t v = 0; for (uint32_t k = 0; k < 8; k++) v |= (uint64_t)ze_sp_byte(sp, i + k) << (8 * k);
+    return v;
+}
+// ZSTD_count_2segments (zstd.c:20034): the match may run off the dictionary's end into the start of the source
+ZH_DEV uint32_t ze_sp_count(const ZeSpace& sp, uint32_t ip, uint32_t m)
+{
+    const uint8_t* const a = sp.src + (ip - sp.CE);
+    const uint8_t* const iend = sp.src + (sp.end - sp.CE);
+    if (m >= sp.CE) return ze_common_len(a, sp.src + (m - sp.CE), iend);
+    const uint32_t inDict = sp.CE - m, room = sp.end - ip;
+    const uint8_t* const vend = a + (inDict < room ? inDict : room);
+    const uint32_t n = ze_common_len(a, sp.content + (m - 2), vend);
+    if (n != inDict) return n;
+    return n + ze_common_len(a + n, sp.src, iend);
+}
+
+ZH_DEVFN uint32_t ze_dfast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                                const ZeCDict& cd, const uint8_t* content, const uint32_t* dHashLong, const uint32_t* dHashSmall,
+                                uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const int hl = cp.hlog, hs = cp.clog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t CE = 2 + cd.contentSize, DS = 2;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
+    const int dhl = cd.hlog + 8, dhs = cd.clog + 8;
+    const uint32_t iend = CE + srcSize;
+    uint32_t ip = CE, anchor = CE;
+    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_SRC(i) (src + ((i) - CE))
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
+        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
+#define ZE_BACK(LOW) while (ip > anchor && m > (LOW) && ze_sp_byte(sp, ip - 1) == ze_sp_byte(sp, m - 1)) { ip--; m--; mLength++; }
+    if (srcSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        while (ip < ilimit) {
+            uint32_t mLength = 0, offset = 0;
+            const uint32_t h2 = ze_hash(ZE_SRC(ip), hl, 8), h = ze_hash(ZE_SRC(ip), hs, mls);
+            const uint32_t dTagL = ze_hash(ZE_SRC(ip), dhl, 8), dTagS = ze_hash(ZE_SRC(ip), dhs, mls);
+            const uint32_t dEntL = dHashLong[dTagL >> 8], dEntS = dHashSmall[dTagS >> 8];
+            const bool tagL = (dEntL & 255) == (dTagL & 255), tagS = (dEntS & 255) == (dTagS & 255);
+            const uint32_t curr = ip;
+            const uint32_t mIdxL = hashLong[h2]; uint32_t mIdxS = hashSmall[h];
+            const uint32_t repIndex = curr + 1 - off1;
+            hashLong[h2] = curr; hashSmall[h] = curr;
+            int found = 0;
+            if ((uint32_t)((CE - 1) - repIndex) >= 3 && ze_sp_rd32(sp, repIndex) == zh_ld32(ZE_SRC(ip + 1))) {
+                mLength = ze_sp_count(sp, ip + 1 + 4, repIndex + 4) + 4;
+                ip++;
+                ZE_STORE(ip - anchor, 1, mLength);
+                found = 1;
+            } else {
+                if (mIdxL >= CE && zh_ld64(ZE_SRC(mIdxL)) == zh_ld64(ZE_SRC(ip))) {
+                    uint32_t m = mIdxL;
+                    mLength = ze_sp_count(sp, ip + 8, m + 8) + 8;
+                    offset = ip - m;
+                    ZE_BACK(CE)
+                    found = 2;
+                } else if (tagL) {
+                    uint32_t m = dEntL >> 8;
+                    if (m > DS && ze_sp_rd64(sp, m) == zh_ld64(ZE_SRC(ip))) {
+                        mLength = ze_sp_count(sp, ip + 8, m + 8) + 8;
+                        offset = curr - m;
+                        ZE_BACK(DS)
+                        found = 2;
+                    }
+                }
+                if (!found) {
+                    bool shortCand = false; uint32_t match = 0;
+                    if (mIdxS > CE) { if (zh_ld32(ZE_SRC(mIdxS)) == zh_ld32(ZE_SRC(ip))) { shortCand = true; match = mIdxS; } }
+                    else if (tagS) {
+                        match = dEntS >> 8; mIdxS = match;
+                        if (match > DS && ze_sp_rd32(sp, match) == zh_ld32(ZE_SRC(ip))) shortCand = true;
+                    }
+                    if (!shortCand) { ip += ((ip - anchor) >> 8) + 1; continue; }
+                    {   // a short match exists: a long match one position later wins
+                        const uint32_t hl3 = ze_hash(ZE_SRC(ip + 1), hl, 8), dTagL3 = ze_hash(ZE_SRC(ip + 1), dhl, 8);
+                        const uint32_t mIdxL3 = hashLong[hl3], dEntL3 = dHashLong[dTagL3 >> 8];
+                        const bool tagL3 = (dEntL3 & 255) == (dTagL3 & 255);
+                        hashLong[hl3] = curr + 1;
+                        if (mIdxL3 >= CE && zh_ld64(ZE_SRC(mIdxL3)) == zh_ld64(ZE_SRC(ip + 1))) {
+                            uint32_t m = mIdxL3;
+                            mLength = ze_sp_count(sp, ip + 9, m + 8) + 8;
+                            ip++;
+                            offset = ip - m;
+                            ZE_BACK(CE)
+                            found = 2;
+                        } else if (tagL3) {
+                            uint32_t m = dEntL3 >> 8;
+                            if (m > DS && ze_sp_rd64(sp, m) == zh_ld64(ZE_SRC(ip + 1))) {
+                                mLength = ze_sp_count(sp, ip + 1 + 8, m + 8) + 8;
+                                ip++;
+                                offset = curr + 1 - m;
+                                ZE_BACK(DS)
+                                found = 2;
+                            }
+                        }
+                    }
+                    if (!found) {
+                        uint32_t m = match;
+                        mLength = ze_sp_count(sp, ip + 4, m + 4) + 4;
+                        offset = curr - mIdxS;
+                        if (mIdxS < CE) { ZE_BACK(DS) } else { ZE_BACK(CE) }
+                        found = 2;
+                    }
+                }
+                off2 = off1; off1 = offset;
+                ZE_STORE(ip - anchor, offset + 3, mLength);
+            }
+            ip += mLength; anchor = ip;
+            if (ip <= ilimit) {
+                const uint32_t ins = curr + 2;
+                hashLong[ze_hash(ZE_SRC(ins), hl, 8)] = ins;
+                hashLong[ze_hash(ZE_SRC(ip - 2), hl, 8)] = ip - 2;
+                hashSmall[ze_hash(ZE_SRC(ins), hs, mls)] = ins;
+                hashSmall[ze_hash(ZE_SRC(ip - 1), hs, mls)] = ip - 1;
+                while (ip <= ilimit) {
+                    const uint32_t rep2 = ip - off2;
+                    if (!((uint32_t)((CE - 1) - rep2) >= 3 && ze_sp_rd32(sp, rep2) == zh_ld32(ZE_SRC(ip)))) break;
+                    const uint32_t r = ze_sp_count(sp, ip + 4, rep2 + 4) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    ZE_STORE(0, 1, r);
+                    hashSmall[ze_hash(ZE_SRC(ip), hs, mls)] = ip;
+                    hashLong[ze_hash(ZE_SRC(ip), hl, 8)] = ip;
+                    ip += r; anchor = ip;
+                }
+            }
+        }
+    }
+#undef ZE_BACK
+#undef ZE_STORE
+    {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
+#undef ZE_SRC
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+
+// working parameters of a frame compressed against an attached dictionary: the dictionary's own row shrunk to the source
+// (ZSTD_resetCCtx_byAttachingCDict, zstd.c:25279); the window log stays the one chosen for the source.
+ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
+{
+    int w = 31, h = cd.hlog, c = cd.clog;
+    const int srcLog = srcSize < 64 ? 6 : zh_highbit32(srcSize - 1) + 1;
+    if (w > srcLog) w = srcLog;
+    if (h > w + 1) h = w + 1;
+    if (c > w) c = w;
+    cp.hlog = h; cp.clog = c; cp.mml = cd.mml;
+}
+
 // ------------------------------------------------------------------------------------------ sequences section
 // ZSTD_selectEncodingType (zstd.c:21252), strategy below "lazy", first block: 0 basic, 1 rle, 2 compressed
-ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog, bool defaultAllowed)
+ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog, bool defaultAllowed, uint32_t repeatMode)
 {
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
         const uint32_t dynMin = ((1u << defLog) * 8) >> 3;
+        if (repeatMode == 2 && nbSeq < 1000) return 3;          // set_repeat: the dictionary's table
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) return 0;
     }
     return 2;
 }
 // ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq)
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq, const ZeCDict* cd)
 {
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
     const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
@@ -690,8 +886,17 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     uint32_t max = 0, most = 0;
     for (uint32_t s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
     const bool defaultAllowed = which != 1 || max <= 28;
-    *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed);
+    const uint32_t repeatMode = !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;
+    *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode);
     ZeCTab& t = L.tab[which];
+    if (*mode == 3) {
+        const ZeCTab& d = cd->tab[which];
+        t.log = d.log; t.maxSym = d.maxSym;
+        for (uint32_t s = 0; s <= d.maxSym; s++) { t.norm[s] = d.norm[s]; t.cellOf[s] = d.cellOf[s]; }
+        t.cellOf[d.maxSym + 1] = d.cellOf[d.maxSym + 1];
+        for (uint32_t u = 0; u < (1u << d.log); u++) t.next[u] = d.next[u];
+        return 0;
+    }
     if (*mode == 1) { ze_fse_build_rle(t, codes[0]); out[0] = codes[0]; return 1; }
     if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, L.cellSym, nrm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
@@ -711,8 +916,9 @@ ZH_DEV uint32_t ze_ml_code(uint32_t ml) { uint32_t c = 52; while (ze_mlBase[c] >
 struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
 
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
-                                    const ZePre* pre)
+                                    const ZePre* pre, const ZhipEncodeArgs& a)
 {
+    const ZeCDict* cd = a.cdict;
     const uint32_t lane = zh_lane();
     if (srcSize < 7) return 0;
     uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
@@ -734,7 +940,9 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     zh_sync();
     if (zh_opaque(lane) == 0) {
         uint32_t ls = 0;
-        const uint32_t ns = ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
+        const uint32_t ns = cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
+                                               a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                               : ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
         L.misc[1] = ns; L.misc[2] = ls;
     }
     ze_fence();
@@ -742,7 +950,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     nbSeq = zh_first(L.misc[1]); litSize = zh_first(L.misc[2]);
     zh_sync();
     }
-    uint32_t pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq);
+    uint32_t pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, cd);
     // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
     uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
     zh_sync();
@@ -765,9 +973,9 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (nbSeq) {
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; uint32_t lastCount = 0, h;
-            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq); if (mML == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq, cd); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq, cd); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq, cd); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
             // ZSTD_encodeSequences_body (zstd.c:21386): last sequence first; per sequence OF, ML, LL state updates,
             // then the LL, ML, OF extra bits
@@ -842,6 +1050,14 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     const int e = ze_get_cparams(cp, a.level, srcSize);
     if (e) return e;
     if (cp.strat != 2 || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
+    uint32_t dictID = 0;
+    if (a.cdict) {
+        if (a.cdict->status) return a.cdict->status;
+        if (srcSize > ZE_DICT_ATTACH_MAX) return ZE_PARAM_UNSUPPORTED;    // the reference's table-copy mode is not implemented
+        ze_dict_cparams(cp, *a.cdict, srcSize);
+        if (a.dictIDFlag) dictID = a.cdict->dictID;
+    }
+    const uint32_t dictCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     uint32_t pos = 0;
     const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
     const uint32_t windowSize = 1u << cp.wlog;
@@ -850,8 +1066,11 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     zh_sync();
     if (zh_opaque(lane) == 0) {
         zh_st32(dst, ZF_MAGIC); pos = 4;
-        dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+        dst[pos++] = (uint8_t)(dictCode + (checksum << 2) + (single << 5) + (fcsCode << 6));
         if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
+        if (dictCode == 1) dst[pos++] = (uint8_t)dictID;
+        else if (dictCode == 2) { zh_st16(dst + pos, (uint16_t)dictID); pos += 2; }
+        else if (dictCode == 3) { zh_st32(dst + pos, dictID); pos += 4; }
         if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
         else if (fcsCode == 1) { zh_st16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
         else { zh_st32(dst + pos, srcSize); pos += 4; }
@@ -864,7 +1083,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
         if (zh_opaque(lane) == 0) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; }
         pos += 3;
     } else {
-        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre);
+        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre, a);
         if (c == 0) {
             const uint32_t bh = 1 + (0u << 1) + (srcSize << 3);
             if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
@@ -883,6 +1102,135 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     ze_fence();
     *produced = pos;
     return ZE_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------ dictionary digestion (one wave, once per dictionary)
+// parameters of the dictionary's own tables: ZSTD_getCParams_internal(level, unknown source, dictSize, ZSTD_cpm_createCDict)
+// (zstd.c:30848, :24426)
+ZH_DEV int ze_cdict_params(ZePar& out, int level, uint32_t dictSize)
+{
+    if (level == 0) level = 3;
+    if (level < 1 || level > 4) return ZE_PARAM_UNSUPPORTED;
+    const uint64_t rSize = (uint64_t)dictSize + 499;
+    const uint32_t tableID = (rSize <= 256u * 1024) + (rSize <= 128u * 1024) + (rSize <= 16u * 1024);
+    int w = ze_rows[tableID][level][0], c = ze_rows[tableID][level][1], h = ze_rows[tableID][level][2];
+    const uint32_t srcSize = 513;                       // createCDict mode assumes a small source
+    const uint32_t t = srcSize + dictSize;
+    const int srcLog = t < 64 ? 6 : zh_highbit32(t - 1) + 1;
+    if (w > srcLog) w = srcLog;
+    int dawl = w;
+    if ((1ull << w) < (uint64_t)dictSize + srcSize) { const uint64_t dw = (uint64_t)dictSize + (1ull << w); dawl = dw >= (1ull << 31) ? 31 : zh_highbit32((uint32_t)dw - 1) + 1; }
+    if (h > dawl + 1) h = dawl + 1;
+    if (c > dawl) c = dawl;
+    if (w < 10) w = 10;
+    if (h > 24) h = 24;
+    if (c > 24) c = 24;
+    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][level][4]; out.strat = ze_rows[tableID][level][6];
+    return 0;
+}
+ZH_DEV uint32_t ze_ncount_repeat(const int16_t* norm, uint32_t dictMax, uint32_t needMax)      // ZSTD_dictNCountRepeat, zstd.c:27998
+{
+    if (dictMax < needMax) return 1;
+    for (uint32_t s = 0; s <= needMax; s++) if (norm[s] == 0) return 1;
+    return 2;
+}
+
+// ZSTD_loadCEntropy (zstd.c:28015) from the already-parsed entropy section (de, null for a raw-content dictionary), then
+// ZSTD_fillDoubleHashTableForCDict (:30952) done wave-parallel: the sequential fill keeps, per cell, the LAST position of the
+// every-third-position series and otherwise the FIRST of the in-between positions, which is an atomic max / min.
+// hashLong, hashSmall: 1 << ZE_CDICT_MAX_HLOG cells each; tmpLong: scratch of the same size. All lanes call.
+ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, int level, ZeCDict* cd,
+                            uint32_t* hashLong, uint32_t* hashSmall, uint32_t* tmpLong, ZeLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    const bool hasEntropy = de && de->hufCount != 0;
+    const uint32_t contentOff = hasEntropy ? de->contentOffset : 0u;
+    const uint32_t cs = dictSize - contentOff;
+    const uint8_t* content = dict + contentOff;
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        ZePar p; int st = ze_cdict_params(p, level, dictSize);
+        if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
+        cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
+        cd->contentSize = cs; cd->dictID = hasEntropy ? de->dictID : 0u;
+        cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
+        cd->hufRepeat = cd->llRepeat = cd->ofRepeat = cd->mlRepeat = 0; cd->hufMaxSym = 0;
+        if (!st && hasEntropy) {
+            // HUF_readCTable (zstd.c:17048): code lengths from weights, canonical values per length in symbol order
+            const uint32_t cnt = de->hufCount;
+            uint32_t total = 0; bool zero = false;
+            for (uint32_t s = 0; s < cnt; s++) { const uint32_t w = de->hufWeights[s]; total += w ? (1u << w) >> 1 : 0u; zero |= (w == 0); }
+            const uint32_t lg = total ? (uint32_t)zh_highbit32(total) : 0u;
+            if (lg == 0 || lg > 12) st = ZE_DICT_CORRUPTED;
+            else {
+                uint16_t perRank[16], start[16];
+                for (int r = 0; r < 16; r++) { perRank[r] = 0; start[r] = 0; }
+                for (uint32_t s = 0; s < 256; s++) { cd->hufBits[s] = 0; cd->hufCode[s] = 0; }
+                for (uint32_t s = 0; s < cnt; s++) { const uint32_t w = de->hufWeights[s]; const uint32_t nb = w ? lg + 1 - w : 0u; cd->hufBits[s] = (uint8_t)nb; perRank[nb]++; }
+                { uint16_t mn = 0; for (int r = (int)lg; r > 0; r--) { start[r] = mn; mn = (uint16_t)((mn + perRank[r]) >> 1); } }
+                for (uint32_t s = 0; s < cnt; s++) { const uint32_t nb = cd->hufBits[s]; cd->hufCode[s] = nb ? start[nb]++ : (uint16_t)0; }
+                cd->hufMaxSym = cnt - 1;
+                cd->hufRepeat = (!zero && cnt == 256) ? 2u : 1u;
+                int16_t norm[64];
+                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->ofMax && s < 32 ? de->ofNorm[s] : (int16_t)0;
+                ze_fse_build_ctab(cd->tab[1], L.cellSym, norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
+                {   const uint32_t need = (uint32_t)zh_highbit32(cs + 128u * 1024);
+                    cd->ofRepeat = ze_ncount_repeat(norm, de->ofMax, need < ZF_MAXOFF ? need : ZF_MAXOFF); }
+                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->mlMax && s < 53 ? de->mlNorm[s] : (int16_t)0;
+                ze_fse_build_ctab(cd->tab[2], L.cellSym, norm, de->mlMax, de->mlLog);
+                cd->mlRepeat = ze_ncount_repeat(norm, de->mlMax, ZF_MAXML);
+                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->llMax && s < 36 ? de->llNorm[s] : (int16_t)0;
+                ze_fse_build_ctab(cd->tab[0], L.cellSym, norm, de->llMax, de->llLog);
+                cd->llRepeat = ze_ncount_repeat(norm, de->llMax, ZF_MAXLL);
+                for (int i = 0; i < 3; i++) cd->rep[i] = de->rep[i];
+            }
+        }
+        cd->status = st;
+        L.misc[0] = (uint32_t)st; L.misc[1] = (uint32_t)p.hlog; L.misc[2] = (uint32_t)p.clog; L.misc[3] = (uint32_t)p.mml;
+    }
+    ze_fence();
+    zh_sync();
+    const uint32_t st = zh_first(L.misc[0]);
+    const int hlog = (int)zh_first(L.misc[1]), clog = (int)zh_first(L.misc[2]), mml = (int)zh_first(L.misc[3]);
+    zh_sync();
+    if (st) return;
+    for (uint32_t i = lane; i < (1u << hlog); i += 64) { hashLong[i] = 0; tmpLong[i] = 0; }
+    for (uint32_t i = lane; i < (1u << clog); i += 64) hashSmall[i] = 0;
+    ze_fence();
+    zh_sync();
+    // only the tail the tables can reasonably address is indexed (ZSTD_loadDictionaryContent, zstd.c:27895)
+    uint32_t startOff = 0;
+    {   int mx = hlog + 3 > clog + 1 ? hlog + 3 : clog + 1; if (mx > 31) mx = 31;
+        const uint32_t maxDict = 1u << mx;
+        if (cs > maxDict) startOff = cs - maxDict; }
+    if (cs - startOff >= 10) {
+        const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
+        const uint32_t nGroups = (cs - 10 - startOff) / 3 + 1;        // group g covers positions startOff + 3g + {0,1,2}
+        for (uint32_t g = lane; g < nGroups; g += 64) {
+            const uint32_t pos = startOff + 3 * g, curr = pos + 2;
+            const uint32_t sm = ze_hash(content + pos, clog + 8, mls), lg = ze_hash(content + pos, hlog + 8, 8);
+            zh_atomic_max(&hashSmall[sm >> 8], (curr << 8) | (sm & 255));
+            zh_atomic_max(&hashLong[lg >> 8], (curr << 8) | (lg & 255));
+        }
+        ze_fence();
+        zh_sync();
+        for (uint32_t g = lane; g < nGroups; g += 64) {
+            for (uint32_t i = 1; i < 3; i++) {
+                const uint32_t pos = startOff + 3 * g + i, curr = pos + 2;
+                const uint32_t lg = ze_hash(content + pos, hlog + 8, 8);
+                if (hashLong[lg >> 8] == 0) zh_atomic_max(&tmpLong[lg >> 8], ((0xFFFFFFu - curr) << 8) | (lg & 255));
+            }
+        }
+        ze_fence();
+        zh_sync();
+        for (uint32_t i = lane; i < (1u << hlog); i += 64) {
+            const uint32_t t = tmpLong[i];
+            if (hashLong[i] == 0 && t) hashLong[i] = ((0xFFFFFFu - (t >> 8)) << 8) | (t & 255);
+        }
+        ze_fence();
+        zh_sync();
+    }
 }
 
 ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
@@ -923,13 +1271,19 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         if (srcSize64 > ZF_BLOCK_MAX || ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || cp.strat != 2 ||
             (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         const uint32_t srcSize = (uint32_t)srcSize64;
+        if (a.cdict) {
+            if (a.cdict->status || srcSize > ZE_DICT_ATTACH_MAX) { m.mode = 2; a.meta[i] = m; continue; }
+            ze_dict_cparams(cp, *a.cdict, srcSize);
+        }
         if (srcSize < 7) { m.mode = 1; a.meta[i] = m; continue; }
         uint32_t* hashLong = (uint32_t*)tables;
         uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
         { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (4u << cp.clog)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
         uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
         uint32_t litSize = 0;
-        m.nbSeq = ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
+        m.nbSeq = a.cdict ? ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+                                          a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                          : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
         m.litSize = litSize;
         a.meta[i] = m;
     }

@@ -90,6 +90,11 @@ struct ZhipEncodeArgs {
     uint8_t* laneTables;            // (gridDim.x * ZE_E1_LANES) x tableStride : hash tables of the frames being searched
     uint32_t tableStride;
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
+    // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
+    const struct ZeCDict* cdict;
+    const uint8_t* cdictContent;
+    const uint32_t* cdictHashLong;
+    const uint32_t* cdictHashSmall;
 };
 struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched; 1: store raw (too small); 2: error in status
 #define ZE_ARENA_SEQ 0
@@ -99,6 +104,32 @@ struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched;
 #define ZE_E1_LANES 8
 #endif
 #define ZE_CODES_STRIDE ((size_t)3 * (ZE_MAX_SEQ + 8) + 256)   // E2 only needs the symbol-code scratch per wave
+
+// FSE encoding table: per symbol, its cells in table order
+struct ZeCTab {
+    int32_t log;
+    uint32_t maxSym;
+    int16_t norm[64];
+    uint16_t cellOf[66];
+    uint16_t next[512];
+};
+// Digested compression dictionary (what ZSTD_createCDict keeps, zstd.c:28490-28614), built on the device by
+// zhip_build_cdict_kernel. Sources above ZE_DICT_ATTACH_MAX would use the reference's "copy" mode (tables copied, dictionary
+// as an external segment); this backend implements the attached mode only and reports larger sources as unsupported.
+#define ZE_DICT_ATTACH_MAX (16u * 1024)
+#define ZE_CDICT_MAX_HLOG 18
+#define ZE_CDICT_MAX_CONTENT ((1u << 20) - ZE_DICT_ATTACH_MAX - 16)   // offBase must fit the packed sequence's 20 bits
+struct ZeCDict {
+    int32_t  status;            // 0 or a zstd error code
+    int32_t  hlog, clog, mml;   // parameters the tagged tables were filled with
+    uint32_t contentSize, dictID;
+    uint32_t rep[3];
+    uint32_t hufRepeat, llRepeat, ofRepeat, mlRepeat;    // 0 none, 1 check, 2 valid (HUF_repeat / FSE_repeat)
+    uint32_t hufMaxSym;
+    uint8_t  hufBits[256];
+    uint16_t hufCode[256];
+    ZeCTab   tab[3];            // LL, OF, ML
+};
 
 // ------------------------------------------------------------------------------------------------ phase-split decode pipeline
 // per-frame record handed from kernel to kernel (HBM)

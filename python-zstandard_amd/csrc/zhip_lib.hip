@@ -49,6 +49,12 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_entropy_kernel(ZhipEncodeArgs a
     __shared__ ZeLDS L;
     ze_entropy_body(a, L);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_build_cdict_kernel(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, int level,
+                                                              ZeCDict* cd, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* tmpLong)
+{
+    __shared__ ZeLDS L;
+    ze_cdict_body(dict, dictSize, de, level, cd, hashLong, hashSmall, tmpLong, L);
+}
 ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
 {
     uint32_t v = zh_scan_add(zh_lane());                  // 0+1+..+lane
@@ -196,6 +202,10 @@ struct zhip_ctx {
     int e1PerCU = 0, e2PerCU = 0;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
+    // dictionary (compress side): raw bytes, parsed entropy section, digested form and its tagged tables
+    DevBuf cdictBlob, cdictEntropy, cdictDigest, cdictTables;
+    bool hasCDict = false; uint32_t cdictContentOffset = 0;
+    uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy;
     uint32_t dictSize = 0, dictID = 0, dictContentOffset = 0; bool dictHasEntropy = false;
@@ -258,6 +268,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
@@ -282,8 +293,21 @@ extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, u
     return 0;
 }
 
+static uint64_t dict_fingerprint(const void* p, size_t n, uint64_t salt)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ salt;
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    h ^= (uint64_t)n * 0x9E3779B97F4A7C15ull;
+    return h ? h : 1;
+}
 extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dictSize)
 {
+    if (hostDict && dictSize) {
+        const uint64_t key = dict_fingerprint(hostDict, dictSize, 0);
+        if (c->dictSize == dictSize && c->ddictKey == key) return 0;       // same dictionary as last time: tables are still resident
+        c->ddictKey = key;
+    } else c->ddictKey = 0;
     c->dictSize = 0; c->dictID = 0; c->dictContentOffset = 0; c->dictHasEntropy = false;
     if (!hostDict || !dictSize) return 0;
     if (dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; return ZHIP_ERR_UNSUPPORTED; }
@@ -316,9 +340,41 @@ extern "C" int zhip_selftest(void)
 extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
 {
     if (!c || !p) return ZHIP_ERR_UNSUPPORTED;
-    if (p->dict && p->dictSize) { g_lastError = "dictionary compression is not implemented in the HIP backend yet"; return ZHIP_ERR_UNSUPPORTED; }
     int level = p->level == 0 ? 3 : p->level;
     if (level < 1 || level > 4) { g_lastError = "HIP backend compresses with the double-fast strategy only (level 3; level 2/4 for some sizes)"; return ZHIP_ERR_UNSUPPORTED; }
+    if (p->dict && p->dictSize) {
+        const uint64_t key = dict_fingerprint(p->dict, p->dictSize, (uint64_t)level);
+        if (c->hasCDict && c->cdictKey == key) { c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; return 0; }
+        c->cdictKey = key;
+    }
+    c->hasCDict = false;
+    if (p->dict && p->dictSize) {
+        // digest the dictionary on the device: parse its entropy section, build the encoding tables, index its content
+        // (what ZSTD_createCDict does on the host in the reference, zstd.c:28490-28614)
+        if (p->dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; return ZHIP_ERR_UNSUPPORTED; }
+        const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
+        if (c->cdictBlob.reserve(p->dictSize + 16) || c->cdictEntropy.reserve(sizeof(ZhipDictEntropy)) ||
+            c->cdictDigest.reserve(sizeof(ZeCDict)) || c->cdictTables.reserve(3 * cells * sizeof(uint32_t))) return ZHIP_ERR_HIP;
+        HIP_TRY(hipMemcpy(c->cdictBlob.p, p->dict, p->dictSize, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset((uint8_t*)c->cdictBlob.p + p->dictSize, 0, 16));
+        HIP_TRY(hipMemset(c->cdictEntropy.p, 0, sizeof(ZhipDictEntropy)));
+        HIP_TRY(hipMemset(c->cdictDigest.p, 0, sizeof(ZeCDict)));
+        hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
+                           (ZhipDictEntropy*)c->cdictEntropy.p);
+        HIP_TRY(hipGetLastError());
+        ZhipDictEntropy de;
+        HIP_TRY(hipMemcpy(&de, c->cdictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
+        if (de.status) return -de.status;
+        uint32_t* t = (uint32_t*)c->cdictTables.p;
+        hipLaunchKernelGGL(zhip_build_cdict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
+                           (const ZhipDictEntropy*)c->cdictEntropy.p, level, (ZeCDict*)c->cdictDigest.p, t, t + cells, t + 2 * cells);
+        HIP_TRY(hipGetLastError());
+        ZeCDict cd;
+        HIP_TRY(hipMemcpy(&cd, c->cdictDigest.p, sizeof cd, hipMemcpyDeviceToHost));
+        if (cd.status == ZE_PARAM_UNSUPPORTED) { g_lastError = "dictionary / level combination outside the double-fast attached-dictionary path of the HIP backend"; return ZHIP_ERR_UNSUPPORTED; }
+        if (cd.status) return -cd.status;
+        c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
+    }
     c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0;
     return 0;
 }
@@ -483,6 +539,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)((uint8_t*)c->counter.p + 8); a.n = (uint32_t)n;
     a.level = c->cparams.level == 0 ? 3 : c->cparams.level;
     a.contentSizeFlag = c->cparams.contentSizeFlag != 0; a.checksumFlag = c->cparams.checksumFlag != 0; a.dictIDFlag = c->cparams.dictIDFlag != 0;
+    if (c->hasCDict) {
+        const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
+        a.cdict = (const ZeCDict*)c->cdictDigest.p;
+        a.cdictContent = (const uint8_t*)c->cdictBlob.p + c->cdictContentOffset;
+        a.cdictHashLong = (const uint32_t*)c->cdictTables.p;
+        a.cdictHashSmall = (const uint32_t*)c->cdictTables.p + cells;
+    }
     if (getenv("ZHIP_NO_PIPELINE") == nullptr) {
         // two kernels: E1 searches with one LANE per frame (frames in flight hide the probe latency), E2 entropy-codes with one
         // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
@@ -660,7 +723,9 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     zhip_cparams defaults = {3, 1, 0, 1, nullptr, 0};
     int r = zhip_ctx_set_cparams(c, params ? params : &defaults);
+    if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
+    const bool withDict = params && params->dict && params->dictSize;
     // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are
     // compacted into one payload afterwards
     std::vector<zhip_segment> segs(2 * n);
@@ -668,6 +733,10 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     for (size_t i = 0; i < n; i++) {
         if (items[i].srcSize > ZF_BLOCK_MAX) {
             g_lastError = "inputs larger than 128 KiB (multi-block frames) are not implemented in the HIP backend yet";
+            return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
+        }
+        if (withDict && items[i].srcSize > ZE_DICT_ATTACH_MAX) {
+            g_lastError = "dictionary compression of inputs larger than 16 KiB (libzstd's table-copy mode) is not implemented in the HIP backend yet";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;

@@ -1,3 +1,4 @@
+#include <vector>
 // tests/emu/emu_kernels.cpp -- compiles the PRODUCT kernel sources for the host wave emulator (ZHIP_EMU).
 // Test infrastructure only: lets tests/test_emu_*.py exercise kernel logic without a GPU. Never shipped.
 #define ZHIP_EMU 1
@@ -40,6 +41,39 @@ extern "C" int emu_parse_dict(const uint8_t* dict, uint32_t size, ZhipDictEntrop
 extern "C" uint32_t emu_dict_entropy_size(void) { return (uint32_t)sizeof(ZhipDictEntropy); }
 
 static ZeLDS g_elds;
+// compression dictionary digested by the product's own kernels under emulation (mirrors zhip_ctx_set_cparams)
+static std::vector<uint8_t> g_cdBlob; static ZhipDictEntropy g_cdEntropy; static ZeCDict g_cd; static std::vector<uint32_t> g_cdTables;
+static bool g_hasCD = false;
+struct CDLaunch { int level; };
+static void cdict_lane(void* p)
+{
+    const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
+    ze_cdict_body(g_cdBlob.data(), (uint32_t)(g_cdBlob.size() - 16), &g_cdEntropy, ((CDLaunch*)p)->level, &g_cd,
+                  g_cdTables.data(), g_cdTables.data() + cells, g_cdTables.data() + 2 * cells, g_elds);
+}
+extern "C" int emu_set_cdict(const uint8_t* dict, uint32_t size, int level)
+{
+    g_hasCD = false;
+    if (!dict || !size) return 0;
+    g_cdBlob.assign(dict, dict + size); g_cdBlob.resize(size + 16, 0);
+    memset(&g_cdEntropy, 0, sizeof g_cdEntropy); memset(&g_cd, 0, sizeof g_cd);
+    DictLaunch l = { g_cdBlob.data(), size, &g_cdEntropy };
+    zhemu::run_grid(1, dict_lane, &l);
+    if (g_cdEntropy.status) return g_cdEntropy.status;
+    g_cdTables.assign(3 * ((size_t)1 << ZE_CDICT_MAX_HLOG), 0xDEADBEEFu);
+    CDLaunch c = { level };
+    zhemu::run_grid(1, cdict_lane, &c);
+    if (g_cd.status) return g_cd.status;
+    g_hasCD = true;
+    return 0;
+}
+static void attach_cdict(ZhipEncodeArgs& a)
+{
+    if (!g_hasCD) return;
+    a.cdict = &g_cd;
+    a.cdictContent = g_cdBlob.data() + (g_cdEntropy.hufCount ? g_cdEntropy.contentOffset : 0u);
+    a.cdictHashLong = g_cdTables.data(); a.cdictHashSmall = g_cdTables.data() + ((size_t)1 << ZE_CDICT_MAX_HLOG);
+}
 struct EncLaunch { const ZhipEncodeArgs* a; };
 static void enc_lane(void* p) { ze_kernel_body(*((EncLaunch*)p)->a, g_elds); }
 extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
@@ -51,6 +85,7 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
     a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
     a.counter = &counter; a.n = n; a.level = level;
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
+    attach_cdict(a);
     EncLaunch l = { &a };
     zhemu::run_grid(nBlocks, enc_lane, &l);
     free(a.workspace);
@@ -114,6 +149,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
     a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
+    attach_cdict(a);
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0;

@@ -60,8 +60,15 @@ class Emu:
         return outs, status.tolist()
 
 
-def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2, pipeline=False, chunk=0):
+def _emu_compress_batch(self, raws, level=3, flags=5, n_blocks=2, pipeline=False, chunk=0, dict_data=None):
     n = len(raws)
+    if dict_data:
+        d = np.frombuffer(dict_data, dtype=np.uint8).copy()
+        st = self.lib.emu_set_cdict(d.ctypes.data_as(C.c_void_p), C.c_uint32(len(d)), C.c_int(level))
+        if st:
+            raise RuntimeError("cdict error %d" % st)
+    else:
+        self.lib.emu_set_cdict(None, C.c_uint32(0), C.c_int(level))
     src = np.frombuffer(b"".join(raws) + b"\0" * 16, dtype=np.uint8).copy()
     src_segs = np.zeros((n, 2), dtype=np.uint64)
     dst_segs = np.zeros((n, 2), dtype=np.uint64)

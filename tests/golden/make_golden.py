@@ -34,6 +34,29 @@ def inputs(corpus):
     return cases
 
 
+DICT_SIZES = (0, 6, 7, 63, 64, 65, 300, 1024, 1025, 2048, 5000, 9999, 16383, 16384)
+
+
+def dict_inputs(corpus):
+    """(raw-content dictionary, list of sources) used by the dictionary-compression vectors"""
+    raw_dict = b"".join(corpus.frame_bytes(600 + i)[:4096] for i in range(12))
+    base = [b"".join(corpus.frame_bytes(640 + 4 * j + k)[:4096] for k in range(4)) + corpus.frame_bytes(40 + j)[:2000] for j in range(len(DICT_SIZES))]
+    return raw_dict, [b[:n] for b, n in zip(base, DICT_SIZES)]
+
+
+def dict_compress_cases(ref, corpus, trained):
+    raw_dict, srcs = dict_inputs(corpus)
+    out = {"sizes": list(DICT_SIZES), "raw_dict_sha256": hashlib.sha256(raw_dict).hexdigest(), "frames": {}}
+    for name, dd in (("trained", trained), ("raw", raw_dict)):
+        for tag, flags in (("default", reflib.DEFAULT_FLAGS), ("checksum_nodictid", reflib.F_CONTENTSIZE | reflib.F_CHECKSUM)):
+            recs = []
+            for s in srcs:
+                fr = ref.compress(s, level=3, flags=flags, dict_data=dd)
+                recs.append({"size": len(fr), "sha256": hashlib.sha256(fr).hexdigest()})
+            out["frames"]["%s/%s" % (name, tag)] = recs
+    return out
+
+
 def main():
     ref = reflib.RefZstd()
     corpus = Corpus()
@@ -69,6 +92,8 @@ def main():
         out["dictionary"]["frames"].append({"blob_offset": len(blob), "size": len(fr), "input_sha256": hashlib.sha256(s).hexdigest(),
                                             "input_size": len(s)})
         blob += fr
+    # dictionary COMPRESSION (attached-dictionary mode, sources <= 16 KiB): trained and raw-content dictionaries
+    out["dictionary_compress"] = dict_compress_cases(ref, corpus, d)
     with open(os.path.join(HERE, "golden.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     with open(os.path.join(HERE, "frames.bin"), "wb") as fh:

@@ -43,3 +43,19 @@ def test_emulated_decoder_on_golden_libzstd_frames(emu):
     outs, st = emu.decompress_batch(frames, sizes, n_blocks=2)
     assert not any(st) and len(frames) >= 8
     assert [hashlib.sha256(o).hexdigest() for o in outs] == shas
+
+
+def test_emulated_dictionary_compression_matches_golden(emu):
+    """device dictionary digestion (entropy tables, tagged hash tables) + attached-dictionary search, fused and two-kernel forms"""
+    import hashlib
+    from tests.test_oracle_vs_golden import GOLD, _dict_vectors
+    dicts, srcs = _dict_vectors()
+    for key, flags in (("trained/default", 5), ("raw/default", 5), ("trained/checksum_nodictid", 3)):
+        name = key.split("/")[0]
+        for pipeline in (False, True):
+            outs, st = emu.compress_batch(srcs, level=3, flags=flags, n_blocks=2, pipeline=pipeline, dict_data=dicts[name])
+            assert not any(st)
+            for o, rec in zip(outs, GOLD["dictionary_compress"]["frames"][key]):
+                assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (key, pipeline)
+    outs, st = emu.compress_batch([b"a" * 16385, b"abc" * 100], level=3, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
+    assert st[0] == 40 and st[1] == 0       # parameter_unsupported for the oversize source only
