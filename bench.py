@@ -227,7 +227,7 @@ def main():
     for _ in range(args.warmup):
         ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
     barrier()
-    for k in (0, 2, 3, 4):
+    for k in (0, 2, 7, 3, 4):
         ctx.kernel_time(k)                                           # reset the per-kernel timers
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -235,7 +235,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # dominant decode kernel = the one with the largest total time over the timed steps (HIP events on the launch stream)
-    ktimes = {k: ctx.kernel_time(k) for k in (0, 2, 3, 4)}
+    ktimes = {k: ctx.kernel_time(k) for k in (0, 2, 7, 3, 4)}
     kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
     kernel_ms, launches = ktimes[kdom]
 

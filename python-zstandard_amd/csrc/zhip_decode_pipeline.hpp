@@ -4,10 +4,16 @@
 // per CU by its 14 KiB of LDS. Splitting the frame loop by phase lets each phase use the mapping that fits it:
 //
 //   K1 zhip_decode_lit_kernel   one wave per frame : header + block header + literals section (Huffman, 4 lanes / 4 streams)
-//                                                     -> per-frame literal slot; raw / RLE single-block frames finish here
-//   K2 zhip_decode_seq_kernel   one LANE per frame : FSE tables (2-byte cells, 2.8 KiB of LDS per frame) + the serial tANS
-//                                                     decode, 16 frames per wave, up to 48 frames in flight per CU;
-//                                                     emits packed 8-byte sequences to HBM
+//                                                     -> per-frame literal slot; raw / RLE single-block frames finish here.
+//                                                     Also reads the sequences header and builds the three FSE tables
+//                                                     wave-parallel into the frame's 2.5 KiB slot of the table arena (HBM/L2).
+//                                                     Huffman streams are NOT decoded here: the table goes to an arena for K1b.
+//   KB zhip_decode_bin_kernel   two waves per chunk: 256-bin counting sorts -- frames by decreasing sequence count (K2's order) and
+//                                                     by decreasing literal count (K1b's), so lanes sharing a wave finish together
+//   K1b zhip_decode_huf_kernel  4 LANES per frame  : the (up to) four Huffman streams of 16 frames per wave, tables in LDS
+//   K2 zhip_decode_seq_kernel   one LANE per frame : the serial tANS decode; one 63-lane wave per CU with the 63 frames' tables
+//                                                     (copied from the arena) filling the CU's 160 KiB of LDS; 32-bit-only inner
+//                                                     loop. Emits packed 8-byte sequences to HBM
 //   K3 zhip_decode_exec_kernel  one wave per frame : reads 64 sequences per batch (coalesced), assembles the batch output in
 //                                                     LDS, flushes with 16-byte stores
 //
@@ -20,6 +26,10 @@
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
+    // zd_build_fse folds the extra-bit counts into its LDS cells: the tables it reads must be initialised (K2 ignores that field)
+    if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
+    if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
+    zh_sync();
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
@@ -30,12 +40,14 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         const uint32_t f = a.first + i;
         ZdMeta m;
         m.status = 0; m.path = 0; m.seqOff = m.seqEnd = 0; m.litSize = 0; m.litMode = 0; m.litOff = 0; m.nbSeq = 0;
-        m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0;
+        m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0; m.logs = 0; m.pad = 0;
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
         uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
         const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
         int err = 0; bool fallback = false;
+        ZdProf P; P.on = a.prof != nullptr;
+        if (P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
         do {
             if (srcSize64 > 0x7FFFFFFFull) { fallback = true; break; }
             const uint32_t srcSize = (uint32_t)srcSize64;
@@ -98,14 +110,57 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             st.rep0 = 1; st.rep1 = 4; st.rep2 = 8; st.hufCount = 0; st.llLog = st.ofLog = st.mlLog = 0xFF;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
             st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
-            ZdProf P; P.on = false;
-            const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P);
+            ZD_T(P, ZP_HEADER);
+            ZdLitDefer df; df.table = a.hufTables + (size_t)i * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
+            df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src;
+            const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
             if (r < 0) { err = -r; break; }
             m.litSize = st.litSize;
-            if (st.litRLE) { m.litMode = 2; m.litOff = st.rleByte; }
+            if (df.taken) { m.litMode = 3u | (df.log << 8) | (df.four << 16); m.litOff = (uint32_t)(df.streams - src); m.produced = df.streamBytes; }
+            else if (st.litRLE) { m.litMode = 2; m.litOff = st.rleByte; }
             else if (st.litPtr == lit) { m.litMode = 1; m.litOff = 0; }
             else { m.litMode = 0; m.litOff = (uint32_t)(st.litPtr - src); }
-            m.seqOff = pos + (uint32_t)r; m.seqEnd = pos + bs;
+            {   // sequences header (RFC 8878 3.1.1.3.2): count, compression modes, table descriptions -> FSE tables for K2
+                const uint8_t* sp = src + pos + (uint32_t)r; const uint8_t* const send = src + pos + bs;
+                if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
+                uint32_t nbSeq = *sp++;
+                if (nbSeq > 127) {
+                    if (nbSeq == 255) { if (sp + 2 > send) { err = ZE_SRC_SIZE_WRONG; break; } nbSeq = zh_ld16(sp) + 0x7F00; sp += 2; }
+                    else { if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; } nbSeq = ((nbSeq - 128) << 8) + *sp++; }
+                }
+                m.nbSeq = nbSeq;
+                if (nbSeq == 0) { if (sp != send) { err = ZE_CORRUPTION; break; } }
+                else {
+                    if (nbSeq > ZP_SEQ_CAP) { err = ZE_CORRUPTION; break; }
+                    if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
+                    const uint32_t modes = *sp++;
+                    if (modes & 3) { err = ZE_CORRUPTION; break; }
+                    int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
+                    q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
+                    q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
+                    if (sp >= send) { err = ZE_CORRUPTION; break; }
+                    zh_sync();
+                    // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
+                    uint32_t* const T = (uint32_t*)(a.fseTables + (size_t)i * ZP_FSE_CELLS);
+                    for (uint32_t u = lane; u < ZP_FSE_CELLS / 2; u += 64) {
+                        const uint32_t lg = u < 256 ? st.llLog : u < 512 ? st.mlLog : st.ofLog;
+                        const uint32_t local = (2 * u) & (u < 512 ? 511u : 255u);
+                        uint32_t pair = 0;
+                        for (uint32_t k = 0; k < 2; k++) {
+                            uint32_t cell = 0;
+                            if (local + k < (1u << lg)) {
+                                const uint32_t e = L.fse[2 * u + k];
+                                cell = ((e >> 19) << 10) | (((e & 1023) + (1u << lg)) >> ((e >> 10) & 15));
+                            }
+                            pair |= cell << (16 * k);
+                        }
+                        T[u] = pair;
+                    }
+                    m.logs = st.llLog | (st.ofLog << 8) | (st.mlLog << 16);
+                }
+                m.seqOff = (uint32_t)(sp - src); m.seqEnd = pos + bs;
+                ZD_T(P, ZP_SEQTAB);
+            }
             if (hasChecksum) {
                 if (pos + bs + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
                 m.hasChecksum = 1; m.checksum = zh_ld32(src + pos + bs);
@@ -121,235 +176,283 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
         }
         zd_fence();
+        if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + q, P.acc[q]); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ KB (work order for K2)
+// One wave per chunk: 256-bin counting sort of the frames that have sequences to decode, by decreasing sequence count.
+struct ZpBinLDS { uint32_t hist[256]; uint32_t base[256]; };
+// block 0: K2's order (frames with sequences, by sequence count); block 1: K1b's order (frames with Huffman literals, by literal count)
+ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    const bool lit = zh_block() != 0;
+    uint32_t* const order = lit ? a.orderLit : a.order;
+    for (uint32_t b = lane; b < 256; b += 64) L.hist[b] = 0;
+    zh_sync();
+#define ZP_BIN_KEY(m) (lit ? (((m)->litMode & 255u) == 3u ? 1u + ((m)->litSize >> ZP_LITBIN_SHIFT) : 0u) : ((m)->nbSeq ? 1u + ((m)->nbSeq >> ZP_BIN_SHIFT) : 0u))
+    for (uint32_t i = lane; i < a.count; i += 64) {
+        const ZdMeta* m = a.meta + i;
+        const uint32_t k = m->path == 1 ? ZP_BIN_KEY(m) : 0u;
+        if (k) zh_lds_atomic_inc(&L.hist[256 - (k > 256 ? 256 : k)]);
+    }
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < 256; b++) { L.base[b] = run; run += L.hist[b]; }
+        a.counters[lit ? 4 : 1] = run;
+    }
+    zh_sync();
+    for (uint32_t i = lane; i < a.count; i += 64) {
+        const ZdMeta* m = a.meta + i;
+        const uint32_t k = m->path == 1 ? ZP_BIN_KEY(m) : 0u;
+        if (k) order[zh_lds_atomic_add(&L.base[256 - (k > 256 ? 256 : k)], 1u)] = i;
+    }
+#undef ZP_BIN_KEY
+    zd_fence();
+}
+
+// ------------------------------------------------------------------------------------------ K1b (Huffman streams, 4 lanes per frame)
+// A Huffman stream is a serial chain of table lookups (~150 cycles per symbol) and a frame has at most four of them, so a wave per
+// frame keeps 60 of 64 lanes idle (profiles/r01c: 91 % of K1's cycles). Here one wave decodes 16 frames at once -- lane = 4 * slot
+// + stream -- with the 16 tables (4 KiB each, built by K1) in LDS; frames come in KB's order so that a wave's streams have similar
+// lengths. Same 32-bit bit window as K2: two symbols per v_alignbit, dword refills.
+struct alignas(16) ZpVec16 { uint32_t a, b, c, d; };
+struct ZpHufLDS { alignas(16) uint16_t tab[ZP_HUF_FRAMES][ZP_HUF_CELLS]; };
+
+ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
+{
+    if (size == 0) return false;
+    const uint32_t last = p[size - 1];
+    if (last == 0) return false;
+#define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
+#define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
+#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; used = ge_ ? used - 32 : used; \
+        off = ge_ ? off - 4 : off; n2 = ZP_WORD(off); } while (0)
+    int32_t off = (int32_t)size - 16;
+    uint32_t hi = ZP_WORD(off + 12), lo = ZP_WORD(off + 8), n1 = ZP_WORD(off + 4), n2 = ZP_WORD(off);
+    uint32_t used = 8 - (uint32_t)zh_highbit32(last);
+    const uint32_t sh = 32 - log;
+    uint32_t i = 0;
+    while (i + 4 <= count) {
+        uint32_t top = ZP_TOP();
+        const uint32_t e0 = tab[top >> sh]; top <<= e0 >> 8;
+        const uint32_t e1 = tab[top >> sh];
+        used += (e0 >> 8) + (e1 >> 8);
+        ZP_REFILL();
+        top = ZP_TOP();
+        const uint32_t e2 = tab[top >> sh]; top <<= e2 >> 8;
+        const uint32_t e3 = tab[top >> sh];
+        used += (e2 >> 8) + (e3 >> 8);
+        ZP_REFILL();
+        zh_st32(out + i, (e0 & 255) | ((e1 & 255) << 8) | ((e2 & 255) << 16) | (e3 << 24));
+        i += 4;
+    }
+    while (i < count) {
+        const uint32_t e = tab[ZP_TOP() >> sh];
+        used += e >> 8;
+        ZP_REFILL();
+        out[i++] = (uint8_t)e;
+    }
+#undef ZP_REFILL
+#undef ZP_TOP
+#undef ZP_WORD
+    return (int32_t)((int32_t)size - 16 - off) * 8 + (int32_t)used == (int32_t)size * 8;     // consumed exactly
+}
+
+ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
+{
+    const uint32_t lane = zh_lane(), slot = lane >> 2, strm = lane & 3;
+    const uint32_t total = a.counters[4];
+    const uint32_t nGroups = (total + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES;
+    for (;;) {
+        const uint32_t g = zh_first(zh_atomic_add(a.counters + 5, lane == 0 ? 1u : 0u));
+        if (g >= nGroups) break;
+        const uint32_t k = g * ZP_HUF_FRAMES + slot;
+        const bool active = k < total;
+        const uint32_t i = active ? a.orderLit[k] : 0xFFFFFFFFu;
+        uint32_t mode = 0, litSize = 0, streamOff = 0, streamBytes = 0;
+        if (active) { const ZdMeta* m = a.meta + i; mode = m->litMode; litSize = m->litSize; streamOff = m->litOff; streamBytes = m->produced; }
+        const uint32_t log = (mode >> 8) & 255, four = (mode >> 16) & 1;
+        zh_sync();
+        // the group's tables, HBM -> LDS: whole 4 KiB slots (cells past 2^log are never indexed), 16 bytes per lane, the four loads of a
+        // frame in flight before its first LDS write
+#pragma unroll 2
+        for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
+            const uint32_t fj = zh_shfl(i, 4 * j);
+            if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
+            const ZpVec16* src = (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
+            ZpVec16* dstv = (ZpVec16*)L.tab[j];
+            const ZpVec16 r0 = src[lane], r1 = src[lane + 64], r2 = src[lane + 128], r3 = src[lane + 192];
+            dstv[lane] = r0; dstv[lane + 64] = r1; dstv[lane + 128] = r2; dstv[lane + 192] = r3;
+        }
+        zh_sync();
+        bool ok = true;
+        if (active) {
+            const uint32_t f = a.first + i;
+            const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
+            uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
+            if (!four) { if (strm == 0) ok = zp_huf_stream(L.tab[slot], log, p, streamBytes, lit, litSize); }
+            else {
+                const uint32_t s1 = zh_ld16(p), s2 = zh_ld16(p + 2), s3 = zh_ld16(p + 4);
+                if (6 + s1 + s2 + s3 > streamBytes) ok = false;
+                else {
+                    const uint32_t seg = (litSize + 3) / 4;
+                    const uint32_t so = strm == 0 ? 0 : strm == 1 ? s1 : strm == 2 ? s1 + s2 : s1 + s2 + s3;
+                    const uint32_t sz = strm == 0 ? s1 : strm == 1 ? s2 : strm == 2 ? s3 : streamBytes - 6 - s1 - s2 - s3;
+                    const uint32_t n = strm < 3 ? seg : litSize - 3 * seg;
+                    ok = zp_huf_stream(L.tab[slot], log, p + 6 + so, sz, lit + strm * seg, n);
+                }
+            }
+        }
+        const uint64_t badMask = zh_ballot(!ok);
+        if (active && strm == 0 && ((badMask >> (4 * slot)) & 15)) {
+            ZdMeta* m = a.meta + i;
+            const uint32_t f = a.first + i;
+            m->status = ZE_CORRUPTION; m->path = 0; a.status[f] = ZE_CORRUPTION; a.outSizes[f] = 0;
+        }
+        zd_fence();
+        zh_sync();
     }
 }
 
 // ------------------------------------------------------------------------------------------ K2 (one lane == one frame)
-// 2-byte FSE cell: symbol[10:16) | x[0:10) where x = normalized count + rank; nbBits = log - highbit(x); base = (x << nbBits) - size
-struct ZpLaneLDS { uint16_t ll[512]; uint16_t ml[512]; uint16_t of[256]; int16_t norm[64]; uint16_t next[64]; uint8_t pad[4]; };
+// The tANS chain of a frame is serial and needs its three tables (2.5 KiB as 2-byte cells) at LDS latency: a CU's 160 KiB hold 63
+// frames' tables, so K2 runs ONE wave per CU with 63 active lanes, each decoding its own frame in lockstep; what is left to
+// optimise is the length of the per-sequence dependent instruction chain, so the loop is written with 32-bit operations only:
+//   * 2-byte cell = symbol[10:16) | x[0:10), x = normalized count + rank; nbBits = log - highbit(x); next state = (x << nbBits) + bits
+//   * bit window = two dwords (hi:lo) + two prefetched dwords; a group of fields (<= 32 bits) is one v_alignbit + one v_bfe per field;
+//     the window advances a dword at a time at two fixed points per sequence (after the extra bits, after the state bits)
+//   * per-symbol {baseline, extra-bit count} come from one 4-byte LDS word; repcodes are resolved with selects
+// Frames of a wave come from the KB order (similar sequence counts), so lanes finish together.
+struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
 
-// per-lane forward-bit NCount reader (same format logic as zd_read_ncount, private arrays)
-ZH_DEVFN int zp_read_ncount(int16_t* norm, const uint8_t* src, const uint8_t* end, uint32_t* pMax, uint32_t* pLog)
+ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8_t* T, const uint32_t* llInfo, const uint32_t* mlInfo,
+                               uint32_t logs, uint32_t nbSeq, uint64_t* out)
 {
-    if (src >= end) return -ZE_SRC_SIZE_WRONG;
-    uint32_t bitpos = 0;
-    const uint32_t srcBytes = (uint32_t)(end - src);
-#define ZP_PEEK(n) ((uint32_t)((zd_ld64_bounded(src + (bitpos >> 3), end) >> (bitpos & 7)) & ((1ull << (n)) - 1)))
-    const int al = (int)ZP_PEEK(4) + 5; bitpos += 4;
-    if (al > 9) return -ZE_TABLELOG_TOO_LARGE;
-    *pLog = (uint32_t)al;
-    int remaining = (1 << al) + 1, threshold = 1 << al, nbBits = al + 1;
-    uint32_t sym = 0; const uint32_t maxS = *pMax;
-    int prev0 = 0;
-    while (remaining > 1 && sym <= maxS) {
-        if (prev0) {
-            for (;;) {
-                const uint32_t r = ZP_PEEK(2); bitpos += 2;
-                for (uint32_t k = 0; k < r && sym <= maxS; k++) norm[sym++] = 0;
-                if (r != 3) break;
-                if (bitpos > srcBytes * 8) return -ZE_CORRUPTION;
-            }
-            if (sym > maxS) return -ZE_MAXSYMBOL_TOO_SMALL;
-        }
-        const int max = (2 * threshold - 1) - remaining;
-        int count;
-        const int low = (int)ZP_PEEK((uint32_t)nbBits - 1);
-        if (low < max) { count = low; bitpos += (uint32_t)nbBits - 1; }
-        else { count = (int)ZP_PEEK((uint32_t)nbBits); if (count >= threshold) count -= max; bitpos += (uint32_t)nbBits; }
-        count--;
-        remaining -= count < 0 ? -count : count;
-        if (remaining < 1) return -ZE_CORRUPTION;
-        norm[sym++] = (int16_t)count;
-        prev0 = (count == 0);
-        while (remaining < threshold) { nbBits--; threshold >>= 1; }
-        if (((bitpos + 7) >> 3) > srcBytes) return -ZE_CORRUPTION;
-    }
-#undef ZP_PEEK
-    if (remaining != 1) return -ZE_CORRUPTION;
-    *pMax = sym - 1;
-    return (int)((bitpos + 7) >> 3);
-}
-
-// serial table construction by one lane (RFC 8878 4.1.1): spread, then number each symbol's cells in table order
-ZH_DEVFN int zp_build_table(uint16_t* cells, const int16_t* norm, uint16_t* next, uint32_t maxSym, uint32_t lg)
-{
-    const uint32_t S = 1u << lg, mask = S - 1, step = (S >> 1) + (S >> 3) + 3;
-    uint32_t high = S - 1, total = 0;
-    for (uint32_t s = 0; s <= maxSym; s++) {
-        if (norm[s] == -1) { cells[high--] = (uint16_t)s; next[s] = 1; total += 1; }
-        else { next[s] = (uint16_t)norm[s]; total += (uint32_t)norm[s]; }
-    }
-    if (total != S) return -ZE_CORRUPTION;
-    uint32_t pos = 0;
-    for (uint32_t s = 0; s <= maxSym; s++)
-        for (int i = 0; i < norm[s]; i++) {
-            cells[pos] = (uint16_t)s;
-            do { pos = (pos + step) & mask; } while (pos > high);
-        }
-    if (pos != 0) return -ZE_CORRUPTION;
-    for (uint32_t u = 0; u < S; u++) { const uint32_t s = cells[u]; cells[u] = (uint16_t)((s << 10) | next[s]++); }
-    return 0;
-}
-
-ZH_DEVFN int zp_seq_table(uint16_t* cells, ZpLaneLDS* Ll, uint32_t mode, int kind, uint32_t* pLog, const uint8_t* p, const uint8_t* end)
-{
-    const uint32_t maxSym = kind == ZD_KIND_LL ? ZF_MAXLL : kind == ZD_KIND_ML ? ZF_MAXML : ZF_MAXOFF;
-    const uint32_t maxLog = kind == ZD_KIND_OF ? ZF_OF_LOGMAX : ZF_LL_LOGMAX;
-    if (mode == 0) {
-        const int16_t* def = kind == ZD_KIND_LL ? zc_llDef : kind == ZD_KIND_ML ? zc_mlDef : zc_ofDef;
-        const uint32_t ms = kind == ZD_KIND_LL ? 35 : kind == ZD_KIND_ML ? 52 : 28, lg = kind == ZD_KIND_OF ? 5 : 6;
-        for (uint32_t s = 0; s <= ms; s++) Ll->norm[s] = def[s];
-        if (zp_build_table(cells, Ll->norm, Ll->next, ms, lg) < 0) return -ZE_CORRUPTION;
-        *pLog = lg; return 0;
-    }
-    if (mode == 1) {
-        if (p >= end) return -ZE_SRC_SIZE_WRONG;
-        const uint32_t s = p[0];
-        if (s > maxSym) return -ZE_CORRUPTION;
-        cells[0] = (uint16_t)((s << 10) | 1);          // x = 1: nbBits = 0 - 0, base = 1 - 1 = 0
-        *pLog = 0; return 1;
-    }
-    if (mode == 2) {
-        uint32_t ms = maxSym, lg = 0;
-        const int r = zp_read_ncount(Ll->norm, p, end, &ms, &lg);
-        if (r < 0 || lg > maxLog) return -ZE_CORRUPTION;
-        if (zp_build_table(cells, Ll->norm, Ll->next, ms, lg) < 0) return -ZE_CORRUPTION;
-        *pLog = lg; return r;
-    }
-    return -ZE_CORRUPTION;                              // "repeat" has nothing to repeat in a first block
-}
-
-// the whole sequences section of one frame, decoded by ONE lane straight from global memory
-ZH_DEVFN int zp_decode_sequences(const uint8_t* p, const uint8_t* end, ZpLaneLDS* Ll, const uint32_t* llBase, const uint32_t* mlBase,
-                                 const uint8_t* llBits, const uint8_t* mlBits, uint64_t* out, uint32_t* pNbSeq)
-{
-    *pNbSeq = 0;
-    if (p >= end) return ZE_SRC_SIZE_WRONG;
-    uint32_t nbSeq = *p++;
-    if (nbSeq > 127) {
-        if (nbSeq == 255) { if (p + 2 > end) return ZE_SRC_SIZE_WRONG; nbSeq = zh_ld16(p) + 0x7F00; p += 2; }
-        else { if (p >= end) return ZE_SRC_SIZE_WRONG; nbSeq = ((nbSeq - 128) << 8) + *p++; }
-    }
-    if (nbSeq == 0) return p == end ? 0 : ZE_CORRUPTION;
-    if (nbSeq > ZP_SEQ_CAP) return ZE_CORRUPTION;
-    if (p >= end) return ZE_SRC_SIZE_WRONG;
-    const uint32_t modes = *p++;
-    if (modes & 3) return ZE_CORRUPTION;
-    uint32_t llLog = 0, ofLog = 0, mlLog = 0;
-    int r = zp_seq_table(Ll->ll, Ll, modes >> 6, ZD_KIND_LL, &llLog, p, end); if (r < 0) return -r; p += r;
-    r = zp_seq_table(Ll->of, Ll, (modes >> 4) & 3, ZD_KIND_OF, &ofLog, p, end); if (r < 0) return -r; p += r;
-    r = zp_seq_table(Ll->ml, Ll, (modes >> 2) & 3, ZD_KIND_ML, &mlLog, p, end); if (r < 0) return -r; p += r;
-    if (p >= end) return ZE_CORRUPTION;
-    ZdPBits b;
-    if (!zd_pb_init(b, p, (uint32_t)(end - p))) return ZE_CORRUPTION;
-    int32_t left = ((end - p) >= 8) ? (int32_t)(end - p) * 8 - (int32_t)b.used : 64 - (int32_t)b.used;
-    // The loop below is the hot serial chain of the whole decoder, so it is written branch-lean: reads of n in [0,32]
-    // bits never branch on n, renormalisation is a funnel shift of (c, d) with the next load already issued, extra-bit
-    // counts come from nibble tables instead of a second dependent LDS lookup, repcode handling is select-based, and the
-    // rare sequence with more than 31 extra bits takes a side path.
-    const uint64_t kLL = 0xCBA9876433221111ull;    // LL_bits[16..31] = 1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12
-    const uint64_t kML = 0xBA98754433221111ull;    // ML_bits[32..47] = 1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11
-    const uint8_t* const start = b.start;
-    const uint8_t* ptr = b.ptr;
-    uint64_t c = b.c, d = b.d;
-    uint32_t used = b.used;
-    const bool tiny = (end - p) < 8;                 // whole stream already sits in c; d stays 0
-#define ZP_PEEK(n) ((uint32_t)(((c << (used & 63)) >> 1) >> (63 - (n))))
-#define ZP_NORM() do { uint32_t nb_ = used >> 3; if (nb_ > 7) nb_ = 7; const uint32_t room_ = (uint32_t)(ptr - start); if (nb_ > room_) nb_ = room_; \
-        c = (c << (8 * nb_)) | ((d >> 1) >> (63 - 8 * nb_)); ptr -= nb_; used -= 8 * nb_; \
-        const uint32_t r2_ = room_ - nb_; \
-        if (r2_ >= 8) d = zh_ld64(ptr - 8); else d = (tiny || r2_ == 0) ? 0ull : (zh_ld64(start) << (8 * (8 - r2_))); } while (0)
-    uint32_t sL, sO, sM;
-    ZP_NORM();
-    sL = ZP_PEEK(llLog); used += llLog; sO = ZP_PEEK(ofLog); used += ofLog; sM = ZP_PEEK(mlLog); used += mlLog;
-    left -= (int32_t)(llLog + ofLog + mlLog);
-    ZP_NORM();
+    const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
+    const uint32_t size = (uint32_t)(end - p);
+    if (size == 0) return ZE_CORRUPTION;
+    const uint32_t last = p[size - 1];
+    if (last == 0) return ZE_CORRUPTION;
+    // Bit window: the stream is consumed from its last byte down, a dword at a time. hi:lo are the current dwords, n1/n2 the next
+    // two (prefetched). `used` bits of hi are gone; invariant at every group start: 1 <= used <= 32, so the next 32 stream bits are
+    // one v_alignbit away (ZP_TOP) and fields totalling <= 32 bits are cut from that with v_bfe. After a group ZP_REFILL advances
+    // by at most one dword. Loads may reach up to 4 bytes below p (inside the frame: >= 11 header bytes precede any sequences
+    // bitstream); those bytes are only consumed by a corrupt stream, which the position check at the end rejects.
+#define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
+#define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
+#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; used = ge_ ? used - 32 : used; \
+        off = ge_ ? off - 4 : off; n2 = ZP_WORD(off); } while (0)
+    int32_t off = (int32_t)size - 16;                       // offset of the lowest prefetched dword; not clamped: it is the position
+    uint32_t hi = ZP_WORD(off + 12), lo = ZP_WORD(off + 8), n1 = ZP_WORD(off + 4), n2 = ZP_WORD(off);
+    uint32_t used = 8 - (uint32_t)zh_highbit32(last);       // padding + end mark
+    const uint32_t maskL = (1u << llLog) - 1, maskO = (1u << ofLog) - 1, maskM = (1u << mlLog) - 1;
+    const uint32_t kL = 31 - llLog, kO = 31 - ofLog, kM = 31 - mlLog;
+    uint32_t top = ZP_TOP();
+    uint32_t sL = zh_bfe(top, 32 - llLog, llLog), sO = zh_bfe(top, 32 - llLog - ofLog, ofLog);      // <= 17 bits
+    used += llLog + ofLog;
+    ZP_REFILL();
+    top = ZP_TOP();
+    uint32_t sM = zh_bfe(top, 32 - mlLog, mlLog);
+    used += mlLog;
+    ZP_REFILL();
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8, bad = 0;
-    const uint32_t sizeL = 1u << llLog, sizeO = 1u << ofLog, sizeM = 1u << mlLog;
-    for (uint32_t n = 0; n < nbSeq; n++) {
-        const uint32_t cL = Ll->ll[sL], cM = Ll->ml[sM], cO = Ll->of[sO];
-        const uint32_t symL = cL >> 10, symM = cM >> 10, symO = cO >> 10;
-        const uint32_t nibL = (uint32_t)(kLL >> ((4 * symL) & 63)) & 15u, nibM = (uint32_t)(kML >> ((4 * symM) & 63)) & 15u;
-        const uint32_t bitsL = symL < 16 ? 0u : (symL < 32 ? nibL : symL - 19);
-        const uint32_t bitsM = symM < 32 ? 0u : (symM < 48 ? nibM : symM - 36);
-        const uint32_t extra = symO + bitsM + bitsL;
-        uint32_t xo, xm, xl;
-        if (extra > 31) {                               // rare: long offsets plus long lengths
-            xo = ZP_PEEK(symO); used += symO; ZP_NORM();
-            xm = ZP_PEEK(bitsM); used += bitsM; xl = ZP_PEEK(bitsL); used += bitsL; ZP_NORM();
-        } else {
-            xo = ZP_PEEK(symO); used += symO; xm = ZP_PEEK(bitsM); used += bitsM; xl = ZP_PEEK(bitsL); used += bitsL;
-        }
-        const uint32_t ofv = (1u << symO) + xo;
-        const uint32_t mlv = mlBase[symM] + xm;
-        const uint32_t llv = llBase[symL] + xl;
-        // repcode resolution (RFC 8878 3.1.1.5) with selects
-        const uint32_t idx = ofv - 1 + (llv == 0);           // meaningful when ofv <= 3
-        uint32_t ro = idx == 0 ? rep0 : idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
-        if (ro == 0) ro = 1;
-        const bool isRep = ofv <= 3;
-        const uint32_t offset = isRep ? ro : ofv - 3;
-        const bool shift3 = !isRep || idx >= 2;               // rep2 <- rep1
-        const bool shift2 = !isRep || idx >= 1;               // rep1 <- rep0, rep0 <- offset
-        rep2 = shift3 ? rep1 : rep2;
-        rep1 = shift2 ? rep0 : rep1;
-        rep0 = shift2 ? offset : rep0;
-        // state updates (skipped bit-wise for the last sequence by zeroing the widths)
-        const uint32_t live = n + 1 < nbSeq;
+    uint32_t cL, cM, cO;
+#define ZP_DECODE_ONE(n) do { \
+        cL = *(const uint16_t*)(T + 2 * ZP_FSE_LL + 2 * sL); cM = *(const uint16_t*)(T + 2 * ZP_FSE_ML + 2 * sM); cO = *(const uint16_t*)(T + 2 * ZP_FSE_OF + 2 * sO); \
+        const uint32_t symO = cO >> 10; \
+        const uint32_t iL = llInfo[cL >> 10], iM = mlInfo[cM >> 10]; \
+        const uint32_t bitsL = iL >> 24, bitsM = iM >> 24; \
+        top = ZP_TOP(); \
+        const uint32_t xo = zh_bfe(top, 32 - symO, symO); \
+        uint32_t cum = symO; \
+        if (symO + bitsM + bitsL > 32) { used += symO; ZP_REFILL(); top = ZP_TOP(); cum = 0; }     /* rare: far offset with long lengths */ \
+        const uint32_t xm = zh_bfe(top, 32 - cum - bitsM, bitsM); cum += bitsM; \
+        const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL; \
+        used += cum; \
+        ZP_REFILL(); \
+        const uint32_t ofv = (1u << symO) + xo, mlv = (iM & 0xFFFFFFu) + xm, llv = (iL & 0xFFFFFFu) + xl; \
+        /* repcode resolution (RFC 8878 3.1.1.5), select form */ \
+        const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */ \
+        uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro; \
+        ro = ro == 0 ? 1u : ro; \
+        const bool isRep = ofv <= 3; \
+        const uint32_t offset = isRep ? ro : ofv - 3; \
+        const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1); \
+        rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0; \
+        bad |= offset >> 30; \
+        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32); \
+    } while (0)
+    ZP_DECODE_ONE(0);
+    for (uint32_t n = 1; n < nbSeq; n++) {
         const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
-        const uint32_t nbL = live ? llLog - (uint32_t)zh_highbit32(xL) : 0u;
-        const uint32_t nbM = live ? mlLog - (uint32_t)zh_highbit32(xM) : 0u;
-        const uint32_t nbO = live ? ofLog - (uint32_t)zh_highbit32(xO) : 0u;
-        const uint32_t tL = ZP_PEEK(nbL); used += nbL;
-        const uint32_t tM = ZP_PEEK(nbM); used += nbM;
-        const uint32_t tO = ZP_PEEK(nbO); used += nbO;
-        sL = ((xL << nbL) - sizeL + tL) & (sizeL - 1);
-        sM = ((xM << nbM) - sizeM + tM) & (sizeM - 1);
-        sO = ((xO << nbO) - sizeO + tO) & (sizeO - 1);
-        left -= (int32_t)(extra + nbL + nbM + nbO);
-        ZP_NORM();                                       // the load it issues is consumed one iteration later
-        bad |= (uint32_t)(left < 0) | ((offset >> 30) << 1);
-        out[n] = (uint64_t)llv | ((uint64_t)mlv << 17) | ((uint64_t)offset << 34);
+        const uint32_t nbL = (uint32_t)__builtin_clz(xL) - kL, nbM = (uint32_t)__builtin_clz(xM) - kM, nbO = (uint32_t)__builtin_clz(xO) - kO;
+        top = ZP_TOP();                                       /* the three state fields total <= 26 bits */
+        const uint32_t tL = zh_bfe(top, 32 - nbL, nbL), tM = zh_bfe(top, 32 - nbL - nbM, nbM), tO = zh_bfe(top, 32 - nbL - nbM - nbO, nbO);
+        used += nbL + nbM + nbO;
+        sL = ((xL << nbL) + tL) & maskL; sM = ((xM << nbM) + tM) & maskM; sO = ((xO << nbO) + tO) & maskO;
+        ZP_REFILL();
+        ZP_DECODE_ONE(n);
     }
-#undef ZP_PEEK
-#undef ZP_NORM
-    if (bad & 2) return ZE_PARAM_UNSUPPORTED;           // an offset does not fit the packed form (window > 1 GiB)
-    if (bad & 1) return ZE_CORRUPTION;
-    if (left != 0) return ZE_CORRUPTION;
-    *pNbSeq = nbSeq;
+#undef ZP_DECODE_ONE
+#undef ZP_REFILL
+#undef ZP_TOP
+#undef ZP_WORD
+    if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 1 GiB)
+    // every bit of the stream must have been consumed, no more: position = dwords advanced * 32 + used
+    if ((int32_t)((int32_t)size - 16 - off) * 8 + (int32_t)used != (int32_t)size * 8) return ZE_CORRUPTION;
     return 0;
 }
 
-ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, uint8_t* ldsBase, uint32_t* llBase, uint32_t* mlBase, uint8_t* llBits, uint8_t* mlBits)
+ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
 {
     const uint32_t lane = zh_lane();
-    if (lane < 36) { llBase[lane] = zc_llBase[lane]; llBits[lane] = zc_llBits[lane]; }
-    if (lane < 53) { mlBase[lane] = zc_mlBase[lane]; mlBits[lane] = zc_mlBits[lane]; }
+    if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
+    if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
     zh_sync();
-    if (lane >= ZP_K2_LANES) return;
-    ZpLaneLDS* Ll = (ZpLaneLDS*)(ldsBase + (size_t)lane * ZP_K2_LANE_LDS);
-    for (;;) {                                                            // every lane steals its own frames
-        const uint32_t i = zh_atomic_add(a.counters + 1, 1u);
-        if (i >= a.count) break;
-        ZdMeta* m = a.meta + i;
-        if (m->path != 1) continue;
-        const uint32_t f = a.first + i;
-        const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
-        uint32_t nbSeq = 0;
-        const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, Ll, llBase, mlBase, llBits, mlBits,
-                                            a.seqArena + (size_t)i * ZP_SEQ_CAP, &nbSeq);
-        if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
-            m->path = 2;
-            const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f;
-        } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
-        else m->nbSeq = nbSeq;
+    const uint32_t total = a.counters[1];
+    const uint32_t nGroups = (total + ZP_K2_LANES - 1) / ZP_K2_LANES;
+    for (;;) {
+        const uint32_t g = zh_first(zh_atomic_add(a.counters + 3, lane == 0 ? 1u : 0u));
+        if (g >= nGroups) break;
+        const uint32_t k = g * ZP_K2_LANES + lane;
+        const bool active = lane < ZP_K2_LANES && k < total;
+        const uint32_t i = active ? a.order[k] : 0xFFFFFFFFu;
+        zh_sync();
+        // the group's tables, HBM -> LDS, one frame at a time with coalesced dword loads (K1 built them)
+        for (uint32_t j = 0; j < ZP_K2_LANES; j++) {
+            const uint32_t fj = zh_shfl(i, j);
+            if (fj == 0xFFFFFFFFu) break;                                  // active lanes are a prefix
+            const uint32_t* src = (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
+            uint32_t* dstw = (uint32_t*)(L.tab + (size_t)j * ZP_K2_STRIDE);
+            uint32_t r[ZP_FSE_CELLS / 128];                                 // all loads in flight before the first LDS write
+#pragma unroll
+            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) r[q] = src[lane + 64 * q];
+#pragma unroll
+            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) dstw[lane + 64 * q] = r[q];
+        }
+        zh_sync();
+        if (active) {
+            ZdMeta* m = a.meta + i;
+            const uint32_t f = a.first + i;
+            const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+            const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, L.tab + (size_t)lane * ZP_K2_STRIDE, L.llInfo, L.mlInfo,
+                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP);
+            if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
+                m->path = 2;
+                const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
+            } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
+        }
+        zh_sync();
     }
 }
 
 // ------------------------------------------------------------------------------------------ K3 (one wave per frame)
 struct ZpExecLDS { uint8_t asmb[ZD_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8]; };
 
-ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced)
+ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
     const ZdMeta m = a.meta[i];
@@ -394,6 +497,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             op += totT; lp += totL; done += 1;
             continue;
         }
+        ZD_T(P, ZP_STAGE);
         const int32_t sAbs = (int32_t)(op + mRel) - (int32_t)myOF;
         const bool hasM = act && myML > 0;
         const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)op;
@@ -426,6 +530,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         // batch-relative match extents), so the number of rounds is the dependency depth, not the batch length.
         L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
         zh_sync();
+        ZD_T(P, ZP_EXEC1);
         bool pending = hasM && !farM;
         uint64_t need = 0;
         if (pending) {
@@ -485,6 +590,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             }
             zh_sync();
         }
+        ZD_T(P, ZP_EXEC2);
         {
             uint8_t* out = dst + op;
             for (uint32_t j = lane * 16; j < totT; j += 1024) {
@@ -498,6 +604,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             }
         }
         zh_sync();
+        ZD_T(P, ZP_FLUSH);
         op += totT; lp += totL; done += cnt;
     }
     const uint32_t rest = m.litSize - lp;
@@ -532,7 +639,10 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
         if (i >= a.count) break;
         if (a.meta[i].path != 1) continue;
         uint32_t produced = 0;
-        const int err = zp_exec_frame(a, L, i, &produced);
+        ZdProf P; P.on = a.prof != nullptr;
+        if (P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
+        const int err = zp_exec_frame(a, L, i, &produced, P);
+        if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }
     }

@@ -37,6 +37,7 @@ ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v);
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { atomicAdd(p, 1u); }
+ZH_DEV uint32_t zh_lds_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV uint32_t zh_wave_max(uint32_t v) { for (int d = 32; d; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; } return v; }
 ZH_DEV void ze_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 // hides a value's provenance from the optimizer (used so `lane == 0` is not provably loop-invariant)
@@ -44,6 +45,10 @@ ZH_DEV uint32_t zh_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }   // v != 0
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
+// v_bfe_u32: (v >> (off & 31)) & ((1 << (width & 31)) - 1); width 0 gives 0 whatever off is
+ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+// v_alignbit_b32: low 32 bits of ((hi:lo) >> (sh & 31))
+ZH_DEV uint32_t zh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
 #else
 // =====================================================================================  emulation
@@ -98,6 +103,7 @@ ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __syn
 ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { (*p)++; }
+ZH_DEV uint32_t zh_lds_atomic_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 ZH_DEV uint32_t zh_wave_max(uint32_t v)
 {
     zhemu::slot[zhemu::lane] = v;
@@ -111,6 +117,8 @@ ZH_DEV void ze_fence() { zhemu::collective_wait(); }
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
+ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { width &= 31; return (v >> (off & 31)) & ((1u << width) - 1); }
+ZH_DEV uint32_t zh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
 #endif
 
 // ------------------------------------------------------------------------------------- common helpers

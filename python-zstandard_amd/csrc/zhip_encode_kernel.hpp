@@ -1150,7 +1150,8 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     const uint8_t* content = dict + contentOff;
     zh_sync();
     if (zh_opaque(lane) == 0) {
-        ZePar p; int st = ze_cdict_params(p, level, dictSize);
+        ZePar p; p.wlog = p.clog = p.hlog = p.mml = p.strat = 0;
+        int st = ze_cdict_params(p, level, dictSize);
         if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
         cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
         cd->contentSize = cs; cd->dictID = hasEntropy ? de->dictID : 0u;

@@ -136,26 +136,36 @@ struct ZeCDict {
 struct ZdMeta {
     int32_t  status;        // 0 or a zstd error code
     uint32_t path;          // 0: finished in K1 (raw / RLE / empty, or failed), 1: fast path (K2 + K3), 2: generic fused kernel
-    uint32_t seqOff;        // sequences section [seqOff, seqEnd) inside the frame
+    uint32_t seqOff;        // the sequences bitstream is [seqOff, seqEnd) inside the frame (headers and table descriptions consumed)
     uint32_t seqEnd;
     uint32_t litSize;
-    uint32_t litMode;       // 0: literals sit in the frame at litOff, 1: in this frame's literal slot, 2: RLE (litOff = byte)
+    uint32_t litMode;       // 0: literals sit in the frame at litOff, 1: in this frame's literal slot, 2: RLE (litOff = byte),
+                            // 3 | log << 8 | fourStreams << 16: Huffman streams at litOff (produced = their byte count) still to be
+                            //    decoded into the literal slot by K1b with the table K1 left in the Huffman-table arena
     uint32_t litOff;
-    uint32_t nbSeq;         // filled by K2
+    uint32_t nbSeq;         // sequence count (K1 reads it from the sequences header)
     uint32_t blockMax;
     uint32_t fcsLo, fcsHi;  // frame content size (0xFFFFFFFF/0xFFFFFFFF when absent)
     uint32_t produced;
     uint32_t hasChecksum, checksum;   // content checksum to verify after execution
-    uint32_t pad[2];
+    uint32_t logs;          // llLog | ofLog << 8 | mlLog << 16 of the frame's FSE tables (built by K1 into the table arena)
+    uint32_t pad;
 };
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
 #define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)
 #define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
-#ifndef ZP_K2_LANES
-#define ZP_K2_LANES 16
-#endif
-//                                // frames decoded per wave in K2 (one lane each)
-#define ZP_K2_LANE_LDS 2820                             // bytes of LDS per K2 lane (odd dword stride: no bank aliasing)
+// per-frame FSE decoding tables in HBM / L2: 2-byte cells (symbol << 10 | x), LL 512 + ML 512 + OF 256 cells
+#define ZP_FSE_LL 0
+#define ZP_FSE_ML 512
+#define ZP_FSE_OF 1024
+#define ZP_FSE_CELLS 1280
+#define ZP_K2_LANES 63                                  // frames decoded per K2 wave (one lane each); one wave per CU
+#define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
+#define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
+#define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)
+#define ZP_HUF_FRAMES 16                                // frames per K1b wave: 4 lanes (the 4 streams) each
+#define ZP_LITBIN_SHIFT 9                               // K1b work order: frames binned by litSize >> 9
+#define ZP_BIN_SHIFT 7                                  // K2 work order: frames binned by nbSeq >> 7 (256 bins), longest first
 
 struct ZhipPipeArgs {
     const uint8_t* src; const uint64_t* srcSegs;
@@ -164,9 +174,15 @@ struct ZhipPipeArgs {
     ZdMeta* meta;               // chunk-local
     uint8_t* litArena;          // chunk x ZP_LIT_STRIDE
     uint64_t* seqArena;         // chunk x ZP_SEQ_CAP
-    uint32_t* counters;         // [0] K1 work, [1] K2 work, [2] K3 work (per chunk slot)
+    uint16_t* fseTables;        // chunk x ZP_FSE_CELLS
+    uint32_t* order;            // chunk : K2's work list (chunk-local frame indices sorted by decreasing sequence count)
+    uint16_t* hufTables;        // chunk x ZP_HUF_CELLS : Huffman decoding tables (symbol | nbBits << 8) for K1b
+    uint32_t* orderLit;         // chunk : K1b's work list (frames with Huffman literals, by decreasing literal count)
+    uint32_t* counters;         // per chunk slot: [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
+                                //                 [4] length of `orderLit`, [5] K1b group counter
     uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk
     uint64_t maxWindowSize;
+    unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases
 };

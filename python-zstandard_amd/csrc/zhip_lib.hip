@@ -26,12 +26,20 @@ ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_kernel(ZhipPipeArgs a)
     __shared__ ZdLDS L;
     zp_lit_body(a, L);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_bin_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpBinLDS L;
+    zp_bin_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_huf_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpHufLDS L;
+    zp_huf_body(a, L);
+}
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ZP_K2_LANES * ZP_K2_LANE_LDS];
-    __shared__ uint32_t llBase[36], mlBase[53];
-    __shared__ uint8_t llBits[36], mlBits[56];
-    zp_seq_body(a, lds, llBase, mlBase, llBits, mlBits);
+    __shared__ ZpSeqLDS L;
+    zp_seq_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
@@ -184,6 +192,7 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+#define ZHIP_NTIMER 8
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
     std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
@@ -196,7 +205,7 @@ struct zhip_ctx {
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
-    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback;
+    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables;
     int e1PerCU = 0, e2PerCU = 0;
@@ -213,7 +222,7 @@ struct zhip_ctx {
     // host-API staging
     DevBuf hSrc, hDst, hSegs, hStatus;
     void* pinned = nullptr; size_t pinnedCap = 0;
-    KTimer timer[7];     // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy
+    KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
 };
 
 extern "C" zhip_ctx* zhip_ctx_create(void)
@@ -263,10 +272,10 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 7; i++) drain_shared(c->timer[i]);
-    for (int i = 0; i < 7; i++) drain_timer(c->timer[i]);
+    for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
+    for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
-    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release();
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
@@ -275,16 +284,16 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
 }
 extern "C" const char* zhip_kernel_name(int k)
 {
-    static const char* names[7] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
+    static const char* names[ZHIP_NTIMER] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
                                    "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
-                                   "zhip_encode_entropy_kernel"};
-    return k >= 0 && k < 7 ? names[k] : "";
+                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel"};
+    return k >= 0 && k < ZHIP_NTIMER ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
 {
-    if (!c || direction < 0 || direction > 6) return ZHIP_ERR_UNSUPPORTED;
+    if (!c || direction < 0 || direction >= ZHIP_NTIMER) return ZHIP_ERR_UNSUPPORTED;
     HIP_TRY(hipDeviceSynchronize());
-    for (int i = 0; i < 7; i++) drain_shared(c->timer[i]);
+    for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     KTimer& t = c->timer[direction];
     drain_timer(t);
     if (avgMs) *avgMs = t.launches ? t.totalMs / (double)t.launches : 0.0;
@@ -401,12 +410,16 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        const size_t chunkMax = ZHIP_DCHUNK;
+        size_t chunkMax = ZHIP_DCHUNK; int slotMax = ZHIP_NSLOT;
+        if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) chunkMax = (size_t)v; }    // tuning knobs
+        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) slotMax = (int)v; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t nChunks = (n + chunk - 1) / chunk;
-        const int nslot = (int)(nChunks < ZHIP_NSLOT ? nChunks : ZHIP_NSLOT);
+        const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
         if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
-            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16)) return ZHIP_ERR_HIP;
+            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16) ||
+            c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
+            c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return ZHIP_ERR_HIP;
         for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 256, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
@@ -417,7 +430,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
         pa.outSizes = d_outSizes; pa.status = d_status; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
         pa.maxWindowSize = c->maxWindowSize;
-        uint32_t* counters = (uint32_t*)c->pipeCounters.p;        // [0] = fallback length, then 4 words per slot
+        static unsigned long long* d_pprof = nullptr;
+        if (getenv("ZHIP_PROF")) {
+            if (!d_pprof) HIP_TRY(hipMalloc((void**)&d_pprof, 32 * 8));
+            HIP_TRY(hipMemsetAsync(d_pprof, 0, 32 * 8, stream));
+            pa.prof = d_pprof;
+        }
+        uint32_t* counters = (uint32_t*)c->pipeCounters.p;        // [0] = fallback length, then 8 words per slot
         pa.fallbackCount = counters;
         size_t ci = 0;
         for (size_t first = 0; first < n; first += chunk, ci++) {
@@ -428,15 +447,26 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * chunk;
             pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * chunk * ZP_LIT_STRIDE;
             pa.seqArena = (uint64_t*)c->pipeSeq.p + (size_t)sidx * chunk * ZP_SEQ_CAP;
-            pa.counters = counters + 4 + 4 * sidx;
-            if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 16, ss));
-            const size_t g1m = (size_t)c->numCU * c->k1PerCU, g2m = (size_t)c->numCU * c->k2PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
-            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;
-            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
-            hipEvent_t ev[4];
+            pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * chunk * ZP_FSE_CELLS;
+            pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * chunk;
+            pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * chunk * ZP_HUF_CELLS;
+            pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * chunk;
+            pa.counters = counters + 8 + 8 * sidx;
+            if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 32, ss));
+            const size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
+            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;          // K2 takes a whole CU's LDS: one wave per CU
+            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < (size_t)c->numCU ? w2 : (size_t)c->numCU), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
+            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * 2;      // K1b: 64 KiB of LDS per wave
+            const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
+            hipEvent_t ev[4], evh, evh2;
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));
+            HIP_TRY(hipEventCreate(&evh)); HIP_TRY(hipEventCreate(&evh2));
             HIP_TRY(hipEventRecord(ev[0], ss));
             hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2), dim3(64), 0, ss, pa);      // tiny; timed with K1
+            HIP_TRY(hipEventRecord(evh, ss));
+            HIP_TRY(hipEventRecord(evh2, ss));
+            hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             HIP_TRY(hipEventRecord(ev[1], ss));
             hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
             HIP_TRY(hipEventRecord(ev[2], ss));
@@ -444,10 +474,45 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
             // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
-            // ev[0..1], K3's owns ev[2..3]; K2's pair (ev[1], ev[2]) is borrowed and always drained before any destroy.
-            c->timer[2].pending.emplace_back(ev[0], ev[1]);
+            // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
+            // before any destroy.
+            c->timer[2].pending.emplace_back(ev[0], evh);          // K1 (+ the two bin waves)
+            c->timer[7].pending.emplace_back(evh2, ev[1]);         // K1b
             c->timer[3].shared.emplace_back(ev[1], ev[2]);
             c->timer[4].pending.emplace_back(ev[2], ev[3]);
+        }
+        if (pa.prof) {
+            HIP_TRY(hipDeviceSynchronize());
+            unsigned long long h[32];
+            HIP_TRY(hipMemcpy(h, pa.prof, sizeof h, hipMemcpyDeviceToHost));
+            static const char* nm[10] = {"header", "huf-table", "huf-decode", "seq-header+fse", "K3 load+scan", "-", "K3 literal/far fetch", "K3 near rounds", "K3 flush", "tail"};
+            for (int k = 0; k < 2; k++) {
+                unsigned long long tot = 0; for (int q = 0; q < 10; q++) tot += h[16 * k + q];
+                fprintf(stderr, "[zhip-prof] %s: %.0f wave-cycles per frame\n", k ? "K3" : "K1", (double)tot / (double)n);
+                for (int q = 0; q < 10; q++) if (h[16 * k + q]) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[16 * k + q] / (tot ? tot : 1), (double)h[16 * k + q] / (double)n);
+            }
+        }
+        if (getenv("ZHIP_DEBUG_PIPE")) {          // bring-up aid: per-frame records of the first chunk, after the pipeline drained
+            HIP_TRY(hipDeviceSynchronize());
+            const size_t cnt = n < chunk ? n : chunk;
+            std::vector<ZdMeta> hm(cnt); std::vector<uint32_t> ord(cnt); uint32_t hc[16];
+            HIP_TRY(hipMemcpy(hm.data(), c->pipeMeta.p, cnt * sizeof(ZdMeta), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ord.data(), c->pipeOrder.p, cnt * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(hc, c->pipeCounters.p, sizeof hc, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pipe] counters: fallback %u | slot0 k1 %u order %u k3 %u\n", hc[0], hc[4], hc[5], hc[6]);
+            for (size_t i = 0; i < cnt && i < 64; i++) {
+                const ZdMeta& m = hm[i];
+                fprintf(stderr, "[pipe] frame %zu status %d path %u seq [%u,%u) lit %u mode %u nbSeq %u logs %06x produced %u order[%zu]=%u\n", i, m.status, m.path,
+                        m.seqOff, m.seqEnd, m.litSize, m.litMode, m.nbSeq, m.logs, m.produced, i, ord[i]);
+                if (m.nbSeq) {
+                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8];
+                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + i * ZP_SEQ_CAP, sizeof q, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
+                            (uint32_t)q[0] & 0x1FFFF, (uint32_t)(q[0] >> 17) & 0x1FFFF, (uint32_t)(q[0] >> 34),
+                            (uint32_t)q[1] & 0x1FFFF, (uint32_t)(q[1] >> 17) & 0x1FFFF, (uint32_t)(q[1] >> 34), cells[0], cells[1], cells[2], cells[3]);
+                }
+            }
         }
         for (int sidx = 0; sidx < nslot; sidx++) {                 // the caller's stream continues after every slot has drained
             hipEvent_t evEnd; HIP_TRY(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
@@ -518,7 +583,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         fprintf(stderr, "[zhip-prof] grid=%u (CUs %d x %d blocks) frames=%u wave-cycles total=%.3e (%.0f per frame)\n", grid, c->numCU, c->decBlocksPerCU, a.n, (double)tot, (double)tot / a.n);
         for (int i = 0; i < ZP_N; i++) fprintf(stderr, "[zhip-prof]   %-22s %6.2f%%  %10.0f cyc/frame\n", names[i], 100.0 * h[i] / (tot ? tot : 1), (double)h[i] / a.n);
     }
-    if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < 7; i++) drain_shared(c->timer[i]); for (int i = 0; i < 7; i++) drain_timer(c->timer[i]); }
+    if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]); for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]); }
     return 0;
 }
 extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,

@@ -23,6 +23,7 @@ extern "C" int emu_decompress_batch(const uint8_t* src, const uint64_t* srcSegs,
     a.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
     a.counter = &counter; a.n = n; a.dictID = dictID; a.dictContent = dictContent; a.dictContentSize = dictContentSize;
     a.dictEntropy = de; a.maxWindowSize = (1ull << 27) + 1;
+    memset(&g_lds, 0xA5, sizeof g_lds);
     DecLaunch l = { &a };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     free(a.scratch);
@@ -86,6 +87,7 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
     a.counter = &counter; a.n = n; a.level = level;
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
     attach_cdict(a);
+    memset(&g_elds, 0xA5, sizeof g_elds);
     EncLaunch l = { &a };
     zhemu::run_grid(nBlocks, enc_lane, &l);
     free(a.workspace);
@@ -94,27 +96,40 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
 
 // ---- phase-split decode pipeline under emulation
 static ZpExecLDS g_xlds;
-static uint8_t g_k2lds[ZP_K2_LANES * ZP_K2_LANE_LDS + 64];
+static ZpBinLDS g_binlds;
 static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBits[56];
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
-static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_k2lds, g_llBase, g_mlBase, g_llBits, g_mlBits); }
+static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
+static ZpSeqLDS g_seqlds;
+static ZpHufLDS g_huflds;
+static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
+static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
 static void k3_lane(void* p) { zp_exec_body(*(const ZhipPipeArgs*)p, g_xlds); }
 extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst,
                                        const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status, uint32_t nBlocks, uint32_t chunk)
 {
     ZhipPipeArgs a; memset(&a, 0, sizeof(a));
-    uint32_t counters[4] = {0, 0, 0, 0};
+    uint32_t counters[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // [0..7] per-slot words, [8] fallback length
     if (chunk == 0 || chunk > n) chunk = n ? n : 1;
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
     a.litArena = (uint8_t*)malloc((size_t)chunk * ZP_LIT_STRIDE);
     a.seqArena = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE);
-    a.counters = counters; a.fallbackCount = &counters[3]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
+    a.fseTables = (uint16_t*)malloc((size_t)chunk * ZP_FSE_CELLS * 2);
+    a.order = (uint32_t*)calloc(chunk, 4);
+    a.hufTables = (uint16_t*)malloc((size_t)chunk * ZP_HUF_CELLS * 2 + 64);
+    a.orderLit = (uint32_t*)calloc(chunk, 4);
+    a.counters = counters; a.fallbackCount = &counters[8]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
-        counters[0] = counters[1] = counters[2] = 0;
+        for (int q = 0; q < 8; q++) counters[q] = 0;
+        memset(&g_lds, 0xA5, sizeof g_lds); memset(&g_xlds, 0xA5, sizeof g_xlds); memset(&g_binlds, 0xA5, sizeof g_binlds);   // LDS is not zeroed on hardware
         zhemu::run_grid(nBlocks, k1_lane, &a);
+        zhemu::run_grid(2, kb_lane, &a);
+        memset(&g_huflds, 0xA5, sizeof g_huflds);
+        zhemu::run_grid(nBlocks, kh_lane, &a);
+        memset(&g_seqlds, 0xA5, sizeof g_seqlds);
         zhemu::run_grid(nBlocks, k2_lane, &a);
         zhemu::run_grid(nBlocks, k3_lane, &a);
     }
@@ -123,11 +138,11 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     uint32_t counter = 0;
     g.src = src; g.srcSegs = srcSegs; g.dst = dst; g.dstSegs = dstSegs; g.outSizes = outSizes; g.status = status;
     g.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
-    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.frameList = a.fallbackList; g.listCount = &counters[3];
+    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.frameList = a.fallbackList; g.listCount = &counters[8];
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
-    int nfb = (int)counters[3];
-    free(g.scratch); free(a.meta); free(a.litArena); free(a.seqArena); free(a.fallbackList);
+    int nfb = (int)counters[8];
+    free(g.scratch); free(a.meta); free(a.litArena); free(a.seqArena); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
     return nfb;
 }
 
@@ -150,6 +165,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
     a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
     attach_cdict(a);
+    memset(&g_elds, 0xA5, sizeof g_elds);
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0;

@@ -59,3 +59,48 @@ def test_emulated_dictionary_compression_matches_golden(emu):
                 assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (key, pipeline)
     outs, st = emu.compress_batch([b"a" * 16385, b"abc" * 100], level=3, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
     assert st[0] == 40 and st[1] == 0       # parameter_unsupported for the oversize source only
+
+
+def test_emulated_decode_pipeline_matches_oracle(emu, oracle, corpus):
+    """K1 -> bin -> K2 -> K3 under emulation: mixed frame kinds in one batch, several chunkings, errors isolated per frame"""
+    import numpy as np
+    from tests.test_oracle_vs_golden import GOLD, BLOB
+    rng = np.random.default_rng(9)
+    raws = [b"", b"foo", b"a" * 5000, b"abcabcabcabcabcabcabcabcabc" * 300, rng.bytes(3000), bytes(rng.integers(0, 4, 9000, dtype=np.uint8))]
+    raws += [corpus.frame_bytes(i)[: 6000 + 2777 * i] for i in range(10)]
+    frames = [oracle.compress(r, flags=7 if k % 3 == 0 else 5) for k, r in enumerate(raws)]
+    mb = GOLD["multiblock_level19"]                      # multi-block frame: takes the fallback list to the generic kernel
+    frames.append(BLOB[mb["blob_offset"]: mb["blob_offset"] + mb["frame_size"]]); raws.append(oracle.decompress(frames[-1], mb["size"]))
+    sizes = [len(r) for r in raws]
+    for chunk in (0, 5):
+        outs, st, nfb = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=chunk)
+        assert not any(st) and nfb == 1
+        assert outs == raws
+    # damage: truncated, bit-flipped in the sequences section, wrong checksum -- neighbours unaffected
+    bad = list(frames[:-1])
+    bad[7] = bad[7][: len(bad[7]) - 9]
+    b = bytearray(bad[9]); b[-20] ^= 0x10; bad[9] = bytes(b)
+    b = bytearray(bad[6]); b[-1] ^= 0xFF; bad[6] = bytes(b)          # frame 6 carries a checksum (k % 3 == 0)
+    outs, st, nfb = emu.decompress_pipeline(bad, sizes[:-1], n_blocks=2, chunk=4)
+    assert st[7] != 0 and st[6] == 22
+    for k in range(len(bad)):
+        if k not in (6, 7, 9):
+            assert st[k] == 0 and outs[k] == raws[k]
+    if st[9] == 0:
+        assert outs[9] == oracle.decompress(bad[9], sizes[9])
+    # damage inside the Huffman streams / tree description (K1, K1b): never accept what the oracle rejects
+    for pos in (14, 40, 90, 200, 400):
+        bad = list(frames[:-1])
+        for k in (10, 12, 14):
+            b = bytearray(bad[k]); b[pos] ^= 0x04; bad[k] = bytes(b)
+        outs, st, nfb = emu.decompress_pipeline(bad, sizes[:-1], n_blocks=2, chunk=0)
+        for k in (10, 12, 14):
+            try:
+                want = oracle.decompress(bad[k], sizes[k])
+            except RuntimeError:
+                want = None
+            if want is None:
+                assert st[k] != 0, (pos, k)
+            elif st[k] == 0:
+                assert outs[k] == want, (pos, k)
+        assert st[11] == 0 and outs[11] == raws[11]
