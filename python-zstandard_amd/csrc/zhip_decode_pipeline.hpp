@@ -228,10 +228,10 @@ ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, u
     if (last == 0) return false;
 #define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
 #define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
-#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; used = ge_ ? used - 32 : used; \
-        off = ge_ ? off - 4 : off; n2 = ZP_WORD(off); } while (0)
-    int32_t off = (int32_t)size - 16;
-    uint32_t hi = ZP_WORD(off + 12), lo = ZP_WORD(off + 8), n1 = ZP_WORD(off + 4), n2 = ZP_WORD(off);
+#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; n2 = ge_ ? n3 : n2; n3 = ge_ ? n4 : n3; \
+        n4 = ge_ ? n5 : n4; used = ge_ ? used - 32 : used; off = ge_ ? off - 4 : off; n5 = ZP_WORD(off); } while (0)
+    int32_t off = (int32_t)size - 28;
+    uint32_t hi = ZP_WORD(off + 24), lo = ZP_WORD(off + 20), n1 = ZP_WORD(off + 16), n2 = ZP_WORD(off + 12), n3 = ZP_WORD(off + 8), n4 = ZP_WORD(off + 4), n5 = ZP_WORD(off);
     uint32_t used = 8 - (uint32_t)zh_highbit32(last);
     const uint32_t sh = 32 - log;
     uint32_t i = 0;
@@ -258,7 +258,7 @@ ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, u
 #undef ZP_REFILL
 #undef ZP_TOP
 #undef ZP_WORD
-    return (int32_t)((int32_t)size - 16 - off) * 8 + (int32_t)used == (int32_t)size * 8;     // consumed exactly
+    return (int32_t)((int32_t)size - 28 - off) * 8 + (int32_t)used == (int32_t)size * 8;     // consumed exactly
 }
 
 ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
@@ -336,17 +336,18 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
     if (size == 0) return ZE_CORRUPTION;
     const uint32_t last = p[size - 1];
     if (last == 0) return ZE_CORRUPTION;
-    // Bit window: the stream is consumed from its last byte down, a dword at a time. hi:lo are the current dwords, n1/n2 the next
-    // two (prefetched). `used` bits of hi are gone; invariant at every group start: 1 <= used <= 32, so the next 32 stream bits are
+    // Bit window: the stream is consumed from its last byte down, a dword at a time. hi:lo are the current dwords, n1..n5 the next
+    // five, loaded that far ahead because loads return in order for the whole wave: any lane's HBM miss must be older than the
+    // latency by the time another lane needs its own dword (two dwords ahead measured 1000 cycles per sequence, i.e. the latency). `used` bits of hi are gone; invariant at every group start: 1 <= used <= 32, so the next 32 stream bits are
     // one v_alignbit away (ZP_TOP) and fields totalling <= 32 bits are cut from that with v_bfe. After a group ZP_REFILL advances
     // by at most one dword. Loads may reach up to 4 bytes below p (inside the frame: >= 11 header bytes precede any sequences
     // bitstream); those bytes are only consumed by a corrupt stream, which the position check at the end rejects.
 #define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
 #define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
-#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; used = ge_ ? used - 32 : used; \
-        off = ge_ ? off - 4 : off; n2 = ZP_WORD(off); } while (0)
-    int32_t off = (int32_t)size - 16;                       // offset of the lowest prefetched dword; not clamped: it is the position
-    uint32_t hi = ZP_WORD(off + 12), lo = ZP_WORD(off + 8), n1 = ZP_WORD(off + 4), n2 = ZP_WORD(off);
+#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; n2 = ge_ ? n3 : n2; n3 = ge_ ? n4 : n3; \
+        n4 = ge_ ? n5 : n4; used = ge_ ? used - 32 : used; off = ge_ ? off - 4 : off; n5 = ZP_WORD(off); } while (0)
+    int32_t off = (int32_t)size - 28;                       // offset of the lowest prefetched dword; not clamped: it is the position
+    uint32_t hi = ZP_WORD(off + 24), lo = ZP_WORD(off + 20), n1 = ZP_WORD(off + 16), n2 = ZP_WORD(off + 12), n3 = ZP_WORD(off + 8), n4 = ZP_WORD(off + 4), n5 = ZP_WORD(off);
     uint32_t used = 8 - (uint32_t)zh_highbit32(last);       // padding + end mark
     const uint32_t maskL = (1u << llLog) - 1, maskO = (1u << ofLog) - 1, maskM = (1u << mlLog) - 1;
     const uint32_t kL = 31 - llLog, kO = 31 - ofLog, kM = 31 - mlLog;
@@ -402,7 +403,7 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
 #undef ZP_WORD
     if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 1 GiB)
     // every bit of the stream must have been consumed, no more: position = dwords advanced * 32 + used
-    if ((int32_t)((int32_t)size - 16 - off) * 8 + (int32_t)used != (int32_t)size * 8) return ZE_CORRUPTION;
+    if ((int32_t)((int32_t)size - 28 - off) * 8 + (int32_t)used != (int32_t)size * 8) return ZE_CORRUPTION;
     return 0;
 }
 
@@ -469,16 +470,18 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     uint8_t* const asmb = L.asmb;
     uint32_t op = 0, lp = 0, done = 0;
     const uint32_t nbSeq = m.nbSeq;
+    uint64_t qNext = lane < nbSeq ? seqs[lane] : 0;      // the next batch's sequences are requested a batch ahead
     while (done < nbSeq) {
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
-        if (lane < avail) { const uint64_t q = seqs[done + lane]; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }
+        if (lane < avail) { const uint64_t q = qNext; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer
         const uint64_t fits = zh_ballot(lane < avail && incT <= ZD_ASM_BYTES);
         uint32_t cnt = (uint32_t)zh_popc64(fits);          // fits is a prefix mask (incT is monotone)
         const bool big = cnt == 0;
         if (big) cnt = 1;
+        qNext = done + cnt + lane < nbSeq ? seqs[done + cnt + lane] : 0;
         const bool act = lane < cnt;
         if (!act) { myLL = 0; myML = 0; myOF = 1; }
         const uint32_t totL = zh_shfl(incL, cnt - 1), totT = zh_shfl(incT, cnt - 1);

@@ -159,7 +159,10 @@ struct ZdMeta {
 #define ZP_FSE_ML 512
 #define ZP_FSE_OF 1024
 #define ZP_FSE_CELLS 1280
-#define ZP_K2_LANES 63                                  // frames decoded per K2 wave (one lane each); one wave per CU
+#ifndef ZP_K2_LANES
+#define ZP_K2_LANES 63
+#endif
+//      ^                                  // frames decoded per K2 wave (one lane each); one wave per CU
 #define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
 #define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
 #define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)

@@ -41,7 +41,10 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)
     __shared__ ZpSeqLDS L;
     zp_seq_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_decode_exec_kernel(ZhipPipeArgs a)
+#ifndef ZP_K3_MINWAVES
+#define ZP_K3_MINWAVES 1
+#endif
+ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpExecLDS L;
     zp_exec_body(a, L);
@@ -178,7 +181,7 @@ extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
 #define ZHIP_NSLOT 3
 #endif
 #ifndef ZHIP_DCHUNK
-#define ZHIP_DCHUNK 8192
+#define ZHIP_DCHUNK 32768
 #endif
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -410,7 +413,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        size_t chunkMax = ZHIP_DCHUNK; int slotMax = ZHIP_NSLOT;
+        size_t chunkMax = ZHIP_DCHUNK; int slotMax = 2;      // measured best on MI355X (profiles/README.md, r01c): 32768 frames x 2 slots
         if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) chunkMax = (size_t)v; }    // tuning knobs
         if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) slotMax = (int)v; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
@@ -453,7 +456,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * chunk;
             pa.counters = counters + 8 + 8 * sidx;
             if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 32, ss));
-            const size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
+            size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
+            if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g3m = (size_t)c->numCU * (size_t)v; }   // tuning knobs
+            if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g1m = (size_t)c->numCU * (size_t)v; }
             const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;          // K2 takes a whole CU's LDS: one wave per CU
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < (size_t)c->numCU ? w2 : (size_t)c->numCU), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * 2;      // K1b: 64 KiB of LDS per wave
