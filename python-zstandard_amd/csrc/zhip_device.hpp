@@ -135,6 +135,20 @@ ZH_DEV void zh_st16(uint8_t* p, uint16_t v) { *(zh_u16u*)p = v; }
 ZH_DEV uint64_t zh_lt_mask() { return (1ull << zh_lane()) - 1; }
 
 // inclusive wave prefix sum (all 64 lanes must call)
+#ifndef ZHIP_EMU
+// six DPP adds: Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals carried across rows with the
+// gfx9 row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3). Lanes without a source add 0.
+ZH_DEV uint32_t zh_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+#else
 ZH_DEV uint32_t zh_scan_add(uint32_t v)
 {
     for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -143,3 +157,4 @@ ZH_DEV uint32_t zh_scan_add(uint32_t v)
     }
     return v;
 }
+#endif

@@ -19,6 +19,11 @@ def _enc():
     return reflib.RefZstd() if reflib.have_ref() else reflib.Oracle()
 
 
+def test_wave_primitives_selftest(zstd):
+    """scan (DPP), ballot, shuffles, readfirstlane as the kernels use them"""
+    assert zstd._lib.lib().zhip_selftest() == 0, zstd._lib.last_error()
+
+
 def test_small_and_edge_frames(zstd, oracle):
     enc = _enc()
     raws = [b"", b"foo", b"foo" * 4, b"bar" * 6, b"a" * 1000, b"a" * 131072, bytes(range(256)) * 40,
