@@ -37,9 +37,13 @@ static const zo_cpar zo_rows[4][5] = {
 static int zo_get_cparams(zo_cpar* out, int level, uint64_t srcSize)
 {
     if (level == 0) level = 3;
-    if (level < 1 || level > 4) return -ZO_E_PARAM_UNSUPPORTED;
+    if (level > 4) return -ZO_E_PARAM_UNSUPPORTED;
     unsigned tableID = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
-    zo_cpar c = zo_rows[tableID][level];
+    zo_cpar c = zo_rows[tableID][level < 0 ? 0 : level];
+    if (level < 0) {                                    /* negative levels: row 0 with targetLength = -level (zstd.c:30870-30875) */
+        if (level < -(1 << 17)) level = -(1 << 17);
+        c.tlen = -level;
+    }
     /* shrink to the source (no dictionary): window, then hash and chain logs follow the window */
     uint32_t t = (uint32_t)srcSize;
     int srcLog = (t < 64) ? 6 : zo_highbit(t - 1) + 1;
@@ -696,6 +700,91 @@ static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8
 }
 
 
+/* ------------------------------------------------------------------ fast strategy (levels 1-2 and negative levels)
+ * Restates ZSTD_compressBlock_fast_noDict_generic (zstd.c:31906) for a block that is the whole frame. One hash table (hashLog bits,
+ * minMatch bytes hashed), cells hold position + 2 (0 = empty). Positions are examined in pairs (p, p+1) `step` apart; the pair
+ * distance grows by one for every 128 bytes advanced without a match; a repcode test sits two positions ahead of the first of a
+ * pair; the table write for the second position of a pair is skipped after a hit only when step > 4. */
+static size_t zo_fast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp, uint32_t* table)
+{
+    const int hlog = cp->hlog;
+    const int mls = cp->mml <= 4 ? 4 : cp->mml >= 7 ? 7 : cp->mml;
+    const size_t stepSize = (size_t)cp->tlen + !cp->tlen + 1;
+    const uint8_t* const base = src - 2;
+    const uint32_t LOW = 2;
+    const uint8_t* const iend = src + srcSize;
+    const uint8_t* const ilimit = iend - 8;
+    const uint8_t* anchor = src;
+    const uint8_t* ip0 = src + 1;
+    uint32_t rep1 = 1, rep2 = 0;                       /* {1,4} clipped to what the empty history allows */
+    size_t nseq = 0; uint8_t* lp = lits;
+    memset(table, 0, sizeof(uint32_t) << hlog);
+#define STORE(LL, OFFBASE, ML) do { size_t ll_ = (LL); memcpy(lp, anchor, ll_); lp += ll_; \
+        seqs[nseq].litLength = (uint32_t)ll_; seqs[nseq].offBase = (OFFBASE); seqs[nseq].matchLength = (uint32_t)(ML); nseq++; } while (0)
+#define IDX(p) ((uint32_t)((p) - base))
+    if (srcSize >= 8) for (;;) {
+        size_t step = stepSize;
+        const uint8_t* nextStep = ip0 + 128;
+        const uint8_t* ip1 = ip0 + 1; const uint8_t* ip2 = ip0 + step; const uint8_t* ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        uint32_t hash0 = hash_n(ip0, hlog, mls), hash1 = hash_n(ip1, hlog, mls);
+        uint32_t matchIdx = table[hash0];
+        uint32_t current0 = 0, offBase = 0; size_t mLength = 0; const uint8_t* match0 = NULL;
+        int found = 0;      /* 1 repcode, 2 offset */
+        do {
+            const uint32_t rval = zo_rd32(ip2 - rep1);
+            current0 = IDX(ip0); table[hash0] = current0;
+            if (zo_rd32(ip2) == rval && rep1 > 0) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = (ip0[-1] == match0[-1]);
+                ip0 -= mLength; match0 -= mLength;
+                offBase = 1; mLength += 4;
+                table[hash1] = IDX(ip1);
+                found = 1; break;
+            }
+            if (matchIdx >= LOW && zo_rd32(base + matchIdx) == zo_rd32(ip0)) { table[hash1] = IDX(ip1); found = 2; break; }
+            matchIdx = table[hash1];
+            hash0 = hash1; hash1 = hash_n(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = IDX(ip0); table[hash0] = current0;
+            if (matchIdx >= LOW && zo_rd32(base + matchIdx) == zo_rd32(ip0)) { if (step <= 4) table[hash1] = IDX(ip1); found = 2; break; }
+            matchIdx = table[hash1];
+            hash0 = hash1; hash1 = hash_n(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (found == 2) {
+            match0 = base + matchIdx;
+            rep2 = rep1; rep1 = (uint32_t)(ip0 - match0);
+            offBase = rep1 + 3; mLength = 4;
+            while (ip0 > anchor && match0 > base + LOW && ip0[-1] == match0[-1]) { ip0--; match0--; mLength++; }
+        }
+        mLength += common_len(ip0 + mLength, match0 + mLength, iend);
+        STORE(ip0 - anchor, offBase, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip0 <= ilimit) {
+            table[hash_n(base + current0 + 2, hlog, mls)] = current0 + 2;
+            table[hash_n(ip0 - 2, hlog, mls)] = IDX(ip0 - 2);
+            if (rep2 > 0) {
+                while (ip0 <= ilimit && zo_rd32(ip0) == zo_rd32(ip0 - rep2)) {
+                    const size_t rLength = common_len(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    uint32_t t = rep2; rep2 = rep1; rep1 = t;
+                    table[hash_n(ip0, hlog, mls)] = IDX(ip0);
+                    ip0 += rLength;
+                    STORE(0, 1, rLength);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+#undef IDX
+#undef STORE
+    { size_t last = (size_t)(iend - anchor); memcpy(lp, anchor, last); lp += last; }
+    *litSize = (size_t)(lp - lits);
+    return nseq;
+}
+
 /* ------------------------------------------------------------------ dictionary (attached CDict, sources <= 16 KiB) */
 /* Restates: ZSTD_createCDict_advanced2 (zstd.c:28614) parameters, ZSTD_loadCEntropy (:28015), ZSTD_loadDictionaryContent (:27895),
  * ZSTD_fillDoubleHashTableForCDict (:30952, tagged cells :20636), ZSTD_resetCCtx_byAttachingCDict (:25279) and
@@ -969,12 +1058,12 @@ static unsigned ll_code(uint32_t v) { unsigned c = 35; while (zo_ll_base[c] > v)
 static unsigned ml_code(uint32_t ml) { unsigned c = 52; while (zo_ml_base[c] > ml) c--; return c; }
 
 /* picks basic / rle / compressed exactly like the reference does for strategies below "lazy" on a first block */
-static int select_mode(const unsigned* count, unsigned max, unsigned mostFrequent, size_t nbSeq, unsigned defLog, int defaultAllowed, int repeatMode)
+static int select_mode(const unsigned* count, unsigned max, unsigned mostFrequent, size_t nbSeq, unsigned defLog, int defaultAllowed, int repeatMode, int strat)
 {
     (void)count; (void)max;
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
-        size_t dynMin = (((size_t)1 << defLog) * 8) >> 3;     /* mult = 10 - strategy(2) */
+        size_t dynMin = (((size_t)1 << defLog) * (size_t)(10 - strat)) >> 3;     /* mult = 10 - strategy (fast 1, dfast 2) */
         if (repeatMode == 2 && nbSeq < 1000) return 3;         /* set_repeat: the dictionary's table is known to cover everything */
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) return 0;
     }
@@ -983,13 +1072,13 @@ static int select_mode(const unsigned* count, unsigned max, unsigned mostFrequen
 
 static size_t build_seq_table(fse_ctab* t, uint8_t* out, int* mode, const uint8_t* codes, size_t nbSeq, unsigned maxCode,
                               unsigned fseLog, const int16_t* defNorm, unsigned defLog, unsigned defMax, int allowDefaultIfMaxLE,
-                              const fse_ctab* prevTab, int prevRepeat)
+                              const fse_ctab* prevTab, int prevRepeat, int strat)
 {
     unsigned count[64] = {0}, max = 0, most = 0;
     for (size_t i = 0; i < nbSeq; i++) count[codes[i]]++;
     for (unsigned s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
     int defaultAllowed = allowDefaultIfMaxLE < 0 ? 1 : (max <= (unsigned)allowDefaultIfMaxLE);
-    *mode = select_mode(count, max, most, nbSeq, defLog, defaultAllowed, prevTab ? prevRepeat : 0);
+    *mode = select_mode(count, max, most, nbSeq, defLog, defaultAllowed, prevTab ? prevRepeat : 0, strat);
     if (*mode == 3) { *t = *prevTab; return 0; }
     if (*mode == 1) { fse_build_rle(t, codes[0]); out[0] = codes[0]; return 1; }
     if (*mode == 0) { fse_build_ctab(t, defNorm, defMax, defLog); return 0; }
@@ -1020,9 +1109,12 @@ static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, si
     {
         size_t litSize = 0;
         size_t nbSeq = cd ? zo_dfast_dict(seqs, lits, &litSize, src, srcSize, cp, cd, hashLong, hashSmall)
+                          : cp->strat == 1 ? zo_fast(seqs, lits, &litSize, src, srcSize, cp, hashLong)
                           : zo_dfast(seqs, lits, &litSize, src, srcSize, cp, hashLong, hashSmall);
         uint8_t* op = out;
-        op += zo_compress_literals(op, cap, lits, litSize, nbSeq, prev);
+        /* literals stay raw with the fast strategy at a non-zero target length, i.e. negative levels (ZSTD_literalsCompressionIsDisabled, zstd.c:24208) */
+        if (cp->strat == 1 && cp->tlen > 0) op += zo_raw_literals(op, lits, litSize, 0, 0);
+        else op += zo_compress_literals(op, cap, lits, litSize, nbSeq, prev);
         if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
         else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
         else { op[0] = 0xFF; zo_wr16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
@@ -1035,9 +1127,9 @@ static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, si
             }
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; size_t lastCount = 0, h;
-            h = build_seq_table(&tabs[0], op, &mLL, llc, nbSeq, 35, 9, zo_ll_defnorm, 6, 35, -1, prev ? &prev->ll : NULL, prev ? prev->llRepeat : 0); if (mLL == 2) lastCount = h; op += h;
-            h = build_seq_table(&tabs[1], op, &mOF, ofc, nbSeq, 31, 8, zo_of_defnorm, 5, 28, 28, prev ? &prev->of : NULL, prev ? prev->ofRepeat : 0); if (mOF == 2) lastCount = h; op += h;
-            h = build_seq_table(&tabs[2], op, &mML, mlc, nbSeq, 52, 9, zo_ml_defnorm, 6, 52, -1, prev ? &prev->ml : NULL, prev ? prev->mlRepeat : 0); if (mML == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[0], op, &mLL, llc, nbSeq, 35, 9, zo_ll_defnorm, 6, 35, -1, prev ? &prev->ll : NULL, prev ? prev->llRepeat : 0, cp->strat); if (mLL == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[1], op, &mOF, ofc, nbSeq, 31, 8, zo_of_defnorm, 5, 28, 28, prev ? &prev->of : NULL, prev ? prev->ofRepeat : 0, cp->strat); if (mOF == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[2], op, &mML, mlc, nbSeq, 52, 9, zo_ml_defnorm, 6, 52, -1, prev ? &prev->ml : NULL, prev ? prev->mlRepeat : 0, cp->strat); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
             /* three interleaved states, sequences visited last to first; per sequence OF state, ML state, LL state,
              * then LL, ML, OF extra bits (the decoder reads them in the opposite order) */
@@ -1095,7 +1187,7 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
         w.wlog = cp.wlog;
         cp = w;
     }
-    if (cp.strat != 2) { zo_cdict_free(cd); return -ZO_E_PARAM_UNSUPPORTED; }
+    if (cp.strat != 2 && !(cp.strat == 1 && !cd)) { zo_cdict_free(cd); return -ZO_E_PARAM_UNSUPPORTED; }
     /* frame header */
     size_t pos = 0;
     const int contentSize = (flags & ZO_F_CONTENTSIZE) != 0, checksum = (flags & ZO_F_CHECKSUM) != 0;
