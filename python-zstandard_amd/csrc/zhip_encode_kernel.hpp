@@ -50,7 +50,7 @@ struct ZeLDS {
     uint32_t stack[64];
 };
 
-struct ZePar { int wlog, clog, hlog, mml, strat; };
+struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
 
 // ------------------------------------------------------------------------------------------ LSB-first bit writer (one lane)
 struct ZeBits { uint8_t* p; uint32_t cap; uint64_t acc; uint32_t n; uint32_t pos; };
@@ -698,6 +698,89 @@ ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const 
 }
 
 
+// ------------------------------------------------------------------------------------------ fast strategy (levels 1-2, negative levels)
+// ZSTD_compressBlock_fast_noDict_generic (zstd.c:31906) for a block that is the whole frame: one hash table of hashLog bits over
+// minMatch bytes, cells hold position + 2. Positions are examined in pairs `step` apart (step grows by one per 128 bytes without a
+// match), with a repcode test two positions ahead of a pair's first; after a hit at a pair's second position the pending table
+// write is kept only while step <= 4. One lane.
+ZH_DEVFN uint32_t ze_fast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint32_t* table)
+{
+    const int hlog = cp.hlog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t stepSize = (uint32_t)cp.tlen + (cp.tlen == 0) + 1;
+    const uint32_t LOW = 2;
+    const uint8_t* const base = src - 2;
+    const uint8_t* const iend = src + srcSize;
+    const uint8_t* const ilimit = iend - 8;
+    const uint8_t* anchor = src;
+    const uint8_t* ip0 = src + 1;
+    uint32_t rep1 = 1, rep2 = 0;            // {1,4} clipped to what the empty history allows (zstd.c:31958-31963)
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
+        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
+#define ZE_IDX(p) ((uint32_t)((p) - base))
+    if (srcSize >= 8) for (;;) {
+        uint32_t step = stepSize;
+        const uint8_t* nextStep = ip0 + 128;
+        const uint8_t* ip1 = ip0 + 1; const uint8_t* ip2 = ip0 + step; const uint8_t* ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        uint32_t hash0 = ze_hash(ip0, hlog, mls), hash1 = ze_hash(ip1, hlog, mls);
+        uint32_t matchIdx = table[hash0];
+        uint32_t current0 = 0, offBase = 0, mLength = 0; const uint8_t* match0 = ip0;
+        int found = 0;
+        do {
+            const uint32_t rval = zh_ld32(ip2 - rep1);
+            current0 = ZE_IDX(ip0); table[hash0] = current0;
+            if (zh_ld32(ip2) == rval && rep1 > 0) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = ip0[-1] == match0[-1] ? 1u : 0u;
+                ip0 -= mLength; match0 -= mLength;
+                offBase = 1; mLength += 4;
+                table[hash1] = ZE_IDX(ip1);
+                found = 1; break;
+            }
+            if (matchIdx >= LOW && zh_ld32(base + matchIdx) == zh_ld32(ip0)) { table[hash1] = ZE_IDX(ip1); found = 2; break; }
+            matchIdx = table[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = ZE_IDX(ip0); table[hash0] = current0;
+            if (matchIdx >= LOW && zh_ld32(base + matchIdx) == zh_ld32(ip0)) { if (step <= 4) table[hash1] = ZE_IDX(ip1); found = 2; break; }
+            matchIdx = table[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (found == 2) {
+            match0 = base + matchIdx;
+            rep2 = rep1; rep1 = (uint32_t)(ip0 - match0);
+            offBase = rep1 + 3; mLength = 4;
+            while (ip0 > anchor && match0 > base + LOW && ip0[-1] == match0[-1]) { ip0--; match0--; mLength++; }
+        }
+        mLength += ze_common_len(ip0 + mLength, match0 + mLength, iend);
+        ZE_STORE(ip0 - anchor, offBase, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip0 <= ilimit) {
+            table[ze_hash(base + current0 + 2, hlog, mls)] = current0 + 2;
+            table[ze_hash(ip0 - 2, hlog, mls)] = ZE_IDX(ip0 - 2);
+            if (rep2 > 0) {
+                while (ip0 <= ilimit && zh_ld32(ip0) == zh_ld32(ip0 - rep2)) {
+                    const uint32_t rLength = ze_common_len(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+                    table[ze_hash(ip0, hlog, mls)] = ZE_IDX(ip0);
+                    ZE_STORE(0, 1, rLength);
+                    ip0 += rLength; anchor = ip0;
+                }
+            }
+        }
+    }
+#undef ZE_IDX
+#undef ZE_STORE
+    {   const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+
 // ------------------------------------------------------------------------------------------ double-fast search against an attached dictionary
 // ZSTD_compressBlock_doubleFast_dictMatchState_generic (zstd.c:31262) for a frame of one block. One index space: dictionary
 // content byte k is index 2 + k, the source follows at CE = 2 + contentSize, so offsets are index differences. The frame's own
@@ -866,18 +949,18 @@ ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
 
 // ------------------------------------------------------------------------------------------ sequences section
 // ZSTD_selectEncodingType (zstd.c:21252), strategy below "lazy", first block: 0 basic, 1 rle, 2 compressed
-ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog, bool defaultAllowed, uint32_t repeatMode)
+ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog, bool defaultAllowed, uint32_t repeatMode, uint32_t strat)
 {
     if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;
     if (defaultAllowed) {
-        const uint32_t dynMin = ((1u << defLog) * 8) >> 3;
+        const uint32_t dynMin = ((1u << defLog) * (10u - strat)) >> 3;      // mult = 10 - strategy (fast 1, double-fast 2)
         if (repeatMode == 2 && nbSeq < 1000) return 3;          // set_repeat: the dictionary's table
         if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defLog - 1))) return 0;
     }
     return 2;
 }
 // ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq, const ZeCDict* cd)
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat)
 {
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
     const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
@@ -887,7 +970,7 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     for (uint32_t s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
     const bool defaultAllowed = which != 1 || max <= 28;
     const uint32_t repeatMode = !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;
-    *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode);
+    *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode, strat);
     ZeCTab& t = L.tab[which];
     if (*mode == 3) {
         const ZeCTab& d = cd->tab[which];
@@ -942,6 +1025,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         uint32_t ls = 0;
         const uint32_t ns = cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
                                                a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                               : cp.strat == 1 ? ze_fast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong)
                                : ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
         L.misc[1] = ns; L.misc[2] = ls;
     }
@@ -950,7 +1034,14 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     nbSeq = zh_first(L.misc[1]); litSize = zh_first(L.misc[2]);
     zh_sync();
     }
-    uint32_t pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, cd);
+    uint32_t pos;
+    if (cp.strat == 1 && cp.tlen > 0) {          // negative levels keep literals raw (ZSTD_literalsCompressionIsDisabled, zstd.c:24208)
+        zh_sync();
+        if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lits, litSize, 0u, false);
+        zh_sync();
+        pos = zh_first(L.misc[0]);
+        zh_sync();
+    } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, cd);
     // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
     uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
     zh_sync();
@@ -973,9 +1064,9 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (nbSeq) {
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; uint32_t lastCount = 0, h;
-            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq, cd); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq, cd); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq, cd); if (mML == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq, cd, (uint32_t)cp.strat); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq, cd, (uint32_t)cp.strat); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq, cd, (uint32_t)cp.strat); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
             // ZSTD_encodeSequences_body (zstd.c:21386): last sequence first; per sequence OF, ML, LL state updates,
             // then the LL, ML, OF extra bits
@@ -1020,15 +1111,17 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
 ZH_DEV int ze_get_cparams(ZePar& out, int level, uint32_t srcSize)
 {
     if (level == 0) level = 3;
-    if (level < 1 || level > 4) return ZE_PARAM_UNSUPPORTED;
+    if (level > 4) return ZE_PARAM_UNSUPPORTED;
     const uint32_t tableID = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
-    int w = ze_rows[tableID][level][0], c = ze_rows[tableID][level][1], h = ze_rows[tableID][level][2];
+    const int row = level < 0 ? 0 : level;                 // negative levels: row 0 with targetLength = -level (zstd.c:30870-30875)
+    int w = ze_rows[tableID][row][0], c = ze_rows[tableID][row][1], h = ze_rows[tableID][row][2];
     const int srcLog = srcSize < 64 ? 6 : zh_highbit32(srcSize - 1) + 1;
     if (w > srcLog) w = srcLog;
     if (h > w + 1) h = w + 1;
     if (c > w) c = w;
     if (w < 10) w = 10;
-    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][level][4]; out.strat = ze_rows[tableID][level][6];
+    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][row][4]; out.strat = ze_rows[tableID][row][6];
+    out.tlen = level < 0 ? (level < -(1 << 17) ? (1 << 17) : -level) : ze_rows[tableID][row][5];
     return 0;
 }
 
@@ -1049,7 +1142,8 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     ZePar cp;
     const int e = ze_get_cparams(cp, a.level, srcSize);
     if (e) return e;
-    if (cp.strat != 2 || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
+    if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
+    if (cp.strat == 1 && a.cdict) return ZE_PARAM_UNSUPPORTED;           // dictionary search is implemented for double-fast only
     uint32_t dictID = 0;
     if (a.cdict) {
         if (a.cdict->status) return a.cdict->status;
@@ -1150,7 +1244,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     const uint8_t* content = dict + contentOff;
     zh_sync();
     if (zh_opaque(lane) == 0) {
-        ZePar p; p.wlog = p.clog = p.hlog = p.mml = p.strat = 0;
+        ZePar p; p.wlog = p.clog = p.hlog = p.mml = p.strat = p.tlen = 0;
         int st = ze_cdict_params(p, level, dictSize);
         if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
         cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
@@ -1269,8 +1363,8 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
         ZePar cp;
-        if (srcSize64 > ZF_BLOCK_MAX || ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || cp.strat != 2 ||
-            (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
+        if (srcSize64 > ZF_BLOCK_MAX || ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
+            (size_t)(4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         const uint32_t srcSize = (uint32_t)srcSize64;
         if (a.cdict) {
             if (a.cdict->status || srcSize > ZE_DICT_ATTACH_MAX) { m.mode = 2; a.meta[i] = m; continue; }
@@ -1279,11 +1373,12 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         if (srcSize < 7) { m.mode = 1; a.meta[i] = m; continue; }
         uint32_t* hashLong = (uint32_t*)tables;
         uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
-        { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (4u << cp.clog)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
+        { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
         uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
         uint32_t litSize = 0;
         m.nbSeq = a.cdict ? ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
                                           a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                          : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong)
                           : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
         m.litSize = litSize;
         a.meta[i] = m;

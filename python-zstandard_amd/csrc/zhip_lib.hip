@@ -353,7 +353,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
 {
     if (!c || !p) return ZHIP_ERR_UNSUPPORTED;
     int level = p->level == 0 ? 3 : p->level;
-    if (level < 1 || level > 4) { g_lastError = "HIP backend compresses with the double-fast strategy only (level 3; level 2/4 for some sizes)"; return ZHIP_ERR_UNSUPPORTED; }
+    if (level > 4) { g_lastError = "HIP backend compresses with the fast and double-fast strategies only (levels <= 3, negative levels; level 4 for inputs above 16 KiB)"; return ZHIP_ERR_UNSUPPORTED; }
     if (p->dict && p->dictSize) {
         const uint64_t key = dict_fingerprint(p->dict, p->dictSize, (uint64_t)level);
         if (c->hasCDict && c->cdictKey == key) { c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; return 0; }

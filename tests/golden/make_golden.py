@@ -57,6 +57,19 @@ def dict_compress_cases(ref, corpus, trained):
     return out
 
 
+LEVELS = (1, 2, -1, -5, -100)
+
+
+def level_cases(ref, cases):
+    out = {"levels": list(LEVELS), "frames": {}}
+    for name, data in cases.items():
+        out["frames"][name] = {}
+        for lvl in LEVELS:
+            fr = ref.compress(data, level=lvl, flags=reflib.DEFAULT_FLAGS)
+            out["frames"][name][str(lvl)] = {"size": len(fr), "sha256": hashlib.sha256(fr).hexdigest()}
+    return out
+
+
 def main():
     ref = reflib.RefZstd()
     corpus = Corpus()
@@ -92,6 +105,8 @@ def main():
         out["dictionary"]["frames"].append({"blob_offset": len(blob), "size": len(fr), "input_sha256": hashlib.sha256(s).hexdigest(),
                                             "input_size": len(s)})
         blob += fr
+    # other strategies of the same path: the `fast` parser (levels 1, 2 and negative levels)
+    out["levels"] = level_cases(ref, inputs(corpus))
     # dictionary COMPRESSION (attached-dictionary mode, sources <= 16 KiB): trained and raw-content dictionaries
     out["dictionary_compress"] = dict_compress_cases(ref, corpus, d)
     with open(os.path.join(HERE, "golden.json"), "w") as fh:

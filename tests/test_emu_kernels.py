@@ -104,3 +104,20 @@ def test_emulated_decode_pipeline_matches_oracle(emu, oracle, corpus):
             elif st[k] == 0:
                 assert outs[k] == want, (pos, k)
         assert st[11] == 0 and outs[11] == raws[11]
+
+
+def test_emulated_fast_strategy_matches_golden(emu, corpus):
+    """device `fast` parser (levels 1, 2, negative) in the fused and the two-kernel form, small inputs of the golden set"""
+    import hashlib
+    from tests.test_oracle_vs_golden import GOLD, _inputs
+    inputs = _inputs()
+    names = [n for n in GOLD["levels"]["frames"] if len(inputs[n]) <= 20000]
+    assert len(names) >= 20
+    raws = [inputs[n] for n in names]
+    for lvl in (1, 2, -5):
+        for pipeline in (False, True):
+            outs, st = emu.compress_batch(raws, level=lvl, flags=5, n_blocks=2, pipeline=pipeline)
+            assert not any(st)
+            for n, o in zip(names, outs):
+                rec = GOLD["levels"]["frames"][n][str(lvl)]
+                assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (n, lvl, pipeline)

@@ -113,3 +113,31 @@ def test_dictionary_compression_bit_exact(zstd, corpus):
     # sources above 16 KiB would need libzstd's table-copy mode: loud failure, never a silent different frame
     with pytest.raises(zstd.ZstdError):
         zstd.ZstdCompressor(level=3, dict_data=zd).compress(b"a" * 20000)
+
+
+def test_fast_strategy_levels_bit_exact(zstd):
+    """levels 1, 2 and negative levels (ZSTD_fast, zstd.c:31906) against the golden vectors of all 46 inputs, then live on ragged sizes"""
+    import hashlib
+    from tests import reflib
+    from tests.test_oracle_vs_golden import GOLD, _inputs
+    inputs = _inputs()
+    names = list(GOLD["levels"]["frames"])
+    raws = [inputs[n] for n in names]
+    nonempty = [i for i, r in enumerate(raws) if len(r)]
+    for lvl in GOLD["levels"]["levels"]:
+        res = zstd.ZstdCompressor(level=lvl).multi_compress_to_buffer([raws[i] for i in nonempty])
+        for k, i in enumerate(nonempty):
+            rec = GOLD["levels"]["frames"][names[i]][str(lvl)]
+            fr = res[k].tobytes()
+            assert len(fr) == rec["size"] and hashlib.sha256(fr).hexdigest() == rec["sha256"], (names[i], lvl)
+    chk = _checker()
+    from tests.corpus import Corpus
+    c = Corpus()
+    rng = np.random.default_rng(8)
+    more = [c.frame_bytes(700 + i)[: int(rng.integers(1, 131073))] for i in range(200)]
+    for lvl in (1, 2, -3):
+        res = zstd.ZstdCompressor(level=lvl, write_checksum=True).multi_compress_to_buffer(more)
+        for i, r in enumerate(more):
+            assert res[i].tobytes() == chk.compress(r, level=lvl, flags=reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM), (lvl, i)
+    back = zstd.ZstdDecompressor().multi_decompress_to_buffer(res)
+    assert [back[i].tobytes() for i in range(len(more))] == more
