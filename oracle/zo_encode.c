@@ -475,8 +475,12 @@ static int huf_validate(const huf_ctab* ct, const unsigned* count, unsigned maxS
     return 1;
 }
 
-static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit, size_t n, size_t nbSeq, const zo_entropy* prev)
+/* *usedNew = 1 and *newTab = the table when the section is emitted with a freshly built Huffman table (the table the NEXT block may
+ * reuse after validation, zstd.c:21046-21049); otherwise the previous table stays current. */
+static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit, size_t n, size_t nbSeq, const zo_entropy* prev,
+                                   huf_ctab* newTab, int* usedNew)
 {
+    if (usedNew) *usedNew = 0;
     if (prev && prev->hufRepeat) {
         /* ZSTD_compressLiterals + HUF_compress_internal with a candidate previous table (zstd.c:20932, :18089) */
         const size_t lh = 3 + (n >= 1024) + (n >= 16384);
@@ -544,6 +548,7 @@ static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit,
             if (n >= 8 || same) return zo_raw_literals(out, lit, n, 1, 1);
         }
         const unsigned hType = repeat != 0 ? 3u : 2u;
+        if (hType == 2 && usedNew) { *usedNew = 1; *newTab = nt; }
         if (lh == 3) { uint32_t v = hType + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 14); zo_wr24(out, v); }
         else if (lh == 4) { zo_wr32(out, hType + (2u << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 18)); }
         else { zo_wr32(out, hType + (3u << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 22)); out[4] = (uint8_t)(cl >> 10); }
@@ -578,6 +583,7 @@ static size_t zo_compress_literals(uint8_t* out, size_t cap, const uint8_t* lit,
     size_t cl = c ? h + c : 0;
     if (cl >= n - 1) cl = 0;
     if (cl == 0 || cl >= n - ((n >> 6) + 2)) return zo_raw_literals(out, lit, n, 0, 0);
+    if (usedNew) { *usedNew = 1; *newTab = ct; }
     /* header: type 2 (compressed), size format by header length */
     if (lh == 3) { uint32_t v = 2 + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 14); zo_wr24(out, v); }
     else if (lh == 4) { zo_wr32(out, 2 + (2u << 2) + ((uint32_t)n << 4) + ((uint32_t)cl << 18)); }
@@ -610,22 +616,29 @@ static size_t common_len(const uint8_t* a, const uint8_t* b, const uint8_t* aend
 /* One block that is also the whole frame (no history). Positions are frame-relative; table cells hold pos+2 so that
  * 0 means "empty" and the reference's index comparisons (>= lowest for matches at ip, > lowest for the long match
  * at ip+1) keep their meaning with lowest == 2. Returns the number of sequences. */
-static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
-                       uint32_t* hashLong, uint32_t* hashSmall)
+/* `frame` is the first byte of the frame (index 2), `src` the block; rep[] carries the two repcodes in and out
+ * (zstd.c:31091-31098 and :31175-31182: offsets larger than the history are parked and restored). Tables are the caller's:
+ * zeroed before the first block, kept between blocks. */
+static size_t zo_dfast_g(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* frame, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
+                         uint32_t* hashLong, uint32_t* hashSmall, uint32_t rep[2])
 {
     const int hl = cp->hlog, hs = cp->clog;
     const int mls = cp->mml <= 4 ? 4 : cp->mml >= 7 ? 7 : cp->mml;
-    const uint32_t LOW = 2;
-    const uint8_t* const base = src - 2;                       /* index = pos + 2 */
+    const uint8_t* const base = frame - 2;                     /* index = frame position + 2 */
     const uint8_t* const iend = src + srcSize;
     const uint8_t* const ilimit = iend - 8;
+    /* lowest index a match may start at: the frame start, or what the window still covers at the END of this block
+     * (ZSTD_getLowestPrefixIndex, zstd.c:20566, after ZSTD_window_enforceMaxDist :20386) */
+    const uint32_t maxDist = 1u << cp->wlog;
+    const uint32_t endIndex = (uint32_t)(iend - base);
+    const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip = src + 1;                               /* position 0 is never searched nor inserted */
-    uint32_t off1 = 1, off2 = 4;                               /* repcodes {1,4,8}; block starts at index LOW+1 */
-    { uint32_t maxRep = 1; if (off2 > maxRep) off2 = 0; if (off1 > maxRep) off1 = 0; }
+    const uint8_t* ip = src + (src == frame);                  /* frame position 0 is never searched nor inserted */
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
+    { const uint32_t curr = (uint32_t)(ip - base); uint32_t maxRep = curr - 2 > maxDist ? maxDist : curr - 2;
+      if (off2 > maxRep) { saved2 = off2; off2 = 0; } if (off1 > maxRep) { saved1 = off1; off1 = 0; } }
     size_t nseq = 0; uint8_t* lp = lits;
-    memset(hashLong, 0, sizeof(uint32_t) << hl);
-    memset(hashSmall, 0, sizeof(uint32_t) << hs);
+    if (srcSize < 8) { memcpy(lp, src, srcSize); *litSize = srcSize; return 0; }
 #define STORE(LL, OFFBASE, ML) do { size_t ll_ = (LL); memcpy(lp, anchor, ll_); lp += ll_; \
         seqs[nseq].litLength = (uint32_t)ll_; seqs[nseq].offBase = (OFFBASE); seqs[nseq].matchLength = (uint32_t)(ML); nseq++; } while (0)
     for (;;) {
@@ -696,7 +709,17 @@ static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8
 #undef STORE
     { size_t last = (size_t)(iend - anchor); memcpy(lp, anchor, last); lp += last; }
     *litSize = (size_t)(lp - lits);
+    if (saved1 != 0 && off1 != 0) saved2 = saved1;
+    rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
     return nseq;
+}
+static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
+                       uint32_t* hashLong, uint32_t* hashSmall)
+{
+    uint32_t rep[2] = {1, 4};
+    memset(hashLong, 0, sizeof(uint32_t) << cp->hlog);
+    memset(hashSmall, 0, sizeof(uint32_t) << cp->clog);
+    return zo_dfast_g(seqs, lits, litSize, src, src, srcSize, cp, hashLong, hashSmall, rep);
 }
 
 
@@ -705,20 +728,24 @@ static size_t zo_dfast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8
  * minMatch bytes hashed), cells hold position + 2 (0 = empty). Positions are examined in pairs (p, p+1) `step` apart; the pair
  * distance grows by one for every 128 bytes advanced without a match; a repcode test sits two positions ahead of the first of a
  * pair; the table write for the second position of a pair is skipped after a hit only when step > 4. */
-static size_t zo_fast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp, uint32_t* table)
+static size_t zo_fast_g(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* frame, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
+                        uint32_t* table, uint32_t rep[2])
 {
     const int hlog = cp->hlog;
     const int mls = cp->mml <= 4 ? 4 : cp->mml >= 7 ? 7 : cp->mml;
     const size_t stepSize = (size_t)cp->tlen + !cp->tlen + 1;
-    const uint8_t* const base = src - 2;
-    const uint32_t LOW = 2;
+    const uint8_t* const base = frame - 2;
     const uint8_t* const iend = src + srcSize;
     const uint8_t* const ilimit = iend - 8;
+    const uint32_t maxDist = 1u << cp->wlog;
+    const uint32_t endIndex = (uint32_t)(iend - base);
+    const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip0 = src + 1;
-    uint32_t rep1 = 1, rep2 = 0;                       /* {1,4} clipped to what the empty history allows */
+    const uint8_t* ip0 = src + (src == frame);
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    { const uint32_t curr = (uint32_t)(ip0 - base); uint32_t maxRep = curr - 2 > maxDist ? maxDist : curr - 2;
+      if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; } if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }
     size_t nseq = 0; uint8_t* lp = lits;
-    memset(table, 0, sizeof(uint32_t) << hlog);
 #define STORE(LL, OFFBASE, ML) do { size_t ll_ = (LL); memcpy(lp, anchor, ll_); lp += ll_; \
         seqs[nseq].litLength = (uint32_t)ll_; seqs[nseq].offBase = (OFFBASE); seqs[nseq].matchLength = (uint32_t)(ML); nseq++; } while (0)
 #define IDX(p) ((uint32_t)((p) - base))
@@ -782,7 +809,15 @@ static size_t zo_fast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_
 #undef STORE
     { size_t last = (size_t)(iend - anchor); memcpy(lp, anchor, last); lp += last; }
     *litSize = (size_t)(lp - lits);
+    if (saved1 != 0 && rep1 != 0) saved2 = saved1;
+    rep[0] = rep1 ? rep1 : saved1; rep[1] = rep2 ? rep2 : saved2;
     return nseq;
+}
+static size_t zo_fast(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint8_t* src, size_t srcSize, const zo_cpar* cp, uint32_t* table)
+{
+    uint32_t rep[2] = {1, 4};
+    memset(table, 0, sizeof(uint32_t) << cp->hlog);
+    return zo_fast_g(seqs, lits, litSize, src, src, srcSize, cp, table, rep);
 }
 
 /* ------------------------------------------------------------------ dictionary (attached CDict, sources <= 16 KiB) */
@@ -1114,7 +1149,7 @@ static size_t zo_compress_block(uint8_t* out, size_t cap, const uint8_t* src, si
         uint8_t* op = out;
         /* literals stay raw with the fast strategy at a non-zero target length, i.e. negative levels (ZSTD_literalsCompressionIsDisabled, zstd.c:24208) */
         if (cp->strat == 1 && cp->tlen > 0) op += zo_raw_literals(op, lits, litSize, 0, 0);
-        else op += zo_compress_literals(op, cap, lits, litSize, nbSeq, prev);
+        else op += zo_compress_literals(op, cap, lits, litSize, nbSeq, prev, NULL, NULL);
         if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
         else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
         else { op[0] = 0xFF; zo_wr16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
@@ -1162,6 +1197,162 @@ done:
     return result;
 }
 
+
+/* ------------------------------------------------------------------ multi-block frames (sources above 128 KiB)
+ * Restates ZSTD_compress_frameChunk (zstd.c:27545), ZSTD_optimalBlockSize (:27506) with the pre-splitter (:22263-22502),
+ * ZSTD_compressBlock_internal (:27337) and the state that survives a block: hash tables, two repcodes and the literals
+ * Huffman table -- each of them advanced ONLY when the block was emitted compressed (:27391-27393). Without a dictionary and
+ * below the lazy strategies the FSE tables never repeat (a table left by a block is "check", which this strategy class
+ * ignores, :21252-21331), so they are not carried. When the source outgrows the window, the lowest usable index follows the end
+ * of each block (ZSTD_window_enforceMaxDist / ZSTD_getLowestPrefixIndex). */
+static uint64_t fp_distance(const unsigned* a, uint64_t na, const unsigned* b, uint64_t nb, int bins)
+{
+    uint64_t d = 0;
+    for (int i = 0; i < bins; i++) { int64_t x = (int64_t)a[i] * (int64_t)nb - (int64_t)b[i] * (int64_t)na; d += (uint64_t)(x < 0 ? -x : x); }
+    return d;
+}
+static int fp_too_different(const unsigned* ref, uint64_t nref, const unsigned* nw, uint64_t nnew, int penalty, int bins)
+{
+    uint64_t p50 = nref * nnew, dev = fp_distance(ref, nref, nw, nnew, bins);
+    return dev >= p50 * (uint64_t)(14 + penalty) / 16;
+}
+/* where to end a full 128 KiB block once the frame has shown savings */
+static size_t zo_split_block(const uint8_t* p, int strat)
+{
+    const size_t B = 128 << 10;
+    if (strat == 1) {           /* fast: compare byte histograms of the first, last (and middle) 512 bytes */
+        unsigned first[256], last[256], mid[256];
+        memset(first, 0, sizeof first); memset(last, 0, sizeof last); memset(mid, 0, sizeof mid);
+        for (int i = 0; i < 512; i++) { first[p[i]]++; last[p[B - 512 + i]]++; }
+        if (!fp_too_different(first, 512, last, 512, 0, 256)) return B;
+        for (int i = 0; i < 512; i++) mid[p[B / 2 - 256 + i]]++;
+        uint64_t db = fp_distance(first, 512, mid, 512, 256), de = fp_distance(last, 512, mid, 512, 256);
+        int64_t diff = (int64_t)db - (int64_t)de; if (diff < 0) diff = -diff;
+        if ((uint64_t)diff < 512ull * 512 / 3) return 64 << 10;
+        return db > de ? (32 << 10) : (96 << 10);
+    }
+    /* double-fast: 8 KiB chunks, byte histogram of every 43rd position, split at the first chunk that differs from the past */
+    unsigned past[256], cur[256]; uint64_t npast = 0;
+    memset(past, 0, sizeof past);
+    const size_t C = 8 << 10, limit = C - 2 + 1;          /* positions 0 .. C-2 step 43 */
+    for (size_t n = 0; n < limit; n += 43) past[p[n]]++;
+    npast = limit / 43;
+    int penalty = 3;
+    for (size_t pos = C; pos <= B - C; pos += C) {
+        memset(cur, 0, sizeof cur);
+        for (size_t n = 0; n < limit; n += 43) cur[p[pos + n]]++;
+        const uint64_t ncur = limit / 43;
+        if (fp_too_different(past, npast, cur, ncur, penalty, 256)) return pos;
+        for (int i = 0; i < 256; i++) past[i] += cur[i];
+        npast += ncur;
+        if (penalty > 0) penalty--;
+    }
+    return B;
+}
+
+typedef struct { uint32_t rep[2]; huf_ctab huf; int hufRepeat; } zo_blockstate;
+
+/* one block of a multi-block frame; returns the body size (0: store raw, 1: RLE block, body[0] = the byte) */
+static size_t zo_compress_block_g(uint8_t* out, size_t cap, const uint8_t* frame, const uint8_t* src, size_t srcSize, const zo_cpar* cp,
+                                  uint32_t* hashLong, uint32_t* hashSmall, zo_blockstate* st, int firstBlock,
+                                  zo_seq* seqs, uint8_t* lits, uint8_t* codes, fse_ctab* tabs)
+{
+    if (srcSize < 7) return 0;                       /* too small to try: the search is skipped as well */
+    zo_blockstate next = *st;
+    size_t litSize = 0, cSize = 0;
+    const size_t nbSeq = cp->strat == 1 ? zo_fast_g(seqs, lits, &litSize, frame, src, srcSize, cp, hashLong, next.rep)
+                                        : zo_dfast_g(seqs, lits, &litSize, frame, src, srcSize, cp, hashLong, hashSmall, next.rep);
+    {
+        uint8_t* op = out;
+        zo_entropy prev; memset(&prev, 0, sizeof prev); prev.huf = st->huf; prev.hufRepeat = st->hufRepeat;
+        int usedNew = 0; huf_ctab nt;
+        if (cp->strat == 1 && cp->tlen > 0) op += zo_raw_literals(op, lits, litSize, 0, 0);
+        else op += zo_compress_literals(op, cap, lits, litSize, nbSeq, &prev, &nt, &usedNew);
+        if (usedNew) { next.huf = nt; next.hufRepeat = 1; }
+        if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
+        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
+        else { op[0] = 0xFF; zo_wr16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
+        int ok = 1;
+        if (nbSeq) {
+            uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
+            for (size_t i = 0; i < nbSeq; i++) { llc[i] = (uint8_t)ll_code(seqs[i].litLength); ofc[i] = (uint8_t)zo_highbit(seqs[i].offBase); mlc[i] = (uint8_t)ml_code(seqs[i].matchLength); }
+            uint8_t* seqHead = op++;
+            int mLL, mOF, mML; size_t lastCount = 0, h;
+            h = build_seq_table(&tabs[0], op, &mLL, llc, nbSeq, 35, 9, zo_ll_defnorm, 6, 35, -1, NULL, 0, cp->strat); if (mLL == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[1], op, &mOF, ofc, nbSeq, 31, 8, zo_of_defnorm, 5, 28, 28, NULL, 0, cp->strat); if (mOF == 2) lastCount = h; op += h;
+            h = build_seq_table(&tabs[2], op, &mML, mlc, nbSeq, 52, 9, zo_ml_defnorm, 6, 52, -1, NULL, 0, cp->strat); if (mML == 2) lastCount = h; op += h;
+            *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
+            bitw b; bw_init(&b, op, cap - (size_t)(op - out));
+            size_t n = nbSeq - 1;
+            uint32_t sML = fse_first_state(&tabs[2], mlc[n]), sOF = fse_first_state(&tabs[1], ofc[n]), sLL = fse_first_state(&tabs[0], llc[n]);
+            bw_add(&b, seqs[n].litLength, zo_ll_bits[llc[n]]); bw_add(&b, seqs[n].matchLength - 3, zo_ml_bits[mlc[n]]); bw_add(&b, seqs[n].offBase, ofc[n]);
+            while (n-- > 0) {
+                sOF = fse_encode(&tabs[1], &b, sOF, ofc[n]); sML = fse_encode(&tabs[2], &b, sML, mlc[n]); sLL = fse_encode(&tabs[0], &b, sLL, llc[n]);
+                bw_add(&b, seqs[n].litLength, zo_ll_bits[llc[n]]); bw_add(&b, seqs[n].matchLength - 3, zo_ml_bits[mlc[n]]); bw_add(&b, seqs[n].offBase, ofc[n]);
+            }
+            bw_add(&b, sML, tabs[2].log); bw_add(&b, sOF, tabs[1].log); bw_add(&b, sLL, tabs[0].log);
+            size_t bs = bw_close(&b);
+            if (bs == 0) ok = 0;
+            op += bs;
+            if (ok && lastCount && lastCount + bs < 4) ok = 0;
+        }
+        if (ok) { cSize = (size_t)(op - out); if (cSize >= srcSize - ((srcSize >> 6) + 2)) cSize = 0; }
+    }
+    if (!firstBlock && cSize < 25) {                 /* a later block made of one byte value becomes an RLE block (zstd.c:27373-27384) */
+        int same = 1; for (size_t i = 1; i < srcSize; i++) if (src[i] != src[0]) { same = 0; break; }
+        if (same) { out[0] = src[0]; cSize = 1; }
+    }
+    if (cSize > 1) *st = next;                       /* repcodes and the Huffman table advance only with a compressed block */
+    return cSize;
+}
+
+static int64_t zo_compress_frame_multi(uint8_t* dst, size_t dstCap, const uint8_t* src, size_t srcSize, const zo_cpar* cp, unsigned flags)
+{
+    (void)dstCap;
+    if (srcSize >= (1u << 31)) return -ZO_E_PARAM_UNSUPPORTED;                   /* index overflow correction is not restated */
+    const int contentSize = (flags & ZO_F_CONTENTSIZE) != 0, checksum = (flags & ZO_F_CHECKSUM) != 0;
+    size_t pos = 0;
+    zo_wr32(dst, ZO_MAGIC); pos = 4;
+    const uint32_t windowSize = 1u << cp->wlog;
+    const int single = contentSize && windowSize >= srcSize;
+    const unsigned fcsCode = contentSize ? (srcSize >= 256) + (srcSize >= 65536 + 256) + (srcSize >= 0xFFFFFFFFu) : 0;
+    dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+    if (!single) dst[pos++] = (uint8_t)((cp->wlog - 10) << 3);
+    if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
+    else if (fcsCode == 1) { zo_wr16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
+    else if (fcsCode == 2) { zo_wr32(dst + pos, (uint32_t)srcSize); pos += 4; }
+    else { zo_wr64(dst + pos, (uint64_t)srcSize); pos += 8; }
+    uint32_t* hashLong = (uint32_t*)calloc((size_t)1 << cp->hlog, 4);
+    uint32_t* hashSmall = (uint32_t*)calloc((size_t)1 << cp->clog, 4);
+    zo_seq* seqs = (zo_seq*)malloc(sizeof(zo_seq) * (ZO_BLOCK_MAX / 3 + 8));
+    uint8_t* lits = (uint8_t*)malloc(ZO_BLOCK_MAX + 64);
+    uint8_t* codes = (uint8_t*)malloc(3 * (ZO_BLOCK_MAX / 3 + 8));
+    fse_ctab* tabs = (fse_ctab*)malloc(3 * sizeof(fse_ctab));
+    int64_t result = -ZO_E_MEMORY;
+    if (hashLong && hashSmall && seqs && lits && codes && tabs) {
+        zo_blockstate st; memset(&st, 0, sizeof st); st.rep[0] = 1; st.rep[1] = 4;
+        size_t ip = 0; int64_t savings = 0; int first = 1;
+        while (ip < srcSize) {
+            const size_t remaining = srcSize - ip;
+            size_t blockSize = remaining < ZO_BLOCK_MAX ? remaining : ZO_BLOCK_MAX;
+            if (remaining >= ZO_BLOCK_MAX && savings >= 3) blockSize = zo_split_block(src + ip, cp->strat);
+            const int last = blockSize == remaining;
+            const size_t c = zo_compress_block_g(dst + pos + 3, zo_compress_bound(blockSize) + 64, src, src + ip, blockSize, cp, hashLong, hashSmall, &st, first,
+                                                 seqs, lits, codes, tabs);
+            size_t total;
+            if (c == 0) { zo_wr24(dst + pos, (uint32_t)(last + (0u << 1) + (blockSize << 3))); memcpy(dst + pos + 3, src + ip, blockSize); total = 3 + blockSize; }
+            else if (c == 1) { zo_wr24(dst + pos, (uint32_t)(last + (1u << 1) + (blockSize << 3))); total = 4; }
+            else { zo_wr24(dst + pos, (uint32_t)(last + (2u << 1) + (c << 3))); total = 3 + c; }
+            savings += (int64_t)blockSize - (int64_t)total;
+            pos += total; ip += blockSize; first = 0;
+        }
+        if (checksum) { zo_wr32(dst + pos, (uint32_t)zo_xxh64(src, srcSize, 0)); pos += 4; }
+        result = (int64_t)pos;
+    }
+    free(hashLong); free(hashSmall); free(seqs); free(lits); free(codes); free(tabs);
+    return result;
+}
+
 /* ------------------------------------------------------------------ frame */
 size_t zo_compress_bound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
 
@@ -1169,9 +1360,12 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
                           const void* dict, size_t dictSize)
 {
     uint8_t* dst = (uint8_t*)dstv; const uint8_t* src = (const uint8_t*)srcv;
-    if (srcSize > ZO_BLOCK_MAX) return -ZO_E_PARAM_UNSUPPORTED;
     if (dstCap < zo_compress_bound(srcSize)) return -ZO_E_DST_TOO_SMALL;
     zo_cpar cp; int e = zo_get_cparams(&cp, level, srcSize); if (e < 0) return e;
+    if (srcSize > ZO_BLOCK_MAX) {
+        if ((dict && dictSize) || (cp.strat != 1 && cp.strat != 2)) return -ZO_E_PARAM_UNSUPPORTED;
+        return zo_compress_frame_multi(dst, dstCap, src, srcSize, &cp, flags);
+    }
     zo_cdict* cd = NULL;
     if (dict && dictSize) {
         /* only the attached-CDict mode (sources <= 16 KiB for double-fast, zstd.c:25235-25276) is restated */
