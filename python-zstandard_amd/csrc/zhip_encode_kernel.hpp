@@ -48,7 +48,13 @@ struct ZeLDS {
     uint8_t weights[256];
     uint32_t misc[16];
     uint32_t stack[64];
+    // state that survives a block of a multi-block frame (advanced only when the block is emitted compressed, zstd.c:27391)
+    uint32_t mrep[2];
+    uint32_t prevRepeat, prevMaxSym;    // previous block's Huffman table: 0 none, 1 usable after validation
+    uint8_t prevBits[256];
+    uint16_t prevCode[256];
 };
+struct ZePrevHuf { const uint8_t* bits; const uint16_t* code; uint32_t maxSym, repeat; };   // a candidate table for the literals (dictionary or previous block)
 
 struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
 
@@ -444,11 +450,13 @@ ZH_DEVFN uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n
 // ZSTD_compressLiterals (zstd.c:20932) + HUF_compress_internal (:18089). The only "previous" Huffman table a single-block
 // frame can have is the dictionary's (cd, may be null): repeat 0 none, 1 usable after validation, 2 valid.
 // All lanes call; returns the literals-section size (uniform).
-ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq, const ZeCDict* cd)
+ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq, const ZePrevHuf* cd,
+                                       uint32_t* pNewMaxSym /* 0xFFFFFFFF unless the section carries a freshly built table */)
 {
+    *pNewMaxSym = 0xFFFFFFFFu;
     const uint32_t lane = zh_lane();
     const uint32_t lh = 3 + (n >= 1024) + (n >= 16384);
-    uint32_t repeat = cd ? cd->hufRepeat : 0;
+    uint32_t repeat = cd ? cd->repeat : 0;
     bool single = n < 256;
     if (repeat == 2 && lh == 3) single = true;
     const bool preferRepeat = n <= 1024;
@@ -461,7 +469,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
     zh_sync();
     for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = 0;
     zh_sync();
-    uint32_t h = 0;
+    uint32_t h = 0, builtMaxSym = 0;
     if (decision == 2 && preferRepeat && repeat == 2) useOld = true;          // no statistics needed
     else if (decision == 2) {
         if (suspect && n >= 4096 * 10) {
@@ -494,8 +502,8 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         zh_sync();
         if (decision == 2 && repeat == 1) {
             // HUF_validateCTable (zstd.c:17693): every present symbol needs a code in the old table
-            uint32_t bad = cd->hufMaxSym < maxSym ? 1u : 0u;
-            for (uint32_t i = lane; i <= maxSym; i += 64) if (L.hist[i] && !cd->hufBits[i]) bad = 1;
+            uint32_t bad = cd->maxSym < maxSym ? 1u : 0u;
+            for (uint32_t i = lane; i <= maxSym; i += 64) if (L.hist[i] && !cd->bits[i]) bad = 1;
             if (zh_wave_max(bad)) repeat = 0;
         }
         if (decision == 2 && preferRepeat && repeat != 0) useOld = true;
@@ -509,11 +517,12 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
             zh_sync();
             h = zh_first(L.misc[0]);
             zh_sync();
+            builtMaxSym = maxSym;
             if (h == 0) decision = 0;
             else if (repeat != 0) {
                 // HUF_estimateCompressedSize (zstd.c:17681) of both tables on this histogram
                 uint32_t ob = 0, nb = 0;
-                for (uint32_t i = lane; i <= maxSym; i += 64) { ob += (uint32_t)cd->hufBits[i] * L.hist[i]; nb += (uint32_t)L.hufBits[i] * L.hist[i]; }
+                for (uint32_t i = lane; i <= maxSym; i += 64) { ob += (uint32_t)cd->bits[i] * L.hist[i]; nb += (uint32_t)L.hufBits[i] * L.hist[i]; }
                 ob = zh_scan_add(ob); nb = zh_scan_add(nb);
                 const uint32_t oldSize = zh_shfl(ob, 63) >> 3, newSize = zh_shfl(nb, 63) >> 3;
                 if (oldSize <= h + newSize || h + 12 >= n) useOld = true;
@@ -527,7 +536,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
     if (decision == 2) {
         if (useOld) {
             zh_sync();
-            for (uint32_t i = lane; i < 256; i += 64) { L.hufBits[i] = cd->hufBits[i]; L.hufCode[i] = cd->hufCode[i]; }
+            for (uint32_t i = lane; i < 256; i += 64) { L.hufBits[i] = cd->bits[i]; L.hufCode[i] = cd->code[i]; }
             zh_sync();
             h = 0;
         }
@@ -567,6 +576,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         if (cl == 0 || cl >= n - ((n >> 6) + 2)) decision = 0;
         else {
             const uint32_t hType = repeat != 0 ? 3u : 2u;
+            if (hType == 2) *pNewMaxSym = builtMaxSym;
             if (zh_opaque(lane) == 0) {
                 if (lh == 3) { const uint32_t v = hType + ((uint32_t)(!single) << 2) + (n << 4) + (cl << 14); out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16); }
                 else if (lh == 4) zh_st32(out, hType + (2u << 2) + (n << 4) + (cl << 18));
@@ -610,22 +620,32 @@ ZH_DEV uint32_t ze_common_len(const uint8_t* a, const uint8_t* b, const uint8_t*
 
 // ZSTD_compressBlock_doubleFast_noDict_generic (zstd.c:31039) for a block that is the whole frame. Table cells hold
 // position + 2 (0 = empty), so the reference's index comparisons keep their meaning with lowest == 2. lane 0 only.
-// seqs: packed (offBase | litLength << 20 | matchLength << 42). Returns nbSeq; *pLit = literal count.
-ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
-                           uint32_t* hashLong, uint32_t* hashSmall)
+// seqs: packed with ZE_SEQ_PACK. Returns nbSeq; *pLit = literal count.
+// `frame` = first byte of the frame (index 2), `src` = the block; rep[] = the two repcodes in and out (offsets larger than the
+// history are parked and restored, zstd.c:31091-31098, :31175-31182). Tables are the caller's: zeroed before a frame's first block.
+ZH_DEVFN uint32_t ze_dfast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* frame, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                             uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep)
 {
     const int hl = cp.hlog, hs = cp.clog;
     const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
-    const uint32_t LOW = 2;
-    const uint8_t* const base = src - 2;
+    const uint8_t* const base = frame - 2;
     const uint8_t* const iend = src + srcSize;
     const uint8_t* const ilimit = iend - 8;
+    // lowest index a match may start at: the frame start, or what the window still covers at the END of this block
+    // (ZSTD_getLowestPrefixIndex zstd.c:20566 after ZSTD_window_enforceMaxDist :20386)
+    const uint32_t maxDist = 1u << cp.wlog;
+    const uint32_t endIndex = (uint32_t)(iend - base);
+    const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip = src + 1;
-    uint32_t off1 = 1, off2 = 0;            // {1,4,8} clipped to maxRep == 1 at the frame start (zstd.c:31091-31098)
+    const uint8_t* ip = src + (src == frame ? 1 : 0);
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
+    {   const uint32_t c0 = (uint32_t)(ip - base); const uint32_t maxRep = c0 - 2 > maxDist ? maxDist : c0 - 2;
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; } }
     uint32_t nseq = 0; uint8_t* lp = lits;
+    if (srcSize < 8) { for (uint32_t i = 0; i < srcSize; i++) lp[i] = src[i]; *pLit = srcSize; return 0; }
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
-        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
     for (;;) {
         uint32_t step = 1; const uint8_t* nextStep = ip + 256; const uint8_t* ip1 = ip + step;
         uint32_t mLength = 0, offset = 0, curr = 0;
@@ -694,7 +714,15 @@ ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const 
 #undef ZE_STORE
     {   const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
     *pLit = (uint32_t)(lp - lits);
+    if (saved1 != 0 && off1 != 0) saved2 = saved1;
+    rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
     return nseq;
+}
+ZH_DEV uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                         uint32_t* hashLong, uint32_t* hashSmall)
+{
+    uint32_t rep[2] = {1, 4};
+    return ze_dfast_g(seqs, lits, pLit, src, src, srcSize, cp, hashLong, hashSmall, rep);
 }
 
 
@@ -703,21 +731,27 @@ ZH_DEVFN uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const 
 // minMatch bytes, cells hold position + 2. Positions are examined in pairs `step` apart (step grows by one per 128 bytes without a
 // match), with a repcode test two positions ahead of a pair's first; after a hit at a pair's second position the pending table
 // write is kept only while step <= 4. One lane.
-ZH_DEVFN uint32_t ze_fast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint32_t* table)
+ZH_DEVFN uint32_t ze_fast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* frame, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                            uint32_t* table, uint32_t* rep)
 {
     const int hlog = cp.hlog;
     const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
     const uint32_t stepSize = (uint32_t)cp.tlen + (cp.tlen == 0) + 1;
-    const uint32_t LOW = 2;
-    const uint8_t* const base = src - 2;
+    const uint8_t* const base = frame - 2;
     const uint8_t* const iend = src + srcSize;
     const uint8_t* const ilimit = iend - 8;
+    const uint32_t maxDist = 1u << cp.wlog;
+    const uint32_t endIndex = (uint32_t)(iend - base);
+    const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip0 = src + 1;
-    uint32_t rep1 = 1, rep2 = 0;            // {1,4} clipped to what the empty history allows (zstd.c:31958-31963)
+    const uint8_t* ip0 = src + (src == frame ? 1 : 0);
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    {   const uint32_t c0 = (uint32_t)(ip0 - base); const uint32_t maxRep = c0 - 2 > maxDist ? maxDist : c0 - 2;
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }
     uint32_t nseq = 0; uint8_t* lp = lits;
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
-        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
 #define ZE_IDX(p) ((uint32_t)((p) - base))
     if (srcSize >= 8) for (;;) {
         uint32_t step = stepSize;
@@ -778,7 +812,14 @@ ZH_DEVFN uint32_t ze_fast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const u
 #undef ZE_STORE
     {   const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
     *pLit = (uint32_t)(lp - lits);
+    if (saved1 != 0 && rep1 != 0) saved2 = saved1;
+    rep[0] = rep1 ? rep1 : saved1; rep[1] = rep2 ? rep2 : saved2;
     return nseq;
+}
+ZH_DEV uint32_t ze_fast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint32_t* table)
+{
+    uint32_t rep[2] = {1, 4};
+    return ze_fast_g(seqs, lits, pLit, src, src, srcSize, cp, table, rep);
 }
 
 // ------------------------------------------------------------------------------------------ double-fast search against an attached dictionary
@@ -829,7 +870,7 @@ ZH_DEVFN uint32_t ze_dfast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, c
     uint32_t nseq = 0; uint8_t* lp = lits;
 #define ZE_SRC(i) (src + ((i) - CE))
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
-        seqs[nseq] = (uint64_t)(OFFBASE) | ((uint64_t)ll_ << 20) | ((uint64_t)(uint32_t)(ML) << 42); nseq++; } while (0)
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
 #define ZE_BACK(LOW) while (ip > anchor && m > (LOW) && ze_sp_byte(sp, ip - 1) == ze_sp_byte(sp, m - 1)) { ip--; m--; mLength++; }
     if (srcSize >= 8) {
         const uint32_t ilimit = iend - 8;
@@ -995,13 +1036,16 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
 ZH_DEV uint32_t ze_ll_code(uint32_t v) { uint32_t c = 35; while (ze_llBase[c] > v) c--; return c; }
 ZH_DEV uint32_t ze_ml_code(uint32_t ml) { uint32_t c = 52; while (ze_mlBase[c] > ml) c--; return c; }
 
-// ZSTD_compressBlock_internal (zstd.c:27337) for the first-and-only block. All lanes call. Returns body size, 0 = store raw.
+// ZSTD_compressBlock_internal (zstd.c:27337). All lanes call. Returns body size, 0 = store raw, 1 = RLE block (out[0] = the byte).
+// mb == null: the block is the whole frame. mb != null: one block of a multi-block frame -- the hash tables, the two repcodes
+// (L.mrep) and the previous block's Huffman table (L.prev*) carry over and advance only when the block is emitted compressed.
 struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
+struct ZeMulti { const uint8_t* frame; bool firstBlock; };
 
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
-                                    const ZePre* pre, const ZhipEncodeArgs& a)
+                                    const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr)
 {
-    const ZeCDict* cd = a.cdict;
+    const ZeCDict* cd = mb ? nullptr : a.cdict;
     const uint32_t lane = zh_lane();
     if (srcSize < 7) return 0;
     uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
@@ -1013,7 +1057,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     if (pre) { nbSeq = pre->nbSeq; litSize = pre->litSize; }
     else {
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
-    {
+    if (!mb || mb->firstBlock) {
         uint64_t* a = (uint64_t*)hashLong; const uint32_t na = (1u << cp.hlog) / 2;
         for (uint32_t i = lane; i < na; i += 64) a[i] = 0;
         uint64_t* b = (uint64_t*)hashSmall; const uint32_t nb = (1u << cp.clog) / 2;
@@ -1023,25 +1067,33 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     zh_sync();
     if (zh_opaque(lane) == 0) {
         uint32_t ls = 0;
-        const uint32_t ns = cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
+        uint32_t nrep[2] = {1, 4};
+        if (mb) { nrep[0] = L.mrep[0]; nrep[1] = L.mrep[1]; }
+        const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
+                                                : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
+                          : cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
                                                a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
                                : cp.strat == 1 ? ze_fast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong)
                                : ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
-        L.misc[1] = ns; L.misc[2] = ls;
+        L.misc[1] = ns; L.misc[2] = ls; L.misc[5] = nrep[0]; L.misc[6] = nrep[1];
     }
     ze_fence();
     zh_sync();
     nbSeq = zh_first(L.misc[1]); litSize = zh_first(L.misc[2]);
     zh_sync();
     }
-    uint32_t pos;
+    uint32_t pos, newMaxSym = 0xFFFFFFFFu;
+    const uint32_t nextRep0 = mb ? zh_first(L.misc[5]) : 0, nextRep1 = mb ? zh_first(L.misc[6]) : 0;
+    ZePrevHuf ph; const ZePrevHuf* php = nullptr;
+    if (cd && cd->hufRepeat) { ph.bits = cd->hufBits; ph.code = cd->hufCode; ph.maxSym = cd->hufMaxSym; ph.repeat = cd->hufRepeat; php = &ph; }
+    else if (mb && L.prevRepeat) { ph.bits = L.prevBits; ph.code = L.prevCode; ph.maxSym = L.prevMaxSym; ph.repeat = L.prevRepeat; php = &ph; }
     if (cp.strat == 1 && cp.tlen > 0) {          // negative levels keep literals raw (ZSTD_literalsCompressionIsDisabled, zstd.c:24208)
         zh_sync();
         if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lits, litSize, 0u, false);
         zh_sync();
         pos = zh_first(L.misc[0]);
         zh_sync();
-    } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, cd);
+    } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, php, &newMaxSym);
     // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
     uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
     zh_sync();
@@ -1049,7 +1101,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     zh_sync();
     for (uint32_t i = lane; i < nbSeq; i += 64) {
         const uint64_t q = seqs[i];
-        const uint32_t a = ze_ll_code((uint32_t)(q >> 20) & 0x3FFFFF), o = (uint32_t)zh_highbit32((uint32_t)q & 0xFFFFF), m = ze_ml_code((uint32_t)(q >> 42));
+        const uint32_t a = ze_ll_code(ZE_SEQ_LL(q)), o = (uint32_t)zh_highbit32(ZE_SEQ_OFF(q)), m = ze_ml_code(ZE_SEQ_ML(q));
         llc[i] = (uint8_t)a; ofc[i] = (uint8_t)o; mlc[i] = (uint8_t)m;
         zh_lds_atomic_inc(&L.cnt[0][a]); zh_lds_atomic_inc(&L.cnt[1][o]); zh_lds_atomic_inc(&L.cnt[2][m]);
     }
@@ -1073,21 +1125,18 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
             ZeBits b; ze_bw_init(b, op, cap - (uint32_t)(op - out));
             uint32_t n = nbSeq - 1;
             uint32_t sML = ze_fse_first_state(L.tab[2], mlc[n]), sOF = ze_fse_first_state(L.tab[1], ofc[n]), sLL = ze_fse_first_state(L.tab[0], llc[n]);
-#define ZE_SQ_OFF(q) ((uint32_t)(q) & 0xFFFFF)
-#define ZE_SQ_LL(q) ((uint32_t)((q) >> 20) & 0x3FFFFF)
-#define ZE_SQ_ML(q) ((uint32_t)((q) >> 42))
             { const uint64_t q = seqs[n];
-              ze_bw_add(b, ZE_SQ_LL(q), ze_llBits[llc[n]]);
-              ze_bw_add(b, ZE_SQ_ML(q) - 3, ze_mlBits[mlc[n]]);
-              ze_bw_add(b, ZE_SQ_OFF(q), ofc[n]); }
+              ze_bw_add(b, ZE_SEQ_LL(q), ze_llBits[llc[n]]);
+              ze_bw_add(b, ZE_SEQ_ML(q) - 3, ze_mlBits[mlc[n]]);
+              ze_bw_add(b, ZE_SEQ_OFF(q), ofc[n]); }
             while (n-- > 0) {
                 sOF = ze_fse_encode(L.tab[1], b, sOF, ofc[n]);
                 sML = ze_fse_encode(L.tab[2], b, sML, mlc[n]);
                 sLL = ze_fse_encode(L.tab[0], b, sLL, llc[n]);
                 const uint64_t q = seqs[n];
-                ze_bw_add(b, ZE_SQ_LL(q), ze_llBits[llc[n]]);
-                ze_bw_add(b, ZE_SQ_ML(q) - 3, ze_mlBits[mlc[n]]);
-                ze_bw_add(b, ZE_SQ_OFF(q), ofc[n]);
+                ze_bw_add(b, ZE_SEQ_LL(q), ze_llBits[llc[n]]);
+                ze_bw_add(b, ZE_SEQ_ML(q) - 3, ze_mlBits[mlc[n]]);
+                ze_bw_add(b, ZE_SEQ_OFF(q), ofc[n]);
             }
             ze_bw_add(b, sML, (uint32_t)L.tab[2].log); ze_bw_add(b, sOF, (uint32_t)L.tab[1].log); ze_bw_add(b, sLL, (uint32_t)L.tab[0].log);
             const uint32_t bs = ze_bw_close(b);
@@ -1101,8 +1150,26 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     }
     ze_fence();
     zh_sync();
-    const uint32_t r = zh_first(L.misc[3]);
+    uint32_t r = zh_first(L.misc[3]);
     zh_sync();
+    if (mb) {
+        if (!mb->firstBlock && r < 25) {          // a later block made of one byte value becomes an RLE block (zstd.c:27373-27384)
+            const uint32_t b0 = src[0];
+            bool diff = false;
+            for (uint32_t i = lane; i < srcSize; i += 64) diff |= src[i] != b0;
+            if (!zh_ballot(diff)) { if (zh_opaque(lane) == 0) out[0] = (uint8_t)b0; r = 1; }
+        }
+        zh_sync();
+        if (r > 1) {                               // confirm: repcodes, and the Huffman table if this block carried a new one
+            if (zh_opaque(lane) == 0) { L.mrep[0] = nextRep0; L.mrep[1] = nextRep1; }
+            if (newMaxSym != 0xFFFFFFFFu) {
+                for (uint32_t i = lane; i < 256; i += 64) { L.prevBits[i] = L.hufBits[i]; L.prevCode[i] = L.hufCode[i]; }
+                if (zh_opaque(lane) == 0) { L.prevRepeat = 1; L.prevMaxSym = newMaxSym; }
+            }
+        }
+        ze_fence();
+        zh_sync();
+    }
     return r;
 }
 
@@ -1125,6 +1192,122 @@ ZH_DEV int ze_get_cparams(ZePar& out, int level, uint32_t srcSize)
     return 0;
 }
 
+// Where to end a full 128 KiB block once the frame has shown savings (ZSTD_splitBlock, zstd.c:22263-22502). All lanes call.
+// fast strategy: byte histograms of the first / last / middle 512 bytes; double-fast: 8 KiB chunks, a byte histogram of every 43rd
+// position, split at the first chunk whose histogram strays from everything before it.
+ZH_DEV uint32_t ze_fp_distance(const uint32_t* A, uint32_t na, const uint32_t* B, uint32_t nb)     // sum |A[i] nb - B[i] na| over 256 bins (fits 32 bits)
+{
+    const uint32_t lane = zh_lane();
+    uint32_t d = 0;
+    for (uint32_t i = lane; i < 256; i += 64) { const int32_t x = (int32_t)(A[i] * nb) - (int32_t)(B[i] * na); d += (uint32_t)(x < 0 ? -x : x); }
+    return zh_shfl(zh_scan_add(d), 63);
+}
+ZH_DEVFN uint32_t ze_split_block(ZeLDS& L, const uint8_t* p, int strat)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t B = 128u << 10;
+    uint32_t* const past = L.hist; uint32_t* const cur = (uint32_t*)L.node; uint32_t* const mid = cur + 256;
+    zh_sync();
+    for (uint32_t i = lane; i < 256; i += 64) { past[i] = 0; cur[i] = 0; mid[i] = 0; }
+    zh_sync();
+    if (strat == 1) {
+        for (uint32_t i = lane; i < 512; i += 64) { zh_lds_atomic_inc(&past[p[i]]); zh_lds_atomic_inc(&cur[p[B - 512 + i]]); }
+        zh_sync();
+        const uint32_t dev = ze_fp_distance(past, 512, cur, 512);
+        if (!(dev >= (uint32_t)(((uint64_t)512 * 512 * 14) / 16))) return B;
+        for (uint32_t i = lane; i < 512; i += 64) zh_lds_atomic_inc(&mid[p[B / 2 - 256 + i]]);
+        zh_sync();
+        const uint32_t db = ze_fp_distance(past, 512, mid, 512), de = ze_fp_distance(cur, 512, mid, 512);
+        const uint32_t diff = db > de ? db - de : de - db;
+        if (diff < 512u * 512u / 3u) return 64u << 10;
+        return db > de ? (32u << 10) : (96u << 10);
+    }
+    const uint32_t C = 8u << 10, nSamples = 191, nEv = 190;       // positions 0, 43, ... < 8191; the event count is 8191 / 43
+    for (uint32_t k = lane; k < nSamples; k += 64) zh_lds_atomic_inc(&past[p[43 * k]]);
+    zh_sync();
+    uint32_t npast = nEv, penalty = 3;
+    for (uint32_t pos = C; pos <= B - C; pos += C) {
+        for (uint32_t i = lane; i < 256; i += 64) cur[i] = 0;
+        zh_sync();
+        for (uint32_t k = lane; k < nSamples; k += 64) zh_lds_atomic_inc(&cur[p[pos + 43 * k]]);
+        zh_sync();
+        const uint32_t dev = ze_fp_distance(past, npast, cur, nEv);
+        const uint32_t threshold = (uint32_t)(((uint64_t)npast * nEv * (14 + penalty)) / 16);
+        if (dev >= threshold) return pos;
+        for (uint32_t i = lane; i < 256; i += 64) past[i] += cur[i];
+        npast += nEv;
+        if (penalty > 0) penalty--;
+        zh_sync();
+    }
+    return B;
+}
+
+// A frame of several blocks (ZSTD_compress_frameChunk, zstd.c:27545): sources above 128 KiB. All lanes call.
+ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced)
+{
+    const uint32_t lane = zh_lane();
+    *produced = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
+    const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
+    if (srcSize64 >= (1ull << 31) || a.cdict) return ZE_PARAM_UNSUPPORTED;        // index overflow correction / dictionary + multi-block: not implemented
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    if (cap64 < (uint64_t)srcSize + (srcSize >> 8)) return ZE_DST_TOO_SMALL;
+    ZePar cp;
+    const int e = ze_get_cparams(cp, a.level, srcSize);
+    if (e) return e;
+    if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
+    const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
+    const uint32_t single = contentSize && cp.wlog < 32 && (1ull << cp.wlog) >= srcSize;
+    const uint32_t fcsCode = contentSize ? (srcSize >= 256) + (srcSize >= 65536 + 256) : 0;
+    uint32_t pos = 0;
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        zh_st32(dst, ZF_MAGIC); pos = 4;
+        dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+        if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
+        if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
+        else if (fcsCode == 1) { zh_st16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
+        else { zh_st32(dst + pos, srcSize); pos += 4; }
+        L.misc[4] = pos;
+        L.mrep[0] = 1; L.mrep[1] = 4; L.prevRepeat = 0; L.prevMaxSym = 0;
+    }
+    zh_sync();
+    pos = zh_first(L.misc[4]);
+    zh_sync();
+    ZeMulti mb; mb.frame = src; mb.firstBlock = true;
+    uint32_t ip = 0; int32_t savings = 0;
+    while (ip < srcSize) {
+        const uint32_t remaining = srcSize - ip;
+        uint32_t blockSize = remaining < ZF_BLOCK_MAX ? remaining : ZF_BLOCK_MAX;
+        if (remaining >= ZF_BLOCK_MAX && savings >= 3) blockSize = ze_split_block(L, src + ip, cp.strat);
+        const uint32_t last = blockSize == remaining ? 1u : 0u;
+        const uint64_t room = cap64 - pos - 3;                      // never let a block's scratch output run past this frame's slot
+        const uint32_t want = blockSize + (blockSize >> 7) + 512;
+        const uint32_t c = ze_compress_block(L, dst + pos + 3, room < want ? (uint32_t)room : want, src + ip, blockSize, cp, ws, nullptr, a, &mb);
+        uint32_t total, bh;
+        if (c == 0) {
+            bh = last + (0u << 1) + (blockSize << 3);
+            for (uint32_t i = lane; i < blockSize; i += 64) dst[pos + 3 + i] = src[ip + i];
+            total = 3 + blockSize;
+        } else if (c == 1) { bh = last + (1u << 1) + (blockSize << 3); total = 4; }
+        else { bh = last + (2u << 1) + (c << 3); total = 3 + c; }
+        if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
+        savings += (int32_t)blockSize - (int32_t)total;
+        pos += total; ip += blockSize; mb.firstBlock = false;
+        ze_fence();
+        zh_sync();
+    }
+    if (checksum) {
+        if (zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));
+        pos += 4;
+    }
+    ze_fence();
+    *produced = pos;
+    return ZE_OK;
+}
+
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
 ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre)
 {
@@ -1134,7 +1317,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
     uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
-    if (srcSize64 > ZF_BLOCK_MAX) return ZE_PARAM_UNSUPPORTED;           // multi-block frames: next round
+    if (srcSize64 > ZF_BLOCK_MAX) return pre ? ZE_PARAM_UNSUPPORTED : ze_frame_multi(a, L, f, ws, produced);   // multi-block frames: generic kernel only
     const uint32_t srcSize = (uint32_t)srcSize64;
     const uint32_t bound = srcSize + (srcSize >> 8) + (srcSize < (128u << 10) ? (((128u << 10) - srcSize) >> 11) : 0);
     if (cap64 < bound) return ZE_DST_TOO_SMALL;
@@ -1332,13 +1515,15 @@ ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
 {
     const uint32_t lane = zh_lane();
     uint8_t* ws = a.workspace + (size_t)zh_block() * ZHIP_ENC_STRIDE;
+    const uint32_t total = a.frameList ? *a.listCount : a.n;              // an explicit list: the inputs the two-kernel form declined
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counter, lane == 0 ? 1u : 0u);     // branch-free fetch (see decoder note)
         if (zh_opaque(lane) == 0) L.misc[15] = got;
         zh_sync();
-        const uint32_t f = zh_first(L.misc[15]);
+        const uint32_t k = zh_first(L.misc[15]);
         zh_sync();
-        if (f >= a.n) break;
+        if (k >= total) break;
+        const uint32_t f = a.frameList ? a.frameList[k] : k;
         uint64_t produced = 0;
         const int err = ze_frame(a, L, f, ws, &produced, nullptr);
         zh_sync();
@@ -1363,7 +1548,12 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
         ZePar cp;
-        if (srcSize64 > ZF_BLOCK_MAX || ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
+        if (srcSize64 > ZF_BLOCK_MAX) {                                    // several blocks: the generic kernel takes it
+            m.mode = 3; a.meta[i] = m;
+            a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
+            continue;
+        }
+        if (ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
             (size_t)(4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         const uint32_t srcSize = (uint32_t)srcSize64;
         if (a.cdict) {
@@ -1400,6 +1590,7 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         if (i >= a.count) break;
         const uint32_t f = a.first + i;
         const ZeMeta m = a.meta[i];
+        if (m.mode == 3) continue;                                         // listed for the generic kernel
         const uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
         ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
         uint64_t produced = 0;

@@ -63,7 +63,11 @@ struct ZhipDecodeArgs {
 #define ZE_MAX_HLOG 17
 #define ZE_MAX_SEQ 43704                                 // >= 131072 / 3 sequences per block
 #define ZE_SEQ_CAP ZE_MAX_SEQ
-// packed sequence: offBase[0:20) litLength[20:42) matchLength[42:64)
+// packed sequence: offBase[0:28) litLength[28:46) matchLength[46:64)  (lengths <= 128 KiB = one block, offsets < 256 MiB)
+#define ZE_SEQ_PACK(off, ll, ml) ((uint64_t)(off) | ((uint64_t)(ll) << 28) | ((uint64_t)(ml) << 46))
+#define ZE_SEQ_OFF(q) ((uint32_t)(q) & 0xFFFFFFFu)
+#define ZE_SEQ_LL(q) ((uint32_t)((q) >> 28) & 0x3FFFFu)
+#define ZE_SEQ_ML(q) ((uint32_t)((q) >> 46))
 #define ZE_WS_HASHL 0
 #define ZE_WS_HASHS (ZE_WS_HASHL + (4u << ZE_MAX_HLOG))
 #define ZE_WS_SEQ   (ZE_WS_HASHS + (4u << ZE_MAX_HLOG))
@@ -90,6 +94,9 @@ struct ZhipEncodeArgs {
     uint8_t* laneTables;            // (gridDim.x * ZE_E1_LANES) x tableStride : hash tables of the frames being searched
     uint32_t tableStride;
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
+    // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
+    uint32_t* bigList; uint32_t* bigCount;
+    const uint32_t* frameList; const uint32_t* listCount;
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;
@@ -118,7 +125,7 @@ struct ZeCTab {
 // as an external segment); this backend implements the attached mode only and reports larger sources as unsupported.
 #define ZE_DICT_ATTACH_MAX (16u * 1024)
 #define ZE_CDICT_MAX_HLOG 18
-#define ZE_CDICT_MAX_CONTENT ((1u << 20) - ZE_DICT_ATTACH_MAX - 16)   // offBase must fit the packed sequence's 20 bits
+#define ZE_CDICT_MAX_CONTENT ((1u << 24) - ZE_DICT_ATTACH_MAX - 16)   // tagged cells keep 24 bits of index
 struct ZeCDict {
     int32_t  status;            // 0 or a zstd error code
     int32_t  hlog, clog, mml;   // parameters the tagged tables were filled with

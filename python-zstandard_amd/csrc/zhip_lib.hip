@@ -210,7 +210,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
-    DevBuf encWorkspace, encMeta, encArena, encTables;
+    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs;
     int e1PerCU = 0, e2PerCU = 0;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
@@ -279,7 +279,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -628,10 +628,14 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
+        const uint32_t gBig = (uint32_t)(n < 64 ? n : 64);                       // waves for inputs above one block (generic kernel)
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
-            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE) ||
+            c->encBigList.reserve(n * sizeof(uint32_t) + 16)) return ZHIP_ERR_HIP;
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
+        a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)((uint8_t*)c->counter.p + 24);
+        HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
@@ -648,6 +652,14 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             hipEvent_t dup; HIP_TRY(hipEventCreate(&dup)); HIP_TRY(hipEventRecord(dup, stream));
             c->timer[6].shared.emplace_back(ev[1], ev[2]);
             c->timer[1].pending.emplace_back(ev[2], dup);      // owns ev[2]; measures ~0
+        }
+        {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
+            if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+            ZhipEncodeArgs b = a;
+            b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);
+            b.frameList = a.bigList; b.listCount = a.bigCount;
+            hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
+            HIP_TRY(hipGetLastError());
         }
         if (getenv("ZHIP_WATCHDOG")) {
             for (int it = 0; it < 2400; it++) {
@@ -801,8 +813,8 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     std::vector<zhip_segment> segs(2 * n);
     uint64_t srcTotal = 0, dstTotal = 0;
     for (size_t i = 0; i < n; i++) {
-        if (items[i].srcSize > ZF_BLOCK_MAX) {
-            g_lastError = "inputs larger than 128 KiB (multi-block frames) are not implemented in the HIP backend yet";
+        if (items[i].srcSize >= (1ull << 31)) {
+            g_lastError = "inputs of 2 GiB and more are not implemented in the HIP backend";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
         if (withDict && items[i].srcSize > ZE_DICT_ATTACH_MAX) {

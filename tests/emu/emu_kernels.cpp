@@ -164,6 +164,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
     a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
+    uint32_t bigCount = 0; a.bigList = (uint32_t*)calloc(n ? n : 1, 4); a.bigCount = &bigCount;
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);
     for (uint32_t first = 0; first < n; first += chunk) {
@@ -172,6 +173,13 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);
     }
-    free(a.workspace); free(a.laneTables); free(a.meta); free(a.arena);
+    if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
+        ZhipEncodeArgs b = a; uint32_t bc = 0;
+        b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;
+        EncLaunch l = { &b };
+        zhemu::run_grid(nBlocks, enc_lane, &l);
+        free(b.workspace);
+    }
+    free(a.workspace); free(a.laneTables); free(a.meta); free(a.arena); free(a.bigList);
     return 0;
 }

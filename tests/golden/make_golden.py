@@ -58,6 +58,33 @@ def dict_compress_cases(ref, corpus, trained):
 
 
 LEVELS = (1, 2, -1, -5, -100)
+MB_LEVELS = (3, 1, -3)
+
+
+def multiblock_inputs(corpus):
+    def cb(i, n):
+        out = b""
+        k = 0
+        while len(out) < n:
+            out += corpus.frame_bytes(2000 + i * 16 + k)
+            k += 1
+        return out[:n]
+    rng = np.random.default_rng(1)
+    return {"random1M": rng.bytes(1 << 20), "zeros600k": bytes(600000), "corpus128k+1": cb(0, 131073), "corpus300k": cb(1, 300000),
+            "corpus1M": cb(2, 1 << 20), "mixed": cb(3, 200000) + np.random.default_rng(3).bytes(200000) + cb(4, 150000),
+            "rle_tail": cb(5, 131072) + b"x" * 131072 + b"y" * 3, "beyond_window_l1": cb(6, 700000)}
+
+
+def multiblock_cases(ref, corpus):
+    out = {"levels": list(MB_LEVELS), "frames": {}}
+    for name, data in multiblock_inputs(corpus).items():
+        rec = {"size": len(data), "input_sha256": hashlib.sha256(data).hexdigest()}
+        for lvl in MB_LEVELS:
+            for tag, flags in (("default", reflib.DEFAULT_FLAGS), ("checksum", reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM)):
+                fr = ref.compress(data, level=lvl, flags=flags)
+                rec["%d/%s" % (lvl, tag)] = {"size": len(fr), "sha256": hashlib.sha256(fr).hexdigest()}
+        out["frames"][name] = rec
+    return out
 
 
 def level_cases(ref, cases):
@@ -105,6 +132,8 @@ def main():
         out["dictionary"]["frames"].append({"blob_offset": len(blob), "size": len(fr), "input_sha256": hashlib.sha256(s).hexdigest(),
                                             "input_size": len(s)})
         blob += fr
+    # frames of several blocks (sources above 128 KiB): SURVEY config 1 (1 MiB of random bytes -> 1 048 609 bytes) and compressible ones
+    out["multiblock_compress"] = multiblock_cases(ref, corpus)
     # other strategies of the same path: the `fast` parser (levels 1, 2 and negative levels)
     out["levels"] = level_cases(ref, inputs(corpus))
     # dictionary COMPRESSION (attached-dictionary mode, sources <= 16 KiB): trained and raw-content dictionaries

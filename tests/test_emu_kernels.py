@@ -121,3 +121,18 @@ def test_emulated_fast_strategy_matches_golden(emu, corpus):
             for n, o in zip(names, outs):
                 rec = GOLD["levels"]["frames"][n][str(lvl)]
                 assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (n, lvl, pipeline)
+
+
+def test_emulated_multiblock_encode_matches_golden(emu):
+    """inputs above one block are listed by E1 and encoded by the generic kernel: block split, carried state, raw / RLE blocks"""
+    import hashlib
+    from tests.test_oracle_vs_golden import GOLD, _multiblock_inputs
+    data = _multiblock_inputs()
+    names = ["random1M", "corpus128k+1", "corpus300k", "rle_tail"]
+    raws = [data[n] for n in names] + [b"tiny input next to the big ones " * 20]
+    for lvl, pipeline in ((3, True), (1, False)):
+        outs, st = emu.compress_batch(raws, level=lvl, flags=5, n_blocks=2, pipeline=pipeline)
+        assert not any(st)
+        for n, o in zip(names, outs):
+            want = GOLD["multiblock_compress"]["frames"][n]["%d/default" % lvl]
+            assert len(o) == want["size"] and hashlib.sha256(o).hexdigest() == want["sha256"], (n, lvl)

@@ -141,3 +141,23 @@ def test_fast_strategy_levels_bit_exact(zstd):
             assert res[i].tobytes() == chk.compress(r, level=lvl, flags=reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM), (lvl, i)
     back = zstd.ZstdDecompressor().multi_decompress_to_buffer(res)
     assert [back[i].tobytes() for i in range(len(more))] == more
+
+
+def test_multiblock_frames_bit_exact(zstd):
+    """inputs above 128 KiB (SURVEY config 1 and friends): golden vectors, one-shot and batch, round trip through the HIP decoder"""
+    import hashlib
+    from tests.test_oracle_vs_golden import GOLD, _multiblock_inputs
+    data = _multiblock_inputs()
+    one = zstd.ZstdCompressor(level=3).compress(data["random1M"])
+    assert len(one) == 1048609 and hashlib.sha256(one).hexdigest() == GOLD["multiblock_compress"]["frames"]["random1M"]["3/default"]["sha256"]
+    assert zstd.ZstdDecompressor().decompress(one) == data["random1M"]
+    names = list(data)
+    for lvl in GOLD["multiblock_compress"]["levels"]:
+        for tag, kw in (("default", {}), ("checksum", {"write_checksum": True})):
+            res = zstd.ZstdCompressor(level=lvl, **kw).multi_compress_to_buffer([data[n] for n in names] + [b"small neighbour"])
+            for i, n in enumerate(names):
+                want = GOLD["multiblock_compress"]["frames"][n]["%d/%s" % (lvl, tag)]
+                fr = res[i].tobytes()
+                assert len(fr) == want["size"] and hashlib.sha256(fr).hexdigest() == want["sha256"], (n, lvl, tag)
+    back = zstd.ZstdDecompressor().multi_decompress_to_buffer(res)
+    assert [back[i].tobytes() for i in range(len(names))] == [data[n] for n in names]
