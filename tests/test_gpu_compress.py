@@ -77,8 +77,10 @@ def test_errors(zstd):
         c.multi_compress_to_buffer([b"", b"", b""])
     with pytest.raises(TypeError, match="item 0 not a bytes like object"):
         c.multi_compress_to_buffer([None])
-    with pytest.raises(zstd.ZstdError):                      # loud: multi-block frames are not implemented yet
-        c.compress(b"x" * 200000)
+    with pytest.raises(zstd.ZstdError):                      # loud: strategies above double-fast are not implemented
+        zstd.ZstdCompressor(level=5).compress(b"x" * 2000)
+    with pytest.raises(zstd.ZstdError):                      # level 4 is the greedy strategy for inputs up to 16 KiB
+        zstd.ZstdCompressor(level=4).multi_compress_to_buffer([b"y" * 5000, b"z" * 300])
 
 
 def test_dictionary_compression_bit_exact(zstd, corpus):
