@@ -49,13 +49,13 @@ ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(Zhi
     __shared__ ZpExecLDS L;
     zp_exec_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
+ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeLDS L;
     ze_kernel_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
+ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeLDS L;
     ze_entropy_body(a, L);
