@@ -36,6 +36,8 @@ ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+ZH_DEV void zh_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+ZH_DEV void zh_lds_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_lds_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV uint32_t zh_wave_max(uint32_t v) { for (int d = 32; d; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; } return v; }
@@ -101,6 +103,8 @@ ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u);
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __sync_fetch_and_add(p, v); }
 ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+ZH_DEV void zh_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+ZH_DEV void zh_lds_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { (*p)++; }
 ZH_DEV uint32_t zh_lds_atomic_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
@@ -125,6 +129,8 @@ ZH_DEV uint32_t zh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uin
 typedef uint64_t __attribute__((aligned(1))) zh_u64u;
 typedef uint32_t __attribute__((aligned(1))) zh_u32u;
 typedef uint16_t __attribute__((aligned(1))) zh_u16u;
+struct __attribute__((packed, aligned(1))) zh_v16 { uint64_t lo, hi; };      // 16 bytes at any address: one global_load_dwordx4
+ZH_DEV zh_v16 zh_ld128(const uint8_t* p) { return *(const zh_v16*)p; }
 ZH_DEV uint64_t zh_ld64(const uint8_t* p) { return *(const zh_u64u*)p; }
 ZH_DEV uint32_t zh_ld32(const uint8_t* p) { return *(const zh_u32u*)p; }
 ZH_DEV uint32_t zh_ld16(const uint8_t* p) { return *(const zh_u16u*)p; }

@@ -435,6 +435,75 @@ ZH_DEVFN uint32_t ze_huf_encode_1x(const ZeLDS& L, uint8_t* out, uint32_t cap, c
     return ze_bw_close(b);
 }
 
+// LDS scratch that aliases the Huffman tree nodes (dead once the code lengths are final): first the literal code table
+// (code | nbBits << 16 per byte value), later -- the literals being done -- the sequence encoder's scratch.
+ZH_DEV uint32_t* ze_scratch(ZeLDS& L) { return (uint32_t*)L.node; }
+
+// The four Huffman streams of a literals section (HUF_compress4X_usingCTable_internal zstd.c:17925; each stream is
+// HUF_compress1X_usingCTable_internal_body :17813, last symbol first, closed by a 1 bit), encoded by the whole wave: 16 lanes
+// per stream, each lane a contiguous run of the stream's symbols. A stream is a pure concatenation of codes, so a lane's bit
+// offset is the code-length total of the runs behind it (wave prefix sum); lanes write whole dwords they own with plain stores
+// and the two dwords they may share with a neighbour with atomic ORs into a zeroed area. ct = code | nbBits << 16 (LDS).
+// All lanes call. Returns 6 + the four stream sizes, or 0 when a stream is too long for the jump table or the room.
+ZH_DEVFN uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t strm = lane >> 4, sub = lane & 15;
+    const uint32_t seg = (n + 3) / 4;
+    const uint32_t s0 = strm * seg, len = strm < 3 ? seg : n - 3 * seg;
+    const uint32_t run = (len + 15) / 16;
+    const uint32_t ra = sub * run < len ? sub * run : len, rb = ra + run < len ? ra + run : len;
+    const uint8_t* p = lit + s0;
+    uint32_t bits = 0;
+    {   uint32_t i = rb;
+        while (i - ra >= 4) { const uint32_t w = zh_ld32(p + i - 4); i -= 4;
+            bits += (ct[w >> 24] >> 16) + (ct[(w >> 16) & 255] >> 16) + (ct[(w >> 8) & 255] >> 16) + (ct[w & 255] >> 16); }
+        while (i > ra) { --i; bits += ct[p[i]] >> 16; } }
+    const uint32_t incl = zh_scan_add(bits);
+    const uint32_t gEnd = zh_shfl(incl, strm * 16 + 15);
+    const uint32_t gBefore = zh_shfl(incl, strm ? strm * 16 - 1 : 0);
+    const uint32_t T = gEnd - (strm ? gBefore : 0u);                 // bits of my stream
+    const uint32_t off = gEnd - incl;                                // bits emitted before mine: the runs behind me
+    const uint32_t mySize = (T + 1 + 7) / 8;
+    const uint32_t z1 = zh_shfl(mySize, 0), z2 = zh_shfl(mySize, 16), z3 = zh_shfl(mySize, 32), z4 = zh_shfl(mySize, 48);
+    if (z1 > 65535 || z2 > 65535 || z3 > 65535 || z4 > 65535 || n < 12 || 6 + z1 + z2 + z3 + z4 > bcap) return 0;
+    const uint32_t total = 6 + z1 + z2 + z3 + z4;
+    {   // zero the stream area byte-exactly (neighbouring bytes belong to headers already written / to other frames)
+        uint8_t* z0 = body + 6; uint8_t* const ze = body + total;
+        const uint32_t head = (uint32_t)((4 - ((uintptr_t)z0 & 3)) & 3);
+        const uint32_t h = head < (uint32_t)(ze - z0) ? head : (uint32_t)(ze - z0);
+        if (lane < h) z0[lane] = 0;
+        z0 += h;
+        const uint32_t nd = (uint32_t)(ze - z0) >> 2;
+        for (uint32_t i = lane; i < nd; i += 64) ((uint32_t*)z0)[i] = 0;
+        z0 += 4 * (size_t)nd;
+        if (lane < (uint32_t)(ze - z0)) z0[lane] = 0;
+    }
+    ze_fence();
+    zh_sync();
+    {
+        const uint32_t so = 6 + (strm > 0 ? z1 : 0u) + (strm > 1 ? z2 : 0u) + (strm > 2 ? z3 : 0u);
+        const uintptr_t A = (uintptr_t)(body + so);
+        const uint32_t sh0 = (uint32_t)(A & 3) * 8 + off;            // bit offset from the aligned dword at or below the stream start
+        uint32_t* d = (uint32_t*)(A & ~(uintptr_t)3) + (sh0 >> 5);
+        uint32_t nacc = sh0 & 31; uint64_t acc = 0; bool first = true;
+#define ZE_HEMIT() do { if (first) { zh_atomic_or(d, (uint32_t)acc); first = false; } else *d = (uint32_t)acc; d++; acc >>= 32; nacc -= 32; } while (0)
+#define ZE_HSYM(s) do { const uint32_t e_ = ct[(s)]; acc |= (uint64_t)(e_ & 0xFFFFu) << nacc; nacc += e_ >> 16; if (nacc >= 32) ZE_HEMIT(); } while (0)
+        uint32_t i = rb;
+        while (i - ra >= 4) { const uint32_t w = zh_ld32(p + i - 4); i -= 4;
+            ZE_HSYM(w >> 24); ZE_HSYM((w >> 16) & 255); ZE_HSYM((w >> 8) & 255); ZE_HSYM(w & 255); }
+        while (i > ra) { --i; ZE_HSYM(p[i]); }
+        if (sub == 0) { acc |= 1ull << nacc; nacc++; if (nacc >= 32) ZE_HEMIT(); }     // end mark after the stream's first symbol
+        if (acc) zh_atomic_or(d, (uint32_t)acc);
+#undef ZE_HSYM
+#undef ZE_HEMIT
+        if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)(lane == 0 ? z1 : lane == 1 ? z2 : z3));
+    }
+    ze_fence();
+    zh_sync();
+    return total;
+}
+
 // literals header for raw / rle sections (ZSTD_noCompressLiterals :20842, ZSTD_compressRleLiteralsBlock :20884). lane 0.
 ZH_DEVFN uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n, uint32_t type, bool rle)
 {
@@ -549,27 +618,12 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
             total = zh_first(L.misc[0]);
             zh_sync();
         } else {
-            // 4 streams (HUF_compress4X_usingCTable_internal, zstd.c:17925): 6-byte jump table + 4 bodies. The bodies
-            // must be contiguous, so every lane first measures its stream, then writes it at its final offset.
-            const uint32_t seg = (n + 3) / 4;
-            uint32_t bits = 0;
-            if (lane < 4) {
-                const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
-                for (uint32_t i = 0; i < len; i++) bits += L.hufBits[lit[s0 + i]];
-            }
-            const uint32_t mySize = (bits + 1 + 7) / 8;
-            const uint32_t z1 = zh_shfl(mySize, 0), z2 = zh_shfl(mySize, 1), z3 = zh_shfl(mySize, 2), z4 = zh_shfl(mySize, 3);
-            bool ok = !(z1 > 65535 || z2 > 65535 || z3 > 65535 || z4 > 65535) && n >= 12 && (6 + z1 + z2 + z3 + z4 <= bcap);
-            if (ok) {
-                if (lane < 4) {
-                    const uint32_t s0 = lane * seg, len = lane < 3 ? seg : n - 3 * seg;
-                    const uint32_t off = 6 + (lane > 0 ? z1 : 0) + (lane > 1 ? z2 : 0) + (lane > 2 ? z3 : 0);
-                    (void)ze_huf_encode_1x(L, body + off, mySize, lit + s0, len);
-                    if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)mySize);
-                }
-                total = 6 + z1 + z2 + z3 + z4;
-            }
+            // 4 streams, wave-parallel
+            uint32_t* ct = ze_scratch(L);
             zh_sync();
+            for (uint32_t i = lane; i < 256; i += 64) ct[i] = (uint32_t)L.hufCode[i] | ((uint32_t)L.hufBits[i] << 16);
+            zh_sync();
+            total = ze_huf_encode_4x_wave(ct, body, bcap, lit, n);
         }
         uint32_t cl = total ? h + total : 0;
         if (cl >= n - 1) cl = 0;
@@ -1001,7 +1055,7 @@ ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog
     return 2;
 }
 // ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, const uint8_t* codes, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat)
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat)
 {
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
     const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
@@ -1021,11 +1075,10 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
         for (uint32_t u = 0; u < (1u << d.log); u++) t.next[u] = d.next[u];
         return 0;
     }
-    if (*mode == 1) { ze_fse_build_rle(t, codes[0]); out[0] = codes[0]; return 1; }
+    if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
     if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, L.cellSym, nrm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
     uint32_t n1 = nbSeq;
-    const uint32_t lastCode = codes[nbSeq - 1];
     if (count[lastCode] > 1) { count[lastCode]--; n1--; }
     int16_t norm[53];
     ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
@@ -1033,8 +1086,170 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     ze_fse_build_ctab(t, L.cellSym, norm, max, lg);
     return h;
 }
-ZH_DEV uint32_t ze_ll_code(uint32_t v) { uint32_t c = 35; while (ze_llBase[c] > v) c--; return c; }
-ZH_DEV uint32_t ze_ml_code(uint32_t ml) { uint32_t c = 52; while (ze_mlBase[c] > ml) c--; return c; }
+// ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755): small values by table, the rest by their highest bit
+ZH_CONST uint8_t ze_llCodeTab[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
+ZH_CONST uint8_t ze_mlCodeTab[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+                                       32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+                                       40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+                                       42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42};
+ZH_DEV uint32_t ze_ll_code(uint32_t v) { return v > 63 ? (uint32_t)zh_highbit32(v) + 19 : ze_llCodeTab[v]; }
+ZH_DEV uint32_t ze_ml_code(uint32_t ml) { const uint32_t b = ml - 3; return b > 127 ? (uint32_t)zh_highbit32(b) + 36 : ze_mlCodeTab[b]; }
+
+// ------------------------------------------------------------------------------------------ sequences bitstream, wave-parallel
+// ZSTD_encodeSequences_body (zstd.c:21386): sequences last to first; per sequence the OF, ML, LL state transitions
+// (FSE_encodeSymbol :2785) then the LL, ML, OF extra bits; finally the three states and the end mark. The only serial part is the
+// three state chains -- one lane per table walks them, 64 sequences per round, through LDS -- while what each sequence contributes
+// to the stream (up to 89 bits) is assembled by its own lane, placed by a wave prefix sum of the bit counts and ORed into an LDS
+// bit buffer that is flushed to the frame in whole bytes (the odd bits carry into the next round). All lanes call.
+// Returns the stream's size, 0 when it does not fit in cap.
+ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq)
+{
+    const uint32_t lane = zh_lane();
+    uint32_t* const tt = ze_scratch(L);          // [table][symbol] -> deltaNbBits, deltaFindState (FSE_symbolCompressionTransform)
+    uint32_t* const cpack = tt + 384;            // the round's codes: ll | of << 8 | ml << 16
+    uint32_t* const rec = cpack + 64;            // [table][slot]: state bits | nbBits << 16
+    uint32_t* const bitbuf = rec + 192;          // 196 dwords
+    zh_sync();
+    for (uint32_t k = lane; k < 192; k += 64) {
+        const uint32_t t = k >> 6, sy = k & 63;
+        const ZeCTab& T = L.tab[t];
+        uint32_t dnb = 0, dfs = 0;
+        if (T.log != 0 && sy <= T.maxSym && T.norm[sy] != 0) {
+            const uint32_t c = T.norm[sy] == -1 ? 1u : (uint32_t)T.norm[sy];
+            const uint32_t mb = c > 1 ? (uint32_t)T.log - (uint32_t)zh_highbit32(c - 1) : (uint32_t)T.log;
+            dnb = (mb << 16) - (c << mb);
+            dfs = (uint32_t)T.cellOf[sy] - c;
+        }
+        tt[2 * k] = dnb; tt[2 * k + 1] = dfs;
+    }
+    for (uint32_t k = lane; k < 196; k += 64) bitbuf[k] = 0;
+    zh_sync();
+    uint32_t v = 0;                               // lanes 0..2: the LL / OF / ML state
+    uint32_t carryBits = 0, bytePos = 0; bool ovf = false;
+    uint32_t hi = nbSeq - 1;
+    for (;;) {
+        const bool valid = lane <= hi;
+        const uint64_t q = valid ? seqs[hi - lane] : 0;
+        const uint32_t ll = ZE_SEQ_LL(q), ml = ZE_SEQ_ML(q), ob = ZE_SEQ_OFF(q);
+        uint32_t lc = 0, oc = 0, mc = 0;
+        if (valid) { lc = ze_ll_code(ll); oc = (uint32_t)zh_highbit32(ob); mc = ze_ml_code(ml); }
+        cpack[lane] = lc | (oc << 8) | (mc << 16);
+        zh_sync();
+        if (zh_opaque(lane) < 3) {
+            const uint32_t t = lane;
+            const ZeCTab& T = L.tab[t];
+            const uint32_t cnt = hi < 63 ? hi + 1 : 64;
+            const bool rle = T.log == 0;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t sy = (cpack[j] >> (8 * t)) & 255;
+                const uint32_t dnb = tt[2 * (64 * t + sy)], dfs = tt[2 * (64 * t + sy) + 1];
+                uint32_t r = 0;
+                if (rle) v = 0;
+                else if (hi == nbSeq - 1 && j == 0) {                     // FSE_initCState2, zstd.c:2774
+                    const uint32_t nbOut = (dnb + (1u << 15)) >> 16;
+                    const uint32_t value = (nbOut << 16) - dnb;
+                    v = T.next[(value >> nbOut) + dfs];
+                } else {
+                    const uint32_t nb = (v + dnb) >> 16;
+                    r = (v & ((1u << nb) - 1)) | (nb << 16);
+                    v = T.next[(v >> nb) + dfs];
+                }
+                rec[64 * t + j] = r;
+            }
+        }
+        zh_sync();
+        uint64_t lo = 0, up = 0; uint32_t pos = 0;
+#define ZE_ADD(val, nbits) do { const uint32_t n_ = (nbits); const uint64_t v_ = (val); if (n_) { if (pos < 64) { lo |= v_ << pos; if (pos + n_ > 64) up |= v_ >> (64 - pos); } \
+                                else up |= v_ << (pos - 64); pos += n_; } } while (0)
+        if (valid) {
+            const uint32_t rL = rec[lane], rO = rec[64 + lane], rM = rec[128 + lane];
+            ZE_ADD(rO & 0xFFFFu, rO >> 16); ZE_ADD(rM & 0xFFFFu, rM >> 16); ZE_ADD(rL & 0xFFFFu, rL >> 16);
+            const uint32_t lb = ze_llBits[lc], mb = ze_mlBits[mc];
+            ZE_ADD(ll & ((1u << lb) - 1), lb); ZE_ADD((ml - 3) & ((1u << mb) - 1), mb); ZE_ADD(ob & ((1u << oc) - 1), oc);
+        }
+#undef ZE_ADD
+        const uint32_t incl = zh_scan_add(pos);
+        const uint32_t tot = zh_shfl(incl, 63);
+        if (pos) {
+            const uint32_t P = carryBits + incl - pos, sh = P & 31;
+            uint32_t* w = bitbuf + (P >> 5);
+            const uint64_t A = lo << sh, B = (up << sh) | (sh ? lo >> (64 - sh) : 0ull);
+            if ((uint32_t)A) zh_lds_atomic_or(w, (uint32_t)A);
+            if ((uint32_t)(A >> 32)) zh_lds_atomic_or(w + 1, (uint32_t)(A >> 32));
+            if ((uint32_t)B) zh_lds_atomic_or(w + 2, (uint32_t)B);
+            if ((uint32_t)(B >> 32)) zh_lds_atomic_or(w + 3, (uint32_t)(B >> 32));
+        }
+        zh_sync();
+        const uint32_t totalBits = carryBits + tot, nbytes = totalBits >> 3;
+        if (bytePos + nbytes > cap) ovf = true;
+        if (!ovf) {
+            const uint32_t nd = nbytes >> 2;
+            for (uint32_t i = lane; i < nd; i += 64) zh_st32(out + bytePos + 4 * i, bitbuf[i]);
+            if (lane < (nbytes & 3)) out[bytePos + 4 * nd + lane] = ((const uint8_t*)bitbuf)[4 * nd + lane];
+        }
+        const uint32_t rem = totalBits & 7;
+        const uint32_t cb = rem ? ((const uint8_t*)bitbuf)[nbytes] : 0u;
+        zh_sync();
+        for (uint32_t k = lane; k < 196; k += 64) bitbuf[k] = k == 0 ? cb : 0u;
+        zh_sync();
+        carryBits = rem; bytePos += nbytes;
+        if (hi < 64) break;
+        hi -= 64;
+    }
+    if (zh_opaque(lane) < 3) L.misc[12 + lane] = v;
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        uint64_t acc = bitbuf[0] & 0xFFu; uint32_t nb = carryBits;
+        const uint32_t lgL = (uint32_t)L.tab[0].log, lgO = (uint32_t)L.tab[1].log, lgM = (uint32_t)L.tab[2].log;
+        acc |= (uint64_t)(L.misc[14] & ((1u << lgM) - 1)) << nb; nb += lgM;
+        acc |= (uint64_t)(L.misc[13] & ((1u << lgO) - 1)) << nb; nb += lgO;
+        acc |= (uint64_t)(L.misc[12] & ((1u << lgL) - 1)) << nb; nb += lgL;
+        acc |= 1ull << nb; nb++;
+        const uint32_t nby = (nb + 7) >> 3;
+        if (ovf || bytePos + nby > cap) L.misc[11] = 0;
+        else { for (uint32_t i = 0; i < nby; i++) out[bytePos + i] = (uint8_t)(acc >> (8 * i)); L.misc[11] = bytePos + nby; }
+    }
+    ze_fence();
+    zh_sync();
+    const uint32_t r = zh_first(L.misc[11]);
+    zh_sync();
+    return r;
+}
+
+// The literals of a block from its sequence list: every source byte the matches do not cover, in order (what ZSTD_storeSeq's
+// literal copy accumulates, zstd.c:19930). The match-finding kernel records sequences only; this runs wave-parallel at byte
+// granularity: 64 sequences per round, two prefix sums place the literal runs, every output byte finds its run by a binary
+// search over the round's run ends. All lanes call. Returns the literal count.
+ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src, uint32_t srcSize, const uint64_t* seqs, uint32_t nbSeq)
+{
+    const uint32_t lane = zh_lane();
+    uint32_t* const ends = ze_scratch(L);
+    uint32_t* const srcAt = ends + 64;
+    uint32_t litBase = 0, srcBase = 0;
+    for (uint32_t b0 = 0; b0 < nbSeq; b0 += 64) {
+        const bool valid = b0 + lane < nbSeq;
+        const uint64_t q = valid ? seqs[b0 + lane] : 0;
+        const uint32_t ll = ZE_SEQ_LL(q), ml = ZE_SEQ_ML(q);
+        const uint32_t le = zh_scan_add(ll), se = zh_scan_add(ll + ml);
+        zh_sync();
+        ends[lane] = le; srcAt[lane] = srcBase + se - ll - ml;
+        zh_sync();
+        const uint32_t T = zh_shfl(le, 63), S = zh_shfl(se, 63);
+        for (uint32_t t = lane; t < T; t += 64) {
+            uint32_t j = 0;                                                // smallest j with ends[j] > t
+            for (uint32_t stp = 32; stp; stp >>= 1) if (ends[j + stp - 1] <= t) j += stp;
+            const uint32_t start = j ? ends[j - 1] : 0u;
+            lits[litBase + t] = src[srcAt[j] + (t - start)];
+        }
+        litBase += T; srcBase += S;
+    }
+    const uint32_t tail = srcSize - srcBase;
+    for (uint32_t t = lane; t < tail; t += 64) lits[litBase + t] = src[srcBase + t];
+    ze_fence();
+    zh_sync();
+    return litBase + tail;
+}
 
 // ZSTD_compressBlock_internal (zstd.c:27337). All lanes call. Returns body size, 0 = store raw, 1 = RLE block (out[0] = the byte).
 // mb == null: the block is the whole frame. mb != null: one block of a multi-block frame -- the hash tables, the two repcodes
@@ -1051,10 +1266,12 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
     uint32_t* hashSmall = (uint32_t*)(ws + ZE_WS_HASHS);
     const uint64_t* seqs = pre ? pre->seqs : (const uint64_t*)(ws + ZE_WS_SEQ);
-    const uint8_t* lits = pre ? pre->lits : ws + ZE_WS_LIT;
-    uint8_t* codes = ws + ZE_WS_CODES;
+    const uint8_t* lits = pre && pre->lits ? pre->lits : ws + ZE_WS_LIT;
     uint32_t nbSeq, litSize;
-    if (pre) { nbSeq = pre->nbSeq; litSize = pre->litSize; }
+    if (pre) {
+        nbSeq = pre->nbSeq; litSize = pre->litSize;
+        if (!pre->lits) litSize = ze_gather_literals(L, ws + ZE_WS_LIT, src, srcSize, seqs, nbSeq);    // sequences-only search output
+    }
     else {
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
     if (!mb || mb->firstBlock) {
@@ -1094,64 +1311,50 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         pos = zh_first(L.misc[0]);
         zh_sync();
     } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, php, &newMaxSym);
-    // symbol codes + histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast)
-    uint8_t* llc = codes; uint8_t* ofc = codes + nbSeq; uint8_t* mlc = codes + 2 * nbSeq;
+    // symbol histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast); the codes themselves are recomputed by the
+    // stream encoder, only the first and the last sequence's are kept (rle mode / FSE_normalizeCount's last-symbol rule)
     zh_sync();
     for (uint32_t i = lane; i < 192; i += 64) (&L.cnt[0][0])[i] = 0;
     zh_sync();
     for (uint32_t i = lane; i < nbSeq; i += 64) {
         const uint64_t q = seqs[i];
         const uint32_t a = ze_ll_code(ZE_SEQ_LL(q)), o = (uint32_t)zh_highbit32(ZE_SEQ_OFF(q)), m = ze_ml_code(ZE_SEQ_ML(q));
-        llc[i] = (uint8_t)a; ofc[i] = (uint8_t)o; mlc[i] = (uint8_t)m;
         zh_lds_atomic_inc(&L.cnt[0][a]); zh_lds_atomic_inc(&L.cnt[1][o]); zh_lds_atomic_inc(&L.cnt[2][m]);
+        if (i == 0) L.misc[8] = a | (o << 8) | (m << 16);
+        if (i == nbSeq - 1) L.misc[9] = a | (o << 8) | (m << 16);
     }
     ze_fence();
     zh_sync();
     if (zh_opaque(lane) == 0) {
         uint8_t* op = out + pos;
-        uint32_t result = 1;
+        uint32_t lastCount = 0;
         if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
         else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
         else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
         if (nbSeq) {
             uint8_t* seqHead = op++;
-            int mLL, mOF, mML; uint32_t lastCount = 0, h;
-            h = ze_build_seq_table(L, 0, op, &mLL, llc, nbSeq, cd, (uint32_t)cp.strat); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, ofc, nbSeq, cd, (uint32_t)cp.strat); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, mlc, nbSeq, cd, (uint32_t)cp.strat); if (mML == 2) lastCount = h; op += h;
+            int mLL, mOF, mML; uint32_t h;
+            const uint32_t c0 = L.misc[8], c1 = L.misc[9];
+            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, (uint32_t)cp.strat); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, (uint32_t)cp.strat); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, (uint32_t)cp.strat); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
-            // ZSTD_encodeSequences_body (zstd.c:21386): last sequence first; per sequence OF, ML, LL state updates,
-            // then the LL, ML, OF extra bits
-            ZeBits b; ze_bw_init(b, op, cap - (uint32_t)(op - out));
-            uint32_t n = nbSeq - 1;
-            uint32_t sML = ze_fse_first_state(L.tab[2], mlc[n]), sOF = ze_fse_first_state(L.tab[1], ofc[n]), sLL = ze_fse_first_state(L.tab[0], llc[n]);
-            { const uint64_t q = seqs[n];
-              ze_bw_add(b, ZE_SEQ_LL(q), ze_llBits[llc[n]]);
-              ze_bw_add(b, ZE_SEQ_ML(q) - 3, ze_mlBits[mlc[n]]);
-              ze_bw_add(b, ZE_SEQ_OFF(q), ofc[n]); }
-            while (n-- > 0) {
-                sOF = ze_fse_encode(L.tab[1], b, sOF, ofc[n]);
-                sML = ze_fse_encode(L.tab[2], b, sML, mlc[n]);
-                sLL = ze_fse_encode(L.tab[0], b, sLL, llc[n]);
-                const uint64_t q = seqs[n];
-                ze_bw_add(b, ZE_SEQ_LL(q), ze_llBits[llc[n]]);
-                ze_bw_add(b, ZE_SEQ_ML(q) - 3, ze_mlBits[mlc[n]]);
-                ze_bw_add(b, ZE_SEQ_OFF(q), ofc[n]);
-            }
-            ze_bw_add(b, sML, (uint32_t)L.tab[2].log); ze_bw_add(b, sOF, (uint32_t)L.tab[1].log); ze_bw_add(b, sLL, (uint32_t)L.tab[0].log);
-            const uint32_t bs = ze_bw_close(b);
-            if (bs == 0) result = 0;
-            op += bs;
-            if (lastCount && lastCount + bs < 4) result = 0;
         }
-        const uint32_t cSize = (uint32_t)(op - out);
-        if (cSize >= srcSize - ((srcSize >> 6) + 2)) result = 0;           // ZSTD_minGain, zstd.c:19831
-        L.misc[3] = result ? cSize : 0;
+        L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
     }
     ze_fence();
     zh_sync();
-    uint32_t r = zh_first(L.misc[3]);
+    const uint32_t seqStart = zh_first(L.misc[10]), lastCount = zh_first(L.misc[3]);
     zh_sync();
+    uint32_t r = 1, cSize = seqStart;
+    if (nbSeq) {
+        const uint32_t bs = ze_encode_sequences_wave(L, out + seqStart, cap - seqStart, seqs, nbSeq);
+        if (bs == 0) r = 0;
+        if (lastCount && lastCount + bs < 4) r = 0;
+        cSize += bs;
+    }
+    if (cSize >= srcSize - ((srcSize >> 6) + 2)) r = 0;                    // ZSTD_minGain, zstd.c:19831
+    r = r ? cSize : 0;
     if (mb) {
         if (!mb->firstBlock && r < 25) {          // a later block made of one byte value becomes an RLE block (zstd.c:27373-27384)
             const uint32_t b0 = src[0];
@@ -1579,8 +1782,8 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
 ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
 {
     const uint32_t lane = zh_lane();
-    // only the symbol-code region of the fused kernel's workspace layout is used here; bias the base so it lands in our slot
-    uint8_t* ws = a.workspace + (size_t)zh_block() * ZE_CODES_STRIDE - ZE_WS_CODES;
+    // only the literal region of the fused kernel's workspace layout is used here; bias the base so it lands in our slot
+    uint8_t* ws = a.workspace + (size_t)zh_block() * ZE_E2_STRIDE - ZE_WS_LIT;
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counter + 1, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[15] = got;

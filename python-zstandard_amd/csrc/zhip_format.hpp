@@ -72,8 +72,7 @@ struct ZhipDecodeArgs {
 #define ZE_WS_HASHS (ZE_WS_HASHL + (4u << ZE_MAX_HLOG))
 #define ZE_WS_SEQ   (ZE_WS_HASHS + (4u << ZE_MAX_HLOG))
 #define ZE_WS_LIT   (ZE_WS_SEQ + 8u * (ZE_SEQ_CAP + 8))
-#define ZE_WS_CODES (ZE_WS_LIT + ZF_BLOCK_MAX + 256)
-#define ZHIP_ENC_STRIDE (ZE_WS_CODES + 3u * (ZE_MAX_SEQ + 8) + 256)
+#define ZHIP_ENC_STRIDE (ZE_WS_LIT + ZF_BLOCK_MAX + 256)
 
 struct ZhipEncodeArgs {
     const uint8_t* src;             // all inputs
@@ -110,7 +109,7 @@ struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched;
 #ifndef ZE_E1_LANES
 #define ZE_E1_LANES 8
 #endif
-#define ZE_CODES_STRIDE ((size_t)3 * (ZE_MAX_SEQ + 8) + 256)   // E2 only needs the symbol-code scratch per wave
+#define ZE_E2_STRIDE ((size_t)ZF_BLOCK_MAX + 256)              // E2 needs one block's literals per resident wave (gathered from the sequences)
 
 // FSE encoding table: per symbol, its cells in table order
 struct ZeCTab {

@@ -630,7 +630,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
         const uint32_t gBig = (uint32_t)(n < 64 ? n : 64);                       // waves for inputs above one block (generic kernel)
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
-            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE) ||
+            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
             c->encBigList.reserve(n * sizeof(uint32_t) + 16)) return ZHIP_ERR_HIP;
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;

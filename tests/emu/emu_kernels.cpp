@@ -159,7 +159,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
     a.counter = counters; a.n = n; a.level = level;
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
-    free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_CODES_STRIDE + ZHIP_ENC_STRIDE);
+    free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_E2_STRIDE + ZHIP_ENC_STRIDE);
     a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
