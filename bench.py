@@ -94,8 +94,33 @@ def cpu_decompress_baseline(ref, frames, nthreads, budget_s=8.0):
     return F * FRAME / best / 1e9, reps
 
 
-def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F):
-    """multi_compress_to_buffer direction: same inputs, frames must be bit-identical to libzstd's (all of them)."""
+def cpu_compress_baseline(ref, raw_np, nthreads, budget_s=10.0):
+    """reference ZSTD_compressStream2(e_end) at level 3 on a bounded sample, one CCtx per thread (compress_worker's loop)."""
+    F = raw_np.shape[0]
+    bound = ref.lib.ZSTD_compressBound(FRAME)
+    base = raw_np.ctypes.data
+
+    def work(lo, hi):
+        buf = C.create_string_buffer(bound)
+        for i in range(lo, hi):
+            ref.compress_into(C.addressof(buf), bound, base + i * FRAME, FRAME)
+
+    step = (F + nthreads - 1) // nthreads
+    best, reps, t_start = None, 0, time.time()
+    while reps < 2 or (time.time() - t_start < budget_s and reps < 20):
+        ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
+        t0 = time.time()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return F * FRAME / best / 1e9, reps
+
+
+def measure_compress(ctx, raw, frames, rank, world, dev, F, steps, warmup):
+    """multi_compress_to_buffer direction on the first F rows of raw: every frame must be bit-identical to libzstd's.
+    Returns (elapsed seconds over `steps` passes (max over ranks), compressed total, per-kernel times)."""
     bound = FRAME + (FRAME >> 8)
     bound = (bound + 15) & ~15
     src_segs = torch.zeros((F, 2), dtype=torch.int64, device=dev)
@@ -107,26 +132,24 @@ def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world,
     dst = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
     out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
     status = torch.zeros(F, dtype=torch.int32, device=dev)
-    src = raw.reshape(-1)
+    src = raw[:F].reshape(-1)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
     barrier()
-    for k in (1, 5, 6):
+    for k in (1, 5, 6, 8):
         ctx.kernel_time(k)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
     barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = {k: ctx.kernel_time(k) for k in (1, 5, 6)}
-    kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
-    kernel_ms, launches = ktimes[kdom]
+    ktimes = {k: ctx.kernel_time(k) for k in (1, 5, 6, 8)}
     assert int(status.abs().max().item()) == 0, "a frame failed to compress"
     sizes = out_sizes.cpu().numpy()
     out = dst.view(F, bound).cpu().numpy()
@@ -138,6 +161,15 @@ def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world,
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    del dst
+    return elapsed, ctotal, ktimes
+
+
+def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F):
+    """--direction compress: the whole line is about multi_compress_to_buffer on the same inputs."""
+    elapsed, ctotal, ktimes = measure_compress(ctx, raw, frames, rank, world, dev, F, args.steps, args.warmup)
+    kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
+    kernel_ms, launches = ktimes[kdom]
     value = world * F * FRAME * args.steps / elapsed / 1e9
     line = {
         "metric": "GB/s uncompressed throughput, batch compress of 128 KiB inputs at level 3 (bit-exact vs libzstd 1.5.7)",
@@ -156,6 +188,13 @@ def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world,
         line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                             "kernel_ms": round(kernel_ms, 3), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes)}
+        if world == 1 and not args.no_cpu_baseline:
+            sample = min(F, 4096)
+            v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads)
+            line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
+                                    "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 over the first %d inputs of the same "
+                                              "workload, %d threads (host has %d cores), best of %d passes"
+                                              % (sample, nthreads, os.cpu_count() or 0, reps)}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -168,6 +207,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (BASELINE config: 65536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compress-frames", type=int, default=16384,
+                    help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default="decompress",
                     help="decompress is the BASELINE.json headline; compress times multi_compress_to_buffer on the same inputs")
     args = ap.parse_args()
@@ -291,6 +332,21 @@ def main():
                                               "workload, %d threads (host has %d cores), best of %d passes"
                                               % (sample, nthreads, os.cpu_count() or 0, reps)}
         line["setup_s"] = {"generate": round(t_gen, 1), "host_compress": round(t_comp, 1)}
+    if args.compress_frames > 0:
+        # the other half of BASELINE.json's metric, on a bounded slice of the same inputs (the timed decompress region above is over)
+        Fc = min(F, args.compress_frames)
+        del dst
+        c_elapsed, c_total, c_k = measure_compress(ctx, raw, frames, rank, world, dev, Fc, 2, 1)
+        if rank == 0:
+            line["compress"] = {"value": round(world * Fc * FRAME * 2 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 2,
+                                "ms_per_step": round(c_elapsed / 2 * 1e3, 3), "bit_exact_vs_libzstd": True,
+                                "kernels": {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in c_k.items() if v[1]}}
+            if world == 1 and not args.no_cpu_baseline:
+                sample = min(Fc, 4096)
+                v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads, budget_s=6.0)
+                line["compress"]["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
+                                                    "sample": "libzstd 1.5.7 level 3, first %d inputs, %d threads, best of %d" % (sample, nthreads, reps)}
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -44,8 +44,10 @@ ZH_DEV uint32_t zh_wave_max(uint32_t v) { for (int d = 32; d; d >>= 1) { uint32_
 ZH_DEV void ze_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 // hides a value's provenance from the optimizer (used so `lane == 0` is not provably loop-invariant)
 ZH_DEV uint32_t zh_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+ZH_DEV uint64_t zh_opaque64(uint64_t v) { asm volatile("" : "+v"(v)); return v; }   // also pins a load: it cannot sink below this point
 ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }   // v != 0
+ZH_DEV int zh_clz64(uint64_t v) { return __clzll((long long)v); }                  // v != 0
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
 // v_bfe_u32: (v >> (off & 31)) & ((1 << (width & 31)) - 1); width 0 gives 0 whatever off is
 ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
@@ -106,6 +108,7 @@ ZH_DEV void zh_atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 ZH_DEV void zh_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ZH_DEV void zh_lds_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 ZH_DEV uint32_t zh_opaque(uint32_t v) { return v; }
+ZH_DEV uint64_t zh_opaque64(uint64_t v) { return v; }
 ZH_DEV void zh_lds_atomic_inc(uint32_t* p) { (*p)++; }
 ZH_DEV uint32_t zh_lds_atomic_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 ZH_DEV uint32_t zh_wave_max(uint32_t v)
@@ -120,6 +123,7 @@ ZH_DEV uint32_t zh_wave_max(uint32_t v)
 ZH_DEV void ze_fence() { zhemu::collective_wait(); }
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+ZH_DEV int zh_clz64(uint64_t v) { return __builtin_clzll(v); }
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __builtin_clz(v); }
 ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { width &= 31; return (v >> (off & 31)) & ((1u << width) - 1); }
 ZH_DEV uint32_t zh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }

@@ -780,6 +780,135 @@ ZH_DEV uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const ui
 }
 
 
+// ------------------------------------------------------------------------------------------ E1, flat form (double-fast, no dictionary)
+// ZSTD_compressBlock_doubleFast_noDict_generic (zstd.c:31039) for a frame of one block, one LANE per frame and every lane of the
+// wave busy: the reference's nested loops (probe until a match, then extend, store, insert, repeat-offset loop) are flattened into
+// ONE loop whose every trip is a probe step that may end in a match, so lanes never wait for their neighbours to find a match.
+// Each trip is two dependent memory rounds -- the table cells, then the candidates' bytes -- and, on a match, the extension /
+// insertion reads, which hit the lines just fetched. The long-hash candidate of ip+step is fetched once and carried into the next
+// trip, where it is the long-hash candidate of ip (zstd.c:31208-31211 carries hl1 / idxl1 the same way). Literals are not copied:
+// the entropy kernel gathers them from the sequence list. Positions are frame-relative; cells hold position + 2 (0 = empty), so
+// the reference's comparisons against the lowest prefix index (2) keep their meaning. srcSize in [16, 128 KiB]; tables zeroed.
+#ifdef ZHIP_EMU
+#define ZE_STAT(i) (zd_stat[i]++)
+#else
+#define ZE_STAT(i) ((void)0)
+#endif
+ZH_DEV uint32_t ze_hl8(uint64_t u, uint32_t sh) { return (uint32_t)((u * 0xCF1BBCDCB7A56463ull) >> 32) >> sh; }
+ZH_DEV uint32_t ze_hsx(uint64_t u, uint32_t shl, uint64_t prime, uint32_t sh) { return (uint32_t)(((u << shl) * prime) >> 32) >> sh; }
+ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_t srcSize)     // ZSTD_count (zstd.c:20008): b < a, a + result <= srcSize
+{
+    uint32_t len = 0;
+    while (a + len + 16 <= srcSize) {
+        ZE_STAT(12);
+        const zh_v16 x = zh_ld128(src + a + len), y = zh_ld128(src + b + len);
+        const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
+        if (d0) return len + (uint32_t)(zh_ctz64(d0) >> 3);
+        if (d1) return len + 8 + (uint32_t)(zh_ctz64(d1) >> 3);
+        len += 16;
+    }
+    while (a + len < srcSize && src[a + len] == src[b + len]) len++;
+    return len;
+}
+ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
+    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
+    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
+    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
+    const uint32_t ilimit = srcSize - 8;
+    uint32_t ip = 1, anchor = 0, off1 = 1, off2 = 0, nseq = 0;        // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
+    uint32_t step = 1, nextStep = 0, hl0 = 0, idxl0 = 0; uint64_t cl0 = 0;
+    bool fresh = true;
+    for (;;) {
+        if (fresh) { step = 1; nextStep = ip + 256; }
+        const uint32_t ip1 = ip + step;
+        if (ip1 > ilimit) break;
+        ZE_STAT(10);
+        const uint64_t w0 = zh_ld64(src + ip), w1 = zh_ld64(src + ip1);
+        const uint32_t hs0 = ze_hsx(w0, shlS, primeS, shS), hl1 = ze_hl8(w1, shL);
+        const uint32_t hlf = ze_hl8(w0, shL);
+        if (fresh) hl0 = hlf;
+        // round 1: the table cells (and the repeat-offset candidate), all in flight together. Every load is unconditional with an
+        // address that is always valid, so the compiler keeps them in one straight line behind a single wait.
+        const uint32_t tA = hashLong[fresh ? hl0 : hl1];
+        const uint32_t idxs0 = hashSmall[hs0];
+        uint32_t idxl1 = hashLong[hl1];
+        const uint32_t rp = zh_ld32(src + ip + 1 - off1);
+        if (fresh) idxl0 = tA;
+        const uint32_t curr = ip + 2;
+        if (hl1 == hl0) idxl1 = curr;                                   // the reference reads this cell after writing curr (zstd.c:31121, :31163)
+        hashLong[hl0] = curr; hashSmall[hs0] = curr;
+        // round 2: the candidates' bytes (an empty cell reads the probe position itself and is rejected by its index)
+        uint64_t xl0 = zh_ld64(src + ((fresh && idxl0 >= 2) ? idxl0 - 2 : ip));
+        uint32_t cs0 = zh_ld32(src + (idxs0 >= 2 ? idxs0 - 2 : ip));
+        uint64_t cl1 = zh_ld64(src + (idxl1 >= 2 ? idxl1 - 2 : ip1));
+        xl0 = zh_opaque64(xl0); cs0 = zh_opaque(cs0); cl1 = zh_opaque64(cl1);      // keep the three loads together (none sinks into a branch)
+        if (fresh) cl0 = xl0;
+        int found = 0; uint32_t ipm = ip, mpos = 0, ca = 0, cb = 0, add = 0;
+        if (off1 > 0 && rp == (uint32_t)(w0 >> 8)) { found = 1; ipm = ip + 1; ca = ip + 5; cb = ip + 5 - off1; add = 4; }
+        else if (idxl0 >= 2 && cl0 == w0) { found = 2; mpos = idxl0 - 2; ca = ip + 8; cb = mpos + 8; add = 8; }
+        else if (idxs0 >= 2 && cs0 == (uint32_t)w0) { found = 3; mpos = idxs0 - 2; ca = ip + 4; cb = mpos + 4; add = 4; }
+        if (found) {
+            ZE_STAT(11);
+            uint32_t mLength = ze_count_fwd(src, ca, cb, srcSize) + add;
+            if (found == 3 && idxl1 > 2 && cl1 == w1) {                 // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
+                const uint32_t m1 = idxl1 - 2;
+                const uint32_t l1 = ze_count_fwd(src, ip1 + 8, m1 + 8, srcSize) + 8;
+                if (l1 > mLength) { ipm = ip1; mLength = l1; mpos = m1; }
+            }
+            uint32_t offBase = 1;
+            if (found >= 2) {
+                const uint32_t offset = ipm - mpos;
+                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204)
+                    ZE_STAT(13);
+                    if (mpos >= 8 && ipm - anchor >= 8) {
+                        const uint64_t d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8);
+                        uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
+                        const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
+                        if (k > room) k = room;
+                        ipm -= k; mpos -= k; mLength += k;
+                        if (k < 8) break;
+                    } else {
+                        if (src[ipm - 1] != src[mpos - 1]) break;
+                        ipm--; mpos--; mLength++;
+                    }
+                }
+                off2 = off1; off1 = offset;
+                if (step < 4) hashLong[hl1] = ip1 + 2;
+                offBase = offset + 3;
+            }
+            seqs[nseq++] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
+            const uint32_t pI = ip + 2;                                 // curr + 2 as a position
+            ip = ipm + mLength; anchor = ip;
+            if (ip <= ilimit) {
+                const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
+                hashLong[ze_hl8(wI, shL)] = pI + 2;
+                hashLong[ze_hl8(wE2, shL)] = ip;
+                hashSmall[ze_hsx(wI, shlS, primeS, shS)] = pI + 2;
+                hashSmall[ze_hsx(wE1, shlS, primeS, shS)] = ip + 1;
+                while (ip <= ilimit && off2 > 0) {                      // immediate repeat-offset matches (zstd.c:31236-31250)
+                    const uint64_t wr = zh_ld64(src + ip);
+                    ZE_STAT(14);
+                    if ((uint32_t)wr != zh_ld32(src + ip - off2)) break;
+                    const uint32_t r = ze_count_fwd(src, ip + 4, ip + 4 - off2, srcSize) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    hashSmall[ze_hsx(wr, shlS, primeS, shS)] = ip + 2;
+                    hashLong[ze_hl8(wr, shL)] = ip + 2;
+                    seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
+                    ip += r; anchor = ip;
+                }
+            }
+            fresh = true;
+        } else {
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; hl0 = hl1; idxl0 = idxl1; cl0 = cl1; fresh = false;
+        }
+    }
+    return nseq;
+}
+
+
 // ------------------------------------------------------------------------------------------ fast strategy (levels 1-2, negative levels)
 // ZSTD_compressBlock_fast_noDict_generic (zstd.c:31906) for a block that is the whole frame: one hash table of hashLog bits over
 // minMatch bytes, cells hold position + 2. Positions are examined in pairs `step` apart (step grows by one per 128 bytes without a
@@ -1744,8 +1873,9 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
     if (lane >= ZE_E1_LANES) return;
     uint8_t* tables = a.laneTables + ((size_t)zh_block() * ZE_E1_LANES + lane) * a.tableStride;
     for (;;) {
-        const uint32_t i = zh_atomic_add(a.counter, 1u);
-        if (i >= a.count) break;
+        const uint32_t k = zh_atomic_add(a.counter, 1u);
+        if (k >= (a.useE1List ? *a.e1Count : a.count)) break;
+        const uint32_t i = a.useE1List ? a.e1List[k] : k;
         const uint32_t f = a.first + i;
         ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
@@ -1778,6 +1908,37 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
     }
 }
 
+// E1 flat: one lane per frame, statically assigned, every frame of the chunk in flight (ze_dfast_flat). Frames it does not cover are
+// listed for the lane-serial kernel above (chunk-local index) or, above one block, for the generic kernel.
+ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
+{
+    const uint32_t lane = zh_lane();
+    if (lane >= ZE_FLAT_LANES) return;
+    const uint32_t i = zh_block() * ZE_FLAT_LANES + lane;
+    if (i >= a.count) return;
+    const uint32_t f = a.first + i;
+    ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    ZePar cp;
+    if (srcSize64 > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; return; }
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    if (a.cdict || srcSize < 64 || ze_get_cparams(cp, a.level, srcSize) || cp.strat != 2 ||
+        (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) {
+        a.e1List[zh_atomic_add(a.e1Count, 1u)] = i;                       // the lane-serial kernel decides (and reports errors)
+        return;
+    }
+    uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
+    uint32_t* hashSmall = hashLong + (1u << cp.hlog);
+    uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
+    m.nbSeq = ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
+    m.mode = 4;
+#ifdef ZHIP_EMU
+    zd_stat[15]++;
+#endif
+    a.meta[i] = m;
+}
+
 // E2: everything after the search (entropy coding + frame assembly), one wave per frame
 ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
 {
@@ -1795,9 +1956,9 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         const ZeMeta m = a.meta[i];
         if (m.mode == 3) continue;                                         // listed for the generic kernel
         const uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
-        ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
+        ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = m.mode == 4 ? nullptr : fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
         uint64_t produced = 0;
-        const int err = ze_frame(a, L, f, ws, &produced, m.mode == 0 ? &pre : nullptr);   // modes 1/2 never reach the search inside
+        const int err = ze_frame(a, L, f, ws, &produced, (m.mode == 0 || m.mode == 4) ? &pre : nullptr);   // modes 1/2 never reach the search inside
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }

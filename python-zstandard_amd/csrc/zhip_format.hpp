@@ -96,13 +96,22 @@ struct ZhipEncodeArgs {
     // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
     uint32_t* bigList; uint32_t* bigCount;
     const uint32_t* frameList; const uint32_t* listCount;
+    // flat match kernel (one lane per frame, every frame of the chunk in flight): its tables, and the chunk-local indices it
+    // leaves to the lane-serial match kernel (strategies / sizes / dictionaries the flat form does not cover)
+    uint8_t* flatTables;            // count x tableStride, zeroed by the host before the launch
+    uint32_t* e1List; uint32_t* e1Count;
+    uint32_t useE1List;             // lane-serial match kernel: 1 = work is e1List[0 .. *e1Count), 0 = the whole chunk
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;
     const uint32_t* cdictHashLong;
     const uint32_t* cdictHashSmall;
 };
-struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched; 1: store raw (too small); 2: error in status
+struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched (sequences + literals); 1: store raw (too small); 2: error in status;
+                                                            // 3: multi-block, listed for the generic kernel; 4: searched, sequences only (flat kernel)
+#ifndef ZE_FLAT_LANES
+#define ZE_FLAT_LANES 64
+#endif
 #define ZE_ARENA_SEQ 0
 #define ZE_ARENA_LIT (8u * (ZE_SEQ_CAP + 8))
 #define ZE_ARENA_STRIDE ((size_t)ZE_ARENA_LIT + ZF_BLOCK_MAX + 256)

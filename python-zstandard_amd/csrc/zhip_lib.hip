@@ -55,6 +55,7 @@ ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs
     ze_kernel_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
 ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeLDS L;
@@ -195,7 +196,7 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-#define ZHIP_NTIMER 8
+#define ZHIP_NTIMER 9
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
     std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
@@ -210,7 +211,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
-    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs;
+    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
     int e1PerCU = 0, e2PerCU = 0;
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
     DevBuf scratch, counter;
@@ -279,7 +280,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -289,7 +290,7 @@ extern "C" const char* zhip_kernel_name(int k)
 {
     static const char* names[ZHIP_NTIMER] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
                                    "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
-                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel"};
+                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel"};
     return k >= 0 && k < ZHIP_NTIMER ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
@@ -621,9 +622,16 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
         const int level = a.level;
         a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));        // largest dfast tables for inputs <= 128 KiB
-        const size_t chunkMax = 32768;
+        // levels 3-4 without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
+        // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
+        // (levels <= 2) and dictionary batches use the lane-serial kernel for the whole chunk.
+        const bool flat = level >= 3 && !c->hasCDict && getenv("ZHIP_NO_FLAT") == nullptr;
+        size_t chunkMax = flat ? 65536 : 32768;
+        if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
+        if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64 && (size_t)v < chunkMax) chunkMax = (size_t)v; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
         size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * ZE_E1_LANES > 32768) g1max = 32768 / ZE_E1_LANES;
+        if (flat && g1max > 256) g1max = 256;                                      // only the frames the flat kernel declines
         const size_t w1 = (chunk + ZE_E1_LANES - 1) / ZE_E1_LANES;
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
@@ -631,27 +639,38 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const uint32_t gBig = (uint32_t)(n < 64 ? n : 64);                       // waves for inputs above one block (generic kernel)
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
             c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
-            c->encBigList.reserve(n * sizeof(uint32_t) + 16)) return ZHIP_ERR_HIP;
+            c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
+            (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return ZHIP_ERR_HIP;
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
+        a.flatTables = (uint8_t*)c->encFlatTables.p; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)((uint8_t*)c->counter.p + 32);
+        a.useE1List = flat ? 1u : 0u;
         a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)((uint8_t*)c->counter.p + 24);
         HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
             HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 8, stream));
-            hipEvent_t ev[3];
-            for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&ev[i]));
-            HIP_TRY(hipEventRecord(ev[0], stream));
-            hipLaunchKernelGGL(zhip_encode_match_kernel, dim3(g1), dim3(64), 0, stream, a);
-            HIP_TRY(hipEventRecord(ev[1], stream));
-            hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
+            HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 32, 0, 4, stream));
+            hipEvent_t ev[6];
+            for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
+            if (flat) {
+                HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
+                HIP_TRY(hipEventRecord(ev[0], stream));
+                hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
+                HIP_TRY(hipEventRecord(ev[1], stream));
+            }
             HIP_TRY(hipEventRecord(ev[2], stream));
+            hipLaunchKernelGGL(zhip_encode_match_kernel, dim3(g1), dim3(64), 0, stream, a);
+            HIP_TRY(hipEventRecord(ev[3], stream));
+            HIP_TRY(hipEventRecord(ev[4], stream));
+            hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
+            HIP_TRY(hipEventRecord(ev[5], stream));
             HIP_TRY(hipGetLastError());
-            c->timer[5].pending.emplace_back(ev[0], ev[1]);
-            hipEvent_t dup; HIP_TRY(hipEventCreate(&dup)); HIP_TRY(hipEventRecord(dup, stream));
-            c->timer[6].shared.emplace_back(ev[1], ev[2]);
-            c->timer[1].pending.emplace_back(ev[2], dup);      // owns ev[2]; measures ~0
+            if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
+            else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+            c->timer[5].pending.emplace_back(ev[2], ev[3]);
+            c->timer[6].pending.emplace_back(ev[4], ev[5]);
         }
         {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;

@@ -149,6 +149,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 // ---- two-kernel encoder under emulation
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
+static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
 extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
                                      uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks, uint32_t chunk)
 {
@@ -167,12 +168,20 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     uint32_t bigCount = 0; a.bigList = (uint32_t*)calloc(n ? n : 1, 4); a.bigCount = &bigCount;
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);
+    const bool flat = level >= 3 && !g_hasCD;                 // mirrors zhip_compress_batch_device
+    uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
+    a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
-        counters[0] = counters[1] = 0;
+        counters[0] = counters[1] = 0; e1Count = 0;
+        if (flat) {
+            memset(a.flatTables, 0, (size_t)a.count * a.tableStride);
+            zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
+        }
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);
     }
+    free(a.e1List); free(a.flatTables);
     if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
         ZhipEncodeArgs b = a; uint32_t bc = 0;
         b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;
@@ -183,3 +192,4 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     free(a.workspace); free(a.laneTables); free(a.meta); free(a.arena); free(a.bigList);
     return 0;
 }
+extern "C" long emu_stat(int i) { return i >= 0 && i < 16 ? zd_stat[i] : -1; }     // [15]: frames searched by the flat match kernel
