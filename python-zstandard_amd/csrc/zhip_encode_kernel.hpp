@@ -799,73 +799,123 @@ ZH_DEV uint32_t ze_hsx(uint64_t u, uint32_t shl, uint64_t prime, uint32_t sh) { 
 ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_t srcSize)     // ZSTD_count (zstd.c:20008): b < a, a + result <= srcSize
 {
     uint32_t len = 0;
-    while (a + len + 16 <= srcSize) {
+    while (a + len + 32 <= srcSize) {                                  // 32 bytes a round: most matches end inside the first
         ZE_STAT(12);
-        const zh_v16 x = zh_ld128(src + a + len), y = zh_ld128(src + b + len);
-        const uint64_t d0 = x.lo ^ y.lo, d1 = x.hi ^ y.hi;
+        const zh_v16 x0 = zh_ld128(src + a + len), y0 = zh_ld128(src + b + len), x1 = zh_ld128(src + a + len + 16), y1 = zh_ld128(src + b + len + 16);
+        const uint64_t d0 = x0.lo ^ y0.lo, d1 = x0.hi ^ y0.hi, d2 = x1.lo ^ y1.lo, d3 = x1.hi ^ y1.hi;
         if (d0) return len + (uint32_t)(zh_ctz64(d0) >> 3);
         if (d1) return len + 8 + (uint32_t)(zh_ctz64(d1) >> 3);
-        len += 16;
+        if (d2) return len + 16 + (uint32_t)(zh_ctz64(d2) >> 3);
+        if (d3) return len + 24 + (uint32_t)(zh_ctz64(d3) >> 3);
+        len += 32;
+    }
+    while (a + len + 8 <= srcSize) {
+        const uint64_t d = zh_ld64(src + a + len) ^ zh_ld64(src + b + len);
+        if (d) return len + (uint32_t)(zh_ctz64(d) >> 3);
+        len += 8;
     }
     while (a + len < srcSize && src[a + len] == src[b + len]) len++;
     return len;
 }
+// Cells of the flat kernel's tables: position + 2 in the low 18 bits (one block: <= 131 074), and in the 14 bits above a TAG of
+// the bytes the cell's owner hashed -- more bits of the same product for the long table (so equal 8 bytes give equal tags), a hash
+// of the first 4 bytes for the short table (the short check compares 4 bytes, zstd.c:31167). A candidate whose tag differs cannot
+// pass the reference's byte comparison, so its bytes are never fetched: the decisions are the reference's, most failed probes
+// cost no candidate read (libzstd does the same for dictionary tables, ZSTD_SHORT_CACHE_TAG_BITS zstd.c:20636).
+#define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
 ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
 {
     const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
     const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
     const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
     const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
+#define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))                       /* long table: high half of the product */
+#define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))                            /* short table */
+#define ZE_TL(ph) ((((ph) >> (shL - 14)) & 0x3FFFu) << 18)                               /* tag = the 14 product bits below the index */
+#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - 14)) & 0x3FFFu) << 18)       /* tag over the first 4 bytes only */
     const uint32_t ilimit = srcSize - 8;
     uint32_t ip = 1, anchor = 0, off1 = 1, off2 = 0, nseq = 0;        // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
-    uint32_t step = 1, nextStep = 0, hl0 = 0, idxl0 = 0; uint64_t cl0 = 0;
+    uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
     bool fresh = true;
+    // Every trip examines TWO consecutive probe positions, A = ip and B = ip + step, in the same three memory rounds: four probes in
+    // five fail, and after a failed probe the next one is fully determined (its position, its step, and -- through the forwarding
+    // selects below -- the table state it must see), so B is probed speculatively and simply dropped when A matches. A's table
+    // writes always happen; B's only when A failed. This is the reference's sequential order, two steps at a time.
     for (;;) {
         if (fresh) { step = 1; nextStep = ip + 256; }
-        const uint32_t ip1 = ip + step;
-        if (ip1 > ilimit) break;
+        const uint32_t ipA = ip, ipB = ip + step;
+        if (ipB > ilimit) break;
+        uint32_t stepB = step, nextB = nextStep;
+        if (ipB >= nextStep) { stepB++; nextB += 256; }                 // the step update a failed probe at A makes (zstd.c:31207)
+        const uint32_t ipC = ipB + stepB;
+        const bool hasB = ipC <= ilimit;                                // B is probed only if the search goes on after A
+        const uint32_t ipCs = hasB ? ipC : ipB;
         ZE_STAT(10);
-        const uint64_t w0 = zh_ld64(src + ip), w1 = zh_ld64(src + ip1);
-        const uint32_t hs0 = ze_hsx(w0, shlS, primeS, shS), hl1 = ze_hl8(w1, shL);
-        const uint32_t hlf = ze_hl8(w0, shL);
-        if (fresh) hl0 = hlf;
-        // round 1: the table cells (and the repeat-offset candidate), all in flight together. Every load is unconditional with an
-        // address that is always valid, so the compiler keeps them in one straight line behind a single wait.
-        const uint32_t tA = hashLong[fresh ? hl0 : hl1];
-        const uint32_t idxs0 = hashSmall[hs0];
-        uint32_t idxl1 = hashLong[hl1];
-        const uint32_t rp = zh_ld32(src + ip + 1 - off1);
-        if (fresh) idxl0 = tA;
-        const uint32_t curr = ip + 2;
-        if (hl1 == hl0) idxl1 = curr;                                   // the reference reads this cell after writing curr (zstd.c:31121, :31163)
-        hashLong[hl0] = curr; hashSmall[hs0] = curr;
-        // round 2: the candidates' bytes (an empty cell reads the probe position itself and is rejected by its index)
-        uint64_t xl0 = zh_ld64(src + ((fresh && idxl0 >= 2) ? idxl0 - 2 : ip));
-        uint32_t cs0 = zh_ld32(src + (idxs0 >= 2 ? idxs0 - 2 : ip));
-        uint64_t cl1 = zh_ld64(src + (idxl1 >= 2 ? idxl1 - 2 : ip1));
-        xl0 = zh_opaque64(xl0); cs0 = zh_opaque(cs0); cl1 = zh_opaque64(cl1);      // keep the three loads together (none sinks into a branch)
+        // round 0: the probes' own bytes
+        const uint64_t wA = zh_ld64(src + ipA), wB = zh_ld64(src + ipB), wC = zh_ld64(src + ipCs);
+        const uint32_t rpA = zh_ld32(src + ipA + 1 - off1), rpB = zh_ld32(src + ipB + 1 - off1);
+        const uint32_t pLA = ZE_PL(wA), pLB = ZE_PL(wB), pLC = ZE_PL(wC);
+        const uint32_t hlA = pLA >> shL, hlB = pLB >> shL, hlC = pLC >> shL, hsA = ZE_PS(wA) >> shS, hsB = ZE_PS(wB) >> shS;
+        // round 1: the table cells, all in flight together (every load unconditional with an always-valid address, so the compiler
+        // keeps them in one straight line behind a single wait). The long cell of A was read one trip earlier unless A is fresh.
+        const uint32_t tA = hashLong[fresh ? hlA : hlB];
+        const uint32_t cSA = hashSmall[hsA];
+        uint32_t cSB = hashSmall[hsB], cLB = hashLong[hlB], cLC = hashLong[hlC];
+        if (fresh) cellL0 = tA;
+        const uint32_t newLA = (ipA + 2) | ZE_TL(pLA), newSA = (ipA + 2) | ZE_TS(wA), newLB = (ipB + 2) | ZE_TL(pLB), newSB = (ipB + 2) | ZE_TS(wB);
+        // what the reference's later reads would see after its earlier writes of this trip (zstd.c:31121 then :31163, twice)
+        if (hlB == hlA) cLB = newLA;
+        if (hsB == hsA) cSB = newSA;
+        if (hlC == hlA) cLC = newLA;
+        if (hlC == hlB) cLC = newLB;
+        hashLong[hlA] = newLA; hashSmall[hsA] = newSA;
+        const uint32_t idxl0 = ZE_CELL_IDX(cellL0), idxsA = ZE_CELL_IDX(cSA), idxlB = ZE_CELL_IDX(cLB), idxsB = ZE_CELL_IDX(cSB), idxlC = ZE_CELL_IDX(cLC);
+        // plausible = the cell is in use and carries the probe's tag
+        if (fresh) pl0 = (idxl0 >= 2 && (cellL0 >> 18) == (ZE_TL(pLA) >> 18)) ? 1u : 0u;
+        const bool psA = idxsA >= 2 && (cSA >> 18) == (ZE_TS(wA) >> 18);
+        const uint32_t plB = (idxlB >= 2 && (cLB >> 18) == (ZE_TL(pLB) >> 18)) ? 1u : 0u;
+        const bool psB = idxsB >= 2 && (cSB >> 18) == (ZE_TS(wB) >> 18);
+        const uint32_t plC = (idxlC >= 2 && (cLC >> 18) == (ZE_TL(pLC) >> 18)) ? 1u : 0u;
+        // round 2: the bytes of the plausible candidates (the others read the probe position itself: a cache hit, and ignored)
+        uint64_t xl0 = zh_ld64(src + ((fresh && pl0) ? idxl0 - 2 : ipA));
+        uint32_t csA = zh_ld32(src + (psA ? idxsA - 2 : ipA));
+        uint64_t clB = zh_ld64(src + (plB ? idxlB - 2 : ipB));
+        uint32_t csB = zh_ld32(src + (psB ? idxsB - 2 : ipB));
+        uint64_t clC = zh_ld64(src + (plC ? idxlC - 2 : ipCs));
+        xl0 = zh_opaque64(xl0); csA = zh_opaque(csA); clB = zh_opaque64(clB); csB = zh_opaque(csB); clC = zh_opaque64(clC);   // no load sinks into a branch
         if (fresh) cl0 = xl0;
-        int found = 0; uint32_t ipm = ip, mpos = 0, ca = 0, cb = 0, add = 0;
-        if (off1 > 0 && rp == (uint32_t)(w0 >> 8)) { found = 1; ipm = ip + 1; ca = ip + 5; cb = ip + 5 - off1; add = 4; }
-        else if (idxl0 >= 2 && cl0 == w0) { found = 2; mpos = idxl0 - 2; ca = ip + 8; cb = mpos + 8; add = 8; }
-        else if (idxs0 >= 2 && cs0 == (uint32_t)w0) { found = 3; mpos = idxs0 - 2; ca = ip + 4; cb = mpos + 4; add = 4; }
+        const int foundA = (off1 > 0 && rpA == (uint32_t)(wA >> 8)) ? 1 : (pl0 && cl0 == wA) ? 2 : (psA && csA == (uint32_t)wA) ? 3 : 0;
+        const int foundB = !hasB ? 0 : (off1 > 0 && rpB == (uint32_t)(wB >> 8)) ? 1 : (plB && clB == wB) ? 2 : (psB && csB == (uint32_t)wB) ? 3 : 0;
+        const bool tookB = !foundA && hasB;                             // A failed and the search goes on: B is a real probe
+        if (tookB) { hashLong[hlB] = newLB; hashSmall[hsB] = newSB; }
+        const int found = foundA ? foundA : foundB;
         if (found) {
             ZE_STAT(11);
+            const bool atB = !foundA;
+            // the matching probe P, the position after it P1, and what was fetched for them
+            const uint32_t ipP = atB ? ipB : ipA, ipP1 = atB ? ipC : ipB, stepP = atB ? stepB : step;
+            const uint32_t idxlP = atB ? idxlB : idxl0, idxsP = atB ? idxsB : idxsA, idxl1 = atB ? idxlC : idxlB, pl1 = atB ? plC : plB;
+            const uint64_t w1 = atB ? wC : wB, cl1 = atB ? clC : clB;
+            const uint32_t hl1 = atB ? hlC : hlB, newL1 = atB ? ((ipC + 2) | ZE_TL(pLC)) : newLB;
+            uint32_t ipm = ipP, mpos = 0, ca, cb, add;
+            if (found == 1) { ipm = ipP + 1; ca = ipP + 5; cb = ipP + 5 - off1; add = 4; }
+            else if (found == 2) { mpos = idxlP - 2; ca = ipP + 8; cb = mpos + 8; add = 8; }
+            else { mpos = idxsP - 2; ca = ipP + 4; cb = mpos + 4; add = 4; }
             uint32_t mLength = ze_count_fwd(src, ca, cb, srcSize) + add;
-            if (found == 3 && idxl1 > 2 && cl1 == w1) {                 // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
+            if (found == 3 && pl1 && idxl1 > 2 && cl1 == w1) {          // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
                 const uint32_t m1 = idxl1 - 2;
-                const uint32_t l1 = ze_count_fwd(src, ip1 + 8, m1 + 8, srcSize) + 8;
-                if (l1 > mLength) { ipm = ip1; mLength = l1; mpos = m1; }
+                const uint32_t l1 = ze_count_fwd(src, ipP1 + 8, m1 + 8, srcSize) + 8;
+                if (l1 > mLength) { ipm = ipP1; mLength = l1; mpos = m1; }
             }
             uint32_t offBase = 1;
             if (found >= 2) {
                 const uint32_t offset = ipm - mpos;
-                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204)
+                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204), 8 bytes a round
                     ZE_STAT(13);
-                    if (mpos >= 8 && ipm - anchor >= 8) {
+                    const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
+                    if (mpos >= 8) {                                    // both 8-byte reads stay inside the frame; bytes beyond `room` are ignored
                         const uint64_t d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8);
                         uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
-                        const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
                         if (k > room) k = room;
                         ipm -= k; mpos -= k; mLength += k;
                         if (k < 8) break;
@@ -875,36 +925,47 @@ ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSi
                     }
                 }
                 off2 = off1; off1 = offset;
-                if (step < 4) hashLong[hl1] = ip1 + 2;
+                if (stepP < 4) hashLong[hl1] = newL1;
                 offBase = offset + 3;
             }
             seqs[nseq++] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
-            const uint32_t pI = ip + 2;                                 // curr + 2 as a position
+            const uint32_t pI = ipP + 2;                                // curr + 2 as a position
             ip = ipm + mLength; anchor = ip;
             if (ip <= ilimit) {
+                // one round for the insertions' bytes and the first repeat-offset test
                 const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
-                hashLong[ze_hl8(wI, shL)] = pI + 2;
-                hashLong[ze_hl8(wE2, shL)] = ip;
-                hashSmall[ze_hsx(wI, shlS, primeS, shS)] = pI + 2;
-                hashSmall[ze_hsx(wE1, shlS, primeS, shS)] = ip + 1;
-                while (ip <= ilimit && off2 > 0) {                      // immediate repeat-offset matches (zstd.c:31236-31250)
-                    const uint64_t wr = zh_ld64(src + ip);
+                uint64_t wr = zh_ld64(src + ip); uint32_t r2 = zh_ld32(src + ip - off2);
+                const uint32_t qI = ZE_PL(wI), qE = ZE_PL(wE2);
+                hashLong[qI >> shL] = (pI + 2) | ZE_TL(qI);
+                hashLong[qE >> shL] = ip | ZE_TL(qE);
+                hashSmall[ZE_PS(wI) >> shS] = (pI + 2) | ZE_TS(wI);
+                hashSmall[ZE_PS(wE1) >> shS] = (ip + 1) | ZE_TS(wE1);
+                while (off2 > 0 && (uint32_t)wr == r2) {                // immediate repeat-offset matches (zstd.c:31236-31250)
                     ZE_STAT(14);
-                    if ((uint32_t)wr != zh_ld32(src + ip - off2)) break;
                     const uint32_t r = ze_count_fwd(src, ip + 4, ip + 4 - off2, srcSize) + 4;
                     const uint32_t t = off2; off2 = off1; off1 = t;
-                    hashSmall[ze_hsx(wr, shlS, primeS, shS)] = ip + 2;
-                    hashLong[ze_hl8(wr, shL)] = ip + 2;
+                    const uint32_t qr = ZE_PL(wr);
+                    hashSmall[ZE_PS(wr) >> shS] = (ip + 2) | ZE_TS(wr);
+                    hashLong[qr >> shL] = (ip + 2) | ZE_TL(qr);
                     seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
                     ip += r; anchor = ip;
+                    if (ip > ilimit) break;
+                    wr = zh_ld64(src + ip); r2 = zh_ld32(src + ip - off2);
                 }
             }
             fresh = true;
-        } else {
-            if (ip1 >= nextStep) { step++; nextStep += 256; }
-            ip = ip1; hl0 = hl1; idxl0 = idxl1; cl0 = cl1; fresh = false;
+        } else if (!hasB) {                                             // A failed and the search ends at the next bound check
+            step = stepB; nextStep = nextB; ip = ipB; cellL0 = cLB; pl0 = plB; cl0 = clB; fresh = false;
+        } else {                                                        // A and B failed: go on from C
+            step = stepB; nextStep = nextB;
+            if (ipC >= nextStep) { step++; nextStep += 256; }
+            ip = ipC; cellL0 = cLC; pl0 = plC; cl0 = clC; fresh = false;
         }
     }
+#undef ZE_PL
+#undef ZE_PS
+#undef ZE_TL
+#undef ZE_TS
     return nseq;
 }
 
@@ -1235,14 +1296,16 @@ ZH_DEV uint32_t ze_ml_code(uint32_t ml) { const uint32_t b = ml - 3; return b > 
 ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq)
 {
     const uint32_t lane = zh_lane();
-    uint32_t* const tt = ze_scratch(L);          // [table][symbol] -> deltaNbBits, deltaFindState (FSE_symbolCompressionTransform)
-    uint32_t* const cpack = tt + 384;            // the round's codes: ll | of << 8 | ml << 16
-    uint32_t* const rec = cpack + 64;            // [table][slot]: state bits | nbBits << 16
+    uint32_t* const tt = ze_scratch(L);          // per symbol: deltaNbBits, deltaFindState (FSE_symbolCompressionTransform); LL at 0, OF at 36, ML at 68
+    uint32_t* const pre = tt + 2 * 121;          // [table][slot] -> the slot's sequence's two constants (3 x 64 x 2)
+    uint32_t* const rec = pre + 384;             // [table][slot]: state | nbBits << 16
     uint32_t* const bitbuf = rec + 192;          // 196 dwords
+    static_assert((2 * 121 + 384 + 192 + 196) * 4 <= sizeof(L.node), "sequence encoder scratch must fit the tree-node area");
     zh_sync();
     for (uint32_t k = lane; k < 192; k += 64) {
         const uint32_t t = k >> 6, sy = k & 63;
         const ZeCTab& T = L.tab[t];
+        const uint32_t size = t == 0 ? 36u : t == 1 ? 32u : 53u, base = t == 0 ? 0u : t == 1 ? 36u : 68u;
         uint32_t dnb = 0, dfs = 0;
         if (T.log != 0 && sy <= T.maxSym && T.norm[sy] != 0) {
             const uint32_t c = T.norm[sy] == -1 ? 1u : (uint32_t)T.norm[sy];
@@ -1250,7 +1313,7 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
             dnb = (mb << 16) - (c << mb);
             dfs = (uint32_t)T.cellOf[sy] - c;
         }
-        tt[2 * k] = dnb; tt[2 * k + 1] = dfs;
+        if (sy < size) { tt[2 * (base + sy)] = dnb; tt[2 * (base + sy) + 1] = dfs; }
     }
     for (uint32_t k = lane; k < 196; k += 64) bitbuf[k] = 0;
     zh_sync();
@@ -1263,28 +1326,35 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
         const uint32_t ll = ZE_SEQ_LL(q), ml = ZE_SEQ_ML(q), ob = ZE_SEQ_OFF(q);
         uint32_t lc = 0, oc = 0, mc = 0;
         if (valid) { lc = ze_ll_code(ll); oc = (uint32_t)zh_highbit32(ob); mc = ze_ml_code(ml); }
-        cpack[lane] = lc | (oc << 8) | (mc << 16);
+        // every lane looks up its own sequence's transition constants for the three tables, so the chain lanes below only do the
+        // state-dependent part: two adds, two shifts, one table read per step
+        {   const uint32_t* eL = tt + 2 * lc; const uint32_t* eO = tt + 2 * (36 + oc); const uint32_t* eM = tt + 2 * (68 + mc);
+            pre[2 * lane] = eL[0]; pre[2 * lane + 1] = eL[1];
+            pre[128 + 2 * lane] = eO[0]; pre[128 + 2 * lane + 1] = eO[1];
+            pre[256 + 2 * lane] = eM[0]; pre[256 + 2 * lane + 1] = eM[1]; }
         zh_sync();
         if (zh_opaque(lane) < 3) {
             const uint32_t t = lane;
             const ZeCTab& T = L.tab[t];
             const uint32_t cnt = hi < 63 ? hi + 1 : 64;
-            const bool rle = T.log == 0;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t sy = (cpack[j] >> (8 * t)) & 255;
-                const uint32_t dnb = tt[2 * (64 * t + sy)], dfs = tt[2 * (64 * t + sy) + 1];
-                uint32_t r = 0;
-                if (rle) v = 0;
-                else if (hi == nbSeq - 1 && j == 0) {                     // FSE_initCState2, zstd.c:2774
+            const uint32_t* pt = pre + 128 * t;
+            uint32_t* rt = rec + 64 * t;
+            if (T.log == 0) { for (uint32_t j = 0; j < cnt; j++) rt[j] = 0; v = 0; }
+            else {
+                uint32_t j = 0;
+                if (hi == nbSeq - 1) {                                      // FSE_initCState2, zstd.c:2774
+                    const uint32_t dnb = pt[0], dfs = pt[1];
                     const uint32_t nbOut = (dnb + (1u << 15)) >> 16;
                     const uint32_t value = (nbOut << 16) - dnb;
                     v = T.next[(value >> nbOut) + dfs];
-                } else {
+                    rt[0] = 0; j = 1;
+                }
+                for (; j < cnt; j++) {
+                    const uint32_t dnb = pt[2 * j], dfs = pt[2 * j + 1];
                     const uint32_t nb = (v + dnb) >> 16;
-                    r = (v & ((1u << nb) - 1)) | (nb << 16);
+                    rt[j] = v | (nb << 16);                                 // the state before the transition; its low nb bits go to the stream
                     v = T.next[(v >> nb) + dfs];
                 }
-                rec[64 * t + j] = r;
             }
         }
         zh_sync();
@@ -1293,7 +1363,7 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
                                 else up |= v_ << (pos - 64); pos += n_; } } while (0)
         if (valid) {
             const uint32_t rL = rec[lane], rO = rec[64 + lane], rM = rec[128 + lane];
-            ZE_ADD(rO & 0xFFFFu, rO >> 16); ZE_ADD(rM & 0xFFFFu, rM >> 16); ZE_ADD(rL & 0xFFFFu, rL >> 16);
+            ZE_ADD(rO & ((1u << (rO >> 16)) - 1), rO >> 16); ZE_ADD(rM & ((1u << (rM >> 16)) - 1), rM >> 16); ZE_ADD(rL & ((1u << (rL >> 16)) - 1), rL >> 16);
             const uint32_t lb = ze_llBits[lc], mb = ze_mlBits[mc];
             ZE_ADD(ll & ((1u << lb) - 1), lb); ZE_ADD((ml - 3) & ((1u << mb) - 1), mb); ZE_ADD(ob & ((1u << oc) - 1), oc);
         }
