@@ -64,58 +64,38 @@ def compress_on_host(ref, raw_np, nthreads):
     return outs
 
 
-def cpu_decompress_baseline(ref, frames, nthreads, budget_s=8.0):
-    """reference ZSTD_decompressStream on a bounded sample, one DCtx per thread (decompress_worker's loop)."""
+def _mtbench():
+    """oracle/libzo_mtbench.so: native pthread driver for the CPU baseline (Python threads would mostly measure the interpreter lock)"""
+    path = os.path.join(ROOT, "oracle", "libzo_mtbench.so")
+    lib = C.CDLL(path)
+    lib.zo_mt_bench.restype = C.c_double
+    lib.zo_mt_bench.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    return lib
+
+
+def cpu_decompress_baseline(ref, frames, nthreads, passes=12):
+    """reference ZSTD_decompressStream on a bounded sample: native threads, one DCtx each, static contiguous partition
+    (decompress_worker's loop, c-ext/decompressor.c:1237-1320). Returns (GB/s of uncompressed bytes, passes)."""
+    from tests import reflib
     F = len(frames)
     blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
-    offs = np.zeros(F + 1, dtype=np.int64)
+    offs = np.zeros(F + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(f) for f in frames])
-    base = blob.ctypes.data
-
-    def work(lo, hi):
-        dctx = ref.lib.ZSTD_createDCtx()
-        dst = C.create_string_buffer(FRAME)
-        for i in range(lo, hi):
-            ref.decompress_into(dctx, C.addressof(dst), FRAME, base + int(offs[i]), int(offs[i + 1] - offs[i]))
-        ref.lib.ZSTD_freeDCtx(dctx)
-
-    step = (F + nthreads - 1) // nthreads
-    best, reps, t_start = None, 0, time.time()
-    while reps < 3 or (time.time() - t_start < budget_s and reps < 50):
-        ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
-        t0 = time.time()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        dt = time.time() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
-        if time.time() - t_start > budget_s:
-            break
-    return F * FRAME / best / 1e9, reps
+    best = _mtbench().zo_mt_bench(reflib.REF_SO.encode(), 1, blob.ctypes.data, offs.ctypes.data, F, FRAME, 3, nthreads, passes)
+    assert best > 0, "native CPU baseline failed (%r)" % best
+    return F * FRAME / best / 1e9, passes
 
 
-def cpu_compress_baseline(ref, raw_np, nthreads, budget_s=10.0):
-    """reference ZSTD_compressStream2(e_end) at level 3 on a bounded sample, one CCtx per thread (compress_worker's loop)."""
+def cpu_compress_baseline(ref, raw_np, nthreads, passes=6):
+    """reference ZSTD_compressStream2(e_end) at level 3 on a bounded sample: native threads, one CCtx each (compress_worker's loop,
+    c-ext/compressor.c:1127-1216). Returns (GB/s of uncompressed bytes, passes)."""
+    from tests import reflib
     F = raw_np.shape[0]
-    bound = ref.lib.ZSTD_compressBound(FRAME)
-    base = raw_np.ctypes.data
-
-    def work(lo, hi):
-        buf = C.create_string_buffer(bound)
-        for i in range(lo, hi):
-            ref.compress_into(C.addressof(buf), bound, base + i * FRAME, FRAME)
-
-    step = (F + nthreads - 1) // nthreads
-    best, reps, t_start = None, 0, time.time()
-    while reps < 2 or (time.time() - t_start < budget_s and reps < 20):
-        ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
-        t0 = time.time()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        dt = time.time() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
-    return F * FRAME / best / 1e9, reps
+    raw_np = np.ascontiguousarray(raw_np)
+    offs = (np.arange(F + 1, dtype=np.uint64) * np.uint64(FRAME))
+    best = _mtbench().zo_mt_bench(reflib.REF_SO.encode(), 0, raw_np.ctypes.data, offs.ctypes.data, F, 0, 3, nthreads, passes)
+    assert best > 0, "native CPU baseline failed (%r)" % best
+    return F * FRAME / best / 1e9, passes
 
 
 def measure_compress(ctx, raw, frames, rank, world, dev, F, steps, warmup):
@@ -193,7 +173,7 @@ def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world,
             v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads)
             line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
                                     "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 over the first %d inputs of the same "
-                                              "workload, %d threads (host has %d cores), best of %d passes"
+                                              "workload, %d native threads (host has %d cores), best of %d passes"
                                               % (sample, nthreads, os.cpu_count() or 0, reps)}
         print(json.dumps(line))
     if world > 1:
@@ -329,7 +309,7 @@ def main():
             v, reps = cpu_decompress_baseline(ref, frames[:sample], nthreads)
             line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
                                     "sample": "libzstd 1.5.7 ZSTD_decompressStream over the first %d frames of the same "
-                                              "workload, %d threads (host has %d cores), best of %d passes"
+                                              "workload, %d native threads (host has %d cores), best of %d passes"
                                               % (sample, nthreads, os.cpu_count() or 0, reps)}
         line["setup_s"] = {"generate": round(t_gen, 1), "host_compress": round(t_comp, 1)}
     if args.compress_frames > 0:
@@ -343,7 +323,7 @@ def main():
                                 "kernels": {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in c_k.items() if v[1]}}
             if world == 1 and not args.no_cpu_baseline:
                 sample = min(Fc, 4096)
-                v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads, budget_s=6.0)
+                v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads)
                 line["compress"]["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
                                                     "sample": "libzstd 1.5.7 level 3, first %d inputs, %d threads, best of %d" % (sample, nthreads, reps)}
     if rank == 0:

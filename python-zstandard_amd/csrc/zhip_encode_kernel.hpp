@@ -39,16 +39,17 @@ struct ZeNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; }
 
 struct ZeLDS {
     uint32_t hist[256];
-    ZeNode node[2 * 256 + 2];
+    ZeNode node[2 * 256 + 2];   // Huffman tree nodes; once the code lengths are final the area is scratch (ze_scratch, ze_cell_sym, ze_weights)
     uint8_t hufBits[256];
     uint16_t hufCode[256];
     ZeCTab tab[3];              // LL, OF, ML
     uint32_t cnt[3][64];        // code histograms
-    uint8_t cellSym[512];
-    uint8_t weights[256];
     uint32_t misc[16];
     uint32_t stack[64];
-    // state that survives a block of a multi-block frame (advanced only when the block is emitted compressed, zstd.c:27391)
+};
+// state that survives a block of a multi-block frame (advanced only when the block is emitted compressed, zstd.c:27391); only the
+// generic one-wave-per-frame kernel has it
+struct ZeLDSMulti {
     uint32_t mrep[2];
     uint32_t prevRepeat, prevMaxSym;    // previous block's Huffman table: 0 none, 1 usable after validation
     uint8_t prevBits[256];
@@ -57,6 +58,11 @@ struct ZeLDS {
 struct ZePrevHuf { const uint8_t* bits; const uint16_t* code; uint32_t maxSym, repeat; };   // a candidate table for the literals (dictionary or previous block)
 
 struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
+// scratch inside the tree-node area, valid while no tree is being built and disjoint from what ze_scratch users touch at the same time:
+// the FSE table builder's symbol spread (512 B at +3072) and the Huffman weights (256 B at +3584)
+ZH_DEV uint8_t* ze_cell_sym(ZeLDS& L) { return (uint8_t*)L.node + 3072; }
+ZH_DEV uint8_t* ze_weights(ZeLDS& L) { return (uint8_t*)L.node + 3584; }
+static_assert(sizeof(ZeNode) * (2 * 256 + 2) >= 3584 + 256, "node area too small for its scratch uses");
 
 // ------------------------------------------------------------------------------------------ LSB-first bit writer (one lane)
 struct ZeBits { uint8_t* p; uint32_t cap; uint64_t acc; uint32_t n; uint32_t pos; };
@@ -398,7 +404,7 @@ ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t*
     if (ze_fse_normalize(norm, lg, count, n, maxSym, 0) < 0) return 0;
     const uint32_t h = ze_fse_write_ncount(out, norm, maxSym, lg);
     ZeCTab& t = L.tab[0];
-    ze_fse_build_ctab(t, L.cellSym, norm, maxSym, lg);
+    ze_fse_build_ctab(t, ze_cell_sym(L), norm, maxSym, lg);
     if (n <= 2) return 0;
     ZeBits b; ze_bw_init(b, out + h, 512);
     uint32_t ip = n, s1, s2;
@@ -416,7 +422,7 @@ ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t*
 // HUF_writeCTable_wksp (zstd.c:17005). 0 = cannot be described.
 ZH_DEVFN uint32_t ze_huf_write_table(ZeLDS& L, uint8_t* out, uint32_t maxSym, uint32_t lg)
 {
-    uint8_t* w = L.weights;
+    uint8_t* w = ze_weights(L);
     for (uint32_t n = 0; n < maxSym; n++) w[n] = L.hufBits[n] ? (uint8_t)(lg + 1 - L.hufBits[n]) : (uint8_t)0;
     const uint32_t h = ze_huf_compress_weights(L, out + 1, w, maxSym);
     if (h > 1 && h < maxSym / 2) { out[0] = (uint8_t)h; return h + 1; }
@@ -1266,14 +1272,14 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
         return 0;
     }
     if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
-    if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, L.cellSym, nrm, defMax, defLog); return 0; }
+    if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, ze_cell_sym(L), nrm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
     uint32_t n1 = nbSeq;
     if (count[lastCode] > 1) { count[lastCode]--; n1--; }
     int16_t norm[53];
     ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
     const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
-    ze_fse_build_ctab(t, L.cellSym, norm, max, lg);
+    ze_fse_build_ctab(t, ze_cell_sym(L), norm, max, lg);
     return h;
 }
 // ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755): small values by table, the rest by their highest bit
@@ -1454,7 +1460,7 @@ ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src
 // mb == null: the block is the whole frame. mb != null: one block of a multi-block frame -- the hash tables, the two repcodes
 // (L.mrep) and the previous block's Huffman table (L.prev*) carry over and advance only when the block is emitted compressed.
 struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
-struct ZeMulti { const uint8_t* frame; bool firstBlock; };
+struct ZeMulti { const uint8_t* frame; bool firstBlock; ZeLDSMulti* st; };
 
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
                                     const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr)
@@ -1484,7 +1490,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     if (zh_opaque(lane) == 0) {
         uint32_t ls = 0;
         uint32_t nrep[2] = {1, 4};
-        if (mb) { nrep[0] = L.mrep[0]; nrep[1] = L.mrep[1]; }
+        if (mb) { nrep[0] = mb->st->mrep[0]; nrep[1] = mb->st->mrep[1]; }
         const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
                                                 : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
                           : cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
@@ -1502,7 +1508,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     const uint32_t nextRep0 = mb ? zh_first(L.misc[5]) : 0, nextRep1 = mb ? zh_first(L.misc[6]) : 0;
     ZePrevHuf ph; const ZePrevHuf* php = nullptr;
     if (cd && cd->hufRepeat) { ph.bits = cd->hufBits; ph.code = cd->hufCode; ph.maxSym = cd->hufMaxSym; ph.repeat = cd->hufRepeat; php = &ph; }
-    else if (mb && L.prevRepeat) { ph.bits = L.prevBits; ph.code = L.prevCode; ph.maxSym = L.prevMaxSym; ph.repeat = L.prevRepeat; php = &ph; }
+    else if (mb && mb->st->prevRepeat) { ph.bits = mb->st->prevBits; ph.code = mb->st->prevCode; ph.maxSym = mb->st->prevMaxSym; ph.repeat = mb->st->prevRepeat; php = &ph; }
     if (cp.strat == 1 && cp.tlen > 0) {          // negative levels keep literals raw (ZSTD_literalsCompressionIsDisabled, zstd.c:24208)
         zh_sync();
         if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lits, litSize, 0u, false);
@@ -1563,10 +1569,10 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         }
         zh_sync();
         if (r > 1) {                               // confirm: repcodes, and the Huffman table if this block carried a new one
-            if (zh_opaque(lane) == 0) { L.mrep[0] = nextRep0; L.mrep[1] = nextRep1; }
+            if (zh_opaque(lane) == 0) { mb->st->mrep[0] = nextRep0; mb->st->mrep[1] = nextRep1; }
             if (newMaxSym != 0xFFFFFFFFu) {
-                for (uint32_t i = lane; i < 256; i += 64) { L.prevBits[i] = L.hufBits[i]; L.prevCode[i] = L.hufCode[i]; }
-                if (zh_opaque(lane) == 0) { L.prevRepeat = 1; L.prevMaxSym = newMaxSym; }
+                for (uint32_t i = lane; i < 256; i += 64) { mb->st->prevBits[i] = L.hufBits[i]; mb->st->prevCode[i] = L.hufCode[i]; }
+                if (zh_opaque(lane) == 0) { mb->st->prevRepeat = 1; mb->st->prevMaxSym = newMaxSym; }
             }
         }
         ze_fence();
@@ -1645,7 +1651,7 @@ ZH_DEVFN uint32_t ze_split_block(ZeLDS& L, const uint8_t* p, int strat)
 }
 
 // A frame of several blocks (ZSTD_compress_frameChunk, zstd.c:27545): sources above 128 KiB. All lanes call.
-ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced)
+ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, uint32_t f, uint8_t* ws, uint64_t* produced)
 {
     const uint32_t lane = zh_lane();
     *produced = 0;
@@ -1673,12 +1679,12 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8
         else if (fcsCode == 1) { zh_st16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
         else { zh_st32(dst + pos, srcSize); pos += 4; }
         L.misc[4] = pos;
-        L.mrep[0] = 1; L.mrep[1] = 4; L.prevRepeat = 0; L.prevMaxSym = 0;
+        ms->mrep[0] = 1; ms->mrep[1] = 4; ms->prevRepeat = 0; ms->prevMaxSym = 0;
     }
     zh_sync();
     pos = zh_first(L.misc[4]);
     zh_sync();
-    ZeMulti mb; mb.frame = src; mb.firstBlock = true;
+    ZeMulti mb; mb.frame = src; mb.firstBlock = true; mb.st = ms;
     uint32_t ip = 0; int32_t savings = 0;
     while (ip < srcSize) {
         const uint32_t remaining = srcSize - ip;
@@ -1711,7 +1717,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8
 }
 
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
-ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre)
+ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre, ZeLDSMulti* ms = nullptr)
 {
     const uint32_t lane = zh_lane();
     *produced = 0;
@@ -1719,7 +1725,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
     uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
-    if (srcSize64 > ZF_BLOCK_MAX) return pre ? ZE_PARAM_UNSUPPORTED : ze_frame_multi(a, L, f, ws, produced);   // multi-block frames: generic kernel only
+    if (srcSize64 > ZF_BLOCK_MAX) return (pre || !ms) ? ZE_PARAM_UNSUPPORTED : ze_frame_multi(a, L, ms, f, ws, produced);   // multi-block frames: generic kernel only
     const uint32_t srcSize = (uint32_t)srcSize64;
     const uint32_t bound = srcSize + (srcSize >> 8) + (srcSize < (128u << 10) ? (((128u << 10) - srcSize) >> 11) : 0);
     if (cap64 < bound) return ZE_DST_TOO_SMALL;
@@ -1854,14 +1860,14 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
                 cd->hufRepeat = (!zero && cnt == 256) ? 2u : 1u;
                 int16_t norm[64];
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->ofMax && s < 32 ? de->ofNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[1], L.cellSym, norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
+                ze_fse_build_ctab(cd->tab[1], ze_cell_sym(L), norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
                 {   const uint32_t need = (uint32_t)zh_highbit32(cs + 128u * 1024);
                     cd->ofRepeat = ze_ncount_repeat(norm, de->ofMax, need < ZF_MAXOFF ? need : ZF_MAXOFF); }
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->mlMax && s < 53 ? de->mlNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[2], L.cellSym, norm, de->mlMax, de->mlLog);
+                ze_fse_build_ctab(cd->tab[2], ze_cell_sym(L), norm, de->mlMax, de->mlLog);
                 cd->mlRepeat = ze_ncount_repeat(norm, de->mlMax, ZF_MAXML);
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->llMax && s < 36 ? de->llNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[0], L.cellSym, norm, de->llMax, de->llLog);
+                ze_fse_build_ctab(cd->tab[0], ze_cell_sym(L), norm, de->llMax, de->llLog);
                 cd->llRepeat = ze_ncount_repeat(norm, de->llMax, ZF_MAXLL);
                 for (int i = 0; i < 3; i++) cd->rep[i] = de->rep[i];
             }
@@ -1913,7 +1919,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     }
 }
 
-ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
+ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti& M)
 {
     const uint32_t lane = zh_lane();
     uint8_t* ws = a.workspace + (size_t)zh_block() * ZHIP_ENC_STRIDE;
@@ -1927,7 +1933,7 @@ ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L)
         if (k >= total) break;
         const uint32_t f = a.frameList ? a.frameList[k] : k;
         uint64_t produced = 0;
-        const int err = ze_frame(a, L, f, ws, &produced, nullptr);
+        const int err = ze_frame(a, L, f, ws, &produced, nullptr, &M);
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }

@@ -52,11 +52,15 @@ ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(Zhi
 ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeLDS L;
-    ze_kernel_body(a, L);
+    __shared__ ZeLDSMulti M;
+    ze_kernel_body(a, L, M);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
-ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
+#ifndef ZE_E2_MINWAVES
+#define ZE_E2_MINWAVES 4
+#endif
+ZH_GLOBAL __launch_bounds__(64, ZE_E2_MINWAVES) void zhip_encode_entropy_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeLDS L;
     ze_entropy_body(a, L);

@@ -76,7 +76,8 @@ static void attach_cdict(ZhipEncodeArgs& a)
     a.cdictHashLong = g_cdTables.data(); a.cdictHashSmall = g_cdTables.data() + ((size_t)1 << ZE_CDICT_MAX_HLOG);
 }
 struct EncLaunch { const ZhipEncodeArgs* a; };
-static void enc_lane(void* p) { ze_kernel_body(*((EncLaunch*)p)->a, g_elds); }
+static ZeLDSMulti g_eldsm;
+static void enc_lane(void* p) { ze_kernel_body(*((EncLaunch*)p)->a, g_elds, g_eldsm); }
 extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
                                   uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks)
 {

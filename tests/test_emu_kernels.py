@@ -136,3 +136,46 @@ def test_emulated_multiblock_encode_matches_golden(emu):
         for n, o in zip(names, outs):
             want = GOLD["multiblock_compress"]["frames"][n]["%d/default" % lvl]
             assert len(o) == want["size"] and hashlib.sha256(o).hexdigest() == want["sha256"], (n, lvl)
+
+
+def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
+    """two-kernel form at level 3: the flat double-fast kernel (one lane per frame, tagged cells, two probes per trip, sequences
+    only) + the wave-parallel entropy kernel (literals gathered from the sequence list, 16-lane Huffman streams, 3-lane tANS
+    chains) against the oracle on inputs that reach every branch: long literal runs (> 63), long matches (> 130), far and
+    repeated offsets, matches that run into the end of the input, incompressible and single-byte inputs, tiny inputs that the
+    flat kernel hands to the lane-serial kernel (< 64 bytes), full 128 KiB blocks"""
+    import ctypes
+    import numpy as np
+    rng = np.random.default_rng(77)
+    raws = []
+    for i in range(36):
+        kind = i % 9
+        n = int(rng.integers(64, 131073)) if i % 4 else int(rng.integers(1, 4000))
+        if kind == 0: r = corpus.frame_bytes(int(rng.integers(0, 500)))[:n]
+        elif kind == 1: r = rng.bytes(n)
+        elif kind == 2: r = bytes(rng.integers(0, 3, n, dtype=np.uint8))
+        elif kind == 3: r = (b"abcdefgh" * (n // 8 + 1))[:n]
+        elif kind == 4: r = (rng.bytes(700) * (n // 700 + 1))[:n]
+        elif kind == 5:
+            a = bytearray(corpus.frame_bytes(int(rng.integers(0, 500)))[:n])
+            for k in range(0, len(a), 997): a[k] = int(rng.integers(0, 256))
+            r = bytes(a)
+        elif kind == 6: r = b"\0" * n
+        elif kind == 7:
+            parts, tot = [], 0
+            while tot < n:
+                m = int(rng.integers(1, 5000))
+                parts.append(rng.bytes(m) if rng.integers(0, 2) else bytes([int(rng.integers(0, 256))]) * m); tot += m
+            r = b"".join(parts)[:n]
+        else:
+            blk = rng.bytes(300); r = (blk + rng.bytes(40000) + blk * 3 + rng.bytes(50000) + blk)[:n]   # offsets beyond 64 KiB
+        raws.append(r)
+    raws += [corpus.frame_bytes(7), b"x" * 63, b"y" * 64, b"hello " * 11]
+    emu.lib.emu_stat.restype = ctypes.c_long
+    before = emu.lib.emu_stat(15)
+    for flags in (5, 7):
+        outs, st = emu.compress_batch(raws, level=3, flags=flags, n_blocks=3, pipeline=True, chunk=17)
+        assert not any(st)
+        for i, (r, o) in enumerate(zip(raws, outs)):
+            assert o == oracle.compress(r, level=3, flags=flags), (flags, i, len(r))
+    assert emu.lib.emu_stat(15) - before >= 2 * 30, "the flat match kernel did not take these frames"
