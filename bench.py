@@ -165,8 +165,16 @@ def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world,
         algo_bytes = (F * FRAME + ctotal) // launches_per_step
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line["kernels"] = {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
+        traffic = None
+        try:                                                         # PMC passes are separate runs (profiles/README.md); scaled per launch
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            per_frame = tj["bytes_per_frame"].get(ctx.kernel_name(kdom))
+            if per_frame:
+                traffic = int(per_frame * F / launches_per_step)
+        except (OSError, ValueError, KeyError):
+            pass
         line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                             "kernel_ms": round(kernel_ms, 3), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes)}
         if world == 1 and not args.no_cpu_baseline:
             sample = min(F, 4096)
@@ -187,7 +195,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (BASELINE config: 65536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--compress-frames", type=int, default=16384,
+    ap.add_argument("--compress-frames", type=int, default=65536,
                     help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default="decompress",
                     help="decompress is the BASELINE.json headline; compress times multi_compress_to_buffer on the same inputs")
