@@ -67,6 +67,9 @@ def compress_on_host(ref, raw_np, nthreads):
 def _mtbench():
     """oracle/libzo_mtbench.so: native pthread driver for the CPU baseline (Python threads would mostly measure the interpreter lock)"""
     path = os.path.join(ROOT, "oracle", "libzo_mtbench.so")
+    if not os.path.exists(path):                                    # normally built by __graft_entry__.build(); gcc is in the image
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libzo_mtbench.so"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(path)
     lib.zo_mt_bench.restype = C.c_double
     lib.zo_mt_bench.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_int]

@@ -569,10 +569,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, stream));
     if (watchdog && !debug) {
-        for (int it = 0; it < 100; it++) {
+        for (int it = 0; it < 5000; it++) {                  // 1 ms polls: the aid must not quantise what a caller times
             if (hipStreamQuery(stream) == hipSuccess) break;
-            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
-            if (it == 99) { fprintf(stderr, "[zhip] WATCHDOG: kernel did not finish in 5 s; aborting process\n"); abort(); }
+            struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
+            if (it == 4999) { fprintf(stderr, "[zhip] WATCHDOG: kernel did not finish in 5 s; aborting process\n"); abort(); }
         }
     }
     if (debug) {
@@ -685,10 +685,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             HIP_TRY(hipGetLastError());
         }
         if (getenv("ZHIP_WATCHDOG")) {
-            for (int it = 0; it < 2400; it++) {
+            for (int it = 0; it < 120000; it++) {
                 if (hipStreamQuery(stream) == hipSuccess) break;
-                struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
-                if (it == 2399) { fprintf(stderr, "[zhip] WATCHDOG: encode kernels did not finish in 120 s; aborting process\n"); abort(); }
+                struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
+                if (it == 119999) { fprintf(stderr, "[zhip] WATCHDOG: encode kernels did not finish in 120 s; aborting process\n"); abort(); }
             }
         }
         return 0;
@@ -703,10 +703,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     HIP_TRY(hipEventRecord(e1, stream));
     c->timer[1].pending.emplace_back(e0, e1);
     if (getenv("ZHIP_WATCHDOG")) {
-        for (int it = 0; it < 1200; it++) {
+        for (int it = 0; it < 60000; it++) {
             if (hipStreamQuery(stream) == hipSuccess) break;
-            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
-            if (it == 1199) { fprintf(stderr, "[zhip] WATCHDOG: encode kernel did not finish in 60 s; aborting process\n"); abort(); }
+            struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
+            if (it == 59999) { fprintf(stderr, "[zhip] WATCHDOG: encode kernel did not finish in 60 s; aborting process\n"); abort(); }
         }
     }
     if (c->timer[1].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[1]); }
