@@ -62,7 +62,11 @@ struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
 // the FSE table builder's symbol spread (512 B at +3072) and the Huffman weights (256 B at +3584)
 ZH_DEV uint8_t* ze_cell_sym(ZeLDS& L) { return (uint8_t*)L.node + 3072; }
 ZH_DEV uint8_t* ze_weights(ZeLDS& L) { return (uint8_t*)L.node + 3584; }
-static_assert(sizeof(ZeNode) * (2 * 256 + 2) >= 3584 + 256, "node area too small for its scratch uses");
+// small per-routine arrays of the serial table builders live here too: a private array indexed at run time would sit in scratch
+// (global) memory, a ~500-cycle round trip per access inside loops that only lane 0 runs
+ZH_DEV uint16_t* ze_fill_area(ZeLDS& L) { return (uint16_t*)((uint8_t*)L.node + 3840); }     // 64 x u16
+ZH_DEV int16_t* ze_norm_area(ZeLDS& L) { return (int16_t*)((uint8_t*)L.node + 3968); }       // 64 x i16
+static_assert(sizeof(ZeNode) * (2 * 256 + 2) >= 3968 + 128, "node area too small for its scratch uses");
 
 // ------------------------------------------------------------------------------------------ LSB-first bit writer (one lane)
 struct ZeBits { uint8_t* p; uint32_t cap; uint64_t acc; uint32_t n; uint32_t pos; };
@@ -146,10 +150,11 @@ ZH_DEVFN int ze_fse_normalize_m2(int16_t* norm, uint32_t lg, const uint32_t* cou
     return 0;
 }
 
+ZH_CONST uint32_t ze_rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
 // FSE_normalizeCount, zstd.c:16402
 ZH_DEVFN int ze_fse_normalize(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, int useLowProb)
 {
-    const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+    const uint32_t* rtb = ze_rtb;
     const int lowProb = useLowProb ? -1 : 1;
     const uint64_t scale = 62 - lg, step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
     int still = 1 << lg;
@@ -208,7 +213,7 @@ ZH_DEVFN uint32_t ze_fse_write_ncount(uint8_t* out, const int16_t* norm, uint32_
 }
 
 // FSE_buildCTable_wksp, zstd.c:16005 (same symbol spread as the decoding table; per symbol the sorted cell list)
-ZH_DEVFN void ze_fse_build_ctab(ZeCTab& t, uint8_t* cellSym, const int16_t* norm, uint32_t maxSym, uint32_t lg)
+ZH_DEVFN void ze_fse_build_ctab(ZeCTab& t, uint8_t* cellSym, uint16_t* fill /* 64 entries of fast scratch */, const int16_t* norm, uint32_t maxSym, uint32_t lg)
 {
     const uint32_t size = 1u << lg, step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     uint32_t high = size - 1, pos = 0;
@@ -224,7 +229,6 @@ ZH_DEVFN void ze_fse_build_ctab(ZeCTab& t, uint8_t* cellSym, const int16_t* norm
     t.cellOf[maxSym + 1] = (uint16_t)cum;
     // second pass needs a running fill pointer per symbol: reuse cellOf by walking cells in order per symbol
     for (uint32_t u = 0, filled = 0; filled < size && u < 1; u++) { (void)filled; }
-    uint16_t fill[64];
     for (uint32_t s = 0; s <= maxSym; s++) fill[s] = t.cellOf[s];
     for (uint32_t u = 0; u < size; u++) { uint32_t s = cellSym[u]; t.next[fill[s]++] = (uint16_t)(size + u); }
 }
@@ -350,7 +354,7 @@ ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
         while (node[n].nbBits > maxBits) { totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits))); node[n].nbBits = (uint8_t)maxBits; n--; }
         while (node[n].nbBits == maxBits) --n;
         totalCost >>= (largest - maxBits);
-        const uint32_t none = 0xF0F0F0F0u; uint32_t rankLast[14];
+        const uint32_t none = 0xF0F0F0F0u; uint32_t* const rankLast = L.stack;      // 14 entries; the quicksort's stack is idle now
         for (int i = 0; i < 14; i++) rankLast[i] = none;
         {   uint32_t curBits = maxBits;
             for (int pos = n; pos >= 0; pos--) { if (node[pos].nbBits >= curBits) continue; curBits = node[pos].nbBits; rankLast[maxBits - curBits] = (uint32_t)pos; } }
@@ -379,7 +383,7 @@ ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
         }
         largest = maxBits;
     }
-    uint16_t perRank[14], start[14];
+    uint16_t* const perRank = (uint16_t*)(L.stack + 16); uint16_t* const start = perRank + 16;
     for (int i = 0; i < 14; i++) { perRank[i] = 0; start[i] = 0; }
     for (int n = 0; n <= last; n++) perRank[node[n].nbBits]++;
     {   uint16_t mn = 0; for (int r = (int)largest; r > 0; r--) { start[r] = mn; mn = (uint16_t)((mn + perRank[r]) >> 1); } }
@@ -392,7 +396,8 @@ ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
 // HUF_compressWeights (zstd.c:16904) + FSE_compress_usingCTable_generic (:16488). 0 = not compressible, 1 = one symbol.
 ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t* w, uint32_t n)
 {
-    uint32_t count[13]; uint32_t maxSym = 0, maxCount = 0;
+    uint32_t* const count = &L.cnt[0][0];           // free here: the bucket sort is over, the sequence histograms come later
+    uint32_t maxSym = 0, maxCount = 0;
     if (n <= 1) return 0;
     for (int s = 0; s < 13; s++) count[s] = 0;
     for (uint32_t i = 0; i < n; i++) count[w[i]]++;
@@ -400,11 +405,11 @@ ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t*
     if (maxCount == n) return 1;
     if (maxCount == 1) return 0;
     const uint32_t lg = ze_fse_optimal_log(6, n, maxSym, 2);
-    int16_t norm[13];
+    int16_t* const norm = ze_norm_area(L);
     if (ze_fse_normalize(norm, lg, count, n, maxSym, 0) < 0) return 0;
     const uint32_t h = ze_fse_write_ncount(out, norm, maxSym, lg);
     ZeCTab& t = L.tab[0];
-    ze_fse_build_ctab(t, ze_cell_sym(L), norm, maxSym, lg);
+    ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, maxSym, lg);
     if (n <= 2) return 0;
     ZeBits b; ze_bw_init(b, out + h, 512);
     uint32_t ip = n, s1, s2;
@@ -1272,14 +1277,14 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
         return 0;
     }
     if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
-    if (*mode == 0) { int16_t nrm[53]; for (uint32_t s = 0; s <= defMax; s++) nrm[s] = defNorm[s]; ze_fse_build_ctab(t, ze_cell_sym(L), nrm, defMax, defLog); return 0; }
+    int16_t* const norm = ze_norm_area(L);
+    if (*mode == 0) { for (uint32_t s = 0; s <= defMax; s++) norm[s] = defNorm[s]; ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
     uint32_t n1 = nbSeq;
     if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-    int16_t norm[53];
     ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
     const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
-    ze_fse_build_ctab(t, ze_cell_sym(L), norm, max, lg);
+    ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, max, lg);
     return h;
 }
 // ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755): small values by table, the rest by their highest bit
@@ -1860,14 +1865,14 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
                 cd->hufRepeat = (!zero && cnt == 256) ? 2u : 1u;
                 int16_t norm[64];
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->ofMax && s < 32 ? de->ofNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[1], ze_cell_sym(L), norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
+                ze_fse_build_ctab(cd->tab[1], ze_cell_sym(L), ze_fill_area(L), norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
                 {   const uint32_t need = (uint32_t)zh_highbit32(cs + 128u * 1024);
                     cd->ofRepeat = ze_ncount_repeat(norm, de->ofMax, need < ZF_MAXOFF ? need : ZF_MAXOFF); }
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->mlMax && s < 53 ? de->mlNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[2], ze_cell_sym(L), norm, de->mlMax, de->mlLog);
+                ze_fse_build_ctab(cd->tab[2], ze_cell_sym(L), ze_fill_area(L), norm, de->mlMax, de->mlLog);
                 cd->mlRepeat = ze_ncount_repeat(norm, de->mlMax, ZF_MAXML);
                 for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->llMax && s < 36 ? de->llNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[0], ze_cell_sym(L), norm, de->llMax, de->llLog);
+                ze_fse_build_ctab(cd->tab[0], ze_cell_sym(L), ze_fill_area(L), norm, de->llMax, de->llLog);
                 cd->llRepeat = ze_ncount_repeat(norm, de->llMax, ZF_MAXLL);
                 for (int i = 0; i < 3; i++) cd->rep[i] = de->rep[i];
             }
