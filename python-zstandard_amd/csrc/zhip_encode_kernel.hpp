@@ -58,6 +58,10 @@ struct ZeLDSMulti {
 struct ZePrevHuf { const uint8_t* bits; const uint16_t* code; uint32_t maxSym, repeat; };   // a candidate table for the literals (dictionary or previous block)
 
 struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
+// optional per-phase cycle totals of the entropy kernel (ZHIP_PROF tuning aid; lives in registers, null when off)
+enum { ZEP_GATHER = 0, ZEP_LITSTAT, ZEP_HUFBUILD, ZEP_HUFENC, ZEP_SEQSTAT, ZEP_SEQTAB, ZEP_SEQENC, ZEP_REST, ZEP_N };
+struct ZeProf { uint64_t t0; uint64_t acc[ZEP_N]; };
+#define ZE_T(P, i) do { if (P) { const uint64_t t1_ = zd_clock(); (P)->acc[i] += t1_ - (P)->t0; (P)->t0 = t1_; } } while (0)
 // scratch inside the tree-node area, valid while no tree is being built and disjoint from what ze_scratch users touch at the same time:
 // the FSE table builder's symbol spread (512 B at +3072) and the Huffman weights (256 B at +3584)
 ZH_DEV uint8_t* ze_cell_sym(ZeLDS& L) { return (uint8_t*)L.node + 3072; }
@@ -515,23 +519,71 @@ ZH_DEVFN uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint3
     return total;
 }
 
-// literals header for raw / rle sections (ZSTD_noCompressLiterals :20842, ZSTD_compressRleLiteralsBlock :20884). lane 0.
-ZH_DEVFN uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n, uint32_t type, bool rle)
+// n bytes from s to d by the whole wave: 16 bytes per lane per step, four steps' loads in flight before the first store (a byte
+// per lane per step is one memory round trip per 64 bytes: 2 048 of them for a 128 KiB block). Ranges must not overlap.
+ZH_DEV void ze_copy_wave(uint8_t* d, const uint8_t* s, uint32_t n)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t ng = n >> 4;
+    for (uint32_t g = lane; g < ng; g += 256) {
+        zh_v16 v0 = zh_ld128(s + 16 * (size_t)g), v1 = v0, v2 = v0, v3 = v0;
+        if (g + 64 < ng) v1 = zh_ld128(s + 16 * (size_t)(g + 64));
+        if (g + 128 < ng) v2 = zh_ld128(s + 16 * (size_t)(g + 128));
+        if (g + 192 < ng) v3 = zh_ld128(s + 16 * (size_t)(g + 192));
+        *(zh_v16*)(d + 16 * (size_t)g) = v0;
+        if (g + 64 < ng) *(zh_v16*)(d + 16 * (size_t)(g + 64)) = v1;
+        if (g + 128 < ng) *(zh_v16*)(d + 16 * (size_t)(g + 128)) = v2;
+        if (g + 192 < ng) *(zh_v16*)(d + 16 * (size_t)(g + 192)) = v3;
+    }
+    const uint32_t done = ng << 4;
+    if (lane < n - done) d[done + lane] = s[done + lane];
+}
+
+// literals header for raw / rle sections (ZSTD_noCompressLiterals :20842, ZSTD_compressRleLiteralsBlock :20884). All lanes call;
+// returns the section size.
+ZH_DEV uint32_t ze_plain_literals(uint8_t* out, const uint8_t* lit, uint32_t n, uint32_t type, bool rle)
 {
     const uint32_t fl = 1 + (n > 31) + (n > 4095);
-    if (fl == 1) out[0] = (uint8_t)(type + (n << 3));
-    else if (fl == 2) zh_st16(out, (uint16_t)(type + (1 << 2) + (n << 4)));
-    else zh_st32(out, type + (3u << 2) + (n << 4));
-    if (rle) { out[fl] = lit[0]; return fl + 1; }
-    for (uint32_t i = 0; i < n; i++) out[fl + i] = lit[i];
+    if (zh_opaque(zh_lane()) == 0) {
+        if (fl == 1) out[0] = (uint8_t)(type + (n << 3));
+        else if (fl == 2) zh_st16(out, (uint16_t)(type + (1 << 2) + (n << 4)));
+        else zh_st32(out, type + (3u << 2) + (n << 4));
+        if (rle) out[fl] = lit[0];
+    }
+    if (rle) return fl + 1;
+    ze_copy_wave(out + fl, lit, n);
     return fl + n;
+}
+
+// Byte histogram of p[0 .. n) into hist (LDS, 256 counters, zeroed by the caller; HIST_count_wksp zstd.c:16714). All lanes call.
+// Sixteen bytes per lane per round with the next round's load already in flight: one byte per lane per round (the obvious loop)
+// spends a global-memory round trip per 64 bytes and was 40 % of the entropy kernel.
+ZH_DEV void ze_byte_hist(uint32_t* hist, const uint8_t* p, uint32_t n)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t ng = n >> 4;
+    uint32_t g = lane;
+    zh_v16 cur; cur.lo = 0; cur.hi = 0;
+    if (g < ng) cur = zh_ld128(p + 16 * (size_t)g);
+    while (g < ng) {
+        const uint32_t g2 = g + 64;
+        zh_v16 nxt; nxt.lo = 0; nxt.hi = 0;
+        if (g2 < ng) nxt = zh_ld128(p + 16 * (size_t)g2);
+        uint64_t w = cur.lo;
+        for (int k = 0; k < 8; k++) { zh_lds_atomic_inc(&hist[(uint32_t)w & 255]); w >>= 8; }
+        w = cur.hi;
+        for (int k = 0; k < 8; k++) { zh_lds_atomic_inc(&hist[(uint32_t)w & 255]); w >>= 8; }
+        cur = nxt; g = g2;
+    }
+    const uint32_t done = ng << 4;
+    if (lane < n - done) zh_lds_atomic_inc(&hist[p[done + lane]]);
 }
 
 // ZSTD_compressLiterals (zstd.c:20932) + HUF_compress_internal (:18089). The only "previous" Huffman table a single-block
 // frame can have is the dictionary's (cd, may be null): repeat 0 none, 1 usable after validation, 2 valid.
 // All lanes call; returns the literals-section size (uniform).
 ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* lit, uint32_t n, uint32_t nbSeq, const ZePrevHuf* cd,
-                                       uint32_t* pNewMaxSym /* 0xFFFFFFFF unless the section carries a freshly built table */)
+                                       uint32_t* pNewMaxSym /* 0xFFFFFFFF unless the section carries a freshly built table */, ZeProf* P = nullptr)
 {
     *pNewMaxSym = 0xFFFFFFFFu;
     const uint32_t lane = zh_lane();
@@ -557,7 +609,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
             uint32_t total = 0;
             for (int part = 0; part < 2; part++) {
                 const uint8_t* p = part ? lit + n - 4096 : lit;
-                for (uint32_t i = lane; i < 4096; i += 64) zh_lds_atomic_inc(&L.hist[p[i]]);
+                ze_byte_hist(L.hist, p, 4096);
                 zh_sync();
                 uint32_t m = 0;
                 for (uint32_t i = lane; i < 256; i += 64) { if (L.hist[i] > m) m = L.hist[i]; }
@@ -571,7 +623,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         }
         uint32_t maxSym = 0, largest = 0;
         if (decision == 2) {
-            for (uint32_t i = lane; i < n; i += 64) zh_lds_atomic_inc(&L.hist[lit[i]]);
+            ze_byte_hist(L.hist, lit, n);
             zh_sync();
             uint32_t m = 0, ms = 0;
             for (uint32_t i = lane; i < 256; i += 64) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) ms = i; }
@@ -589,6 +641,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         if (decision == 2 && preferRepeat && repeat != 0) useOld = true;
         else if (decision == 2) {
             uint32_t lg = 0;
+            ZE_T(P, ZEP_LITSTAT);
             if (zh_opaque(lane) == 0) {
                 lg = ze_fse_optimal_log(11, n, maxSym, 1);
                 lg = ze_huf_build(L, maxSym, lg);
@@ -597,6 +650,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
             zh_sync();
             h = zh_first(L.misc[0]);
             zh_sync();
+            ZE_T(P, ZEP_HUFBUILD);
             builtMaxSym = maxSym;
             if (h == 0) decision = 0;
             else if (repeat != 0) {
@@ -635,6 +689,7 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
             for (uint32_t i = lane; i < 256; i += 64) ct[i] = (uint32_t)L.hufCode[i] | ((uint32_t)L.hufBits[i] << 16);
             zh_sync();
             total = ze_huf_encode_4x_wave(ct, body, bcap, lit, n);
+            ZE_T(P, ZEP_HUFENC);
         }
         uint32_t cl = total ? h + total : 0;
         if (cl >= n - 1) cl = 0;
@@ -652,9 +707,9 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         }
     }
     // raw or rle literals
-    if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lit, n, decision == 1 ? 1u : 0u, decision == 1);
     zh_sync();
-    const uint32_t r = zh_first(L.misc[0]);
+    const uint32_t r = ze_plain_literals(out, lit, n, decision == 1 ? 1u : 0u, decision == 1);
+    ze_fence();
     zh_sync();
     return r;
 }
@@ -1287,15 +1342,27 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, max, lg);
     return h;
 }
-// ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755): small values by table, the rest by their highest bit
-ZH_CONST uint8_t ze_llCodeTab[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
-                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
-ZH_CONST uint8_t ze_mlCodeTab[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
-                                       32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
-                                       40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
-                                       42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42};
-ZH_DEV uint32_t ze_ll_code(uint32_t v) { return v > 63 ? (uint32_t)zh_highbit32(v) + 19 : ze_llCodeTab[v]; }
-ZH_DEV uint32_t ze_ml_code(uint32_t ml) { const uint32_t b = ml - 3; return b > 127 ? (uint32_t)zh_highbit32(b) + 36 : ze_mlCodeTab[b]; }
+// ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755) and the extra-bit counts (LL_bits / ML_bits), computed: the reference's lookup
+// tables would be per-lane reads of global memory in the middle of per-sequence work. Nibble k of 0x5555444433221100 is the
+// code step inside [16, 32) of the LL scale / [32, 48) of the ML scale: 0 0 1 1 2 2 3 3 4 4 4 4 5 5 5 5.
+ZH_DEV uint32_t ze_ll_code(uint32_t v)
+{
+    if (v < 16) return v;
+    if (v < 32) return 16 + (uint32_t)((0x5555444433221100ull >> (4 * (v - 16))) & 15);
+    if (v < 64) { const uint32_t t = (v - 32) >> 3; return 22 + (t > 2 ? 2u : t); }
+    return (uint32_t)zh_highbit32(v) + 19;
+}
+ZH_DEV uint32_t ze_ml_code(uint32_t ml)
+{
+    const uint32_t b = ml - 3;
+    if (b < 32) return b;
+    if (b < 48) return 32 + (uint32_t)((0x5555444433221100ull >> (4 * (b - 32))) & 15);
+    if (b < 64) return 38 + ((b - 48) >> 3);
+    if (b < 128) { const uint32_t t = (b - 64) >> 4; return 40 + (t > 2 ? 2u : t); }
+    return (uint32_t)zh_highbit32(b) + 36;
+}
+ZH_DEV uint32_t ze_ll_bits(uint32_t c) { return c < 16 ? 0u : c < 25 ? (uint32_t)((0x433221111ull >> (4 * (c - 16))) & 15) : c - 19; }
+ZH_DEV uint32_t ze_ml_bits(uint32_t c) { return c < 32 ? 0u : c < 43 ? (uint32_t)((0x54433221111ull >> (4 * (c - 32))) & 15) : c - 36; }
 
 // ------------------------------------------------------------------------------------------ sequences bitstream, wave-parallel
 // ZSTD_encodeSequences_body (zstd.c:21386): sequences last to first; per sequence the OF, ML, LL state transitions
@@ -1360,11 +1427,17 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
                     v = T.next[(value >> nbOut) + dfs];
                     rt[0] = 0; j = 1;
                 }
-                for (; j < cnt; j++) {
-                    const uint32_t dnb = pt[2 * j], dfs = pt[2 * j + 1];
+                // the chain: add, shift, shift, add, one table read per step; the next slot's two constants are requested right
+                // behind that read (LDS answers in order), so their latency is not on the chain
+                uint64_t c = *(const uint64_t*)(pt + 2 * (j < cnt ? j : 0));
+                while (j < cnt) {
+                    const uint32_t dnb = (uint32_t)c, dfs = (uint32_t)(c >> 32);
                     const uint32_t nb = (v + dnb) >> 16;
                     rt[j] = v | (nb << 16);                                 // the state before the transition; its low nb bits go to the stream
-                    v = T.next[(v >> nb) + dfs];
+                    const uint32_t vn = T.next[(v >> nb) + dfs];
+                    j++;
+                    c = *(const uint64_t*)(pt + 2 * (j < cnt ? j : 0));
+                    v = vn;
                 }
             }
         }
@@ -1375,7 +1448,7 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
         if (valid) {
             const uint32_t rL = rec[lane], rO = rec[64 + lane], rM = rec[128 + lane];
             ZE_ADD(rO & ((1u << (rO >> 16)) - 1), rO >> 16); ZE_ADD(rM & ((1u << (rM >> 16)) - 1), rM >> 16); ZE_ADD(rL & ((1u << (rL >> 16)) - 1), rL >> 16);
-            const uint32_t lb = ze_llBits[lc], mb = ze_mlBits[mc];
+            const uint32_t lb = ze_ll_bits(lc), mb = ze_ml_bits(mc);
             ZE_ADD(ll & ((1u << lb) - 1), lb); ZE_ADD((ml - 3) & ((1u << mb) - 1), mb); ZE_ADD(ob & ((1u << oc) - 1), oc);
         }
 #undef ZE_ADD
@@ -1428,34 +1501,58 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
 }
 
 // The literals of a block from its sequence list: every source byte the matches do not cover, in order (what ZSTD_storeSeq's
-// literal copy accumulates, zstd.c:19930). The match-finding kernel records sequences only; this runs wave-parallel at byte
-// granularity: 64 sequences per round, two prefix sums place the literal runs, every output byte finds its run by a binary
-// search over the round's run ends. All lanes call. Returns the literal count.
+// literal copy accumulates, zstd.c:19930). The match-finding kernel records sequences only; this runs wave-parallel: 64 sequences
+// per round, two prefix sums place the literal runs, each lane copies its own run when it is short, the wave copies the long
+// ones together. All lanes call. Returns the literal count.
 ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src, uint32_t srcSize, const uint64_t* seqs, uint32_t nbSeq)
 {
     const uint32_t lane = zh_lane();
-    uint32_t* const ends = ze_scratch(L);
-    uint32_t* const srcAt = ends + 64;
+    uint32_t* const uend = ze_scratch(L);                                   // per round: inclusive 16-byte-unit ends of the long runs
+    uint32_t* const rsrc = uend + 64; uint32_t* const rdst = rsrc + 64; uint32_t* const rlen = rdst + 64;
     uint32_t litBase = 0, srcBase = 0;
+    uint64_t qn = lane < nbSeq ? seqs[lane] : 0;                            // the next round's sequences are requested a round ahead
     for (uint32_t b0 = 0; b0 < nbSeq; b0 += 64) {
-        const bool valid = b0 + lane < nbSeq;
-        const uint64_t q = valid ? seqs[b0 + lane] : 0;
+        const uint64_t q = qn;
+        qn = b0 + 64 + lane < nbSeq ? seqs[b0 + 64 + lane] : 0;
         const uint32_t ll = ZE_SEQ_LL(q), ml = ZE_SEQ_ML(q);
         const uint32_t le = zh_scan_add(ll), se = zh_scan_add(ll + ml);
-        zh_sync();
-        ends[lane] = le; srcAt[lane] = srcBase + se - ll - ml;
-        zh_sync();
         const uint32_t T = zh_shfl(le, 63), S = zh_shfl(se, 63);
-        for (uint32_t t = lane; t < T; t += 64) {
-            uint32_t j = 0;                                                // smallest j with ends[j] > t
-            for (uint32_t stp = 32; stp; stp >>= 1) if (ends[j + stp - 1] <= t) j += stp;
-            const uint32_t start = j ? ends[j - 1] : 0u;
-            lits[litBase + t] = src[srcAt[j] + (t - start)];
+        const uint32_t myLit = litBase + le - ll, mySrc = srcBase + se - ll - ml;
+        // runs of up to 16 bytes (most of them): the run's owner loads 16 source bytes in one go (the load may reach past the run,
+        // never past the source) and stores exactly its ll bytes. Longer runs are cut into 16-byte units -- the last one shifted back
+        // to end with the run -- and ALL the round's units are spread over the lanes (a unit finds its run by a binary search over
+        // the unit prefix sums), so a round costs one memory round trip whatever its run lengths are.
+        const bool small = ll > 0 && ll <= 16 && mySrc + 16 <= srcSize;
+        const bool tiny = ll > 0 && ll < 16 && !small;                      // a short run within 16 bytes of the source's end
+        const uint32_t units = ll > 16 ? (ll + 15) >> 4 : 0u;
+        const uint32_t ue = zh_scan_add(units);
+        const uint32_t U = zh_shfl(ue, 63);
+        zh_v16 v; v.lo = 0; v.hi = 0;
+        if (small) v = zh_ld128(src + mySrc);
+        if (U) {
+            zh_sync();
+            uend[lane] = ue; rsrc[lane] = mySrc; rdst[lane] = myLit; rlen[lane] = ll;
+            zh_sync();
+            for (uint32_t u = lane; u < U; u += 64) {
+                uint32_t j = 0;                                                // smallest j with uend[j] > u
+                for (uint32_t stp = 32; stp; stp >>= 1) if (uend[j + stp - 1] <= u) j += stp;
+                const uint32_t k = u - (j ? uend[j - 1] : 0u), len = rlen[j];
+                const uint32_t off = 16 * k + 16 <= len ? 16 * k : len - 16;
+                *(zh_v16*)(lits + rdst[j] + off) = zh_ld128(src + rsrc[j] + off);
+            }
         }
+        if (small) {
+            uint8_t* d = lits + myLit;
+            uint64_t w = v.lo;
+            for (uint32_t k = 0; k < 8; k++) { if (k < ll) d[k] = (uint8_t)w; w >>= 8; }
+            w = v.hi;
+            for (uint32_t k = 8; k < 16; k++) { if (k < ll) d[k] = (uint8_t)w; w >>= 8; }
+        }
+        if (tiny) for (uint32_t k = 0; k < ll; k++) lits[myLit + k] = src[mySrc + k];
         litBase += T; srcBase += S;
     }
     const uint32_t tail = srcSize - srcBase;
-    for (uint32_t t = lane; t < tail; t += 64) lits[litBase + t] = src[srcBase + t];
+    ze_copy_wave(lits + litBase, src + srcBase, tail);
     ze_fence();
     zh_sync();
     return litBase + tail;
@@ -1468,7 +1565,7 @@ struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSiz
 struct ZeMulti { const uint8_t* frame; bool firstBlock; ZeLDSMulti* st; };
 
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
-                                    const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr)
+                                    const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr, ZeProf* P = nullptr)
 {
     const ZeCDict* cd = mb ? nullptr : a.cdict;
     const uint32_t lane = zh_lane();
@@ -1481,6 +1578,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     if (pre) {
         nbSeq = pre->nbSeq; litSize = pre->litSize;
         if (!pre->lits) litSize = ze_gather_literals(L, ws + ZE_WS_LIT, src, srcSize, seqs, nbSeq);    // sequences-only search output
+        ZE_T(P, ZEP_GATHER);
     }
     else {
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
@@ -1516,11 +1614,11 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     else if (mb && mb->st->prevRepeat) { ph.bits = mb->st->prevBits; ph.code = mb->st->prevCode; ph.maxSym = mb->st->prevMaxSym; ph.repeat = mb->st->prevRepeat; php = &ph; }
     if (cp.strat == 1 && cp.tlen > 0) {          // negative levels keep literals raw (ZSTD_literalsCompressionIsDisabled, zstd.c:24208)
         zh_sync();
-        if (zh_opaque(lane) == 0) L.misc[0] = ze_plain_literals(out, lits, litSize, 0u, false);
+        pos = ze_plain_literals(out, lits, litSize, 0u, false);
+        ze_fence();
         zh_sync();
-        pos = zh_first(L.misc[0]);
-        zh_sync();
-    } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, php, &newMaxSym);
+    } else pos = ze_compress_literals(L, out, cap, lits, litSize, nbSeq, php, &newMaxSym, P);
+    ZE_T(P, ZEP_LITSTAT);
     // symbol histograms, wave-parallel (ZSTD_seqToCodes zstd.c:25647, HIST_countFast); the codes themselves are recomputed by the
     // stream encoder, only the first and the last sequence's are kept (rle mode / FSE_normalizeCount's last-symbol rule)
     zh_sync();
@@ -1535,6 +1633,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     }
     ze_fence();
     zh_sync();
+    ZE_T(P, ZEP_SEQSTAT);
     if (zh_opaque(lane) == 0) {
         uint8_t* op = out + pos;
         uint32_t lastCount = 0;
@@ -1556,9 +1655,11 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     zh_sync();
     const uint32_t seqStart = zh_first(L.misc[10]), lastCount = zh_first(L.misc[3]);
     zh_sync();
+    ZE_T(P, ZEP_SEQTAB);
     uint32_t r = 1, cSize = seqStart;
     if (nbSeq) {
         const uint32_t bs = ze_encode_sequences_wave(L, out + seqStart, cap - seqStart, seqs, nbSeq);
+        ZE_T(P, ZEP_SEQENC);
         if (bs == 0) r = 0;
         if (lastCount && lastCount + bs < 4) r = 0;
         cSize += bs;
@@ -1702,7 +1803,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
         uint32_t total, bh;
         if (c == 0) {
             bh = last + (0u << 1) + (blockSize << 3);
-            for (uint32_t i = lane; i < blockSize; i += 64) dst[pos + 3 + i] = src[ip + i];
+            ze_copy_wave(dst + pos + 3, src + ip, blockSize);
             total = 3 + blockSize;
         } else if (c == 1) { bh = last + (1u << 1) + (blockSize << 3); total = 4; }
         else { bh = last + (2u << 1) + (c << 3); total = 3 + c; }
@@ -1722,7 +1823,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
 }
 
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
-ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre, ZeLDSMulti* ms = nullptr)
+ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre, ZeLDSMulti* ms = nullptr, ZeProf* P = nullptr)
 {
     const uint32_t lane = zh_lane();
     *produced = 0;
@@ -1773,11 +1874,11 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
         if (zh_opaque(lane) == 0) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; }
         pos += 3;
     } else {
-        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre, a);
+        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre, a, nullptr, P);
         if (c == 0) {
             const uint32_t bh = 1 + (0u << 1) + (srcSize << 3);
             if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
-            for (uint32_t i = lane; i < srcSize; i += 64) dst[pos + 3 + i] = src[i];
+            ze_copy_wave(dst + pos + 3, src, srcSize);
             pos += 3 + srcSize;
         } else {
             const uint32_t bh = 1 + (2u << 1) + (c << 3);
@@ -2039,7 +2140,10 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         const uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
         ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = m.mode == 4 ? nullptr : fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
         uint64_t produced = 0;
-        const int err = ze_frame(a, L, f, ws, &produced, (m.mode == 0 || m.mode == 4) ? &pre : nullptr);   // modes 1/2 never reach the search inside
+        ZeProf prof; ZeProf* P = a.prof ? &prof : nullptr;
+        if (P) { for (int q = 0; q < ZEP_N; q++) prof.acc[q] = 0; prof.t0 = zd_clock(); }
+        const int err = ze_frame(a, L, f, ws, &produced, (m.mode == 0 || m.mode == 4) ? &pre : nullptr, nullptr, P);   // modes 1/2 never reach the search inside
+        if (P) { ZE_T(P, ZEP_REST); if (zh_opaque(lane) == 0) for (int q = 0; q < ZEP_N; q++) zh_atomic_add64(a.prof + q, (unsigned long long)prof.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }

@@ -651,6 +651,12 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         a.useE1List = flat ? 1u : 0u;
         a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)((uint8_t*)c->counter.p + 24);
         HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));
+        static unsigned long long* d_eprof = nullptr;
+        if (getenv("ZHIP_PROF")) {                                                  // tuning aid: per-phase cycle totals of the entropy kernel
+            if (!d_eprof) HIP_TRY(hipMalloc((void**)&d_eprof, 16 * 8));
+            HIP_TRY(hipMemsetAsync(d_eprof, 0, 16 * 8, stream));
+            a.prof = d_eprof;
+        }
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
@@ -675,6 +681,16 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
             c->timer[5].pending.emplace_back(ev[2], ev[3]);
             c->timer[6].pending.emplace_back(ev[4], ev[5]);
+        }
+        if (a.prof) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            unsigned long long h[16];
+            HIP_TRY(hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
+            static const char* nm[ZEP_N] = {"gather literals", "literal stats+decide", "huffman build+table", "huffman encode", "sequence stats", "sequence tables", "sequence stream", "frame assembly"};
+            unsigned long long tot = 0; for (int q = 0; q < ZEP_N; q++) tot += h[q];
+            fprintf(stderr, "[zhip-prof] E2: %.0f wave-cycles per frame\n", (double)tot / (double)n);
+            for (int q = 0; q < ZEP_N; q++) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[q] / (tot ? tot : 1), (double)h[q] / (double)n);
+            a.prof = nullptr;
         }
         {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;

@@ -194,3 +194,17 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     return 0;
 }
 extern "C" long emu_stat(int i) { return i >= 0 && i < 16 ? zd_stat[i] : -1; }     // [15]: frames searched by the flat match kernel
+// exhaustive check of the computed LL / ML codes and extra-bit counts against the format's base tables (RFC 8878 3.1.1.3.2.1.1)
+extern "C" int emu_check_code_formulas(void)
+{
+    int bad = 0;
+    for (uint32_t v = 0; v < 131072; v++) {          // a sequence of a 128 KiB block has at most 131 069 literals
+        uint32_t c = 35; while (ze_llBase[c] > v) c--;
+        if (ze_ll_code(v) != c || ze_ll_bits(c) != ze_llBits[c]) bad++;
+    }
+    for (uint32_t ml = 3; ml <= 131074; ml++) {
+        uint32_t c = 52; while (ze_mlBase[c] > ml) c--;
+        if (ze_ml_code(ml) != c || ze_ml_bits(c) != ze_mlBits[c]) bad++;
+    }
+    return bad;
+}

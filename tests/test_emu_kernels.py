@@ -179,3 +179,8 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
         for i, (r, o) in enumerate(zip(raws, outs)):
             assert o == oracle.compress(r, level=3, flags=flags), (flags, i, len(r))
     assert emu.lib.emu_stat(15) - before >= 2 * 30, "the flat match kernel did not take these frames"
+
+
+def test_computed_sequence_codes_match_the_format_tables(emu):
+    """the entropy kernel computes LL / ML codes and extra-bit counts instead of reading tables: every length up to one block"""
+    assert emu.lib.emu_check_code_formulas() == 0
