@@ -104,13 +104,45 @@ ZH_DEV uint64_t zd_ld64_bounded(const uint8_t* p, const uint8_t* end)
     return v;
 }
 
+// len bytes by the whole wave (ranges must not overlap): 16 bytes per lane per step with four steps' loads in flight before the
+// first store. The obvious `dst[j] = src[j]` loop is one memory round trip per 64 bytes, because the compiler has to assume the
+// store feeds the next load: 2 048 round trips for a raw 128 KiB block.
 ZH_DEV void zd_copy_wave(uint8_t* dst, const uint8_t* src, uint32_t len)
 {
-    for (uint32_t j = zh_lane(); j < len; j += 64) dst[j] = src[j];
+    const uint32_t lane = zh_lane();
+    const uint32_t ng = len >> 4;
+    for (uint32_t g = lane; g < ng; g += 256) {
+        zh_v16 v0 = zh_ld128(src + 16 * (size_t)g), v1 = v0, v2 = v0, v3 = v0;
+        if (g + 64 < ng) v1 = zh_ld128(src + 16 * (size_t)(g + 64));
+        if (g + 128 < ng) v2 = zh_ld128(src + 16 * (size_t)(g + 128));
+        if (g + 192 < ng) v3 = zh_ld128(src + 16 * (size_t)(g + 192));
+        *(zh_v16*)(dst + 16 * (size_t)g) = v0;
+        if (g + 64 < ng) *(zh_v16*)(dst + 16 * (size_t)(g + 64)) = v1;
+        if (g + 128 < ng) *(zh_v16*)(dst + 16 * (size_t)(g + 128)) = v2;
+        if (g + 192 < ng) *(zh_v16*)(dst + 16 * (size_t)(g + 192)) = v3;
+    }
+    const uint32_t done = ng << 4;
+    if (lane < len - done) dst[done + lane] = src[done + lane];
 }
 ZH_DEV void zd_fill_wave(uint8_t* dst, uint32_t byte, uint32_t len)
 {
-    for (uint32_t j = zh_lane(); j < len; j += 64) dst[j] = (uint8_t)byte;
+    const uint32_t lane = zh_lane();
+    const uint32_t ng = len >> 4;
+    zh_v16 v; v.lo = 0x0101010101010101ull * (byte & 255); v.hi = v.lo;
+    for (uint32_t g = lane; g < ng; g += 64) *(zh_v16*)(dst + 16 * (size_t)g) = v;
+    const uint32_t done = ng << 4;
+    if (lane < len - done) dst[done + lane] = (uint8_t)byte;
+}
+// len bytes from global memory into the LDS assembly buffer (any alignment, so bytes), eight per lane in flight per step
+ZH_DEV void zd_stage_wave(uint8_t* lds, const uint8_t* src, uint32_t len)
+{
+    for (uint32_t j = zh_lane(); j < len; j += 512) {
+        uint8_t b[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) b[k] = j + 64 * k < len ? src[j + 64 * k] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) if (j + 64 * k < len) lds[j + 64 * k] = b[k];
+    }
 }
 
 #ifndef ZHIP_EMU
@@ -833,7 +865,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                 const uint32_t l = (uint32_t)zh_ctz64(m);
                 const uint32_t d = zh_shfl(oRel, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
                 if (st.litRLE) { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)st.rleByte; }
-                else { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = st.litPtr[s + j]; }
+                else zd_stage_wave(asmb + d, st.litPtr + s, n);
             }
             for (uint64_t m = zh_ballot(farM && myML > ZD_COOP_LEN); m; m &= m - 1) {      // long far matches: whole wave
                 const uint32_t l = (uint32_t)zh_ctz64(m);

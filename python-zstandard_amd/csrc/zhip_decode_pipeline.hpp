@@ -520,13 +520,13 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const uint32_t l = (uint32_t)zh_ctz64(mk);
             const uint32_t d = zh_shfl(oRel, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
             if (litRLE) { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)rleByte; }
-            else { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = litPtr[s + j]; }
+            else zd_stage_wave(asmb + d, litPtr + s, n);
         }
         for (uint64_t mk = zh_ballot(farM && myML > ZD_COOP_LEN); mk; mk &= mk - 1) {
             const uint32_t l = (uint32_t)zh_ctz64(mk);
             const uint32_t d = zh_shfl(mRel, l), n = zh_shfl(myML, l);
             const uint32_t s = zh_shfl((uint32_t)sAbs, l);
-            for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = dst[s + j];
+            zd_stage_wave(asmb + d, dst + s, n);
         }
         // ---- matches that read this batch's own output. A match may start as soon as every near match whose output
         // it reads is done: `need` = the set of those sequences (contiguous index range found by binary search over the
