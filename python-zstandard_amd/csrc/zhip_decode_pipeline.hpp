@@ -451,7 +451,11 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
 }
 
 // ------------------------------------------------------------------------------------------ K3 (one wave per frame)
-struct ZpExecLDS { uint8_t asmb[ZD_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8]; };
+struct ZpExecLDS {
+    uint8_t asmb[ZD_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
+    // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
+    uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
+};
 
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
@@ -505,28 +509,50 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         const bool hasM = act && myML > 0;
         const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)op;
         {
+            // Everything this batch reads from global memory is requested before anything is waited for: the short literal runs and
+            // short far matches (up to 32 bytes, by their own lanes), then the long items. One at a time by the whole wave, a long item
+            // costs a memory round trip each (several per batch: this was most of the kernel's literal / far-match phase); instead
+            // every long item of the batch is cut into 16-byte units (the last one shifted back to end with the item), the units are
+            // dealt out to the lanes -- a unit finds its item by a binary search over the unit prefix sums -- and the first 64 units'
+            // loads fly together with the short ones.
             uint64_t rl[4], rm[4];
             const bool shortL = act && myLL > 0 && myLL <= ZD_COOP_LEN;
             const bool shortFar = farM && myML <= ZD_COOP_LEN;
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
             if (shortFar) zd_ld32(dst + sAbs, myML, rm);
+            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = farM && myML > ZD_COOP_LEN;
+            const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (myML + 15) >> 4 : 0u;
+            const uint32_t ue = zh_scan_add(uL + uM);
+            const uint32_t U = zh_shfl(ue, 63);
+            zh_v16 uv; uv.lo = 0; uv.hi = 0; uint8_t* udp = asmb;
+            if (U) {
+                L.uEnd[lane] = (uint16_t)ue; L.uLit[lane] = (uint16_t)uL;
+                L.srcL[lane] = litStart; L.dstL[lane] = (uint16_t)oRel; L.lenL[lane] = (uint16_t)myLL;
+                L.srcM[lane] = (uint32_t)sAbs; L.dstM[lane] = (uint16_t)mRel; L.lenM[lane] = (uint16_t)myML;
+                zh_sync();
+#define ZP_UNIT(u) do { uint32_t j_ = 0; for (uint32_t stp_ = 32; stp_; stp_ >>= 1) if (L.uEnd[j_ + stp_ - 1] <= (u)) j_ += stp_; \
+                    uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
+                    const uint32_t len_ = isL_ ? L.lenL[j_] : L.lenM[j_]; const uint32_t off_ = 16 * k_ + 16 <= len_ ? 16 * k_ : len_ - 16; \
+                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : dst + L.srcM[j_] + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
+                if (lane < U) ZP_UNIT(lane);
+            }
             if (shortL) {
                 if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }
                 zd_st32(asmb + oRel, myLL, rl);
             }
             if (shortFar) zd_st32(asmb + mRel, myML, rm);
+            if (U) {
+                if (lane < U) { zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
+                for (uint32_t u = lane + 64; u < U; u += 64) { ZP_UNIT(u); zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
+#undef ZP_UNIT
+            }
         }
-        for (uint64_t mk = zh_ballot(act && myLL > ZD_COOP_LEN); mk; mk &= mk - 1) {
-            const uint32_t l = (uint32_t)zh_ctz64(mk);
-            const uint32_t d = zh_shfl(oRel, l), s = zh_shfl(litStart, l), n = zh_shfl(myLL, l);
-            if (litRLE) { for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)rleByte; }
-            else zd_stage_wave(asmb + d, litPtr + s, n);
-        }
-        for (uint64_t mk = zh_ballot(farM && myML > ZD_COOP_LEN); mk; mk &= mk - 1) {
-            const uint32_t l = (uint32_t)zh_ctz64(mk);
-            const uint32_t d = zh_shfl(mRel, l), n = zh_shfl(myML, l);
-            const uint32_t s = zh_shfl((uint32_t)sAbs, l);
-            zd_stage_wave(asmb + d, dst + s, n);
+        if (litRLE) {
+            for (uint64_t mk = zh_ballot(act && myLL > ZD_COOP_LEN); mk; mk &= mk - 1) {
+                const uint32_t l = (uint32_t)zh_ctz64(mk);
+                const uint32_t d = zh_shfl(oRel, l), n = zh_shfl(myLL, l);
+                for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)rleByte;
+            }
         }
         // ---- matches that read this batch's own output. A match may start as soon as every near match whose output
         // it reads is done: `need` = the set of those sequences (contiguous index range found by binary search over the
