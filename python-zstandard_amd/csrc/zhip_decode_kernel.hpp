@@ -660,19 +660,20 @@ ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst,
 // r[0..2] hold bytes [0,8) [8,16) [16,24); r[3] holds the LAST 8 bytes (overlapping) when len >= 8, else the whole run.
 ZH_DEV void zd_ld32(const uint8_t* p, uint32_t len, uint64_t r[4])
 {
-    r[0] = r[1] = r[2] = r[3] = 0;
-    if (len >= 8) {
-        r[0] = zh_ld64(p);
-        if (len > 16) r[1] = zh_ld64(p + 8);
-        if (len > 24) r[2] = zh_ld64(p + 16);
-        r[3] = zh_ld64(p + len - 8);
-    } else {
-        uint64_t v = 0; uint32_t o = 0;
-        if (len & 4) { v = zh_ld32(p); o = 4; }
-        if (len & 2) { v |= (uint64_t)zh_ld16(p + o) << (8 * o); o += 2; }
-        if (len & 1) { v |= (uint64_t)p[o] << (8 * o); }
-        r[3] = v;
-    }
+    // every piece is a predicated load into its own register and nothing is combined before all of them are issued: written as
+    // nested branches the pieces of a short run (4 + 2 + 1 bytes) were three dependent memory round trips
+    const bool ge8 = len >= 8;
+    const uint32_t o2 = len & 4, o1 = o2 + (len & 2);
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0; uint32_t b4 = 0, b2 = 0, b1 = 0;
+    if (ge8) a0 = zh_ld64(p);
+    if (len > 16) a1 = zh_ld64(p + 8);
+    if (len > 24) a2 = zh_ld64(p + 16);
+    if (ge8) a3 = zh_ld64(p + len - 8);
+    if (!ge8 && (len & 4)) b4 = zh_ld32(p);
+    if (!ge8 && (len & 2)) b2 = zh_ld16(p + o2);
+    if (!ge8 && (len & 1)) b1 = p[o1];
+    r[0] = a0; r[1] = a1; r[2] = a2;
+    r[3] = ge8 ? a3 : ((uint64_t)b4 | ((uint64_t)b2 << (8 * o2)) | ((uint64_t)b1 << (8 * o1)));
 }
 ZH_DEV void zd_st32(uint8_t* q, uint32_t len, const uint64_t r[4])
 {
