@@ -508,6 +508,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         const int32_t sAbs = (int32_t)(op + mRel) - (int32_t)myOF;
         const bool hasM = act && myML > 0;
         const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)op;
+        uint32_t nearSkip = 0;                                              // bytes of a near match that precede the batch (staged with the far data)
         {
             // Everything this batch reads from global memory is requested before anything is waited for: the short literal runs and
             // short far matches (up to 32 bytes, by their own lanes), then the long items. One at a time by the whole wave, a long item
@@ -520,15 +521,23 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const bool shortFar = farM && myML <= ZD_COOP_LEN;
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
             if (shortFar) zd_ld32(dst + sAbs, myML, rm);
-            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = farM && myML > ZD_COOP_LEN;
-            const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (myML + 15) >> 4 : 0u;
+            // a near match whose source starts before the batch: that part is global memory too and is fetched here like a far
+            // match (byte by byte in the dependency rounds it was a memory round trip per byte)
+            const bool pre = hasM && !farM && sAbs < (int32_t)op;
+            const uint32_t preLen = pre ? (uint32_t)((int32_t)op - sAbs) : 0u;
+            nearSkip = preLen;
+            const bool shortPre = pre && preLen <= ZD_COOP_LEN;
+            if (shortPre) zd_ld32(dst + sAbs, preLen, rm);
+            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM && myML > ZD_COOP_LEN) || (pre && !shortPre);
+            const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
+            const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
             const uint32_t ue = zh_scan_add(uL + uM);
             const uint32_t U = zh_shfl(ue, 63);
             zh_v16 uv; uv.lo = 0; uv.hi = 0; uint8_t* udp = asmb;
             if (U) {
                 L.uEnd[lane] = (uint16_t)ue; L.uLit[lane] = (uint16_t)uL;
                 L.srcL[lane] = litStart; L.dstL[lane] = (uint16_t)oRel; L.lenL[lane] = (uint16_t)myLL;
-                L.srcM[lane] = (uint32_t)sAbs; L.dstM[lane] = (uint16_t)mRel; L.lenM[lane] = (uint16_t)myML;
+                L.srcM[lane] = (uint32_t)sAbs; L.dstM[lane] = (uint16_t)mRel; L.lenM[lane] = (uint16_t)lenMi;
                 zh_sync();
 #define ZP_UNIT(u) do { uint32_t j_ = 0; for (uint32_t stp_ = 32; stp_; stp_ >>= 1) if (L.uEnd[j_ + stp_ - 1] <= (u)) j_ += stp_; \
                     uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
@@ -541,6 +550,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 zd_st32(asmb + oRel, myLL, rl);
             }
             if (shortFar) zd_st32(asmb + mRel, myML, rm);
+            if (shortPre) zd_st32(asmb + mRel, preLen, rm);
             if (U) {
                 if (lane < U) { zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
                 for (uint32_t u = lane + 64; u < U; u += 64) { ZP_UNIT(u); zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
@@ -603,14 +613,23 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             } else {
                 const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
                 if (ready) {
-                    if (sAbs >= (int32_t)op && myOF >= myML) {
+                    // what is left of the match lies in the assembly buffer: source nSrc, destination nSrc + myOF, nLen bytes
+                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
+                    if (myOF >= nLen) {
                         uint64_t rr[4];
-                        zd_ld32(asmb + (sAbs - (int32_t)op), myML, rr);
-                        zd_st32(asmb + mRel, myML, rr);
+                        zd_ld32(asmb + nSrc, nLen, rr);
+                        zd_st32(asmb + nDst, nLen, rr);
                     } else {
-                        for (uint32_t j = 0; j < myML; j++) {
-                            const int32_t sp = sAbs + (int32_t)j;
-                            asmb[mRel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp];
+                        // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
+                        // step can copy as much as is already final -- the copied length doubles instead of advancing a byte at a time
+                        uint32_t done = 0;
+                        while (done < nLen) {
+                            const uint32_t ph = done % myOF;
+                            uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
+                            uint64_t rr[4];
+                            zd_ld32(asmb + nSrc + ph, c, rr);
+                            zd_st32(asmb + nDst + done, c, rr);
+                            done += c;
                         }
                     }
                     pending = false;
