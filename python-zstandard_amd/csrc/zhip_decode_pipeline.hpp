@@ -363,9 +363,12 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
     uint32_t cL, cM, cO;
 #define ZP_DECODE_ONE(n) do { \
         cL = *(const uint16_t*)(T + 2 * ZP_FSE_LL + 2 * sL); cM = *(const uint16_t*)(T + 2 * ZP_FSE_ML + 2 * sM); cO = *(const uint16_t*)(T + 2 * ZP_FSE_OF + 2 * sO); \
-        const uint32_t symO = cO >> 10; \
-        const uint32_t iL = llInfo[cL >> 10], iM = mlInfo[cM >> 10]; \
-        const uint32_t bitsL = iL >> 24, bitsM = iM >> 24; \
+        const uint32_t symO = cO >> 10, symL = cL >> 10, symM = cM >> 10; \
+        /* baselines and extra-bit counts computed from the codes (RFC 8878 3.1.1.3.2.1.1): a table read here would be a second dependent LDS round on the chain */ \
+        const uint32_t bitsL = symL < 16 ? 0u : symL < 25 ? (uint32_t)(0x433221111ull >> (4 * (symL - 16))) & 15u : symL - 19; \
+        const uint32_t baseL = symL < 16 ? symL : symL < 24 ? (uint32_t)(0x28201C1816141210ull >> (8 * (symL - 16))) & 255u : symL == 24 ? 48u : 1u << (symL - 19); \
+        const uint32_t bitsM = symM < 32 ? 0u : symM < 43 ? (uint32_t)(0x54433221111ull >> (4 * (symM - 32))) & 15u : symM - 36; \
+        const uint32_t baseM = symM < 32 ? symM + 3 : symM < 40 ? (uint32_t)(0x3B332F2B29272523ull >> (8 * (symM - 32))) & 255u : symM < 43 ? (uint32_t)(0x635343u >> (8 * (symM - 40))) & 255u : (1u << (symM - 36)) + 3; \
         top = ZP_TOP(); \
         const uint32_t xo = zh_bfe(top, 32 - symO, symO); \
         uint32_t cum = symO; \
@@ -374,7 +377,7 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL; \
         used += cum; \
         ZP_REFILL(); \
-        const uint32_t ofv = (1u << symO) + xo, mlv = (iM & 0xFFFFFFu) + xm, llv = (iL & 0xFFFFFFu) + xl; \
+        const uint32_t ofv = (1u << symO) + xo, mlv = baseM + xm, llv = baseL + xl; \
         /* repcode resolution (RFC 8878 3.1.1.5), select form */ \
         const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */ \
         uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro; \

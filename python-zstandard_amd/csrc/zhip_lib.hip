@@ -42,7 +42,7 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)
     zp_seq_body(a, L);
 }
 #ifndef ZP_K3_MINWAVES
-#define ZP_K3_MINWAVES 1
+#define ZP_K3_MINWAVES 4
 #endif
 ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
