@@ -326,11 +326,16 @@ def main():
     if args.compress_frames > 0:
         # the other half of BASELINE.json's metric, on a bounded slice of the same inputs (the timed decompress region above is over)
         Fc = min(F, args.compress_frames)
-        del dst
-        c_elapsed, c_total, c_k = measure_compress(ctx, raw, frames, rank, world, dev, Fc, 2, 1)
+        # the compressor is its own object in the reference API: release the decode direction's working set (its context's arenas,
+        # the frames and their output) and start from a fresh context, as a ZstdCompressor next to a ZstdDecompressor would
+        del dst, src, src_segs, dst_segs, out_sizes, status
+        ctx.close()
+        torch.cuda.empty_cache()
+        ctx = DeviceBatchContext()
+        c_elapsed, c_total, c_k = measure_compress(ctx, raw, frames, rank, world, dev, Fc, 3, 2)
         if rank == 0:
-            line["compress"] = {"value": round(world * Fc * FRAME * 2 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 2,
-                                "ms_per_step": round(c_elapsed / 2 * 1e3, 3), "bit_exact_vs_libzstd": True,
+            line["compress"] = {"value": round(world * Fc * FRAME * 3 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 3,
+                                "ms_per_step": round(c_elapsed / 3 * 1e3, 3), "bit_exact_vs_libzstd": True,
                                 "kernels": {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in c_k.items() if v[1]}}
             if world == 1 and not args.no_cpu_baseline:
                 sample = min(Fc, 4096)
