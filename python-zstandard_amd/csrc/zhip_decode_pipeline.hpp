@@ -219,9 +219,12 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
 // + stream -- with the 16 tables (4 KiB each, built by K1) in LDS; frames come in KB's order so that a wave's streams have similar
 // lengths. Same 32-bit bit window as K2: two symbols per v_alignbit, dword refills.
 struct alignas(16) ZpVec16 { uint32_t a, b, c, d; };
-struct ZpHufLDS { alignas(16) uint16_t tab[ZP_HUF_FRAMES][ZP_HUF_CELLS]; };
+// A decoding cell is 12 bits of information (symbol, code length <= 11): kept as a byte array of symbols and a nibble array of lengths,
+// a frame's table is 3 KiB instead of 4, a wave's 16 tables 48 KiB, and THREE waves fit a CU's LDS instead of two -- the kernel is a
+// latency-bound lookup chain, so residency is throughput.
+struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; };
 
-ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
+ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
 {
     if (size == 0) return false;
     const uint32_t last = p[size - 1];
@@ -230,6 +233,7 @@ ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, u
 #define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
 #define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; n2 = ge_ ? n3 : n2; n3 = ge_ ? n4 : n3; \
         n4 = ge_ ? n5 : n4; used = ge_ ? used - 32 : used; off = ge_ ? off - 4 : off; n5 = ZP_WORD(off); } while (0)
+#define ZP_LEN(i) (((uint32_t)lenTab[(i) >> 1] >> (((i) & 1) * 4)) & 15u)
     int32_t off = (int32_t)size - 28;
     uint32_t hi = ZP_WORD(off + 24), lo = ZP_WORD(off + 20), n1 = ZP_WORD(off + 16), n2 = ZP_WORD(off + 12), n3 = ZP_WORD(off + 8), n4 = ZP_WORD(off + 4), n5 = ZP_WORD(off);
     uint32_t used = 8 - (uint32_t)zh_highbit32(last);
@@ -237,24 +241,25 @@ ZH_DEV bool zp_huf_stream(const uint16_t* tab, uint32_t log, const uint8_t* p, u
     uint32_t i = 0;
     while (i + 4 <= count) {
         uint32_t top = ZP_TOP();
-        const uint32_t e0 = tab[top >> sh]; top <<= e0 >> 8;
-        const uint32_t e1 = tab[top >> sh];
-        used += (e0 >> 8) + (e1 >> 8);
+        const uint32_t i0 = top >> sh; const uint32_t s0 = symTab[i0], l0 = ZP_LEN(i0); top <<= l0;
+        const uint32_t i1 = top >> sh; const uint32_t s1 = symTab[i1], l1 = ZP_LEN(i1);
+        used += l0 + l1;
         ZP_REFILL();
         top = ZP_TOP();
-        const uint32_t e2 = tab[top >> sh]; top <<= e2 >> 8;
-        const uint32_t e3 = tab[top >> sh];
-        used += (e2 >> 8) + (e3 >> 8);
+        const uint32_t i2 = top >> sh; const uint32_t s2 = symTab[i2], l2 = ZP_LEN(i2); top <<= l2;
+        const uint32_t i3 = top >> sh; const uint32_t s3 = symTab[i3], l3 = ZP_LEN(i3);
+        used += l2 + l3;
         ZP_REFILL();
-        zh_st32(out + i, (e0 & 255) | ((e1 & 255) << 8) | ((e2 & 255) << 16) | (e3 << 24));
+        zh_st32(out + i, s0 | (s1 << 8) | (s2 << 16) | (s3 << 24));
         i += 4;
     }
     while (i < count) {
-        const uint32_t e = tab[ZP_TOP() >> sh];
-        used += e >> 8;
+        const uint32_t ix = ZP_TOP() >> sh;
+        used += ZP_LEN(ix);
         ZP_REFILL();
-        out[i++] = (uint8_t)e;
+        out[i++] = symTab[ix];
     }
+#undef ZP_LEN
 #undef ZP_REFILL
 #undef ZP_TOP
 #undef ZP_WORD
@@ -283,9 +288,17 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
             const uint32_t fj = zh_shfl(i, 4 * j);
             if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
             const ZpVec16* src = (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
-            ZpVec16* dstv = (ZpVec16*)L.tab[j];
             const ZpVec16 r0 = src[lane], r1 = src[lane + 64], r2 = src[lane + 128], r3 = src[lane + 192];
-            dstv[lane] = r0; dstv[lane + 64] = r1; dstv[lane + 128] = r2; dstv[lane + 192] = r3;
+            // eight 2-byte cells (symbol | length << 8) per 16 bytes -> eight symbol bytes + eight length nibbles
+#define ZP_SPLIT(v, q) do { const uint32_t w0_ = (v).a, w1_ = (v).b, w2_ = (v).c, w3_ = (v).d; \
+                const uint32_t sy0_ = (w0_ & 255) | ((w0_ >> 8) & 0xFF00) | ((w1_ & 255) << 16) | ((w1_ >> 16 & 255) << 24); \
+                const uint32_t sy1_ = (w2_ & 255) | ((w2_ >> 8) & 0xFF00) | ((w3_ & 255) << 16) | ((w3_ >> 16 & 255) << 24); \
+                const uint32_t ln_ = ((w0_ >> 8) & 15) | ((w0_ >> 24 & 15) << 4) | (((w1_ >> 8) & 15) << 8) | ((w1_ >> 24 & 15) << 12) | \
+                                     (((w2_ >> 8) & 15) << 16) | ((w2_ >> 24 & 15) << 20) | (((w3_ >> 8) & 15) << 24) | ((w3_ >> 24 & 15) << 28); \
+                ((uint32_t*)L.sym[j])[2 * (lane + 64 * (q))] = sy0_; ((uint32_t*)L.sym[j])[2 * (lane + 64 * (q)) + 1] = sy1_; \
+                ((uint32_t*)L.len[j])[lane + 64 * (q)] = ln_; } while (0)
+            ZP_SPLIT(r0, 0); ZP_SPLIT(r1, 1); ZP_SPLIT(r2, 2); ZP_SPLIT(r3, 3);
+#undef ZP_SPLIT
         }
         zh_sync();
         bool ok = true;
@@ -293,7 +306,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
             const uint32_t f = a.first + i;
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
-            if (!four) { if (strm == 0) ok = zp_huf_stream(L.tab[slot], log, p, streamBytes, lit, litSize); }
+            if (!four) { if (strm == 0) ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p, streamBytes, lit, litSize); }
             else {
                 const uint32_t s1 = zh_ld16(p), s2 = zh_ld16(p + 2), s3 = zh_ld16(p + 4);
                 if (6 + s1 + s2 + s3 > streamBytes) ok = false;
@@ -302,7 +315,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
                     const uint32_t so = strm == 0 ? 0 : strm == 1 ? s1 : strm == 2 ? s1 + s2 : s1 + s2 + s3;
                     const uint32_t sz = strm == 0 ? s1 : strm == 1 ? s2 : strm == 2 ? s3 : streamBytes - 6 - s1 - s2 - s3;
                     const uint32_t n = strm < 3 ? seg : litSize - 3 * seg;
-                    ok = zp_huf_stream(L.tab[slot], log, p + 6 + so, sz, lit + strm * seg, n);
+                    ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p + 6 + so, sz, lit + strm * seg, n);
                 }
             }
         }

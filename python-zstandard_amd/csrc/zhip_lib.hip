@@ -466,7 +466,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g1m = (size_t)c->numCU * (size_t)v; }
             const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;          // K2 takes a whole CU's LDS: one wave per CU
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < (size_t)c->numCU ? w2 : (size_t)c->numCU), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
-            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * 2;      // K1b: 64 KiB of LDS per wave
+            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * 3;      // K1b: 48 KiB of LDS per wave
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
             hipEvent_t ev[4], evh, evh2;
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));

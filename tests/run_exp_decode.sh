@@ -1,7 +1,6 @@
 #!/bin/sh
-# GPU experiment: the default bench line
+# GPU experiment: decode direction at the BASELINE size
 cd /root/repo
 mkdir -p gpurun_out
-timeout 400 python bench.py --no-cpu-baseline > gpurun_out/exp_full.json 2> gpurun_out/exp_full.err
-cut -c80-130 gpurun_out/exp_full.json; python -c "
-import json; d=json.load(open('gpurun_out/exp_full.json')); print(d['compress'])"; tail -n 3 gpurun_out/exp_full.err
+timeout 300 python bench.py --compress-frames 0 --no-cpu-baseline > gpurun_out/exp_d64k.json 2> gpurun_out/exp_d64k.err
+cat gpurun_out/exp_d64k.json | cut -c80-140,560-1000; tail -n 2 gpurun_out/exp_d64k.err
