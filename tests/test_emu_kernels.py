@@ -184,3 +184,38 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
 def test_computed_sequence_codes_match_the_format_tables(emu):
     """the entropy kernel computes LL / ML codes and extra-bit counts instead of reading tables: every length up to one block"""
     assert emu.lib.emu_check_code_formulas() == 0
+
+
+def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
+    """K1 -> KB -> K1b -> K2 -> K3 on libzstd frames that reach the staging paths of K3: literal runs and far matches above and below
+    32 bytes, near matches that start before their batch, overlapped matches (offset < length), raw and RLE blocks, checksums"""
+    import numpy as np
+    from tests import reflib
+    if not reflib.have_ref():
+        pytest.skip("needs oracle/_ref (libzstd 1.5.7) to produce the frames")
+    ref = reflib.RefZstd()
+    rng = np.random.default_rng(5)
+    raws = []
+    for i in range(20):
+        kind = i % 8
+        n = int(rng.integers(1000, 131073))
+        if kind in (0, 1, 2): r = corpus.frame_bytes(int(rng.integers(0, 2000)))[:n]
+        elif kind == 3: r = rng.bytes(n)
+        elif kind == 4:
+            blk = rng.bytes(700); r = ((blk + rng.bytes(3000) + blk * 5 + rng.bytes(100) + blk) * 20)[:n]
+        elif kind == 5:
+            a = bytearray(corpus.frame_bytes(int(rng.integers(0, 2000)))[:n])
+            for k in range(0, len(a), 97): a[k] = int(rng.integers(0, 256))
+            r = bytes(a)
+        elif kind == 6:
+            parts, tot = [], 0
+            while tot < n:
+                m = int(rng.integers(1, 3000)); parts.append(rng.bytes(m) if rng.integers(0, 2) else bytes([int(rng.integers(0, 256))]) * m); tot += m
+            r = b"".join(parts)[:n]
+        else: r = bytes(rng.integers(0, 5, n, dtype=np.uint8))
+        raws.append(r)
+    raws += [b"ab" * 40000, b"x" * 100000, b"0123456789" * 9000]
+    frames = [ref.compress(r, level=3, flags=7 if i % 2 else 5) for i, r in enumerate(raws)]
+    outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws], n_blocks=3, chunk=0)
+    assert not any(st) and nfb == 0
+    assert outs == raws

@@ -133,3 +133,34 @@ def test_partition_by_bytes_matches_reference_rule():
     assert par.partition_by_bytes([5], 4) == [(0, 1)]
     bounds = par.partition_by_bytes(list(range(1, 100)), 8)
     assert bounds[0][0] == 0 and bounds[-1][1] == 99 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+
+
+def test_native_cpu_baseline_driver_runs(ref, corpus):
+    """oracle/libzo_mtbench.so (bench.py's cpu_baseline leg): both directions over a few frames with two threads; the frames it
+    compresses are the reference's, so it must at least succeed and report a positive time"""
+    import ctypes as C
+    import os
+    import subprocess
+    import numpy as np
+    from tests import reflib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "libzo_mtbench.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "libzo_mtbench.so"])
+    lib = C.CDLL(so)
+    lib.zo_mt_bench.restype = C.c_double
+    lib.zo_mt_bench.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    raws = [corpus.frame_bytes(i) for i in range(6)]
+    raw = np.frombuffer(b"".join(raws), dtype=np.uint8)
+    offs = (np.arange(7, dtype=np.uint64) * np.uint64(131072))
+    t = lib.zo_mt_bench(reflib.REF_SO.encode(), 0, raw.ctypes.data, offs.ctypes.data, 6, 0, 3, 2, 1)
+    assert t > 0
+    frames = [ref.compress(r) for r in raws]
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    foffs = np.zeros(7, dtype=np.uint64); foffs[1:] = np.cumsum([len(f) for f in frames])
+    t = lib.zo_mt_bench(reflib.REF_SO.encode(), 1, blob.ctypes.data, foffs.ctypes.data, 6, 131072, 3, 2, 1)
+    assert t > 0
+    # a damaged frame makes the pass fail loudly instead of timing garbage
+    bad = bytearray(blob.tobytes()); bad[int(foffs[2]) + 20] ^= 0xFF
+    badnp = np.frombuffer(bytes(bad), dtype=np.uint8)
+    assert lib.zo_mt_bench(reflib.REF_SO.encode(), 1, badnp.ctypes.data, foffs.ctypes.data, 6, 131072, 3, 2, 1) < 0
