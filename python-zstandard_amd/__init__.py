@@ -29,3 +29,19 @@ def frame_content_size(data):
     if v == _lib.CONTENTSIZE_ERROR:
         raise ZstdError("error when determining content size")
     return -1 if v == _lib.CONTENTSIZE_UNKNOWN else v
+
+
+def load_cext():
+    """The same surface as a CPython extension (cext/backend_hip.c -> backend_hip.so), like the reference's c-ext backend.
+    ``ZSTANDARD_AMD_BACKEND=cext`` makes it the implementation behind this package's names."""
+    import importlib
+    return importlib.import_module(__name__ + ".backend_hip")
+
+
+import os as _os
+if _os.environ.get("ZSTANDARD_AMD_BACKEND") == "cext":
+    _c = load_cext()
+    for _n in ("ZstdCompressor", "ZstdDecompressor", "BufferWithSegments", "BufferWithSegmentsCollection", "BufferSegment",
+               "BufferSegments", "ZstdCompressionDict", "ZstdError", "frame_content_size"):
+        globals()[_n] = getattr(_c, _n)
+    backend = _c.backend

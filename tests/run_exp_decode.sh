@@ -1,6 +1,5 @@
 #!/bin/sh
-# GPU experiment: decode direction at the BASELINE size
+# GPU check of the CPython extension's compute paths
 cd /root/repo
 mkdir -p gpurun_out
-timeout 300 python bench.py --compress-frames 0 --no-cpu-baseline > gpurun_out/exp_d64k.json 2> gpurun_out/exp_d64k.err
-cat gpurun_out/exp_d64k.json | cut -c80-140,560-1000; tail -n 2 gpurun_out/exp_d64k.err
+( timeout 300 python -m pytest tests/test_cext_backend.py -x -q -m gpu 2>&1 | tail -25 ) > gpurun_out/exp_cext.log 2>&1; cat gpurun_out/exp_cext.log

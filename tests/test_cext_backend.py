@@ -1,0 +1,179 @@
+"""The CPython extension (python-zstandard_amd/cext/backend_hip.c) behaves like the reference's C extension for the hot path.
+CPU part: types, argument validation and error messages (mirrors of the reference's tests/test_buffer_util.py and the validation
+branches of its compressor / decompressor tests), object lifetimes. GPU part: its frames and outputs against the oracle and
+against the Python + ctypes mirror of the same surface."""
+import gc
+import struct
+
+import pytest
+
+ss = struct.Struct("=QQ")
+
+
+@pytest.fixture(scope="module")
+def cext():
+    import zstandard_amd
+    return zstandard_amd.load_cext()
+
+
+def test_cext_surface(cext):
+    assert cext.backend == "hip_cext"
+    assert cext.backend_features >= {"buffer_types", "multi_compress_to_buffer", "multi_decompress_to_buffer"}
+    for name in ("ZstdCompressor", "ZstdDecompressor", "BufferWithSegments", "BufferWithSegmentsCollection", "BufferSegment",
+                 "BufferSegments", "ZstdCompressionDict", "ZstdError", "frame_content_size", "MAX_COMPRESSION_LEVEL"):
+        assert hasattr(cext, name)
+    assert cext.frame_content_size(bytes.fromhex("28b52ffd2000010000")) == 0
+    with pytest.raises(cext.ZstdError, match="error when determining content size"):
+        cext.frame_content_size(b"foobarbaz")
+
+
+def test_cext_buffer_with_segments(cext):
+    with pytest.raises(TypeError):
+        cext.BufferWithSegments()
+    with pytest.raises(TypeError):
+        cext.BufferWithSegments(b"foo")
+    with pytest.raises(ValueError, match="segments array size is not a multiple of 16"):
+        cext.BufferWithSegments(b"foo", b"\x00\x00")
+    with pytest.raises(ValueError, match="offset within segments array references memory"):
+        cext.BufferWithSegments(b"foo", ss.pack(0, 4))
+    b = cext.BufferWithSegments(b"foo", ss.pack(0, 3))
+    with pytest.raises(IndexError, match="offset must be non-negative"):
+        b[-10]
+    with pytest.raises(IndexError, match="offset must be less than 1"):
+        b[1]
+    assert len(b) == 1 and b.size == 3 and b.tobytes() == b"foo" and bytes(memoryview(b)) == b"foo"
+    assert len(b[0]) == 3 and b[0].offset == 0 and b[0].tobytes() == b"foo" and bytes(memoryview(b[0])) == b"foo"
+    b = cext.BufferWithSegments(b"foofooxfooxy", b"".join([ss.pack(0, 3), ss.pack(3, 4), ss.pack(7, 5)]))
+    assert len(b) == 3 and b.size == 12
+    assert [b[i].tobytes() for i in range(3)] == [b"foo", b"foox", b"fooxy"] and b[2].offset == 7
+    assert b.segments().tobytes() == b"".join([ss.pack(0, 3), ss.pack(3, 4), ss.pack(7, 5)])
+    assert bytes(memoryview(b.segments())) == b.segments().tobytes()
+    with pytest.raises(TypeError, match="cannot create 'BufferSegment' instances directly"):
+        cext.BufferSegment()
+    with pytest.raises(TypeError, match="cannot create 'BufferSegments' instances directly"):
+        cext.BufferSegments()
+
+
+def test_cext_collection_and_lifetimes(cext):
+    with pytest.raises(ValueError, match="must pass at least 1 argument"):
+        cext.BufferWithSegmentsCollection()
+    with pytest.raises(TypeError, match="arguments must be BufferWithSegments"):
+        cext.BufferWithSegmentsCollection(None)
+    with pytest.raises(ValueError, match="ZstdBufferWithSegments cannot be empty"):
+        cext.BufferWithSegmentsCollection(cext.BufferWithSegments(b"", b""))
+    b1 = cext.BufferWithSegments(b"foo", ss.pack(0, 3))
+    b2 = cext.BufferWithSegments(b"barbaz", b"".join([ss.pack(0, 3), ss.pack(3, 3)]))
+    c = cext.BufferWithSegmentsCollection(b1, b2)
+    assert len(c) == 3 and c.size() == 9
+    with pytest.raises(IndexError, match="offset must be less than 3"):
+        c[3]
+    assert [c[i].tobytes() for i in range(3)] == [b"foo", b"bar", b"baz"]
+    # a segment keeps its buffer alive, a buffer keeps the object it was built from alive
+    payload = bytearray(b"0123456789")
+    seg = cext.BufferWithSegments(payload, ss.pack(2, 5))[0]
+    del c, b1, b2
+    gc.collect()
+    assert seg.tobytes() == b"23456"
+    with pytest.raises(BufferError):
+        payload.extend(b"x")              # the exported buffer pins the bytearray, like the reference's Py_buffer does
+    del seg
+    gc.collect()
+    payload.extend(b"x")
+
+
+def test_cext_argument_validation(cext):
+    with pytest.raises(ValueError, match="level must be less than 23"):
+        cext.ZstdCompressor(level=23)
+    with pytest.raises(TypeError, match="dict_data must be a ZstdCompressionDict"):
+        cext.ZstdCompressor(dict_data=b"raw bytes")
+    c = cext.ZstdCompressor(level=3, write_checksum=True, write_content_size=False, write_dict_id=None, threads=-1)
+    assert c.memory_size() == 0
+    with pytest.raises(TypeError, match="argument must be list of BufferWithSegments"):
+        c.multi_compress_to_buffer(True)
+    with pytest.raises(ValueError, match="no source elements found"):
+        c.multi_compress_to_buffer([])
+    with pytest.raises(ValueError, match="source elements are empty"):
+        c.multi_compress_to_buffer([b"", b""])
+    with pytest.raises(TypeError, match="item 1 not a bytes like object"):
+        c.multi_compress_to_buffer([b"ok", 7])
+    d = cext.ZstdDecompressor()
+    with pytest.raises(TypeError, match="argument must be list or BufferWithSegments"):
+        d.multi_decompress_to_buffer(True)
+    with pytest.raises(TypeError):
+        d.multi_decompress_to_buffer((1, 2))
+    with pytest.raises(TypeError, match="item 0 not a bytes like object"):
+        d.multi_decompress_to_buffer(["foo"])
+    with pytest.raises(ValueError, match="decompressed_sizes size mismatch; expected 16, got 8"):
+        d.multi_decompress_to_buffer([b"a", b"b"], decompressed_sizes=struct.pack("=Q", 1))
+    with pytest.raises(ValueError, match="no source elements found"):
+        d.multi_decompress_to_buffer([])
+    with pytest.raises(cext.ZstdError, match="read_across_frames=True is not yet implemented"):
+        d.decompress(b"whatever", read_across_frames=True)
+    with pytest.raises(cext.ZstdError, match="error determining content size from frame header"):
+        d.decompress(b"")
+    assert d.decompress(bytes.fromhex("28b52ffd2000010000")) == b""        # an empty frame needs no GPU
+    with pytest.raises(cext.ZstdError, match="unable to set decoding format"):
+        cext.ZstdDecompressor(format=cext.FORMAT_ZSTD1_MAGICLESS)
+    assert cext.ZstdCompressionDict(b"\x37\xa4\x30\xec" + struct.pack("<I", 1234) + b"x" * 100).dict_id() == 1234
+    assert cext.ZstdCompressionDict(b"plain content").dict_id() == 0
+    assert cext.ZstdCompressionDict(b"plain content").as_bytes() == b"plain content"
+    with pytest.raises(ValueError, match="invalid dictionary load mode"):
+        cext.ZstdCompressionDict(b"x", dict_type=7)
+    # dictionaries are reference-counted by the contexts that use them
+    import sys
+    dd = cext.ZstdCompressionDict(b"some dictionary content " * 8)
+    before = sys.getrefcount(dd)
+    comp = cext.ZstdCompressor(dict_data=dd)
+    dec = cext.ZstdDecompressor(dict_data=dd)
+    assert sys.getrefcount(dd) == before + 2
+    del comp, dec
+    gc.collect()
+    assert sys.getrefcount(dd) == before
+
+
+@pytest.mark.gpu
+def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracle, corpus):
+    import numpy as np
+    import zstandard_amd as pyz
+    rng = np.random.default_rng(21)
+    raws = [b"f", b"foo" * 4, b"a" * 1000, b"hello world, hello there world! " * 300, rng.bytes(5000), bytes(range(256)) * 20]
+    raws += [corpus.frame_bytes(i)[: 4000 + 9000 * i] for i in range(8)] + [corpus.frame_bytes(33)]
+    c = cext.ZstdCompressor(level=3)
+    res = c.multi_compress_to_buffer(raws)
+    assert len(res) == len(raws) and res[0].offset == 0
+    frames = [res[i].tobytes() for i in range(len(raws))]
+    for r, f in zip(raws, frames):
+        assert f == oracle.compress(r, level=3)
+    mirror = pyz.ZstdCompressor(level=3).multi_compress_to_buffer(raws)
+    assert [mirror[i].tobytes() for i in range(len(raws))] == frames
+    for r in raws[:4]:
+        assert c.compress(r) == oracle.compress(r, level=3)
+    # a BufferWithSegments / collection as input, sizes given and not given
+    d = cext.ZstdDecompressor()
+    out = d.multi_decompress_to_buffer(res)
+    assert [out[i].tobytes() for i in range(len(raws))] == raws
+    sizes = struct.pack("=%dQ" % len(raws), *[len(r) for r in raws])
+    out = d.multi_decompress_to_buffer(frames, decompressed_sizes=sizes)
+    assert [out[i].tobytes() for i in range(len(raws))] == raws and out.size() == sum(map(len, raws))
+    assert d.decompress(frames[7]) == raws[7]
+    # errors carry the reference's messages
+    bad = list(frames)
+    bad[3] = bad[3][:20] + bytes([bad[3][20] ^ 0x55]) + bad[3][21:-7]
+    with pytest.raises(cext.ZstdError, match="error decompressing item 3: "):
+        d.multi_decompress_to_buffer(bad)
+    with pytest.raises(cext.ZstdError, match="error decompressing item 1: decompressed 12 bytes; expected 13"):
+        d.multi_decompress_to_buffer(frames[:3], decompressed_sizes=struct.pack("=3Q", 1, 13, 1000))
+    with pytest.raises(cext.ZstdError, match="compressed input contains 3 bytes of unused data"):
+        d.decompress(frames[2] + b"xyz", allow_extra_data=False)
+    # checksum and dictionary paths through the extension
+    cc = cext.ZstdCompressor(level=3, write_checksum=True)
+    f = cc.compress(raws[8])
+    assert f == oracle.compress(raws[8], level=3, flags=7) and d.decompress(f) == raws[8]
+    dict_bytes = b"".join(corpus.frame_bytes(90 + i)[:700] for i in range(12))
+    dobj = cext.ZstdCompressionDict(dict_bytes, dict_type=cext.DICT_TYPE_RAWCONTENT)
+    small = [corpus.frame_bytes(90 + i)[300:300 + 2000] for i in range(6)]
+    rd = cext.ZstdCompressor(level=3, dict_data=dobj).multi_compress_to_buffer(small)
+    for i, r in enumerate(small):
+        assert rd[i].tobytes() == oracle.compress(r, level=3, dict_data=dict_bytes)
+    od = cext.ZstdDecompressor(dict_data=dobj).multi_decompress_to_buffer(rd)
+    assert [od[i].tobytes() for i in range(len(small))] == small
