@@ -1,0 +1,11 @@
+#!/bin/sh
+# The reference's own hot-path tests (staged by tests/stage_reference_tests.sh) against the CPython extension and the Python mirror.
+# Expected: everything passes except test_dict, which needs zstd.train_dictionary (dictionary training is out of scope).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+cd .reftmp || { echo "run tests/stage_reference_tests.sh first"; exit 1; }
+for b in cext python; do
+  echo "== backend $b"
+  ( SHIM_BACKEND=$b PYTHONPATH="$PWD" timeout 300 python -m pytest -q -p no:cacheprovider tests 2>&1 | tail -30 )
+done > ../gpurun_out/reference_hotpath_tests.log 2>&1
+cat ../gpurun_out/reference_hotpath_tests.log

@@ -1,0 +1,20 @@
+#!/bin/sh
+# Stages throw-away COPIES of the reference's own hot-path tests + a `zstandard` shim into .reftmp/ (git-ignored, never committed;
+# it travels to the GPU box with gpurun, where /root/reference does not exist). Run here, then:
+#   gpurun -- 'sh tests/run_reference_hotpath_tests.sh'
+set -e
+cd "$(dirname "$0")/.."
+REF=${REF:-/root/reference}
+rm -rf .reftmp; mkdir -p .reftmp/zstandard .reftmp/tests
+cat > .reftmp/zstandard/__init__.py <<'PY'
+# throw-away shim (never committed): `import zstandard` in a copy of the reference's tests resolves to this backend
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import zstandard_amd as _z
+_c = _z.load_cext() if os.environ.get("SHIM_BACKEND", "cext") == "cext" else _z
+globals().update({k: getattr(_c, k) for k in dir(_c) if not k.startswith("_")})
+PY
+for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py; do
+  cp "$REF/tests/$f" .reftmp/tests/
+done
+echo "staged $(ls .reftmp/tests | wc -l) files under .reftmp/"
