@@ -9,8 +9,10 @@ The package directory is ``python-zstandard_amd`` (not an identifier); ``import 
 the importable alias.
 """
 from .common import (  # noqa: F401
-    DICT_TYPE_AUTO, DICT_TYPE_FULLDICT, DICT_TYPE_RAWCONTENT, FORMAT_ZSTD1, FORMAT_ZSTD1_MAGICLESS,
-    MAX_COMPRESSION_LEVEL, ZstdCompressionDict, ZstdError,
+    BLOCKSIZE_MAX, COMPRESSION_RECOMMENDED_INPUT_SIZE, COMPRESSION_RECOMMENDED_OUTPUT_SIZE, CONTENTSIZE_ERROR, CONTENTSIZE_UNKNOWN,
+    DECOMPRESSION_RECOMMENDED_INPUT_SIZE, DECOMPRESSION_RECOMMENDED_OUTPUT_SIZE, DICT_TYPE_AUTO, DICT_TYPE_FULLDICT,
+    DICT_TYPE_RAWCONTENT, FORMAT_ZSTD1, FORMAT_ZSTD1_MAGICLESS, MAGIC_NUMBER, MAX_COMPRESSION_LEVEL, WINDOWLOG_MAX, WINDOWLOG_MIN,
+    FrameParameters, ZstdCompressionDict, ZstdError, get_frame_parameters,
 )
 from .buffers import BufferSegment, BufferSegments, BufferWithSegments, BufferWithSegmentsCollection  # noqa: F401
 from .compressor import ZstdCompressor  # noqa: F401
@@ -42,6 +44,6 @@ import os as _os
 if _os.environ.get("ZSTANDARD_AMD_BACKEND") == "cext":
     _c = load_cext()
     for _n in ("ZstdCompressor", "ZstdDecompressor", "BufferWithSegments", "BufferWithSegmentsCollection", "BufferSegment",
-               "BufferSegments", "ZstdCompressionDict", "ZstdError", "frame_content_size"):
+               "BufferSegments", "ZstdCompressionDict", "ZstdError", "frame_content_size", "get_frame_parameters", "FrameParameters"):
         globals()[_n] = getattr(_c, _n)
     backend = _c.backend

@@ -559,6 +559,55 @@ static PyMethodDef decomp_methods[] = {
     { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "host memory held by the context" },
     { NULL, NULL, 0, NULL } };
 
+/* ------------------------------------------------------------------------------------------ FrameParameters (c-ext/frameparams.c) */
+typedef struct { PyObject_HEAD unsigned long long contentSize, windowSize; unsigned dictID; char checksumFlag; } FrameParameters;
+static PyTypeObject FrameParametersType = { PyVarObject_HEAD_INIT(NULL, 0) };
+static void fp_dealloc(FrameParameters* self) { Py_TYPE(self)->tp_free((PyObject*)self); }
+static PyMemberDef fp_members[] = {
+    { "content_size", T_ULONGLONG, offsetof(FrameParameters, contentSize), READONLY, "frame content size" },
+    { "window_size", T_ULONGLONG, offsetof(FrameParameters, windowSize), READONLY, "window size" },
+    { "dict_id", T_UINT, offsetof(FrameParameters, dictID), READONLY, "dictionary ID" },
+    { "has_checksum", T_BOOL, offsetof(FrameParameters, checksumFlag), READONLY, "checksum flag" },
+    { NULL, 0, 0, 0, NULL } };
+
+/* frame header parse on the host (RFC 8878 3.1.1.1; ZSTD_getFrameHeader_advanced zstd.c:43668) */
+static PyObject* mod_get_frame_parameters(PyObject* self, PyObject* args, PyObject* kwargs)
+{
+    (void)self;
+    static char* kwlist[] = { "data", "format", NULL };
+    Py_buffer src; unsigned format = FORMAT_ZSTD1;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "y*|I:get_frame_parameters", kwlist, &src, &format)) return NULL;
+    const unsigned char* p = (const unsigned char*)src.buf; const size_t n = (size_t)src.len;
+    PyObject* result = NULL;
+    if (format != FORMAT_ZSTD1) { PyErr_SetString(ZstdError, "cannot get frame parameters: only FORMAT_ZSTD1 is supported by the HIP backend"); goto done; }
+    if (n < 5) { PyErr_Format(ZstdError, "not enough data for frame parameters; need %zu bytes", (size_t)5); goto done; }
+    if (!(p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD)) { PyErr_SetString(ZstdError, "cannot get frame parameters: Unknown frame descriptor"); goto done; }
+    {
+        const unsigned fhd = p[4], fcsCode = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, didCode = fhd & 3;
+        if (fhd & 8) { PyErr_SetString(ZstdError, "cannot get frame parameters: Unsupported frame parameter"); goto done; }
+        static const size_t didSizes[4] = { 0, 1, 2, 4 };
+        const size_t didSize = didSizes[didCode], fcsSize = fcsCode == 0 ? (single ? 1 : 0) : fcsCode == 1 ? 2 : fcsCode == 2 ? 4 : 8;
+        const size_t need = 5 + (single ? 0 : 1) + didSize + fcsSize;
+        if (n < need) { PyErr_Format(ZstdError, "not enough data for frame parameters; need %zu bytes", need); goto done; }
+        size_t pos = 5; unsigned long long window = 0, content = ZHIP_CONTENTSIZE_UNKNOWN; unsigned dictID = 0;
+        if (!single) {
+            const unsigned b = p[pos++], wlog = 10 + (b >> 3);
+            if (wlog > 31) { PyErr_SetString(ZstdError, "cannot get frame parameters: Frame requires too much memory for decoding"); goto done; }
+            window = (1ull << wlog) + ((1ull << wlog) >> 3) * (b & 7);
+        }
+        for (size_t i = 0; i < didSize; i++) dictID |= (unsigned)p[pos + i] << (8 * i);
+        pos += didSize;
+        if (fcsSize) { content = 0; for (size_t i = 0; i < fcsSize; i++) content |= (unsigned long long)p[pos + i] << (8 * i); if (fcsSize == 2) content += 256; }
+        if (single) window = content;
+        FrameParameters* r = (FrameParameters*)FrameParametersType.tp_alloc(&FrameParametersType, 0);
+        if (r) { r->contentSize = content; r->windowSize = window; r->dictID = dictID; r->checksumFlag = (char)checksum; }
+        result = (PyObject*)r;
+    }
+done:
+    PyBuffer_Release(&src);
+    return result;
+}
+
 /* ------------------------------------------------------------------------------------------ module */
 static PyObject* mod_frame_content_size(PyObject* self, PyObject* args)
 {
@@ -571,7 +620,10 @@ static PyObject* mod_frame_content_size(PyObject* self, PyObject* args)
     if (v == ZHIP_CONTENTSIZE_UNKNOWN) return PyLong_FromLong(-1);
     return PyLong_FromUnsignedLongLong(v);
 }
-static PyMethodDef module_methods[] = { { "frame_content_size", mod_frame_content_size, METH_VARARGS, "content size of a frame, -1 if unknown" }, { NULL, NULL, 0, NULL } };
+static PyMethodDef module_methods[] = {
+    { "frame_content_size", mod_frame_content_size, METH_VARARGS, "content size of a frame, -1 if unknown" },
+    { "get_frame_parameters", (PyCFunction)mod_get_frame_parameters, METH_VARARGS | METH_KEYWORDS, "parse a frame header" },
+    { NULL, NULL, 0, NULL } };
 static struct PyModuleDef moduledef = { PyModuleDef_HEAD_INIT, "backend_hip", "python-zstandard hot path on MI355X: CPython extension over libzstd_hip.so", -1, module_methods, 0, 0, 0, 0 };
 
 static int no_direct_init(PyObject* self, PyObject* args, PyObject* kwargs)
@@ -610,9 +662,12 @@ PyMODINIT_FUNC PyInit_backend_hip(void)
     READY(DecompressorType, "ZstdDecompressor", sizeof(Decompressor), decomp_dealloc, decomp_init, "batch / one-shot decompressor (HIP kernels)");
     DecompressorType.tp_methods = decomp_methods;
 
-    PyTypeObject* types[] = { &BufferWithSegmentsType, &BufferSegmentType, &BufferSegmentsType, &BufferCollectionType, &CompressionDictType, &CompressorType, &DecompressorType };
-    const char* names[] = { "BufferWithSegments", "BufferSegment", "BufferSegments", "BufferWithSegmentsCollection", "ZstdCompressionDict", "ZstdCompressor", "ZstdDecompressor" };
-    for (int i = 0; i < 7; i++) {
+    READY(FrameParametersType, "FrameParameters", sizeof(FrameParameters), fp_dealloc, no_direct_init, "what a frame header says");
+    FrameParametersType.tp_members = fp_members;
+
+    PyTypeObject* types[] = { &BufferWithSegmentsType, &BufferSegmentType, &BufferSegmentsType, &BufferCollectionType, &CompressionDictType, &CompressorType, &DecompressorType, &FrameParametersType };
+    const char* names[] = { "BufferWithSegments", "BufferSegment", "BufferSegments", "BufferWithSegmentsCollection", "ZstdCompressionDict", "ZstdCompressor", "ZstdDecompressor", "FrameParameters" };
+    for (int i = 0; i < 8; i++) {
         if (PyType_Ready(types[i]) < 0) { Py_DECREF(m); return NULL; }
         Py_INCREF(types[i]);
         if (PyModule_AddObject(m, names[i], (PyObject*)types[i]) < 0) { Py_DECREF(m); return NULL; }
@@ -622,6 +677,15 @@ PyMODINIT_FUNC PyInit_backend_hip(void)
     PyModule_AddIntConstant(m, "MAX_COMPRESSION_LEVEL", MAX_COMPRESSION_LEVEL);
     PyModule_AddIntConstant(m, "DICT_TYPE_AUTO", DICT_TYPE_AUTO); PyModule_AddIntConstant(m, "DICT_TYPE_RAWCONTENT", DICT_TYPE_RAWCONTENT);
     PyModule_AddIntConstant(m, "DICT_TYPE_FULLDICT", DICT_TYPE_FULLDICT);
+    PyModule_AddObject(m, "CONTENTSIZE_UNKNOWN", PyLong_FromUnsignedLongLong(ZHIP_CONTENTSIZE_UNKNOWN));
+    PyModule_AddObject(m, "CONTENTSIZE_ERROR", PyLong_FromUnsignedLongLong(ZHIP_CONTENTSIZE_ERROR));
+    PyModule_AddObject(m, "MAGIC_NUMBER", PyLong_FromUnsignedLong(0xFD2FB528ul));
+    PyModule_AddIntConstant(m, "BLOCKSIZE_MAX", 1 << 17);
+    PyModule_AddIntConstant(m, "COMPRESSION_RECOMMENDED_INPUT_SIZE", 1 << 17);
+    PyModule_AddIntConstant(m, "COMPRESSION_RECOMMENDED_OUTPUT_SIZE", (1 << 17) + 512 + 3 + 4);
+    PyModule_AddIntConstant(m, "DECOMPRESSION_RECOMMENDED_INPUT_SIZE", (1 << 17) + 3);
+    PyModule_AddIntConstant(m, "DECOMPRESSION_RECOMMENDED_OUTPUT_SIZE", 1 << 17);
+    PyModule_AddIntConstant(m, "WINDOWLOG_MIN", 10); PyModule_AddIntConstant(m, "WINDOWLOG_MAX", 31);
     PyModule_AddStringConstant(m, "backend", "hip_cext");
     {   PyObject* feats = PySet_New(NULL);
         const char* f[] = { "buffer_types", "multi_compress_to_buffer", "multi_decompress_to_buffer" };

@@ -14,7 +14,8 @@ import zstandard_amd as _z
 _c = _z.load_cext() if os.environ.get("SHIM_BACKEND", "cext") == "cext" else _z
 globals().update({k: getattr(_c, k) for k in dir(_c) if not k.startswith("_")})
 PY
-for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py; do
+for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py \
+         test_compressor_compress.py test_decompressor_decompress.py; do
   cp "$REF/tests/$f" .reftmp/tests/
 done
 echo "staged $(ls .reftmp/tests | wc -l) files under .reftmp/"

@@ -177,3 +177,27 @@ def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracl
         assert rd[i].tobytes() == oracle.compress(r, level=3, dict_data=dict_bytes)
     od = cext.ZstdDecompressor(dict_data=dobj).multi_decompress_to_buffer(rd)
     assert [od[i].tobytes() for i in range(len(small))] == small
+
+
+def test_get_frame_parameters_both_implementations(cext, ref):
+    """values pinned by the reference's tests (test_compressor_compress.py:16-30, :90-116) and cross-checked between the two host
+    implementations on libzstd frames"""
+    import zstandard_amd as pyz
+    frames = [bytes.fromhex("28b52ffd0000010000"), bytes.fromhex("28b52ffd2000010000"), ref.compress(b"foobar" * 256),
+              ref.compress(b"foobar" * 256, flags=6), ref.compress(b"x" * 70000, flags=7), ref.compress(b"q" * 300000)]
+    for mod in (pyz, cext):
+        p = mod.get_frame_parameters(frames[0])
+        assert (p.content_size, p.window_size, p.dict_id, p.has_checksum) == (mod.CONTENTSIZE_UNKNOWN, 1024, 0, False)
+        assert mod.get_frame_parameters(frames[1]).content_size == 0
+        assert mod.get_frame_parameters(frames[2]).content_size == 1536
+        p = mod.get_frame_parameters(frames[3])
+        assert p.content_size == mod.CONTENTSIZE_UNKNOWN and p.has_checksum
+        with pytest.raises(mod.ZstdError, match="not enough data for frame parameters; need 5 bytes"):
+            mod.get_frame_parameters(b"")
+        with pytest.raises(mod.ZstdError, match="cannot get frame parameters: Unknown frame descriptor"):
+            mod.get_frame_parameters(b"foobarbaz")
+        assert mod.COMPRESSION_RECOMMENDED_INPUT_SIZE == 131072 and mod.WINDOWLOG_MIN == 10
+    for f in frames:
+        a, b = pyz.get_frame_parameters(f), cext.get_frame_parameters(f)
+        assert (a.content_size, a.window_size, a.dict_id, a.has_checksum) == (b.content_size, b.window_size, b.dict_id, b.has_checksum)
+        assert a.content_size == ref.frame_content_size(f)
