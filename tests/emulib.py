@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
-EMU_SO = os.path.join(_DIR, "libzhip_emu.so")
+EMU_SO = os.environ.get("ZHIP_EMU_SO") or os.path.join(_DIR, "libzhip_emu.so")      # ZHIP_EMU_SO: e.g. the ASan build (tests/emu/build_asan.sh)
 
 
 def build():
