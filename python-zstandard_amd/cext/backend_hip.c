@@ -372,13 +372,25 @@ static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
     PyObject *dict = NULL, *params = NULL, *writeChecksum = NULL, *writeContentSize = NULL, *writeDictID = NULL;
     if (!PyArg_ParseTupleAndKeywords(args, kwargs, "|iOOOOOi:ZstdCompressor", kwlist, &level, &dict, &params, &writeChecksum, &writeContentSize, &writeDictID, &threads)) return -1;
     if (level > MAX_COMPRESSION_LEVEL) { PyErr_Format(PyExc_ValueError, "level must be less than %d", MAX_COMPRESSION_LEVEL + 1); return -1; }
-    if (params && params != Py_None) { PyErr_SetString(ZstdError, "compression_params is not supported by the HIP backend; pass level="); return -1; }
+    if (writeChecksum == Py_None) writeChecksum = NULL;
+    if (writeContentSize == Py_None) writeContentSize = NULL;
+    if (writeDictID == Py_None) writeDictID = NULL;
+    if (params && params != Py_None) {
+        /* the reference's mutual-exclusion checks come first (compressor.c:177-200) ... */
+        if (writeChecksum) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_checksum"); return -1; }
+        if (writeContentSize) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_content_size"); return -1; }
+        if (writeDictID) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_dict_id"); return -1; }
+        if (threads) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and threads"); return -1; }
+        /* ... explicit compression parameters themselves are not plumbed to the kernels yet: fail loudly */
+        PyErr_SetString(ZstdError, "compression_params is not supported by the HIP backend; pass level=");
+        return -1;
+    }
     if (dict == Py_None) dict = NULL;
     if (dict && !PyObject_TypeCheck(dict, &CompressionDictType)) { PyErr_SetString(PyExc_TypeError, "dict_data must be a ZstdCompressionDict"); return -1; }
     self->level = level;
-    self->writeChecksum = (writeChecksum && writeChecksum != Py_None) ? PyObject_IsTrue(writeChecksum) : 0;
-    self->writeContentSize = (writeContentSize && writeContentSize != Py_None) ? PyObject_IsTrue(writeContentSize) : 1;
-    self->writeDictID = (writeDictID && writeDictID != Py_None) ? PyObject_IsTrue(writeDictID) : 1;
+    self->writeChecksum = writeChecksum ? PyObject_IsTrue(writeChecksum) : 0;
+    self->writeContentSize = writeContentSize ? PyObject_IsTrue(writeContentSize) : 1;
+    self->writeDictID = writeDictID ? PyObject_IsTrue(writeDictID) : 1;
     Py_XINCREF(dict); Py_XSETREF(self->dict, dict);
     return 0;
 }

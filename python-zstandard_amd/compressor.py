@@ -19,6 +19,12 @@ class ZstdCompressor:
         if threads < 0:
             threads = 0
         if compression_params is not None:
+            # the reference's mutual-exclusion checks come first (compressor.c:177-200) ...
+            for given, name in ((write_checksum, "write_checksum"), (write_content_size, "write_content_size"),
+                                (write_dict_id, "write_dict_id"), (threads or None, "threads")):
+                if given is not None:
+                    raise ValueError("cannot define compression_params and %s" % name)
+            # ... explicit compression parameters themselves are not plumbed to the kernels yet: fail loudly
             raise ZstdError("compression_params is not supported by the HIP backend; pass level=")
         if dict_data is not None and not isinstance(dict_data, ZstdCompressionDict):
             raise TypeError("dict_data must be a ZstdCompressionDict")

@@ -184,6 +184,22 @@ def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracl
     assert [od[i].tobytes() for i in range(len(small))] == small
 
 
+def test_compression_params_conflicts_both_implementations(cext):
+    """compressor.c:177-200: a compression_params object excludes the individual flags (ValueError first); the object itself is
+    refused loudly because explicit parameters are not plumbed to the kernels"""
+    import zstandard_amd as pyz
+    marker = object()
+    for mod in (pyz, cext):
+        for kw, name in (({"write_checksum": True}, "write_checksum"), ({"write_content_size": False}, "write_content_size"),
+                         ({"write_dict_id": True}, "write_dict_id"), ({"threads": 2}, "threads")):
+            with pytest.raises(ValueError, match="cannot define compression_params and %s" % name):
+                mod.ZstdCompressor(compression_params=marker, **kw)
+        with pytest.raises(mod.ZstdError, match="compression_params is not supported"):
+            mod.ZstdCompressor(compression_params=marker, write_checksum=None, write_content_size=None, write_dict_id=None, threads=0)
+        mod.ZstdCompressor(level=3, dict_data=None, compression_params=None, write_checksum=None, write_content_size=None,
+                           write_dict_id=None, threads=0)
+
+
 def test_get_frame_parameters_both_implementations(cext, ref):
     """values pinned by the reference's tests (test_compressor_compress.py:16-30, :90-116) and cross-checked between the two host
     implementations on libzstd frames"""
