@@ -601,6 +601,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         const uint64_t nearMask = zh_ballot(pending);
         need &= nearMask;                       // literals and far matches are already in the buffer
         uint64_t doneMask = ~nearMask;
+#ifndef ZP_K3_LONGALL
         for (;;) {
             const uint64_t pend = zh_ballot(pending);
             if (!pend) break;
@@ -654,6 +655,67 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             }
             zh_sync();
         }
+#else
+        // EXPERIMENTAL (-DZP_K3_LONGALL; emulator-verified, not yet measured on hardware): a round serves its ready short matches AND
+        // every ready long match (one after the other by the whole wave) instead of one long match per round: what is ready at the
+        // start of a round never depends on anything else that is ready in it.
+        for (;;) {
+            const uint64_t pend = zh_ballot(pending);
+            if (!pend) break;
+            const uint64_t longReady = zh_ballot(pending && myML > ZD_COOP_LEN && (need & ~doneMask) == 0);
+            {
+                const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
+                if (ready) {
+                    // what is left of the match lies in the assembly buffer: source nSrc, destination nSrc + myOF, nLen bytes
+                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
+                    if (myOF >= nLen) {
+                        uint64_t rr[4];
+                        zd_ld32(asmb + nSrc, nLen, rr);
+                        zd_st32(asmb + nDst, nLen, rr);
+                    } else {
+                        // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
+                        // step can copy as much as is already final -- the copied length doubles instead of advancing a byte at a time
+                        uint32_t done = 0;
+                        while (done < nLen) {
+                            const uint32_t ph = done % myOF;
+                            uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
+                            uint64_t rr[4];
+                            zd_ld32(asmb + nSrc + ph, c, rr);
+                            zd_st32(asmb + nDst + done, c, rr);
+                            done += c;
+                        }
+                    }
+                    pending = false;
+                }
+                uint64_t newDone = zh_ballot(ready);
+                for (uint64_t lm = longReady; lm; lm &= lm - 1) {
+                    const uint32_t pf = (uint32_t)zh_ctz64(lm);
+                // whole wave copies one long ready match
+                    const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
+                    const int32_t fs = (int32_t)(op + Frel) - (int32_t)fof;
+                    if (fof >= 64) {
+                        for (uint32_t c = 0; c < fml; c += 64) {
+                            const uint32_t j = c + lane;
+                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp]; }
+                            if (fof < fml) zh_sync();
+                        }
+                    } else {
+                        uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
+                        for (uint32_t j = lane; j < fml; j += 64) {
+                            const int32_t sp = fs + (int32_t)idx;
+                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp];
+                            idx += adv; if (idx >= fof) idx -= fof;
+                        }
+                    }
+                    if (lane == pf) pending = false;
+                    newDone |= 1ull << pf;
+                    if (lm & (lm - 1)) zh_sync();
+                }
+                doneMask |= newDone;
+            }
+            zh_sync();
+        }
+#endif
         ZD_T(P, ZP_EXEC2);
         {
             uint8_t* out = dst + op;

@@ -1311,7 +1311,8 @@ ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog
     return 2;
 }
 // ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat)
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat,
+                                     uint8_t* cellSym, uint16_t* fill, int16_t* norm)
 {
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
     const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
@@ -1332,14 +1333,13 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
         return 0;
     }
     if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
-    int16_t* const norm = ze_norm_area(L);
-    if (*mode == 0) { for (uint32_t s = 0; s <= defMax; s++) norm[s] = defNorm[s]; ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, defMax, defLog); return 0; }
+    if (*mode == 0) { for (uint32_t s = 0; s <= defMax; s++) norm[s] = defNorm[s]; ze_fse_build_ctab(t, cellSym, fill, norm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
     uint32_t n1 = nbSeq;
     if (count[lastCode] > 1) { count[lastCode]--; n1--; }
     ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
     const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
-    ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, max, lg);
+    ze_fse_build_ctab(t, cellSym, fill, norm, max, lg);
     return h;
 }
 // ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755) and the extra-bit counts (LL_bits / ML_bits), computed: the reference's lookup
@@ -1634,6 +1634,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     ze_fence();
     zh_sync();
     ZE_T(P, ZEP_SEQSTAT);
+#ifndef ZE_TAB3
     if (zh_opaque(lane) == 0) {
         uint8_t* op = out + pos;
         uint32_t lastCount = 0;
@@ -1644,13 +1645,47 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; uint32_t h;
             const uint32_t c0 = L.misc[8], c1 = L.misc[9];
-            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, (uint32_t)cp.strat); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, (uint32_t)cp.strat); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, (uint32_t)cp.strat); if (mML == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
         }
         L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
     }
+#else
+    // EXPERIMENTAL (-DZE_TAB3; emulator-verified, not yet measured on hardware): the three tables are independent, so lanes 0..2 build
+    // LL / OF / ML at the same time, each with its own scratch inside the tree-node area and its table description written to an
+    // LDS slot; lane 0 then lays the descriptions out in order.
+    if (nbSeq && zh_opaque(lane) < 3) {
+        uint8_t* const nodeB = (uint8_t*)L.node;
+        const uint32_t c0 = L.misc[8], c1 = L.misc[9];
+        int md = 0;
+        const uint32_t h = ze_build_seq_table(L, (int)lane, nodeB + 3328 + 80 * lane, &md, (c0 >> (8 * lane)) & 255, (c1 >> (8 * lane)) & 255, nbSeq, cd, (uint32_t)cp.strat,
+                                              nodeB + 1024 + 512 * lane, (uint16_t*)(nodeB + 2560 + 128 * lane), (int16_t*)(nodeB + 2944 + 128 * lane));
+        L.misc[4 + lane] = h | ((uint32_t)md << 16);
+    }
+    zh_sync();
+    if (zh_opaque(lane) == 0) {
+        uint8_t* op = out + pos;
+        uint32_t lastCount = 0;
+        if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
+        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
+        else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
+        if (nbSeq) {
+            uint8_t* seqHead = op++;
+            uint32_t modes[3];
+            for (uint32_t t = 0; t < 3; t++) {
+                const uint32_t h = L.misc[4 + t] & 0xFFFF; modes[t] = L.misc[4 + t] >> 16;
+                const uint8_t* hd = (const uint8_t*)L.node + 3328 + 80 * t;
+                for (uint32_t k = 0; k < h; k++) op[k] = hd[k];
+                if (modes[t] == 2) lastCount = h;
+                op += h;
+            }
+            *seqHead = (uint8_t)((modes[0] << 6) + (modes[1] << 4) + (modes[2] << 2));
+        }
+        L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
+    }
+#endif
     ze_fence();
     zh_sync();
     const uint32_t seqStart = zh_first(L.misc[10]), lastCount = zh_first(L.misc[3]);

@@ -13,11 +13,19 @@ def build():
     subprocess.check_call(["sh", os.path.join(_DIR, "build.sh")])
 
 
+def build_variant(out_path, defines):
+    """the same sources with extra -D flags (experimental kernel variants), e.g. ["-DZE_TAB3", "-DZP_K3_LONGALL"]"""
+    subprocess.check_call(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable"] + list(defines) +
+                          ["-o", out_path, os.path.join(_DIR, "zhemu.cpp"), os.path.join(_DIR, "emu_kernels.cpp")])
+    return out_path
+
+
 class Emu:
-    def __init__(self):
-        if not os.path.exists(EMU_SO):
+    def __init__(self, so_path=None):
+        path = so_path or EMU_SO
+        if not os.path.exists(path):
             build()
-        self.lib = C.CDLL(EMU_SO)
+        self.lib = C.CDLL(path)
 
     def parse_dict(self, dict_bytes):
         """returns (entropy blob or None, content bytes, dictID) using the device dictionary parser under emulation"""

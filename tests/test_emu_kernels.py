@@ -219,3 +219,25 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
     outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws], n_blocks=3, chunk=0)
     assert not any(st) and nfb == 0
     assert outs == raws
+
+
+def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
+    """-DZE_TAB3 (three-lane sequence-table build in the entropy kernel) and -DZP_K3_LONGALL (all ready long matches per dependency
+    round in K3) are compiled out of the product by default (emulator-verified, not yet measured on hardware): keep them
+    bit-exact so that the next GPU session can measure them straight away"""
+    import numpy as np
+    from tests import emulib
+    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZE_TAB3", "-DZP_K3_LONGALL"])
+    emu = emulib.Emu(so)
+    rng = np.random.default_rng(11)
+    blk = rng.bytes(600)
+    raws = [corpus.frame_bytes(i)[: 5000 + 21000 * i] for i in range(6)] + [b"ab" * 20000, (blk + rng.bytes(2000) + blk * 4 + rng.bytes(50) + blk) * 12,
+            rng.bytes(30000), b"x" * 7, b"hello " * 11, bytes(rng.integers(0, 4, 50000, dtype=np.uint8))]
+    outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=2, pipeline=True)
+    assert not any(st)
+    frames = [oracle.compress(r, level=3) for r in raws]
+    assert outs == frames
+    big = [r for r in raws if len(r) > 100]
+    bigf = [oracle.compress(r, level=3, flags=7) for r in big]
+    dec, st, nfb = emu.decompress_pipeline(bigf, [len(r) for r in big], n_blocks=3, chunk=0)
+    assert not any(st) and dec == big
