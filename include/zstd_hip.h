@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ZHIP_ABI_VERSION 1
+#define ZHIP_ABI_VERSION 2
 
 typedef struct { uint64_t offset, length; } zhip_segment;             /* BufferSegment */
 typedef struct { const void* src; size_t srcSize; size_t dstSize; } zhip_item; /* dstSize: decompress only (0 = unknown) */
@@ -54,17 +54,36 @@ typedef struct {
     uint64_t detail[2];  /* size mismatch: produced, expected */
 } zhip_error;
 
+/* dictionary content type == ZSTD_dictContentType_e (zstd/zstd.h; ZstdCompressionDict(data, dict_type=...), c-ext/compressiondict.c:170-191,
+ * consumed at c-ext/compressor.c:37-52 and c-ext/compressiondict.c:148-162): AUTO = a blob that starts with the dictionary magic is a
+ * full dictionary, anything else raw content; RAWCONTENT = content whatever the first bytes are; FULLDICT = the magic is required
+ * (compression reports "Dictionary mismatch", decompression "Dictionary is corrupted", as libzstd does). */
+enum { ZHIP_DICT_AUTO = 0, ZHIP_DICT_RAWCONTENT = 1, ZHIP_DICT_FULLDICT = 2 };
+/* frame format == ZSTD_format_e (ZstdCompressionParameters(format=...), ZstdDecompressor(format=...), c-ext/decompressor.c:32-35):
+ * MAGICLESS frames have no 4-byte magic number in front of the frame header. */
+enum { ZHIP_FORMAT_ZSTD1 = 0, ZHIP_FORMAT_ZSTD1_MAGICLESS = 1 };
+/* explicit compression parameters == ZSTD_compressionParameters; the reference keeps them in the ZSTD_CCtx_params it applies to every
+ * worker context (c-ext/compressor.c:20,203,1138; c-ext/compressionparams.c:13-120). 0 = "take it from the level" for each field,
+ * exactly like ZSTD_CCtxParams_setParameter(…, 0). strategy: 1 = fast, 2 = dfast are the strategies this backend implements; a
+ * combination that resolves to any other strategy fails loudly with ZHIP_ERR_UNSUPPORTED. */
+typedef struct { uint32_t windowLog, chainLog, hashLog, searchLog, minMatch, targetLength; int32_t strategy; } zhip_compression_parameters;
+
 /* compression parameters the hot path reads (the reference keeps them in ZSTD_CCtx_params,
  * c-ext/compressor.c:209-233; defaults there: contentSize=1, checksum=0, dictID=1). */
 typedef struct {
     int level;
     int contentSizeFlag, checksumFlag, dictIDFlag;
     const void* dict; size_t dictSize;      /* raw bytes of a ZstdCompressionDict (or NULL) */
+    int dictType;                           /* ZHIP_DICT_* */
+    int format;                             /* ZHIP_FORMAT_* */
+    zhip_compression_parameters cp;         /* all zero = derive everything from `level` */
 } zhip_cparams;
 
 typedef struct {
     const void* dict; size_t dictSize;      /* raw bytes of a ZstdCompressionDict (or NULL) */
     uint64_t maxWindowSize;                 /* 0 = default (1 << 27) */
+    int dictType;                           /* ZHIP_DICT_* */
+    int format;                             /* ZHIP_FORMAT_* */
 } zhip_dparams;
 
 /* ---- library / device ---- */
@@ -81,6 +100,12 @@ size_t      zhip_compress_bound(size_t srcSize);     /* ZSTD_compressBound, zstd
 #define ZHIP_CONTENTSIZE_ERROR   ((uint64_t)-2)
 uint64_t zhip_frame_content_size(const void* src, size_t srcSize);
 int64_t  zhip_find_frame_compressed_size(const void* src, size_t srcSize);  /* <0: -(zstd error code) */
+/* the same with an explicit frame format (ZSTD_getFrameHeader_advanced zstd.c:43668, ZSTD_findFrameCompressedSize_advanced) */
+uint64_t zhip_frame_content_size_format(const void* src, size_t srcSize, int format);
+int64_t  zhip_find_frame_compressed_size_format(const void* src, size_t srcSize, int format);
+/* level + size hints -> the parameters libzstd would use (ZSTD_getCParams zstd.c:30863; ZstdCompressionParameters.from_level,
+ * c-ext/compressionparams.c:231-345). Host only. */
+void     zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out);
 
 /* ---- host-buffer batch API (drop-in for the reference's workers) ----
  * items are borrowed; *out is an array of *nOut malloc()ed buffers the caller owns (free each data/segs, then the
@@ -98,7 +123,8 @@ void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload);
 typedef struct zhip_ctx zhip_ctx;
 zhip_ctx* zhip_ctx_create(void);
 void      zhip_ctx_destroy(zhip_ctx*);
-int       zhip_ctx_set_ddict(zhip_ctx*, const void* hostDict, size_t dictSize);   /* parses + uploads; NULL clears */
+int       zhip_ctx_set_ddict(zhip_ctx*, const void* hostDict, size_t dictSize, int dictType);   /* parses + uploads; NULL clears */
+int       zhip_ctx_set_dformat(zhip_ctx*, int format, uint64_t maxWindowSize);     /* frame format + window limit of the next decode calls */
 int       zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams* params);            /* uploads dict / tables */
 
 /* d_src: concatenated frames; d_srcSegs[i] = (offset,length) of frame i in d_src.

@@ -30,13 +30,24 @@ class Error(C.Structure):
     _fields_ = [("kind", C.c_int), ("zstdErr", C.c_int), ("index", C.c_size_t), ("detail", C.c_uint64 * 2)]
 
 
+class CompressionParameters(C.Structure):
+    _fields_ = [("windowLog", C.c_uint32), ("chainLog", C.c_uint32), ("hashLog", C.c_uint32), ("searchLog", C.c_uint32),
+                ("minMatch", C.c_uint32), ("targetLength", C.c_uint32), ("strategy", C.c_int32)]
+
+
 class CParams(C.Structure):
     _fields_ = [("level", C.c_int), ("contentSizeFlag", C.c_int), ("checksumFlag", C.c_int), ("dictIDFlag", C.c_int),
-                ("dict", C.c_void_p), ("dictSize", C.c_size_t)]
+                ("dict", C.c_void_p), ("dictSize", C.c_size_t), ("dictType", C.c_int), ("format", C.c_int),
+                ("cp", CompressionParameters)]
 
 
 class DParams(C.Structure):
-    _fields_ = [("dict", C.c_void_p), ("dictSize", C.c_size_t), ("maxWindowSize", C.c_uint64)]
+    _fields_ = [("dict", C.c_void_p), ("dictSize", C.c_size_t), ("maxWindowSize", C.c_uint64), ("dictType", C.c_int),
+                ("format", C.c_int)]
+
+
+DICT_AUTO, DICT_RAWCONTENT, DICT_FULLDICT = 0, 1, 2
+FORMAT_ZSTD1, FORMAT_ZSTD1_MAGICLESS = 0, 1
 
 
 _lib = None
@@ -69,6 +80,9 @@ def lib():
         "zhip_compress_bound": (sz, [sz]),
         "zhip_frame_content_size": (u64, [vp, sz]),
         "zhip_find_frame_compressed_size": (C.c_int64, [vp, sz]),
+        "zhip_frame_content_size_format": (u64, [vp, sz, C.c_int]),
+        "zhip_find_frame_compressed_size_format": (C.c_int64, [vp, sz, C.c_int]),
+        "zhip_get_cparams": (None, [C.c_int, u64, sz, C.POINTER(CompressionParameters)]),
         "zhip_compress_batch": (C.c_int, [C.POINTER(CParams), C.POINTER(Item), sz, C.POINTER(C.POINTER(OutBuf)),
                                           C.POINTER(sz), C.POINTER(Error)]),
         "zhip_decompress_batch": (C.c_int, [C.POINTER(DParams), C.POINTER(Item), sz, C.c_int,
@@ -76,7 +90,8 @@ def lib():
         "zhip_free_outbufs": (None, [C.POINTER(OutBuf), sz, C.c_int]),
         "zhip_ctx_create": (vp, []),
         "zhip_ctx_destroy": (None, [vp]),
-        "zhip_ctx_set_ddict": (C.c_int, [vp, vp, sz]),
+        "zhip_ctx_set_ddict": (C.c_int, [vp, vp, sz, C.c_int]),
+        "zhip_ctx_set_dformat": (C.c_int, [vp, C.c_int, u64]),
         "zhip_ctx_set_cparams": (C.c_int, [vp, C.POINTER(CParams)]),
         "zhip_decompress_batch_device": (C.c_int, [vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "zhip_compress_batch_device": (C.c_int, [vp, vp, vp, sz, vp, vp, vp, vp, vp]),
@@ -87,7 +102,7 @@ def lib():
     for name, (res, args) in protos.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
-    if L.zhip_abi_version() != 1:
+    if L.zhip_abi_version() != 2:
         raise ImportError("libzstd_hip.so ABI mismatch")
     _lib = L
     return L
@@ -95,7 +110,8 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "zhip_abi_version", "zhip_device_count", "zhip_set_device", "zhip_last_error", "zhip_error_name",
-    "zhip_selftest", "zhip_compress_bound", "zhip_frame_content_size", "zhip_find_frame_compressed_size", "zhip_compress_batch",
+    "zhip_selftest", "zhip_compress_bound", "zhip_frame_content_size", "zhip_find_frame_compressed_size", "zhip_frame_content_size_format",
+    "zhip_find_frame_compressed_size_format", "zhip_get_cparams", "zhip_ctx_set_dformat", "zhip_compress_batch",
     "zhip_decompress_batch", "zhip_free_outbufs", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
     "zhip_kernel_name", "zhip_ctx_kernel_time",

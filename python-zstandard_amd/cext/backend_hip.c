@@ -9,14 +9,15 @@
  * the reference does around its worker pool (compressor.c:1170-1223). The library is bound with dlopen at import (after
  * importing torch when it is installed, so that both use the same HIP runtime instance); there is no CPU fallback.
  *
- * python-zstandard_amd/{buffers,compressor,decompressor}.py are the same surface in Python + ctypes; both are kept and
- * tested against each other (tests/test_cext_backend.py).
+ * This extension IS the package's implementation of the reference's names (python-zstandard_amd/__init__.py re-exports it);
+ * there is no second host implementation.
  */
 #define _GNU_SOURCE
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <structmember.h>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <stdint.h>
 #include <string.h>
 #include "zstd_hip.h"
@@ -32,11 +33,15 @@ static struct {
     int (*decompress_batch)(const zhip_dparams*, const zhip_item*, size_t, int, zhip_outbuf**, size_t*, zhip_error*);
     void (*free_outbufs)(zhip_outbuf*, size_t, int);
     int (*abi_version)(void);
+    uint64_t (*frame_content_size_format)(const void*, size_t, int);
+    int64_t (*find_frame_compressed_size_format)(const void*, size_t, int);
+    void (*get_cparams)(int, uint64_t, size_t, zhip_compression_parameters*);
 } Z;
 
 static PyObject* ZstdError;
 #define FLAG_ALLOW_SHORT 2      /* zhip_decompress_batch requireSizes bit: dstSize is a capacity, not an exact size */
 #define FORMAT_ZSTD1 0
+#define FORMAT_ZSTD1_MAGICLESS 1
 #define MAX_COMPRESSION_LEVEL 22
 #define DICT_TYPE_AUTO 0
 #define DICT_TYPE_RAWCONTENT 1
@@ -70,6 +75,8 @@ static int bind_library(PyObject* module)
     BIND(last_error, "zhip_last_error"); BIND(error_name, "zhip_error_name"); BIND(frame_content_size, "zhip_frame_content_size");
     BIND(find_frame_compressed_size, "zhip_find_frame_compressed_size"); BIND(compress_batch, "zhip_compress_batch");
     BIND(decompress_batch, "zhip_decompress_batch"); BIND(free_outbufs, "zhip_free_outbufs"); BIND(abi_version, "zhip_abi_version");
+    BIND(frame_content_size_format, "zhip_frame_content_size_format"); BIND(find_frame_compressed_size_format, "zhip_find_frame_compressed_size_format");
+    BIND(get_cparams, "zhip_get_cparams");
 #undef BIND
     if (Z.abi_version() != ZHIP_ABI_VERSION) { PyErr_SetString(PyExc_ImportError, "libzstd_hip.so ABI mismatch"); return -1; }
     return 0;
@@ -361,8 +368,107 @@ static PyObject* collection_from_outbufs(zhip_outbuf* out, size_t nOut)
     return r;
 }
 
+/* ------------------------------------------------------------------------------------------ ZstdCompressionParameters (c-ext/compressionparams.c) */
+typedef struct {
+    PyObject_HEAD
+    int format, compressionLevel, windowLog, hashLog, chainLog, searchLog, minMatch, targetLength, strategy;
+    int contentSizeFlag, checksumFlag, dictIDFlag, jobSize, overlapLog, forceMaxWindow, enableLDM, ldmHashLog, ldmMinMatch, ldmBucketSizeLog, ldmHashRateLog, threads;
+} CompressionParameters;
+static PyTypeObject CompressionParametersType = { PyVarObject_HEAD_INIT(NULL, 0) };
+static void cparams_dealloc(CompressionParameters* self) { Py_TYPE(self)->tp_free((PyObject*)self); }
+/* the bounds ZSTD_CCtxParams_setParameter enforces (ZSTD_cParam_getBounds, zstd.c:23370-23560); 0 always means "default" */
+static int cparams_bound(int v, int lo, int hi) { return v == 0 || (v >= lo && v <= hi); }
+static int cparams_init(CompressionParameters* self, PyObject* args, PyObject* kwargs)
+{
+    static char* kwlist[] = { "format", "compression_level", "window_log", "hash_log", "chain_log", "search_log", "min_match", "target_length",
+                              "strategy", "write_content_size", "write_checksum", "write_dict_id", "job_size", "overlap_log", "force_max_window",
+                              "enable_ldm", "ldm_hash_log", "ldm_min_match", "ldm_bucket_size_log", "ldm_hash_rate_log", "threads", NULL };
+    int format = 0, level = 0, windowLog = 0, hashLog = 0, chainLog = 0, searchLog = 0, minMatch = 0, targetLength = 0, strategy = -1;
+    int contentSize = 1, checksum = 0, dictID = 0, jobSize = 0, overlapLog = -1, forceMaxWindow = 0, enableLDM = 0, ldmHashLog = 0, ldmMinMatch = 0,
+        ldmBucketSizeLog = 0, ldmHashRateLog = -1, threads = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "|iiiiiiiiiiiiiiiiiiiii:ZstdCompressionParameters", kwlist, &format, &level, &windowLog, &hashLog,
+                                     &chainLog, &searchLog, &minMatch, &targetLength, &strategy, &contentSize, &checksum, &dictID, &jobSize, &overlapLog,
+                                     &forceMaxWindow, &enableLDM, &ldmHashLog, &ldmMinMatch, &ldmBucketSizeLog, &ldmHashRateLog, &threads)) return -1;
+    if (strategy == -1) strategy = 0;
+    if (overlapLog == -1) overlapLog = 0;
+    if (ldmHashRateLog == -1) ldmHashRateLog = 0;
+    if (threads < 0) { long n = sysconf(_SC_NPROCESSORS_ONLN); threads = n > 0 ? (int)n : 1; }
+    if (!(format == FORMAT_ZSTD1 || format == FORMAT_ZSTD1_MAGICLESS) || !cparams_bound(windowLog, 10, 31) || !cparams_bound(hashLog, 6, 30) ||
+        !cparams_bound(chainLog, 6, 30) || !cparams_bound(searchLog, 1, 30) || !cparams_bound(minMatch, 3, 7) || targetLength < 0 || targetLength > (1 << 17) ||
+        !cparams_bound(strategy, 1, 9) || threads > 256 || !cparams_bound(overlapLog, 0, 9) || !cparams_bound(ldmHashLog, 6, 30) ||
+        !cparams_bound(ldmMinMatch, 4, 4096) || ldmBucketSizeLog < 0 || ldmBucketSizeLog > 8 || ldmHashRateLog < 0 || ldmHashRateLog > 25) {
+        PyErr_SetString(ZstdError, "unable to set compression context parameter: Parameter is out of bound");
+        return -1;
+    }
+    self->format = format; self->compressionLevel = level; self->windowLog = windowLog; self->hashLog = hashLog; self->chainLog = chainLog;
+    self->searchLog = searchLog; self->minMatch = minMatch; self->targetLength = targetLength; self->strategy = strategy;
+    self->contentSizeFlag = contentSize != 0; self->checksumFlag = checksum != 0; self->dictIDFlag = dictID != 0; self->jobSize = jobSize;
+    self->overlapLog = overlapLog; self->forceMaxWindow = forceMaxWindow; self->enableLDM = enableLDM; self->ldmHashLog = ldmHashLog;
+    self->ldmMinMatch = ldmMinMatch; self->ldmBucketSizeLog = ldmBucketSizeLog; self->ldmHashRateLog = ldmHashRateLog; self->threads = threads;
+    return 0;
+}
+/* from_level(level, source_size=0, dict_size=0, **kwargs): the parameters libzstd derives (ZSTD_getCParams) become explicit values unless
+ * the caller names them (compressionparams.c:231-345) */
+static PyObject* cparams_from_level(PyObject* undef, PyObject* args, PyObject* kwargs)
+{
+    (void)undef;
+    int level; unsigned long long sourceSize = 0; Py_ssize_t dictSize = 0;
+    if (!PyArg_ParseTuple(args, "i:from_level", &level)) return NULL;
+    PyObject* kw = kwargs ? PyDict_Copy(kwargs) : PyDict_New();
+    if (!kw) return NULL;
+    PyObject* v;
+    if ((v = PyDict_GetItemString(kw, "source_size")) != NULL) {
+        sourceSize = PyLong_AsUnsignedLongLong(v);
+        if (sourceSize == (unsigned long long)-1 && PyErr_Occurred()) { Py_DECREF(kw); return NULL; }
+        PyDict_DelItemString(kw, "source_size");
+    }
+    if ((v = PyDict_GetItemString(kw, "dict_size")) != NULL) {
+        dictSize = PyLong_AsSsize_t(v);
+        if (dictSize == -1 && PyErr_Occurred()) { Py_DECREF(kw); return NULL; }
+        PyDict_DelItemString(kw, "dict_size");
+    }
+    zhip_compression_parameters cp;
+    Z.get_cparams(level, (uint64_t)sourceSize, (size_t)dictSize, &cp);
+    const char* names[7] = { "window_log", "chain_log", "hash_log", "search_log", "min_match", "target_length", "strategy" };
+    const unsigned long vals[7] = { cp.windowLog, cp.chainLog, cp.hashLog, cp.searchLog, cp.minMatch, cp.targetLength, (unsigned long)cp.strategy };
+    for (int i = 0; i < 7; i++) {
+        if (PyDict_GetItemString(kw, names[i])) continue;
+        PyObject* val = PyLong_FromUnsignedLong(vals[i]);
+        if (!val || PyDict_SetItemString(kw, names[i], val) != 0) { Py_XDECREF(val); Py_DECREF(kw); return NULL; }
+        Py_DECREF(val);
+    }
+    PyObject* empty = PyTuple_New(0);
+    PyObject* r = empty ? PyObject_Call((PyObject*)&CompressionParametersType, empty, kw) : NULL;
+    Py_XDECREF(empty); Py_DECREF(kw);
+    return r;
+}
+/* what ZSTD_estimateCCtxSize_usingCCtxParams counts for these strategies: the two index tables + a block of sequences and literals */
+static PyObject* cparams_estimated_size(CompressionParameters* self, PyObject* noargs)
+{
+    (void)noargs;
+    zhip_compression_parameters cp;
+    Z.get_cparams(self->compressionLevel, 0, 0, &cp);
+    const unsigned w = self->windowLog ? (unsigned)self->windowLog : cp.windowLog, h = self->hashLog ? (unsigned)self->hashLog : cp.hashLog,
+                   c = self->chainLog ? (unsigned)self->chainLog : cp.chainLog;
+    const unsigned long long block = (1ull << w) < (1ull << 17) ? (1ull << w) : (1ull << 17);
+    return PyLong_FromUnsignedLongLong((4ull << h) + (4ull << c) + block * 3 + 65536);
+}
+#define CP_MEMBER(name, field) { name, T_INT, offsetof(CompressionParameters, field), READONLY, name }
+static PyMemberDef cparams_members[] = {
+    CP_MEMBER("format", format), CP_MEMBER("compression_level", compressionLevel), CP_MEMBER("window_log", windowLog), CP_MEMBER("hash_log", hashLog),
+    CP_MEMBER("chain_log", chainLog), CP_MEMBER("search_log", searchLog), CP_MEMBER("min_match", minMatch), CP_MEMBER("target_length", targetLength),
+    CP_MEMBER("strategy", strategy), CP_MEMBER("write_content_size", contentSizeFlag), CP_MEMBER("write_checksum", checksumFlag),
+    CP_MEMBER("write_dict_id", dictIDFlag), CP_MEMBER("job_size", jobSize), CP_MEMBER("overlap_log", overlapLog), CP_MEMBER("force_max_window", forceMaxWindow),
+    CP_MEMBER("enable_ldm", enableLDM), CP_MEMBER("ldm_hash_log", ldmHashLog), CP_MEMBER("ldm_min_match", ldmMinMatch),
+    CP_MEMBER("ldm_bucket_size_log", ldmBucketSizeLog), CP_MEMBER("ldm_hash_rate_log", ldmHashRateLog), CP_MEMBER("threads", threads),
+    { NULL, 0, 0, 0, NULL } };
+static PyMethodDef cparams_methods[] = {
+    { "from_level", (PyCFunction)cparams_from_level, METH_VARARGS | METH_KEYWORDS | METH_STATIC, "parameters libzstd derives from a level (and size hints)" },
+    { "estimated_compression_context_size", (PyCFunction)cparams_estimated_size, METH_NOARGS, "bytes of working memory a frame of these parameters needs" },
+    { NULL, NULL, 0, NULL } };
+
 /* ------------------------------------------------------------------------------------------ ZstdCompressor */
-typedef struct { PyObject_HEAD int level; int writeChecksum, writeContentSize, writeDictID; PyObject* dict; } Compressor;
+typedef struct { PyObject_HEAD int level; int writeChecksum, writeContentSize, writeDictID; int format, threads; zhip_compression_parameters cp; PyObject* dict; } Compressor;
 static PyTypeObject CompressorType = { PyVarObject_HEAD_INIT(NULL, 0) };
 static void comp_dealloc(Compressor* self) { Py_CLEAR(self->dict); Py_TYPE(self)->tp_free((PyObject*)self); }
 static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
@@ -375,15 +481,15 @@ static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
     if (writeChecksum == Py_None) writeChecksum = NULL;
     if (writeContentSize == Py_None) writeContentSize = NULL;
     if (writeDictID == Py_None) writeDictID = NULL;
-    if (params && params != Py_None) {
-        /* the reference's mutual-exclusion checks come first (compressor.c:177-200) ... */
+    memset(&self->cp, 0, sizeof self->cp); self->format = FORMAT_ZSTD1; self->threads = 0;
+    if (params == Py_None) params = NULL;
+    if (params) {
+        if (!PyObject_TypeCheck(params, &CompressionParametersType)) { PyErr_SetString(PyExc_TypeError, "compression_params must be zstd.ZstdCompressionParameters"); return -1; }
+        /* the reference's mutual-exclusion checks (compressor.c:177-200) */
         if (writeChecksum) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_checksum"); return -1; }
         if (writeContentSize) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_content_size"); return -1; }
         if (writeDictID) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and write_dict_id"); return -1; }
         if (threads) { PyErr_SetString(PyExc_ValueError, "cannot define compression_params and threads"); return -1; }
-        /* ... explicit compression parameters themselves are not plumbed to the kernels yet: fail loudly */
-        PyErr_SetString(ZstdError, "compression_params is not supported by the HIP backend; pass level=");
-        return -1;
     }
     if (dict == Py_None) dict = NULL;
     if (dict && !PyObject_TypeCheck(dict, &CompressionDictType)) { PyErr_SetString(PyExc_TypeError, "dict_data must be a ZstdCompressionDict"); return -1; }
@@ -391,6 +497,17 @@ static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
     self->writeChecksum = writeChecksum ? PyObject_IsTrue(writeChecksum) : 0;
     self->writeContentSize = writeContentSize ? PyObject_IsTrue(writeContentSize) : 1;
     self->writeDictID = writeDictID ? PyObject_IsTrue(writeDictID) : 1;
+    if (threads < 0) { long n = sysconf(_SC_NPROCESSORS_ONLN); threads = n > 0 ? (int)n : 1; }
+    self->threads = threads;
+    if (params) {       /* set_parameters (compressionparams.c:43-68): the object's values replace the constructor's */
+        const CompressionParameters* q = (const CompressionParameters*)params;
+        if (q->enableLDM || q->forceMaxWindow) { PyErr_SetString(ZstdError, "long distance matching / force_max_window are not supported by the HIP backend"); return -1; }
+        self->level = q->compressionLevel; self->format = q->format; self->threads = q->threads;
+        self->writeChecksum = q->checksumFlag; self->writeContentSize = q->contentSizeFlag; self->writeDictID = q->dictIDFlag;
+        self->cp.windowLog = (uint32_t)q->windowLog; self->cp.chainLog = (uint32_t)q->chainLog; self->cp.hashLog = (uint32_t)q->hashLog;
+        self->cp.searchLog = (uint32_t)q->searchLog; self->cp.minMatch = (uint32_t)q->minMatch; self->cp.targetLength = (uint32_t)q->targetLength;
+        self->cp.strategy = q->strategy;
+    }
     Py_XINCREF(dict); Py_XSETREF(self->dict, dict);
     return 0;
 }
@@ -398,13 +515,18 @@ static void comp_params(Compressor* self, zhip_cparams* p)
 {
     memset(p, 0, sizeof *p);
     p->level = self->level; p->contentSizeFlag = self->writeContentSize; p->checksumFlag = self->writeChecksum; p->dictIDFlag = self->writeDictID;
+    p->format = self->format; p->cp = self->cp;
     if (self->dict && PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data)) {
         p->dict = PyBytes_AS_STRING(((CompressionDict*)self->dict)->data); p->dictSize = (size_t)PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data);
+        p->dictType = ((CompressionDict*)self->dict)->dictType;
     }
 }
 static void comp_raise(int rc, const zhip_error* err, int oneShot)
 {
-    if (rc == ZHIP_ERR_ZSTD) {
+    if (rc == ZHIP_ERR_ZSTD && (err->zstdErr == 30 || err->zstdErr == 32))          /* dictionary_corrupted / dictionary_wrong: compressor.c:44-52 */
+        PyErr_Format(ZstdError, "could not load compression dictionary: %s", Z.error_name(err->zstdErr));
+    else if (rc == ZHIP_ERR_ZSTD && err->zstdErr == 42) PyErr_Format(ZstdError, "could not set compression parameters: %s", Z.error_name(err->zstdErr));
+    else if (rc == ZHIP_ERR_ZSTD) {
         if (oneShot) PyErr_Format(ZstdError, "cannot compress: %s", Z.error_name(err->zstdErr));
         else PyErr_Format(ZstdError, "error compressing item %zd: %s", (Py_ssize_t)err->index, Z.error_name(err->zstdErr));
     } else if (rc == ZHIP_ERR_NO_MEMORY) PyErr_NoMemory();
@@ -466,7 +588,7 @@ static int decomp_init(Decompressor* self, PyObject* args, PyObject* kwargs)
     if (!PyArg_ParseTupleAndKeywords(args, kwargs, "|OKi:ZstdDecompressor", kwlist, &dict, &maxWindow, &format)) return -1;
     if (dict == Py_None) dict = NULL;
     if (dict && !PyObject_TypeCheck(dict, &CompressionDictType)) { PyErr_SetString(PyExc_TypeError, "dict_data must be a ZstdCompressionDict"); return -1; }
-    if (format != FORMAT_ZSTD1) { PyErr_SetString(ZstdError, "unable to set decoding format: only FORMAT_ZSTD1 is supported by the HIP backend"); return -1; }
+    if (format != FORMAT_ZSTD1 && format != FORMAT_ZSTD1_MAGICLESS) { PyErr_SetString(ZstdError, "unable to set decoding format: Parameter is out of bound"); return -1; }
     Py_XINCREF(dict); Py_XSETREF(self->dict, dict);
     self->maxWindowSize = maxWindow; self->format = format;
     return 0;
@@ -476,8 +598,9 @@ static void decomp_params(Decompressor* self, zhip_dparams* p)
     memset(p, 0, sizeof *p);
     if (self->dict && PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data)) {
         p->dict = PyBytes_AS_STRING(((CompressionDict*)self->dict)->data); p->dictSize = (size_t)PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data);
+        p->dictType = ((CompressionDict*)self->dict)->dictType;
     }
-    p->maxWindowSize = self->maxWindowSize;
+    p->maxWindowSize = self->maxWindowSize; p->format = self->format;
 }
 static PyObject* decomp_decompress(Decompressor* self, PyObject* args, PyObject* kwargs)
 {
@@ -487,7 +610,7 @@ static PyObject* decomp_decompress(Decompressor* self, PyObject* args, PyObject*
     PyObject* result = NULL;
     if (readAcross) { PyErr_SetString(ZstdError, "ZstdDecompressor.read_across_frames=True is not yet implemented"); goto done; }
     {
-        const uint64_t fcs = Z.frame_content_size(src.len ? src.buf : NULL, (size_t)src.len);
+        const uint64_t fcs = Z.frame_content_size_format(src.len ? src.buf : NULL, (size_t)src.len, self->format);
         if (fcs == ZHIP_CONTENTSIZE_ERROR) { PyErr_SetString(ZstdError, "error determining content size from frame header"); goto done; }
         if (fcs == 0) { result = PyBytes_FromStringAndSize("", 0); goto done; }
         int flags = 0; uint64_t cap, expected;
@@ -503,18 +626,19 @@ static PyObject* decomp_decompress(Decompressor* self, PyObject* args, PyObject*
         Py_BEGIN_ALLOW_THREADS
         rc = Z.decompress_batch(&p, &item, 1, flags, &out, &nOut, &err);
         Py_END_ALLOW_THREADS
+        if (rc == ZHIP_ERR_ZSTD && err.zstdErr == 30 && p.dict) { PyErr_SetString(ZstdError, "could not create decompression dict"); goto done; }   /* compressiondict.c:155-159 */
         if (rc == ZHIP_ERR_ZSTD) {
             if (flags && err.zstdErr == 70) PyErr_SetString(ZstdError, "decompression error: did not decompress full frame");
             else PyErr_Format(ZstdError, "decompression error: %s", Z.error_name(err.zstdErr));
             goto done;
         }
-        if (rc == ZHIP_ERR_SIZE_MISMATCH) { PyErr_Format(ZstdError, "decompression error: decompressed %d bytes; expected %llu", 0, (unsigned long long)expected); goto done; }
+        if (rc == ZHIP_ERR_SIZE_MISMATCH) { PyErr_Format(ZstdError, "decompression error: decompressed %llu bytes; expected %llu", (unsigned long long)err.detail[0], (unsigned long long)expected); goto done; }
         if (rc == ZHIP_ERR_NO_MEMORY) { PyErr_NoMemory(); goto done; }
         if (rc != ZHIP_ERR_NONE) { PyErr_Format(ZstdError, "HIP backend failure: %s", Z.last_error()); goto done; }
         result = PyBytes_FromStringAndSize((const char*)out[0].data, (Py_ssize_t)out[0].segs[0].length);
         Z.free_outbufs(out, nOut, 1);
         if (result && !allowExtra) {
-            const int64_t used = Z.find_frame_compressed_size(src.buf, (size_t)src.len);
+            const int64_t used = Z.find_frame_compressed_size_format(src.buf, (size_t)src.len, self->format);
             if (used >= 0 && used < (int64_t)src.len) {
                 Py_CLEAR(result);
                 PyErr_Format(ZstdError, "compressed input contains %zd bytes of unused data, which is disallowed", (Py_ssize_t)(src.len - used));
@@ -551,6 +675,7 @@ static PyObject* decomp_multi(Decompressor* self, PyObject* args, PyObject* kwar
         rc = Z.decompress_batch(&p, s.items, (size_t)s.n, sizesObj ? 1 : 0, &out, &nOut, &err);
         Py_END_ALLOW_THREADS
         if (rc == ZHIP_ERR_UNKNOWN_SIZE) PyErr_Format(PyExc_ValueError, "could not determine decompressed size of item %zd", (Py_ssize_t)err.index);
+        else if (rc == ZHIP_ERR_ZSTD && err.zstdErr == 30 && p.dict) PyErr_SetString(ZstdError, "could not create decompression dict");
         else if (rc == ZHIP_ERR_ZSTD) PyErr_Format(ZstdError, "error decompressing item %zd: %s", (Py_ssize_t)err.index, Z.error_name(err.zstdErr));
         else if (rc == ZHIP_ERR_SIZE_MISMATCH)
             PyErr_Format(ZstdError, "error decompressing item %zd: decompressed %llu bytes; expected %llu", (Py_ssize_t)err.index,
@@ -591,17 +716,18 @@ static PyObject* mod_get_frame_parameters(PyObject* self, PyObject* args, PyObje
     if (!PyArg_ParseTupleAndKeywords(args, kwargs, "y*|I:get_frame_parameters", kwlist, &src, &format)) return NULL;
     const unsigned char* p = (const unsigned char*)src.buf; const size_t n = (size_t)src.len;
     PyObject* result = NULL;
-    if (format != FORMAT_ZSTD1) { PyErr_SetString(ZstdError, "cannot get frame parameters: only FORMAT_ZSTD1 is supported by the HIP backend"); goto done; }
-    if (n < 5) { PyErr_Format(ZstdError, "not enough data for frame parameters; need %zu bytes", (size_t)5); goto done; }
-    if (!(p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD)) { PyErr_SetString(ZstdError, "cannot get frame parameters: Unknown frame descriptor"); goto done; }
+    if (format != FORMAT_ZSTD1 && format != FORMAT_ZSTD1_MAGICLESS) { PyErr_SetString(ZstdError, "cannot get frame parameters: Parameter is out of bound"); goto done; }
+    const size_t mg = format == FORMAT_ZSTD1_MAGICLESS ? 0 : 4;
+    if (n < mg + 1) { PyErr_Format(ZstdError, "not enough data for frame parameters; need %zu bytes", mg + 1); goto done; }
+    if (mg && !(p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD)) { PyErr_SetString(ZstdError, "cannot get frame parameters: Unknown frame descriptor"); goto done; }
     {
-        const unsigned fhd = p[4], fcsCode = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, didCode = fhd & 3;
+        const unsigned fhd = p[mg], fcsCode = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, didCode = fhd & 3;
         if (fhd & 8) { PyErr_SetString(ZstdError, "cannot get frame parameters: Unsupported frame parameter"); goto done; }
         static const size_t didSizes[4] = { 0, 1, 2, 4 };
         const size_t didSize = didSizes[didCode], fcsSize = fcsCode == 0 ? (single ? 1 : 0) : fcsCode == 1 ? 2 : fcsCode == 2 ? 4 : 8;
-        const size_t need = 5 + (single ? 0 : 1) + didSize + fcsSize;
+        const size_t need = mg + 1 + (single ? 0 : 1) + didSize + fcsSize;
         if (n < need) { PyErr_Format(ZstdError, "not enough data for frame parameters; need %zu bytes", need); goto done; }
-        size_t pos = 5; unsigned long long window = 0, content = ZHIP_CONTENTSIZE_UNKNOWN; unsigned dictID = 0;
+        size_t pos = mg + 1; unsigned long long window = 0, content = ZHIP_CONTENTSIZE_UNKNOWN; unsigned dictID = 0;
         if (!single) {
             const unsigned b = p[pos++], wlog = 10 + (b >> 3);
             if (wlog > 31) { PyErr_SetString(ZstdError, "cannot get frame parameters: Frame requires too much memory for decoding"); goto done; }
@@ -676,16 +802,18 @@ PyMODINIT_FUNC PyInit_backend_hip(void)
 
     READY(FrameParametersType, "FrameParameters", sizeof(FrameParameters), fp_dealloc, no_direct_init, "what a frame header says");
     FrameParametersType.tp_members = fp_members;
+    READY(CompressionParametersType, "ZstdCompressionParameters", sizeof(CompressionParameters), cparams_dealloc, cparams_init, "explicit compression parameters");
+    CompressionParametersType.tp_members = cparams_members; CompressionParametersType.tp_methods = cparams_methods;
 
-    PyTypeObject* types[] = { &BufferWithSegmentsType, &BufferSegmentType, &BufferSegmentsType, &BufferCollectionType, &CompressionDictType, &CompressorType, &DecompressorType, &FrameParametersType };
-    const char* names[] = { "BufferWithSegments", "BufferSegment", "BufferSegments", "BufferWithSegmentsCollection", "ZstdCompressionDict", "ZstdCompressor", "ZstdDecompressor", "FrameParameters" };
-    for (int i = 0; i < 8; i++) {
+    PyTypeObject* types[] = { &BufferWithSegmentsType, &BufferSegmentType, &BufferSegmentsType, &BufferCollectionType, &CompressionDictType, &CompressorType, &DecompressorType, &FrameParametersType, &CompressionParametersType };
+    const char* names[] = { "BufferWithSegments", "BufferSegment", "BufferSegments", "BufferWithSegmentsCollection", "ZstdCompressionDict", "ZstdCompressor", "ZstdDecompressor", "FrameParameters", "ZstdCompressionParameters" };
+    for (int i = 0; i < 9; i++) {
         if (PyType_Ready(types[i]) < 0) { Py_DECREF(m); return NULL; }
         Py_INCREF(types[i]);
         if (PyModule_AddObject(m, names[i], (PyObject*)types[i]) < 0) { Py_DECREF(m); return NULL; }
     }
     Py_INCREF(ZstdError); PyModule_AddObject(m, "ZstdError", ZstdError);
-    PyModule_AddIntConstant(m, "FORMAT_ZSTD1", FORMAT_ZSTD1); PyModule_AddIntConstant(m, "FORMAT_ZSTD1_MAGICLESS", 1);
+    PyModule_AddIntConstant(m, "FORMAT_ZSTD1", FORMAT_ZSTD1); PyModule_AddIntConstant(m, "FORMAT_ZSTD1_MAGICLESS", FORMAT_ZSTD1_MAGICLESS);
     PyModule_AddIntConstant(m, "MAX_COMPRESSION_LEVEL", MAX_COMPRESSION_LEVEL);
     PyModule_AddIntConstant(m, "DICT_TYPE_AUTO", DICT_TYPE_AUTO); PyModule_AddIntConstant(m, "DICT_TYPE_RAWCONTENT", DICT_TYPE_RAWCONTENT);
     PyModule_AddIntConstant(m, "DICT_TYPE_FULLDICT", DICT_TYPE_FULLDICT);
@@ -698,6 +826,15 @@ PyMODINIT_FUNC PyInit_backend_hip(void)
     PyModule_AddIntConstant(m, "DECOMPRESSION_RECOMMENDED_INPUT_SIZE", (1 << 17) + 3);
     PyModule_AddIntConstant(m, "DECOMPRESSION_RECOMMENDED_OUTPUT_SIZE", 1 << 17);
     PyModule_AddIntConstant(m, "WINDOWLOG_MIN", 10); PyModule_AddIntConstant(m, "WINDOWLOG_MAX", 31);
+    /* parameter bounds and strategy numbers the reference exports (c-ext/constants.c:60-100; values of zstd.h) */
+    PyModule_AddIntConstant(m, "CHAINLOG_MIN", 6); PyModule_AddIntConstant(m, "CHAINLOG_MAX", 30);
+    PyModule_AddIntConstant(m, "HASHLOG_MIN", 6); PyModule_AddIntConstant(m, "HASHLOG_MAX", 30);
+    PyModule_AddIntConstant(m, "SEARCHLOG_MIN", 1); PyModule_AddIntConstant(m, "SEARCHLOG_MAX", 30);
+    PyModule_AddIntConstant(m, "MINMATCH_MIN", 3); PyModule_AddIntConstant(m, "MINMATCH_MAX", 7);
+    PyModule_AddIntConstant(m, "TARGETLENGTH_MIN", 0); PyModule_AddIntConstant(m, "TARGETLENGTH_MAX", 1 << 17);
+    PyModule_AddIntConstant(m, "STRATEGY_FAST", 1); PyModule_AddIntConstant(m, "STRATEGY_DFAST", 2); PyModule_AddIntConstant(m, "STRATEGY_GREEDY", 3);
+    PyModule_AddIntConstant(m, "STRATEGY_LAZY", 4); PyModule_AddIntConstant(m, "STRATEGY_LAZY2", 5); PyModule_AddIntConstant(m, "STRATEGY_BTLAZY2", 6);
+    PyModule_AddIntConstant(m, "STRATEGY_BTOPT", 7); PyModule_AddIntConstant(m, "STRATEGY_BTULTRA", 8); PyModule_AddIntConstant(m, "STRATEGY_BTULTRA2", 9);
     PyModule_AddStringConstant(m, "backend", "hip_cext");
     {   PyObject* feats = PySet_New(NULL);
         const char* f[] = { "buffer_types", "multi_compress_to_buffer", "multi_decompress_to_buffer" };

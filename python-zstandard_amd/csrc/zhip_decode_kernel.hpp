@@ -976,16 +976,17 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
     const uint32_t srcSize = (uint32_t)srcSize64;
     const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
     // ---- frame header (RFC 8878 3.1.1.1)
-    if (srcSize < 5) return ZE_SRC_SIZE_WRONG;
-    if (zh_ld32(src) != ZF_MAGIC) return ZE_PREFIX_UNKNOWN;
-    const uint32_t fhd = src[4];
+    const uint32_t mg = a.magicless ? 0u : 4u;             // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
+    if (srcSize < mg + 1) return ZE_SRC_SIZE_WRONG;
+    if (mg && zh_ld32(src) != ZF_MAGIC) return ZE_PREFIX_UNKNOWN;
+    const uint32_t fhd = src[mg];
     const uint32_t dictCode = fhd & 3, hasChecksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
     const uint32_t dictBytes = dictCode == 3 ? 4 : dictCode;
     const uint32_t fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
-    const uint32_t hs = 5 + (single ? 0 : 1) + dictBytes + fcsBytes;
+    const uint32_t hs = mg + 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
     if (fhd & 8) return ZE_FRAMEPARAM_UNSUPPORTED;
     if (srcSize < hs) return ZE_SRC_SIZE_WRONG;
-    uint32_t pos = 5;
+    uint32_t pos = mg + 1;
     uint64_t windowSize = 0;
     if (!single) {
         uint32_t wd = src[pos++], wl = 10 + (wd >> 3);

@@ -52,17 +52,18 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (srcSize64 > 0x7FFFFFFFull) { fallback = true; break; }
             const uint32_t srcSize = (uint32_t)srcSize64;
             const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
-            if (srcSize < 5) { err = ZE_SRC_SIZE_WRONG; break; }
-            if (zh_ld32(src) != ZF_MAGIC) { err = ZE_PREFIX_UNKNOWN; break; }
-            const uint32_t fhd = src[4];
+            const uint32_t mg = a.magicless ? 0u : 4u;                     // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
+            if (srcSize < mg + 1) { err = ZE_SRC_SIZE_WRONG; break; }
+            if (mg && zh_ld32(src) != ZF_MAGIC) { err = ZE_PREFIX_UNKNOWN; break; }
+            const uint32_t fhd = src[mg];
             const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6, hasChecksum = (fhd >> 2) & 1;
             const uint32_t dictBytes = dictCode == 3 ? 4 : dictCode;
             const uint32_t fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
-            const uint32_t hs = 5 + (single ? 0 : 1) + dictBytes + fcsBytes;
+            const uint32_t hs = mg + 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
             if (fhd & 8) { err = ZE_FRAMEPARAM_UNSUPPORTED; break; }
             if (srcSize < hs) { err = ZE_SRC_SIZE_WRONG; break; }
             if (dictCode) { fallback = true; break; }                       // dictionary frames: generic kernel decides
-            uint32_t pos = 5;
+            uint32_t pos = mg + 1;
             uint64_t windowSize = 0;
             if (!single) {
                 const uint32_t wd = src[pos++], wl = 10 + (wd >> 3);
@@ -219,51 +220,124 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
 // + stream -- with the 16 tables (4 KiB each, built by K1) in LDS; frames come in KB's order so that a wave's streams have similar
 // lengths. Same 32-bit bit window as K2: two symbols per v_alignbit, dword refills.
 struct alignas(16) ZpVec16 { uint32_t a, b, c, d; };
-// A decoding cell is 12 bits of information (symbol, code length <= 11): kept as a byte array of symbols and a nibble array of lengths,
-// a frame's table is 3 KiB instead of 4, a wave's 16 tables 48 KiB, and THREE waves fit a CU's LDS instead of two -- the kernel is a
-// latency-bound lookup chain, so residency is throughput.
-struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; };
 
-ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count)
+// ------------------------------------------------------------------------------------------ backward bit reader over an LDS ring
+// Both serial chains of the decoder (Huffman streams in K1b, the tANS sequence stream in K2) read a bitstream from its last byte
+// down, every lane its own stream at its own pace. Round 1 kept a five-dword queue in registers and shifted it with selects; the load
+// issued by one refill was an input of the very next refill's select chain, so every refill waited for a global load issued a few
+// hundred cycles earlier (s_waitcnt vmcnt(1) in the loop, profiles/README.md r02a): ~600 cycles of memory latency per refill on a
+// chain whose arithmetic is ~100. Here global memory is out of the chain:
+//   * every lane owns a ring of RW dwords in LDS, laid out [word][lane] so that no two lanes ever share a bank;
+//   * the stream is fetched in aligned 16-byte blocks, up to M per burst, one burst every T loop trips. A block requested in burst b
+//     is written to the ring in burst b + 1, i.e. T trips later -- thousands of cycles -- so the wait is free;
+//   * a refill is three selects and one ds_read_b32 (the dword after next, consumed a refill later).
+// Sizing (C = most bytes a lane can consume between two bursts): a block is requested as soon as it cannot overwrite a dword the
+// consumer may still read (block + ring >= cur), so after every burst the requested data reaches below cur - ring; what is readable
+// (committed) lags one burst, and the consumer moves at most C per burst: ring >= 2 C + 32 and 16 M >= C + 16 keep it fed whatever
+// the input. K2: T = 4 sequences of <= 89 bits, C = 45, ring 128, M = 4. K1b: T = 8 symbols of <= 11 bits, C = 11, ring 64, M = 2.
+// Reads may touch the 16-byte blocks around the stream (never another page: blocks are aligned) and never go below the block that
+// holds the first byte of the arena side of the stream (offsets are clamped at 0 relative to the aligned base).
+#define ZP_NOBLK 0x7FFFFFF0
+template <uint32_t RW, uint32_t M>
+struct ZpBits {
+    uint32_t hi, lo, nx, used;      // `used` bits of hi are consumed (1..32 at every group start); lo, nx = the next two dwords
+    int32_t cur;                    // offset of lo's dword from p0
+    int32_t pb;                     // offset of the next block to request
+    int32_t s0;                     // offset of the stream's first byte
+    int32_t bo[M]; ZpVec16 blk[M];  // blocks in flight and where they go (ZP_NOBLK: none)
+    const uint8_t* p0;              // 16-byte aligned base
+    uint32_t* col;                  // this lane's column of the ring: word w of the lane is col[64 * w]
+};
+template <uint32_t RW, uint32_t M> ZH_DEV uint32_t zb_index(int32_t off) { return ((uint32_t)off << 4) & ((RW - 1) << 6); }
+template <uint32_t RW, uint32_t M> ZH_DEV ZpVec16 zb_fetch(const ZpBits<RW, M>& B, int32_t off)
 {
+    return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off));
+}
+template <uint32_t RW, uint32_t M> ZH_DEV void zb_commit(ZpBits<RW, M>& B, int32_t off, const ZpVec16& v)
+{
+    uint32_t* q = B.col + zb_index<RW, M>(off);          // off is a multiple of 16: four consecutive words, no wrap inside
+    q[0] = v.a; q[64] = v.b; q[128] = v.c; q[192] = v.d;
+}
+// false: empty stream or missing end mark (the caller reports corruption)
+template <uint32_t RW, uint32_t M> ZH_DEV bool zb_init(ZpBits<RW, M>& B, const uint8_t* p, uint32_t size, uint32_t* col)
+{
+    B.col = col;
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
+    B.p0 = p - mis; B.s0 = (int32_t)mis;
+#pragma unroll
+    for (uint32_t k = 0; k < M; k++) { B.bo[k] = ZP_NOBLK; B.blk[k].a = B.blk[k].b = B.blk[k].c = B.blk[k].d = 0; }
+    B.hi = B.lo = B.nx = 0; B.used = 32; B.cur = 0; B.pb = 0;
     if (size == 0) return false;
     const uint32_t last = p[size - 1];
     if (last == 0) return false;
-#define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
-#define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
-#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; n2 = ge_ ? n3 : n2; n3 = ge_ ? n4 : n3; \
-        n4 = ge_ ? n5 : n4; used = ge_ ? used - 32 : used; off = ge_ ? off - 4 : off; n5 = ZP_WORD(off); } while (0)
+    const int32_t end = (int32_t)(mis + size);
+    const int32_t d0 = (end - 1) & ~3, tb = d0 & ~15;
+    // the top RW * 4 bytes of the stream, straight into the ring (all loads in flight before the first write)
+    ZpVec16 f[RW / 4];
+#pragma unroll
+    for (uint32_t k = 0; k < RW / 4; k++) f[k] = zb_fetch(B, tb - 16 * (int32_t)k);
+#pragma unroll
+    for (uint32_t k = 0; k < RW / 4; k++) zb_commit(B, tb - 16 * (int32_t)k, f[k]);
+    B.pb = tb - (int32_t)(RW * 4);
+    B.hi = B.col[zb_index<RW, M>(d0)]; B.lo = B.col[zb_index<RW, M>(d0 - 4)]; B.nx = B.col[zb_index<RW, M>(d0 - 8)];
+    B.cur = d0 - 4;
+    B.used = 8 * (uint32_t)(d0 + 4 - end) + 8 - (uint32_t)zh_highbit32(last);      // bytes above the stream + padding + end mark
+    return true;
+}
+// write what the previous burst requested, request what fits now
+template <uint32_t RW, uint32_t M> ZH_DEV void zb_burst(ZpBits<RW, M>& B)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < M; k++) if (B.bo[k] != ZP_NOBLK) { zb_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
+#pragma unroll
+    for (uint32_t k = 0; k < M; k++) {
+        if (B.pb + (int32_t)(RW * 4) >= B.cur) { B.bo[k] = B.pb; B.blk[k] = zb_fetch(B, B.pb); B.pb -= 16; }
+    }
+}
+template <uint32_t RW, uint32_t M> ZH_DEV uint32_t zb_top(const ZpBits<RW, M>& B) { return zh_alignbit(B.hi, B.lo, 32u - B.used); }   // the next 32 stream bits
+template <uint32_t RW, uint32_t M> ZH_DEV void zb_refill(ZpBits<RW, M>& B)                                                         // after `used += n`, n <= 32
+{
+    const bool ge = B.used > 32;
+    B.hi = ge ? B.lo : B.hi; B.lo = ge ? B.nx : B.lo; B.cur = ge ? B.cur - 4 : B.cur; B.used = ge ? B.used - 32 : B.used;
+    B.nx = B.col[zb_index<RW, M>(B.cur - 4)];
+}
+// every bit consumed, no more: the unconsumed part of hi is exactly what lies below the stream's first byte
+template <uint32_t RW, uint32_t M> ZH_DEV bool zb_finished(const ZpBits<RW, M>& B) { return (int32_t)B.used == 8 * (B.cur + 8 - B.s0); }
+
+#define ZP_HUF_RING 16          // K1b: dwords of ring per lane (64 bytes), 2 blocks per burst, a burst every 8 symbols
+typedef ZpBits<ZP_HUF_RING, 2> ZpHufBits;
+// A decoding cell is 12 bits of information (symbol, code length <= 11): kept as a byte array of symbols and a nibble array of lengths,
+// a frame's table is 3 KiB instead of 4, a wave's 16 tables 48 KiB (+ 4 KiB of rings), and THREE waves fit a CU's LDS instead of two --
+// the kernel is a latency-bound lookup chain, so residency is throughput.
+struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; uint32_t ring[ZP_HUF_RING * 64]; };
+
+ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count,
+                          uint32_t* ringCol)
+{
+    ZpHufBits B;
+    if (!zb_init(B, p, size, ringCol)) return false;
 #define ZP_LEN(i) (((uint32_t)lenTab[(i) >> 1] >> (((i) & 1) * 4)) & 15u)
-    int32_t off = (int32_t)size - 28;
-    uint32_t hi = ZP_WORD(off + 24), lo = ZP_WORD(off + 20), n1 = ZP_WORD(off + 16), n2 = ZP_WORD(off + 12), n3 = ZP_WORD(off + 8), n4 = ZP_WORD(off + 4), n5 = ZP_WORD(off);
-    uint32_t used = 8 - (uint32_t)zh_highbit32(last);
+#define ZP_PAIR(sa, sb) do { uint32_t top_ = zb_top(B); const uint32_t ia_ = top_ >> sh; sa = symTab[ia_]; const uint32_t la_ = ZP_LEN(ia_); top_ <<= la_; \
+        const uint32_t ib_ = top_ >> sh; sb = symTab[ib_]; B.used += la_ + ZP_LEN(ib_); zb_refill(B); } while (0)
     const uint32_t sh = 32 - log;
     uint32_t i = 0;
-    while (i + 4 <= count) {
-        uint32_t top = ZP_TOP();
-        const uint32_t i0 = top >> sh; const uint32_t s0 = symTab[i0], l0 = ZP_LEN(i0); top <<= l0;
-        const uint32_t i1 = top >> sh; const uint32_t s1 = symTab[i1], l1 = ZP_LEN(i1);
-        used += l0 + l1;
-        ZP_REFILL();
-        top = ZP_TOP();
-        const uint32_t i2 = top >> sh; const uint32_t s2 = symTab[i2], l2 = ZP_LEN(i2); top <<= l2;
-        const uint32_t i3 = top >> sh; const uint32_t s3 = symTab[i3], l3 = ZP_LEN(i3);
-        used += l2 + l3;
-        ZP_REFILL();
-        zh_st32(out + i, s0 | (s1 << 8) | (s2 << 16) | (s3 << 24));
-        i += 4;
+    while (i + 8 <= count) {                    // two symbols (<= 22 bits) per window, eight per trip and per 8-byte store
+        zb_burst(B);
+        uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
+        ZP_PAIR(s0, s1); ZP_PAIR(s2, s3); ZP_PAIR(s4, s5); ZP_PAIR(s6, s7);
+        zh_st64(out + i, (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32));
+        i += 8;
     }
+    zb_burst(B);                                // the tail (<= 7 symbols) reads what the last burst requested
     while (i < count) {
-        const uint32_t ix = ZP_TOP() >> sh;
-        used += ZP_LEN(ix);
-        ZP_REFILL();
+        const uint32_t ix = zb_top(B) >> sh;
+        B.used += ZP_LEN(ix);
+        zb_refill(B);
         out[i++] = symTab[ix];
     }
+#undef ZP_PAIR
 #undef ZP_LEN
-#undef ZP_REFILL
-#undef ZP_TOP
-#undef ZP_WORD
-    return (int32_t)((int32_t)size - 28 - off) * 8 + (int32_t)used == (int32_t)size * 8;     // consumed exactly
+    return zb_finished(B);
 }
 
 ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
@@ -306,7 +380,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
             const uint32_t f = a.first + i;
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
-            if (!four) { if (strm == 0) ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p, streamBytes, lit, litSize); }
+            if (!four) { if (strm == 0) ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p, streamBytes, lit, litSize, L.ring + lane); }
             else {
                 const uint32_t s1 = zh_ld16(p), s2 = zh_ld16(p + 2), s3 = zh_ld16(p + 4);
                 if (6 + s1 + s2 + s3 > streamBytes) ok = false;
@@ -315,7 +389,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
                     const uint32_t so = strm == 0 ? 0 : strm == 1 ? s1 : strm == 2 ? s1 + s2 : s1 + s2 + s3;
                     const uint32_t sz = strm == 0 ? s1 : strm == 1 ? s2 : strm == 2 ? s3 : streamBytes - 6 - s1 - s2 - s3;
                     const uint32_t n = strm < 3 ? seg : litSize - 3 * seg;
-                    ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p + 6 + so, sz, lit + strm * seg, n);
+                    ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p + 6 + so, sz, lit + strm * seg, n, L.ring + lane);
                 }
             }
         }
@@ -339,87 +413,71 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
 //     the window advances a dword at a time at two fixed points per sequence (after the extra bits, after the state bits)
 //   * per-symbol {baseline, extra-bit count} come from one 4-byte LDS word; repcodes are resolved with selects
 // Frames of a wave come from the KB order (similar sequence counts), so lanes finish together.
-struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
+#define ZP_SEQ_RING 32          // K2: dwords of ring per lane (128 bytes), 4 blocks per burst, a burst every 4 sequences
+typedef ZpBits<ZP_SEQ_RING, 4> ZpSeqBits;
+struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t ring[ZP_SEQ_RING * 64]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
 
 ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8_t* T, const uint32_t* llInfo, const uint32_t* mlInfo,
-                               uint32_t logs, uint32_t nbSeq, uint64_t* out)
+                               uint32_t logs, uint32_t nbSeq, uint64_t* out, uint32_t* ringCol)
 {
     const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
-    const uint32_t size = (uint32_t)(end - p);
-    if (size == 0) return ZE_CORRUPTION;
-    const uint32_t last = p[size - 1];
-    if (last == 0) return ZE_CORRUPTION;
-    // Bit window: the stream is consumed from its last byte down, a dword at a time. hi:lo are the current dwords, n1..n5 the next
-    // five, loaded that far ahead because loads return in order for the whole wave: any lane's HBM miss must be older than the
-    // latency by the time another lane needs its own dword (two dwords ahead measured 1000 cycles per sequence, i.e. the latency). `used` bits of hi are gone; invariant at every group start: 1 <= used <= 32, so the next 32 stream bits are
-    // one v_alignbit away (ZP_TOP) and fields totalling <= 32 bits are cut from that with v_bfe. After a group ZP_REFILL advances
-    // by at most one dword. Loads may reach up to 4 bytes below p (inside the frame: >= 11 header bytes precede any sequences
-    // bitstream); those bytes are only consumed by a corrupt stream, which the position check at the end rejects.
-#define ZP_WORD(o) zh_ld32(p + ((o) < -4 ? -4 : (o)))
-#define ZP_TOP() zh_alignbit(hi, lo, 32u - used)
-#define ZP_REFILL() do { const bool ge_ = used > 32; hi = ge_ ? lo : hi; lo = ge_ ? n1 : lo; n1 = ge_ ? n2 : n1; n2 = ge_ ? n3 : n2; n3 = ge_ ? n4 : n3; \
-        n4 = ge_ ? n5 : n4; used = ge_ ? used - 32 : used; off = ge_ ? off - 4 : off; n5 = ZP_WORD(off); } while (0)
-    int32_t off = (int32_t)size - 28;                       // offset of the lowest prefetched dword; not clamped: it is the position
-    uint32_t hi = ZP_WORD(off + 24), lo = ZP_WORD(off + 20), n1 = ZP_WORD(off + 16), n2 = ZP_WORD(off + 12), n3 = ZP_WORD(off + 8), n4 = ZP_WORD(off + 4), n5 = ZP_WORD(off);
-    uint32_t used = 8 - (uint32_t)zh_highbit32(last);       // padding + end mark
+    // Bit window (ZpBits above): hi:lo are the current dwords, `used` bits of hi are gone; invariant at every group start:
+    // 1 <= used <= 32, so the next 32 stream bits are one v_alignbit away (zb_top) and fields totalling <= 32 bits are cut from that
+    // with v_bfe. After a group zb_refill advances by at most one dword, served from the lane's LDS ring.
+    ZpSeqBits B;
+    if (!zb_init(B, p, (uint32_t)(end - p), ringCol)) return ZE_CORRUPTION;
     const uint32_t maskL = (1u << llLog) - 1, maskO = (1u << ofLog) - 1, maskM = (1u << mlLog) - 1;
     const uint32_t kL = 31 - llLog, kO = 31 - ofLog, kM = 31 - mlLog;
-    uint32_t top = ZP_TOP();
+    const uint16_t* const TL = (const uint16_t*)(T + 2 * ZP_FSE_LL); const uint16_t* const TM = (const uint16_t*)(T + 2 * ZP_FSE_ML);
+    const uint16_t* const TO = (const uint16_t*)(T + 2 * ZP_FSE_OF);
+    uint32_t top = zb_top(B);
     uint32_t sL = zh_bfe(top, 32 - llLog, llLog), sO = zh_bfe(top, 32 - llLog - ofLog, ofLog);      // <= 17 bits
-    used += llLog + ofLog;
-    ZP_REFILL();
-    top = ZP_TOP();
+    B.used += llLog + ofLog;
+    zb_refill(B);
+    top = zb_top(B);
     uint32_t sM = zh_bfe(top, 32 - mlLog, mlLog);
-    used += mlLog;
-    ZP_REFILL();
+    B.used += mlLog;
+    zb_refill(B);
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8, bad = 0;
-    uint32_t cL, cM, cO;
-#define ZP_DECODE_ONE(n) do { \
-        cL = *(const uint16_t*)(T + 2 * ZP_FSE_LL + 2 * sL); cM = *(const uint16_t*)(T + 2 * ZP_FSE_ML + 2 * sM); cO = *(const uint16_t*)(T + 2 * ZP_FSE_OF + 2 * sO); \
-        const uint32_t symO = cO >> 10, symL = cL >> 10, symM = cM >> 10; \
-        /* baselines and extra-bit counts computed from the codes (RFC 8878 3.1.1.3.2.1.1): a table read here would be a second dependent LDS round on the chain */ \
-        const uint32_t bitsL = symL < 16 ? 0u : symL < 25 ? (uint32_t)(0x433221111ull >> (4 * (symL - 16))) & 15u : symL - 19; \
-        const uint32_t baseL = symL < 16 ? symL : symL < 24 ? (uint32_t)(0x28201C1816141210ull >> (8 * (symL - 16))) & 255u : symL == 24 ? 48u : 1u << (symL - 19); \
-        const uint32_t bitsM = symM < 32 ? 0u : symM < 43 ? (uint32_t)(0x54433221111ull >> (4 * (symM - 32))) & 15u : symM - 36; \
-        const uint32_t baseM = symM < 32 ? symM + 3 : symM < 40 ? (uint32_t)(0x3B332F2B29272523ull >> (8 * (symM - 32))) & 255u : symM < 43 ? (uint32_t)(0x635343u >> (8 * (symM - 40))) & 255u : (1u << (symM - 36)) + 3; \
-        top = ZP_TOP(); \
-        const uint32_t xo = zh_bfe(top, 32 - symO, symO); \
-        uint32_t cum = symO; \
-        if (symO + bitsM + bitsL > 32) { used += symO; ZP_REFILL(); top = ZP_TOP(); cum = 0; }     /* rare: far offset with long lengths */ \
-        const uint32_t xm = zh_bfe(top, 32 - cum - bitsM, bitsM); cum += bitsM; \
-        const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL; \
-        used += cum; \
-        ZP_REFILL(); \
-        const uint32_t ofv = (1u << symO) + xo, mlv = baseM + xm, llv = baseL + xl; \
-        /* repcode resolution (RFC 8878 3.1.1.5), select form */ \
-        const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */ \
-        uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro; \
-        ro = ro == 0 ? 1u : ro; \
-        const bool isRep = ofv <= 3; \
-        const uint32_t offset = isRep ? ro : ofv - 3; \
-        const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1); \
-        rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0; \
-        bad |= offset >> 30; \
-        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32); \
-    } while (0)
-    ZP_DECODE_ONE(0);
-    for (uint32_t n = 1; n < nbSeq; n++) {
+    for (uint32_t n = 0;;) {
+        if ((n & 3) == 0) zb_burst(B);
+        const uint32_t cL = TL[sL], cM = TM[sM], cO = TO[sO];
+        const uint32_t symO = cO >> 10, symL = cL >> 10, symM = cM >> 10;
+        // baseline | extra-bit count << 24 of the length codes (RFC 8878 3.1.1.3.2.1.1) from a 89-word LDS table shared by the wave:
+        // one more LDS round on the chain, a tenth of the instructions of computing them (the loop is bound by issue slots)
+        const uint32_t iL = llInfo[symL], iM = mlInfo[symM];
+        const uint32_t bitsL = iL >> 24, baseL = iL & 0xFFFFFFu, bitsM = iM >> 24, baseM = iM & 0xFFFFFFu;
+        top = zb_top(B);
+        const uint32_t xo = zh_bfe(top, 32 - symO, symO);
+        uint32_t cum = symO;
+        if (symO + bitsM + bitsL > 32) { B.used += symO; zb_refill(B); top = zb_top(B); cum = 0; }     /* rare: far offset with long lengths */
+        const uint32_t xm = zh_bfe(top, 32 - cum - bitsM, bitsM); cum += bitsM;
+        const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL;
+        B.used += cum;
+        zb_refill(B);
+        const uint32_t ofv = (1u << symO) + xo, mlv = baseM + xm, llv = baseL + xl;
+        /* repcode resolution (RFC 8878 3.1.1.5), select form */
+        const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */
+        uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro;
+        ro = ro == 0 ? 1u : ro;
+        const bool isRep = ofv <= 3;
+        const uint32_t offset = isRep ? ro : ofv - 3;
+        const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1);
+        rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0;
+        bad |= offset >> 30;
+        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
+        if (++n >= nbSeq) break;
+        // state update: the three fields total <= 26 bits
         const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
         const uint32_t nbL = (uint32_t)__builtin_clz(xL) - kL, nbM = (uint32_t)__builtin_clz(xM) - kM, nbO = (uint32_t)__builtin_clz(xO) - kO;
-        top = ZP_TOP();                                       /* the three state fields total <= 26 bits */
+        top = zb_top(B);
         const uint32_t tL = zh_bfe(top, 32 - nbL, nbL), tM = zh_bfe(top, 32 - nbL - nbM, nbM), tO = zh_bfe(top, 32 - nbL - nbM - nbO, nbO);
-        used += nbL + nbM + nbO;
+        B.used += nbL + nbM + nbO;
         sL = ((xL << nbL) + tL) & maskL; sM = ((xM << nbM) + tM) & maskM; sO = ((xO << nbO) + tO) & maskO;
-        ZP_REFILL();
-        ZP_DECODE_ONE(n);
+        zb_refill(B);
     }
-#undef ZP_DECODE_ONE
-#undef ZP_REFILL
-#undef ZP_TOP
-#undef ZP_WORD
     if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 1 GiB)
-    // every bit of the stream must have been consumed, no more: position = dwords advanced * 32 + used
-    if ((int32_t)((int32_t)size - 28 - off) * 8 + (int32_t)used != (int32_t)size * 8) return ZE_CORRUPTION;
+    if (!zb_finished(B)) return ZE_CORRUPTION;
     return 0;
 }
 
@@ -456,7 +514,7 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
             const uint32_t f = a.first + i;
             const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
             const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, L.tab + (size_t)lane * ZP_K2_STRIDE, L.llInfo, L.mlInfo,
-                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP);
+                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP, L.ring + lane);
             if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
                 m->path = 2;
                 const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;

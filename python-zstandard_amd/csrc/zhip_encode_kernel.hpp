@@ -27,14 +27,6 @@ ZH_CONST int16_t ze_llDef[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2
 ZH_CONST int16_t ze_mlDef[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
                                  1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
 ZH_CONST int16_t ze_ofDef[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
-// level rows 1..4 of the four source-size classes (zstd.c:30650-30755): wlog clog hlog slog mml tlen strategy
-ZH_CONST int8_t ze_rows[4][5][7] = {
-    {{19,12,13,1,6,1,1},{19,13,14,1,7,0,1},{20,15,16,1,6,0,1},{21,16,17,1,5,0,2},{21,18,18,1,5,0,2}},
-    {{18,12,13,1,5,1,1},{18,13,14,1,6,0,1},{18,14,14,1,5,0,2},{18,16,16,1,4,0,2},{18,16,17,3,5,2,3}},
-    {{17,12,12,1,5,1,1},{17,12,13,1,6,0,1},{17,13,15,1,5,0,1},{17,15,16,2,5,0,2},{17,17,17,2,4,0,2}},
-    {{14,12,13,1,5,1,1},{14,14,15,1,5,0,1},{14,14,15,1,4,0,1},{14,14,15,2,4,0,2},{14,14,14,4,4,2,3}},
-};
-
 struct ZeNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
 
 struct ZeLDS {
@@ -1723,21 +1715,23 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
 }
 
 // ------------------------------------------------------------------------------------------ frame
-// ZSTD_getCParams_internal + ZSTD_adjustCParams_internal (zstd.c:30848, :24426) for a known source size, no dictionary
-ZH_DEV int ze_get_cparams(ZePar& out, int level, uint32_t srcSize)
+// the row of the source's size class (level + explicit parameters, resolved on the host: ZSTD_getCParams_internal zstd.c:30848 +
+// ZSTD_overrideCParams :24578) adjusted to a known source size without dictionary (ZSTD_adjustCParams_internal :24427)
+ZH_DEV int ze_get_cparams(ZePar& out, const ZeRows& rows, uint32_t srcSize)
 {
-    if (level == 0) level = 3;
-    if (level > 4) return ZE_PARAM_UNSUPPORTED;
     const uint32_t tableID = (srcSize <= 256u * 1024) + (srcSize <= 128u * 1024) + (srcSize <= 16u * 1024);
-    const int row = level < 0 ? 0 : level;                 // negative levels: row 0 with targetLength = -level (zstd.c:30870-30875)
-    int w = ze_rows[tableID][row][0], c = ze_rows[tableID][row][1], h = ze_rows[tableID][row][2];
+    const int32_t* const r = rows.r[tableID];
+    int w = r[0], c = r[1], h = r[2];
     const int srcLog = srcSize < 64 ? 6 : zh_highbit32(srcSize - 1) + 1;
     if (w > srcLog) w = srcLog;
     if (h > w + 1) h = w + 1;
-    if (c > w) c = w;
+    if (c > w) c = w;                                      // cycleLog == chainLog below btlazy2
     if (w < 10) w = 10;
-    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][row][4]; out.strat = ze_rows[tableID][row][6];
-    out.tlen = level < 0 ? (level < -(1 << 17) ? (1 << 17) : -level) : ze_rows[tableID][row][5];
+    out.wlog = w; out.clog = c; out.hlog = h; out.mml = r[4]; out.strat = r[6]; out.tlen = r[5];
+    if (out.strat != 1 && out.strat != 2) return ZE_PARAM_UNSUPPORTED;     // greedy and above are not implemented: refused, never approximated
+    // an explicit window smaller than the source AND smaller than a block makes the match window slide inside a block
+    // (ZSTD_getLowestPrefixIndex, zstd.c:19470); the level tables never produce that and the kernels do not implement it: refused
+    if (w < 17 && (1u << w) < srcSize) return ZE_PARAM_UNSUPPORTED;
     return 0;
 }
 
@@ -1804,7 +1798,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     const uint32_t srcSize = (uint32_t)srcSize64;
     if (cap64 < (uint64_t)srcSize + (srcSize >> 8)) return ZE_DST_TOO_SMALL;
     ZePar cp;
-    const int e = ze_get_cparams(cp, a.level, srcSize);
+    const int e = ze_get_cparams(cp, a.rows, srcSize);
     if (e) return e;
     if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
     const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
@@ -1813,7 +1807,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     uint32_t pos = 0;
     zh_sync();
     if (zh_opaque(lane) == 0) {
-        zh_st32(dst, ZF_MAGIC); pos = 4;
+        if (!a.magicless) { zh_st32(dst, ZF_MAGIC); pos = 4; }
         dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
         if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
         if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
@@ -1872,7 +1866,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     if (cap64 < bound) return ZE_DST_TOO_SMALL;
     const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
     ZePar cp;
-    const int e = ze_get_cparams(cp, a.level, srcSize);
+    const int e = ze_get_cparams(cp, a.rows, srcSize);
     if (e) return e;
     if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
     if (cp.strat == 1 && a.cdict) return ZE_PARAM_UNSUPPORTED;           // dictionary search is implemented for double-fast only
@@ -1891,7 +1885,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     const uint32_t fcsCode = contentSize ? (srcSize >= 256) + (srcSize >= 65536 + 256) : 0;
     zh_sync();
     if (zh_opaque(lane) == 0) {
-        zh_st32(dst, ZF_MAGIC); pos = 4;
+        if (!a.magicless) { zh_st32(dst, ZF_MAGIC); pos = 4; }
         dst[pos++] = (uint8_t)(dictCode + (checksum << 2) + (single << 5) + (fcsCode << 6));
         if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
         if (dictCode == 1) dst[pos++] = (uint8_t)dictID;
@@ -1934,13 +1928,12 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
 // ------------------------------------------------------------------------------------------ dictionary digestion (one wave, once per dictionary)
 // parameters of the dictionary's own tables: ZSTD_getCParams_internal(level, unknown source, dictSize, ZSTD_cpm_createCDict)
 // (zstd.c:30848, :24426)
-ZH_DEV int ze_cdict_params(ZePar& out, int level, uint32_t dictSize)
+ZH_DEV int ze_cdict_params(ZePar& out, const ZeRows& rows, uint32_t dictSize)
 {
-    if (level == 0) level = 3;
-    if (level < 1 || level > 4) return ZE_PARAM_UNSUPPORTED;
     const uint64_t rSize = (uint64_t)dictSize + 499;
     const uint32_t tableID = (rSize <= 256u * 1024) + (rSize <= 128u * 1024) + (rSize <= 16u * 1024);
-    int w = ze_rows[tableID][level][0], c = ze_rows[tableID][level][1], h = ze_rows[tableID][level][2];
+    const int32_t* const r = rows.r[tableID];
+    int w = r[0], c = r[1], h = r[2];
     const uint32_t srcSize = 513;                       // createCDict mode assumes a small source
     const uint32_t t = srcSize + dictSize;
     const int srcLog = t < 64 ? 6 : zh_highbit32(t - 1) + 1;
@@ -1952,7 +1945,7 @@ ZH_DEV int ze_cdict_params(ZePar& out, int level, uint32_t dictSize)
     if (w < 10) w = 10;
     if (h > 24) h = 24;
     if (c > 24) c = 24;
-    out.wlog = w; out.clog = c; out.hlog = h; out.mml = ze_rows[tableID][level][4]; out.strat = ze_rows[tableID][level][6];
+    out.wlog = w; out.clog = c; out.hlog = h; out.mml = r[4]; out.strat = r[6]; out.tlen = r[5];
     return 0;
 }
 ZH_DEV uint32_t ze_ncount_repeat(const int16_t* norm, uint32_t dictMax, uint32_t needMax)      // ZSTD_dictNCountRepeat, zstd.c:27998
@@ -1966,7 +1959,7 @@ ZH_DEV uint32_t ze_ncount_repeat(const int16_t* norm, uint32_t dictMax, uint32_t
 // ZSTD_fillDoubleHashTableForCDict (:30952) done wave-parallel: the sequential fill keeps, per cell, the LAST position of the
 // every-third-position series and otherwise the FIRST of the in-between positions, which is an atomic max / min.
 // hashLong, hashSmall: 1 << ZE_CDICT_MAX_HLOG cells each; tmpLong: scratch of the same size. All lanes call.
-ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, int level, ZeCDict* cd,
+ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, const ZeRows& rows, ZeCDict* cd,
                             uint32_t* hashLong, uint32_t* hashSmall, uint32_t* tmpLong, ZeLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -1977,7 +1970,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     zh_sync();
     if (zh_opaque(lane) == 0) {
         ZePar p; p.wlog = p.clog = p.hlog = p.mml = p.strat = p.tlen = 0;
-        int st = ze_cdict_params(p, level, dictSize);
+        int st = ze_cdict_params(p, rows, dictSize);
         if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
         cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
         cd->contentSize = cs; cd->dictID = hasEntropy ? de->dictID : 0u;
@@ -2103,7 +2096,7 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
             a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
             continue;
         }
-        if (ze_get_cparams(cp, a.level, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
+        if (ze_get_cparams(cp, a.rows, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
             (size_t)(4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         const uint32_t srcSize = (uint32_t)srcSize64;
         if (a.cdict) {
@@ -2140,7 +2133,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     ZePar cp;
     if (srcSize64 > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; return; }
     const uint32_t srcSize = (uint32_t)srcSize64;
-    if (a.cdict || srcSize < 64 || ze_get_cparams(cp, a.level, srcSize) || cp.strat != 2 ||
+    if (a.cdict || srcSize < 64 || ze_get_cparams(cp, a.rows, srcSize) || cp.strat != 2 ||
         (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) {
         a.e1List[zh_atomic_add(a.e1Count, 1u)] = i;                       // the lane-serial kernel decides (and reports errors)
         return;

@@ -6,7 +6,7 @@
 enum {
     ZE_OK = 0, ZE_GENERIC = 1, ZE_PREFIX_UNKNOWN = 10, ZE_FRAMEPARAM_UNSUPPORTED = 14, ZE_WINDOW_TOO_LARGE = 16,
     ZE_CORRUPTION = 20, ZE_CHECKSUM_WRONG = 22, ZE_LITERALS_HEADER_WRONG = 24, ZE_DICT_CORRUPTED = 30,
-    ZE_DICT_WRONG = 32, ZE_PARAM_UNSUPPORTED = 40, ZE_TABLELOG_TOO_LARGE = 44, ZE_MAXSYMBOL_TOO_LARGE = 46,
+    ZE_DICT_WRONG = 32, ZE_PARAM_UNSUPPORTED = 40, ZE_PARAM_OUTOFBOUND = 42, ZE_TABLELOG_TOO_LARGE = 44, ZE_MAXSYMBOL_TOO_LARGE = 46,
     ZE_MAXSYMBOL_TOO_SMALL = 48, ZE_MEMORY = 64, ZE_DST_TOO_SMALL = 70, ZE_SRC_SIZE_WRONG = 72
 };
 
@@ -52,6 +52,7 @@ struct ZhipDecodeArgs {
     uint32_t dictContentSize;
     const ZhipDictEntropy* dictEntropy; // null when no dictionary or raw-content dictionary
     uint64_t maxWindowSize;
+    uint32_t magicless;             // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
     const uint32_t* frameList;      // optional indirection: process frameList[0 .. *listCount) instead of 0 .. n (pipeline fallback)
     const uint32_t* listCount;
     unsigned long long* prof;       // optional: per-phase cycle totals (ZHIP_PROF bring-up / tuning aid), else null
@@ -74,6 +75,11 @@ struct ZhipDecodeArgs {
 #define ZE_WS_LIT   (ZE_WS_SEQ + 8u * (ZE_SEQ_CAP + 8))
 #define ZHIP_ENC_STRIDE (ZE_WS_LIT + ZF_BLOCK_MAX + 256)
 
+// compression parameter rows, one per source-size class (> 256 KiB, <= 256 KiB, <= 128 KiB, <= 16 KiB): windowLog chainLog hashLog
+// searchLog minMatch targetLength strategy, resolved on the host from the level and the caller's explicit parameters (zhip_cparams.hpp);
+// the per-source adjustment (ZSTD_adjustCParams_internal) is done per frame on the device
+struct ZeRows { int32_t r[4][7]; };
+
 struct ZhipEncodeArgs {
     const uint8_t* src;             // all inputs
     const uint64_t* srcSegs;        // n x (offset, length)
@@ -84,8 +90,10 @@ struct ZhipEncodeArgs {
     uint8_t* workspace;             // gridDim.x * ZHIP_ENC_STRIDE
     uint32_t* counter;              // work-stealing counter, zeroed before launch
     uint32_t n;
-    int32_t level;
+    int32_t level;                  // informational (the rows below are what the kernels read)
     uint32_t contentSizeFlag, checksumFlag, dictIDFlag;
+    uint32_t magicless;             // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
+    ZeRows rows;
     unsigned long long* prof;
     // two-kernel form (match finding with one LANE per frame, then entropy coding with one wave per frame)
     struct ZeMeta* meta;            // chunk-local per-frame record
@@ -175,7 +183,7 @@ struct ZdMeta {
 #define ZP_FSE_OF 1024
 #define ZP_FSE_CELLS 1280
 #ifndef ZP_K2_LANES
-#define ZP_K2_LANES 63
+#define ZP_K2_LANES 60
 #endif
 //      ^                                  // frames decoded per K2 wave (one lane each); one wave per CU
 #define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
@@ -202,5 +210,6 @@ struct ZhipPipeArgs {
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk
     uint64_t maxWindowSize;
+    uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
     unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases
 };

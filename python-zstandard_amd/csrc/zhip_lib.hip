@@ -14,6 +14,7 @@
 #include "../../include/zstd_hip.h"
 #include "zhip_decode_pipeline.hpp"
 #include "zhip_encode_kernel.hpp"
+#include "zhip_cparams.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
 ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
@@ -65,11 +66,11 @@ ZH_GLOBAL __launch_bounds__(64, ZE_E2_MINWAVES) void zhip_encode_entropy_kernel(
     __shared__ ZeLDS L;
     ze_entropy_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_build_cdict_kernel(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, int level,
+ZH_GLOBAL __launch_bounds__(64) void zhip_build_cdict_kernel(const uint8_t* dict, uint32_t dictSize, const ZhipDictEntropy* de, ZeRows rows,
                                                               ZeCDict* cd, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* tmpLong)
 {
     __shared__ ZeLDS L;
-    ze_cdict_body(dict, dictSize, de, level, cd, hashLong, hashSmall, tmpLong, L);
+    ze_cdict_body(dict, dictSize, de, rows, cd, hashLong, hashSmall, tmpLong, L);
 }
 ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
 {
@@ -120,6 +121,7 @@ extern "C" const char* zhip_error_name(int code)
     case ZE_DICT_CORRUPTED: return "Dictionary is corrupted";
     case ZE_DICT_WRONG: return "Dictionary mismatch";
     case ZE_PARAM_UNSUPPORTED: return "Unsupported parameter";
+    case ZE_PARAM_OUTOFBOUND: return "Parameter is out of bound";
     case ZE_TABLELOG_TOO_LARGE: return "tableLog requires too much memory : unsupported";
     case ZE_MAXSYMBOL_TOO_LARGE: return "Unsupported max Symbol Value : too large";
     case ZE_MAXSYMBOL_TOO_SMALL: return "Specified maxSymbolValue is too small";
@@ -138,34 +140,37 @@ static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); re
 
 struct HostFrameHeader { uint64_t contentSize; uint32_t headerSize; uint32_t hasChecksum; };
 // RFC 8878 3.1.1.1; restates ZSTD_getFrameHeader_advanced (zstd.c:43668) for the fields the dispatcher needs.
-static int host_frame_header(HostFrameHeader* h, const uint8_t* src, size_t n)
+static int host_frame_header(HostFrameHeader* h, const uint8_t* src, size_t n, int format)
 {
-    if (n < 5) return -ZE_SRC_SIZE_WRONG;
-    if (rd32(src) != ZF_MAGIC) return -ZE_PREFIX_UNKNOWN;
-    uint32_t fhd = src[4], dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
+    const size_t mg = format == ZHIP_FORMAT_ZSTD1_MAGICLESS ? 0 : 4;
+    if (n < mg + 1) return -ZE_SRC_SIZE_WRONG;
+    if (mg && rd32(src) != ZF_MAGIC) return -ZE_PREFIX_UNKNOWN;
+    src += mg; n -= mg;
+    uint32_t fhd = src[0], dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
     uint32_t dictBytes = dictCode == 3 ? 4 : dictCode, fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
-    uint32_t hs = 5 + (single ? 0 : 1) + dictBytes + fcsBytes;
+    uint32_t hs = 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
     if (fhd & 8) return -ZE_FRAMEPARAM_UNSUPPORTED;
     if (n < hs) return -ZE_SRC_SIZE_WRONG;
-    const uint8_t* p = src + 5 + (single ? 0 : 1) + dictBytes;
+    const uint8_t* p = src + 1 + (single ? 0 : 1) + dictBytes;
     h->contentSize = ZHIP_CONTENTSIZE_UNKNOWN;
     if (fcsCode == 0) { if (single) h->contentSize = p[0]; }
     else if (fcsCode == 1) h->contentSize = (uint64_t)rd16(p) + 256;
     else if (fcsCode == 2) h->contentSize = rd32(p);
     else h->contentSize = rd64(p);
-    h->headerSize = hs; h->hasChecksum = (fhd >> 2) & 1;
+    h->headerSize = (uint32_t)mg + hs; h->hasChecksum = (fhd >> 2) & 1;
     return 0;
 }
-extern "C" uint64_t zhip_frame_content_size(const void* src, size_t n)
+extern "C" uint64_t zhip_frame_content_size_format(const void* src, size_t n, int format)
 {
     HostFrameHeader h;
-    if (host_frame_header(&h, (const uint8_t*)src, n) < 0) return ZHIP_CONTENTSIZE_ERROR;
+    if (host_frame_header(&h, (const uint8_t*)src, n, format) < 0) return ZHIP_CONTENTSIZE_ERROR;
     return h.contentSize;
 }
-extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
+extern "C" uint64_t zhip_frame_content_size(const void* src, size_t n) { return zhip_frame_content_size_format(src, n, ZHIP_FORMAT_ZSTD1); }
+extern "C" int64_t zhip_find_frame_compressed_size_format(const void* srcv, size_t n, int format)
 {
     const uint8_t* src = (const uint8_t*)srcv;
-    HostFrameHeader h; int e = host_frame_header(&h, src, n); if (e < 0) return e;
+    HostFrameHeader h; int e = host_frame_header(&h, src, n, format); if (e < 0) return e;
     size_t pos = h.headerSize;
     for (;;) {
         if (pos + 3 > n) return -ZE_SRC_SIZE_WRONG;
@@ -180,6 +185,8 @@ extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
     if (h.hasChecksum) { if (pos + 4 > n) return -ZE_SRC_SIZE_WRONG; pos += 4; }
     return (int64_t)pos;
 }
+extern "C" int64_t zhip_find_frame_compressed_size(const void* src, size_t n) { return zhip_find_frame_compressed_size_format(src, n, ZHIP_FORMAT_ZSTD1); }
+extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out) { if (out) zh_get_cparams(level, srcSizeHint, dictSize, out); }
 
 // ------------------------------------------------------------------------------------------ context
 #ifndef ZHIP_NSLOT
@@ -188,6 +195,7 @@ extern "C" int64_t zhip_find_frame_compressed_size(const void* srcv, size_t n)
 #ifndef ZHIP_DCHUNK
 #define ZHIP_DCHUNK 32768
 #endif
+static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed DevBuf::reserve failed (ZHIP_ERR_NO_MEMORY or ZHIP_ERR_HIP)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t n) {
@@ -195,7 +203,10 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = n + (n >> 3) + 4096;
-        HIP_TRY(hipMalloc(&p, want));
+        if (want < n) { g_lastError = "allocation size overflow"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
+        const hipError_t e = hipMalloc(&p, want);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
+        if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
         cap = want; return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -217,7 +228,8 @@ struct zhip_ctx {
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
     int e1PerCU = 0, e2PerCU = 0;
-    zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0};
+    zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
+    ZeRows rows = {};                  // cparams resolved per source-size class (zhip_cparams.hpp)
     DevBuf scratch, counter;
     // dictionary (compress side): raw bytes, parsed entropy section, digested form and its tagged tables
     DevBuf cdictBlob, cdictEntropy, cdictDigest, cdictTables;
@@ -227,6 +239,7 @@ struct zhip_ctx {
     DevBuf dictBlob, dictEntropy;
     uint32_t dictSize = 0, dictID = 0, dictContentOffset = 0; bool dictHasEntropy = false;
     uint64_t maxWindowSize = (1ull << 27) + 1;
+    int dformat = ZHIP_FORMAT_ZSTD1;
     // host-API staging
     DevBuf hSrc, hDst, hSegs, hStatus;
     void* pinned = nullptr; size_t pinnedCap = 0;
@@ -240,6 +253,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { g_lastError = "hipGetDeviceProperties failed"; delete c; return nullptr; }
     c->numCU = prop.multiProcessorCount;
+    zh_resolve_rows(&c->rows, 3, nullptr);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 8;
     c->decBlocksPerCU = nb;
@@ -318,28 +332,43 @@ static uint64_t dict_fingerprint(const void* p, size_t n, uint64_t salt)
     h ^= (uint64_t)n * 0x9E3779B97F4A7C15ull;
     return h ? h : 1;
 }
-extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dictSize)
+extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dictSize, int dictType)
 {
+    if (!c) return ZHIP_ERR_UNSUPPORTED;
+    if (dictType != ZHIP_DICT_AUTO && dictType != ZHIP_DICT_RAWCONTENT && dictType != ZHIP_DICT_FULLDICT) { g_lastError = "invalid dictionary type"; return ZHIP_ERR_UNSUPPORTED; }
     if (hostDict && dictSize) {
-        const uint64_t key = dict_fingerprint(hostDict, dictSize, 0);
+        const uint64_t key = dict_fingerprint(hostDict, dictSize, 0x100u + (uint64_t)dictType);
         if (c->dictSize == dictSize && c->ddictKey == key) return 0;       // same dictionary as last time: tables are still resident
         c->ddictKey = key;
     } else c->ddictKey = 0;
     c->dictSize = 0; c->dictID = 0; c->dictContentOffset = 0; c->dictHasEntropy = false;
     if (!hostDict || !dictSize) return 0;
-    if (dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; return ZHIP_ERR_UNSUPPORTED; }
-    if (c->dictBlob.reserve(dictSize + 16)) return ZHIP_ERR_HIP;
-    if (c->dictEntropy.reserve(sizeof(ZhipDictEntropy))) return ZHIP_ERR_HIP;
+    if (dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; c->ddictKey = 0; return ZHIP_ERR_UNSUPPORTED; }
+    // ZSTD_loadEntropy_intoDDict (zstd.c:42716): raw content when asked for, when shorter than 8 bytes or when the magic is absent --
+    // unless a full dictionary was demanded, which is then "Dictionary is corrupted"
+    const bool hasMagic = dictSize >= 8 && rd32((const uint8_t*)hostDict) == ZF_DICT_MAGIC;
+    if (dictType == ZHIP_DICT_FULLDICT && !hasMagic) { c->ddictKey = 0; return -ZE_DICT_CORRUPTED; }
+    if (c->dictBlob.reserve(dictSize + 16)) { c->ddictKey = 0; return g_reserveRc; }
+    if (c->dictEntropy.reserve(sizeof(ZhipDictEntropy))) { c->ddictKey = 0; return g_reserveRc; }
     HIP_TRY(hipMemcpy(c->dictBlob.p, hostDict, dictSize, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(c->dictEntropy.p, 0, sizeof(ZhipDictEntropy)));
-    hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->dictBlob.p, (uint32_t)dictSize,
-                       (ZhipDictEntropy*)c->dictEntropy.p);
-    HIP_TRY(hipGetLastError());
-    ZhipDictEntropy de;
-    HIP_TRY(hipMemcpy(&de, c->dictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
-    if (de.status) return -de.status;            // negative zstd error code: dictionary corrupted
+    ZhipDictEntropy de; memset(&de, 0, sizeof de);
+    if (hasMagic && dictType != ZHIP_DICT_RAWCONTENT) {
+        hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->dictBlob.p, (uint32_t)dictSize,
+                           (ZhipDictEntropy*)c->dictEntropy.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(&de, c->dictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
+        if (de.status) { c->ddictKey = 0; return -de.status; }            // negative zstd error code: dictionary corrupted
+    }
     c->dictSize = (uint32_t)dictSize; c->dictID = de.dictID; c->dictContentOffset = de.contentOffset;
     c->dictHasEntropy = de.hufCount != 0;
+    return 0;
+}
+extern "C" int zhip_ctx_set_dformat(zhip_ctx* c, int format, uint64_t maxWindowSize)
+{
+    if (!c || (format != ZHIP_FORMAT_ZSTD1 && format != ZHIP_FORMAT_ZSTD1_MAGICLESS)) { g_lastError = "invalid frame format"; return ZHIP_ERR_UNSUPPORTED; }
+    c->dformat = format;
+    c->maxWindowSize = maxWindowSize ? maxWindowSize : ((1ull << 27) + 1);
     return 0;
 }
 // bring-up probe: launches a 64-lane kernel exercising every wave primitive the codec uses; returns 0 when correct
@@ -357,34 +386,53 @@ extern "C" int zhip_selftest(void)
 extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
 {
     if (!c || !p) return ZHIP_ERR_UNSUPPORTED;
-    int level = p->level == 0 ? 3 : p->level;
-    if (level > 4) { g_lastError = "HIP backend compresses with the fast and double-fast strategies only (levels <= 3, negative levels; level 4 for inputs above 16 KiB)"; return ZHIP_ERR_UNSUPPORTED; }
-    if (p->dict && p->dictSize) {
-        const uint64_t key = dict_fingerprint(p->dict, p->dictSize, (uint64_t)level);
-        if (c->hasCDict && c->cdictKey == key) { c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; return 0; }
+    if (p->dictType != ZHIP_DICT_AUTO && p->dictType != ZHIP_DICT_RAWCONTENT && p->dictType != ZHIP_DICT_FULLDICT) { g_lastError = "invalid dictionary type"; return ZHIP_ERR_UNSUPPORTED; }
+    if (p->format != ZHIP_FORMAT_ZSTD1 && p->format != ZHIP_FORMAT_ZSTD1_MAGICLESS) { g_lastError = "invalid frame format"; return ZHIP_ERR_UNSUPPORTED; }
+    // level + explicit parameters -> one row per source-size class; the kernels implement the fast and double-fast strategies
+    ZeRows rows;
+    zh_resolve_rows(&rows, p->level, &p->cp);
+    bool any = false;
+    for (int t = 0; t < 4; t++) {
+        if (!zh_check_cparams(rows.r[t])) return -ZE_PARAM_OUTOFBOUND;        // what ZSTD_CCtx_setParametersUsingCCtxParams reports
+        any |= rows.r[t][6] == 1 || rows.r[t][6] == 2;
+    }
+    if (!any) { g_lastError = "HIP backend compresses with the fast and double-fast strategies only (levels <= 3, negative levels; level 4 for inputs above 16 KiB; or explicit strategy / parameters that select them)"; return ZHIP_ERR_UNSUPPORTED; }
+    // a dictionary shorter than 8 bytes is not loaded at all (ZSTD_compress_insertDictionary, zstd.c:28167) -- unless a full dictionary
+    // was demanded, which is then "Dictionary mismatch"; so is a blob without the magic
+    const bool hasDict = p->dict && p->dictSize;
+    const bool hasMagic = hasDict && p->dictSize >= 8 && rd32((const uint8_t*)p->dict) == ZF_DICT_MAGIC;
+    if (hasDict && p->dictType == ZHIP_DICT_FULLDICT && !hasMagic) return -ZE_DICT_WRONG;
+    const bool useDict = hasDict && p->dictSize >= 8;
+    if (useDict) {
+        uint64_t salt = 0x200u + (uint64_t)p->dictType;
+        for (int t = 0; t < 4; t++) for (int k = 0; k < 7; k++) salt = salt * 1000003u + (uint64_t)(uint32_t)rows.r[t][k];
+        const uint64_t key = dict_fingerprint(p->dict, p->dictSize, salt);
+        if (c->hasCDict && c->cdictKey == key) { c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows; return 0; }
         c->cdictKey = key;
     }
     c->hasCDict = false;
-    if (p->dict && p->dictSize) {
+    if (useDict) {
         // digest the dictionary on the device: parse its entropy section, build the encoding tables, index its content
         // (what ZSTD_createCDict does on the host in the reference, zstd.c:28490-28614)
         if (p->dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
         if (c->cdictBlob.reserve(p->dictSize + 16) || c->cdictEntropy.reserve(sizeof(ZhipDictEntropy)) ||
-            c->cdictDigest.reserve(sizeof(ZeCDict)) || c->cdictTables.reserve(3 * cells * sizeof(uint32_t))) return ZHIP_ERR_HIP;
+            c->cdictDigest.reserve(sizeof(ZeCDict)) || c->cdictTables.reserve(3 * cells * sizeof(uint32_t))) return g_reserveRc;
         HIP_TRY(hipMemcpy(c->cdictBlob.p, p->dict, p->dictSize, hipMemcpyHostToDevice));
         HIP_TRY(hipMemset((uint8_t*)c->cdictBlob.p + p->dictSize, 0, 16));
         HIP_TRY(hipMemset(c->cdictEntropy.p, 0, sizeof(ZhipDictEntropy)));
         HIP_TRY(hipMemset(c->cdictDigest.p, 0, sizeof(ZeCDict)));
-        hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
-                           (ZhipDictEntropy*)c->cdictEntropy.p);
-        HIP_TRY(hipGetLastError());
-        ZhipDictEntropy de;
-        HIP_TRY(hipMemcpy(&de, c->cdictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
-        if (de.status) return -de.status;
+        ZhipDictEntropy de; memset(&de, 0, sizeof de);
+        if (hasMagic && p->dictType != ZHIP_DICT_RAWCONTENT) {
+            hipLaunchKernelGGL(zhip_parse_dict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
+                               (ZhipDictEntropy*)c->cdictEntropy.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(&de, c->cdictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
+            if (de.status) return -de.status;
+        }
         uint32_t* t = (uint32_t*)c->cdictTables.p;
         hipLaunchKernelGGL(zhip_build_cdict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
-                           (const ZhipDictEntropy*)c->cdictEntropy.p, level, (ZeCDict*)c->cdictDigest.p, t, t + cells, t + 2 * cells);
+                           (const ZhipDictEntropy*)c->cdictEntropy.p, rows, (ZeCDict*)c->cdictDigest.p, t, t + cells, t + 2 * cells);
         HIP_TRY(hipGetLastError());
         ZeCDict cd;
         HIP_TRY(hipMemcpy(&cd, c->cdictDigest.p, sizeof cd, hipMemcpyDeviceToHost));
@@ -392,7 +440,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         if (cd.status) return -cd.status;
         c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
     }
-    c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0;
+    c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows;
     return 0;
 }
 
@@ -407,8 +455,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     hipStream_t stream = (hipStream_t)streamv;
     size_t maxBlocks = (size_t)c->numCU * (size_t)c->decBlocksPerCU;
     uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
-    if (c->scratch.reserve((size_t)grid * ZHIP_LIT_STRIDE)) return ZHIP_ERR_HIP;
-    if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
+    if (c->scratch.reserve((size_t)grid * ZHIP_LIT_STRIDE)) return g_reserveRc;
+    if (c->counter.reserve(64)) return g_reserveRc;
     HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
     const uint32_t* d_fallbackList = nullptr; const uint32_t* d_fallbackCount = nullptr;
     const bool usePipeline = c->dictSize == 0 && getenv("ZHIP_NO_PIPELINE") == nullptr;
@@ -427,7 +475,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
             c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
-            c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return ZHIP_ERR_HIP;
+            c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return g_reserveRc;
         for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 256, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
@@ -437,7 +485,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         ZhipPipeArgs pa; memset(&pa, 0, sizeof pa);
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
         pa.outSizes = d_outSizes; pa.status = d_status; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
-        pa.maxWindowSize = c->maxWindowSize;
+        pa.maxWindowSize = c->maxWindowSize; pa.magicless = c->dformat == ZHIP_FORMAT_ZSTD1_MAGICLESS;
         static unsigned long long* d_pprof = nullptr;
         if (getenv("ZHIP_PROF")) {
             if (!d_pprof) HIP_TRY(hipMalloc((void**)&d_pprof, 32 * 8));
@@ -538,7 +586,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
     a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
     a.scratch = (uint8_t*)c->scratch.p; a.counter = (uint32_t*)c->counter.p; a.n = (uint32_t)n;
-    a.maxWindowSize = c->maxWindowSize;
+    a.maxWindowSize = c->maxWindowSize; a.magicless = c->dformat == ZHIP_FORMAT_ZSTD1_MAGICLESS;
     a.frameList = d_fallbackList; a.listCount = d_fallbackCount;
     if (c->dictSize) {
         a.dictID = c->dictID;
@@ -606,13 +654,14 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     hipStream_t stream = (hipStream_t)streamv;
     size_t maxBlocks = (size_t)c->numCU * (size_t)c->encBlocksPerCU;
     uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
-    if (c->counter.reserve(64)) return ZHIP_ERR_HIP;
+    if (c->counter.reserve(64)) return g_reserveRc;
     HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 4, stream));
     ZhipEncodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
     a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
     a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)((uint8_t*)c->counter.p + 8); a.n = (uint32_t)n;
     a.level = c->cparams.level == 0 ? 3 : c->cparams.level;
+    a.rows = c->rows; a.magicless = c->cparams.format == ZHIP_FORMAT_ZSTD1_MAGICLESS;
     a.contentSizeFlag = c->cparams.contentSizeFlag != 0; a.checksumFlag = c->cparams.checksumFlag != 0; a.dictIDFlag = c->cparams.dictIDFlag != 0;
     if (c->hasCDict) {
         const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
@@ -624,12 +673,25 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     if (getenv("ZHIP_NO_PIPELINE") == nullptr) {
         // two kernels: E1 searches with one LANE per frame (frames in flight hide the probe latency), E2 entropy-codes with one
         // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
-        const int level = a.level;
-        a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));        // largest dfast tables for inputs <= 128 KiB
-        // levels 3-4 without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
+        // table bytes of the largest one-block source of the two size classes these kernels serve (<= 128 KiB, <= 16 KiB), after the
+        // per-source adjustment ze_get_cparams makes (windowLog <= 17 / 14, hashLog <= windowLog + 1, chainLog <= windowLog)
+        bool anyDfast = false; uint32_t stride = 0;
+        for (int t = 2; t < 4; t++) {
+            const int32_t* r = a.rows.r[t];
+            if (r[6] != 1 && r[6] != 2) continue;
+            const int w = r[0] < (t == 2 ? 17 : 14) ? r[0] : (t == 2 ? 17 : 14);
+            const int h = r[2] > w + 1 ? w + 1 : r[2], cl = r[1] > w ? w : r[1];
+            const uint32_t bytes = (4u << h) + (r[6] == 2 ? (4u << cl) : 0u);
+            if (bytes > stride) stride = bytes;
+            anyDfast |= r[6] == 2;
+        }
+        if (stride < (4u << 10)) stride = 4u << 10;
+        if (stride > (12u << 17)) stride = 12u << 17;                  // larger tables: the frame is refused loudly by the match kernels
+        a.tableStride = stride;
+        // double-fast without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
         // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
-        // (levels <= 2) and dictionary batches use the lane-serial kernel for the whole chunk.
-        const bool flat = level >= 3 && !c->hasCDict && getenv("ZHIP_NO_FLAT") == nullptr;
+        // and dictionary batches use the lane-serial kernel for the whole chunk.
+        const bool flat = anyDfast && !c->hasCDict && getenv("ZHIP_NO_FLAT") == nullptr;
         size_t chunkMax = flat ? 65536 : 32768;
         if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64 && (size_t)v < chunkMax) chunkMax = (size_t)v; }
@@ -644,7 +706,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
             c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
             c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
-            (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return ZHIP_ERR_HIP;
+            (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return g_reserveRc;
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
         a.flatTables = (uint8_t*)c->encFlatTables.p; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)((uint8_t*)c->counter.p + 32);
@@ -693,7 +755,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.prof = nullptr;
         }
         {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
-            if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+            if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
             ZhipEncodeArgs b = a;
             b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);
             b.frameList = a.bigList; b.listCount = a.bigCount;
@@ -709,7 +771,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         return 0;
     }
-    if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return ZHIP_ERR_HIP;
+    if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return g_reserveRc;
     a.workspace = (uint8_t*)c->encWorkspace.p;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -755,11 +817,24 @@ static int ensure_pinned(zhip_ctx* c, size_t n)
     c->pinnedCap = want;
     return 0;
 }
-static thread_local zhip_ctx* g_tlsCtx = nullptr;   // one lazily created context per calling thread
+// one lazily created context per calling thread, destroyed when the thread exits; re-created when the thread switched devices
+struct TlsCtx { zhip_ctx* c = nullptr; ~TlsCtx() { if (c) zhip_ctx_destroy(c); } };
+static thread_local TlsCtx g_tls;
 static zhip_ctx* tls_ctx()
 {
-    if (!g_tlsCtx) g_tlsCtx = zhip_ctx_create();
-    return g_tlsCtx;
+    int dev = -1;
+    if (g_tls.c && hipGetDevice(&dev) == hipSuccess && dev != g_tls.c->device) { zhip_ctx_destroy(g_tls.c); g_tls.c = nullptr; }
+    if (!g_tls.c) g_tls.c = zhip_ctx_create();
+    return g_tls.c;
+}
+// the host-buffer API keeps its scratch between calls (allocation is slow), but not the tens of GiB a 65 536-frame batch needs
+static void tls_trim(zhip_ctx* c)
+{
+    const size_t limit = (size_t)2 << 30;
+    DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeSeq, &c->pipeFse, &c->pipeHuf, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
+                       &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst };
+    for (DevBuf* b : bufs) if (b->cap > limit) b->release();
+    if (c->pinnedCap > limit) { (void)hipHostFree(c->pinned); c->pinned = nullptr; c->pinnedCap = 0; }
 }
 static int set_err(zhip_error* err, int kind, size_t index, int zerr, uint64_t d0 = 0, uint64_t d1 = 0)
 {
@@ -784,28 +859,33 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // pass 1 (decompress_worker pass 1, decompressor.c:981-1014): every frame needs a known decompressed size
     std::vector<zhip_segment> segs(2 * n);           // [0,n) source, [n,2n) destination
+    const int format = params ? params->format : ZHIP_FORMAT_ZSTD1;
     uint64_t srcTotal = 0, dstTotal = 0;
     for (size_t i = 0; i < n; i++) {
         uint64_t ds = items[i].dstSize;
         if (ds == 0) {
-            uint64_t fcs = zhip_frame_content_size(items[i].src, items[i].srcSize);
+            uint64_t fcs = zhip_frame_content_size_format(items[i].src, items[i].srcSize, format);
             if (fcs == ZHIP_CONTENTSIZE_ERROR || fcs == ZHIP_CONTENTSIZE_UNKNOWN) return set_err(err, ZHIP_ERR_UNKNOWN_SIZE, i, 0);
             ds = fcs;
         }
+        // the sizes come from untrusted frame headers: a claimed size that cannot be allocated is "out of memory" (what the reference's
+        // malloc of the destination reports, decompressor.c:1085-1090), never a wrapped sum
+        if (ds > ((uint64_t)1 << 46) || dstTotal + ds > ((uint64_t)1 << 46)) return set_err(err, ZHIP_ERR_NO_MEMORY, i, 0);
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;
         segs[n + i].offset = dstTotal; segs[n + i].length = ds; dstTotal += ds;
     }
-    c->maxWindowSize = (params && params->maxWindowSize) ? params->maxWindowSize : ((1ull << 27) + 1);
-    int r = zhip_ctx_set_ddict(c, params ? params->dict : nullptr, params ? params->dictSize : 0);
+    int r = zhip_ctx_set_dformat(c, format, params ? params->maxWindowSize : 0);
+    if (r) return set_err(err, r, 0, 0);
+    r = zhip_ctx_set_ddict(c, params ? params->dict : nullptr, params ? params->dictSize : 0, params ? params->dictType : ZHIP_DICT_AUTO);
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
     // stage: pack the frames into one pinned buffer, one H2D copy
     if (ensure_pinned(c, srcTotal + 8)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
     if (c->hSrc.reserve(srcTotal + 8) || c->hDst.reserve(dstTotal + 8) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
-        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    if (hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess && srcTotal) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, g_reserveRc, 0, 0);
+    if (hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess && srcTotal) return set_err(err, g_reserveRc, 0, 0);
+    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
     uint64_t* dSizes = (uint64_t*)c->hStatus.p;
     int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
     r = zhip_decompress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
@@ -833,6 +913,7 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     memcpy(osegs, segs.data() + n, n * sizeof(zhip_segment));
     ob->data = payload; ob->dataSize = dstTotal; ob->segs = osegs; ob->nSegs = n;
     *out = ob; *nOut = 1;
+    tls_trim(c);
     return ZHIP_ERR_NONE;
 }
 
@@ -842,11 +923,12 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     *out = nullptr; *nOut = 0;
     zhip_ctx* c = tls_ctx();
     if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    zhip_cparams defaults = {3, 1, 0, 1, nullptr, 0};
+    zhip_cparams defaults; memset(&defaults, 0, sizeof defaults);
+    defaults.level = 3; defaults.contentSizeFlag = 1; defaults.dictIDFlag = 1;
     int r = zhip_ctx_set_cparams(c, params ? params : &defaults);
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
-    const bool withDict = params && params->dict && params->dictSize;
+    const bool withDict = c->hasCDict;
     // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are
     // compacted into one payload afterwards
     std::vector<zhip_segment> segs(2 * n);
@@ -868,9 +950,9 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (ensure_pinned(c, (srcTotal > dstTotal ? srcTotal : dstTotal) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
     if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
-        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    if (srcTotal && hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, g_reserveRc, 0, 0);
+    if (srcTotal && hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
+    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
     uint64_t* dSizes = (uint64_t*)c->hStatus.p;
     int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
     r = zhip_compress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
@@ -900,5 +982,6 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     }
     ob->data = payload; ob->dataSize = outTotal; ob->segs = osegs; ob->nSegs = n;
     *out = ob; *nOut = 1;
+    tls_trim(c);
     return ZHIP_ERR_NONE;
 }

@@ -9,23 +9,41 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .common import ZstdError
+from .backend_hip import ZstdError
 
 
 class DeviceBatchContext:
     """Owns the native context (scratch, dictionary tables, kernel timers) for one GPU / one stream."""
 
-    def __init__(self, dict_data=None):
+    def __init__(self, dict_data=None, level=3, write_checksum=False, write_content_size=True, write_dict_id=True, dict_type=0,
+                 format=0, max_window_size=0, **cparams):
+        """dict_data: a ZstdCompressionDict (or bytes) used by both directions; level / write_* / cparams (window_log, hash_log,
+        chain_log, min_match, target_length, strategy): what ZstdCompressor takes; format / max_window_size: what ZstdDecompressor takes."""
         self.L = _lib.lib()
         self.ctx = self.L.zhip_ctx_create()
         if not self.ctx:
             raise ZstdError("HIP backend failure: %s" % _lib.last_error())
-        if dict_data is not None:
-            raw = dict_data.as_bytes()
-            buf = C.create_string_buffer(raw, len(raw))
-            rc = self.L.zhip_ctx_set_ddict(self.ctx, C.cast(buf, C.c_void_p), len(raw))
+        raw = None if dict_data is None else (dict_data.as_bytes() if hasattr(dict_data, "as_bytes") else bytes(dict_data))
+        self._dict_buf = C.create_string_buffer(raw, len(raw)) if raw else None          # kept alive: the library fingerprints it per call
+        rc = self.L.zhip_ctx_set_dformat(self.ctx, format, max_window_size)
+        if rc:
+            raise ZstdError("HIP backend failure: %s" % _lib.last_error())
+        if raw:
+            rc = self.L.zhip_ctx_set_ddict(self.ctx, C.cast(self._dict_buf, C.c_void_p), len(raw), dict_type)
             if rc:
                 raise ZstdError("could not load dictionary: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
+        p = _lib.CParams()
+        p.level, p.contentSizeFlag, p.checksumFlag, p.dictIDFlag = level, int(write_content_size), int(write_checksum), int(write_dict_id)
+        p.dictType, p.format = dict_type, format
+        names = {"window_log": "windowLog", "chain_log": "chainLog", "hash_log": "hashLog", "search_log": "searchLog",
+                 "min_match": "minMatch", "target_length": "targetLength", "strategy": "strategy"}
+        for k, v in cparams.items():
+            setattr(p.cp, names[k], v)
+        if raw:
+            p.dict, p.dictSize = C.cast(self._dict_buf, C.c_void_p), len(raw)
+        rc = self.L.zhip_ctx_set_cparams(self.ctx, C.byref(p))
+        if rc:
+            raise ZstdError("could not set compression parameters: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
 
     def close(self):
         if self.ctx:

@@ -5,10 +5,12 @@
 extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; long zd_stat[16]; }
 #include "../../python-zstandard_amd/csrc/zhip_decode_pipeline.hpp"
 #include "../../python-zstandard_amd/csrc/zhip_encode_kernel.hpp"
+#include "../../python-zstandard_amd/csrc/zhip_cparams.hpp"
 #include <stdlib.h>
 #include <string.h>
 
 static ZdLDS g_lds;
+static uint32_t g_magicless = 0;     // frame format of the next emulated launches (1: ZSTD_f_zstd1_magicless)
 struct DecLaunch { const ZhipDecodeArgs* a; };
 static void dec_lane(void* p) { zd_kernel_body(*((DecLaunch*)p)->a, g_lds); }
 
@@ -22,7 +24,7 @@ extern "C" int emu_decompress_batch(const uint8_t* src, const uint64_t* srcSegs,
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
     a.counter = &counter; a.n = n; a.dictID = dictID; a.dictContent = dictContent; a.dictContentSize = dictContentSize;
-    a.dictEntropy = de; a.maxWindowSize = (1ull << 27) + 1;
+    a.dictEntropy = de; a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
     memset(&g_lds, 0xA5, sizeof g_lds);
     DecLaunch l = { &a };
     zhemu::run_grid(nBlocks, dec_lane, &l);
@@ -45,11 +47,33 @@ static ZeLDS g_elds;
 // compression dictionary digested by the product's own kernels under emulation (mirrors zhip_ctx_set_cparams)
 static std::vector<uint8_t> g_cdBlob; static ZhipDictEntropy g_cdEntropy; static ZeCDict g_cd; static std::vector<uint32_t> g_cdTables;
 static bool g_hasCD = false;
-struct CDLaunch { int level; };
+// explicit compression parameters of the next emulated launches (all zero: derive everything from the level) and the frame format
+static zhip_compression_parameters g_ov;
+extern "C" void emu_set_cparams(uint32_t w, uint32_t c, uint32_t h, uint32_t s, uint32_t mm, uint32_t tl, int32_t strat, uint32_t magicless)
+{
+    g_ov.windowLog = w; g_ov.chainLog = c; g_ov.hashLog = h; g_ov.searchLog = s; g_ov.minMatch = mm; g_ov.targetLength = tl; g_ov.strategy = strat;
+    g_magicless = magicless;
+}
+static uint32_t emu_table_stride(const ZeRows& rows)            // mirrors zhip_compress_batch_device
+{
+    uint32_t stride = 0;
+    for (int t = 2; t < 4; t++) {
+        const int32_t* r = rows.r[t];
+        if (r[6] != 1 && r[6] != 2) continue;
+        const int w = r[0] < (t == 2 ? 17 : 14) ? r[0] : (t == 2 ? 17 : 14);
+        const int h = r[2] > w + 1 ? w + 1 : r[2], cl = r[1] > w ? w : r[1];
+        const uint32_t bytes = (4u << h) + (r[6] == 2 ? (4u << cl) : 0u);
+        if (bytes > stride) stride = bytes;
+    }
+    if (stride < (4u << 10)) stride = 4u << 10;
+    if (stride > (12u << 17)) stride = 12u << 17;
+    return stride;
+}
+struct CDLaunch { ZeRows rows; };
 static void cdict_lane(void* p)
 {
     const size_t cells = (size_t)1 << ZE_CDICT_MAX_HLOG;
-    ze_cdict_body(g_cdBlob.data(), (uint32_t)(g_cdBlob.size() - 16), &g_cdEntropy, ((CDLaunch*)p)->level, &g_cd,
+    ze_cdict_body(g_cdBlob.data(), (uint32_t)(g_cdBlob.size() - 16), &g_cdEntropy, ((CDLaunch*)p)->rows, &g_cd,
                   g_cdTables.data(), g_cdTables.data() + cells, g_cdTables.data() + 2 * cells, g_elds);
 }
 extern "C" int emu_set_cdict(const uint8_t* dict, uint32_t size, int level)
@@ -62,7 +86,7 @@ extern "C" int emu_set_cdict(const uint8_t* dict, uint32_t size, int level)
     zhemu::run_grid(1, dict_lane, &l);
     if (g_cdEntropy.status) return g_cdEntropy.status;
     g_cdTables.assign(3 * ((size_t)1 << ZE_CDICT_MAX_HLOG), 0xDEADBEEFu);
-    CDLaunch c = { level };
+    CDLaunch c; zh_resolve_rows(&c.rows, level, &g_ov);
     zhemu::run_grid(1, cdict_lane, &c);
     if (g_cd.status) return g_cd.status;
     g_hasCD = true;
@@ -85,7 +109,7 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
     uint32_t counter = 0;
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
-    a.counter = &counter; a.n = n; a.level = level;
+    a.counter = &counter; a.n = n; a.level = level; zh_resolve_rows(&a.rows, level, &g_ov); a.magicless = g_magicless;
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);
@@ -121,7 +145,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     a.hufTables = (uint16_t*)malloc((size_t)chunk * ZP_HUF_CELLS * 2 + 64);
     a.orderLit = (uint32_t*)calloc(chunk, 4);
     a.counters = counters; a.fallbackCount = &counters[8]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
-    a.maxWindowSize = (1ull << 27) + 1;
+    a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (int q = 0; q < 8; q++) counters[q] = 0;
@@ -139,7 +163,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     uint32_t counter = 0;
     g.src = src; g.srcSegs = srcSegs; g.dst = dst; g.dstSegs = dstSegs; g.outSizes = outSizes; g.status = status;
     g.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
-    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.frameList = a.fallbackList; g.listCount = &counters[8];
+    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.magicless = g_magicless; g.frameList = a.fallbackList; g.listCount = &counters[8];
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[8];
@@ -159,17 +183,18 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     if (chunk == 0 || chunk > n) chunk = n ? n : 1;
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE);
-    a.counter = counters; a.n = n; a.level = level;
+    a.counter = counters; a.n = n; a.level = level; zh_resolve_rows(&a.rows, level, &g_ov); a.magicless = g_magicless;
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
     free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_E2_STRIDE + ZHIP_ENC_STRIDE);
-    a.tableStride = level == 4 ? (8u << 17) : ((4u << 16) + (4u << 15));
+    a.tableStride = emu_table_stride(a.rows);
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
     a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
     uint32_t bigCount = 0; a.bigList = (uint32_t*)calloc(n ? n : 1, 4); a.bigCount = &bigCount;
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);
-    const bool flat = level >= 3 && !g_hasCD;                 // mirrors zhip_compress_batch_device
+    bool anyDfast = false; for (int t = 2; t < 4; t++) anyDfast |= a.rows.r[t][6] == 2;
+    const bool flat = anyDfast && !g_hasCD;                 // mirrors zhip_compress_batch_device
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
     for (uint32_t first = 0; first < n; first += chunk) {

@@ -27,6 +27,11 @@ class Emu:
             build()
         self.lib = C.CDLL(path)
 
+    def set_cparams(self, window_log=0, chain_log=0, hash_log=0, search_log=0, min_match=0, target_length=0, strategy=0, magicless=False):
+        """explicit compression parameters / frame format of the following emulated launches (all zero / False = defaults)"""
+        self.lib.emu_set_cparams(C.c_uint32(window_log), C.c_uint32(chain_log), C.c_uint32(hash_log), C.c_uint32(search_log),
+                                 C.c_uint32(min_match), C.c_uint32(target_length), C.c_int32(strategy), C.c_uint32(1 if magicless else 0))
+
     def parse_dict(self, dict_bytes):
         """returns (entropy blob or None, content bytes, dictID) using the device dictionary parser under emulation"""
         import struct

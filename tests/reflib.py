@@ -43,6 +43,9 @@ class RefZstd:
             ("ZSTD_CCtx_setParameter", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
             ("ZSTD_CCtx_setPledgedSrcSize", C.c_size_t, [C.c_void_p, C.c_ulonglong]),
             ("ZSTD_CCtx_loadDictionary", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+            ("ZSTD_CCtx_loadDictionary_advanced", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
+            ("ZSTD_DCtx_loadDictionary_advanced", C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
+            ("ZSTD_DCtx_setParameter", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
             ("ZSTD_CCtx_reset", C.c_size_t, [C.c_void_p, C.c_int]),
             ("ZSTD_compressStream2", C.c_size_t, [C.c_void_p, C.POINTER(_Buf), C.POINTER(_Buf), C.c_int]),
             ("ZSTD_compressBound", C.c_size_t, [C.c_size_t]),
@@ -62,6 +65,64 @@ class RefZstd:
         self._tls = threading.local()
 
     # -- contexts are per-thread, reused across frames like compress_worker does (compressor.c:1129-1168)
+    # ZSTD_cParameter numbers (zstd.h): what c-ext/compressionparams.c sets from a ZstdCompressionParameters object
+    PARAM_IDS = {"window_log": 101, "hash_log": 102, "chain_log": 103, "search_log": 104, "min_match": 105, "target_length": 106,
+                 "strategy": 107, "format": 10}
+
+    def compress_advanced(self, data, level=3, flags=DEFAULT_FLAGS, dict_data=None, dict_type=0, **params):
+        """one frame with explicit parameters / dictionary content type / frame format, driven like compress_worker drives a context
+        whose ZSTD_CCtx_params came from a ZstdCompressionParameters object (a fresh context per call)"""
+        L = self.lib
+        data = bytes(data)
+        ctx = L.ZSTD_createCCtx()
+        try:
+            L.ZSTD_CCtx_setParameter(ctx, _P_LEVEL, level)
+            L.ZSTD_CCtx_setParameter(ctx, _P_CONTENTSIZE, 1 if flags & F_CONTENTSIZE else 0)
+            L.ZSTD_CCtx_setParameter(ctx, _P_CHECKSUM, 1 if flags & F_CHECKSUM else 0)
+            L.ZSTD_CCtx_setParameter(ctx, _P_DICTID, 1 if flags & F_DICTID else 0)
+            for k, v in params.items():
+                r = L.ZSTD_CCtx_setParameter(ctx, self.PARAM_IDS[k], v)
+                if L.ZSTD_isError(r):
+                    raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            if dict_data:
+                r = L.ZSTD_CCtx_loadDictionary_advanced(ctx, dict_data, len(dict_data), 1, dict_type)     # ZSTD_dlm_byRef
+                if L.ZSTD_isError(r):
+                    raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            L.ZSTD_CCtx_setPledgedSrcSize(ctx, len(data))
+            cap = L.ZSTD_compressBound(len(data))
+            dst = C.create_string_buffer(max(cap, 1))
+            src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+            out = _Buf(C.addressof(dst), cap, 0)
+            inp = _Buf(C.addressof(src), len(data), 0)
+            r = L.ZSTD_compressStream2(ctx, C.byref(out), C.byref(inp), 2)
+            if L.ZSTD_isError(r):
+                raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            assert r == 0
+            return dst.raw[: out.pos]
+        finally:
+            L.ZSTD_freeCCtx(ctx)
+
+    def decompress_advanced(self, frame, out_size, dict_data=None, dict_type=0, format=0):
+        L = self.lib
+        ctx = L.ZSTD_createDCtx()
+        try:
+            L.ZSTD_DCtx_setParameter(ctx, 1000, format)                         # ZSTD_d_format (experimentalParam1)
+            if dict_data:
+                r = L.ZSTD_DCtx_loadDictionary_advanced(ctx, dict_data, len(dict_data), 1, dict_type)
+                if L.ZSTD_isError(r):
+                    raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            frame = bytes(frame)
+            dst = C.create_string_buffer(max(out_size, 1))
+            src = C.create_string_buffer(frame, len(frame))
+            out = _Buf(C.addressof(dst), out_size, 0)
+            inp = _Buf(C.addressof(src), len(frame), 0)
+            r = L.ZSTD_decompressStream(ctx, C.byref(out), C.byref(inp))
+            if L.ZSTD_isError(r):
+                raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            return dst.raw[: out.pos]
+        finally:
+            L.ZSTD_freeDCtx(ctx)
+
     def _cctx(self, level, flags, dict_data):
         key = (level, flags, id(dict_data))
         cache = getattr(self._tls, "cctx", None)

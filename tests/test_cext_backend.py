@@ -1,7 +1,7 @@
 """The CPython extension (python-zstandard_amd/cext/backend_hip.c) behaves like the reference's C extension for the hot path.
 CPU part: types, argument validation and error messages (mirrors of the reference's tests/test_buffer_util.py and the validation
-branches of its compressor / decompressor tests), object lifetimes. GPU part: its frames and outputs against the oracle and
-against the Python + ctypes mirror of the same surface."""
+branches of its compressor / decompressor tests), object lifetimes, ZstdCompressionParameters against libzstd's own numbers.
+GPU part: its frames and outputs against the oracle / the reference build."""
 import gc
 import struct
 
@@ -118,7 +118,8 @@ def test_cext_argument_validation(cext):
         d.decompress(b"")
     assert d.decompress(bytes.fromhex("28b52ffd2000010000")) == b""        # an empty frame needs no GPU
     with pytest.raises(cext.ZstdError, match="unable to set decoding format"):
-        cext.ZstdDecompressor(format=cext.FORMAT_ZSTD1_MAGICLESS)
+        cext.ZstdDecompressor(format=7)
+    cext.ZstdDecompressor(format=cext.FORMAT_ZSTD1_MAGICLESS)
     assert cext.ZstdCompressionDict(b"\x37\xa4\x30\xec" + struct.pack("<I", 1234) + b"x" * 100).dict_id() == 1234
     assert cext.ZstdCompressionDict(b"plain content").dict_id() == 0
     assert cext.ZstdCompressionDict(b"plain content").as_bytes() == b"plain content"
@@ -137,9 +138,8 @@ def test_cext_argument_validation(cext):
 
 
 @pytest.mark.gpu
-def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracle, corpus):
+def test_cext_compress_and_decompress_match_oracle(cext, oracle, corpus):
     import numpy as np
-    import zstandard_amd as pyz
     rng = np.random.default_rng(21)
     raws = [b"f", b"foo" * 4, b"a" * 1000, b"hello world, hello there world! " * 300, rng.bytes(5000), bytes(range(256)) * 20]
     raws += [corpus.frame_bytes(i)[: 4000 + 9000 * i] for i in range(8)] + [corpus.frame_bytes(33)]
@@ -149,8 +149,6 @@ def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracl
     frames = [res[i].tobytes() for i in range(len(raws))]
     for r, f in zip(raws, frames):
         assert f == oracle.compress(r, level=3)
-    mirror = pyz.ZstdCompressor(level=3).multi_compress_to_buffer(raws)
-    assert [mirror[i].tobytes() for i in range(len(raws))] == frames
     for r in raws[:4]:
         assert c.compress(r) == oracle.compress(r, level=3)
     # a BufferWithSegments / collection as input, sizes given and not given
@@ -184,41 +182,59 @@ def test_cext_compress_and_decompress_match_oracle_and_python_mirror(cext, oracl
     assert [od[i].tobytes() for i in range(len(small))] == small
 
 
-def test_compression_params_conflicts_both_implementations(cext):
-    """compressor.c:177-200: a compression_params object excludes the individual flags (ValueError first); the object itself is
-    refused loudly because explicit parameters are not plumbed to the kernels"""
-    import zstandard_amd as pyz
-    marker = object()
-    for mod in (pyz, cext):
-        for kw, name in (({"write_checksum": True}, "write_checksum"), ({"write_content_size": False}, "write_content_size"),
-                         ({"write_dict_id": True}, "write_dict_id"), ({"threads": 2}, "threads")):
-            with pytest.raises(ValueError, match="cannot define compression_params and %s" % name):
-                mod.ZstdCompressor(compression_params=marker, **kw)
-        with pytest.raises(mod.ZstdError, match="compression_params is not supported"):
-            mod.ZstdCompressor(compression_params=marker, write_checksum=None, write_content_size=None, write_dict_id=None, threads=0)
-        mod.ZstdCompressor(level=3, dict_data=None, compression_params=None, write_checksum=None, write_content_size=None,
-                           write_dict_id=None, threads=0)
+def test_compression_params_object_and_conflicts(cext, ref):
+    """compressor.c:177-200: a compression_params object excludes the individual flags (ValueError); the object carries what
+    ZSTD_getCParams derives (c-ext/compressionparams.c:231-345) -- checked against the reference build's own function"""
+    import ctypes as C
+    P = cext.ZstdCompressionParameters
+    params = P.from_level(3)
+    for kw, name in (({"write_checksum": True}, "write_checksum"), ({"write_content_size": False}, "write_content_size"),
+                     ({"write_dict_id": True}, "write_dict_id"), ({"threads": 2}, "threads")):
+        with pytest.raises(ValueError, match="cannot define compression_params and %s" % name):
+            cext.ZstdCompressor(compression_params=params, **kw)
+    with pytest.raises(TypeError, match="compression_params must be zstd.ZstdCompressionParameters"):
+        cext.ZstdCompressor(compression_params=object())
+    cext.ZstdCompressor(level=3, dict_data=None, compression_params=params, write_checksum=None, write_content_size=None,
+                        write_dict_id=None, threads=0)
+    cext.ZstdCompressor(level=3, dict_data=None, compression_params=None, write_checksum=None, write_content_size=None,
+                        write_dict_id=None, threads=0)
+
+    class CP(C.Structure):
+        _fields_ = [(n, C.c_uint) for n in "windowLog chainLog hashLog searchLog minMatch targetLength".split()] + [("strategy", C.c_int)]
+    ref.lib.ZSTD_getCParams.restype = CP
+    ref.lib.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
+    for level in (-5, 1, 3, 4, 7, 19, 22):
+        for src, dct in ((0, 0), (1000, 0), (16384, 0), (131072, 0), (131073, 0), (1 << 20, 0), (0, 112640), (4096, 112640)):
+            want = ref.lib.ZSTD_getCParams(level, src, dct)
+            got = P.from_level(level, source_size=src, dict_size=dct)
+            assert (got.window_log, got.chain_log, got.hash_log, got.search_log, got.min_match, got.target_length, got.strategy) == \
+                   (want.windowLog, want.chainLog, want.hashLog, want.searchLog, want.minMatch, want.targetLength, want.strategy), (level, src, dct)
+    p = P.from_level(3, window_log=12, write_checksum=1, threads=2, format=cext.FORMAT_ZSTD1_MAGICLESS)
+    assert (p.window_log, p.write_checksum, p.write_content_size, p.write_dict_id, p.threads, p.format, p.compression_level) == (12, 1, 1, 0, 2, 1, 0)
+    assert P().strategy == 0 and P(strategy=cext.STRATEGY_DFAST).strategy == 2 and p.estimated_compression_context_size() > 0
+    for bad in ({"window_log": 9}, {"window_log": 32}, {"hash_log": 31}, {"min_match": 8}, {"strategy": 10}, {"format": 2}):
+        with pytest.raises(cext.ZstdError, match="unable to set compression context parameter: Parameter is out of bound"):
+            P(**bad)
 
 
-def test_get_frame_parameters_both_implementations(cext, ref):
-    """values pinned by the reference's tests (test_compressor_compress.py:16-30, :90-116) and cross-checked between the two host
-    implementations on libzstd frames"""
-    import zstandard_amd as pyz
+def test_get_frame_parameters(cext, ref):
+    """values pinned by the reference's tests (test_compressor_compress.py:16-30, :90-116), cross-checked with libzstd on its frames"""
     frames = [bytes.fromhex("28b52ffd0000010000"), bytes.fromhex("28b52ffd2000010000"), ref.compress(b"foobar" * 256),
               ref.compress(b"foobar" * 256, flags=6), ref.compress(b"x" * 70000, flags=7), ref.compress(b"q" * 300000)]
-    for mod in (pyz, cext):
-        p = mod.get_frame_parameters(frames[0])
-        assert (p.content_size, p.window_size, p.dict_id, p.has_checksum) == (mod.CONTENTSIZE_UNKNOWN, 1024, 0, False)
-        assert mod.get_frame_parameters(frames[1]).content_size == 0
-        assert mod.get_frame_parameters(frames[2]).content_size == 1536
-        p = mod.get_frame_parameters(frames[3])
-        assert p.content_size == mod.CONTENTSIZE_UNKNOWN and p.has_checksum
-        with pytest.raises(mod.ZstdError, match="not enough data for frame parameters; need 5 bytes"):
-            mod.get_frame_parameters(b"")
-        with pytest.raises(mod.ZstdError, match="cannot get frame parameters: Unknown frame descriptor"):
-            mod.get_frame_parameters(b"foobarbaz")
-        assert mod.COMPRESSION_RECOMMENDED_INPUT_SIZE == 131072 and mod.WINDOWLOG_MIN == 10
+    mod = cext
+    p = mod.get_frame_parameters(frames[0])
+    assert (p.content_size, p.window_size, p.dict_id, p.has_checksum) == (mod.CONTENTSIZE_UNKNOWN, 1024, 0, False)
+    assert mod.get_frame_parameters(frames[1]).content_size == 0
+    assert mod.get_frame_parameters(frames[2]).content_size == 1536
+    p = mod.get_frame_parameters(frames[3])
+    assert p.content_size == mod.CONTENTSIZE_UNKNOWN and p.has_checksum
+    with pytest.raises(mod.ZstdError, match="not enough data for frame parameters; need 5 bytes"):
+        mod.get_frame_parameters(b"")
+    with pytest.raises(mod.ZstdError, match="cannot get frame parameters: Unknown frame descriptor"):
+        mod.get_frame_parameters(b"foobarbaz")
+    assert mod.COMPRESSION_RECOMMENDED_INPUT_SIZE == 131072 and mod.WINDOWLOG_MIN == 10
     for f in frames:
-        a, b = pyz.get_frame_parameters(f), cext.get_frame_parameters(f)
-        assert (a.content_size, a.window_size, a.dict_id, a.has_checksum) == (b.content_size, b.window_size, b.dict_id, b.has_checksum)
-        assert a.content_size == ref.frame_content_size(f)
+        b = cext.get_frame_parameters(f)
+        assert b.content_size == ref.frame_content_size(f)
+        m = cext.get_frame_parameters(f[4:], format=cext.FORMAT_ZSTD1_MAGICLESS)           # the same header without its magic number
+        assert (m.content_size, m.window_size, m.dict_id, m.has_checksum) == (b.content_size, b.window_size, b.dict_id, b.has_checksum)

@@ -241,3 +241,34 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     bigf = [oracle.compress(r, level=3, flags=7) for r in big]
     dec, st, nfb = emu.decompress_pipeline(bigf, [len(r) for r in big], n_blocks=3, chunk=0)
     assert not any(st) and dec == big
+
+
+def test_explicit_parameters_and_magicless_bit_exact(emu, ref, corpus):
+    """ZstdCompressionParameters' fields reach the kernels as per-size-class rows (zhip_cparams.hpp -> ze_get_cparams): frames equal
+    libzstd's with the same explicit parameters; what is not implemented (a window smaller than a one-block source, strategies above
+    double-fast) is refused per frame with "Unsupported parameter", never encoded differently. Magicless frames both ways."""
+    raws = [corpus.frame_bytes(i)[:n] for i, n in [(0, 131072), (1, 50000), (2, 16384), (3, 9000), (9, 300), (10, 20000)]]
+    cases = [dict(hash_log=10, chain_log=8), dict(min_match=7), dict(min_match=4, hash_log=17, chain_log=16), dict(strategy=1, target_length=5),
+             dict(strategy=2), dict(min_match=3), dict(window_log=12), dict(window_log=17, hash_log=16, chain_log=14, min_match=6, strategy=2)]
+    try:
+        for level, kw in [(3, c) for c in cases] + [(1, cases[0]), (-3, cases[4]), (19, cases[7])]:
+            want = [ref.compress_advanced(r, level=level, **kw) for r in raws]
+            emu.set_cparams(**kw)
+            outs, st = emu.compress_batch(raws, level=level, pipeline=True)
+            for i, (o, w) in enumerate(zip(outs, want)):
+                if "window_log" in kw and (1 << kw["window_log"]) < len(raws[i]):
+                    assert st[i] == 40, (level, kw, i)                                   # ZSTD_error_parameter_unsupported
+                else:
+                    assert st[i] == 0 and o == w, (level, kw, i)
+        emu.set_cparams(strategy=3)
+        assert set(emu.compress_batch(raws[:2], level=3, pipeline=True)[1]) == {40}
+        emu.set_cparams(magicless=True)
+        want = [ref.compress_advanced(r, level=3, format=1) for r in raws]
+        outs, st = emu.compress_batch(raws, level=3, pipeline=True)
+        assert st == [0] * len(raws) and outs == want and all(w[:4] != b"\x28\xb5\x2f\xfd" for w in want)
+        back, st, nfb = emu.decompress_pipeline(want, [len(r) for r in raws])
+        assert st == [0] * len(raws) and back == raws
+        back, st = emu.decompress_batch(want, [len(r) for r in raws])
+        assert st == [0] * len(raws) and back == raws
+    finally:
+        emu.set_cparams()

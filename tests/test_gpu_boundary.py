@@ -1,0 +1,137 @@
+"""GPU parity tests for the boundary fields round 1 left out of the C ABI: dictionary content type, frame format,
+explicit compression parameters -- each against the reference build (oracle/_ref) -- plus a BASELINE-shaped batch of >= 8192 frames
+per direction compared frame by frame, and hostile frame headers (the sizes a frame claims are untrusted input)."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zstd():
+    import zstandard_amd
+    assert zstandard_amd._lib.lib().zhip_device_count() >= 1, "no GPU visible"
+    return zstandard_amd
+
+
+def test_dictionary_content_type(zstd, ref, corpus):
+    """c-ext/compressiondict.c:170-191 -> compressor.c:37-52 / compressiondict.c:148-162: DICT_TYPE_RAWCONTENT treats a blob that starts
+    with the dictionary magic as plain content (different frames from AUTO!), DICT_TYPE_FULLDICT demands the magic"""
+    from tests.test_oracle_vs_golden import _dict_vectors
+    dicts, _ = _dict_vectors()
+    trained = dicts["trained"]                                            # starts with 37 a4 30 ec
+    assert trained[:4] == bytes.fromhex("37a430ec")
+    fake = bytes.fromhex("37a430ec") + b"not an entropy section at all " * 40     # magic but no valid tables
+    raws = [corpus.frame_bytes(40 + i)[300:300 + 1500 + 700 * i] for i in range(12)] + [b"tiny"]
+    for blob, dtype, label in ((trained, zstd.DICT_TYPE_RAWCONTENT, "trained as raw"), (trained, zstd.DICT_TYPE_FULLDICT, "trained as full"),
+                               (trained, zstd.DICT_TYPE_AUTO, "trained auto"), (fake, zstd.DICT_TYPE_RAWCONTENT, "magic-prefixed content as raw"),
+                               (b"short", zstd.DICT_TYPE_AUTO, "5-byte dictionary (not loaded at all)"),
+                               (corpus.frame_bytes(60)[:5000], zstd.DICT_TYPE_RAWCONTENT, "content as raw")):
+        zd = zstd.ZstdCompressionDict(blob, dict_type=dtype)
+        res = zstd.ZstdCompressor(level=3, dict_data=zd).multi_compress_to_buffer(raws)
+        for i, r in enumerate(raws):
+            assert res[i].tobytes() == ref.compress_advanced(r, level=3, dict_data=blob, dict_type=dtype), (label, i)
+        back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(res)
+        assert [back[i].tobytes() for i in range(len(raws))] == raws, label
+        assert ref.decompress_advanced(res[3].tobytes(), len(raws[3]), dict_data=blob, dict_type=dtype) == raws[3]
+    # raw and auto readings of the same blob are different frames (the bug round 1 had: dict_type never reached the kernels)
+    a = zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(trained)).compress(raws[2])
+    b = zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(trained, dict_type=zstd.DICT_TYPE_RAWCONTENT)).compress(raws[2])
+    assert a != b and zstd.get_frame_parameters(a).dict_id != 0 and zstd.get_frame_parameters(b).dict_id == 0
+    # a full dictionary is demanded but the blob is not one: libzstd's errors, both directions
+    for blob in (b"plain content without magic " * 10, b"abc"):
+        with pytest.raises(RuntimeError, match="Dictionary mismatch"):
+            ref.compress_advanced(raws[0], dict_data=blob, dict_type=2)
+        with pytest.raises(zstd.ZstdError, match="could not load compression dictionary: Dictionary mismatch"):
+            zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_FULLDICT)).compress(raws[0])
+        with pytest.raises(zstd.ZstdError, match="could not create decompression dict"):
+            zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_FULLDICT)).decompress(a)
+    with pytest.raises(zstd.ZstdError, match="Dictionary is corrupted"):                  # magic, then garbage, read as a full dictionary
+        zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(fake)).compress(raws[0])
+
+
+def test_compression_parameters_and_format(zstd, ref, corpus):
+    """ZstdCompressor(compression_params=ZstdCompressionParameters(...)) -- c-ext/compressor.c:203 -> set_parameters: explicit fields,
+    from_level() rows, the flags carried by the object, the magicless format in both directions"""
+    P = zstd.ZstdCompressionParameters
+    raws = [corpus.frame_bytes(300 + i)[: 2000 + 9000 * i] for i in range(14)] + [corpus.frame_bytes(320), b"foobar"]
+    cases = [dict(hash_log=12, chain_log=10), dict(min_match=6), dict(strategy=zstd.STRATEGY_FAST, target_length=3), dict(strategy=zstd.STRATEGY_DFAST, min_match=7),
+             dict(compression_level=1), dict(compression_level=-5), dict(window_log=17, hash_log=17, chain_log=16, search_log=1, min_match=5, target_length=0, strategy=2)]
+    for kw in cases:
+        params = P(write_checksum=1, write_dict_id=1, **kw)
+        res = zstd.ZstdCompressor(compression_params=params).multi_compress_to_buffer(raws)
+        rkw = {k: v for k, v in kw.items() if k != "compression_level"}
+        for i, r in enumerate(raws):
+            assert res[i].tobytes() == ref.compress_advanced(r, level=kw.get("compression_level", 3), flags=7, **rkw), (kw, i)
+    # from_level: the row of an unknown-size source made explicit -- not the same frames as level=3 (which picks the row per source size)
+    fl = zstd.ZstdCompressor(compression_params=P.from_level(3)).multi_compress_to_buffer(raws)
+    kw = dict(window_log=21, chain_log=16, hash_log=17, search_log=1, min_match=5, target_length=0, strategy=2)
+    for i, r in enumerate(raws):
+        assert fl[i].tobytes() == ref.compress_advanced(r, level=3, flags=1, **kw), i             # the object's write_dict_id defaults to 0
+    assert zstd.ZstdCompressor(compression_params=P.from_level(3)).compress(b"") == bytes.fromhex("28b52ffd2000010000")
+    # strategies the kernels do not implement: loud
+    with pytest.raises(zstd.ZstdError):
+        zstd.ZstdCompressor(compression_params=P.from_level(9)).compress(raws[3])
+    # magicless frames (reference tests test_no_magic / test_headerless)
+    m = zstd.ZstdCompressor(compression_params=P.from_level(1, format=zstd.FORMAT_ZSTD1_MAGICLESS))
+    z = zstd.ZstdCompressor(compression_params=P.from_level(1, format=zstd.FORMAT_ZSTD1))
+    assert z.compress(b"foobar")[:4] == b"\x28\xb5\x2f\xfd" and z.compress(b"foobar")[4:] == m.compress(b"foobar")
+    res = m.multi_compress_to_buffer(raws)
+    kw1 = dict(zip(("window_log", "chain_log", "hash_log", "search_log", "min_match", "target_length", "strategy"), (19, 13, 14, 1, 7, 0, 1)))
+    for i, r in enumerate(raws):
+        assert res[i].tobytes() == ref.compress_advanced(r, level=3, flags=1, format=1, **kw1), i
+    d = zstd.ZstdDecompressor(format=zstd.FORMAT_ZSTD1_MAGICLESS)
+    back = d.multi_decompress_to_buffer(res)
+    assert [back[i].tobytes() for i in range(len(raws))] == raws and d.decompress(res[5].tobytes()) == raws[5]
+    with pytest.raises(zstd.ZstdError, match="error determining content size from frame header"):
+        zstd.ZstdDecompressor().decompress(res[5].tobytes())
+    assert zstd.get_frame_parameters(res[14].tobytes(), format=zstd.FORMAT_ZSTD1_MAGICLESS).content_size == len(raws[14])
+
+
+def test_large_batch_both_directions_frame_by_frame(zstd, ref):
+    """>= 8192 frames per direction: BASELINE-shaped 128 KiB inputs plus ragged ones, every compressed frame
+    compared with the reference build's (sha256), every decoded frame with its source"""
+    import torch
+    from tests.corpus import Corpus
+    dev = torch.device("cuda", 0)
+    n_full, n_ragged = 6144, 2560
+    raw = Corpus(device=dev).frames(70000, n_full, chunk=256).cpu().numpy()
+    rng = np.random.default_rng(12)
+    items = [raw[i].tobytes() for i in range(n_full)]
+    items += [raw[int(rng.integers(0, n_full))][: int(rng.integers(1, 131073))].tobytes() for _ in range(n_ragged)]
+    want = [ref.compress(r) for r in items]
+    got = zstd.ZstdCompressor(level=3).multi_compress_to_buffer(items)
+    assert len(got) == len(items)
+    for i in range(len(items)):
+        f = got[i].tobytes()
+        assert len(f) == len(want[i]) and hashlib.sha256(f).digest() == hashlib.sha256(want[i]).digest(), "compressed frame %d differs from libzstd" % i
+    back = zstd.ZstdDecompressor().multi_decompress_to_buffer(want)
+    assert len(back) == len(items) and back.size() == sum(map(len, items))
+    for i in range(len(items)):
+        assert back[i].tobytes() == items[i], "decoded frame %d" % i
+
+
+def test_hostile_content_sizes(zstd):
+    """the decompressed size a frame header claims is untrusted: claims that cannot be allocated are MemoryError /
+    ZstdError, never a wrapped allocation that the kernels then write past"""
+    def frame(fcs, payload_blocks):
+        # single-segment off, 8-byte frame content size, then raw/RLE blocks
+        return bytes.fromhex("28b52ffd") + bytes([0xC0, 0x38]) + struct.pack("<Q", fcs) + payload_blocks
+    rle = lambda n, last: struct.pack("<I", (n << 3) | 2 | last)[:3] + b"z"
+    huge = frame((1 << 64) - 8, rle(100000, 0) * 8 + rle(100000, 1))
+    half = frame(1 << 63, rle(5, 1))
+    good = zstd.ZstdCompressor().compress(b"ok" * 500)
+    d = zstd.ZstdDecompressor(max_window_size=1 << 31)
+    for batch in ([huge], [half, half], [good, huge], [half, good, half]):
+        with pytest.raises((MemoryError, zstd.ZstdError)):
+            d.multi_decompress_to_buffer(batch)
+    with pytest.raises((MemoryError, zstd.ZstdError)):
+        d.decompress(huge)
+    # a large-but-allocatable lie is caught by the kernels' own bounds: the frame produces 800 005 bytes, claims 64 MiB
+    lie = frame(64 << 20, rle(100000, 0) * 8 + rle(5, 1))
+    with pytest.raises(zstd.ZstdError, match="error decompressing item 0"):
+        d.multi_decompress_to_buffer([lie])
+    assert d.multi_decompress_to_buffer([good])[0].tobytes() == b"ok" * 500             # the context is still healthy
