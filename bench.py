@@ -1,12 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): multi_decompress_to_buffer over 65 536 pre-compressed level-3 frames of
-128 KiB "Silesia-like" slices per GPU, inputs and outputs resident in HBM. A step = one pass over all frames.
-value = uncompressed GB/s (1e9) over all ranks; roofline = (compressed + uncompressed bytes) / kernel time vs HBM peak.
-cpu_baseline = the reference libzstd 1.5.7 (oracle/_ref) decoding a bounded sample of the same frames on host cores.
+Workloads (BASELINE.json configs):
+  --config decompress (default; configs[1]): multi_decompress_to_buffer over 65 536 pre-compressed level-3 frames of 128 KiB
+      "Silesia-like" slices per GPU, inputs and outputs resident in HBM. A step = one pass over all frames. value = uncompressed
+      GB/s (1e9) over all ranks of the DECOMPRESS direction; the other half of BASELINE.json's metric string (compress, configs[2])
+      is timed after the timed region on the same inputs and reported in the line's "compress" object.
+  --config compress (configs[2]): the same inputs through multi_compress_to_buffer as its own line, every frame compared with libzstd's.
+  --config dict (configs[3]): 262 144 x 4 KiB JSON-like documents with a shared trained dictionary (tests/golden/dict_json4k.bin,
+      made by train_dictionary's own call in tests/golden/make_dict_json4k.py): value = compress GB/s, every frame compared with
+      libzstd's; the line's "decompress" object is the opposite direction on those frames.
+roofline = (compressed + uncompressed bytes) / time vs the HBM peak, for the dominant kernel (HIP events on its launch stream) and
+end to end. cpu_baseline = the reference libzstd 1.5.7 (oracle/_ref) on host threads over a bounded sample of the same workload.
 
-  python bench.py [--gpus N --steps K --warmup W --frames F]
+  python bench.py [--gpus N --steps K --warmup W --frames F --config ...]
   (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 """
 import argparse
@@ -14,7 +21,6 @@ import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,6 +30,7 @@ import numpy as np
 import torch
 
 FRAME = 131072
+DOC = 4096
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -40,155 +47,228 @@ def _ref_lib():
     raise RuntimeError("no libzstd 1.5.7 available to prepare the bench input")
 
 
-def _threads():
-    return max(1, min(os.cpu_count() or 1, 64))
-
-
-def compress_on_host(ref, raw_np, nthreads):
-    """level-3 frames of every row of raw_np [F, FRAME] with the reference library, contiguous partition by bytes."""
-    F = raw_np.shape[0]
-    bound = ref.lib.ZSTD_compressBound(FRAME)
-    outs = [None] * F
-    base = raw_np.ctypes.data
-
-    def work(lo, hi):
-        buf = C.create_string_buffer(bound)
-        for i in range(lo, hi):
-            n = ref.compress_into(C.addressof(buf), bound, base + i * FRAME, FRAME)
-            outs[i] = buf.raw[:n]
-
-    step = (F + nthreads - 1) // nthreads
-    ts = [threading.Thread(target=work, args=(lo, min(F, lo + step))) for lo in range(0, F, step)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    return outs
-
-
 def _mtbench():
-    """oracle/libzo_mtbench.so: native pthread driver for the CPU baseline (Python threads would mostly measure the interpreter lock)"""
+    """oracle/libzo_mtbench.so: native pthread driver for input preparation and the CPU baseline (Python threads would mostly
+    measure the interpreter lock)"""
     path = os.path.join(ROOT, "oracle", "libzo_mtbench.so")
     if not os.path.exists(path):                                    # normally built by __graft_entry__.build(); gcc is in the image
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libzo_mtbench.so"], stdout=subprocess.DEVNULL)
     lib = C.CDLL(path)
-    lib.zo_mt_bench.restype = C.c_double
-    lib.zo_mt_bench.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    lib.zo_mt_bench_dict.restype = C.c_double
+    lib.zo_mt_bench_dict.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                     C.c_char_p, C.c_size_t, C.c_void_p]
+    lib.zo_mt_compress_all.restype = C.c_int
+    lib.zo_mt_compress_all.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]
     return lib
 
 
-def cpu_decompress_baseline(ref, frames, nthreads, passes=12):
-    """reference ZSTD_decompressStream on a bounded sample: native threads, one DCtx each, static contiguous partition
-    (decompress_worker's loop, c-ext/decompressor.c:1237-1320). Returns (GB/s of uncompressed bytes, passes)."""
-    from tests import reflib
-    F = len(frames)
-    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
-    offs = np.zeros(F + 1, dtype=np.uint64)
-    offs[1:] = np.cumsum([len(f) for f in frames])
-    best = _mtbench().zo_mt_bench(reflib.REF_SO.encode(), 1, blob.ctypes.data, offs.ctypes.data, F, FRAME, 3, nthreads, passes)
-    assert best > 0, "native CPU baseline failed (%r)" % best
-    return F * FRAME / best / 1e9, passes
-
-
-def cpu_compress_baseline(ref, raw_np, nthreads, passes=6):
-    """reference ZSTD_compressStream2(e_end) at level 3 on a bounded sample: native threads, one CCtx each (compress_worker's loop,
-    c-ext/compressor.c:1127-1216). Returns (GB/s of uncompressed bytes, passes)."""
+def compress_on_host(raw_np, item, dict_data=None, level=3):
+    """level-3 frames of every row of raw_np [F, item] with the reference library (native threads, contiguous partition).
+    Returns (list of frames, int64 sizes)."""
     from tests import reflib
     F = raw_np.shape[0]
     raw_np = np.ascontiguousarray(raw_np)
-    offs = (np.arange(F + 1, dtype=np.uint64) * np.uint64(FRAME))
-    best = _mtbench().zo_mt_bench(reflib.REF_SO.encode(), 0, raw_np.ctypes.data, offs.ctypes.data, F, 0, 3, nthreads, passes)
-    assert best > 0, "native CPU baseline failed (%r)" % best
-    return F * FRAME / best / 1e9, passes
+    offs = np.arange(F + 1, dtype=np.uint64) * np.uint64(item)
+    slot = item + (item >> 7) + 512
+    out = np.empty((F, slot), dtype=np.uint8)
+    sizes = np.zeros(F, dtype=np.uint64)
+    rc = _mtbench().zo_mt_compress_all(reflib.REF_SO.encode(), raw_np.ctypes.data, offs.ctypes.data, F, level, min(os.cpu_count() or 1, 64),
+                                       dict_data, len(dict_data) if dict_data else 0, out.ctypes.data, slot, sizes.ctypes.data)
+    assert rc == 0, "reference compression of the bench input failed (%d)" % rc
+    sizes = sizes.astype(np.int64)
+    return [out[i, : sizes[i]].tobytes() for i in range(F)], sizes
 
 
-def measure_compress(ctx, raw, frames, rank, world, dev, F, steps, warmup):
-    """multi_compress_to_buffer direction on the first F rows of raw: every frame must be bit-identical to libzstd's.
-    Returns (elapsed seconds over `steps` passes (max over ranks), compressed total, per-kernel times)."""
-    bound = FRAME + (FRAME >> 8)
-    bound = (bound + 15) & ~15
-    src_segs = torch.zeros((F, 2), dtype=torch.int64, device=dev)
-    src_segs[:, 0] = torch.arange(F, device=dev, dtype=torch.int64) * FRAME
-    src_segs[:, 1] = FRAME
-    dst_segs = torch.zeros((F, 2), dtype=torch.int64, device=dev)
-    dst_segs[:, 0] = torch.arange(F, device=dev, dtype=torch.int64) * bound
-    dst_segs[:, 1] = bound
-    dst = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
-    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
-    status = torch.zeros(F, dtype=torch.int32, device=dev)
-    src = raw[:F].reshape(-1)
+def cpu_baseline(decompress, blob, offs, n, max_out, unc_bytes, dict_data=None, passes=5):
+    """the reference libzstd on host threads over items [0, n) of blob (offs: n + 1 offsets): native threads, one context each, static
+    contiguous partition (compress_worker / decompress_worker, c-ext/compressor.c:1127-1216, c-ext/decompressor.c:1237-1320), at 64
+    threads and at every host core; per thread count the MEDIAN and best of `passes` passes. Returns the cpu_baseline object."""
+    from tests import reflib
+    lib = _mtbench()
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(64, ncpu), ncpu})
+    by = {}
+    for t in counts:
+        times = (C.c_double * passes)()
+        best = lib.zo_mt_bench_dict(reflib.REF_SO.encode(), 1 if decompress else 0, blob.ctypes.data, offs.ctypes.data, n, max_out, 3, t, passes,
+                                    dict_data, len(dict_data) if dict_data else 0, times)
+        assert best > 0, "native CPU baseline failed (%r)" % best
+        ts = sorted(times)
+        by[t] = {"median": round(unc_bytes / ts[len(ts) // 2] / 1e9, 3), "best": round(unc_bytes / ts[0] / 1e9, 3)}
+    top = max(by, key=lambda t: by[t]["median"])
+    return {"value": by[top]["median"], "unit": "GB/s", "cores": top, "by_threads": {str(t): v for t, v in by.items()}, "passes": passes,
+            "host_cores": ncpu}
 
-    def barrier():
-        if world > 1:
+
+class Job:
+    """one direction's device buffers + the timed loop (barrier + synchronize on both sides, max over ranks)"""
+
+    def __init__(self, world, dev):
+        self.world, self.dev = world, dev
+
+    def barrier(self):
+        if self.world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
-    barrier()
-    for k in (1, 5, 6, 8):
-        ctx.kernel_time(k)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ktimes = {k: ctx.kernel_time(k) for k in (1, 5, 6, 8)}
+    def timed(self, fn, ctx, kernels, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        for k in kernels:
+            ctx.kernel_time(k)                                       # reset the per-kernel timers
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        ktimes = {k: ctx.kernel_time(k) for k in kernels}
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, ktimes
+
+
+def segs(offsets, lengths, dev):
+    s = np.zeros((len(lengths), 2), dtype=np.int64)
+    s[:, 0] = offsets
+    s[:, 1] = lengths
+    return torch.from_numpy(s).to(dev)
+
+
+def roofline(ctx, ktimes, steps, algo_bytes_per_step, ms_per_step, frames_per_step=None):
+    """dominant kernel = the one with the largest total time over the timed steps (HIP events on the launch stream); achieved =
+    algorithmic bytes of one of its launches / its average duration. end_to_end = the same bytes per step / the step's wall time.
+    traffic = FETCH_SIZE + WRITE_SIZE per launch of that kernel, from the separate rocprofv3 --pmc passes of the same build
+    (tests/run_profiles.sh -> tests/prof_traffic.py -> profiles/traffic.json, per 128 KiB frame), scaled to the launch."""
+    kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
+    kernel_ms, launches = ktimes[kdom]
+    launches_per_step = max(1, int(launches) // max(1, steps))
+    algo_bytes = algo_bytes_per_step // launches_per_step
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, tsrc = None, None
+    if frames_per_step:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            per_frame = tj["bytes_per_frame"].get(ctx.kernel_name(kdom))
+            if per_frame:
+                traffic, tsrc = int(per_frame * frames_per_step / launches_per_step), tj.get("round")
+        except (OSError, ValueError, KeyError):
+            pass
+    e2e = algo_bytes_per_step / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "kernel_ms": round(kernel_ms, 4),
+            "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes),
+            "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(algo_bytes_per_step)}}, kdom
+
+
+def kernels_obj(ctx, ktimes):
+    return {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
+
+
+DEC_KERNELS = (0, 2, 7, 3, 4)
+ENC_KERNELS = (1, 5, 6, 8)
+
+
+def run_decompress(job, ctx, frames, csizes, raw, item, steps, warmup):
+    """the decode direction on `frames` (list of bytes) whose originals are raw [F, item] in HBM. Returns (elapsed, ktimes)."""
+    F = len(frames)
+    dev = job.dev
+    offs = np.zeros(F, dtype=np.int64)
+    offs[1:] = np.cumsum(csizes)[:-1]
+    src = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).to(dev)
+    src_segs = segs(offs, csizes, dev)
+    dst_segs = segs(np.arange(F, dtype=np.int64) * item, np.full(F, item, dtype=np.int64), dev)
+    dst = torch.zeros(F * item, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    status = torch.zeros(F, dtype=torch.int32, device=dev)
+    elapsed, ktimes = job.timed(lambda: ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status), ctx, DEC_KERNELS, steps, warmup)
+    # correctness gate at full size: every frame decoded, every byte equals the original input
+    assert int(status.abs().max().item()) == 0, "a frame failed to decode"
+    assert bool((out_sizes == item).all().item())
+    assert torch.equal(dst.view(F, item), raw), "round-trip mismatch"
+    return elapsed, ktimes, out_sizes
+
+
+def run_compress(job, ctx, raw, frames, item, steps, warmup):
+    """the encode direction on raw [F, item]: every frame must be byte-identical to libzstd's (`frames`). Returns (elapsed, total, ktimes)."""
+    F = raw.shape[0]
+    dev = job.dev
+    bound = (item + (item >> 8) + 64 + 15) & ~15
+    src_segs = segs(np.arange(F, dtype=np.int64) * item, np.full(F, item, dtype=np.int64), dev)
+    dst_segs = segs(np.arange(F, dtype=np.int64) * bound, np.full(F, bound, dtype=np.int64), dev)
+    dst = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    status = torch.zeros(F, dtype=torch.int32, device=dev)
+    src = raw.reshape(-1)
+    elapsed, ktimes = job.timed(lambda: ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status), ctx, ENC_KERNELS, steps, warmup)
     assert int(status.abs().max().item()) == 0, "a frame failed to compress"
     sizes = out_sizes.cpu().numpy()
     out = dst.view(F, bound).cpu().numpy()
     for i in range(F):                                              # bit-exactness gate over every frame
         assert out[i, : sizes[i]].tobytes() == frames[i], "frame %d differs from libzstd 1.5.7" % i
-    ctotal = int(sizes.sum())
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     del dst
-    return elapsed, ctotal, ktimes
+    return elapsed, int(sizes.sum()), ktimes
 
 
-def bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F):
-    """--direction compress: the whole line is about multi_compress_to_buffer on the same inputs."""
-    elapsed, ctotal, ktimes = measure_compress(ctx, raw, frames, rank, world, dev, F, args.steps, args.warmup)
-    kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
-    kernel_ms, launches = ktimes[kdom]
-    value = world * F * FRAME * args.steps / elapsed / 1e9
+def sample_blob(frames, n):
+    blob = np.frombuffer(b"".join(frames[:n]), dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(f) for f in frames[:n]])
+    return blob, offs
+
+
+def bench_dict(args, rank, world, dev):
+    """BASELINE.json configs[3]: multi_compress_to_buffer with a shared trained dictionary over 262 144 x 4 KiB JSON-like documents."""
+    from zstandard_amd.device import DeviceBatchContext
+    from tests.corpus import Corpus
+    F = args.docs
+    dict_data = open(os.path.join(ROOT, "tests", "golden", "dict_json4k.bin"), "rb").read()
+    raw = Corpus(frame_size=DOC, device=dev).json_docs(rank * F, F)
+    torch.cuda.synchronize()
+    ref, ref_kind = _ref_lib()
+    raw_np = raw.cpu().numpy()
+    frames, csizes = compress_on_host(raw_np, DOC, dict_data)
+    ctotal = int(csizes.sum())
+    job = Job(world, dev)
+    ctx = DeviceBatchContext(dict_data=dict_data, level=3)
+    elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, DOC, args.steps, args.warmup)
+    assert ctot2 == ctotal
+    ms = elapsed / args.steps * 1e3
     line = {
-        "metric": "GB/s uncompressed throughput, batch compress of 128 KiB inputs at level 3 (bit-exact vs libzstd 1.5.7)",
-        "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "multi_compress_to_buffer (device-resident): %d x 128 KiB Silesia-like inputs per GPU, level 3" % F,
-                   "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3, "compression_ratio": round(F * FRAME / ctotal, 3),
-                   "parallelism": "frames sharded by rank, no data-path collective"},
+        "metric": "GB/s uncompressed throughput, batch compress of 4 KiB inputs with a shared trained dictionary at level 3 (bit-exact vs libzstd 1.5.7)",
+        "value": round(world * F * DOC * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "multi_compress_to_buffer (device-resident) with a shared ZstdCompressionDict (16 KiB, trained on 10 000 JSON samples): "
+                               "%d x 4 KiB JSON-like documents per GPU, level 3" % F,
+                   "docs_per_gpu": F, "doc_bytes": DOC, "level": 3, "dict_bytes": len(dict_data), "compression_ratio": round(F * DOC / ctotal, 3),
+                   "parallelism": "documents sharded by rank, no data-path collective"},
     }
+    d_elapsed, d_k, _ = run_decompress(job, ctx, frames, csizes, raw, DOC, args.steps, args.warmup)
     if rank == 0:
-        launches_per_step = max(1, int(launches) // max(1, args.steps))
-        algo_bytes = (F * FRAME + ctotal) // launches_per_step
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        line["kernels"] = {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
-        traffic = None
-        try:                                                         # PMC passes are separate runs (profiles/README.md); scaled per launch
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            per_frame = tj["bytes_per_frame"].get(ctx.kernel_name(kdom))
-            if per_frame:
-                traffic = int(per_frame * F / launches_per_step)
-        except (OSError, ValueError, KeyError):
-            pass
-        line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                            "kernel_ms": round(kernel_ms, 3), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes)}
+        line["kernels"] = kernels_obj(ctx, ktimes)
+        line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * DOC + ctotal, ms)
+        d_ms = d_elapsed / args.steps * 1e3
+        line["decompress"] = {"value": round(world * F * DOC * args.steps / d_elapsed / 1e9, 3), "unit": "GB/s", "ms_per_step": round(d_ms, 3),
+                              "round_trip_exact": True, "kernels": kernels_obj(ctx, d_k)}
+        line["decompress"]["roofline"], _ = roofline(ctx, d_k, args.steps, F * DOC + ctotal, d_ms)
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(F, 4096)
-            v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads)
-            line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
-                                    "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 over the first %d inputs of the same "
-                                              "workload, %d native threads (host has %d cores), best of %d passes"
-                                              % (sample, nthreads, os.cpu_count() or 0, reps)}
+            n = min(F, 65536)
+            offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(DOC)
+            cb = cpu_baseline(False, np.ascontiguousarray(raw_np[:n]), offs, n, 0, n * DOC, dict_data)
+            cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 with the shared ZSTD_CDict over the first %d documents "
+                                                   "of the same workload; median of %d passes at the better of 64 / all host threads" % (n, cb["passes"])})
+            line["cpu_baseline"] = cb
+            blob, boffs = sample_blob(frames, n)
+            db = cpu_baseline(True, blob, boffs, n, DOC, n * DOC, dict_data)
+            db.update({"kind": ref_kind, "sample": "ZSTD_decompressStream with the shared ZSTD_DDict, first %d frames" % n})
+            line["decompress"]["cpu_baseline"] = db
         print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    ctx.close()
 
 
 def main():
@@ -197,12 +277,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU (BASELINE config: 65536)")
+    ap.add_argument("--docs", type=int, default=262144, help="--config dict: documents per GPU (BASELINE config: 262144)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compress-frames", type=int, default=65536,
                     help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
-    ap.add_argument("--direction", choices=["decompress", "compress"], default="decompress",
-                    help="decompress is the BASELINE.json headline; compress times multi_compress_to_buffer on the same inputs")
+    ap.add_argument("--config", choices=["decompress", "compress", "dict"], default=None,
+                    help="decompress (default) is the BASELINE.json headline; compress / dict are configs[2] / configs[3] as their own lines")
+    ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
     args = ap.parse_args()
+    config = args.config or args.direction or "decompress"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -215,8 +298,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        if config == "dict":
+            bench_dict(args, rank, world, dev)
+        else:
+            bench_frames(args, config, rank, world, dev)
+    finally:
+        if world > 1:
+            torch.distributed.destroy_process_group()
 
-    import zstandard_amd as zstd
+
+def bench_frames(args, config, rank, world, dev):
+    import zstandard_amd as zstd  # noqa: F401
     from zstandard_amd.device import DeviceBatchContext
     from tests.corpus import Corpus
 
@@ -227,125 +320,86 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     ref, ref_kind = _ref_lib()
-    nthreads = _threads()
     t0 = time.time()
     raw_np = raw.cpu().numpy()
-    frames = compress_on_host(ref, raw_np, nthreads)
+    frames, csizes = compress_on_host(raw_np, FRAME)
     t_comp = time.time() - t0
-    csizes = np.array([len(f) for f in frames], dtype=np.int64)
     ctotal = int(csizes.sum())
-    src_segs_np = np.zeros((F, 2), dtype=np.int64)
-    src_segs_np[:, 1] = csizes
-    src_segs_np[1:, 0] = np.cumsum(csizes)[:-1]
-    dst_segs_np = np.zeros((F, 2), dtype=np.int64)
-    dst_segs_np[:, 0] = np.arange(F, dtype=np.int64) * FRAME
-    dst_segs_np[:, 1] = FRAME
-    src = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).to(dev)
-    src_segs = torch.from_numpy(src_segs_np).to(dev)
-    dst_segs = torch.from_numpy(dst_segs_np).to(dev)
-    dst = torch.zeros(F * FRAME, dtype=torch.uint8, device=dev)
-    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
-    status = torch.zeros(F, dtype=torch.int32, device=dev)
-
+    job = Job(world, dev)
     ctx = DeviceBatchContext()
-    if args.direction == "compress":
-        return bench_compress(args, ctx, raw, frames, ref, ref_kind, nthreads, rank, world, dev, F)
+    cfg = {"frames_per_gpu": F, "frame_bytes": FRAME, "level": 3, "compression_ratio": round(F * FRAME / ctotal, 3),
+           "parallelism": "frames sharded by rank, no data-path collective"}
+    nsample = min(F, 16384)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    if config == "compress":
+        elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, FRAME, args.steps, args.warmup)
+        ms = elapsed / args.steps * 1e3
+        cfg["workload"] = "multi_compress_to_buffer (device-resident): %d x 128 KiB Silesia-like inputs per GPU, level 3" % F
+        line = {"metric": "GB/s uncompressed throughput, batch compress of 128 KiB inputs at level 3 (bit-exact vs libzstd 1.5.7)",
+                "value": round(world * F * FRAME * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic", "config": cfg}
+        if rank == 0:
+            line["kernels"] = kernels_obj(ctx, ktimes)
+            line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * FRAME + ctotal, ms, F)
+            if world == 1 and not args.no_cpu_baseline:
+                offs = np.arange(nsample + 1, dtype=np.uint64) * np.uint64(FRAME)
+                cb = cpu_baseline(False, np.ascontiguousarray(raw_np[:nsample]), offs, nsample, 0, nsample * FRAME)
+                cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 over the first %d inputs of the same workload; "
+                                                       "median of %d passes at the better of 64 / all host threads" % (nsample, cb["passes"])})
+                line["cpu_baseline"] = cb
+            print(json.dumps(line))
+        return
 
-    for _ in range(args.warmup):
-        ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
-    barrier()
-    for k in (0, 2, 7, 3, 4):
-        ctx.kernel_time(k)                                           # reset the per-kernel timers
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # dominant decode kernel = the one with the largest total time over the timed steps (HIP events on the launch stream)
-    ktimes = {k: ctx.kernel_time(k) for k in (0, 2, 7, 3, 4)}
-    kdom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
-    kernel_ms, launches = ktimes[kdom]
-
-    # correctness gate at full size: every frame decoded, every byte equals the original input
-    assert int(status.abs().max().item()) == 0, "a frame failed to decode"
-    assert bool((out_sizes == FRAME).all().item())
-    assert torch.equal(dst.view(F, FRAME), raw), "round-trip mismatch"
-
+    elapsed, ktimes, out_sizes = run_decompress(job, ctx, frames, csizes, raw, FRAME, args.steps, args.warmup)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # the only cross-rank exchange the path needs: the segment table of the sharded result (payload stays per GPU)
         gathered = [torch.zeros_like(out_sizes) for _ in range(world)]
         dist.all_gather(gathered, out_sizes)
-
-    total_unc = world * F * FRAME
-    value = total_unc * args.steps / elapsed / 1e9
+    ms = elapsed / args.steps * 1e3
+    cfg["workload"] = ("multi_decompress_to_buffer (device-resident): %d x 128 KiB Silesia-like frames per GPU, level 3, frames compressed by "
+                       "libzstd 1.5.7" % F)
     line = {
-        "metric": "GB/s uncompressed throughput, batch decompress of 128 KiB level-3 frames",
-        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "multi_decompress_to_buffer (device-resident): %d x 128 KiB Silesia-like frames per GPU, "
-                               "level 3, frames compressed by libzstd 1.5.7" % F,
-                   "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3,
-                   "compression_ratio": round(F * FRAME / ctotal, 3), "parallelism": "frames sharded by rank, no data-path collective"},
+        "metric": "GB/s uncompressed throughput, batch decompress of 128 KiB level-3 frames (the decompress half of BASELINE.json's metric; "
+                  "the compress half on the same inputs is this line's 'compress' object)",
+        "value": round(world * F * FRAME * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": cfg,
     }
     if rank == 0:
-        # algorithmic bytes of one launch: compressed bytes read + uncompressed bytes written for the frames that launch covers
-        launches_per_step = max(1, int(launches) // max(1, args.steps))
-        algo_bytes = (F * FRAME + ctotal) // launches_per_step
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        line["kernels"] = {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
-        traffic = None
-        try:                                                         # PMC passes are separate runs (profiles/README.md); scaled per launch
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            per_frame = tj["bytes_per_frame"].get(ctx.kernel_name(kdom))
-            if per_frame:
-                traffic = int(per_frame * F / launches_per_step)
-        except (OSError, ValueError, KeyError):
-            pass
-        line["roofline"] = {"bound": "hbm", "kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 2),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                            "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "launches": int(launches),
-                            "algorithmic_bytes_per_launch": int(algo_bytes)}
+        line["kernels"] = kernels_obj(ctx, ktimes)
+        line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * FRAME + ctotal, ms, F)
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(F, 4096)
-            v, reps = cpu_decompress_baseline(ref, frames[:sample], nthreads)
-            line["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
-                                    "sample": "libzstd 1.5.7 ZSTD_decompressStream over the first %d frames of the same "
-                                              "workload, %d native threads (host has %d cores), best of %d passes"
-                                              % (sample, nthreads, os.cpu_count() or 0, reps)}
+            blob, boffs = sample_blob(frames, nsample)
+            cb = cpu_baseline(True, blob, boffs, nsample, FRAME, nsample * FRAME)
+            cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 ZSTD_decompressStream over the first %d frames of the same workload; median of %d "
+                                                   "passes at the better of 64 / all host threads" % (nsample, cb["passes"])})
+            line["cpu_baseline"] = cb
         line["setup_s"] = {"generate": round(t_gen, 1), "host_compress": round(t_comp, 1)}
     if args.compress_frames > 0:
-        # the other half of BASELINE.json's metric, on a bounded slice of the same inputs (the timed decompress region above is over)
+        # the other half of BASELINE.json's metric, on the same inputs (the timed decompress region above is over). The compressor is
+        # its own object in the reference API: release the decode direction's working set and start from a fresh context
         Fc = min(F, args.compress_frames)
-        # the compressor is its own object in the reference API: release the decode direction's working set (its context's arenas,
-        # the frames and their output) and start from a fresh context, as a ZstdCompressor next to a ZstdDecompressor would
-        del dst, src, src_segs, dst_segs, out_sizes, status
         ctx.close()
         torch.cuda.empty_cache()
         ctx = DeviceBatchContext()
-        c_elapsed, c_total, c_k = measure_compress(ctx, raw, frames, rank, world, dev, Fc, 3, 2)
+        c_elapsed, c_total, c_k = run_compress(job, ctx, raw[:Fc], frames[:Fc], FRAME, 3, 2)
         if rank == 0:
+            c_ms = c_elapsed / 3 * 1e3
             line["compress"] = {"value": round(world * Fc * FRAME * 3 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 3,
-                                "ms_per_step": round(c_elapsed / 3 * 1e3, 3), "bit_exact_vs_libzstd": True,
-                                "kernels": {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in c_k.items() if v[1]}}
+                                "ms_per_step": round(c_ms, 3), "bit_exact_vs_libzstd": True, "kernels": kernels_obj(ctx, c_k)}
+            line["compress"]["roofline"], _ = roofline(ctx, c_k, 3, Fc * FRAME + c_total, c_ms, Fc)
             if world == 1 and not args.no_cpu_baseline:
-                sample = min(Fc, 4096)
-                v, reps = cpu_compress_baseline(ref, raw[:sample].cpu().numpy(), nthreads)
-                line["compress"]["cpu_baseline"] = {"value": round(v, 3), "unit": "GB/s", "cores": nthreads, "kind": ref_kind,
-                                                    "sample": "libzstd 1.5.7 level 3, first %d inputs, %d threads, best of %d" % (sample, nthreads, reps)}
+                ns = min(Fc, nsample)
+                offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(FRAME)
+                cb = cpu_baseline(False, np.ascontiguousarray(raw_np[:ns]), offs, ns, 0, ns * FRAME)
+                cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 level 3, first %d inputs; median of %d passes at the better of 64 / all host threads"
+                                                       % (ns, cb["passes"])})
+                line["compress"]["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

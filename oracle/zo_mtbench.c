@@ -22,11 +22,16 @@ typedef struct {
     size_t (*compressStream2)(void*, zbuf*, zbuf*, int); size_t (*compressBound)(size_t);
     void* (*createDCtx)(void); size_t (*freeDCtx)(void*);
     size_t (*decompressStream)(void*, zbuf*, zbuf*); unsigned (*isError)(size_t);
+    /* shared dictionaries, as the reference's workers use them: one ZSTD_CDict / ZSTD_DDict referenced by every worker context
+     * (c-ext/compressor.c:1155-1163 ZSTD_CCtx_refCDict, c-ext/decompressor.c:1262-1270 ZSTD_DCtx_refDDict) */
+    void* (*createCDict)(const void*, size_t, int); size_t (*freeCDict)(void*); size_t (*refCDict)(void*, const void*);
+    void* (*createDDict)(const void*, size_t); size_t (*freeDDict)(void*); size_t (*refDDict)(void*, const void*);
 } zapi;
 
 typedef struct {
     const zapi* z; int decompress, level; const uint8_t* src; const uint64_t* offs; uint32_t lo, hi; size_t maxOut;
     pthread_barrier_t* start; int failed;
+    const void* cdict; const void* ddict;
     struct timespec t0, t1;          /* this worker's first and last instant of work */
 } job;
 
@@ -37,6 +42,8 @@ static void* worker(void* arg)
     uint8_t* out = (uint8_t*)malloc(j->maxOut ? j->maxOut : 1);
     void* ctx = j->decompress ? z->createDCtx() : z->createCCtx();
     if (!j->decompress) { z->setParam(ctx, 100, j->level); z->setParam(ctx, 200, 1); z->setParam(ctx, 201, 0); z->setParam(ctx, 202, 1); }
+    if (j->cdict && !j->decompress) z->refCDict(ctx, j->cdict);
+    if (j->ddict && j->decompress) z->refDDict(ctx, j->ddict);
     pthread_barrier_wait(j->start);
     clock_gettime(CLOCK_MONOTONIC, &j->t0);
     for (uint32_t i = j->lo; i < j->hi; i++) {
@@ -56,8 +63,19 @@ static void* worker(void* arg)
 /* Times `passes` passes over frames [0, n) (offs has n + 1 entries into src) with `threads` threads; returns the best pass in
  * seconds, or a negative value on failure. maxOut = capacity of each thread's output buffer (uncompressed frame size for
  * decompress, ZSTD_compressBound for compress when 0 is passed). */
+double zo_mt_bench_dict(const char* libpath, int decompress, const uint8_t* src, const uint64_t* offs, uint32_t n, size_t maxOut,
+                        int level, int threads, int passes, const void* dict, size_t dictSize, double* times);
+
 double zo_mt_bench(const char* libpath, int decompress, const uint8_t* src, const uint64_t* offs, uint32_t n, size_t maxOut,
                    int level, int threads, int passes)
+{
+    return zo_mt_bench_dict(libpath, decompress, src, offs, n, maxOut, level, threads, passes, 0, 0, 0);
+}
+
+/* the same with an optional shared dictionary; times[passes] (if not NULL) receives every pass's duration so that the caller can
+ * quote a median next to the best */
+double zo_mt_bench_dict(const char* libpath, int decompress, const uint8_t* src, const uint64_t* offs, uint32_t n, size_t maxOut,
+                        int level, int threads, int passes, const void* dict, size_t dictSize, double* times)
 {
     void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
     if (!h) return -1.0;
@@ -67,7 +85,15 @@ double zo_mt_bench(const char* libpath, int decompress, const uint8_t* src, cons
     *(void**)&z.compressStream2 = dlsym(h, "ZSTD_compressStream2"); *(void**)&z.compressBound = dlsym(h, "ZSTD_compressBound");
     *(void**)&z.createDCtx = dlsym(h, "ZSTD_createDCtx"); *(void**)&z.freeDCtx = dlsym(h, "ZSTD_freeDCtx");
     *(void**)&z.decompressStream = dlsym(h, "ZSTD_decompressStream"); *(void**)&z.isError = dlsym(h, "ZSTD_isError");
+    *(void**)&z.createCDict = dlsym(h, "ZSTD_createCDict"); *(void**)&z.freeCDict = dlsym(h, "ZSTD_freeCDict"); *(void**)&z.refCDict = dlsym(h, "ZSTD_CCtx_refCDict");
+    *(void**)&z.createDDict = dlsym(h, "ZSTD_createDDict"); *(void**)&z.freeDDict = dlsym(h, "ZSTD_freeDDict"); *(void**)&z.refDDict = dlsym(h, "ZSTD_DCtx_refDDict");
     if (!z.createCCtx || !z.compressStream2 || !z.createDCtx || !z.decompressStream || !z.compressBound) return -2.0;
+    void* cdict = 0; void* ddict = 0;
+    if (dict && dictSize) {
+        if (!z.createCDict || !z.refCDict || !z.createDDict || !z.refDDict) return -2.0;
+        if (decompress) ddict = z.createDDict(dict, dictSize); else cdict = z.createCDict(dict, dictSize, level);
+        if (!cdict && !ddict) return -5.0;
+    }
     if (threads < 1) threads = 1;
     if ((uint32_t)threads > n) threads = (int)n;
     if (!decompress && maxOut == 0) {
@@ -84,7 +110,7 @@ double zo_mt_bench(const char* libpath, int decompress, const uint8_t* src, cons
         const uint32_t per = (n + (uint32_t)threads - 1) / (uint32_t)threads;
         for (int t = 0; t < threads; t++) {
             job* j = &jobs[t];
-            j->z = &z; j->decompress = decompress; j->level = level; j->src = src; j->offs = offs; j->maxOut = maxOut; j->start = &bar; j->failed = 0;
+            j->z = &z; j->decompress = decompress; j->level = level; j->src = src; j->offs = offs; j->maxOut = maxOut; j->start = &bar; j->failed = 0; j->cdict = cdict; j->ddict = ddict;
             j->lo = (uint32_t)t * per; j->hi = j->lo + per > n ? n : j->lo + per; if (j->lo > n) j->lo = j->hi = n;
             pthread_create(&th[t], 0, worker, j);
         }
@@ -101,9 +127,65 @@ double zo_mt_bench(const char* libpath, int decompress, const uint8_t* src, cons
             if (t == 0 || s1 > last) last = s1;
         }
         const double dt = last - first;
+        if (times) times[p] = dt;
         if (best < 0 || dt < best) best = dt;
     }
     free(th); free(jobs);
+    if (cdict) z.freeCDict(cdict);
+    if (ddict) z.freeDDict(ddict);
     dlclose(h);
     return best;
+}
+
+/* ---- input preparation for bench.py: every item [offs[i], offs[i+1]) of src compressed by `threads` native threads into slot i of
+ * out (slotCap bytes each), sizes to outSizes. Same per-item calls as the timed worker above. Returns 0, or a negative value. */
+typedef struct { const zapi* z; int level; const uint8_t* src; const uint64_t* offs; uint32_t lo, hi; uint8_t* out; size_t slotCap; uint64_t* outSizes;
+                 const void* cdict; int failed; } prepjob;
+static void* prep_worker(void* arg)
+{
+    prepjob* j = (prepjob*)arg;
+    const zapi* z = j->z;
+    void* ctx = z->createCCtx();
+    z->setParam(ctx, 100, j->level); z->setParam(ctx, 200, 1); z->setParam(ctx, 201, 0); z->setParam(ctx, 202, 1);
+    if (j->cdict) z->refCDict(ctx, j->cdict);
+    for (uint32_t i = j->lo; i < j->hi; i++) {
+        zbuf o = { j->out + (size_t)i * j->slotCap, j->slotCap, 0 };
+        zbuf in = { (void*)(j->src + j->offs[i]), (size_t)(j->offs[i + 1] - j->offs[i]), 0 };
+        z->setPledged(ctx, in.size);
+        if (z->compressStream2(ctx, &o, &in, 2) != 0) j->failed = 1;
+        j->outSizes[i] = o.pos;
+    }
+    z->freeCCtx(ctx);
+    return 0;
+}
+int zo_mt_compress_all(const char* libpath, const uint8_t* src, const uint64_t* offs, uint32_t n, int level, int threads,
+                       const void* dict, size_t dictSize, uint8_t* out, size_t slotCap, uint64_t* outSizes)
+{
+    void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    zapi z; memset(&z, 0, sizeof z);
+    *(void**)&z.createCCtx = dlsym(h, "ZSTD_createCCtx"); *(void**)&z.freeCCtx = dlsym(h, "ZSTD_freeCCtx");
+    *(void**)&z.setParam = dlsym(h, "ZSTD_CCtx_setParameter"); *(void**)&z.setPledged = dlsym(h, "ZSTD_CCtx_setPledgedSrcSize");
+    *(void**)&z.compressStream2 = dlsym(h, "ZSTD_compressStream2");
+    *(void**)&z.createCDict = dlsym(h, "ZSTD_createCDict"); *(void**)&z.freeCDict = dlsym(h, "ZSTD_freeCDict"); *(void**)&z.refCDict = dlsym(h, "ZSTD_CCtx_refCDict");
+    if (!z.createCCtx || !z.compressStream2 || !z.setParam || !z.setPledged) return -2;
+    void* cdict = 0;
+    if (dict && dictSize) { if (!z.createCDict || !z.refCDict) return -2; cdict = z.createCDict(dict, dictSize, level); if (!cdict) return -5; }
+    if (threads < 1) threads = 1;
+    if ((uint32_t)threads > n) threads = (int)(n ? n : 1);
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    prepjob* jobs = (prepjob*)malloc(sizeof(prepjob) * (size_t)threads);
+    const uint32_t per = (n + (uint32_t)threads - 1) / (uint32_t)threads;
+    for (int t = 0; t < threads; t++) {
+        prepjob* j = &jobs[t];
+        j->z = &z; j->level = level; j->src = src; j->offs = offs; j->out = out; j->slotCap = slotCap; j->outSizes = outSizes; j->cdict = cdict; j->failed = 0;
+        j->lo = (uint32_t)t * per; j->hi = j->lo + per > n ? n : j->lo + per; if (j->lo > n) j->lo = j->hi = n;
+        pthread_create(&th[t], 0, prep_worker, j);
+    }
+    int failed = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], 0); failed |= jobs[t].failed; }
+    free(th); free(jobs);
+    if (cdict) z.freeCDict(cdict);
+    dlclose(h);
+    return failed ? -4 : 0;
 }

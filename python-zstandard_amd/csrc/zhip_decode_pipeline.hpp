@@ -238,7 +238,7 @@ struct alignas(16) ZpVec16 { uint32_t a, b, c, d; };
 // Reads may touch the 16-byte blocks around the stream (never another page: blocks are aligned) and never go below the block that
 // holds the first byte of the arena side of the stream (offsets are clamped at 0 relative to the aligned base).
 #define ZP_NOBLK 0x7FFFFFF0
-template <uint32_t RW, uint32_t M>
+template <uint32_t RW, uint32_t M, uint32_t LS>
 struct ZpBits {
     uint32_t hi, lo, nx, used;      // `used` bits of hi are consumed (1..32 at every group start); lo, nx = the next two dwords
     int32_t cur;                    // offset of lo's dword from p0
@@ -246,20 +246,20 @@ struct ZpBits {
     int32_t s0;                     // offset of the stream's first byte
     int32_t bo[M]; ZpVec16 blk[M];  // blocks in flight and where they go (ZP_NOBLK: none)
     const uint8_t* p0;              // 16-byte aligned base
-    uint32_t* col;                  // this lane's column of the ring: word w of the lane is col[64 * w]
+    uint32_t* col;                  // this lane's column of the ring: word w of the lane is col[w << LS]
 };
-template <uint32_t RW, uint32_t M> ZH_DEV uint32_t zb_index(int32_t off) { return ((uint32_t)off << 4) & ((RW - 1) << 6); }
-template <uint32_t RW, uint32_t M> ZH_DEV ZpVec16 zb_fetch(const ZpBits<RW, M>& B, int32_t off)
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV uint32_t zb_index(int32_t off) { return ((uint32_t)off << (LS - 2)) & ((RW - 1) << LS); }   // off % 4 == 0, LS >= 2
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV ZpVec16 zb_fetch(const ZpBits<RW, M, LS>& B, int32_t off)
 {
     return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off));
 }
-template <uint32_t RW, uint32_t M> ZH_DEV void zb_commit(ZpBits<RW, M>& B, int32_t off, const ZpVec16& v)
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV void zb_commit(ZpBits<RW, M, LS>& B, int32_t off, const ZpVec16& v)
 {
-    uint32_t* q = B.col + zb_index<RW, M>(off);          // off is a multiple of 16: four consecutive words, no wrap inside
-    q[0] = v.a; q[64] = v.b; q[128] = v.c; q[192] = v.d;
+    uint32_t* q = B.col + zb_index<RW, M, LS>(off);      // off is a multiple of 16: four consecutive words, no wrap inside
+    q[0] = v.a; q[1u << LS] = v.b; q[2u << LS] = v.c; q[3u << LS] = v.d;
 }
 // false: empty stream or missing end mark (the caller reports corruption)
-template <uint32_t RW, uint32_t M> ZH_DEV bool zb_init(ZpBits<RW, M>& B, const uint8_t* p, uint32_t size, uint32_t* col)
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV bool zb_init(ZpBits<RW, M, LS>& B, const uint8_t* p, uint32_t size, uint32_t* col)
 {
     B.col = col;
     const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
@@ -279,13 +279,13 @@ template <uint32_t RW, uint32_t M> ZH_DEV bool zb_init(ZpBits<RW, M>& B, const u
 #pragma unroll
     for (uint32_t k = 0; k < RW / 4; k++) zb_commit(B, tb - 16 * (int32_t)k, f[k]);
     B.pb = tb - (int32_t)(RW * 4);
-    B.hi = B.col[zb_index<RW, M>(d0)]; B.lo = B.col[zb_index<RW, M>(d0 - 4)]; B.nx = B.col[zb_index<RW, M>(d0 - 8)];
+    B.hi = B.col[zb_index<RW, M, LS>(d0)]; B.lo = B.col[zb_index<RW, M, LS>(d0 - 4)]; B.nx = B.col[zb_index<RW, M, LS>(d0 - 8)];
     B.cur = d0 - 4;
     B.used = 8 * (uint32_t)(d0 + 4 - end) + 8 - (uint32_t)zh_highbit32(last);      // bytes above the stream + padding + end mark
     return true;
 }
 // write what the previous burst requested, request what fits now
-template <uint32_t RW, uint32_t M> ZH_DEV void zb_burst(ZpBits<RW, M>& B)
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV void zb_burst(ZpBits<RW, M, LS>& B)
 {
 #pragma unroll
     for (uint32_t k = 0; k < M; k++) if (B.bo[k] != ZP_NOBLK) { zb_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
@@ -294,22 +294,22 @@ template <uint32_t RW, uint32_t M> ZH_DEV void zb_burst(ZpBits<RW, M>& B)
         if (B.pb + (int32_t)(RW * 4) >= B.cur) { B.bo[k] = B.pb; B.blk[k] = zb_fetch(B, B.pb); B.pb -= 16; }
     }
 }
-template <uint32_t RW, uint32_t M> ZH_DEV uint32_t zb_top(const ZpBits<RW, M>& B) { return zh_alignbit(B.hi, B.lo, 32u - B.used); }   // the next 32 stream bits
-template <uint32_t RW, uint32_t M> ZH_DEV void zb_refill(ZpBits<RW, M>& B)                                                         // after `used += n`, n <= 32
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV uint32_t zb_top(const ZpBits<RW, M, LS>& B) { return zh_alignbit(B.hi, B.lo, 32u - B.used); }   // the next 32 stream bits
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV void zb_refill(ZpBits<RW, M, LS>& B)                                                         // after `used += n`, n <= 32
 {
     const bool ge = B.used > 32;
     B.hi = ge ? B.lo : B.hi; B.lo = ge ? B.nx : B.lo; B.cur = ge ? B.cur - 4 : B.cur; B.used = ge ? B.used - 32 : B.used;
-    B.nx = B.col[zb_index<RW, M>(B.cur - 4)];
+    B.nx = B.col[zb_index<RW, M, LS>(B.cur - 4)];
 }
 // every bit consumed, no more: the unconsumed part of hi is exactly what lies below the stream's first byte
-template <uint32_t RW, uint32_t M> ZH_DEV bool zb_finished(const ZpBits<RW, M>& B) { return (int32_t)B.used == 8 * (B.cur + 8 - B.s0); }
+template <uint32_t RW, uint32_t M, uint32_t LS> ZH_DEV bool zb_finished(const ZpBits<RW, M, LS>& B) { return (int32_t)B.used == 8 * (B.cur + 8 - B.s0); }
 
 #define ZP_HUF_RING 16          // K1b: dwords of ring per lane (64 bytes), 2 blocks per burst, a burst every 8 symbols
-typedef ZpBits<ZP_HUF_RING, 2> ZpHufBits;
+typedef ZpBits<ZP_HUF_RING, 2, ZP_HUF_LS> ZpHufBits;
 // A decoding cell is 12 bits of information (symbol, code length <= 11): kept as a byte array of symbols and a nibble array of lengths,
 // a frame's table is 3 KiB instead of 4, a wave's 16 tables 48 KiB (+ 4 KiB of rings), and THREE waves fit a CU's LDS instead of two --
 // the kernel is a latency-bound lookup chain, so residency is throughput.
-struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; uint32_t ring[ZP_HUF_RING * 64]; };
+struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; uint32_t ring[ZP_HUF_RING << ZP_HUF_LS]; };
 
 ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count,
                           uint32_t* ringCol)
@@ -349,7 +349,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
         const uint32_t g = zh_first(zh_atomic_add(a.counters + 5, lane == 0 ? 1u : 0u));
         if (g >= nGroups) break;
         const uint32_t k = g * ZP_HUF_FRAMES + slot;
-        const bool active = k < total;
+        const bool active = slot < ZP_HUF_FRAMES && k < total;
         const uint32_t i = active ? a.orderLit[k] : 0xFFFFFFFFu;
         uint32_t mode = 0, litSize = 0, streamOff = 0, streamBytes = 0;
         if (active) { const ZdMeta* m = a.meta + i; mode = m->litMode; litSize = m->litSize; streamOff = m->litOff; streamBytes = m->produced; }
@@ -414,8 +414,8 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
 //   * per-symbol {baseline, extra-bit count} come from one 4-byte LDS word; repcodes are resolved with selects
 // Frames of a wave come from the KB order (similar sequence counts), so lanes finish together.
 #define ZP_SEQ_RING 32          // K2: dwords of ring per lane (128 bytes), 4 blocks per burst, a burst every 4 sequences
-typedef ZpBits<ZP_SEQ_RING, 4> ZpSeqBits;
-struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t ring[ZP_SEQ_RING * 64]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
+typedef ZpBits<ZP_SEQ_RING, 4, ZP_K2_LS> ZpSeqBits;
+struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t ring[ZP_SEQ_RING << ZP_K2_LS]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
 
 ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8_t* T, const uint32_t* llInfo, const uint32_t* mlInfo,
                                uint32_t logs, uint32_t nbSeq, uint64_t* out, uint32_t* ringCol)

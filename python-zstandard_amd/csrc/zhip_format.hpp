@@ -185,11 +185,16 @@ struct ZdMeta {
 #ifndef ZP_K2_LANES
 #define ZP_K2_LANES 60
 #endif
-//      ^                                  // frames decoded per K2 wave (one lane each); one wave per CU
+//      ^                                  // frames decoded per K2 wave (one lane each). 60: one wave fills a CU's LDS; smaller values give
+//                                         // several one-wave workgroups per CU (LDS per workgroup shrinks with it): 30 -> 2, 15 -> 4, 7 -> 8
+#define ZP_K2_LS (ZP_K2_LANES > 32 ? 6 : ZP_K2_LANES > 16 ? 5 : ZP_K2_LANES > 8 ? 4 : 3)   // log2 of the bit-reader ring's lane stride (dwords)
 #define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
 #define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
 #define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)
-#define ZP_HUF_FRAMES 16                                // frames per K1b wave: 4 lanes (the 4 streams) each
+#ifndef ZP_HUF_FRAMES
+#define ZP_HUF_FRAMES 16                                // frames per K1b wave: 4 lanes (the 4 streams) each; 3 KiB of tables per frame, so 16 -> 3 waves
+#endif                                                  // per CU, 8 -> 6, 4 -> 12 (always 48 frames per CU: more waves hide the lookup latency)
+#define ZP_HUF_LS (ZP_HUF_FRAMES > 8 ? 6 : ZP_HUF_FRAMES > 4 ? 5 : 4)     // log2 of the K1b ring's lane stride (dwords): 4 lanes per frame
 #define ZP_LITBIN_SHIFT 9                               // K1b work order: frames binned by litSize >> 9
 #define ZP_BIN_SHIFT 7                                  // K2 work order: frames binned by nbSeq >> 7 (256 bins), longest first
 

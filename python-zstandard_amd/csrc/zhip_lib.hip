@@ -16,6 +16,9 @@
 #include "zhip_encode_kernel.hpp"
 #include "zhip_cparams.hpp"
 
+#define ZHIP_LDS_BYTES (160u * 1024u)      // per CU on gfx950
+static_assert(sizeof(ZpSeqLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
+
 // ------------------------------------------------------------------------------------------ kernels
 ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
 {
@@ -512,9 +515,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
             if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g3m = (size_t)c->numCU * (size_t)v; }   // tuning knobs
             if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g1m = (size_t)c->numCU * (size_t)v; }
-            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES;          // K2 takes a whole CU's LDS: one wave per CU
-            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < (size_t)c->numCU ? w2 : (size_t)c->numCU), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
-            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * 3;      // K1b: 48 KiB of LDS per wave
+            // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 60 lanes -> 1, 15 -> 4, 7 -> 8)
+            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqLDS));
+            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
+            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
             hipEvent_t ev[4], evh, evh2;
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));

@@ -140,10 +140,12 @@ class Corpus:
         tok = torch.where(grp % 3 == 0, (phrase * phrase) >> 13, tok)
         return self._tokens_to_bytes(torch.zeros_like(tok), tok, [self.text_vocab])
 
-    def _gen_record(self, fi):
+    def _gen_record(self, fi, json_only=False):
         B = fi.numel(); W = self.n // 3 + 16
         w = torch.arange(W, dtype=torch.int64, device=self.dev)
         style = (_h(self.seed + 4, fi) & 1)[:, None]           # json-ish or xml-ish
+        if json_only:
+            style = torch.zeros_like(style)
         slot = w[None, :] % 18
         is_key = (slot & 1) == 0
         json_key = (slot >> 1) % 9
@@ -153,7 +155,8 @@ class Corpus:
         val = ((u % 4096) * (u % 4096)) >> 12                  # skewed values
         val = torch.where((u >> 13) % 4 != 0, (val * val) >> 14, val)
         rec = w[None, :] // 18
-        val = torch.where(slot == 1, rec % 4096, val)          # incrementing ids
+        id0 = (_h(self.seed + 24, fi) % 4096)[:, None] if json_only else 0
+        val = torch.where(slot == 1, (rec + id0) % 4096, val)   # incrementing ids
         tok = torch.where(is_key, key, val)
         tid = torch.where(is_key, torch.zeros_like(tok), torch.ones_like(tok))
         return self._tokens_to_bytes(tid, tok, [self.key_vocab, self.val_vocab])
@@ -215,6 +218,16 @@ class Corpus:
                 if bool(m.any()):
                     sel = torch.nonzero(m).flatten()
                     out[c0 + sel] = g(fi[sel])
+        return out
+
+    def json_docs(self, start, count, chunk=8192):
+        """uint8 tensor [count, frame_size]: JSON-like documents start .. start+count-1 (BASELINE.json configs[3]: many small inputs
+        that share their structure -- the dictionary use case). Use with a Corpus(frame_size=4096)."""
+        out = torch.empty((count, self.n), dtype=torch.uint8, device=self.dev)
+        for c0 in range(0, count, chunk):
+            c1 = min(count, c0 + chunk)
+            fi = torch.arange(start + c0, start + c1, dtype=torch.int64, device=self.dev) + (1 << 24)
+            out[c0:c1] = self._gen_record(fi, json_only=True)
         return out
 
     def frame_bytes(self, i):

@@ -243,6 +243,20 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     assert not any(st) and dec == big
 
 
+@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=8"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"]])
+def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
+    """K2 / K1b with fewer frames per wave (several one-wave workgroups per CU share its LDS; the bit reader's ring stride follows):
+    the shapes csrc/build_variants.sh builds for A/B runs decode the same bytes"""
+    import numpy as np
+    from tests import emulib
+    emu = emulib.Emu(emulib.build_variant(str(tmp_path / "libzhip_emu_shape.so"), defines))
+    rng = np.random.default_rng(5)
+    raws = [corpus.frame_bytes(i)[: 3000 + 9000 * i] for i in range(12)] + [rng.bytes(40000), b"ab" * 30000, bytes(rng.integers(0, 6, 70000, dtype=np.uint8))]
+    frames = [oracle.compress(r, level=3, flags=7) for r in raws]
+    dec, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws], n_blocks=3, chunk=0)
+    assert not any(st) and dec == raws
+
+
 def test_explicit_parameters_and_magicless_bit_exact(emu, ref, corpus):
     """ZstdCompressionParameters' fields reach the kernels as per-size-class rows (zhip_cparams.hpp -> ze_get_cparams): frames equal
     libzstd's with the same explicit parameters; what is not implemented (a window smaller than a one-block source, strategies above

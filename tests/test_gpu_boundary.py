@@ -135,3 +135,36 @@ def test_hostile_content_sizes(zstd):
     with pytest.raises(zstd.ZstdError, match="error decompressing item 0"):
         d.multi_decompress_to_buffer([lie])
     assert d.multi_decompress_to_buffer([good])[0].tobytes() == b"ok" * 500             # the context is still healthy
+
+
+def test_dictionary_batch_config4_shape(zstd):
+    """BASELINE.json configs[3] at a sixteenth of its size: 16 384 x 4 KiB JSON-like documents with the trained dictionary of
+    tests/golden/dict_json4k.bin -- every compressed frame equals the reference build's (native ZSTD_CCtx_refCDict workers, the
+    reference's own call), every frame decodes back with the dictionary; plus the pinned probe vectors of the fixture"""
+    import json
+    import os
+    import bench
+    from tests import reflib
+    from tests.corpus import Corpus
+    if not reflib.have_ref():
+        pytest.skip("needs the reference build")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = open(os.path.join(root, "tests", "golden", "dict_json4k.bin"), "rb").read()
+    meta = json.load(open(os.path.join(root, "tests", "golden", "dict_json4k.json")))
+    assert hashlib.sha256(blob).hexdigest() == meta["dict_sha256"]
+    n = 16384
+    docs = Corpus(frame_size=4096).json_docs(0, n).numpy()
+    assert [hashlib.sha256(docs[i].tobytes()).hexdigest() for i in range(8)] == meta["probe_docs_sha256"]
+    want, sizes = bench.compress_on_host(docs, 4096, blob)
+    zd = zstd.ZstdCompressionDict(blob)
+    items = [docs[i].tobytes() for i in range(n)]
+    got = zstd.ZstdCompressor(level=3, dict_data=zd).multi_compress_to_buffer(items)
+    assert len(got) == n
+    for i in range(n):
+        f = got[i].tobytes()
+        assert len(f) == len(want[i]) and f == want[i], "document %d: frame differs from libzstd's" % i
+    assert [hashlib.sha256(got[i].tobytes()).hexdigest() for i in range(8)] == meta["probe_frames_sha256"]
+    back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
+    assert len(back) == n and back.size() == n * 4096
+    for i in range(n):
+        assert back[i].tobytes() == items[i], "document %d does not round-trip" % i
