@@ -1588,7 +1588,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (mb) { nrep[0] = mb->st->mrep[0]; nrep[1] = mb->st->mrep[1]; }
         const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
                                                 : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
-                          : cd ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
+                          : (cd && cd->contentSize) ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
                                                a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
                                : cp.strat == 1 ? ze_fast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong)
                                : ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
@@ -1973,7 +1973,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
         int st = ze_cdict_params(p, rows, dictSize);
         if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
         cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
-        cd->contentSize = cs; cd->dictID = hasEntropy ? de->dictID : 0u;
+        cd->contentSize = dictSize < 8 ? 0u : cs; cd->dictID = hasEntropy ? de->dictID : 0u;
         cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
         cd->hufRepeat = cd->llRepeat = cd->ofRepeat = cd->mlRepeat = 0; cd->hufMaxSym = 0;
         if (!st && hasEntropy) {
@@ -2109,7 +2109,9 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
         uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
         uint32_t litSize = 0;
-        m.nbSeq = a.cdict ? ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+        // a dictionary without content (shorter than 8 bytes: nothing of it is loaded, zstd.c:28167) is not attached
+        // (ZSTD_resetCCtx_byAttachingCDict, "don't even attach dictionaries with no contents"): the plain search, with the dictionary's row
+        m.nbSeq = (a.cdict && a.cdict->contentSize) ? ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
                                           a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
                           : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong)
                           : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);

@@ -400,12 +400,13 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         any |= rows.r[t][6] == 1 || rows.r[t][6] == 2;
     }
     if (!any) { g_lastError = "HIP backend compresses with the fast and double-fast strategies only (levels <= 3, negative levels; level 4 for inputs above 16 KiB; or explicit strategy / parameters that select them)"; return ZHIP_ERR_UNSUPPORTED; }
-    // a dictionary shorter than 8 bytes is not loaded at all (ZSTD_compress_insertDictionary, zstd.c:28167) -- unless a full dictionary
-    // was demanded, which is then "Dictionary mismatch"; so is a blob without the magic
+    // nothing of a dictionary shorter than 8 bytes is loaded (ZSTD_compress_insertDictionary, zstd.c:28167) -- unless a full dictionary
+    // was demanded, which is then "Dictionary mismatch"; so is a blob without the magic. The ZSTD_CDict still exists and its
+    // parameter row (chosen for a 513-byte source) is what the frames are compressed with, so such a blob is digested like any other
     const bool hasDict = p->dict && p->dictSize;
     const bool hasMagic = hasDict && p->dictSize >= 8 && rd32((const uint8_t*)p->dict) == ZF_DICT_MAGIC;
     if (hasDict && p->dictType == ZHIP_DICT_FULLDICT && !hasMagic) return -ZE_DICT_WRONG;
-    const bool useDict = hasDict && p->dictSize >= 8;
+    const bool useDict = hasDict;
     if (useDict) {
         uint64_t salt = 0x200u + (uint64_t)p->dictType;
         for (int t = 0; t < 4; t++) for (int k = 0; k < 7; k++) salt = salt * 1000003u + (uint64_t)(uint32_t)rows.r[t][k];

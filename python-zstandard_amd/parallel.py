@@ -4,8 +4,9 @@ Frames are independent, so the only "parallelism strategy" is the reference's ow
 item list with (almost) equal input bytes per worker -- c-ext/compressor.c:1127-1216 / c-ext/decompressor.c:1237-1326 --
 here with one worker per rank instead of one per pthread. No collective touches the payload: results stay resident in
 each rank's HBM (the returned collection holds one BufferWithSegments per rank, which the API allows, SURVEY.md 8(b));
-the only exchange is an all-gather of the per-frame output sizes so every rank knows the global segment table
-("all-gatherv" of tiny metadata; payload gathers over xGMI are link-bound and deliberately not done).
+the exchange every call needs is an all-gather of the per-frame output sizes so every rank knows the global segment table.
+The callable form of all this -- including the optional payload all-gatherv over RCCL -- is sharded.py; this module holds the
+partition rule and the metadata exchange it is built from.
 """
 import torch
 import torch.distributed as dist
@@ -31,27 +32,27 @@ def partition_by_bytes(sizes, workers):
     return bounds
 
 
-def my_shard(sizes, rank=None, world=None):
-    rank = dist.get_rank() if rank is None else rank
-    world = dist.get_world_size() if world is None else world
+def my_shard(sizes, rank=None, world=None, group=None):
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
     bounds = partition_by_bytes(sizes, world)
     return bounds[rank] if rank < len(bounds) else (len(sizes), len(sizes))
 
 
-def gather_segment_table(local_sizes, counts=None):
+def gather_segment_table(local_sizes, counts=None, group=None):
     """all-gather of per-frame output sizes (int64 tensor on this rank's device) -> list of per-rank size tensors.
     Ranks may hold different numbers of frames: counts are exchanged first, then padded sizes."""
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     dev = local_sizes.device
     n = torch.tensor([local_sizes.numel()], dtype=torch.int64, device=dev)
     all_n = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(all_n, n)
+    dist.all_gather(all_n, n, group=group)
     counts = [int(t.item()) for t in all_n]
     m = max(counts) if counts else 0
     padded = torch.zeros(m, dtype=torch.int64, device=dev)
     padded[: local_sizes.numel()] = local_sizes
     gathered = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded)
+    dist.all_gather(gathered, padded, group=group)
     return [g[:c] for g, c in zip(gathered, counts)]
 
 

@@ -44,3 +44,88 @@ def test_sharding_and_segment_gather_world2():
     assert tab0 == tab1 and n0 == n1 == 101                           # both ranks hold the same global table
     assert tab0[0] == [s // 3 + 1 for s in sizes[lo0:hi0]] and tab0[1] == [s // 3 + 1 for s in sizes[lo1:hi1]]
     assert head0[0] == (0, 0, sizes[0] // 3 + 1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the callable sharded path (sharded.py) end to end on CPU: partition -> local batch -> size exchange -> payload all-gatherv ->
+# reassembly. The GPU context is replaced by a stand-in that runs the CHECKERS on CPU tensors (test infrastructure: the product's
+# default ctx_factory is DeviceBatchContext and needs a GPU).
+class _CpuCtx:
+    device = torch.device("cpu")
+
+    def __init__(self, dict_data=None, level=3, **kw):
+        from tests import reflib
+        self.z = reflib.RefZstd() if reflib.have_ref() else reflib.Oracle()
+        self.level = level
+
+    def compress(self, src, src_segs, dst, dst_segs, out_sizes, status):
+        for i in range(src_segs.shape[0]):
+            o, n = (int(v) for v in src_segs[i])
+            f = self.z.compress(bytes(src[o:o + n].numpy()), level=self.level)
+            d = int(dst_segs[i, 0])
+            assert len(f) <= int(dst_segs[i, 1])
+            dst[d:d + len(f)] = torch.frombuffer(bytearray(f), dtype=torch.uint8)
+            out_sizes[i] = len(f)
+
+    def decompress(self, src, src_segs, dst, dst_segs, out_sizes, status):
+        for i in range(src_segs.shape[0]):
+            o, n = (int(v) for v in src_segs[i])
+            cap = int(dst_segs[i, 1])
+            try:
+                r = self.z.decompress(bytes(src[o:o + n].numpy()), cap)
+            except Exception:
+                status[i] = 20                                           # corruption_detected
+                continue
+            d = int(dst_segs[i, 0])
+            if r:
+                dst[d:d + len(r)] = torch.frombuffer(bytearray(r), dtype=torch.uint8)
+            out_sizes[i] = len(r)
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zstandard_amd
+    import zstandard_amd.sharded as sh
+    from tests.corpus import Corpus
+    c = Corpus()
+    items = [c.frame_bytes(i)[: 500 + 3100 * i] for i in range(11)] + [b"", b"x" * 40000, b"tail"]
+    res = sh.multi_compress_to_buffer(items, level=3, gather=True, ctx_factory=_CpuCtx)
+    full = res.to_buffer(zstandard_amd)                                  # one BufferWithSegments holding EVERY frame, on every rank
+    frames = [full[i].tobytes() for i in range(len(full))]
+    local = res.to_buffer(zstandard_amd, gathered=False)
+    back = sh.multi_decompress_to_buffer(frames, [len(x) for x in items], gather=True, ctx_factory=_CpuCtx)
+    outs = [bytes(back.full_arena[o:o + n].numpy()) for o, n in back.global_segments()]
+    err = None
+    try:
+        sh.multi_decompress_to_buffer(frames[:5] + [frames[5][:-3] + b"zzz"] + frames[6:], [len(x) for x in items], ctx_factory=_CpuCtx)
+    except zstandard_amd.ZstdError as e:
+        err = str(e)
+    q.put((rank, res.bounds, [len(f) for f in frames], outs == items, len(local), res.sizes.tolist(), err,
+           [res.local_item(i) == frames[i] for i in range(res.lo, res.hi)]))
+    dist.destroy_process_group()
+
+
+def test_sharded_calls_world2_full_control_flow(oracle):
+    from tests import reflib
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=150) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, b0, l0, ok0, n0, s0, e0, loc0), (r1, b1, l1, ok1, n1, s1, e1, loc1) = res
+    assert b0 == b1 and b0[0][0] == 0 and b0[0][1] == b0[1][0] and b0[1][1] == 14        # same contiguous cover on both ranks
+    assert l0 == l1 == s0 == s1                                                           # every rank holds every frame + the global table
+    assert ok0 and ok1                                                                    # round trip through both sharded calls
+    assert n0 == b0[0][1] - b0[0][0] and n1 == b0[1][1] - b0[1][0]                        # the un-gathered buffer holds the rank's items
+    assert all(loc0) and all(loc1)
+    assert e0 == e1 and e0 is not None and "item 5" in e0                                 # both ranks raise the SAME first failing item
+    # and the frames are libzstd's
+    from tests.corpus import Corpus
+    enc = reflib.RefZstd() if reflib.have_ref() else oracle
+    assert l0[3] == len(enc.compress(Corpus().frame_bytes(3)[: 500 + 3100 * 3], level=3))

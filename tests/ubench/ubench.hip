@@ -188,7 +188,7 @@ int main()
     uint64_t* d_out; CHECK(hipMalloc(&d_out, 1 << 20));
     uint32_t seed = 12345;
     void* a1[] = {&d_out, &seed};
-    const int ws[] = {1, 2, 3, 4, 8};
+    const int ws[] = {1, 2, 3, 4};      // 256 * W threads per workgroup: 1024 is the limit
     for (int w : ws) run("valu_dep", (const void*)valu_dep, w, nb, 0, d_out, a1, (double)REP * ITER);
     for (int w : ws) run("valu_ind", (const void*)valu_ind, w, nb, 0, d_out, a1, (double)REP * ITER);
     for (int w : ws) run("mix_vs", (const void*)mix_vs, w, nb, 0, d_out, a1, (double)REP * ITER);
