@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ZHIP_ABI_VERSION 2
+#define ZHIP_ABI_VERSION 3
 
 typedef struct { uint64_t offset, length; } zhip_segment;             /* BufferSegment */
 typedef struct { const void* src; size_t srcSize; size_t dstSize; } zhip_item; /* dstSize: decompress only (0 = unknown) */
@@ -108,13 +108,17 @@ int64_t  zhip_find_frame_compressed_size_format(const void* src, size_t srcSize,
 void     zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out);
 
 /* ---- host-buffer batch API (drop-in for the reference's workers) ----
- * items are borrowed; *out is an array of *nOut malloc()ed buffers the caller owns (free each data/segs, then the
- * array with zhip_free_outbufs or free()). Returns ZHIP_ERR_NONE or fills *err. Re-entrant; call with the GIL released. */
+ * items are borrowed; *out is an array of *nOut buffers the caller owns -- one per pipeline chunk, like the reference's one per worker
+ * (CompressorDestBuffer / DecompressorDestBuffer): release each `data` with zhip_free_payload() (large payloads are PINNED host
+ * memory from a process-wide pool, so that the D2H copy lands in them at link speed; free() is correct only for the `segs` arrays),
+ * each `segs` with free(), then the array with free() -- or everything with zhip_free_outbufs(bufs, n, 1).
+ * Returns ZHIP_ERR_NONE or fills *err. Re-entrant; call with the GIL released. */
 int  zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, size_t n,
                          zhip_outbuf** out, size_t* nOut, zhip_error* err);
 int  zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
                            zhip_outbuf** out, size_t* nOut, zhip_error* err);
 void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload);
+void zhip_free_payload(void* data);     /* a zhip_outbuf.data pointer: back to the pinned pool, or free() */
 
 /* ---- device-resident batch API (all pointers are HBM addresses on the current device) ----
  * A context owns the per-launch scratch (literal buffers, hash tables, work counters, status words) so repeated

@@ -88,6 +88,7 @@ def lib():
         "zhip_decompress_batch": (C.c_int, [C.POINTER(DParams), C.POINTER(Item), sz, C.c_int,
                                             C.POINTER(C.POINTER(OutBuf)), C.POINTER(sz), C.POINTER(Error)]),
         "zhip_free_outbufs": (None, [C.POINTER(OutBuf), sz, C.c_int]),
+        "zhip_free_payload": (None, [C.c_void_p]),
         "zhip_ctx_create": (vp, []),
         "zhip_ctx_destroy": (None, [vp]),
         "zhip_ctx_set_ddict": (C.c_int, [vp, vp, sz, C.c_int]),
@@ -102,7 +103,7 @@ def lib():
     for name, (res, args) in protos.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
-    if L.zhip_abi_version() != 2:
+    if L.zhip_abi_version() != 3:
         raise ImportError("libzstd_hip.so ABI mismatch")
     _lib = L
     return L
@@ -112,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "zhip_abi_version", "zhip_device_count", "zhip_set_device", "zhip_last_error", "zhip_error_name",
     "zhip_selftest", "zhip_compress_bound", "zhip_frame_content_size", "zhip_find_frame_compressed_size", "zhip_frame_content_size_format",
     "zhip_find_frame_compressed_size_format", "zhip_get_cparams", "zhip_ctx_set_dformat", "zhip_compress_batch",
-    "zhip_decompress_batch", "zhip_free_outbufs", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
+    "zhip_decompress_batch", "zhip_free_outbufs", "zhip_free_payload", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
     "zhip_kernel_name", "zhip_ctx_kernel_time",
 ]

@@ -32,6 +32,7 @@ static struct {
     int (*compress_batch)(const zhip_cparams*, const zhip_item*, size_t, zhip_outbuf**, size_t*, zhip_error*);
     int (*decompress_batch)(const zhip_dparams*, const zhip_item*, size_t, int, zhip_outbuf**, size_t*, zhip_error*);
     void (*free_outbufs)(zhip_outbuf*, size_t, int);
+    void (*free_payload)(void*);
     int (*abi_version)(void);
     uint64_t (*frame_content_size_format)(const void*, size_t, int);
     int64_t (*find_frame_compressed_size_format)(const void*, size_t, int);
@@ -75,6 +76,7 @@ static int bind_library(PyObject* module)
     BIND(last_error, "zhip_last_error"); BIND(error_name, "zhip_error_name"); BIND(frame_content_size, "zhip_frame_content_size");
     BIND(find_frame_compressed_size, "zhip_find_frame_compressed_size"); BIND(compress_batch, "zhip_compress_batch");
     BIND(decompress_batch, "zhip_decompress_batch"); BIND(free_outbufs, "zhip_free_outbufs"); BIND(abi_version, "zhip_abi_version");
+    BIND(free_payload, "zhip_free_payload");
     BIND(frame_content_size_format, "zhip_frame_content_size_format"); BIND(find_frame_compressed_size_format, "zhip_find_frame_compressed_size_format");
     BIND(get_cparams, "zhip_get_cparams");
 #undef BIND
@@ -89,7 +91,7 @@ typedef struct {
     Py_buffer segParent;
     void* data; unsigned long long dataSize;
     zhip_segment* segments; Py_ssize_t segmentCount;
-    int useFree;                /* data / segments were malloc()ed by the C ABI: free() them (bufferutil.c:13-37) */
+    int useFree;                /* data / segments came from the C ABI: release them (bufferutil.c:13-37; data through zhip_free_payload) */
 } BufferWithSegments;
 
 typedef struct { PyObject_HEAD PyObject* parent; void* data; Py_ssize_t dataSize; unsigned long long offset; } BufferSegment;
@@ -101,7 +103,7 @@ static PyTypeObject BufferWithSegmentsType = { PyVarObject_HEAD_INIT(NULL, 0) },
 
 static void bws_dealloc(BufferWithSegments* self)
 {
-    if (self->useFree) { free(self->data); free(self->segments); }
+    if (self->useFree) { Z.free_payload(self->data); free(self->segments); }     /* payloads may be pinned pool blocks (zstd_hip.h) */
     if (self->parent.obj) PyBuffer_Release(&self->parent);
     if (self->segParent.obj) PyBuffer_Release(&self->segParent);
     Py_TYPE(self)->tp_free((PyObject*)self);
@@ -357,7 +359,7 @@ static PyObject* collection_from_outbufs(zhip_outbuf* out, size_t nOut)
     for (size_t i = 0; i < nOut; i++) {
         BufferWithSegments* b = bws_from_memory(out[i].data, out[i].dataSize, out[i].segs, (Py_ssize_t)out[i].nSegs);
         if (!b) {       /* buffers 0..i-1 belong to the tuple already; free the rest, then the array */
-            for (size_t k = i; k < nOut; k++) { free(out[k].data); free(out[k].segs); }
+            for (size_t k = i; k < nOut; k++) { Z.free_payload(out[k].data); free(out[k].segs); }
             Z.free_outbufs(out, nOut, 0); Py_DECREF(args); return NULL;
         }
         PyTuple_SET_ITEM(args, (Py_ssize_t)i, (PyObject*)b);

@@ -1,24 +1,30 @@
 #!/bin/sh
 # builds kernel variants next to the product library, for A/B measurement on the GPU with ZHIP_LIB=<path> (tests/run_r02*.sh):
-#   libzstd_hip_k2l{30,15,7}.so   -DZP_K2_LANES=n     K2: n frames per wave -> 2 / 4 / 8 one-wave workgroups per CU instead of 1
-#   libzstd_hip_huf{8,4}.so       -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 6 / 12 workgroups per CU instead of 3
-#   libzstd_hip_longall.so        -DZP_K3_LONGALL     K3: every ready long match of a dependency round handled in that round
+#   libzstd_hip_k2l{30,15,7}.so   -DZP_K2_LANES=n     K2: n frames per wave -> 2 / 4 / 8 one-wave workgroups per CU instead of 1   (r02c: all slower)
+#   libzstd_hip_huf{16,4}.so      -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
+#   libzstd_hip_longone.so        -DZP_K3_LONGONE     K3: one ready long match per dependency round (round 1's form)
 #   libzstd_hip_tab3.so           -DZE_TAB3           entropy kernel: the three sequence tables built by three lanes at once
-#   libzstd_hip_c1.so / _c2.so    combinations
 # All are emulator-verified (tests/test_emu_kernels.py: test_decode_shape_variants_stay_correct, test_experimental_kernel_variants_stay_correct).
+# usage: build_variants.sh [name ...]   (no names: all)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 B="$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
-$B -DZP_K2_LANES=30 -o libzstd_hip_k2l30.so zhip_lib.hip &
-$B -DZP_K2_LANES=15 -o libzstd_hip_k2l15.so zhip_lib.hip &
-$B -DZP_K2_LANES=7 -o libzstd_hip_k2l7.so zhip_lib.hip &
-$B -DZP_HUF_FRAMES=8 -o libzstd_hip_huf8.so zhip_lib.hip &
+want() { [ $# -eq 0 ] && return 0; }
+build() { name=$1; shift; $B "$@" -o libzstd_hip_$name.so zhip_lib.hip; }
+ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3"
+[ $# -gt 0 ] && ALL="$*"
+for v in $ALL; do
+  case $v in
+    k2l30) build k2l30 -DZP_K2_LANES=30 & ;;
+    k2l15) build k2l15 -DZP_K2_LANES=15 & ;;
+    k2l7) build k2l7 -DZP_K2_LANES=7 & ;;
+    huf16) build huf16 -DZP_HUF_FRAMES=16 & ;;
+    huf4) build huf4 -DZP_HUF_FRAMES=4 & ;;
+    longone) build longone -DZP_K3_LONGONE & ;;
+    tab3) build tab3 -DZE_TAB3 & ;;
+    *) echo "unknown variant $v"; exit 1 ;;
+  esac
+done
 wait
-$B -DZP_HUF_FRAMES=4 -o libzstd_hip_huf4.so zhip_lib.hip &
-$B -DZP_K3_LONGALL -o libzstd_hip_longall.so zhip_lib.hip &
-$B -DZP_K2_LANES=15 -DZP_HUF_FRAMES=8 -o libzstd_hip_c1.so zhip_lib.hip &
-$B -DZP_K2_LANES=7 -DZP_HUF_FRAMES=4 -o libzstd_hip_c2.so zhip_lib.hip &
-wait
-$B -DZE_TAB3 -o libzstd_hip_tab3.so zhip_lib.hip
 ls -la libzstd_hip_*.so

@@ -439,13 +439,20 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
     B.used += mlLog;
     zb_refill(B);
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8, bad = 0;
+    // Software-pipelined by hand: a lone wave issues one instruction every ~4 cycles (~8 when it depends on the previous one) and waits
+    // out every LDS round trip (tests/ubench), so the order of the body matters more than its length. The cells of sequence n + 1 are
+    // requested as soon as the new states exist; the work that is NOT on the state chain -- values, repeat offsets, packing, the store
+    // of sequence n -- is placed behind that request and runs while the lookups are in flight.
+    uint32_t cL = TL[sL], cM = TM[sM], cO = TO[sO];
     for (uint32_t n = 0;;) {
         if ((n & 3) == 0) zb_burst(B);
-        const uint32_t cL = TL[sL], cM = TM[sM], cO = TO[sO];
         const uint32_t symO = cO >> 10, symL = cL >> 10, symM = cM >> 10;
         // baseline | extra-bit count << 24 of the length codes (RFC 8878 3.1.1.3.2.1.1) from a 89-word LDS table shared by the wave:
-        // one more LDS round on the chain, a tenth of the instructions of computing them (the loop is bound by issue slots)
+        // one more LDS round on the chain, a tenth of the instructions of computing them
         const uint32_t iL = llInfo[symL], iM = mlInfo[symM];
+        // (independent of the info words: the state chain's own arithmetic fills the wait)
+        const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
+        const uint32_t nbL = (uint32_t)__builtin_clz(xL) - kL, nbM = (uint32_t)__builtin_clz(xM) - kM, nbO = (uint32_t)__builtin_clz(xO) - kO;
         const uint32_t bitsL = iL >> 24, baseL = iL & 0xFFFFFFu, bitsM = iM >> 24, baseM = iM & 0xFFFFFFu;
         top = zb_top(B);
         const uint32_t xo = zh_bfe(top, 32 - symO, symO);
@@ -455,6 +462,17 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL;
         B.used += cum;
         zb_refill(B);
+        const bool last = n + 1 >= nbSeq;
+        if (!last) {
+            // state update: the three fields total <= 26 bits; then straight to the next cells
+            top = zb_top(B);
+            const uint32_t tL = zh_bfe(top, 32 - nbL, nbL), tM = zh_bfe(top, 32 - nbL - nbM, nbM), tO = zh_bfe(top, 32 - nbL - nbM - nbO, nbO);
+            B.used += nbL + nbM + nbO;
+            sL = ((xL << nbL) + tL) & maskL; sM = ((xM << nbM) + tM) & maskM; sO = ((xO << nbO) + tO) & maskO;
+            cL = TL[sL]; cM = TM[sM]; cO = TO[sO];
+            zb_refill(B);
+        }
+        // ---- off the chain: sequence n's values
         const uint32_t ofv = (1u << symO) + xo, mlv = baseM + xm, llv = baseL + xl;
         /* repcode resolution (RFC 8878 3.1.1.5), select form */
         const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */
@@ -466,15 +484,8 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0;
         bad |= offset >> 30;
         out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
-        if (++n >= nbSeq) break;
-        // state update: the three fields total <= 26 bits
-        const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
-        const uint32_t nbL = (uint32_t)__builtin_clz(xL) - kL, nbM = (uint32_t)__builtin_clz(xM) - kM, nbO = (uint32_t)__builtin_clz(xO) - kO;
-        top = zb_top(B);
-        const uint32_t tL = zh_bfe(top, 32 - nbL, nbL), tM = zh_bfe(top, 32 - nbL - nbM, nbM), tO = zh_bfe(top, 32 - nbL - nbM - nbO, nbO);
-        B.used += nbL + nbM + nbO;
-        sL = ((xL << nbL) + tL) & maskL; sM = ((xM << nbM) + tM) & maskM; sO = ((xO << nbO) + tO) & maskO;
-        zb_refill(B);
+        if (last) break;
+        n++;
     }
     if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 1 GiB)
     if (!zb_finished(B)) return ZE_CORRUPTION;
@@ -659,7 +670,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         const uint64_t nearMask = zh_ballot(pending);
         need &= nearMask;                       // literals and far matches are already in the buffer
         uint64_t doneMask = ~nearMask;
-#ifndef ZP_K3_LONGALL
+#ifdef ZP_K3_LONGONE      // round 1 form (one ready long match per dependency round); r02c: the form below is 1.5 % faster
         for (;;) {
             const uint64_t pend = zh_ballot(pending);
             if (!pend) break;
@@ -714,9 +725,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             zh_sync();
         }
 #else
-        // EXPERIMENTAL (-DZP_K3_LONGALL; emulator-verified, not yet measured on hardware): a round serves its ready short matches AND
-        // every ready long match (one after the other by the whole wave) instead of one long match per round: what is ready at the
-        // start of a round never depends on anything else that is ready in it.
+        // a round serves its ready short matches AND every ready long match (one after the other by the whole wave): what is ready at
+        // the start of a round never depends on anything else that is ready in it.
         for (;;) {
             const uint64_t pend = zh_ballot(pending);
             if (!pend) break;

@@ -244,8 +244,10 @@ struct zhip_ctx {
     uint64_t maxWindowSize = (1ull << 27) + 1;
     int dformat = ZHIP_FORMAT_ZSTD1;
     // host-API staging
-    DevBuf hSrc, hDst, hSegs, hStatus;
+    DevBuf hSrc, hDst, hSegs, hStatus, hDense;
     void* pinned = nullptr; size_t pinnedCap = 0;
+    bool hpReady = false; hipStream_t hpH2D = nullptr, hpCompute = nullptr, hpD2H = nullptr;     // host pipeline: copy-in, kernels, copy-out
+    void* hpStage[2] = {nullptr, nullptr}; size_t hpStageCap[2] = {0, 0}; hipEvent_t hpStageFree[2] = {nullptr, nullptr}; int hpNextSlot = 0;
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
 };
 
@@ -303,8 +305,12 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
-    c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release();
+    c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < 2; i++) { if (c->hpStage[i]) (void)hipHostFree(c->hpStage[i]); if (c->hpStageFree[i]) (void)hipEventDestroy(c->hpStageFree[i]); }
+    if (c->hpH2D) (void)hipStreamDestroy(c->hpH2D);
+    if (c->hpCompute) (void)hipStreamDestroy(c->hpCompute);
+    if (c->hpD2H) (void)hipStreamDestroy(c->hpD2H);
     delete c;
 }
 extern "C" const char* zhip_kernel_name(int k)
@@ -812,7 +818,131 @@ extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status
 }
 
 // ------------------------------------------------------------------------------------------ host-buffer batch API
-static int ensure_pinned(zhip_ctx* c, size_t n)
+// zhip_compress_batch / zhip_decompress_batch: the reference's multi_*_to_buffer hands over host buffers and gets host buffers back
+// (c-ext/compressor.c:1340-1503, c-ext/decompressor.c:1459-1710), so this path is bounded by PCIe (Gen5 x16, ~55 GB/s each way) --
+// provided nothing on the host is slower than the link. Round 1 was: one thread packs every item into a pinned buffer, ONE H2D copy,
+// kernels, ONE D2H copy into pageable memory (10.5 / 2.6 GB/s). Now the batch is cut into chunks that flow through three streams:
+//
+//     host threads pack chunk k+1 into pinned staging  |  H2D(k+1)  |  kernels(k)  |  D2H(k-1) straight into the result payload
+//
+// * staging: two pinned slots, filled by ZHIP_PACK_THREADS host threads (a pageable->pinned memcpy is ~8 GB/s per thread);
+// * results: one zhip_outbuf per chunk (the reference returns one buffer per worker as well, the grouping is not contractual), its
+//   payload PINNED so that the D2H copy runs at link speed and needs no second host copy. Pinning costs ~0.3 ms per MiB, far more than
+//   the copy itself, so payload blocks come from a process-wide pool and return to it when the caller frees them
+//   (zhip_free_payload; the CPython extension's BufferWithSegments does that in its deallocator);
+// * compress: the compressBound-sized slots are compacted ON THE DEVICE (scan of the frame sizes + one wave per frame) so that only
+//   the frames cross the link, into a payload allocated once the chunk's total is known (the host learns it one chunk behind).
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+#ifndef ZHIP_PACK_THREADS
+#define ZHIP_PACK_THREADS 8
+#endif
+#define ZHIP_HOST_CHUNK_ITEMS 32768u                  // most items of one pipeline chunk (the scan kernel's bound)
+#define ZHIP_PIN_MIN ((size_t)1 << 20)                // payloads below 1 MiB are plain malloc() (one-shot calls, small batches)
+#define ZHIP_PIN_POOL_KEEP ((size_t)24 << 30)         // idle pinned bytes kept for reuse; beyond that blocks are unpinned on free
+
+namespace {
+struct PinBlock { size_t cap; bool busy; };
+struct PinPool {
+    std::mutex mu;
+    std::unordered_map<void*, PinBlock> blocks;
+    size_t idle = 0;
+    void* take(size_t n)
+    {
+        if (n < ZHIP_PIN_MIN) return malloc(n ? n : 1);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            void* best = nullptr; size_t bestCap = ~(size_t)0;
+            for (auto& kv : blocks) if (!kv.second.busy && kv.second.cap >= n && kv.second.cap < bestCap) { best = kv.first; bestCap = kv.second.cap; }
+            if (best && bestCap <= n + (n >> 1) + ((size_t)64 << 20)) { blocks[best].busy = true; idle -= bestCap; return best; }
+        }
+        void* p = nullptr;
+        const size_t cap = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return malloc(n); }     // pageable still works, slower
+        std::lock_guard<std::mutex> g(mu);
+        blocks[p] = PinBlock{cap, true};
+        return p;
+    }
+    void give(void* p)
+    {
+        if (!p) return;
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = blocks.find(p);
+            if (it == blocks.end()) { free(p); return; }
+            it->second.busy = false; idle += it->second.cap;
+            while (idle > ZHIP_PIN_POOL_KEEP) {                       // unpin the largest idle blocks first
+                void* big = nullptr; size_t bigCap = 0;
+                for (auto& kv : blocks) if (!kv.second.busy && kv.second.cap > bigCap) { big = kv.first; bigCap = kv.second.cap; }
+                if (!big) break;
+                idle -= bigCap; blocks.erase(big); drop.push_back(big);
+            }
+        }
+        for (void* q : drop) (void)hipHostFree(q);
+    }
+};
+PinPool& pin_pool() { static PinPool* pool = new PinPool(); return *pool; }      // leaked on purpose: payloads may outlive static destruction
+}
+
+extern "C" void zhip_free_payload(void* p) { pin_pool().give(p); }
+
+// sizes -> exclusive offsets (bytes) of the frames of one chunk, total to *total. One workgroup; n <= ZHIP_HOST_CHUNK_ITEMS.
+__global__ __launch_bounds__(1024) void zhip_scan_sizes_kernel(const uint64_t* sizes, const int32_t* status, uint32_t n, uint64_t* offs, uint64_t* total)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023) / 1024, lo = t * per, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += status[i] ? 0 : sizes[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) { offs[i] = run; run += status[i] ? 0 : sizes[i]; }
+    if (t == 1023) *total = part[1023];
+}
+// one wave per frame: the valid prefix of its compressBound-sized slot -> its place in the dense payload
+__global__ __launch_bounds__(64) void zhip_compact_kernel(const uint8_t* slots, const zhip_segment* dstSegs, const uint64_t* sizes, const int32_t* status,
+                                                           const uint64_t* offs, uint32_t n, uint8_t* dense)
+{
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (status[i]) continue;
+        const uint8_t* s = slots + dstSegs[i].offset; uint8_t* d = dense + offs[i];
+        const uint32_t size = (uint32_t)sizes[i], whole = size & ~15u;
+        for (uint32_t j = threadIdx.x * 16; j < whole; j += 1024) { const zh_v16 v = zh_ld128(s + j); zh_st64(d + j, v.lo); zh_st64(d + j + 8, v.hi); }
+        if (threadIdx.x < size - whole) d[whole + threadIdx.x] = s[whole + threadIdx.x];
+    }
+}
+
+// per-context host pipeline state (streams, staging, small pinned metadata)
+static int host_pipe_init(zhip_ctx* c)
+{
+    if (c->hpReady) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&c->hpH2D, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->hpCompute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->hpD2H, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->hpStageFree[i], hipEventDisableTiming));
+    c->hpReady = true;
+    return 0;
+}
+static int ensure_stage(zhip_ctx* c, int slot, size_t n)
+{
+    if (n <= c->hpStageCap[slot]) return 0;
+    if (c->hpStage[slot]) (void)hipHostFree(c->hpStage[slot]);
+    c->hpStage[slot] = nullptr; c->hpStageCap[slot] = 0;
+    const size_t want = n + (n >> 3) + 4096;
+    HIP_TRY(hipHostMalloc(&c->hpStage[slot], want, hipHostMallocDefault));
+    c->hpStageCap[slot] = want;
+    return 0;
+}
+static int ensure_pinned(zhip_ctx* c, size_t n)          // small pinned area for per-item sizes / status / chunk totals coming back
 {
     if (n <= c->pinnedCap) return 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -821,6 +951,26 @@ static int ensure_pinned(zhip_ctx* c, size_t n)
     HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
     c->pinnedCap = want;
     return 0;
+}
+// items [lo, hi) -> stage, item i at offset segs[i].offset - segs[lo].offset. Big chunks are split over host threads by bytes.
+static void pack_items(uint8_t* stage, const zhip_item* items, const zhip_segment* segs, size_t lo, size_t hi)
+{
+    const uint64_t base = segs[lo].offset, bytes = hi > lo ? segs[hi - 1].offset + segs[hi - 1].length - base : 0;
+    auto run = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) if (items[i].srcSize) memcpy(stage + (segs[i].offset - base), items[i].src, items[i].srcSize); };
+    unsigned nt = bytes >= ((uint64_t)32 << 20) ? ZHIP_PACK_THREADS : 1;
+    if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64 && nt > 1) nt = (unsigned)v; }
+    if (nt <= 1 || hi - lo < 2 * nt) { run(lo, hi); return; }
+    std::vector<std::thread> th;
+    size_t a = lo;
+    for (unsigned t = 0; t < nt && a < hi; t++) {
+        const uint64_t target = base + bytes * (t + 1) / nt;
+        size_t b = a;
+        while (b < hi && (t + 1 == nt || segs[b].offset + segs[b].length <= target)) b++;
+        if (b == a) b = a + 1;
+        th.emplace_back(run, a, b);
+        a = b;
+    }
+    for (auto& t : th) t.join();
 }
 // one lazily created context per calling thread, destroyed when the thread exits; re-created when the thread switched devices
 struct TlsCtx { zhip_ctx* c = nullptr; ~TlsCtx() { if (c) zhip_ctx_destroy(c); } };
@@ -837,9 +987,8 @@ static void tls_trim(zhip_ctx* c)
 {
     const size_t limit = (size_t)2 << 30;
     DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeSeq, &c->pipeFse, &c->pipeHuf, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
-                       &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst };
+                       &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst, &c->hDense };
     for (DevBuf* b : bufs) if (b->cap > limit) b->release();
-    if (c->pinnedCap > limit) { (void)hipHostFree(c->pinned); c->pinned = nullptr; c->pinnedCap = 0; }
 }
 static int set_err(zhip_error* err, int kind, size_t index, int zerr, uint64_t d0 = 0, uint64_t d1 = 0)
 {
@@ -850,9 +999,44 @@ static int set_err(zhip_error* err, int kind, size_t index, int zerr, uint64_t d
 extern "C" void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload)
 {
     if (!bufs) return;
-    if (freePayload) for (size_t i = 0; i < n; i++) { free(bufs[i].data); free(bufs[i].segs); }
+    if (freePayload) for (size_t i = 0; i < n; i++) { zhip_free_payload(bufs[i].data); free(bufs[i].segs); }
     free(bufs);
 }
+
+// chunk boundaries [cut[k], cut[k+1]) over n items: a chunk closes when its input or output bytes reach maxBytes or it holds maxItems
+// items. segs: [0,n) source, [n,2n) destination.
+static std::vector<size_t> host_chunks(const zhip_segment* segs, size_t n, uint64_t maxBytes, size_t maxItems)
+{
+    std::vector<size_t> cut(1, 0);
+    uint64_t in = 0, out = 0; size_t cnt = 0;
+    for (size_t i = 0; i < n; i++) {
+        in += segs[i].length; out += segs[n + i].length; cnt++;
+        if (in >= maxBytes || out >= maxBytes || cnt >= maxItems) { cut.push_back(i + 1); in = out = 0; cnt = 0; }
+    }
+    if (cut.back() != n) cut.push_back(n);
+    return cut;
+}
+// items [lo, hi) -> their place in the device source arena, in steps of <= ZHIP_STAGE_BYTES through the two pinned staging slots: the
+// packing of step s+1 (host threads) overlaps the H2D copy of step s. Every copy is only ENQUEUED on hpH2D; `done` is recorded behind
+// the last one. A slot is reused once the copy that last read it has finished (its event).
+#define ZHIP_STAGE_BYTES ((uint64_t)512 << 20)
+static int upload_items(zhip_ctx* c, const zhip_item* items, const zhip_segment* segs, size_t lo, size_t hi, hipEvent_t done)
+{
+    size_t a = lo;
+    while (a < hi) {
+        size_t b = a; uint64_t bytes = 0;
+        while (b < hi && (b == a || bytes + segs[b].length <= ZHIP_STAGE_BYTES)) { bytes += segs[b].length; b++; }
+        const int slot = c->hpNextSlot; c->hpNextSlot ^= 1;
+        if (hipEventSynchronize(c->hpStageFree[slot]) != hipSuccess) return ZHIP_ERR_HIP;
+        if (ensure_stage(c, slot, bytes + 16)) return ZHIP_ERR_HIP;
+        pack_items((uint8_t*)c->hpStage[slot], items, segs, a, b);
+        if (bytes && hipMemcpyAsync((uint8_t*)c->hSrc.p + segs[a].offset, c->hpStage[slot], bytes, hipMemcpyHostToDevice, c->hpH2D) != hipSuccess) return ZHIP_ERR_HIP;
+        if (hipEventRecord(c->hpStageFree[slot], c->hpH2D) != hipSuccess) return ZHIP_ERR_HIP;
+        a = b;
+    }
+    return hipEventRecord(done, c->hpH2D) == hipSuccess ? 0 : ZHIP_ERR_HIP;
+}
+static void empty_outbuf(zhip_outbuf* ob) { ob->data = malloc(1); ob->segs = (zhip_segment*)malloc(sizeof(zhip_segment)); ob->dataSize = 0; ob->nSegs = 0; }
 
 extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
                                      zhip_outbuf** out, size_t* nOut, zhip_error* err)
@@ -884,40 +1068,62 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     r = zhip_ctx_set_ddict(c, params ? params->dict : nullptr, params ? params->dictSize : 0, params ? params->dictType : ZHIP_DICT_AUTO);
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
-    // stage: pack the frames into one pinned buffer, one H2D copy
-    if (ensure_pinned(c, srcTotal + 8)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
-    if (c->hSrc.reserve(srcTotal + 8) || c->hDst.reserve(dstTotal + 8) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
+    if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    // the kernels are several times faster than the link here: chunks of ~1 GiB of output keep all three streams busy
+    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)1 << 30, 32768);
+    const size_t nChunks = cut.size() - 1;
+    if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment) + 16) ||
         c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, g_reserveRc, 0, 0);
-    if (hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess && srcTotal) return set_err(err, g_reserveRc, 0, 0);
-    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
+    if (ensure_pinned(c, n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    zhip_outbuf* ob = (zhip_outbuf*)calloc(nChunks ? nChunks : 1, sizeof(zhip_outbuf));
+    if (!ob) return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0);
+    hipEvent_t evUp = nullptr, evK = nullptr;
+    auto fail = [&](int kind, size_t index = 0, int zerr = 0, uint64_t d0 = 0, uint64_t d1 = 0) -> int {
+        if (kind == ZHIP_ERR_HIP) hip_fail(hipGetLastError(), "host decompress pipeline");
+        (void)hipDeviceSynchronize();
+        if (evUp) (void)hipEventDestroy(evUp);
+        if (evK) (void)hipEventDestroy(evK);
+        zhip_free_outbufs(ob, nChunks ? nChunks : 1, 1);
+        return set_err(err, kind, index, zerr, d0, d1);
+    };
+    if (hipEventCreateWithFlags(&evUp, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&evK, hipEventDisableTiming) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    if (hipMemcpyAsync(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice, c->hpH2D) != hipSuccess ||
+        hipStreamSynchronize(c->hpH2D) != hipSuccess) return fail(ZHIP_ERR_HIP);      // segs is pageable: wait before anything reads the table
     uint64_t* dSizes = (uint64_t*)c->hStatus.p;
     int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
-    r = zhip_decompress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
-                                     (const zhip_segment*)c->hSegs.p + n, dSizes, dStatus, nullptr);
-    if (r) return set_err(err, r, 0, 0);
-    std::vector<uint64_t> sizes(n); std::vector<int32_t> status(n);
-    if (hipMemcpy(sizes.data(), dSizes, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(status.data(), dStatus, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-        hip_fail(hipGetLastError(), "decode kernel / status copy"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    uint64_t* hSizes = (uint64_t*)c->pinned;
+    int32_t* hStatus = (int32_t*)((uint8_t*)c->pinned + n * sizeof(uint64_t));
+    const zhip_segment* dSegs = (const zhip_segment*)c->hSegs.p;
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
+        const uint64_t outBytes = segs[n + hi - 1].offset + segs[n + hi - 1].length - segs[n + lo].offset;
+        if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
+        if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        r = zhip_decompress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
+        if (r) return fail(r);
+        if (hipEventRecord(evK, c->hpCompute) != hipSuccess || hipStreamWaitEvent(c->hpD2H, evK, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        // the chunk's output goes straight into its (pinned) result payload
+        ob[k].data = pin_pool().take((size_t)outBytes);
+        ob[k].segs = (zhip_segment*)malloc((cnt ? cnt : 1) * sizeof(zhip_segment));
+        if (!ob[k].data || !ob[k].segs) return fail(ZHIP_ERR_NO_MEMORY, lo);
+        ob[k].dataSize = (size_t)outBytes; ob[k].nSegs = cnt;
+        if ((outBytes && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDst.p + segs[n + lo].offset, outBytes, hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess) ||
+            hipMemcpyAsync(hSizes + lo, dSizes + lo, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess ||
+            hipMemcpyAsync(hStatus + lo, dStatus + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
     }
-    for (size_t i = 0; i < n; i++) {
-        if (status[i]) return set_err(err, ZHIP_ERR_ZSTD, i, status[i]);
-        if (sizes[i] != segs[n + i].length && !(allowShort && sizes[i] < segs[n + i].length))
-            return set_err(err, ZHIP_ERR_SIZE_MISMATCH, i, 0, sizes[i], segs[n + i].length);
-        segs[n + i].length = sizes[i];
+    if (hipStreamSynchronize(c->hpD2H) != hipSuccess || hipStreamSynchronize(c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t lo = cut[k], hi = cut[k + 1];
+        const uint64_t base = segs[n + lo].offset;
+        for (size_t i = lo; i < hi; i++) {
+            if (hStatus[i]) return fail(ZHIP_ERR_ZSTD, i, hStatus[i]);
+            if (hSizes[i] != segs[n + i].length && !(allowShort && hSizes[i] < segs[n + i].length)) return fail(ZHIP_ERR_SIZE_MISMATCH, i, 0, hSizes[i], segs[n + i].length);
+            ob[k].segs[i - lo].offset = segs[n + i].offset - base; ob[k].segs[i - lo].length = hSizes[i];
+        }
     }
-    // results: one malloc()ed payload + segment table handed to the caller (BufferWithSegments_FromMemory semantics)
-    zhip_outbuf* ob = (zhip_outbuf*)calloc(1, sizeof(zhip_outbuf));
-    void* payload = malloc(dstTotal ? dstTotal : 1);
-    zhip_segment* osegs = (zhip_segment*)malloc((n ? n : 1) * sizeof(zhip_segment));
-    if (!ob || !payload || !osegs) { free(ob); free(payload); free(osegs); return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0); }
-    if (dstTotal && hipMemcpy(payload, c->hDst.p, dstTotal, hipMemcpyDeviceToHost) != hipSuccess) {
-        free(ob); free(payload); free(osegs); hip_fail(hipGetLastError(), "D2H"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    }
-    memcpy(osegs, segs.data() + n, n * sizeof(zhip_segment));
-    ob->data = payload; ob->dataSize = dstTotal; ob->segs = osegs; ob->nSegs = n;
-    *out = ob; *nOut = 1;
+    (void)hipEventDestroy(evUp); (void)hipEventDestroy(evK);
+    if (nChunks == 0) empty_outbuf(&ob[0]);
+    *out = ob; *nOut = nChunks ? nChunks : 1;
     tls_trim(c);
     return ZHIP_ERR_NONE;
 }
@@ -934,8 +1140,8 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
     const bool withDict = c->hasCDict;
-    // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are
-    // compacted into one payload afterwards
+    // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are compacted on the
+    // device, chunk by chunk, and only they travel back
     std::vector<zhip_segment> segs(2 * n);
     uint64_t srcTotal = 0, dstTotal = 0;
     for (size_t i = 0; i < n; i++) {
@@ -952,41 +1158,75 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
         b = (b + 15) & ~(uint64_t)15;
         segs[n + i].offset = dstTotal; segs[n + i].length = b; dstTotal += b;
     }
-    if (ensure_pinned(c, (srcTotal > dstTotal ? srcTotal : dstTotal) + 16)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    for (size_t i = 0; i < n; i++) if (items[i].srcSize) memcpy((uint8_t*)c->pinned + segs[i].offset, items[i].src, items[i].srcSize);
-    if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment)) ||
-        c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, g_reserveRc, 0, 0);
-    if (srcTotal && hipMemcpy(c->hSrc.p, c->pinned, srcTotal, hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
-    if (hipMemcpy(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice) != hipSuccess) return set_err(err, g_reserveRc, 0, 0);
-    uint64_t* dSizes = (uint64_t*)c->hStatus.p;
-    int32_t* dStatus = (int32_t*)((uint8_t*)c->hStatus.p + n * sizeof(uint64_t));
-    r = zhip_compress_batch_device(c, c->hSrc.p, (const zhip_segment*)c->hSegs.p, n, c->hDst.p,
-                                   (const zhip_segment*)c->hSegs.p + n, dSizes, dStatus, nullptr);
-    if (r) return set_err(err, r, 0, 0);
-    std::vector<uint64_t> sizes(n); std::vector<int32_t> status(n);
-    if (hipMemcpy(sizes.data(), dSizes, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(status.data(), dStatus, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-        hip_fail(hipGetLastError(), "encode kernel / status copy"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    // the match kernel is a per-frame latency chain (its time barely depends on the batch below ~16 K frames), so compress chunks are
+    // large: two of them overlap one's upload with the other's kernels, more would only add chains end to end
+    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)4 << 30, 32768);
+    const size_t nChunks = cut.size() - 1;
+    // device: sources, slots, dense frames, segment table, [sizes | offsets | chunk totals | status]
+    const size_t metaBytes = n * (2 * sizeof(uint64_t) + sizeof(int32_t)) + (nChunks + 1) * sizeof(uint64_t) + 32;
+    if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hDense.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment) + 16) ||
+        c->hStatus.reserve(metaBytes)) return set_err(err, g_reserveRc, 0, 0);
+    if (ensure_pinned(c, metaBytes)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
+    zhip_outbuf* ob = (zhip_outbuf*)calloc(nChunks ? nChunks : 1, sizeof(zhip_outbuf));
+    if (!ob) return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0);
+    std::vector<hipEvent_t> evMeta(nChunks, nullptr);
+    hipEvent_t evUp = nullptr;
+    auto fail = [&](int kind, size_t index = 0, int zerr = 0) -> int {
+        if (kind == ZHIP_ERR_HIP) hip_fail(hipGetLastError(), "host compress pipeline");
+        (void)hipDeviceSynchronize();
+        for (auto e : evMeta) if (e) (void)hipEventDestroy(e);
+        if (evUp) (void)hipEventDestroy(evUp);
+        zhip_free_outbufs(ob, nChunks ? nChunks : 1, 1);
+        return set_err(err, kind, index, zerr);
+    };
+    if (hipEventCreateWithFlags(&evUp, hipEventDisableTiming) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    if (hipMemcpyAsync(c->hSegs.p, segs.data(), 2 * n * sizeof(zhip_segment), hipMemcpyHostToDevice, c->hpH2D) != hipSuccess ||
+        hipStreamSynchronize(c->hpH2D) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    uint64_t* dSizes = (uint64_t*)c->hStatus.p; uint64_t* dOffs = dSizes + n; uint64_t* dTotals = dOffs + n; int32_t* dStatus = (int32_t*)(dTotals + nChunks + 1);
+    uint64_t* hSizes = (uint64_t*)c->pinned; uint64_t* hTotals = hSizes + 2 * n; int32_t* hStatus = (int32_t*)(hTotals + nChunks + 1);
+    const zhip_segment* dSegs = (const zhip_segment*)c->hSegs.p;
+    // the host learns a chunk's total one chunk behind: while chunk k is being packed / copied / compressed, chunk k-1's sizes have
+    // arrived, its payload is allocated (exact size) and its frames travel back on the third stream
+    auto collect = [&](size_t k) -> int {
+        const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
+        if (hipEventSynchronize(evMeta[k]) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        (void)hipEventDestroy(evMeta[k]); evMeta[k] = nullptr;
+        for (size_t i = lo; i < hi; i++) if (hStatus[i]) return fail(ZHIP_ERR_ZSTD, i, hStatus[i]);
+        const uint64_t total = hTotals[k];
+        ob[k].data = pin_pool().take((size_t)total);
+        ob[k].segs = (zhip_segment*)malloc((cnt ? cnt : 1) * sizeof(zhip_segment));
+        if (!ob[k].data || !ob[k].segs) return fail(ZHIP_ERR_NO_MEMORY, lo);
+        ob[k].dataSize = (size_t)total; ob[k].nSegs = cnt;
+        uint64_t o = 0;
+        for (size_t i = lo; i < hi; i++) { ob[k].segs[i - lo].offset = o; ob[k].segs[i - lo].length = hSizes[i]; o += hSizes[i]; }
+        // the compaction finished before evMeta (same stream), so the copy needs no further dependency
+        if (total && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDense.p + segs[n + lo].offset, total, hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        return 0;
+    };
+    for (size_t k = 0; k < nChunks; k++) {
+        const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
+        if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
+        if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        r = zhip_compress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
+        if (r) return fail(r);
+        hipLaunchKernelGGL(zhip_scan_sizes_kernel, dim3(1), dim3(1024), 0, c->hpCompute, dSizes + lo, dStatus + lo, (uint32_t)cnt, dOffs + lo, dTotals + k);
+        const uint32_t gridC = (uint32_t)(cnt < (size_t)c->numCU * 16 ? cnt : (size_t)c->numCU * 16);
+        hipLaunchKernelGGL(zhip_compact_kernel, dim3(gridC ? gridC : 1), dim3(64), 0, c->hpCompute, (const uint8_t*)c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo,
+                           dOffs + lo, (uint32_t)cnt, (uint8_t*)c->hDense.p + segs[n + lo].offset);
+        // sizes, status and the chunk total ride the compute stream (a few hundred KiB) so that nothing queues behind a later chunk's kernels
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(hSizes + lo, dSizes + lo, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
+            hipMemcpyAsync(hStatus + lo, dStatus + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
+            hipMemcpyAsync(hTotals + k, dTotals + k, sizeof(uint64_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
+            hipEventCreateWithFlags(&evMeta[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(evMeta[k], c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        if (k >= 1) { const int e = collect(k - 1); if (e) return e; }
     }
-    uint64_t outTotal = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (status[i]) return set_err(err, ZHIP_ERR_ZSTD, i, status[i]);
-        outTotal += sizes[i];
-    }
-    if (dstTotal && hipMemcpy(c->pinned, c->hDst.p, dstTotal, hipMemcpyDeviceToHost) != hipSuccess) {
-        hip_fail(hipGetLastError(), "D2H"); return set_err(err, ZHIP_ERR_HIP, 0, 0);
-    }
-    zhip_outbuf* ob = (zhip_outbuf*)calloc(1, sizeof(zhip_outbuf));
-    uint8_t* payload = (uint8_t*)malloc(outTotal ? outTotal : 1);
-    zhip_segment* osegs = (zhip_segment*)malloc((n ? n : 1) * sizeof(zhip_segment));
-    if (!ob || !payload || !osegs) { free(ob); free(payload); free(osegs); return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0); }
-    uint64_t o = 0;
-    for (size_t i = 0; i < n; i++) {
-        memcpy(payload + o, (const uint8_t*)c->pinned + segs[n + i].offset, sizes[i]);
-        osegs[i].offset = o; osegs[i].length = sizes[i]; o += sizes[i];
-    }
-    ob->data = payload; ob->dataSize = outTotal; ob->segs = osegs; ob->nSegs = n;
-    *out = ob; *nOut = 1;
+    if (nChunks) { const int e = collect(nChunks - 1); if (e) return e; }
+    if (hipStreamSynchronize(c->hpD2H) != hipSuccess || hipStreamSynchronize(c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    (void)hipEventDestroy(evUp);
+    if (nChunks == 0) empty_outbuf(&ob[0]);
+    *out = ob; *nOut = nChunks ? nChunks : 1;
     tls_trim(c);
     return ZHIP_ERR_NONE;
 }

@@ -222,12 +222,12 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
 
 
 def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
-    """-DZE_TAB3 (three-lane sequence-table build in the entropy kernel) and -DZP_K3_LONGALL (all ready long matches per dependency
-    round in K3) are compiled out of the product by default (emulator-verified, not yet measured on hardware): keep them
-    bit-exact so that the next GPU session can measure them straight away"""
+    """-DZE_TAB3 (three-lane sequence-table build in the entropy kernel) and -DZP_K3_LONGONE (round 1's one-long-match-per-round form of
+    K3; the all-ready-long-matches form became the default after the r02c measurement) are compiled out of the product: keep them
+    bit-exact so that a GPU session can A/B them straight away"""
     import numpy as np
     from tests import emulib
-    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZE_TAB3", "-DZP_K3_LONGALL"])
+    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZE_TAB3", "-DZP_K3_LONGONE"])
     emu = emulib.Emu(so)
     rng = np.random.default_rng(11)
     blk = rng.bytes(600)
@@ -243,7 +243,7 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     assert not any(st) and dec == big
 
 
-@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=8"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"]])
+@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
     """K2 / K1b with fewer frames per wave (several one-wave workgroups per CU share its LDS; the bit reader's ring stride follows):
     the shapes csrc/build_variants.sh builds for A/B runs decode the same bytes"""
