@@ -434,14 +434,6 @@ ZH_DEVFN uint32_t ze_huf_write_table(ZeLDS& L, uint8_t* out, uint32_t maxSym, ui
     return (maxSym + 1) / 2 + 1;
 }
 
-// one Huffman stream, last symbol first (HUF_compress1X_usingCTable_internal_body, zstd.c:17813). One lane.
-ZH_DEVFN uint32_t ze_huf_encode_1x(const ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t n)
-{
-    ZeBits b; ze_bw_init(b, out, cap);
-    for (uint32_t i = n; i-- > 0;) { const uint32_t s = src[i]; ze_bw_add(b, L.hufCode[s], L.hufBits[s]); }
-    return ze_bw_close(b);
-}
-
 // LDS scratch that aliases the Huffman tree nodes (dead once the code lengths are final): first the literal code table
 // (code | nbBits << 16 per byte value), later -- the literals being done -- the sequence encoder's scratch.
 ZH_DEV uint32_t* ze_scratch(ZeLDS& L) { return (uint32_t*)L.node; }
@@ -505,6 +497,58 @@ ZH_DEVFN uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint3
 #undef ZE_HSYM
 #undef ZE_HEMIT
         if (lane < 3) zh_st16(body + 2 * lane, (uint16_t)(lane == 0 ? z1 : lane == 1 ? z2 : z3));
+    }
+    ze_fence();
+    zh_sync();
+    return total;
+}
+
+// One Huffman stream (HUF_compress1X_usingCTable_internal_body, zstd.c:17813: last symbol first, closed by a 1 bit) by the whole wave --
+// the single-stream form of the above: 64 lanes, each a contiguous run; no jump table. The
+// lane-0 encoder reads the literals a byte at a time from global memory -- a dependent round trip per literal -- which was 40 % of
+// the entropy kernel on small inputs with a dictionary (sections of fewer than 1 024 literals are single streams; r02d). Returns
+// the stream size, 0 when it does not fit.
+ZH_DEVFN uint32_t ze_huf_encode_1x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t run = (n + 63) / 64;
+    const uint32_t ra = lane * run < n ? lane * run : n, rb = ra + run < n ? ra + run : n;
+    uint32_t bits = 0;
+    for (uint32_t i = ra; i < rb; i++) bits += ct[lit[i]] >> 16;
+    const uint32_t incl = zh_scan_add(bits);
+    const uint32_t T = zh_shfl(incl, 63);
+    const uint32_t off = T - incl;                                   // bits emitted before mine: the runs behind me
+    const uint32_t total = (T + 1 + 7) / 8;
+    if (total > bcap) return 0;
+    {   // zero the stream area byte-exactly
+        uint8_t* z0 = body; uint8_t* const ze = body + total;
+        const uint32_t head = (uint32_t)((4 - ((uintptr_t)z0 & 3)) & 3);
+        const uint32_t h = head < (uint32_t)(ze - z0) ? head : (uint32_t)(ze - z0);
+        if (lane < h) z0[lane] = 0;
+        z0 += h;
+        const uint32_t nd = (uint32_t)(ze - z0) >> 2;
+        for (uint32_t i = lane; i < nd; i += 64) ((uint32_t*)z0)[i] = 0;
+        z0 += 4 * (size_t)nd;
+        if (lane < (uint32_t)(ze - z0)) z0[lane] = 0;
+    }
+    ze_fence();
+    zh_sync();
+    {
+        const uintptr_t A = (uintptr_t)body;
+        const uint32_t sh0 = (uint32_t)(A & 3) * 8 + off;
+        uint32_t* d = (uint32_t*)(A & ~(uintptr_t)3) + (sh0 >> 5);
+        uint32_t nacc = sh0 & 31; uint64_t acc = 0; bool first = true;
+        for (uint32_t i = rb; i > ra;) {
+            --i;
+            const uint32_t e = ct[lit[i]];
+            acc |= (uint64_t)(e & 0xFFFFu) << nacc; nacc += e >> 16;
+            if (nacc >= 32) { if (first) { zh_atomic_or(d, (uint32_t)acc); first = false; } else *d = (uint32_t)acc; d++; acc >>= 32; nacc -= 32; }
+        }
+        if (lane == 0) {                                            // end mark after the stream's first symbol
+            acc |= 1ull << nacc; nacc++;
+            if (nacc >= 32) { if (first) { zh_atomic_or(d, (uint32_t)acc); first = false; } else *d = (uint32_t)acc; d++; acc >>= 32; nacc -= 32; }
+        }
+        if (acc) zh_atomic_or(d, (uint32_t)acc);
     }
     ze_fence();
     zh_sync();
@@ -669,18 +713,13 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         uint8_t* body = out + lh + h;
         const uint32_t bcap = cap - lh - h;
         uint32_t total = 0;
-        if (single) {
-            if (zh_opaque(lane) == 0) L.misc[0] = ze_huf_encode_1x(L, body, bcap, lit, n);
-            zh_sync();
-            total = zh_first(L.misc[0]);
-            zh_sync();
-        } else {
-            // 4 streams, wave-parallel
+        {
+            // one or four streams, wave-parallel
             uint32_t* ct = ze_scratch(L);
             zh_sync();
             for (uint32_t i = lane; i < 256; i += 64) ct[i] = (uint32_t)L.hufCode[i] | ((uint32_t)L.hufBits[i] << 16);
             zh_sync();
-            total = ze_huf_encode_4x_wave(ct, body, bcap, lit, n);
+            total = single ? ze_huf_encode_1x_wave(ct, body, bcap, lit, n) : ze_huf_encode_4x_wave(ct, body, bcap, lit, n);
             ZE_T(P, ZEP_HUFENC);
         }
         uint32_t cl = total ? h + total : 0;
@@ -1316,14 +1355,8 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     const uint32_t repeatMode = !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;
     *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode, strat);
     ZeCTab& t = L.tab[which];
-    if (*mode == 3) {
-        const ZeCTab& d = cd->tab[which];
-        t.log = d.log; t.maxSym = d.maxSym;
-        for (uint32_t s = 0; s <= d.maxSym; s++) { t.norm[s] = d.norm[s]; t.cellOf[s] = d.cellOf[s]; }
-        t.cellOf[d.maxSym + 1] = d.cellOf[d.maxSym + 1];
-        for (uint32_t u = 0; u < (1u << d.log); u++) t.next[u] = d.next[u];
-        return 0;
-    }
+    if (*mode == 3) return 0;        // set_repeat: the dictionary's table, copied into LDS by the whole wave (ze_copy_dict_tables) -- a lane-0
+                                     // copy is ~1 500 dependent global round trips per frame (r02d: most of the entropy kernel on 4 KiB inputs)
     if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
     if (*mode == 0) { for (uint32_t s = 0; s <= defMax; s++) norm[s] = defNorm[s]; ze_fse_build_ctab(t, cellSym, fill, norm, defMax, defLog); return 0; }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
@@ -1333,6 +1366,23 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
     ze_fse_build_ctab(t, cellSym, fill, norm, max, lg);
     return h;
+}
+// the tables whose mode is set_repeat (3): dictionary -> LDS, 4 bytes per lane per step, all loads of a table in flight together
+ZH_DEV void ze_copy_dict_tables(ZeLDS& L, const ZeCDict* cd, uint32_t modes /* mLL | mOF << 2 | mML << 4 */)
+{
+    const uint32_t lane = zh_lane();
+    constexpr uint32_t W = sizeof(ZeCTab) / 4;
+    static_assert(sizeof(ZeCTab) % 4 == 0, "ZeCTab is copied as dwords");
+    for (uint32_t which = 0; which < 3; which++) {
+        if (((modes >> (2 * which)) & 3) != 3) continue;
+        const uint32_t* src = (const uint32_t*)&cd->tab[which];
+        uint32_t* dst = (uint32_t*)&L.tab[which];
+        uint32_t r[(W + 63) / 64];
+#pragma unroll
+        for (uint32_t q = 0; q < (W + 63) / 64; q++) r[q] = lane + 64 * q < W ? src[lane + 64 * q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < (W + 63) / 64; q++) if (lane + 64 * q < W) dst[lane + 64 * q] = r[q];
+    }
 }
 // ZSTD_LLcode / ZSTD_MLcode (zstd.c:19738, :19755) and the extra-bit counts (LL_bits / ML_bits), computed: the reference's lookup
 // tables would be per-lane reads of global memory in the middle of per-sequence work. Nibble k of 0x5555444433221100 is the
@@ -1641,6 +1691,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
             h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mOF == 2) lastCount = h; op += h;
             h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
+            L.misc[7] = (uint32_t)mLL | ((uint32_t)mOF << 2) | ((uint32_t)mML << 4);
         }
         L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
     }
@@ -1674,6 +1725,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
                 op += h;
             }
             *seqHead = (uint8_t)((modes[0] << 6) + (modes[1] << 4) + (modes[2] << 2));
+            L.misc[7] = modes[0] | (modes[1] << 2) | (modes[2] << 4);
         }
         L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
     }
@@ -1681,7 +1733,9 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     ze_fence();
     zh_sync();
     const uint32_t seqStart = zh_first(L.misc[10]), lastCount = zh_first(L.misc[3]);
+    const uint32_t seqModes = nbSeq ? zh_first(L.misc[7]) : 0u;
     zh_sync();
+    if (cd && seqModes) { ze_copy_dict_tables(L, cd, seqModes); ze_fence(); zh_sync(); }
     ZE_T(P, ZEP_SEQTAB);
     uint32_t r = 1, cSize = seqStart;
     if (nbSeq) {

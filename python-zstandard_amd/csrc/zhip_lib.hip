@@ -411,7 +411,11 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
     // parameter row (chosen for a 513-byte source) is what the frames are compressed with, so such a blob is digested like any other
     const bool hasDict = p->dict && p->dictSize;
     const bool hasMagic = hasDict && p->dictSize >= 8 && rd32((const uint8_t*)p->dict) == ZF_DICT_MAGIC;
-    if (hasDict && p->dictType == ZHIP_DICT_FULLDICT && !hasMagic) return -ZE_DICT_WRONG;
+    // What the caller sees when the dictionary cannot be digested is libzstd's, quirk included: the reference hands the blob to
+    // ZSTD_CCtx_loadDictionary_advanced (c-ext/compressor.c:34-37), which only stores it; the ZSTD_CDict is made at the first compression
+    // (ZSTD_initLocalDict, zstd.c:24206) and ANY failure there -- dictionary_wrong, dictionary_corrupted -- comes back as a NULL CDict,
+    // reported as memory_allocation (zstd.c:24232): "cannot compress: Allocation error : not enough memory".
+    if (hasDict && p->dictType == ZHIP_DICT_FULLDICT && !hasMagic) return -ZE_MEMORY;
     const bool useDict = hasDict;
     if (useDict) {
         uint64_t salt = 0x200u + (uint64_t)p->dictType;
@@ -438,7 +442,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
                                (ZhipDictEntropy*)c->cdictEntropy.p);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpy(&de, c->cdictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
-            if (de.status) return -de.status;
+            if (de.status) return -ZE_MEMORY;                   // (dictionary_corrupted inside ZSTD_createCDict: see above)
         }
         uint32_t* t = (uint32_t*)c->cdictTables.p;
         hipLaunchKernelGGL(zhip_build_cdict_kernel, dim3(1), dim3(64), 0, 0, (const uint8_t*)c->cdictBlob.p, (uint32_t)p->dictSize,
@@ -447,7 +451,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         ZeCDict cd;
         HIP_TRY(hipMemcpy(&cd, c->cdictDigest.p, sizeof cd, hipMemcpyDeviceToHost));
         if (cd.status == ZE_PARAM_UNSUPPORTED) { g_lastError = "dictionary / level combination outside the double-fast attached-dictionary path of the HIP backend"; return ZHIP_ERR_UNSUPPORTED; }
-        if (cd.status) return -cd.status;
+        if (cd.status) return cd.status == ZE_DICT_CORRUPTED || cd.status == ZE_DICT_WRONG ? -ZE_MEMORY : -cd.status;
         c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
     }
     c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows;

@@ -41,15 +41,21 @@ def test_dictionary_content_type(zstd, ref, corpus):
     a = zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(trained)).compress(raws[2])
     b = zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(trained, dict_type=zstd.DICT_TYPE_RAWCONTENT)).compress(raws[2])
     assert a != b and zstd.get_frame_parameters(a).dict_id != 0 and zstd.get_frame_parameters(b).dict_id == 0
-    # a full dictionary is demanded but the blob is not one: libzstd's errors, both directions
+    # a full dictionary is demanded but the blob is not one, or the blob is damaged: libzstd's errors, both directions. On the compression
+    # side that is "Allocation error" whatever the cause: the CDict is created lazily (ZSTD_initLocalDict, zstd.c:24206) and a NULL result
+    # is all the caller learns (zstd.c:24232); the reference's message is "cannot compress: ..." (c-ext/compressor.c:560)
     for blob in (b"plain content without magic " * 10, b"abc"):
-        with pytest.raises(RuntimeError, match="Dictionary mismatch"):
+        with pytest.raises(RuntimeError, match="Allocation error"):
             ref.compress_advanced(raws[0], dict_data=blob, dict_type=2)
-        with pytest.raises(zstd.ZstdError, match="could not load compression dictionary: Dictionary mismatch"):
+        with pytest.raises(zstd.ZstdError, match="cannot compress: Allocation error : not enough memory"):
             zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_FULLDICT)).compress(raws[0])
+        with pytest.raises(zstd.ZstdError, match="error compressing item 0: Allocation error"):
+            zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_FULLDICT)).multi_compress_to_buffer(raws)
         with pytest.raises(zstd.ZstdError, match="could not create decompression dict"):
             zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_FULLDICT)).decompress(a)
-    with pytest.raises(zstd.ZstdError, match="Dictionary is corrupted"):                  # magic, then garbage, read as a full dictionary
+    with pytest.raises(RuntimeError, match="Allocation error"):                           # magic, then garbage, read as a full dictionary
+        ref.compress_advanced(raws[0], dict_data=fake, dict_type=0)
+    with pytest.raises(zstd.ZstdError, match="cannot compress: Allocation error"):
         zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(fake)).compress(raws[0])
 
 

@@ -182,6 +182,7 @@ static double run(const char* name, const void* fn, int wavesPerSimd, int nblock
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     printf("device %s, %d CUs, clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
     const int nb = p.multiProcessorCount;
