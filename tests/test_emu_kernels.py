@@ -243,10 +243,10 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     assert not any(st) and dec == big
 
 
-@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"]])
+@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"], ["-DZP_K2_LANES=36", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
-    """K2 / K1b with fewer frames per wave (several one-wave workgroups per CU share its LDS; the bit reader's ring stride follows):
-    the shapes csrc/build_variants.sh builds for A/B runs decode the same bytes"""
+    """K2 / K1b with fewer frames per wave (several one-wave workgroups per CU share its LDS; the bit reader's ring stride follows), K3 with a
+    smaller assembly buffer: the shapes csrc/build_variants.sh builds for A/B runs decode the same bytes"""
     import numpy as np
     from tests import emulib
     emu = emulib.Emu(emulib.build_variant(str(tmp_path / "libzhip_emu_shape.so"), defines))
