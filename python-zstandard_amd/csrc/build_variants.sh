@@ -15,7 +15,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 B="$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
 want() { [ $# -eq 0 ] && return 0; }
 build() { name=$1; shift; $B "$@" -o libzstd_hip_$name.so zhip_lib.hip; }
-ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3 asm2k co36 co40 co44 co48 pf"
+ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3 asm2k co36 co40 co44 co48 pf co40p co44p co48p basep"
 [ $# -gt 0 ] && ALL="$*"
 for v in $ALL; do
   case $v in
@@ -26,6 +26,10 @@ for v in $ALL; do
     huf4) build huf4 -DZP_HUF_FRAMES=4 & ;;
     longone) build longone -DZP_K3_LONGONE & ;;
     tab3) build tab3 -DZE_TAB3 & ;;
+    co40p) build co40p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=40 -DZP_K2_PRIO=3 & ;;
+    co44p) build co44p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=44 -DZP_K2_PRIO=3 & ;;
+    co48p) build co48p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=48 -DZP_K2_PRIO=3 & ;;
+    basep) build basep -DZP_K2_PRIO=3 & ;;
     pf) build pf -DZP_K3_PREFETCH & ;;
     asm2k) build asm2k -DZP_ASM_BYTES=2048 & ;;
     co36) build co36 -DZP_ASM_BYTES=2048 -DZP_K2_LANES=36 & ;;

@@ -495,6 +495,9 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
 ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
 {
     const uint32_t lane = zh_lane();
+#if defined(ZP_K2_PRIO) && !defined(ZHIP_EMU)
+    __builtin_amdgcn_s_setprio(ZP_K2_PRIO);      // the serial chain is the pipeline's critical path: its wave wins issue arbitration over co-resident K3 / K1b waves
+#endif
     if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
     if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
     zh_sync();

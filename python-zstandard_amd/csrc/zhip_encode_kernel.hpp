@@ -1317,6 +1317,102 @@ ZH_DEVFN uint32_t ze_dfast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, c
     return nseq;
 }
 
+// ------------------------------------------------------------------------------------------ fast search against an attached dictionary
+// ZSTD_compressBlock_fast_dictMatchState_generic (zstd.c:32197) for a frame of one block, in the index space of ze_dfast_dict (dictionary
+// content byte k is index 2 + k, the source starts at CE). The dictionary has ONE tagged table here (ZSTD_fillHashTableForCDict). One lane.
+ZH_DEVFN uint32_t ze_fast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                               const ZeCDict& cd, const uint8_t* content, const uint32_t* dHash, uint32_t* hashTable)
+{
+    const int hlog = cp.hlog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t stepSize = (uint32_t)cp.tlen + (cp.tlen == 0);
+    const uint32_t CE = 2 + cd.contentSize, DS = 2;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
+    const int dhb = cd.hlog + 8;
+    const uint32_t iend = CE + srcSize;
+    uint32_t ip0 = CE, ip1 = CE + stepSize, anchor = CE;
+    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_SRC(i) (src + ((i) - CE))
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
+    if (srcSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        while (ip1 <= ilimit) {
+            uint32_t mLength = 0;
+            uint32_t hash0 = ze_hash(ZE_SRC(ip0), hlog, mls);
+            const uint32_t dTag0 = ze_hash(ZE_SRC(ip0), dhb, mls);
+            uint32_t dEnt = dHash[dTag0 >> 8];
+            bool dictTagsMatch = (dEnt & 255) == (dTag0 & 255);
+            uint32_t matchIndex = hashTable[hash0];
+            uint32_t curr = ip0;
+            uint32_t step = stepSize;
+            uint32_t nextStep = ip0 + 256;                                 // kStepIncr = 1 << kSearchStrength
+            bool done = false;
+            for (;;) {
+                const uint32_t repIndex = curr + 1 - off1;
+                const uint32_t hash1 = ze_hash(ZE_SRC(ip1), hlog, mls);
+                const uint32_t dTag1 = ze_hash(ZE_SRC(ip1), dhb, mls);
+                hashTable[hash0] = curr;
+                if ((uint32_t)((CE - 1) - repIndex) >= 3 && ze_sp_rd32(sp, repIndex) == zh_ld32(ZE_SRC(ip0 + 1))) {
+                    mLength = ze_sp_count(sp, ip0 + 1 + 4, repIndex + 4) + 4;
+                    ip0++;
+                    ZE_STORE(ip0 - anchor, 1, mLength);
+                    break;
+                }
+                if (dictTagsMatch) {
+                    uint32_t m = dEnt >> 8;
+                    // "to replicate extDict parse behavior, we only use dict matches when the normal matchIndex is invalid"
+                    if (m > DS && ze_sp_rd32(sp, m) == zh_ld32(ZE_SRC(ip0)) && matchIndex <= CE) {
+                        const uint32_t offset = curr - m;
+                        mLength = ze_sp_count(sp, ip0 + 4, m + 4) + 4;
+                        while (ip0 > anchor && m > DS && ze_sp_byte(sp, ip0 - 1) == ze_sp_byte(sp, m - 1)) { ip0--; m--; mLength++; }
+                        off2 = off1; off1 = offset;
+                        ZE_STORE(ip0 - anchor, offset + 3, mLength);
+                        break;
+                    }
+                }
+                if (matchIndex >= CE && zh_ld32(ZE_SRC(matchIndex)) == zh_ld32(ZE_SRC(ip0))) {           // ZSTD_match4Found_cmov
+                    uint32_t m = matchIndex;
+                    const uint32_t offset = ip0 - m;
+                    mLength = ze_common_len(ZE_SRC(ip0 + 4), ZE_SRC(m + 4), ZE_SRC(iend)) + 4;
+                    while (ip0 > anchor && m > CE && ze_sp_byte(sp, ip0 - 1) == ze_sp_byte(sp, m - 1)) { ip0--; m--; mLength++; }
+                    off2 = off1; off1 = offset;
+                    ZE_STORE(ip0 - anchor, offset + 3, mLength);
+                    break;
+                }
+                dEnt = dHash[dTag1 >> 8]; dictTagsMatch = (dEnt & 255) == (dTag1 & 255);
+                matchIndex = hashTable[hash1];
+                if (ip1 >= nextStep) { step++; nextStep += 256; }
+                ip0 = ip1; ip1 = ip1 + step;
+                if (ip1 > ilimit) { done = true; break; }
+                curr = ip0; hash0 = hash1;
+            }
+            if (done) break;
+            ip0 += mLength; anchor = ip0;
+            if (ip0 <= ilimit) {
+                hashTable[ze_hash(ZE_SRC(curr + 2), hlog, mls)] = curr + 2;
+                hashTable[ze_hash(ZE_SRC(ip0 - 2), hlog, mls)] = ip0 - 2;
+                while (ip0 <= ilimit) {
+                    const uint32_t rep2 = ip0 - off2;
+                    if (!((uint32_t)((CE - 1) - rep2) >= 3 && ze_sp_rd32(sp, rep2) == zh_ld32(ZE_SRC(ip0)))) break;
+                    const uint32_t r = ze_sp_count(sp, ip0 + 4, rep2 + 4) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    ZE_STORE(0, 1, r);
+                    hashTable[ze_hash(ZE_SRC(ip0), hlog, mls)] = ip0;
+                    ip0 += r; anchor = ip0;
+                }
+            }
+            ip1 = ip0 + stepSize;
+        }
+    }
+#undef ZE_STORE
+    {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
+#undef ZE_SRC
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+
 // working parameters of a frame compressed against an attached dictionary: the dictionary's own row shrunk to the source
 // (ZSTD_resetCCtx_byAttachingCDict, zstd.c:25279); the window log stays the one chosen for the source.
 ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
@@ -1326,8 +1422,9 @@ ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
     if (w > srcLog) w = srcLog;
     if (h > w + 1) h = w + 1;
     if (c > w) c = w;
-    cp.hlog = h; cp.clog = c; cp.mml = cd.mml;
+    cp.hlog = h; cp.clog = c; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
 }
+ZH_DEV uint32_t ze_dict_attach_max(const ZeCDict& cd) { return cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX; }
 
 // ------------------------------------------------------------------------------------------ sequences section
 // ZSTD_selectEncodingType (zstd.c:21252), strategy below "lazy", first block: 0 basic, 1 rle, 2 compressed
@@ -1638,8 +1735,10 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (mb) { nrep[0] = mb->st->mrep[0]; nrep[1] = mb->st->mrep[1]; }
         const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
                                                 : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
-                          : (cd && cd->contentSize) ? ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
-                                               a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                          : (cd && cd->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
+                                                                                     a.cdictHashLong, hashLong)
+                                                                    : ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
+                                                                                      a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall))
                                : cp.strat == 1 ? ze_fast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong)
                                : ze_dfast((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, hashLong, hashSmall);
         L.misc[1] = ns; L.misc[2] = ls; L.misc[5] = nrep[0]; L.misc[6] = nrep[1];
@@ -1922,15 +2021,14 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     ZePar cp;
     const int e = ze_get_cparams(cp, a.rows, srcSize);
     if (e) return e;
-    if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
-    if (cp.strat == 1 && a.cdict) return ZE_PARAM_UNSUPPORTED;           // dictionary search is implemented for double-fast only
     uint32_t dictID = 0;
     if (a.cdict) {
         if (a.cdict->status) return a.cdict->status;
-        if (srcSize > ZE_DICT_ATTACH_MAX) return ZE_PARAM_UNSUPPORTED;    // the reference's table-copy mode is not implemented
+        if (srcSize > ze_dict_attach_max(*a.cdict)) return ZE_PARAM_UNSUPPORTED;    // the reference's table-copy mode is not implemented
         ze_dict_cparams(cp, *a.cdict, srcSize);
         if (a.dictIDFlag) dictID = a.cdict->dictID;
     }
+    if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
     const uint32_t dictCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     uint32_t pos = 0;
     const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
@@ -2025,8 +2123,8 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     if (zh_opaque(lane) == 0) {
         ZePar p; p.wlog = p.clog = p.hlog = p.mml = p.strat = p.tlen = 0;
         int st = ze_cdict_params(p, rows, dictSize);
-        if (!st && (p.strat != 2 || p.hlog > ZE_CDICT_MAX_HLOG || p.clog > ZE_CDICT_MAX_HLOG || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
-        cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml;
+        if (!st && ((p.strat != 2 && p.strat != 1) || p.hlog > ZE_CDICT_MAX_HLOG || (p.strat == 2 && p.clog > ZE_CDICT_MAX_HLOG) || cs > ZE_CDICT_MAX_CONTENT)) st = ZE_PARAM_UNSUPPORTED;
+        cd->hlog = p.hlog; cd->clog = p.clog; cd->mml = p.mml; cd->strat = p.strat; cd->tlen = p.tlen;
         cd->contentSize = dictSize < 8 ? 0u : cs; cd->dictID = hasEntropy ? de->dictID : 0u;
         cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
         cd->hufRepeat = cd->llRepeat = cd->ofRepeat = cd->mlRepeat = 0; cd->hufMaxSym = 0;
@@ -2061,16 +2159,17 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
             }
         }
         cd->status = st;
-        L.misc[0] = (uint32_t)st; L.misc[1] = (uint32_t)p.hlog; L.misc[2] = (uint32_t)p.clog; L.misc[3] = (uint32_t)p.mml;
+        L.misc[0] = (uint32_t)st; L.misc[1] = (uint32_t)p.hlog; L.misc[2] = (uint32_t)p.clog; L.misc[3] = (uint32_t)p.mml; L.misc[4] = (uint32_t)p.strat;
     }
     ze_fence();
     zh_sync();
     const uint32_t st = zh_first(L.misc[0]);
     const int hlog = (int)zh_first(L.misc[1]), clog = (int)zh_first(L.misc[2]), mml = (int)zh_first(L.misc[3]);
+    const bool fast = zh_first(L.misc[4]) == 1;          // ZSTD_fillHashTableForCDict (zstd.c:31730): ONE table, hashed on minMatch bytes, same fill rule as the long table
     zh_sync();
     if (st) return;
     for (uint32_t i = lane; i < (1u << hlog); i += 64) { hashLong[i] = 0; tmpLong[i] = 0; }
-    for (uint32_t i = lane; i < (1u << clog); i += 64) hashSmall[i] = 0;
+    if (!fast) for (uint32_t i = lane; i < (1u << clog); i += 64) hashSmall[i] = 0;
     ze_fence();
     zh_sync();
     // only the tail the tables can reasonably address is indexed (ZSTD_loadDictionaryContent, zstd.c:27895)
@@ -2083,8 +2182,8 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
         const uint32_t nGroups = (cs - 10 - startOff) / 3 + 1;        // group g covers positions startOff + 3g + {0,1,2}
         for (uint32_t g = lane; g < nGroups; g += 64) {
             const uint32_t pos = startOff + 3 * g, curr = pos + 2;
-            const uint32_t sm = ze_hash(content + pos, clog + 8, mls), lg = ze_hash(content + pos, hlog + 8, 8);
-            zh_atomic_max(&hashSmall[sm >> 8], (curr << 8) | (sm & 255));
+            const uint32_t lg = ze_hash(content + pos, hlog + 8, fast ? mls : 8);
+            if (!fast) { const uint32_t sm = ze_hash(content + pos, clog + 8, mls); zh_atomic_max(&hashSmall[sm >> 8], (curr << 8) | (sm & 255)); }
             zh_atomic_max(&hashLong[lg >> 8], (curr << 8) | (lg & 255));
         }
         ze_fence();
@@ -2092,7 +2191,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
         for (uint32_t g = lane; g < nGroups; g += 64) {
             for (uint32_t i = 1; i < 3; i++) {
                 const uint32_t pos = startOff + 3 * g + i, curr = pos + 2;
-                const uint32_t lg = ze_hash(content + pos, hlog + 8, 8);
+                const uint32_t lg = ze_hash(content + pos, hlog + 8, fast ? mls : 8);
                 if (hashLong[lg >> 8] == 0) zh_atomic_max(&tmpLong[lg >> 8], ((0xFFFFFFu - curr) << 8) | (lg & 255));
             }
         }
@@ -2150,13 +2249,14 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
             a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
             continue;
         }
-        if (ze_get_cparams(cp, a.rows, (uint32_t)srcSize64) || (cp.strat != 2 && cp.strat != 1) || (cp.strat == 1 && a.cdict) ||
-            (size_t)(4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         const uint32_t srcSize = (uint32_t)srcSize64;
-        if (a.cdict) {
-            if (a.cdict->status || srcSize > ZE_DICT_ATTACH_MAX) { m.mode = 2; a.meta[i] = m; continue; }
-            ze_dict_cparams(cp, *a.cdict, srcSize);
+        bool bad = ze_get_cparams(cp, a.rows, srcSize) != 0;
+        if (!bad && a.cdict) {
+            if (a.cdict->status || srcSize > ze_dict_attach_max(*a.cdict)) bad = true;
+            else ze_dict_cparams(cp, *a.cdict, srcSize);
         }
+        if (bad || (cp.strat != 2 && cp.strat != 1) ||
+            (size_t)(4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u) > a.tableStride) { m.mode = 2; a.meta[i] = m; continue; }   // E2 reports the error
         if (srcSize < 7) { m.mode = 1; a.meta[i] = m; continue; }
         uint32_t* hashLong = (uint32_t*)tables;
         uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
@@ -2165,8 +2265,10 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         uint32_t litSize = 0;
         // a dictionary without content (shorter than 8 bytes: nothing of it is loaded, zstd.c:28167) is not attached
         // (ZSTD_resetCCtx_byAttachingCDict, "don't even attach dictionaries with no contents"): the plain search, with the dictionary's row
-        m.nbSeq = (a.cdict && a.cdict->contentSize) ? ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
-                                          a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+        m.nbSeq = (a.cdict && a.cdict->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+                                                                                   a.cdictHashLong, hashLong)
+                                                                      : ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+                                                                                      a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall))
                           : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong)
                           : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
         m.litSize = litSize;

@@ -140,11 +140,14 @@ struct ZeCTab {
 // zhip_build_cdict_kernel. Sources above ZE_DICT_ATTACH_MAX would use the reference's "copy" mode (tables copied, dictionary
 // as an external segment); this backend implements the attached mode only and reports larger sources as unsupported.
 #define ZE_DICT_ATTACH_MAX (16u * 1024)
+#define ZE_DICT_ATTACH_MAX_FAST (8u * 1024)                  // attachDictSizeCutoffs (zstd.c:25250): 8 KB for ZSTD_fast, 16 KB for ZSTD_dfast
 #define ZE_CDICT_MAX_HLOG 18
 #define ZE_CDICT_MAX_CONTENT ((1u << 24) - ZE_DICT_ATTACH_MAX - 16)   // tagged cells keep 24 bits of index
 struct ZeCDict {
     int32_t  status;            // 0 or a zstd error code
     int32_t  hlog, clog, mml;   // parameters the tagged tables were filled with
+    int32_t  strat, tlen;       // the dictionary's own strategy (1 fast: one tagged table; 2 double-fast: two) and target length: frames compressed
+                                // with an attached dictionary take ALL their parameters but the window from it (ZSTD_resetCCtx_byAttachingCDict)
     uint32_t contentSize, dictID;
     uint32_t rep[3];
     uint32_t hufRepeat, llRepeat, ofRepeat, mlRepeat;    // 0 none, 1 check, 2 valid (HUF_repeat / FSE_repeat)

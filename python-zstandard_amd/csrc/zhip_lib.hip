@@ -236,7 +236,7 @@ struct zhip_ctx {
     DevBuf scratch, counter;
     // dictionary (compress side): raw bytes, parsed entropy section, digested form and its tagged tables
     DevBuf cdictBlob, cdictEntropy, cdictDigest, cdictTables;
-    bool hasCDict = false; uint32_t cdictContentOffset = 0;
+    bool hasCDict = false; uint32_t cdictContentOffset = 0, cdictAttachMax = ZE_DICT_ATTACH_MAX;
     uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy;
@@ -450,9 +450,10 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         HIP_TRY(hipGetLastError());
         ZeCDict cd;
         HIP_TRY(hipMemcpy(&cd, c->cdictDigest.p, sizeof cd, hipMemcpyDeviceToHost));
-        if (cd.status == ZE_PARAM_UNSUPPORTED) { g_lastError = "dictionary / level combination outside the double-fast attached-dictionary path of the HIP backend"; return ZHIP_ERR_UNSUPPORTED; }
+        if (cd.status == ZE_PARAM_UNSUPPORTED) { g_lastError = "dictionary / level combination outside the fast / double-fast attached-dictionary paths of the HIP backend"; return ZHIP_ERR_UNSUPPORTED; }
         if (cd.status) return cd.status == ZE_DICT_CORRUPTED || cd.status == ZE_DICT_WRONG ? -ZE_MEMORY : -cd.status;
         c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
+        c->cdictAttachMax = cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX;
     }
     c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows;
     return 0;
@@ -1153,8 +1154,8 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
             g_lastError = "inputs of 2 GiB and more are not implemented in the HIP backend";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
-        if (withDict && items[i].srcSize > ZE_DICT_ATTACH_MAX) {
-            g_lastError = "dictionary compression of inputs larger than 16 KiB (libzstd's table-copy mode) is not implemented in the HIP backend yet";
+        if (withDict && items[i].srcSize > c->cdictAttachMax) {
+            g_lastError = "dictionary compression of inputs above libzstd's attach cutoff (16 KiB double-fast, 8 KiB fast: its table-copy mode) is not implemented in the HIP backend yet";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;

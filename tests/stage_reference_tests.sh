@@ -16,7 +16,10 @@ globals().update({k: getattr(_z, k) for k in dir(_z) if not k.startswith("_")})
 
 def train_dictionary(dict_size, samples, **kw):
     """dictionary TRAINING is outside the hot path (SURVEY 8): the shim borrows it from the reference build (test infrastructure)"""
-    from tests import reflib
+    import importlib.util
+    root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+    spec = importlib.util.spec_from_file_location("_graft_reflib", os.path.join(root, "tests", "reflib.py"))     # `tests` here is the staged copy
+    reflib = importlib.util.module_from_spec(spec); spec.loader.exec_module(reflib)
     return _z.ZstdCompressionDict(reflib.RefZstd().train_dictionary(dict_size, list(samples)))
 PY
 for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py \

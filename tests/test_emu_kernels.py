@@ -1,5 +1,7 @@
 """Kernel LOGIC on the host: the product kernel sources compiled for the wave emulator (tests/emu) against the oracle.
 Small inputs only -- the emulator runs each of the 64 lanes as a fiber. The real parity tests are the -m gpu ones."""
+import os
+
 import pytest
 
 
@@ -286,3 +288,25 @@ def test_explicit_parameters_and_magicless_bit_exact(emu, ref, corpus):
         assert st == [0] * len(raws) and back == raws
     finally:
         emu.set_cparams()
+
+
+def test_fast_strategy_dictionary_bit_exact(emu, ref, corpus):
+    """levels whose row is ZSTD_fast with an attached dictionary (ZSTD_compressBlock_fast_dictMatchState_generic, zstd.c:32197; the
+    dictionary's single tagged table from ZSTD_fillHashTableForCDict): trained, raw-content and repetitive dictionaries, sources up to
+    the 8 KiB attach cutoff of that strategy; larger sources are refused per frame, never encoded differently"""
+    import numpy as np
+    rng = np.random.default_rng(8)
+    samples = []
+    for i in range(128):
+        samples += [b"foo" * 64, b"bar" * 64, b"foobar" * 64]
+    dicts = [ref.train_dictionary(8192, samples), corpus.frame_bytes(600)[:6000],
+             open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict_json4k.bin"), "rb").read()]
+    raws = [corpus.frame_bytes(i)[: int(rng.integers(40, 8193))] for i in range(24)] + [b"foo bar foobar foo bar foobar", b"", b"x", b"abcdefgh", b"foobar" * 900]
+    for dd in dicts:
+        for level in (1, -3):
+            want = [ref.compress(r, level=level, dict_data=dd) for r in raws]
+            for pipe in (True, False):
+                outs, st = emu.compress_batch(raws, level=level, flags=5, pipeline=pipe, dict_data=dd)
+                assert not any(st) and outs == want, (level, pipe)
+    outs, st = emu.compress_batch([corpus.frame_bytes(3)[:8193], corpus.frame_bytes(3)[:8192]], level=1, flags=5, pipeline=True, dict_data=dicts[0])
+    assert st[0] == 40 and st[1] == 0                                               # above the cutoff: parameter_unsupported, loud

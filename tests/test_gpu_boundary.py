@@ -174,3 +174,26 @@ def test_dictionary_batch_config4_shape(zstd):
     assert len(back) == n and back.size() == n * 4096
     for i in range(n):
         assert back[i].tobytes() == items[i], "document %d does not round-trip" % i
+
+
+def test_fast_strategy_with_dictionary(zstd, ref, corpus):
+    """ZstdCompressor(level=1, dict_data=...) -- what six of the reference's own hot-path tests do (test_compress_dict_multiple,
+    test_dict_precompute, test_no_dict_id, test_dictionary*, test_dict): the fast strategy's dictionary search
+    (ZSTD_compressBlock_fast_dictMatchState_generic, zstd.c:32197), frames equal to the reference build's, round trip with the dictionary"""
+    samples = []
+    for i in range(128):
+        samples += [b"foo" * 64, b"bar" * 64, b"foobar" * 64]
+    trained = ref.train_dictionary(8192, samples)
+    raws = [corpus.frame_bytes(700 + i)[: 300 + 257 * i] for i in range(30)] + [b"foo bar foobar foo bar foobar", b"foobar" * 1000, b"x"]
+    for blob in (trained, corpus.frame_bytes(600)[:6000]):
+        zd = zstd.ZstdCompressionDict(blob)
+        for level in (1, 2, -5):
+            got = zstd.ZstdCompressor(level=level, dict_data=zd).multi_compress_to_buffer(raws)
+            for i, r in enumerate(raws):
+                assert got[i].tobytes() == ref.compress(r, level=level, dict_data=blob), (level, i)
+            back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
+            assert [back[i].tobytes() for i in range(len(raws))] == raws
+        assert zstd.ZstdCompressor(level=1, dict_data=zd).compress(raws[3]) == ref.compress(raws[3], level=1, dict_data=blob)
+    # the fast strategy attaches dictionaries up to 8 KiB of source (attachDictSizeCutoffs, zstd.c:25250); above: loud, not different bytes
+    with pytest.raises(zstd.ZstdError):
+        zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(corpus.frame_bytes(5)[:9000])

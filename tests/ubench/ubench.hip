@@ -192,8 +192,7 @@ int main()
     const int ws[] = {1, 2, 3, 4};      // 256 * W threads per workgroup: 1024 is the limit
     for (int w : ws) run("valu_dep", (const void*)valu_dep, w, nb, 0, d_out, a1, (double)REP * ITER);
     for (int w : ws) run("valu_ind", (const void*)valu_ind, w, nb, 0, d_out, a1, (double)REP * ITER);
-    for (int w : ws) run("mix_vs", (const void*)mix_vs, w, nb, 0, d_out, a1, (double)REP * ITER);
-    for (int w : ws) run("dpp_chain", (const void*)dpp_chain, w, nb, 0, d_out, a1, (double)REP * ITER);
+    run("dpp_chain", (const void*)dpp_chain, 1, nb, 0, d_out, a1, (double)REP * ITER);
     CHECK(hipFuncSetAttribute((const void*)lds_chase, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CHECK(hipFuncSetAttribute((const void*)lds_u16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (uint32_t mode = 0; mode < 2; mode++) {
