@@ -10,6 +10,10 @@ Workloads (BASELINE.json configs):
   --config dict (configs[3]): 262 144 x 4 KiB JSON-like documents with a shared trained dictionary (tests/golden/dict_json4k.bin,
       made by train_dictionary's own call in tests/golden/make_dict_json4k.py): value = compress GB/s, every frame compared with
       libzstd's; the line's "decompress" object is the opposite direction on those frames.
+  --config roundtrip (configs[4]): 1 048 576 / 8 = 131 072 x 128 KiB mixed-entropy buffers per GPU generated in HBM, compressed and
+      decompressed on the GPU (a step = both directions), the round trip compared in HBM, a sample of the frames compared with libzstd's;
+      with N > 1 ranks the compressed payload is then all-gathered over RCCL (sharded.allgatherv_payload), timed on its own.
+The 128 KiB corpus is the "silesia" class mix of tests/corpus.py (level-3 ratio ~3.1); --mix default is round 1's mix (2.55).
 roofline = (compressed + uncompressed bytes) / time vs the HBM peak, for the dominant kernel (HIP events on its launch stream) and
 end to end. cpu_baseline = the reference libzstd 1.5.7 (oracle/_ref) on host threads over a bounded sample of the same workload.
 
@@ -271,6 +275,75 @@ def bench_dict(args, rank, world, dev):
     ctx.close()
 
 
+def bench_roundtrip(args, rank, world, dev):
+    """BASELINE.json configs[4]: every rank generates its shard of the 1 048 576 x 128 KiB corpus in HBM, compresses it, decompresses
+    the frames again and compares in HBM; a sample of frames is compared with libzstd's; N > 1: the compressed payload all-gathered."""
+    from zstandard_amd.device import DeviceBatchContext
+    from zstandard_amd import sharded
+    from tests.corpus import Corpus
+    F = args.frames if args.frames != 65536 else 131072            # BASELINE config: 1 048 576 / 8 per GPU
+    raw = Corpus(device=dev, mix=args.mix).frames(rank * F, F, chunk=256)
+    torch.cuda.synchronize()
+    job = Job(world, dev)
+    bound = (FRAME + (FRAME >> 8) + 64 + 15) & ~15
+    src_segs = segs(np.arange(F, dtype=np.int64) * FRAME, np.full(F, FRAME, dtype=np.int64), dev)
+    slot_segs = segs(np.arange(F, dtype=np.int64) * bound, np.full(F, bound, dtype=np.int64), dev)
+    slots = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
+    csz = torch.zeros(F, dtype=torch.int64, device=dev)
+    st = torch.zeros(F, dtype=torch.int32, device=dev)
+    back = torch.zeros(F * FRAME, dtype=torch.uint8, device=dev)
+    bsz = torch.zeros(F, dtype=torch.int64, device=dev)
+    st2 = torch.zeros(F, dtype=torch.int32, device=dev)
+    cctx, dctx = DeviceBatchContext(), DeviceBatchContext()
+    src = raw.reshape(-1)
+    c_el, c_k = job.timed(lambda: cctx.compress(src, src_segs, slots, slot_segs, csz, st), cctx, ENC_KERNELS, args.steps, args.warmup)
+    assert int(st.abs().max().item()) == 0, "a frame failed to compress"
+    frame_segs = torch.stack([slot_segs[:, 0], csz], dim=1).contiguous()                  # the frames where they lie, inside their slots
+    d_el, d_k = job.timed(lambda: dctx.decompress(slots, frame_segs, back, src_segs, bsz, st2), dctx, DEC_KERNELS, args.steps, args.warmup)
+    assert int(st2.abs().max().item()) == 0 and bool((bsz == FRAME).all().item()), "a frame failed to decode"
+    assert torch.equal(back.view(F, FRAME), raw), "round-trip mismatch"
+    ctotal = int(csz.sum().item())
+    ns = min(F, 2048)                                              # sampled verification against libzstd (every 1 / (F / ns)-th frame)
+    idx = np.linspace(0, F - 1, ns).astype(np.int64)
+    sample_raw = raw[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    want, _ = compress_on_host(sample_raw, FRAME)
+    got_sz = csz.cpu().numpy()
+    slots_v = slots.view(F, bound)
+    for j, i in enumerate(idx):
+        assert bytes(slots_v[int(i), : int(got_sz[i])].cpu().numpy()) == want[j], "frame %d differs from libzstd 1.5.7" % i
+    gather_ms = None
+    if world > 1:                                                  # reassemble the compressed output on every rank (north_star's all-gatherv)
+        import torch.distributed as dist
+        dense, dsegs = sharded._compact(slots, slot_segs, csz, dev)
+        sizes = sharded._exchange_sizes(csz, None)
+        bounds = [(r * F, (r + 1) * F) for r in range(world)]
+        res = sharded.ShardResult(rank, bounds, dense, dsegs, sizes, st)
+        job.barrier()
+        t0 = time.perf_counter()
+        sharded.allgatherv_payload(res)
+        job.barrier()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        assert int(res.full_arena.numel()) == int(sizes.sum())
+    step_s = (c_el + d_el) / args.steps
+    line = {"metric": "GB/s uncompressed throughput, compress + decompress round trip of 128 KiB buffers at level 3 (each step: both directions)",
+            "value": round(world * F * FRAME / step_s / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "round trip on the GPU: %d x 128 KiB mixed-entropy buffers per GPU generated in HBM, multi_compress_to_buffer then "
+                                   "multi_decompress_to_buffer (device-resident), level 3" % F, "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3,
+                       "compression_ratio": round(F * FRAME / ctotal, 3), "corpus_mix": args.mix,
+                       "verification": "round trip compared in HBM for every frame; %d evenly spaced frames compared byte for byte with libzstd 1.5.7" % ns,
+                       "parallelism": "frames sharded by rank; payload all-gatherv over RCCL after the timed steps" if world > 1 else "single GPU"}}
+    if rank == 0:
+        line["compress"] = {"value": round(world * F * FRAME * args.steps / c_el / 1e9, 3), "ms_per_step": round(c_el / args.steps * 1e3, 3), "kernels": kernels_obj(cctx, c_k)}
+        line["decompress"] = {"value": round(world * F * FRAME * args.steps / d_el / 1e9, 3), "ms_per_step": round(d_el / args.steps * 1e3, 3), "kernels": kernels_obj(dctx, d_k)}
+        allk = dict(c_k)
+        line["roofline"], _ = roofline(cctx, allk, args.steps, 2 * (F * FRAME + ctotal), step_s * 1e3, F)
+        if gather_ms is not None:
+            line["allgatherv"] = {"ms": round(gather_ms, 3), "bytes_per_rank": int(ctotal), "GBps_per_rank_received": round((world - 1) * ctotal / gather_ms / 1e6, 2)}
+        print(json.dumps(line))
+    cctx.close(); dctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,8 +354,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compress-frames", type=int, default=65536,
                     help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
-    ap.add_argument("--config", choices=["decompress", "compress", "dict"], default=None,
-                    help="decompress (default) is the BASELINE.json headline; compress / dict are configs[2] / configs[3] as their own lines")
+    ap.add_argument("--config", choices=["decompress", "compress", "dict", "roundtrip"], default=None,
+                    help="decompress (default) is the BASELINE.json headline; compress / dict / roundtrip are configs[2] / [3] / [4] as their own lines")
+    ap.add_argument("--mix", choices=["silesia", "default"], default="silesia", help="class mix of the 128 KiB corpus (tests/corpus.py)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
     args = ap.parse_args()
     config = args.config or args.direction or "decompress"
@@ -301,6 +375,8 @@ def main():
     try:
         if config == "dict":
             bench_dict(args, rank, world, dev)
+        elif config == "roundtrip":
+            bench_roundtrip(args, rank, world, dev)
         else:
             bench_frames(args, config, rank, world, dev)
     finally:
@@ -315,7 +391,7 @@ def bench_frames(args, config, rank, world, dev):
 
     F = args.frames
     t0 = time.time()
-    corpus = Corpus(device=dev)
+    corpus = Corpus(device=dev, mix=args.mix)
     raw = corpus.frames(rank * F, F, chunk=256)                      # [F, FRAME] uint8 in HBM (this rank's shard)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
@@ -327,7 +403,7 @@ def bench_frames(args, config, rank, world, dev):
     ctotal = int(csizes.sum())
     job = Job(world, dev)
     ctx = DeviceBatchContext()
-    cfg = {"frames_per_gpu": F, "frame_bytes": FRAME, "level": 3, "compression_ratio": round(F * FRAME / ctotal, 3),
+    cfg = {"frames_per_gpu": F, "frame_bytes": FRAME, "level": 3, "compression_ratio": round(F * FRAME / ctotal, 3), "corpus_mix": args.mix,
            "parallelism": "frames sharded by rank, no data-path collective"}
     nsample = min(F, 16384)
 

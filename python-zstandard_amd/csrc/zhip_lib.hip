@@ -248,6 +248,15 @@ struct zhip_ctx {
     void* pinned = nullptr; size_t pinnedCap = 0;
     bool hpReady = false; hipStream_t hpH2D = nullptr, hpCompute = nullptr, hpD2H = nullptr;     // host pipeline: copy-in, kernels, copy-out
     void* hpStage[2] = {nullptr, nullptr}; size_t hpStageCap[2] = {0, 0}; hipEvent_t hpStageFree[2] = {nullptr, nullptr}; int hpNextSlot = 0;
+    // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
+    struct Knobs {
+        bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0;
+    } knob;
+    bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
+    unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
+    unsigned long long* profPipe = nullptr;
+    unsigned long long* profEncode = nullptr;
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
 };
 
@@ -258,6 +267,16 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { g_lastError = "hipGetDeviceProperties failed"; delete c; return nullptr; }
     c->numCU = prop.multiProcessorCount;
+    {   zhip_ctx::Knobs& k = c->knob;
+        k.noPipeline = getenv("ZHIP_NO_PIPELINE") != nullptr; k.prof = getenv("ZHIP_PROF") != nullptr; k.debug = getenv("ZHIP_DEBUG") != nullptr;
+        k.debugPipe = getenv("ZHIP_DEBUG_PIPE") != nullptr; k.watchdog = getenv("ZHIP_WATCHDOG") != nullptr; k.noFlat = getenv("ZHIP_NO_FLAT") != nullptr;
+        if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) k.dchunk = (size_t)v; }
+        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) k.nslot = (int)v; }
+        if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
+        if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
+        if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
+        if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
+    }
     zh_resolve_rows(&c->rows, 3, nullptr);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zhip_decode_frames_kernel, 64, 0) != hipSuccess || nb < 1) nb = 8;
@@ -307,6 +326,9 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->profDecode) (void)hipFree(c->profDecode);
+    if (c->profPipe) (void)hipFree(c->profPipe);
+    if (c->profEncode) (void)hipFree(c->profEncode);
     for (int i = 0; i < 2; i++) { if (c->hpStage[i]) (void)hipHostFree(c->hpStage[i]); if (c->hpStageFree[i]) (void)hipEventDestroy(c->hpStageFree[i]); }
     if (c->hpH2D) (void)hipStreamDestroy(c->hpH2D);
     if (c->hpCompute) (void)hipStreamDestroy(c->hpCompute);
@@ -323,6 +345,7 @@ extern "C" const char* zhip_kernel_name(int k)
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
 {
     if (!c || direction < 0 || direction >= ZHIP_NTIMER) return ZHIP_ERR_UNSUPPORTED;
+    c->timing = true;                           // from now on the launches of this context are bracketed by events
     HIP_TRY(hipDeviceSynchronize());
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     KTimer& t = c->timer[direction];
@@ -474,16 +497,14 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->counter.reserve(64)) return g_reserveRc;
     HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
     const uint32_t* d_fallbackList = nullptr; const uint32_t* d_fallbackCount = nullptr;
-    const bool usePipeline = c->dictSize == 0 && getenv("ZHIP_NO_PIPELINE") == nullptr;
+    const bool usePipeline = c->dictSize == 0 && !c->knob.noPipeline;
     if (usePipeline) {
         // phase-split fast path for single-block, dictionary-less frames (zhip_decode_pipeline.hpp); everything it declines
         // lands in the fallback list consumed by the generic kernel below.
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        size_t chunkMax = ZHIP_DCHUNK; int slotMax = 2;      // measured best on MI355X (profiles/README.md, r01c): 32768 frames x 2 slots
-        if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) chunkMax = (size_t)v; }    // tuning knobs
-        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) slotMax = (int)v; }
+        const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured best on MI355X (profiles/README.md, r01c / r02f): 32768 frames x 2 slots
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
@@ -501,11 +522,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
         pa.outSizes = d_outSizes; pa.status = d_status; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
         pa.maxWindowSize = c->maxWindowSize; pa.magicless = c->dformat == ZHIP_FORMAT_ZSTD1_MAGICLESS;
-        static unsigned long long* d_pprof = nullptr;
-        if (getenv("ZHIP_PROF")) {
-            if (!d_pprof) HIP_TRY(hipMalloc((void**)&d_pprof, 32 * 8));
-            HIP_TRY(hipMemsetAsync(d_pprof, 0, 32 * 8, stream));
-            pa.prof = d_pprof;
+        if (c->knob.prof) {
+            if (!c->profPipe) HIP_TRY(hipMalloc((void**)&c->profPipe, 32 * 8));
+            HIP_TRY(hipMemsetAsync(c->profPipe, 0, 32 * 8, stream));
+            pa.prof = c->profPipe;
         }
         uint32_t* counters = (uint32_t*)c->pipeCounters.p;        // [0] = fallback length, then 8 words per slot
         pa.fallbackCount = counters;
@@ -525,35 +545,39 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.counters = counters + 8 + 8 * sidx;
             if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 32, ss));
             size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
-            if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g3m = (size_t)c->numCU * (size_t)v; }   // tuning knobs
-            if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) g1m = (size_t)c->numCU * (size_t)v; }
+            if (c->knob.k3PerCU) g3m = (size_t)c->numCU * (size_t)c->knob.k3PerCU;
+            if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
             // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 60 lanes -> 1, 15 -> 4, 7 -> 8)
             const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqLDS));
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
-            hipEvent_t ev[4], evh, evh2;
-            for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));
-            HIP_TRY(hipEventCreate(&evh)); HIP_TRY(hipEventCreate(&evh2));
-            HIP_TRY(hipEventRecord(ev[0], ss));
+            const bool tm = c->timing;
+            hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, evh = nullptr, evh2 = nullptr;
+            if (tm) {
+                for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));
+                HIP_TRY(hipEventCreate(&evh)); HIP_TRY(hipEventCreate(&evh2));
+                HIP_TRY(hipEventRecord(ev[0], ss));
+            }
             hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
             hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2), dim3(64), 0, ss, pa);      // tiny; timed with K1
-            HIP_TRY(hipEventRecord(evh, ss));
-            HIP_TRY(hipEventRecord(evh2, ss));
+            if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
-            HIP_TRY(hipEventRecord(ev[1], ss));
+            if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
             hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            HIP_TRY(hipEventRecord(ev[2], ss));
+            if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
             hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
-            HIP_TRY(hipEventRecord(ev[3], ss));
+            if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
-            // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
-            // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
-            // before any destroy.
-            c->timer[2].pending.emplace_back(ev[0], evh);          // K1 (+ the two bin waves)
-            c->timer[7].pending.emplace_back(evh2, ev[1]);         // K1b
-            c->timer[3].shared.emplace_back(ev[1], ev[2]);
-            c->timer[4].pending.emplace_back(ev[2], ev[3]);
+            if (tm) {
+                // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
+                // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
+                // before any destroy.
+                c->timer[2].pending.emplace_back(ev[0], evh);          // K1 (+ the two bin waves)
+                c->timer[7].pending.emplace_back(evh2, ev[1]);         // K1b
+                c->timer[3].shared.emplace_back(ev[1], ev[2]);
+                c->timer[4].pending.emplace_back(ev[2], ev[3]);
+            }
         }
         if (pa.prof) {
             HIP_TRY(hipDeviceSynchronize());
@@ -566,7 +590,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 for (int q = 0; q < 10; q++) if (h[16 * k + q]) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[16 * k + q] / (tot ? tot : 1), (double)h[16 * k + q] / (double)n);
             }
         }
-        if (getenv("ZHIP_DEBUG_PIPE")) {          // bring-up aid: per-frame records of the first chunk, after the pipeline drained
+        if (c->knob.debugPipe) {          // bring-up aid: per-frame records of the first chunk, after the pipeline drained
             HIP_TRY(hipDeviceSynchronize());
             const size_t cnt = n < chunk ? n : chunk;
             std::vector<ZdMeta> hm(cnt); std::vector<uint32_t> ord(cnt); uint32_t hc[16];
@@ -610,14 +634,11 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         a.dictContentSize = c->dictSize - c->dictContentOffset;
         a.dictEntropy = c->dictHasEntropy ? (const ZhipDictEntropy*)c->dictEntropy.p : nullptr;
     }
-    const bool debug = getenv("ZHIP_DEBUG") != nullptr;
-    const bool watchdog = getenv("ZHIP_WATCHDOG") != nullptr;
-    const bool prof = getenv("ZHIP_PROF") != nullptr;
-    static unsigned long long* d_prof = nullptr;
+    const bool debug = c->knob.debug, watchdog = c->knob.watchdog, prof = c->knob.prof;
     if (prof) {
-        if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, ZP_N * 8));
-        HIP_TRY(hipMemsetAsync(d_prof, 0, ZP_N * 8, stream));
-        a.prof = d_prof;
+        if (!c->profDecode) HIP_TRY(hipMalloc((void**)&c->profDecode, ZP_N * 8));
+        HIP_TRY(hipMemsetAsync(c->profDecode, 0, ZP_N * 8, stream));
+        a.prof = c->profDecode;
     }
     uint32_t* dbg = nullptr;
     if (debug) {
@@ -626,12 +647,11 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         a.dbg = dbg;
         fprintf(stderr, "[zhip] launch decode grid=%u n=%u scratch=%p counter=%p\n", grid, a.n, (void*)a.scratch, (void*)a.counter);
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     hipLaunchKernelGGL(zhip_decode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, stream));
+    if (c->timing) HIP_TRY(hipEventRecord(e1, stream));
     if (watchdog && !debug) {
         for (int it = 0; it < 5000; it++) {                  // 1 ms polls: the aid must not quantise what a caller times
             if (hipStreamQuery(stream) == hipSuccess) break;
@@ -648,10 +668,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (it == 11) { fprintf(stderr, "[zhip] kernel did not finish in 5 s; aborting process\n"); abort(); }
         }
     }
-    c->timer[0].pending.emplace_back(e0, e1);
+    if (c->timing) c->timer[0].pending.emplace_back(e0, e1);
     if (prof) {
         unsigned long long h[ZP_N];
-        HIP_TRY(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h, c->profDecode, sizeof h, hipMemcpyDeviceToHost));
         static const char* names[ZP_N] = {"header/misc", "huf-table", "huf-decode", "seq-tables", "stage", "seq-decode(lane0)", "exec1(global->lds)", "exec2(lds rounds)", "flush", "raw/lastlit"};
         unsigned long long tot = 0; for (int i = 0; i < ZP_N; i++) tot += h[i];
         fprintf(stderr, "[zhip-prof] grid=%u (CUs %d x %d blocks) frames=%u wave-cycles total=%.3e (%.0f per frame)\n", grid, c->numCU, c->decBlocksPerCU, a.n, (double)tot, (double)tot / a.n);
@@ -686,7 +706,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         a.cdictHashLong = (const uint32_t*)c->cdictTables.p;
         a.cdictHashSmall = (const uint32_t*)c->cdictTables.p + cells;
     }
-    if (getenv("ZHIP_NO_PIPELINE") == nullptr) {
+    if (!c->knob.noPipeline) {
         // two kernels: E1 searches with one LANE per frame (frames in flight hide the probe latency), E2 entropy-codes with one
         // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
         // table bytes of the largest one-block source of the two size classes these kernels serve (<= 128 KiB, <= 16 KiB), after the
@@ -707,10 +727,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // double-fast without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
         // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
         // and dictionary batches use the lane-serial kernel for the whole chunk.
-        const bool flat = anyDfast && !c->hasCDict && getenv("ZHIP_NO_FLAT") == nullptr;
+        const bool flat = anyDfast && !c->hasCDict && !c->knob.noFlat;
         size_t chunkMax = flat ? 65536 : 32768;
         if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
-        if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64 && (size_t)v < chunkMax) chunkMax = (size_t)v; }
+        if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         const size_t chunk = n < chunkMax ? n : chunkMax;
         size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * ZE_E1_LANES > 32768) g1max = 32768 / ZE_E1_LANES;
         if (flat && g1max > 256) g1max = 256;                                      // only the frames the flat kernel declines
@@ -729,36 +749,37 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         a.useE1List = flat ? 1u : 0u;
         a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)((uint8_t*)c->counter.p + 24);
         HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));
-        static unsigned long long* d_eprof = nullptr;
-        if (getenv("ZHIP_PROF")) {                                                  // tuning aid: per-phase cycle totals of the entropy kernel
-            if (!d_eprof) HIP_TRY(hipMalloc((void**)&d_eprof, 16 * 8));
-            HIP_TRY(hipMemsetAsync(d_eprof, 0, 16 * 8, stream));
-            a.prof = d_eprof;
+        if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
+            if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
+            HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
+            a.prof = c->profEncode;
         }
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
             HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 8, stream));
             HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 32, 0, 4, stream));
-            hipEvent_t ev[6];
-            for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
+            const bool tm = c->timing;
+            hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
                 HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
-                HIP_TRY(hipEventRecord(ev[0], stream));
+                if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
-                HIP_TRY(hipEventRecord(ev[1], stream));
+                if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
-            HIP_TRY(hipEventRecord(ev[2], stream));
+            if (tm) HIP_TRY(hipEventRecord(ev[2], stream));
             hipLaunchKernelGGL(zhip_encode_match_kernel, dim3(g1), dim3(64), 0, stream, a);
-            HIP_TRY(hipEventRecord(ev[3], stream));
-            HIP_TRY(hipEventRecord(ev[4], stream));
+            if (tm) { HIP_TRY(hipEventRecord(ev[3], stream)); HIP_TRY(hipEventRecord(ev[4], stream)); }
             hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
-            HIP_TRY(hipEventRecord(ev[5], stream));
+            if (tm) HIP_TRY(hipEventRecord(ev[5], stream));
             HIP_TRY(hipGetLastError());
-            if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
-            else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
-            c->timer[5].pending.emplace_back(ev[2], ev[3]);
-            c->timer[6].pending.emplace_back(ev[4], ev[5]);
+            if (tm) {
+                if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
+                else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
+                c->timer[5].pending.emplace_back(ev[2], ev[3]);
+                c->timer[6].pending.emplace_back(ev[4], ev[5]);
+            }
         }
         if (a.prof) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -778,7 +799,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
             HIP_TRY(hipGetLastError());
         }
-        if (getenv("ZHIP_WATCHDOG")) {
+        if (c->knob.watchdog) {
             for (int it = 0; it < 120000; it++) {
                 if (hipStreamQuery(stream) == hipSuccess) break;
                 struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
@@ -789,14 +810,12 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     }
     if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return g_reserveRc;
     a.workspace = (uint8_t*)c->encWorkspace.p;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, stream));
-    c->timer[1].pending.emplace_back(e0, e1);
-    if (getenv("ZHIP_WATCHDOG")) {
+    if (c->timing) { HIP_TRY(hipEventRecord(e1, stream)); c->timer[1].pending.emplace_back(e0, e1); }
+    if (c->knob.watchdog) {
         for (int it = 0; it < 60000; it++) {
             if (hipStreamQuery(stream) == hipSuccess) break;
             struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
@@ -958,12 +977,11 @@ static int ensure_pinned(zhip_ctx* c, size_t n)          // small pinned area fo
     return 0;
 }
 // items [lo, hi) -> stage, item i at offset segs[i].offset - segs[lo].offset. Big chunks are split over host threads by bytes.
-static void pack_items(uint8_t* stage, const zhip_item* items, const zhip_segment* segs, size_t lo, size_t hi)
+static void pack_items(uint8_t* stage, const zhip_item* items, const zhip_segment* segs, size_t lo, size_t hi, unsigned packThreads)
 {
     const uint64_t base = segs[lo].offset, bytes = hi > lo ? segs[hi - 1].offset + segs[hi - 1].length - base : 0;
     auto run = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) if (items[i].srcSize) memcpy(stage + (segs[i].offset - base), items[i].src, items[i].srcSize); };
-    unsigned nt = bytes >= ((uint64_t)32 << 20) ? ZHIP_PACK_THREADS : 1;
-    if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64 && nt > 1) nt = (unsigned)v; }
+    unsigned nt = bytes >= ((uint64_t)32 << 20) ? (packThreads ? packThreads : ZHIP_PACK_THREADS) : 1;
     if (nt <= 1 || hi - lo < 2 * nt) { run(lo, hi); return; }
     std::vector<std::thread> th;
     size_t a = lo;
@@ -1034,7 +1052,7 @@ static int upload_items(zhip_ctx* c, const zhip_item* items, const zhip_segment*
         const int slot = c->hpNextSlot; c->hpNextSlot ^= 1;
         if (hipEventSynchronize(c->hpStageFree[slot]) != hipSuccess) return ZHIP_ERR_HIP;
         if (ensure_stage(c, slot, bytes + 16)) return ZHIP_ERR_HIP;
-        pack_items((uint8_t*)c->hpStage[slot], items, segs, a, b);
+        pack_items((uint8_t*)c->hpStage[slot], items, segs, a, b, c->knob.packThreads);
         if (bytes && hipMemcpyAsync((uint8_t*)c->hSrc.p + segs[a].offset, c->hpStage[slot], bytes, hipMemcpyHostToDevice, c->hpH2D) != hipSuccess) return ZHIP_ERR_HIP;
         if (hipEventRecord(c->hpStageFree[slot], c->hpH2D) != hipSuccess) return ZHIP_ERR_HIP;
         a = b;

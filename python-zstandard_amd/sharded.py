@@ -123,18 +123,31 @@ def allgatherv_payload(result, group=None):
     return result
 
 
-def _compact(arena, segs, out_sizes, dev):
-    """dense copy of the slots' valid prefixes (device-side gather through one index tensor): the compressed direction's slots are
-    compressBound-sized, what is handed on or gathered is only the frames"""
+def _compact(arena, segs, out_sizes, dev, step_bytes=256 << 20):
+    """dense copy of the slots' valid prefixes (device-side gather through index tensors, at most `step_bytes` of output at a time): the
+    compressed direction's slots are compressBound-sized, what is handed on or gathered is only the frames"""
     n = segs.shape[0]
     lens = out_sizes.to(torch.int64)
     offs = torch.cumsum(lens, 0) - lens
     total = int(lens.sum().item()) if n else 0
+    dense_segs = torch.stack([offs, lens], dim=1)
     if total == 0:
-        return torch.zeros(1, dtype=torch.uint8, device=dev), torch.stack([offs, lens], dim=1)
-    item_of = torch.repeat_interleave(torch.arange(n, device=dev), lens)
-    pos = torch.arange(total, device=dev) - offs[item_of] + segs[:, 0][item_of]
-    return arena[pos], torch.stack([offs, lens], dim=1)
+        return torch.zeros(1, dtype=torch.uint8, device=dev), dense_segs
+    dense = torch.empty(total, dtype=torch.uint8, device=dev)
+    ends = (offs + lens).cpu().numpy()
+    lo = 0
+    while lo < n:
+        hi = int(np.searchsorted(ends, ends[lo] - int(lens[lo].item()) + step_bytes, side="right"))
+        hi = max(hi, lo + 1)
+        l = lens[lo:hi]
+        cnt = int(l.sum().item())
+        if cnt:
+            base = int(offs[lo].item())
+            item_of = torch.repeat_interleave(torch.arange(hi - lo, device=dev), l)
+            pos = torch.arange(cnt, device=dev) - (offs[lo:hi] - base)[item_of] + segs[lo:hi, 0][item_of]
+            dense[base:base + cnt] = arena[pos]
+        lo = hi
+    return dense, dense_segs
 
 
 def multi_decompress_to_buffer(frames, decompressed_sizes, dict_data=None, gather=False, group=None, ctx=None, ctx_factory=None, **ctx_kw):

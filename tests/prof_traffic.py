@@ -1,0 +1,57 @@
+"""Run on the GPU box after tests/run_profiles.sh's rocprofv3 passes: reduces the csv outputs to what profiles/ keeps --
+  <tag>_<dir>_kt_zhip_kernels_summary.csv   per-kernel launch durations (kernel trace)
+  <tag>_<dir>_{fetch,write,sq}_counters.csv  per-kernel counter sums per launch
+  traffic.json                               FETCH_SIZE + WRITE_SIZE bytes per 128 KiB frame and kernel (what bench.py's roofline.traffic scales)
+Usage: python tests/prof_traffic.py <prof dir> <tag> <frames per launch>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+prof, tag, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+out_dir = os.path.join(os.path.dirname(prof.rstrip("/")), "summary")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def rows_of(sub, pattern):
+    for path in glob.glob(os.path.join(prof, sub, "**", pattern), recursive=True):
+        with open(path, newline="") as fh:
+            yield from csv.DictReader(fh)
+
+
+traffic = collections.defaultdict(float)
+for direction in ("decode", "compress"):
+    # kernel trace -> durations
+    dur = collections.defaultdict(list)
+    for r in rows_of(direction + "_kt", "*kernel_trace.csv"):
+        if "zhip_" in r.get("Kernel_Name", ""):
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if dur:
+        with open(os.path.join(out_dir, "%s_%s_kt_zhip_kernels_summary.csv" % (tag, direction)), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+            for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
+    for kind in ("fetch", "write", "sq", "sq2"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows_of("%s_%s" % (direction, kind), "*counter_collection.csv"):
+            if "zhip_" in r.get("Kernel_Name", ""):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not acc:
+            continue
+        with open(os.path.join(out_dir, "%s_%s_%s_counters.csv" % (tag, direction, kind)), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Kernel", "Counter", "Launches", "MeanPerLaunch"])
+            for k in sorted(acc):
+                for c in sorted(acc[k]):
+                    v = acc[k][c]
+                    w.writerow([k, c, len(v), round(sum(v) / len(v), 3)])
+                    if c in ("FETCH_SIZE", "WRITE_SIZE"):               # KiB per launch (rocprofv3's unit) -> bytes per frame
+                        traffic[k] += sum(v) / len(v) * 1024.0 / frames
+json.dump({"round": tag, "frames_per_launch": frames,
+           "source": "profiles/%s_{decode,compress}_{fetch,write}_counters.csv: FETCH_SIZE + WRITE_SIZE (KiB per launch of %d frames, one rocprofv3 --pmc pass each, "
+                     "tests/run_profiles.sh); FETCH_SIZE uncorrected (the guide's x2 applies to wide coalesced reads; these kernels' reads are narrow)" % (tag, frames),
+           "bytes_per_frame": {k: round(v, 1) for k, v in sorted(traffic.items())}}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(out_dir, "traffic.json")).read())

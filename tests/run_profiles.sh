@@ -1,12 +1,22 @@
-# r01c profile collection (run on the GPU box through gpurun): kernel trace + stats, then one PMC pass per counter
+# Profile collection for profiles/ (run on the GPU box:  gpurun --timeout 1500 -- 'TAG=r02 sh tests/run_profiles.sh'): one rocprofv3 pass
+# per purpose as the guide prescribes -- kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ counters -- for both directions, each over
+# 32 768 frames (one chunk per launch), then tests/prof_traffic.py reduces them (per-kernel summaries + traffic.json) under
+# gpurun_out/summary/; copy those into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-P=gpurun_out/prof; rm -rf $P; mkdir -p $P/kt $P/fetch $P/write
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python bench.py --frames 32768 --steps 3 --warmup 1 --no-cpu-baseline > $P/kt/bench.json 2> $P/kt/err.log
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -- python bench.py --frames 32768 --steps 1 --warmup 1 --no-cpu-baseline > $P/fetch/bench.json 2> $P/fetch/err.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -- python bench.py --frames 32768 --steps 1 --warmup 1 --no-cpu-baseline > $P/write/bench.json 2> $P/write/err.log
-python tests/prof_summarize.py $P | tail -8
-find $P -name "*.csv" ! -name "*.zhip.csv" -delete
-timeout 400 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; tail -1 gpurun_out/bench_full.json
-timeout 300 python bench.py --direction compress --frames 32768 --steps 3 --warmup 1 > gpurun_out/bench_enc.json 2> gpurun_out/bench_enc.err; tail -1 gpurun_out/bench_enc.json
-du -sh gpurun_out
+TAG=${TAG:-r02}
+P=gpurun_out/prof; rm -rf $P gpurun_out/summary; mkdir -p $P
+B="python bench.py --frames 32768 --warmup 1 --no-cpu-baseline"
+run() { d=$P/$1; shift; mkdir -p $d; timeout 500 rocprofv3 "$@" > $d/bench.json 2> $d/err.log; echo "$d rc $?"; }
+run decode_kt --kernel-trace --stats --output-format csv -d $P/decode_kt -- $B --steps 3 --compress-frames 0
+run decode_fetch --pmc FETCH_SIZE --output-format csv -d $P/decode_fetch -- $B --steps 1 --compress-frames 0
+run decode_write --pmc WRITE_SIZE --output-format csv -d $P/decode_write -- $B --steps 1 --compress-frames 0
+run decode_sq --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $P/decode_sq -- $B --steps 1 --compress-frames 0
+run decode_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $P/decode_sq2 -- $B --steps 1 --compress-frames 0
+run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- $B --steps 2 --config compress
+run compress_fetch --pmc FETCH_SIZE --output-format csv -d $P/compress_fetch -- $B --steps 1 --warmup 0 --config compress
+run compress_write --pmc WRITE_SIZE --output-format csv -d $P/compress_write -- $B --steps 1 --warmup 0 --config compress
+python tests/prof_traffic.py $P $TAG 32768
+for d in decode_kt compress_kt; do cp $P/$d/bench.json gpurun_out/summary/${TAG}_bench_under_rocprof_${d%_kt}_32768.json; f=$(find $P/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" > gpurun_out/summary/${TAG}_${d}_kernel_stats.csv; done
+rm -rf $P
+ls -la gpurun_out/summary
