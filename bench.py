@@ -122,13 +122,14 @@ class Job:
             fn()
         self.barrier()
         for k in kernels:
-            ctx.kernel_time(k)                                       # reset the per-kernel timers
+            if ctx.kernel_name(k):
+                ctx.kernel_time(k)                                   # reset the per-kernel timers
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         self.barrier()
         elapsed = time.perf_counter() - t0
-        ktimes = {k: ctx.kernel_time(k) for k in kernels}
+        ktimes = {k: ctx.kernel_time(k) for k in kernels if ctx.kernel_name(k)}
         if self.world > 1:
             import torch.distributed as dist
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
@@ -174,7 +175,7 @@ def kernels_obj(ctx, ktimes):
     return {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
 
 
-DEC_KERNELS = (0, 2, 7, 3, 4)
+DEC_KERNELS = (0, 2, 7, 3, 4)         # generic, K1, K1b, K2, K3
 ENC_KERNELS = (1, 5, 6, 8)
 
 

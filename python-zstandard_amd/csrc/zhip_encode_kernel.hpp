@@ -1703,6 +1703,9 @@ ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src
 struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
 struct ZeMulti { const uint8_t* frame; bool firstBlock; ZeLDSMulti* st; };
 
+// SEARCH = false (the entropy kernel, whose sequences always come from a match kernel): the search is not even compiled in -- with it, the
+// 128-register entropy kernel spills in its hot loops (r02g: +350 bytes of scratch per lane made the kernel 30x slower on 4 KiB inputs)
+template <bool SEARCH>
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
                                     const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr, ZeProf* P = nullptr)
 {
@@ -1719,6 +1722,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (!pre->lits) litSize = ze_gather_literals(L, ws + ZE_WS_LIT, src, srcSize, seqs, nbSeq);    // sequences-only search output
         ZE_T(P, ZEP_GATHER);
     }
+    else if constexpr (!SEARCH) return 0;                              // (never reached: frames without pre-computed sequences are raw or errors)
     else {
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
     if (!mb || mb->firstBlock) {
@@ -1981,7 +1985,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
         const uint32_t last = blockSize == remaining ? 1u : 0u;
         const uint64_t room = cap64 - pos - 3;                      // never let a block's scratch output run past this frame's slot
         const uint32_t want = blockSize + (blockSize >> 7) + 512;
-        const uint32_t c = ze_compress_block(L, dst + pos + 3, room < want ? (uint32_t)room : want, src + ip, blockSize, cp, ws, nullptr, a, &mb);
+        const uint32_t c = ze_compress_block<true>(L, dst + pos + 3, room < want ? (uint32_t)room : want, src + ip, blockSize, cp, ws, nullptr, a, &mb);
         uint32_t total, bh;
         if (c == 0) {
             bh = last + (0u << 1) + (blockSize << 3);
@@ -2005,6 +2009,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
 }
 
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
+template <bool SEARCH>
 ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws, uint64_t* produced, const ZePre* pre, ZeLDSMulti* ms = nullptr, ZeProf* P = nullptr)
 {
     const uint32_t lane = zh_lane();
@@ -2013,7 +2018,10 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
     uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
-    if (srcSize64 > ZF_BLOCK_MAX) return (pre || !ms) ? ZE_PARAM_UNSUPPORTED : ze_frame_multi(a, L, ms, f, ws, produced);   // multi-block frames: generic kernel only
+    if (srcSize64 > ZF_BLOCK_MAX) {                                    // multi-block frames: generic kernel only
+        if constexpr (SEARCH) return (pre || !ms) ? ZE_PARAM_UNSUPPORTED : ze_frame_multi(a, L, ms, f, ws, produced);
+        else return ZE_PARAM_UNSUPPORTED;
+    }
     const uint32_t srcSize = (uint32_t)srcSize64;
     const uint32_t bound = srcSize + (srcSize >> 8) + (srcSize < (128u << 10) ? (((128u << 10) - srcSize) >> 11) : 0);
     if (cap64 < bound) return ZE_DST_TOO_SMALL;
@@ -2055,7 +2063,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
         if (zh_opaque(lane) == 0) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; }
         pos += 3;
     } else {
-        const uint32_t c = ze_compress_block(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre, a, nullptr, P);
+        const uint32_t c = ze_compress_block<SEARCH>(L, dst + pos + 3, cap - pos - 3, src, srcSize, cp, ws, pre, a, nullptr, P);
         if (c == 0) {
             const uint32_t bh = 1 + (0u << 1) + (srcSize << 3);
             if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
@@ -2220,7 +2228,7 @@ ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti& M)
         if (k >= total) break;
         const uint32_t f = a.frameList ? a.frameList[k] : k;
         uint64_t produced = 0;
-        const int err = ze_frame(a, L, f, ws, &produced, nullptr, &M);
+        const int err = ze_frame<true>(a, L, f, ws, &produced, nullptr, &M);
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }
@@ -2328,7 +2336,7 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         uint64_t produced = 0;
         ZeProf prof; ZeProf* P = a.prof ? &prof : nullptr;
         if (P) { for (int q = 0; q < ZEP_N; q++) prof.acc[q] = 0; prof.t0 = zd_clock(); }
-        const int err = ze_frame(a, L, f, ws, &produced, (m.mode == 0 || m.mode == 4) ? &pre : nullptr, nullptr, P);   // modes 1/2 never reach the search inside
+        const int err = ze_frame<false>(a, L, f, ws, &produced, (m.mode == 0 || m.mode == 4) ? &pre : nullptr, nullptr, P);   // modes 1/2 never reach the search (raw / error)
         if (P) { ZE_T(P, ZEP_REST); if (zh_opaque(lane) == 0) for (int q = 0; q < ZEP_N; q++) zh_atomic_add64(a.prof + q, (unsigned long long)prof.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
