@@ -164,3 +164,11 @@ def test_native_cpu_baseline_driver_runs(ref, corpus):
     bad = bytearray(blob.tobytes()); bad[int(foffs[2]) + 20] ^= 0xFF
     badnp = np.frombuffer(bytes(bad), dtype=np.uint8)
     assert lib.zo_mt_bench(reflib.REF_SO.encode(), 1, badnp.ctypes.data, foffs.ctypes.data, 6, 131072, 3, 2, 1) < 0
+
+
+def test_integration_stub_compiles_against_the_header(tmp_path):
+    """INTEGRATION.md's reference-side binding (struct literals, calls, ownership hand-off) as C, compiled against include/zstd_hip.h"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(root, "tests", "abi_stub_check.c"), "-o", str(tmp_path / "abi_stub_check.o")])
