@@ -692,8 +692,61 @@ done2:
     if (sizes.obj) PyBuffer_Release(&sizes);
     return result;
 }
+/* decompress_content_dict_chain (c-ext/decompressor.c:620-890): frame 0 stands alone, every later frame is decompressed with the previous
+ * fulltext as a raw-content prefix dictionary (ZSTD_DCtx_refPrefix_advanced(..., ZSTD_dct_rawContent)). The chain is serial by nature;
+ * each link is one call into the batch ABI with that fulltext as the dictionary. Same checks, same messages. */
+static PyObject* decomp_content_dict_chain(Decompressor* self, PyObject* args, PyObject* kwargs)
+{
+    static char* kwlist[] = { "frames", NULL };
+    PyObject* chunks;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O!:decompress_content_dict_chain", kwlist, &PyList_Type, &chunks)) return NULL;
+    const Py_ssize_t n = PyList_Size(chunks);
+    if (!n) { PyErr_SetString(PyExc_ValueError, "empty input chain"); return NULL; }
+    PyObject* prev = NULL;                          /* the previous fulltext (bytes) */
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject* chunk = PyList_GetItem(chunks, i);
+        if (!PyBytes_Check(chunk)) { PyErr_Format(PyExc_ValueError, "chunk %zd must be bytes", i); Py_XDECREF(prev); return NULL; }
+        char* data; Py_ssize_t size;
+        PyBytes_AsStringAndSize(chunk, &data, &size);
+        const uint64_t fcs = Z.frame_content_size_format(size ? data : NULL, (size_t)size, ZHIP_FORMAT_ZSTD1);
+        if (fcs == ZHIP_CONTENTSIZE_ERROR) {
+            /* ZSTD_getFrameHeader: an error for a bad magic / descriptor, "needs more input" for a truncated header */
+            const int tooSmall = size < 5 || (size >= 4 && memcmp(data, "\x28\xb5\x2f\xfd", 4) == 0);
+            if (tooSmall && size < 18) PyErr_Format(PyExc_ValueError, "chunk %zd is too small to contain a zstd frame", i);
+            else PyErr_Format(PyExc_ValueError, "chunk %zd is not a valid zstd frame", i);
+            Py_XDECREF(prev); return NULL;
+        }
+        if (fcs == ZHIP_CONTENTSIZE_UNKNOWN) { PyErr_Format(PyExc_ValueError, "chunk %zd missing content size in frame", i); Py_XDECREF(prev); return NULL; }
+        if (fcs > (uint64_t)PY_SSIZE_T_MAX) { PyErr_Format(PyExc_ValueError, "chunk %zd is too large to decompress on this platform", i); Py_XDECREF(prev); return NULL; }
+        PyObject* cur = NULL;
+        if (fcs == 0) cur = PyBytes_FromStringAndSize("", 0);
+        else {
+            zhip_item item = { data, (size_t)size, (size_t)fcs };
+            zhip_dparams p; memset(&p, 0, sizeof p);
+            p.maxWindowSize = self->maxWindowSize; p.format = ZHIP_FORMAT_ZSTD1;
+            if (prev && PyBytes_GET_SIZE(prev)) { p.dict = PyBytes_AS_STRING(prev); p.dictSize = (size_t)PyBytes_GET_SIZE(prev); p.dictType = ZHIP_DICT_RAWCONTENT; }
+            zhip_outbuf* out = NULL; size_t nOut = 0; zhip_error err; int rc;
+            memset(&err, 0, sizeof err);
+            Py_BEGIN_ALLOW_THREADS
+            rc = Z.decompress_batch(&p, &item, 1, 0, &out, &nOut, &err);
+            Py_END_ALLOW_THREADS
+            /* a frame that ends early is, to the reference's streaming call, a frame that wants more input: "did not decompress full frame" */
+            if (rc == ZHIP_ERR_ZSTD && err.zstdErr == 72) PyErr_Format(ZstdError, "chunk %zd did not decompress full frame", i);
+            else if (rc == ZHIP_ERR_ZSTD) PyErr_Format(ZstdError, "could not decompress chunk %zd: %s", i, Z.error_name(err.zstdErr));
+            else if (rc == ZHIP_ERR_SIZE_MISMATCH) PyErr_Format(ZstdError, "chunk %zd did not decompress full frame", i);
+            else if (rc == ZHIP_ERR_NO_MEMORY) PyErr_NoMemory();
+            else if (rc != ZHIP_ERR_NONE) PyErr_Format(ZstdError, "HIP backend failure: %s", Z.last_error());
+            else { cur = PyBytes_FromStringAndSize((const char*)out[0].data, (Py_ssize_t)out[0].segs[0].length); Z.free_outbufs(out, nOut, 1); }
+        }
+        Py_XDECREF(prev);
+        if (!cur) return NULL;
+        prev = cur;
+    }
+    return prev;
+}
 static PyMethodDef decomp_methods[] = {
     { "decompress", (PyCFunction)decomp_decompress, METH_VARARGS | METH_KEYWORDS, "decompress(data) -> bytes" },
+    { "decompress_content_dict_chain", (PyCFunction)decomp_content_dict_chain, METH_VARARGS | METH_KEYWORDS, "decompress a chain of frames, each using the previous fulltext as its dictionary" },
     { "multi_decompress_to_buffer", (PyCFunction)decomp_multi, METH_VARARGS | METH_KEYWORDS, "decompress many frames into a BufferWithSegmentsCollection" },
     { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "host memory held by the context" },
     { NULL, NULL, 0, NULL } };

@@ -4,6 +4,7 @@
 #   libzstd_hip_huf{16,4}.so      -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
 #   libzstd_hip_longone.so        -DZP_K3_LONGONE     K3: one ready long match per dependency round (round 1's form)
 #   libzstd_hip_tab3.so           -DZE_TAB3           entropy kernel: the three sequence tables built by three lanes at once
+#   libzstd_hip_e1l{16,32,64}.so  -DZE_E1_LANES=n     lane-serial match kernel (dictionary / fast-strategy batches): n frames per wave instead of 8
 #   libzstd_hip_pf.so             -DZP_K3_PREFETCH    K3: the next batch's far-match source lines touched a batch ahead
 #   libzstd_hip_asm2k.so          -DZP_ASM_BYTES=2048 K3: 2 KiB batch assembly buffer (3.7 KiB of LDS per wave instead of 5.7)
 #   libzstd_hip_co{36,40,44,48}.so  asm2k + -DZP_K2_LANES=n: a K2 wave of n frames and sixteen (fourteen, ...) K3 waves fit one CU together
@@ -15,7 +16,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 B="$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
 want() { [ $# -eq 0 ] && return 0; }
 build() { name=$1; shift; $B "$@" -o libzstd_hip_$name.so zhip_lib.hip; }
-ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3 asm2k co36 co40 co44 co48 pf co40p co44p co48p basep"
+ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3 asm2k co36 co40 co44 co48 pf co40p co44p co48p basep e1l16 e1l32 e1l64"
 [ $# -gt 0 ] && ALL="$*"
 for v in $ALL; do
   case $v in
@@ -30,6 +31,9 @@ for v in $ALL; do
     co44p) build co44p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=44 -DZP_K2_PRIO=3 & ;;
     co48p) build co48p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=48 -DZP_K2_PRIO=3 & ;;
     basep) build basep -DZP_K2_PRIO=3 & ;;
+    e1l16) build e1l16 -DZE_E1_LANES=16 & ;;
+    e1l32) build e1l32 -DZE_E1_LANES=32 & ;;
+    e1l64) build e1l64 -DZE_E1_LANES=64 & ;;
     pf) build pf -DZP_K3_PREFETCH & ;;
     asm2k) build asm2k -DZP_ASM_BYTES=2048 & ;;
     co36) build co36 -DZP_ASM_BYTES=2048 -DZP_K2_LANES=36 & ;;

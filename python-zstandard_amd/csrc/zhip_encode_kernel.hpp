@@ -2241,8 +2241,8 @@ ZH_DEVFN void ze_kernel_body(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti& M)
 ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
 {
     const uint32_t lane = zh_lane();
-    if (lane >= ZE_E1_LANES) return;
-    uint8_t* tables = a.laneTables + ((size_t)zh_block() * ZE_E1_LANES + lane) * a.tableStride;
+    if (lane >= a.e1Lanes) return;
+    uint8_t* tables = a.laneTables + ((size_t)zh_block() * a.e1Lanes + lane) * a.tableStride;
     for (;;) {
         const uint32_t k = zh_atomic_add(a.counter, 1u);
         if (k >= (a.useE1List ? *a.e1Count : a.count)) break;
@@ -2269,16 +2269,16 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         uint32_t* hashLong = (uint32_t*)tables;
         uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
         { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
-        uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
+        uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
         uint32_t litSize = 0;
         // a dictionary without content (shorter than 8 bytes: nothing of it is loaded, zstd.c:28167) is not attached
         // (ZSTD_resetCCtx_byAttachingCDict, "don't even attach dictionaries with no contents"): the plain search, with the dictionary's row
-        m.nbSeq = (a.cdict && a.cdict->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+        m.nbSeq = (a.cdict && a.cdict->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
                                                                                    a.cdictHashLong, hashLong)
-                                                                      : ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
+                                                                      : ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
                                                                                       a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall))
-                          : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong)
-                          : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + ZE_ARENA_LIT, &litSize, src, srcSize, cp, hashLong, hashSmall);
+                          : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, hashLong)
+                          : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, hashLong, hashSmall);
         m.litSize = litSize;
         a.meta[i] = m;
     }
@@ -2306,7 +2306,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     }
     uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
     uint32_t* hashSmall = hashLong + (1u << cp.hlog);
-    uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
+    uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
     m.mode = 4;
 #ifdef ZHIP_EMU
@@ -2331,8 +2331,8 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         const uint32_t f = a.first + i;
         const ZeMeta m = a.meta[i];
         if (m.mode == 3) continue;                                         // listed for the generic kernel
-        const uint8_t* fr = a.arena + (size_t)i * ZE_ARENA_STRIDE;
-        ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = m.mode == 4 ? nullptr : fr + ZE_ARENA_LIT; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
+        const uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
+        ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = m.mode == 4 ? nullptr : fr + a.arenaLit; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
         uint64_t produced = 0;
         ZeProf prof; ZeProf* P = a.prof ? &prof : nullptr;
         if (P) { for (int q = 0; q < ZEP_N; q++) prof.acc[q] = 0; prof.t0 = zd_clock(); }

@@ -97,8 +97,10 @@ struct ZhipEncodeArgs {
     unsigned long long* prof;
     // two-kernel form (match finding with one LANE per frame, then entropy coding with one wave per frame)
     struct ZeMeta* meta;            // chunk-local per-frame record
-    uint8_t* arena;                 // chunk x ZE_ARENA_STRIDE : packed sequences + literals of each frame
-    uint8_t* laneTables;            // (gridDim.x * ZE_E1_LANES) x tableStride : hash tables of the frames being searched
+    uint8_t* arena;                 // chunk x arenaStride : packed sequences (at 0) + literals (at arenaLit) of each frame
+    uint32_t arenaStride, arenaLit; // ZE_ARENA_STRIDE / ZE_ARENA_LIT for 128 KiB sources; dictionary batches (sources below the attach cutoff) use smaller slots
+    uint8_t* laneTables;            // (gridDim.x * e1Lanes) x tableStride : hash tables of the frames being searched
+    uint32_t e1Lanes;               // frames per wave of the lane-serial match kernel: ZE_E1_LANES (8), ZE_E1_LANES_DICT (32) for dictionary batches
     uint32_t tableStride;
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
     // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
@@ -125,6 +127,9 @@ struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched 
 #define ZE_ARENA_STRIDE ((size_t)ZE_ARENA_LIT + ZF_BLOCK_MAX + 256)
 #ifndef ZE_E1_LANES
 #define ZE_E1_LANES 8
+#endif
+#ifndef ZE_E1_LANES_DICT
+#define ZE_E1_LANES_DICT 32             // small uniform sources, one dependent-probe chain each: frames in flight beat divergence (r02i: 8 -> 14.2, 16 -> 17.8, 32 -> 20.5, 64 -> 20.0 GB/s)
 #endif
 #define ZE_E2_STRIDE ((size_t)ZF_BLOCK_MAX + 256)              // E2 needs one block's literals per resident wave (gathered from the sequences)
 

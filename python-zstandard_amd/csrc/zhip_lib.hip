@@ -236,7 +236,7 @@ struct zhip_ctx {
     DevBuf scratch, counter;
     // dictionary (compress side): raw bytes, parsed entropy section, digested form and its tagged tables
     DevBuf cdictBlob, cdictEntropy, cdictDigest, cdictTables;
-    bool hasCDict = false; uint32_t cdictContentOffset = 0, cdictAttachMax = ZE_DICT_ATTACH_MAX;
+    bool hasCDict = false; uint32_t cdictContentOffset = 0, cdictAttachMax = ZE_DICT_ATTACH_MAX; int cdictHlog = 0, cdictClog = 0, cdictStrat = 2;
     uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy;
@@ -477,6 +477,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         if (cd.status) return cd.status == ZE_DICT_CORRUPTED || cd.status == ZE_DICT_WRONG ? -ZE_MEMORY : -cd.status;
         c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
         c->cdictAttachMax = cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX;
+        c->cdictHlog = cd.hlog; c->cdictClog = cd.clog; c->cdictStrat = cd.strat;
     }
     c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows;
     return 0;
@@ -723,24 +724,39 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         if (stride < (4u << 10)) stride = 4u << 10;
         if (stride > (12u << 17)) stride = 12u << 17;                  // larger tables: the frame is refused loudly by the match kernels
+        a.arenaStride = (uint32_t)ZE_ARENA_STRIDE; a.arenaLit = ZE_ARENA_LIT;
+        if (c->hasCDict) {
+            // dictionary batches: every source is below the attach cutoff, so the per-lane tables are the dictionary row's shrunk to that
+            // size (ze_dict_cparams) and a frame's sequences + literals fit a slot of the cutoff's size -- a tenth of the 128 KiB shapes,
+            // which is what lets a whole 262 144-document batch be one chunk
+            const int w = c->cdictAttachMax > (8u << 10) ? 14 : 13;
+            const int h = c->cdictHlog > w + 1 ? w + 1 : c->cdictHlog, cl = c->cdictClog > w ? w : c->cdictClog;
+            stride = (4u << h) + (c->cdictStrat == 2 ? (4u << cl) : 0u);
+            if (stride < (4u << 10)) stride = 4u << 10;
+            a.arenaLit = (8u * (c->cdictAttachMax / 3 + 16) + 15) & ~15u;
+            a.arenaStride = (a.arenaLit + c->cdictAttachMax + 256 + 15) & ~15u;
+        }
         a.tableStride = stride;
         // double-fast without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
         // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
         // and dictionary batches use the lane-serial kernel for the whole chunk.
         const bool flat = anyDfast && !c->hasCDict && !c->knob.noFlat;
-        size_t chunkMax = flat ? 65536 : 32768;
+        size_t chunkMax = flat ? 65536 : c->hasCDict ? 262144 : 32768;
         if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         const size_t chunk = n < chunkMax ? n : chunkMax;
-        size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * ZE_E1_LANES > 32768) g1max = 32768 / ZE_E1_LANES;
+        const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
+        const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;
+        a.e1Lanes = (uint32_t)e1Lanes;
+        size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * e1Lanes > laneCap) g1max = laneCap / e1Lanes;
         if (flat && g1max > 256) g1max = 256;                                      // only the frames the flat kernel declines
-        const size_t w1 = (chunk + ZE_E1_LANES - 1) / ZE_E1_LANES;
+        const size_t w1 = (chunk + e1Lanes - 1) / e1Lanes;
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
         const uint32_t gBig = (uint32_t)(n < 64 ? n : 64);                       // waves for inputs above one block (generic kernel)
-        if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * ZE_ARENA_STRIDE) ||
-            c->encTables.reserve((size_t)g1 * ZE_E1_LANES * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
+        if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
+            c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
             c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
             (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return g_reserveRc;
         a.workspace = (uint8_t*)c->encWorkspace.p;

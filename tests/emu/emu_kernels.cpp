@@ -187,9 +187,10 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
     free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_E2_STRIDE + ZHIP_ENC_STRIDE);
     a.tableStride = emu_table_stride(a.rows);
-    a.laneTables = (uint8_t*)malloc((size_t)nBlocks * ZE_E1_LANES * a.tableStride);
+    a.e1Lanes = g_hasCD ? ZE_E1_LANES_DICT : ZE_E1_LANES;
+    a.laneTables = (uint8_t*)malloc((size_t)nBlocks * a.e1Lanes * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
-    a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE);
+    a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE); a.arenaStride = (uint32_t)ZE_ARENA_STRIDE; a.arenaLit = ZE_ARENA_LIT;
     uint32_t bigCount = 0; a.bigList = (uint32_t*)calloc(n ? n : 1, 4); a.bigCount = &bigCount;
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);

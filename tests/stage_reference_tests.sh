@@ -23,7 +23,7 @@ def train_dictionary(dict_size, samples, **kw):
     return _z.ZstdCompressionDict(reflib.RefZstd().train_dictionary(dict_size, list(samples)))
 PY
 for f in __init__.py common.py test_buffer_util.py test_compressor_multi_compress_to_buffer.py test_decompressor_multi_decompress_to_buffer.py \
-         test_compressor_compress.py test_decompressor_decompress.py; do
+         test_compressor_compress.py test_decompressor_decompress.py test_decompressor_content_dict_chain.py; do
   cp "$REF/tests/$f" .reftmp/tests/
 done
 echo "staged $(ls .reftmp/tests | wc -l) files under .reftmp/"

@@ -126,3 +126,22 @@ def test_content_checksum_is_verified(zstd):
         bad[k] = bad[k][:-2] + bytes([bad[k][-2] ^ 0x20]) + bad[k][-1:]
         with pytest.raises(zstd.ZstdError, match="error decompressing item %d: Restored data doesn't match checksum" % k):
             zstd.ZstdDecompressor().multi_decompress_to_buffer(bad)
+
+
+def test_decompress_content_dict_chain(zstd, oracle):
+    """ZstdDecompressor.decompress_content_dict_chain (c-ext/decompressor.c:620-890): every frame after the first is
+    decoded with the previous fulltext as a raw-content dictionary; the reference's own test for it runs in tests/run_reference_hotpath_tests.sh"""
+    from tests.corpus import Corpus
+    c = Corpus()
+    original = [b"foo" * 64, b"foobar" * 64, b"baz" * 64, b"foobaz" * 64, b"foobarbaz" * 64, c.frame_bytes(7)[:9000], c.frame_bytes(7)[400:9400]]
+    chunks = [zstd.ZstdCompressor().compress(original[0])]
+    for i, chunk in enumerate(original[1:]):
+        chunks.append(zstd.ZstdCompressor(dict_data=zstd.ZstdCompressionDict(original[i])).compress(chunk))
+    d = zstd.ZstdDecompressor()
+    for i in range(1, len(original) + 1):
+        assert d.decompress_content_dict_chain(chunks[0:i]) == original[i - 1]
+    assert len(chunks[6]) < len(zstd.ZstdCompressor().compress(original[6])) // 4           # the chain's dictionary really is used
+    with pytest.raises(zstd.ZstdError, match="chunk 1 did not decompress full frame"):
+        d.decompress_content_dict_chain([chunks[0], chunks[1][0:12] + chunks[1][15:]])
+    with pytest.raises(ValueError, match="chunk 1 missing content size in frame"):
+        d.decompress_content_dict_chain([chunks[0], zstd.ZstdCompressor(write_content_size=False).compress(b"foo" * 64)])
