@@ -1413,6 +1413,175 @@ ZH_DEVFN uint32_t ze_fast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, co
     return nseq;
 }
 
+// ------------------------------------------------------------------------------------------ searches of libzstd's table-COPY mode
+// Above the attach cutoff (ZSTD_shouldAttachDict, zstd.c:25263) libzstd copies the dictionary's tables into the frame's own
+// (ZSTD_resetCCtx_byCopyingCDict, zstd.c:25356: tags stripped, the dictionary's hash / chain logs kept as they are) and the dictionary
+// content becomes an EXTERNAL segment of the window, searched by the _extDict variants. Same index space as above (content byte k is
+// index 2 + k, the source starts at CE), ONE table set holding dictionary and source positions alike. One lane each.
+// ZSTD_compressBlock_fast_extDict_generic (zstd.c:32423).
+ZH_DEVFN uint32_t ze_fast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                              const ZeCDict& cd, const uint8_t* content, uint32_t* table)
+{
+    const int hlog = cp.hlog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t stepSize = (uint32_t)cp.tlen + (cp.tlen == 0) + 1;
+    const uint32_t CE = 2 + cd.contentSize, DS = 2;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
+    const uint32_t iend = CE + srcSize;
+    uint32_t ip0 = CE, anchor = CE;
+    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
+    {   const uint32_t maxRep = ip0 - DS;                              // (the saved offsets only matter to a next block: frames here have one)
+        if (off2 >= maxRep) off2 = 0;
+        if (off1 >= maxRep) off1 = 0; }
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_SRC(i) (src + ((i) - CE))
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
+    if (srcSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        for (;;) {
+            uint32_t step = stepSize, nextStep = ip0 + 128;              // kStepIncr = 1 << (kSearchStrength - 1)
+            uint32_t ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
+            if (ip3 >= ilimit) break;
+            uint32_t hash0 = ze_hash(ZE_SRC(ip0), hlog, mls), hash1 = ze_hash(ZE_SRC(ip1), hlog, mls);
+            uint32_t idx = table[hash0];
+            uint32_t current0 = 0, offBase = 0, mLength = 0, m = 0;
+            int found = 0;
+            do {
+                {   const uint32_t repIndex = ip2 - off1;                // repcode at ip2
+                    const bool valid = ((uint32_t)(CE - repIndex) >= 4) & (off1 > 0);      /* intentional underflow */
+                    const uint32_t rval = valid ? ze_sp_rd32(sp, repIndex) : zh_ld32(ZE_SRC(ip2)) ^ 1u;
+                    current0 = ip0; table[hash0] = current0;
+                    if (zh_ld32(ZE_SRC(ip2)) == rval) {
+                        ip0 = ip2; m = repIndex;
+                        mLength = ze_sp_byte(sp, ip0 - 1) == ze_sp_byte(sp, m - 1) ? 1u : 0u;
+                        ip0 -= mLength; m -= mLength;
+                        offBase = 1; mLength += 4;
+                        found = 1; break;
+                    } }
+                if (idx >= DS && ze_sp_rd32(sp, idx) == zh_ld32(ZE_SRC(ip0))) { found = 2; break; }
+                idx = table[hash1];
+                hash0 = hash1; hash1 = ze_hash(ZE_SRC(ip2), hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip3;
+                current0 = ip0; table[hash0] = current0;
+                if (idx >= DS && ze_sp_rd32(sp, idx) == zh_ld32(ZE_SRC(ip0))) { found = 2; break; }
+                idx = table[hash1];
+                hash0 = hash1; hash1 = ze_hash(ZE_SRC(ip2), hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+                if (ip2 >= nextStep) { step++; nextStep += 128; }
+            } while (ip3 < ilimit);
+            if (!found) break;
+            if (found == 2) {
+                const uint32_t offset = current0 - idx, low = idx < CE ? DS : CE;
+                m = idx;
+                off2 = off1; off1 = offset; offBase = offset + 3; mLength = 4;
+                while (ip0 > anchor && m > low && ze_sp_byte(sp, ip0 - 1) == ze_sp_byte(sp, m - 1)) { ip0--; m--; mLength++; }
+            }
+            mLength += ze_sp_count(sp, ip0 + mLength, m + mLength);
+            ZE_STORE(ip0 - anchor, offBase, mLength);
+            ip0 += mLength; anchor = ip0;
+            if (ip1 < ip0) table[hash1] = ip1;
+            if (ip0 <= ilimit) {
+                table[ze_hash(ZE_SRC(current0 + 2), hlog, mls)] = current0 + 2;
+                table[ze_hash(ZE_SRC(ip0 - 2), hlog, mls)] = ip0 - 2;
+                while (ip0 <= ilimit) {
+                    const uint32_t rep2 = ip0 - off2;
+                    if (!(((uint32_t)((CE - 1) - rep2) >= 3) & (off2 > 0)) || ze_sp_rd32(sp, rep2) != zh_ld32(ZE_SRC(ip0))) break;
+                    const uint32_t r = ze_sp_count(sp, ip0 + 4, rep2 + 4) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    ZE_STORE(0, 1, r);
+                    table[ze_hash(ZE_SRC(ip0), hlog, mls)] = ip0;
+                    ip0 += r; anchor = ip0;
+                }
+            }
+        }
+    }
+#undef ZE_STORE
+    {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
+#undef ZE_SRC
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+// ZSTD_compressBlock_doubleFast_extDict_generic (zstd.c:31544).
+ZH_DEVFN uint32_t ze_dfast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
+                               const ZeCDict& cd, const uint8_t* content, uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const int hl = cp.hlog, hs = cp.clog;
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t CE = 2 + cd.contentSize, DS = 2;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
+    const uint32_t iend = CE + srcSize;
+    uint32_t ip = CE, anchor = CE;
+    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
+    uint32_t nseq = 0; uint8_t* lp = lits;
+#define ZE_SRC(i) (src + ((i) - CE))
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
+        seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
+#define ZE_BACKX(M) do { const uint32_t low_ = (M) < CE ? DS : CE; while (ip > anchor && (M) > low_ && ze_sp_byte(sp, ip - 1) == ze_sp_byte(sp, (M) - 1)) { ip--; (M)--; mLength++; } } while (0)
+    if (srcSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        while (ip < ilimit) {
+            const uint32_t hSmall = ze_hash(ZE_SRC(ip), hs, mls), hLong = ze_hash(ZE_SRC(ip), hl, 8);
+            uint32_t matchIndex = hashSmall[hSmall], matchLongIndex = hashLong[hLong];
+            const uint32_t curr = ip;
+            const uint32_t repIndex = curr + 1 - off1;
+            uint32_t mLength = 0, offset = 0;
+            hashSmall[hSmall] = curr; hashLong[hLong] = curr;
+            if ((((uint32_t)((CE - 1) - repIndex) >= 3) & (off1 <= curr + 1 - DS)) && ze_sp_rd32(sp, repIndex) == zh_ld32(ZE_SRC(ip + 1))) {
+                mLength = ze_sp_count(sp, ip + 1 + 4, repIndex + 4) + 4;
+                ip++;
+                ZE_STORE(ip - anchor, 1, mLength);
+            } else {
+                if (matchLongIndex > DS && ze_sp_rd64(sp, matchLongIndex) == zh_ld64(ZE_SRC(ip))) {
+                    mLength = ze_sp_count(sp, ip + 8, matchLongIndex + 8) + 8;
+                    offset = curr - matchLongIndex;
+                    ZE_BACKX(matchLongIndex);
+                } else if (matchIndex > DS && ze_sp_rd32(sp, matchIndex) == zh_ld32(ZE_SRC(ip))) {
+                    const uint32_t h3 = ze_hash(ZE_SRC(ip + 1), hl, 8);
+                    uint32_t matchIndex3 = hashLong[h3];
+                    hashLong[h3] = curr + 1;
+                    if (matchIndex3 > DS && ze_sp_rd64(sp, matchIndex3) == zh_ld64(ZE_SRC(ip + 1))) {
+                        mLength = ze_sp_count(sp, ip + 9, matchIndex3 + 8) + 8;
+                        ip++;
+                        offset = curr + 1 - matchIndex3;
+                        ZE_BACKX(matchIndex3);
+                    } else {
+                        mLength = ze_sp_count(sp, ip + 4, matchIndex + 4) + 4;
+                        offset = curr - matchIndex;
+                        ZE_BACKX(matchIndex);
+                    }
+                } else { ip += ((ip - anchor) >> 8) + 1; continue; }
+                off2 = off1; off1 = offset;
+                ZE_STORE(ip - anchor, offset + 3, mLength);
+            }
+            ip += mLength; anchor = ip;
+            if (ip <= ilimit) {
+                const uint32_t ins = curr + 2;
+                hashLong[ze_hash(ZE_SRC(ins), hl, 8)] = ins;
+                hashLong[ze_hash(ZE_SRC(ip - 2), hl, 8)] = ip - 2;
+                hashSmall[ze_hash(ZE_SRC(ins), hs, mls)] = ins;
+                hashSmall[ze_hash(ZE_SRC(ip - 1), hs, mls)] = ip - 1;
+                while (ip <= ilimit) {
+                    const uint32_t rep2 = ip - off2;
+                    if (!((((uint32_t)((CE - 1) - rep2) >= 3) & (off2 <= ip - DS)) && ze_sp_rd32(sp, rep2) == zh_ld32(ZE_SRC(ip)))) break;
+                    const uint32_t r = ze_sp_count(sp, ip + 4, rep2 + 4) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    ZE_STORE(0, 1, r);
+                    hashSmall[ze_hash(ZE_SRC(ip), hs, mls)] = ip;
+                    hashLong[ze_hash(ZE_SRC(ip), hl, 8)] = ip;
+                    ip += r; anchor = ip;
+                }
+            }
+        }
+    }
+#undef ZE_BACKX
+#undef ZE_STORE
+    {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
+#undef ZE_SRC
+    *pLit = (uint32_t)(lp - lits);
+    return nseq;
+}
+
 // working parameters of a frame compressed against an attached dictionary: the dictionary's own row shrunk to the source
 // (ZSTD_resetCCtx_byAttachingCDict, zstd.c:25279); the window log stays the one chosen for the source.
 ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
@@ -1425,6 +1594,23 @@ ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
     cp.hlog = h; cp.clog = c; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
 }
 ZH_DEV uint32_t ze_dict_attach_max(const ZeCDict& cd) { return cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX; }
+// working parameters of libzstd's table-copy mode (ZSTD_resetCCtx_byCopyingCDict, zstd.c:25368-25373): everything from the dictionary's
+// row UNCHANGED, the window log as ZSTD_getCParamsFromCCtxParams chooses it for source + dictionary content (row of that total size,
+// clamped to its log2). 0, or parameter_unsupported when the window would not hold the dictionary for the whole (single) block.
+ZH_DEV int ze_dict_copy_cparams(ZePar& cp, const ZeCDict& cd, const ZeRows& rows, uint32_t srcSize)
+{
+    ZePar t;
+    const uint32_t total = srcSize + cd.contentSize;
+    const uint32_t tableID = (total <= 256u * 1024) + (total <= 128u * 1024) + (total <= 16u * 1024);
+    int w = rows.r[tableID][0];
+    const int srcLog = total < 64 ? 6 : zh_highbit32(total - 1) + 1;
+    if (w > srcLog) w = srcLog;
+    if (w < 10) w = 10;
+    (void)t;
+    cp.wlog = w; cp.hlog = cd.hlog; cp.clog = cd.clog; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
+    if (w > 30 || ((uint64_t)1 << w) < (uint64_t)total) return ZE_PARAM_UNSUPPORTED;     // (the dictionary would fall out of the window: ZSTD_checkDictValidity)
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------ sequences section
 // ZSTD_selectEncodingType (zstd.c:21252), strategy below "lazy", first block: 0 basic, 1 rle, 2 compressed
@@ -1724,6 +1910,12 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     }
     else if constexpr (!SEARCH) return 0;                              // (never reached: frames without pre-computed sequences are raw or errors)
     else {
+    const bool copyMode = cd && cd->contentSize && srcSize > ze_dict_attach_max(*cd);
+    if (copyMode) {
+        // ZSTD_copyCDictTableIntoCCtx (zstd.c:25340): the dictionary's tagged cells (index << 8 | tag) become plain indices
+        for (uint32_t i = lane; i < (1u << cp.hlog); i += 64) hashLong[i] = a.cdictHashLong[i] >> 8;
+        if (cp.strat == 2) for (uint32_t i = lane; i < (1u << cp.clog); i += 64) hashSmall[i] = a.cdictHashSmall[i] >> 8;
+    } else
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
     if (!mb || mb->firstBlock) {
         uint64_t* a = (uint64_t*)hashLong; const uint32_t na = (1u << cp.hlog) / 2;
@@ -1739,6 +1931,8 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         if (mb) { nrep[0] = mb->st->mrep[0]; nrep[1] = mb->st->mrep[1]; }
         const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
                                                 : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
+                          : copyMode ? (cp.strat == 1 ? ze_fast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent, hashLong)
+                                                      : ze_dfast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent, hashLong, hashSmall))
                           : (cd && cd->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
                                                                                      a.cdictHashLong, hashLong)
                                                                     : ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
@@ -2032,8 +2226,11 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
     uint32_t dictID = 0;
     if (a.cdict) {
         if (a.cdict->status) return a.cdict->status;
-        if (srcSize > ze_dict_attach_max(*a.cdict)) return ZE_PARAM_UNSUPPORTED;    // the reference's table-copy mode is not implemented
-        ze_dict_cparams(cp, *a.cdict, srcSize);
+        if (a.cdict->contentSize && srcSize > ze_dict_attach_max(*a.cdict)) {         // libzstd's table-copy mode: the generic kernel's work
+            if constexpr (!SEARCH) return ZE_PARAM_UNSUPPORTED;
+            const int ce = ze_dict_copy_cparams(cp, *a.cdict, a.rows, srcSize);
+            if (ce) return ce;
+        } else ze_dict_cparams(cp, *a.cdict, srcSize);
         if (a.dictIDFlag) dictID = a.cdict->dictID;
     }
     if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
@@ -2260,7 +2457,12 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         const uint32_t srcSize = (uint32_t)srcSize64;
         bool bad = ze_get_cparams(cp, a.rows, srcSize) != 0;
         if (!bad && a.cdict) {
-            if (a.cdict->status || srcSize > ze_dict_attach_max(*a.cdict)) bad = true;
+            if (a.cdict->status) bad = true;
+            else if (a.cdict->contentSize && srcSize > ze_dict_attach_max(*a.cdict)) {   // table-copy mode (needs tables of the dictionary's own size and a
+                m.mode = 3; a.meta[i] = m;                                              // 128 KiB arena slot): one wave per frame in the generic kernel
+                a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
+                continue;
+            }
             else ze_dict_cparams(cp, *a.cdict, srcSize);
         }
         if (bad || (cp.strat != 2 && cp.strat != 1) ||

@@ -754,7 +754,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
-        const uint32_t gBig = (uint32_t)(n < 64 ? n : 64);                       // waves for inputs above one block (generic kernel)
+        // waves for what the generic kernel takes: inputs above one block, and -- with a dictionary -- inputs above the attach cutoff
+        const size_t gBigMax = c->hasCDict ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : 64;
+        const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
             c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
             c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
@@ -1188,8 +1190,8 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
             g_lastError = "inputs of 2 GiB and more are not implemented in the HIP backend";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
-        if (withDict && items[i].srcSize > c->cdictAttachMax) {
-            g_lastError = "dictionary compression of inputs above libzstd's attach cutoff (16 KiB double-fast, 8 KiB fast: its table-copy mode) is not implemented in the HIP backend yet";
+        if (withDict && items[i].srcSize > ZF_BLOCK_MAX) {
+            g_lastError = "dictionary compression of inputs above 128 KiB (several blocks against a dictionary) is not implemented in the HIP backend yet";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;

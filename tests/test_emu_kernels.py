@@ -59,8 +59,8 @@ def test_emulated_dictionary_compression_matches_golden(emu):
             assert not any(st)
             for o, rec in zip(outs, GOLD["dictionary_compress"]["frames"][key]):
                 assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (key, pipeline)
-    outs, st = emu.compress_batch([b"a" * 16385, b"abc" * 100], level=3, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
-    assert st[0] == 40 and st[1] == 0       # parameter_unsupported for the oversize source only
+    outs, st = emu.compress_batch([b"a" * 131073, b"abc" * 100], level=3, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
+    assert st[0] == 40 and st[1] == 0       # parameter_unsupported for the source of more than one block only
 
 
 def test_emulated_decode_pipeline_matches_oracle(emu, oracle, corpus):
@@ -308,5 +308,25 @@ def test_fast_strategy_dictionary_bit_exact(emu, ref, corpus):
             for pipe in (True, False):
                 outs, st = emu.compress_batch(raws, level=level, flags=5, pipeline=pipe, dict_data=dd)
                 assert not any(st) and outs == want, (level, pipe)
-    outs, st = emu.compress_batch([corpus.frame_bytes(3)[:8193], corpus.frame_bytes(3)[:8192]], level=1, flags=5, pipeline=True, dict_data=dicts[0])
-    assert st[0] == 40 and st[1] == 0                                               # above the cutoff: parameter_unsupported, loud
+
+
+def test_dictionary_table_copy_mode_bit_exact(emu, ref, corpus):
+    """sources above libzstd's attach cutoffs (8 KiB fast / 16 KiB double-fast, zstd.c:25250) up to one block: ZSTD_resetCCtx_byCopyingCDict +
+    ZSTD_compressBlock_{fast,doubleFast}_extDict_generic (zstd.c:25356, :32423, :31544) -- the dictionary's tables copied with their tags
+    stripped, its content an external segment of the window. What three of the reference's own tests do (b"foobar" * 16384 at level 1)."""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    samples = []
+    for i in range(128):
+        samples += [b"foo" * 64, b"bar" * 64, b"foobar" * 64, b"qwert" * 64, b"yuiop" * 64]
+    dicts = [ref.train_dictionary(8192, samples), corpus.frame_bytes(600)[:6000]]
+    raws = [b"foobar" * 16384, corpus.frame_bytes(3)[:8193], corpus.frame_bytes(4)[:16385], corpus.frame_bytes(5)[:40000], rng.bytes(20000),
+            corpus.frame_bytes(600)[3000:50000], corpus.frame_bytes(6)]
+    for dd in dicts:
+        for level in (1, 3):
+            want = [ref.compress(r, level=level, dict_data=dd) for r in raws]
+            for pipe in (True, False):
+                outs, st = emu.compress_batch(raws, level=level, flags=5, pipeline=pipe, dict_data=dd)
+                assert not any(st) and outs == want, (level, pipe)
+    outs, st = emu.compress_batch([corpus.frame_bytes(3) + b"tail"], level=3, flags=5, pipeline=True, dict_data=dicts[0])
+    assert st[0] == 40                                                            # several blocks against a dictionary: parameter_unsupported, loud

@@ -194,6 +194,16 @@ def test_fast_strategy_with_dictionary(zstd, ref, corpus):
             back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
             assert [back[i].tobytes() for i in range(len(raws))] == raws
         assert zstd.ZstdCompressor(level=1, dict_data=zd).compress(raws[3]) == ref.compress(raws[3], level=1, dict_data=blob)
-    # the fast strategy attaches dictionaries up to 8 KiB of source (attachDictSizeCutoffs, zstd.c:25250); above: loud, not different bytes
-    with pytest.raises(zstd.ZstdError):
-        zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(corpus.frame_bytes(5)[:9000])
+    # above libzstd's attach cutoffs (8 KiB fast / 16 KiB double-fast, zstd.c:25250) it copies the dictionary's tables and searches the
+    # content as an external segment (ZSTD_resetCCtx_byCopyingCDict + the _extDict searches): same frames here, up to one block
+    big = [b"foobar" * 16384, corpus.frame_bytes(5)[:9000], corpus.frame_bytes(6)[:16385], corpus.frame_bytes(7)[:70000], corpus.frame_bytes(8)]
+    for blob in (trained, corpus.frame_bytes(600)[:6000]):
+        zd = zstd.ZstdCompressionDict(blob)
+        for level in (1, 3):
+            got = zstd.ZstdCompressor(level=level, dict_data=zd).multi_compress_to_buffer(big + raws[:4])
+            for i, r in enumerate(big + raws[:4]):
+                assert got[i].tobytes() == ref.compress(r, level=level, dict_data=blob), ("copy mode", level, i)
+            back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
+            assert [back[i].tobytes() for i in range(len(big) + 4)] == big + raws[:4]
+    with pytest.raises(zstd.ZstdError):                                           # several blocks against a dictionary: still refused, loudly
+        zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(corpus.frame_bytes(5) + b"tail")

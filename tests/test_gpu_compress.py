@@ -85,7 +85,7 @@ def test_errors(zstd):
 
 def test_dictionary_compression_bit_exact(zstd, corpus):
     """ZstdCompressor(dict_data=...) -- c-ext/compressor.c:150-171, 252-280: dictionary digested on the device, frames identical to
-    libzstd's (attached-dictionary mode, sources <= 16 KiB); golden vectors first, then a wider live comparison."""
+    libzstd's (attached-dictionary mode up to 16 KiB, table-copy mode above); golden vectors first, then a wider live comparison."""
     import hashlib
     from tests import reflib
     from tests.test_oracle_vs_golden import GOLD, _dict_vectors
@@ -112,9 +112,11 @@ def test_dictionary_compression_bit_exact(zstd, corpus):
         assert res[i].tobytes() == chk.compress(r, level=3, flags=reflib.DEFAULT_FLAGS, dict_data=d), i
     back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(res)
     assert [back[i].tobytes() for i in range(len(raws))] == raws
-    # sources above 16 KiB would need libzstd's table-copy mode: loud failure, never a silent different frame
+    # above 16 KiB: libzstd's table-copy mode (tests/test_gpu_boundary.py covers it); more than one block stays a loud failure
+    if reflib.have_ref():                                                         # the C restatement stops at the attach cutoff; libzstd itself does not
+        assert zstd.ZstdCompressor(level=3, dict_data=zd).compress(b"a" * 20000) == reflib.RefZstd().compress(b"a" * 20000, level=3, dict_data=d)
     with pytest.raises(zstd.ZstdError):
-        zstd.ZstdCompressor(level=3, dict_data=zd).compress(b"a" * 20000)
+        zstd.ZstdCompressor(level=3, dict_data=zd).compress(b"a" * 131073)
 
 
 def test_fast_strategy_levels_bit_exact(zstd):
