@@ -875,7 +875,9 @@ PyMODINIT_FUNC PyInit_backend_hip(void)
     PyModule_AddObject(m, "CONTENTSIZE_UNKNOWN", PyLong_FromUnsignedLongLong(ZHIP_CONTENTSIZE_UNKNOWN));
     PyModule_AddObject(m, "CONTENTSIZE_ERROR", PyLong_FromUnsignedLongLong(ZHIP_CONTENTSIZE_ERROR));
     PyModule_AddObject(m, "MAGIC_NUMBER", PyLong_FromUnsignedLong(0xFD2FB528ul));
-    PyModule_AddIntConstant(m, "BLOCKSIZE_MAX", 1 << 17);
+    PyModule_AddIntConstant(m, "BLOCKSIZE_MAX", 1 << 17); PyModule_AddIntConstant(m, "BLOCKSIZELOG_MAX", 17);
+    PyModule_AddObject(m, "FRAME_HEADER", PyBytes_FromStringAndSize("\x28\xb5\x2f\xfd", 4));      /* c-ext/constants.c:46-48 */
+    PyModule_AddIntConstant(m, "SEARCHLENGTH_MIN", 3); PyModule_AddIntConstant(m, "SEARCHLENGTH_MAX", 7);
     PyModule_AddIntConstant(m, "COMPRESSION_RECOMMENDED_INPUT_SIZE", 1 << 17);
     PyModule_AddIntConstant(m, "COMPRESSION_RECOMMENDED_OUTPUT_SIZE", (1 << 17) + 512 + 3 + 4);
     PyModule_AddIntConstant(m, "DECOMPRESSION_RECOMMENDED_INPUT_SIZE", (1 << 17) + 3);

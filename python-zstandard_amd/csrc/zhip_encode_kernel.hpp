@@ -43,7 +43,8 @@ struct ZeLDS {
 // generic one-wave-per-frame kernel has it
 struct ZeLDSMulti {
     uint32_t mrep[2];
-    uint32_t prevRepeat, prevMaxSym;    // previous block's Huffman table: 0 none, 1 usable after validation
+    uint32_t prevRepeat, prevMaxSym;    // previous block's Huffman table: 0 none, 1 usable after validation, 2 valid (a dictionary's, still unreplaced)
+    uint32_t fseRep[3];                 // LL / OF / ML: 2 while the dictionary's table may still be repeated (FSE_repeat_valid), else 0 / 1
     uint8_t prevBits[256];
     uint16_t prevCode[256];
 };
@@ -1419,20 +1420,23 @@ ZH_DEVFN uint32_t ze_fast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, co
 // content becomes an EXTERNAL segment of the window, searched by the _extDict variants. Same index space as above (content byte k is
 // index 2 + k, the source starts at CE), ONE table set holding dictionary and source positions alike. One lane each.
 // ZSTD_compressBlock_fast_extDict_generic (zstd.c:32423).
-ZH_DEVFN uint32_t ze_fast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
-                              const ZeCDict& cd, const uint8_t* content, uint32_t* table)
+// frame + blkOff: the block (several per frame above 128 KiB: the tables and rep[] carry over, the dictionary stays in the window -- the
+// caller refuses frames whose window would drop it). rep: in / out.
+ZH_DEVFN uint32_t ze_fast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* frame, uint32_t blkOff, uint32_t srcSize, const ZePar& cp,
+                              const ZeCDict& cd, const uint8_t* content, uint32_t* table, uint32_t* rep)
 {
     const int hlog = cp.hlog;
     const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
     const uint32_t stepSize = (uint32_t)cp.tlen + (cp.tlen == 0) + 1;
     const uint32_t CE = 2 + cd.contentSize, DS = 2;
-    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
-    const uint32_t iend = CE + srcSize;
-    uint32_t ip0 = CE, anchor = CE;
-    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
-    {   const uint32_t maxRep = ip0 - DS;                              // (the saved offsets only matter to a next block: frames here have one)
-        if (off2 >= maxRep) off2 = 0;
-        if (off1 >= maxRep) off1 = 0; }
+    const uint8_t* const src = frame;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + blkOff + srcSize;
+    const uint32_t iend = CE + blkOff + srcSize;
+    uint32_t ip0 = CE + blkOff, anchor = ip0;
+    uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
+    {   const uint32_t maxRep = ip0 - DS;
+        if (off2 >= maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 >= maxRep) { saved1 = off1; off1 = 0; } }
     uint32_t nseq = 0; uint8_t* lp = lits;
 #define ZE_SRC(i) (src + ((i) - CE))
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
@@ -1499,20 +1503,23 @@ ZH_DEVFN uint32_t ze_fast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, con
 #undef ZE_STORE
     {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
 #undef ZE_SRC
+    if (saved1 != 0 && off1 != 0) saved2 = saved1;
+    rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
     *pLit = (uint32_t)(lp - lits);
     return nseq;
 }
 // ZSTD_compressBlock_doubleFast_extDict_generic (zstd.c:31544).
-ZH_DEVFN uint32_t ze_dfast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* src, uint32_t srcSize, const ZePar& cp,
-                               const ZeCDict& cd, const uint8_t* content, uint32_t* hashLong, uint32_t* hashSmall)
+ZH_DEVFN uint32_t ze_dfast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const uint8_t* frame, uint32_t blkOff, uint32_t srcSize, const ZePar& cp,
+                               const ZeCDict& cd, const uint8_t* content, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep)
 {
     const int hl = cp.hlog, hs = cp.clog;
     const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
     const uint32_t CE = 2 + cd.contentSize, DS = 2;
-    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
-    const uint32_t iend = CE + srcSize;
-    uint32_t ip = CE, anchor = CE;
-    uint32_t off1 = cd.rep[0], off2 = cd.rep[1];
+    const uint8_t* const src = frame;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + blkOff + srcSize;
+    const uint32_t iend = CE + blkOff + srcSize;
+    uint32_t ip = CE + blkOff, anchor = ip;
+    uint32_t off1 = rep[0], off2 = rep[1];
     uint32_t nseq = 0; uint8_t* lp = lits;
 #define ZE_SRC(i) (src + ((i) - CE))
 #define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = a_[i_]; lp += ll_; \
@@ -1578,6 +1585,7 @@ ZH_DEVFN uint32_t ze_dfast_ext(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, co
 #undef ZE_STORE
     {   const uint32_t lastLL = iend - anchor; const uint8_t* a_ = ZE_SRC(anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = a_[i]; lp += lastLL; }
 #undef ZE_SRC
+    rep[0] = off1; rep[1] = off2;
     *pLit = (uint32_t)(lp - lits);
     return nseq;
 }
@@ -1596,7 +1604,7 @@ ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
 ZH_DEV uint32_t ze_dict_attach_max(const ZeCDict& cd) { return cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX; }
 // working parameters of libzstd's table-copy mode (ZSTD_resetCCtx_byCopyingCDict, zstd.c:25368-25373): everything from the dictionary's
 // row UNCHANGED, the window log as ZSTD_getCParamsFromCCtxParams chooses it for source + dictionary content (row of that total size,
-// clamped to its log2). 0, or parameter_unsupported when the window would not hold the dictionary for the whole (single) block.
+// clamped to its log2). 0, or parameter_unsupported when the window would drop the dictionary before the frame ends.
 ZH_DEV int ze_dict_copy_cparams(ZePar& cp, const ZeCDict& cd, const ZeRows& rows, uint32_t srcSize)
 {
     ZePar t;
@@ -1608,7 +1616,9 @@ ZH_DEV int ze_dict_copy_cparams(ZePar& cp, const ZeCDict& cd, const ZeRows& rows
     if (w < 10) w = 10;
     (void)t;
     cp.wlog = w; cp.hlog = cd.hlog; cp.clog = cd.clog; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
-    if (w > 30 || ((uint64_t)1 << w) < (uint64_t)total) return ZE_PARAM_UNSUPPORTED;     // (the dictionary would fall out of the window: ZSTD_checkDictValidity)
+    // the dictionary stays valid while the SOURCE fits the window (ZSTD_checkDictValidity, zstd.c:19360: block end > dictionary end + window);
+    // beyond that libzstd drops it part-way through the frame, which is not implemented: refused
+    if (w > 30 || ((uint64_t)1 << w) < (uint64_t)srcSize) return ZE_PARAM_UNSUPPORTED;
     return 0;
 }
 
@@ -1625,7 +1635,7 @@ ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog
     return 2;
 }
 // ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, uint32_t strat,
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, const uint32_t* fseRep, uint32_t strat,
                                      uint8_t* cellSym, uint16_t* fill, int16_t* norm)
 {
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
@@ -1635,7 +1645,7 @@ ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mod
     uint32_t max = 0, most = 0;
     for (uint32_t s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
     const bool defaultAllowed = which != 1 || max <= 28;
-    const uint32_t repeatMode = !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;
+    const uint32_t repeatMode = fseRep ? fseRep[which] : !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;   // (fseRep: a later block's view)
     *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode, strat);
     ZeCTab& t = L.tab[which];
     if (*mode == 3) return 0;        // set_repeat: the dictionary's table, copied into LDS by the whole wave (ze_copy_dict_tables) -- a lane-0
@@ -1887,7 +1897,7 @@ ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src
 // mb == null: the block is the whole frame. mb != null: one block of a multi-block frame -- the hash tables, the two repcodes
 // (L.mrep) and the previous block's Huffman table (L.prev*) carry over and advance only when the block is emitted compressed.
 struct ZePre { const uint64_t* seqs; const uint8_t* lits; uint32_t nbSeq, litSize; };   // output of the match-finding kernel
-struct ZeMulti { const uint8_t* frame; bool firstBlock; ZeLDSMulti* st; };
+struct ZeMulti { const uint8_t* frame; bool firstBlock; ZeLDSMulti* st; uint32_t blkOff; };
 
 // SEARCH = false (the entropy kernel, whose sequences always come from a match kernel): the search is not even compiled in -- with it, the
 // 128-register entropy kernel spills in its hot loops (r02g: +350 bytes of scratch per lane made the kernel 30x slower on 4 KiB inputs)
@@ -1895,7 +1905,8 @@ template <bool SEARCH>
 ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const uint8_t* src, uint32_t srcSize, const ZePar& cp, uint8_t* ws,
                                     const ZePre* pre, const ZhipEncodeArgs& a, const ZeMulti* mb = nullptr, ZeProf* P = nullptr)
 {
-    const ZeCDict* cd = mb ? nullptr : a.cdict;
+    const ZeCDict* cd = a.cdict;                                      // (multi-block frames against a dictionary: its state lives in mb->st from the second block on)
+    const uint32_t* const fseRep = mb && cd ? mb->st->fseRep : nullptr;
     const uint32_t lane = zh_lane();
     if (srcSize < 7) return 0;
     uint32_t* hashLong = (uint32_t*)(ws + ZE_WS_HASHL);
@@ -1910,11 +1921,13 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     }
     else if constexpr (!SEARCH) return 0;                              // (never reached: frames without pre-computed sequences are raw or errors)
     else {
-    const bool copyMode = cd && cd->contentSize && srcSize > ze_dict_attach_max(*cd);
+    const bool copyMode = cd && cd->contentSize && (mb || srcSize > ze_dict_attach_max(*cd));
     if (copyMode) {
         // ZSTD_copyCDictTableIntoCCtx (zstd.c:25340): the dictionary's tagged cells (index << 8 | tag) become plain indices
-        for (uint32_t i = lane; i < (1u << cp.hlog); i += 64) hashLong[i] = a.cdictHashLong[i] >> 8;
-        if (cp.strat == 2) for (uint32_t i = lane; i < (1u << cp.clog); i += 64) hashSmall[i] = a.cdictHashSmall[i] >> 8;
+        if (!mb || mb->firstBlock) {
+            for (uint32_t i = lane; i < (1u << cp.hlog); i += 64) hashLong[i] = a.cdictHashLong[i] >> 8;
+            if (cp.strat == 2) for (uint32_t i = lane; i < (1u << cp.clog); i += 64) hashSmall[i] = a.cdictHashSmall[i] >> 8;
+        }
     } else
     // fresh tables: the wave zeroes them with coalesced 8-byte stores
     if (!mb || mb->firstBlock) {
@@ -1929,10 +1942,12 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         uint32_t ls = 0;
         uint32_t nrep[2] = {1, 4};
         if (mb) { nrep[0] = mb->st->mrep[0]; nrep[1] = mb->st->mrep[1]; }
-        const uint32_t ns = mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
+        else if (cd) { nrep[0] = cd->rep[0]; nrep[1] = cd->rep[1]; }
+        const uint8_t* const base = mb ? mb->frame : src; const uint32_t off = mb ? mb->blkOff : 0u;
+        const uint32_t ns = copyMode ? (cp.strat == 1 ? ze_fast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, base, off, srcSize, cp, *cd, a.cdictContent, hashLong, nrep)
+                                                      : ze_dfast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, base, off, srcSize, cp, *cd, a.cdictContent, hashLong, hashSmall, nrep))
+                          : mb ? (cp.strat == 1 ? ze_fast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, nrep)
                                                 : ze_dfast_g((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, mb->frame, src, srcSize, cp, hashLong, hashSmall, nrep))
-                          : copyMode ? (cp.strat == 1 ? ze_fast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent, hashLong)
-                                                      : ze_dfast_ext((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent, hashLong, hashSmall))
                           : (cd && cd->contentSize) ? (cp.strat == 1 ? ze_fast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
                                                                                      a.cdictHashLong, hashLong)
                                                                     : ze_dfast_dict((uint64_t*)(ws + ZE_WS_SEQ), ws + ZE_WS_LIT, &ls, src, srcSize, cp, *cd, a.cdictContent,
@@ -1949,7 +1964,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     uint32_t pos, newMaxSym = 0xFFFFFFFFu;
     const uint32_t nextRep0 = mb ? zh_first(L.misc[5]) : 0, nextRep1 = mb ? zh_first(L.misc[6]) : 0;
     ZePrevHuf ph; const ZePrevHuf* php = nullptr;
-    if (cd && cd->hufRepeat) { ph.bits = cd->hufBits; ph.code = cd->hufCode; ph.maxSym = cd->hufMaxSym; ph.repeat = cd->hufRepeat; php = &ph; }
+    if (!mb && cd && cd->hufRepeat) { ph.bits = cd->hufBits; ph.code = cd->hufCode; ph.maxSym = cd->hufMaxSym; ph.repeat = cd->hufRepeat; php = &ph; }
     else if (mb && mb->st->prevRepeat) { ph.bits = mb->st->prevBits; ph.code = mb->st->prevCode; ph.maxSym = mb->st->prevMaxSym; ph.repeat = mb->st->prevRepeat; php = &ph; }
     if (cp.strat == 1 && cp.tlen > 0) {          // negative levels keep literals raw (ZSTD_literalsCompressionIsDisabled, zstd.c:24208)
         zh_sync();
@@ -1984,9 +1999,9 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
             uint8_t* seqHead = op++;
             int mLL, mOF, mML; uint32_t h;
             const uint32_t c0 = L.misc[8], c1 = L.misc[9];
-            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mML == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mLL == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mOF == 2) lastCount = h; op += h;
+            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mML == 2) lastCount = h; op += h;
             *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
             L.misc[7] = (uint32_t)mLL | ((uint32_t)mOF << 2) | ((uint32_t)mML << 4);
         }
@@ -2000,7 +2015,7 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
         uint8_t* const nodeB = (uint8_t*)L.node;
         const uint32_t c0 = L.misc[8], c1 = L.misc[9];
         int md = 0;
-        const uint32_t h = ze_build_seq_table(L, (int)lane, nodeB + 3328 + 80 * lane, &md, (c0 >> (8 * lane)) & 255, (c1 >> (8 * lane)) & 255, nbSeq, cd, (uint32_t)cp.strat,
+        const uint32_t h = ze_build_seq_table(L, (int)lane, nodeB + 3328 + 80 * lane, &md, (c0 >> (8 * lane)) & 255, (c1 >> (8 * lane)) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat,
                                               nodeB + 1024 + 512 * lane, (uint16_t*)(nodeB + 2560 + 128 * lane), (int16_t*)(nodeB + 2944 + 128 * lane));
         L.misc[4 + lane] = h | ((uint32_t)md << 16);
     }
@@ -2058,7 +2073,12 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
                 for (uint32_t i = lane; i < 256; i += 64) { mb->st->prevBits[i] = L.hufBits[i]; mb->st->prevCode[i] = L.hufCode[i]; }
                 if (zh_opaque(lane) == 0) { mb->st->prevRepeat = 1; mb->st->prevMaxSym = newMaxSym; }
             }
+            // ZSTD_selectEncodingType's *repeatMode (zstd.c:21252): basic / rle -> none, compressed -> check, repeat keeps the dictionary's table valid
+            if (fseRep && nbSeq && zh_opaque(lane) == 0)
+                for (uint32_t t = 0; t < 3; t++) { const uint32_t md = (seqModes >> (2 * t)) & 3; if (md != 3) mb->st->fseRep[t] = md == 2 ? 1u : 0u; }
         }
+        // "after the first block, the offcode table might not have large enough codes" (zstd.c:27392): valid -> check, whatever the block became
+        if (fseRep && zh_opaque(lane) == 0 && mb->st->fseRep[1] == 2) mb->st->fseRep[1] = 1;
         ze_fence();
         zh_sync();
     }
@@ -2145,12 +2165,23 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
     uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
-    if (srcSize64 >= (1ull << 31) || a.cdict) return ZE_PARAM_UNSUPPORTED;        // index overflow correction / dictionary + multi-block: not implemented
+    if (srcSize64 >= (1ull << 31)) return ZE_PARAM_UNSUPPORTED;                   // index overflow correction: not implemented
     const uint32_t srcSize = (uint32_t)srcSize64;
     if (cap64 < (uint64_t)srcSize + (srcSize >> 8)) return ZE_DST_TOO_SMALL;
     ZePar cp;
     const int e = ze_get_cparams(cp, a.rows, srcSize);
     if (e) return e;
+    const ZeCDict* const cd = a.cdict;
+    uint32_t dictID = 0;
+    if (cd) {
+        if (cd->status) return cd->status;
+        if (cd->contentSize) {                                                     // table-copy mode; a window that would drop the dictionary part-way
+            const int ce = ze_dict_copy_cparams(cp, *cd, a.rows, srcSize);        // (ZSTD_checkDictValidity, zstd.c:19360) is refused inside
+            if (ce) return ce;
+        }
+        if (a.dictIDFlag) dictID = cd->dictID;
+    }
+    const uint32_t dictCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     if ((cp.strat != 2 && cp.strat != 1) || cp.hlog > ZE_MAX_HLOG || cp.clog > ZE_MAX_HLOG) return ZE_PARAM_UNSUPPORTED;
     const uint32_t contentSize = a.contentSizeFlag != 0, checksum = a.checksumFlag != 0;
     const uint32_t single = contentSize && cp.wlog < 32 && (1ull << cp.wlog) >= srcSize;
@@ -2159,18 +2190,23 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     zh_sync();
     if (zh_opaque(lane) == 0) {
         if (!a.magicless) { zh_st32(dst, ZF_MAGIC); pos = 4; }
-        dst[pos++] = (uint8_t)((checksum << 2) + (single << 5) + (fcsCode << 6));
+        dst[pos++] = (uint8_t)(dictCode + (checksum << 2) + (single << 5) + (fcsCode << 6));
         if (!single) dst[pos++] = (uint8_t)((cp.wlog - 10) << 3);
+        if (dictCode == 1) dst[pos++] = (uint8_t)dictID;
+        else if (dictCode == 2) { zh_st16(dst + pos, (uint16_t)dictID); pos += 2; }
+        else if (dictCode == 3) { zh_st32(dst + pos, dictID); pos += 4; }
         if (fcsCode == 0) { if (single) dst[pos++] = (uint8_t)srcSize; }
         else if (fcsCode == 1) { zh_st16(dst + pos, (uint16_t)(srcSize - 256)); pos += 2; }
         else { zh_st32(dst + pos, srcSize); pos += 4; }
         L.misc[4] = pos;
-        ms->mrep[0] = 1; ms->mrep[1] = 4; ms->prevRepeat = 0; ms->prevMaxSym = 0;
+        ms->mrep[0] = cd ? cd->rep[0] : 1; ms->mrep[1] = cd ? cd->rep[1] : 4; ms->prevMaxSym = cd ? cd->hufMaxSym : 0; ms->prevRepeat = cd ? cd->hufRepeat : 0;
+        ms->fseRep[0] = cd ? cd->llRepeat : 0; ms->fseRep[1] = cd ? cd->ofRepeat : 0; ms->fseRep[2] = cd ? cd->mlRepeat : 0;
     }
+    if (cd && cd->hufRepeat) for (uint32_t i = lane; i < 256; i += 64) { ms->prevBits[i] = cd->hufBits[i]; ms->prevCode[i] = cd->hufCode[i]; }
     zh_sync();
     pos = zh_first(L.misc[4]);
     zh_sync();
-    ZeMulti mb; mb.frame = src; mb.firstBlock = true; mb.st = ms;
+    ZeMulti mb; mb.frame = src; mb.firstBlock = true; mb.st = ms; mb.blkOff = 0;
     uint32_t ip = 0; int32_t savings = 0;
     while (ip < srcSize) {
         const uint32_t remaining = srcSize - ip;
@@ -2189,7 +2225,7 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
         else { bh = last + (2u << 1) + (c << 3); total = 3 + c; }
         if (zh_opaque(lane) == 0) { dst[pos] = (uint8_t)bh; dst[pos + 1] = (uint8_t)(bh >> 8); dst[pos + 2] = (uint8_t)(bh >> 16); }
         savings += (int32_t)blockSize - (int32_t)total;
-        pos += total; ip += blockSize; mb.firstBlock = false;
+        pos += total; ip += blockSize; mb.firstBlock = false; mb.blkOff = ip;
         ze_fence();
         zh_sync();
     }

@@ -1180,7 +1180,6 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     int r = zhip_ctx_set_cparams(c, params ? params : &defaults);
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
-    const bool withDict = c->hasCDict;
     // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are compacted on the
     // device, chunk by chunk, and only they travel back
     std::vector<zhip_segment> segs(2 * n);
@@ -1188,10 +1187,6 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     for (size_t i = 0; i < n; i++) {
         if (items[i].srcSize >= (1ull << 31)) {
             g_lastError = "inputs of 2 GiB and more are not implemented in the HIP backend";
-            return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
-        }
-        if (withDict && items[i].srcSize > ZF_BLOCK_MAX) {
-            g_lastError = "dictionary compression of inputs above 128 KiB (several blocks against a dictionary) is not implemented in the HIP backend yet";
             return set_err(err, ZHIP_ERR_UNSUPPORTED, i, 0);
         }
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;

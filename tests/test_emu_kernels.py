@@ -59,8 +59,8 @@ def test_emulated_dictionary_compression_matches_golden(emu):
             assert not any(st)
             for o, rec in zip(outs, GOLD["dictionary_compress"]["frames"][key]):
                 assert len(o) == rec["size"] and hashlib.sha256(o).hexdigest() == rec["sha256"], (key, pipeline)
-    outs, st = emu.compress_batch([b"a" * 131073, b"abc" * 100], level=3, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
-    assert st[0] == 40 and st[1] == 0       # parameter_unsupported for the source of more than one block only
+    outs, st = emu.compress_batch([b"a" * ((1 << 19) + 1), b"abc" * 100], level=1, flags=5, n_blocks=1, pipeline=True, dict_data=dicts["raw"])
+    assert st[0] == 40 and st[1] == 0       # parameter_unsupported only for the source whose window (level 1: 512 KiB) would drop the dictionary
 
 
 def test_emulated_decode_pipeline_matches_oracle(emu, oracle, corpus):
@@ -328,5 +328,27 @@ def test_dictionary_table_copy_mode_bit_exact(emu, ref, corpus):
             for pipe in (True, False):
                 outs, st = emu.compress_batch(raws, level=level, flags=5, pipeline=pipe, dict_data=dd)
                 assert not any(st) and outs == want, (level, pipe)
-    outs, st = emu.compress_batch([corpus.frame_bytes(3) + b"tail"], level=3, flags=5, pipeline=True, dict_data=dicts[0])
-    assert st[0] == 40                                                            # several blocks against a dictionary: parameter_unsupported, loud
+
+
+def test_dictionary_multi_block_frames_bit_exact(emu, ref, corpus):
+    """sources above 128 KiB against a dictionary (ZSTD_compress_frameChunk, zstd.c:27545, over the table-copy state): the dictionary stays
+    an external segment for every block, repcodes and the Huffman table carry over, the dictionary's LL / ML tables stay repeatable while
+    each block repeats them, its offset table only for the first block (zstd.c:27392). The reference's generate_samples() reaches 196 608 bytes."""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    inputs = [b"foo" * 32, b"bar" * 16, b"abcdef" * 64, b"sometext" * 128, b"baz" * 512]
+    samples = []
+    for i in range(128):
+        samples += [inputs[i % 5], inputs[i % 5] * (i + 3), inputs[-(i % 5)] * (i + 2)]
+    big = b"".join(corpus.frame_bytes(i) for i in range(3))
+    dicts = [ref.train_dictionary(8192, samples), corpus.frame_bytes(600)[:6000]]
+    raws = [samples[-1], samples[-5], big[:131073], big[:200000], b"a" * 300000, rng.bytes(140000), (corpus.frame_bytes(9) + b"x" * 200000)[:250000]]
+    for dd in dicts:
+        for level in (1, 3):
+            want = [ref.compress(r, level=level, dict_data=dd) for r in raws]
+            outs, st = emu.compress_batch(raws, level=level, flags=5, pipeline=True, dict_data=dd)
+            assert not any(st) and outs == want, level
+    # the dictionary stays valid while the source fits the window (level 1: 512 KiB); one byte more and libzstd would drop it part-way: refused
+    edge = (big * 2)[:1 << 19]
+    outs, st = emu.compress_batch([edge, edge + b"!"], level=1, flags=5, pipeline=True, dict_data=dicts[1])
+    assert st == [0, 40] and outs[0] == ref.compress(edge, level=1, dict_data=dicts[1])

@@ -205,5 +205,14 @@ def test_fast_strategy_with_dictionary(zstd, ref, corpus):
                 assert got[i].tobytes() == ref.compress(r, level=level, dict_data=blob), ("copy mode", level, i)
             back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
             assert [back[i].tobytes() for i in range(len(big) + 4)] == big + raws[:4]
-    with pytest.raises(zstd.ZstdError):                                           # several blocks against a dictionary: still refused, loudly
-        zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(corpus.frame_bytes(5) + b"tail")
+    # several blocks against a dictionary (the reference's generate_samples() reaches 196 608 bytes)
+    several = [corpus.frame_bytes(5) + b"tail", b"baz" * 65536, b"".join(corpus.frame_bytes(20 + i) for i in range(3)), (b"".join(corpus.frame_bytes(30 + i) for i in range(4)))[:1 << 19]]
+    for level in (1, 3):
+        zd = zstd.ZstdCompressionDict(trained)
+        got = zstd.ZstdCompressor(level=level, dict_data=zd).multi_compress_to_buffer(several)
+        for i, r in enumerate(several):
+            assert got[i].tobytes() == ref.compress(r, level=level, dict_data=trained), ("multi-block", level, i)
+        back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got)
+        assert [back[i].tobytes() for i in range(len(several))] == several
+    with pytest.raises(zstd.ZstdError):                                           # a source larger than its window (level 1: 512 KiB): libzstd drops the
+        zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(b"q" * ((1 << 19) + 1))   # dictionary part-way; refused, loudly
