@@ -132,7 +132,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 m.nbSeq = nbSeq;
                 if (nbSeq == 0) { if (sp != send) { err = ZE_CORRUPTION; break; } }
                 else {
-                    if (nbSeq > ZP_SEQ_CAP) { err = ZE_CORRUPTION; break; }
+                    if (nbSeq > ZP_SEQ_CAP - 8) { err = ZE_CORRUPTION; break; }      // (> 43 690 cannot fit a block; K2 stores a few slots past the longest frame of its wave and parks idle lanes' stores in the last)
                     if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
                     const uint32_t modes = *sp++;
                     if (modes & 3) { err = ZE_CORRUPTION; break; }
@@ -530,6 +530,186 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
             const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, L.tab + (size_t)lane * ZP_K2_STRIDE, L.llInfo, L.mlInfo,
                                                 m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP, L.ring + lane);
             if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
+                m->path = 2;
+                const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
+            } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
+        }
+        zh_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K2q (four lanes == one frame)
+// K2 above is bound by the issue rate of ONE wave per CU (r02 SQ counters: 130 instructions per sequence step at 6.5 cycles each; the
+// tables of 60 frames fill the CU's LDS, so more waves only split the same frames and every wave still issues the whole step). Here a
+// frame is decoded by a QUAD of lanes -- lane 0 the offset stream, 1 match lengths, 2 literal lengths, 3 spare -- so one instruction
+// does the cell decode / bit extraction / table lookup of all three tANS streams at once, a wave holds 15 frames and FOUR waves (one per
+// SIMD, 15 x 2.5 KiB of tables each) share the CU. What the lanes of a quad owe each other per step -- the bit counts that place every
+// field in the stream -- travels by DPP quad_perm, not through LDS.
+//   * bit reader: an absolute bit cursor `pos` (identical in the four lanes) over the frame's LDS ring [row][slot]; a field is the two
+//     dwords at rows d, d + 1 (row 32 mirrors row 0), one v_alignbit, one v_bfe. No window registers, no refill selects.
+//   * the ring is fed like ZpBits: aligned 16-byte blocks requested a burst (4 steps) ahead, lane r of the quad carries block r.
+//   * baseline | extra-bit count of the length codes come from one shared LDS word, as in K2 (a per-lane formula needs 7 more instructions
+//     than the lookup, and r02l showed this kernel's time is its instruction count).
+#ifndef ZQ_FRAMES
+#define ZQ_FRAMES 15            // frames per wave; 4 waves x (15 x 2 564 + ring 2 112 + 360) = 163 728 of the CU's 163 840 bytes of LDS
+#endif
+#define ZQ_ROWS 32              // ring rows (dwords per frame): 128 bytes, as K2's
+// (the ring comes first: ds_read2_b32's two offsets are 8 bits each, so only a base within 1 KiB folds into the instruction)
+struct ZpSeqQLDS { uint32_t ring[(ZQ_ROWS + 1) * 16]; uint32_t llInfo[36]; uint32_t mlInfo[53]; uint32_t spare; uint8_t tab[ZQ_FRAMES * ZP_K2_STRIDE]; };
+
+// `width` (< 32) bits at absolute bit index q; colAddr = this frame's ring column
+ZH_DEV uint32_t zq_field(const uint32_t* col, int32_t q, uint32_t width)
+{
+    const uint32_t* w = (const uint32_t*)((const uint8_t*)col + (zh_bfe((uint32_t)q, 5, 5) << 6));
+    return zh_bfe(zh_alignbit(w[16], w[0], (uint32_t)q), 0, width);
+}
+ZH_DEV void zq_commit(uint32_t* col, int32_t off, const ZpVec16& v)                // off % 16 == 0: four consecutive rows, no wrap inside
+{
+    const uint32_t r0 = ((uint32_t)off >> 2) & (ZQ_ROWS - 1);
+    uint32_t* q = col + (r0 << 4);
+    q[0] = v.a; q[16] = v.b; q[32] = v.c; q[48] = v.d;
+    if (r0 == 0) col[ZQ_ROWS << 4] = v.a;
+}
+ZH_DEV ZpVec16 zq_fetch(const uint8_t* p0, int32_t off) { return *(const ZpVec16*)(p0 + (uint32_t)(off < 0 ? 0 : off)); }
+
+ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
+{
+    const uint32_t lane = zh_lane(), role = lane & 3, slot = lane >> 2;
+    if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
+    if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
+    if (lane == 0) L.spare = 512;                    // the spare lane's one-cell "table": symbol 0, x = 512 -> with a 9-bit log no state bits, no extra bits
+    zh_sync();
+    const bool isOF = role == 0, isSpare = role == 3;
+    const uint32_t* const info = role == 1 ? L.mlInfo : L.llInfo;
+    const uint32_t tabOff = role == 0 ? ZP_FSE_OF : role == 1 ? ZP_FSE_ML : ZP_FSE_LL;
+    const uint32_t total = a.counters[1];
+    const uint32_t nGroups = (total + ZQ_FRAMES - 1) / ZQ_FRAMES;
+    for (;;) {
+        const uint32_t g = zh_first(zh_atomic_add(a.counters + 3, lane == 0 ? 1u : 0u));
+        if (g >= nGroups) break;
+        const uint32_t k = g * ZQ_FRAMES + slot;
+        const bool active = slot < ZQ_FRAMES && k < total;
+        const uint32_t i = active ? a.order[k] : 0xFFFFFFFFu;
+        zh_sync();
+        for (uint32_t j = 0; j < ZQ_FRAMES; j++) {                                 // the group's tables, HBM -> LDS (K1 built them)
+            const uint32_t fj = zh_shfl(i, 4 * j);
+            if (fj == 0xFFFFFFFFu) break;                                          // active quads are a prefix
+            const uint32_t* src = (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
+            uint32_t* dstw = (uint32_t*)(L.tab + (size_t)j * ZP_K2_STRIDE);
+            uint32_t r[ZP_FSE_CELLS / 128];
+#pragma unroll
+            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) r[q] = src[lane + 64 * q];
+#pragma unroll
+            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) dstw[lane + 64 * q] = r[q];
+        }
+        uint32_t* const col = L.ring + (active ? slot : 0u);
+        const uint16_t* const Tm = isSpare ? (const uint16_t*)&L.spare : (const uint16_t*)(L.tab + (size_t)(active ? slot : 0u) * ZP_K2_STRIDE) + tabOff;
+        ZdMeta* const m = a.meta + (active ? i : 0u);
+        const uint32_t f = a.first + (active ? i : 0u);
+        uint32_t nbSeq = 0, logs = 0;
+        int32_t pos = 0, pb = -(1 << 30), fin = 0;
+        const uint8_t* p0 = nullptr;
+        bool ok = active;
+        ZpVec16 v0, v1; v0.a = v0.b = v0.c = v0.d = 0; v1 = v0;
+        int32_t tb = 0;
+        if (active) {
+            const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+            const uint8_t* p = src + m->seqOff; const uint8_t* end = src + m->seqEnd;
+            const uint32_t size = (uint32_t)(end - p);
+            logs = m->logs;
+            const uint32_t lastB = size ? p[size - 1] : 0u;
+            if (lastB == 0) ok = false;                                            // empty stream or missing end mark
+            else {
+                nbSeq = m->nbSeq;
+                const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
+                p0 = p - mis; fin = (int32_t)(8 * mis);
+                const int32_t topByte = (int32_t)(mis + size) - 1;
+                tb = topByte & ~15;
+                v0 = zq_fetch(p0, tb - 16 * (int32_t)role); v1 = zq_fetch(p0, tb - 16 * (int32_t)(role + 4));   // the top 128 bytes: two blocks per lane
+                pb = tb - 128;
+                pos = 8 * topByte + zh_highbit32(lastB);
+            }
+        }
+        if (ok) { zq_commit(col, tb - 16 * (int32_t)role, v0); zq_commit(col, tb - 16 * (int32_t)(role + 4), v1); }
+        zh_sync();
+        const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
+        const uint32_t myLog = role == 0 ? ofLog : role == 1 ? mlLog : role == 2 ? llLog : 9u;
+        const uint32_t kk = 31 - myLog, mask = isSpare ? 0u : (1u << myLog) - 1;
+        uint32_t state;
+        {   const uint32_t initOff = role == 0 ? llLog : role == 1 ? llLog + ofLog : 0u;       // initial states: LL, OF, ML
+            state = zq_field(col, pos - (int32_t)(initOff + myLog), myLog) & mask;
+            pos -= (int32_t)(llLog + ofLog + mlLog); }
+        const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 1;                  // + 1: the loop is software-pipelined, the last trip drains it
+        uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
+        // the offset lane resolves the repeat offsets and stores; the other lanes' stores go to the frame's last arena slot (never a sequence:
+        // K1 refuses blocks of more than ZP_SEQ_CAP - 8), so the loop body has no branch. Lanes past their frame's last sequence run on
+        // harmlessly: every LDS access is masked, every fetch clamped, and their stores land in the unused tail of the frame's own arena slot.
+        // Trip n stores sequence n - 1: the offset lane starts one slot BEFORE its frame's -- the previous frame's parking slot, or the
+        // arena's front padding -- and simply advances by one every trip.
+        uint64_t* outp = a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 1;
+        const uint32_t outStep = isOF && active ? 1u : 0u;
+        int32_t boff = ZP_NOBLK, posEnd = pos; ZpVec16 blk = v0;
+        // The wave is alone on its SIMD and issues one instruction every ~6.5 cycles whatever it is (r02l: time = instructions x steps), so
+        // the body is written for instruction count first -- then software-pipelined by hand (as K2 above) so the LDS round trips of the
+        // chain are covered: the value / repeat-offset / pack / store work of sequence n - 1 sits right behind the requests of sequence n.
+        uint32_t pe0 = 0, pe1 = 0, pqE = 0, pbits = 0, pbase = 1;               // pending pieces of n - 1 (value 1 everywhere: "repeat rep0", a no-op)
+        for (uint32_t n0 = 0; n0 < nTrips; n0 += 4) {
+            zh_sync();                                       // (every lane is past the previous step's reads: the emulator's lanes are free-running fibers)
+            if (boff != ZP_NOBLK) { zq_commit(col, boff, blk); boff = ZP_NOBLK; }
+            {   // a block may replace ring bytes [off + 128, off + 144) once nothing at or above them will be read again
+                const int32_t t = pb + 128 - (((pos >> 5) << 2) + 4);
+                if ((int32_t)(role * 16) <= t) { boff = pb - 16 * (int32_t)role; blk = zq_fetch(p0, boff); }
+                int32_t cnt = (t >> 4) + 1; cnt = cnt < 0 ? 0 : cnt > 4 ? 4 : cnt;
+                pb -= 16 * cnt; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t n = n0 + u;
+                const uint32_t cell = Tm[state];
+                ZH_SCHED_FENCE();
+                // ---- sequence n - 1: value, choice of the offset (RFC 8878 3.1.1.5: idx 0 / 1 / 2 = a repeat offset, 3 = rep0 - 1 or a new one)
+                const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
+                const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
+                const uint32_t idx = val - 1 + (llv == 0);
+                const uint32_t r0m1 = rep0 - 1 > 1u ? rep0 - 1 : 1u;
+                const uint32_t c3 = val <= 3 ? r0m1 : val - 3;
+                uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
+                ZH_SCHED_FENCE();
+                // ---- the chain: cell -> bit counts -> where my state bits are -> next state
+                const uint32_t sym = cell >> 10, x = cell & 1023;
+                const uint32_t inf = info[sym];                                    // baseline | extra-bit count << 24
+                const uint32_t nb = (uint32_t)__builtin_clz(x) - kk;
+                ZH_SCHED_FENCE();
+                // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
+                rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
+                maxOff = offset > maxOff ? offset : maxOff;
+                *outp = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
+                outp += outStep;
+                ZH_SCHED_FENCE();
+                // ---- chain. Fields lie in the stream in the order OF, ML, LL extra bits, then LL, ML, OF state bits: inclusive prefix sums over
+                // the quad in two DPP adds each (the spare lane contributes zeros)
+                const uint32_t bits = isOF ? sym : inf >> 24;
+                const uint32_t P = zh_quad_add<0xCF>(zh_quad_add<0xD3>(bits, bits), bits);      // OF: e0, ML: e0 + e1, LL: e0 + e1 + e2
+                const uint32_t R = zh_quad_add<0xFE>(zh_quad_add<0xF9>(nb, nb), nb);            // LL: n2, ML: n2 + n1, OF: n2 + n1 + n0
+                const uint32_t totE = zh_quad<2>(P), totN = zh_quad<0>(R);
+                const int32_t pE = pos - (int32_t)totE;
+                const int32_t qS = pE - (int32_t)R, qE = pos - (int32_t)P;
+                const uint32_t* const wS = (const uint32_t*)((const uint8_t*)col + (zh_bfe((uint32_t)qS, 5, 5) << 6));
+                const uint32_t* const wE = (const uint32_t*)((const uint8_t*)col + (zh_bfe((uint32_t)qE, 5, 5) << 6));
+                const uint32_t s0 = wS[0], s1 = wS[16];
+                pe0 = wE[0]; pe1 = wE[16];
+                ZH_SCHED_FENCE();
+                pqE = (uint32_t)qE; pbits = bits;
+                posEnd = n + 1 == nbSeq ? pE : posEnd;         // no state update after the last sequence: the stream must end here
+                pos = pE - (int32_t)totN;
+                pbase = isOF ? 1u << (sym & 31) : inf & 0xFFFFFFu;
+                ZH_SCHED_FENCE();
+                state = ((x << nb) + zh_bfe(zh_alignbit(s1, s0, (uint32_t)qS), 0, nb)) & mask;
+            }
+        }
+        const uint32_t bad = maxOff >> 30;
+        if (active && isOF) {
+            const int err = !ok ? ZE_CORRUPTION : bad ? ZE_PARAM_UNSUPPORTED : posEnd != fin ? ZE_CORRUPTION : 0;
+            if (err == ZE_PARAM_UNSUPPORTED) {                                 // an offset does not fit the packed form: the generic kernel's
                 m->path = 2;
                 const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
             } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }

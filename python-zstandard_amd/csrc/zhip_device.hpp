@@ -32,6 +32,10 @@ ZH_DEV uint64_t zh_ballot(bool p) { return __ballot(p); }
 ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl((int)v, (int)srcLane, 64); }
 ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }
 ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// lane K of the caller's quad (lanes 4q .. 4q+3), to all four: a DPP quad_perm operand, no LDS crossbar trip
+template <int K> ZH_DEV uint32_t zh_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, false); }
+// v + (v of quad lane CTRL[2r+1:2r] for lane r of the quad): one v_add_u32_dpp
+template <int CTRL> ZH_DEV uint32_t zh_quad_add(uint32_t acc, uint32_t v) { return acc + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
@@ -49,6 +53,8 @@ ZH_DEV int zh_popc64(uint64_t v) { return __popcll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __ffsll((unsigned long long)v) - 1; }   // v != 0
 ZH_DEV int zh_clz64(uint64_t v) { return __clzll((long long)v); }                  // v != 0
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
+// the machine scheduler moves nothing across this point (hand-placed software pipelining stays where it was put)
+#define ZH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // v_bfe_u32: (v >> (off & 31)) & ((1 << (width & 31)) - 1); width 0 gives 0 whatever off is
 ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 // v_alignbit_b32: low 32 bits of ((hi:lo) >> (sh & 31))
@@ -101,6 +107,8 @@ ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d)
     return r;
 }
 ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
+template <int K> ZH_DEV uint32_t zh_quad(uint32_t v) { return zh_shfl(v, (zhemu::lane & ~3u) | (uint32_t)K); }
+template <int CTRL> ZH_DEV uint32_t zh_quad_add(uint32_t acc, uint32_t v) { return acc + zh_shfl(v, (zhemu::lane & ~3u) | ((CTRL >> (2 * (zhemu::lane & 3))) & 3)); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return __sync_fetch_and_add(p, v); }
 ZH_DEV void zh_atomic_add64(unsigned long long* p, unsigned long long v) { __sync_fetch_and_add(p, v); }
@@ -121,6 +129,7 @@ ZH_DEV uint32_t zh_wave_max(uint32_t v)
     return m;
 }
 ZH_DEV void ze_fence() { zhemu::collective_wait(); }
+#define ZH_SCHED_FENCE() do { } while (0)
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ZH_DEV int zh_clz64(uint64_t v) { return __builtin_clzll(v); }

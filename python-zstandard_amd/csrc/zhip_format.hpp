@@ -183,6 +183,7 @@ struct ZdMeta {
     uint32_t pad;
 };
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
+#define ZP_SEQ_FRONT 16u                               // slots of padding before the first frame's (K2's pipelined store of "sequence -1" lands there)
 #define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)
 #define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
 // per-frame FSE decoding tables in HBM / L2: 2-byte cells (symbol << 10 | x), LL 512 + ML 512 + OF 256 cells

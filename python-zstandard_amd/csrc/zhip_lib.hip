@@ -40,7 +40,12 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_huf_kernel(ZhipPipeArgs a)
     __shared__ ZpHufLDS L;
     zp_huf_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)           // K2: a quad of lanes per frame, four waves per CU
+{
+    __shared__ ZpSeqQLDS L;
+    zp_seqq_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)          // rounds 1-2 form (a lane per frame, one wave per CU): ZHIP_K2_QUAD=0, A/B only
 {
     __shared__ ZpSeqLDS L;
     zp_seq_body(a, L);
@@ -251,7 +256,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -275,6 +280,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
+        if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
     zh_resolve_rows(&c->rows, 3, nullptr);
@@ -510,7 +516,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
         if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
-            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16) ||
+            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return g_reserveRc;
         for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
@@ -538,7 +544,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * chunk;
             pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * chunk * ZP_LIT_STRIDE;
-            pa.seqArena = (uint64_t*)c->pipeSeq.p + (size_t)sidx * chunk * ZP_SEQ_CAP;
+            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * chunk * ZP_SEQ_CAP;
             pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * chunk * ZP_FSE_CELLS;
             pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * chunk;
             pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * chunk * ZP_HUF_CELLS;
@@ -549,7 +555,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (c->knob.k3PerCU) g3m = (size_t)c->numCU * (size_t)c->knob.k3PerCU;
             if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
             // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 60 lanes -> 1, 15 -> 4, 7 -> 8)
-            const size_t w2 = (cnt + ZP_K2_LANES - 1) / ZP_K2_LANES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqLDS));
+            const bool quad = c->knob.k2quad;
+            const size_t perWave = quad ? ZQ_FRAMES : ZP_K2_LANES;
+            const size_t w2 = (cnt + perWave - 1) / perWave, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / (quad ? sizeof(ZpSeqQLDS) : sizeof(ZpSeqLDS)));
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
@@ -565,7 +573,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
-            hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            else hipLaunchKernelGGL(zhip_decode_seq1_kernel, dim3(g2), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
             hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
@@ -605,7 +614,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                         m.seqOff, m.seqEnd, m.litSize, m.litMode, m.nbSeq, m.logs, m.produced, i, ord[i]);
                 if (m.nbSeq) {
                     uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8];
-                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + i * ZP_SEQ_CAP, sizeof q, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + i * ZP_SEQ_CAP, sizeof q, hipMemcpyDeviceToHost));
                     HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
                     fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
                             (uint32_t)q[0] & 0x1FFFF, (uint32_t)(q[0] >> 17) & 0x1FFFF, (uint32_t)(q[0] >> 34),

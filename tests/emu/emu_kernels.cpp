@@ -128,7 +128,12 @@ static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
 static ZpSeqLDS g_seqlds;
 static ZpHufLDS g_huflds;
 static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
+#ifdef ZP_K2_LANEWISE          // the lane-per-frame form kept for A/B (ZHIP_K2_QUAD=0 in the product)
 static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
+#else
+static ZpSeqQLDS g_seqqlds;
+static void k2_lane(void* p) { zp_seqq_body(*(const ZhipPipeArgs*)p, g_seqqlds); }
+#endif
 static void k3_lane(void* p) { zp_exec_body(*(const ZhipPipeArgs*)p, g_xlds); }
 extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst,
                                        const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status, uint32_t nBlocks, uint32_t chunk)
@@ -139,7 +144,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
     a.litArena = (uint8_t*)malloc((size_t)chunk * ZP_LIT_STRIDE);
-    a.seqArena = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE);
+    uint64_t* const seqAlloc = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8); a.seqArena = seqAlloc + ZP_SEQ_FRONT;
     a.fseTables = (uint16_t*)malloc((size_t)chunk * ZP_FSE_CELLS * 2);
     a.order = (uint32_t*)calloc(chunk, 4);
     a.hufTables = (uint16_t*)malloc((size_t)chunk * ZP_HUF_CELLS * 2 + 64);
@@ -154,7 +159,11 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         zhemu::run_grid(2, kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
         zhemu::run_grid(nBlocks, kh_lane, &a);
+#ifdef ZP_K2_LANEWISE
         memset(&g_seqlds, 0xA5, sizeof g_seqlds);
+#else
+        memset(&g_seqqlds, 0xA5, sizeof g_seqqlds);
+#endif
         zhemu::run_grid(nBlocks, k2_lane, &a);
         zhemu::run_grid(nBlocks, k3_lane, &a);
     }
@@ -167,7 +176,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[8];
-    free(g.scratch); free(a.meta); free(a.litArena); free(a.seqArena); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
+    free(g.scratch); free(a.meta); free(a.litArena); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
     return nfb;
 }
 
