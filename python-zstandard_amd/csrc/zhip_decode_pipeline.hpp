@@ -728,6 +728,17 @@ struct ZpExecLDS {
     uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
 };
 
+// K3's time is its instruction count (r02 SQ counters: issue-bound, 37 % scalar -- mostly exec-mask bookkeeping of predicated piece loads
+// and stores). A piece that is READ from LDS needs none of it: reading past an item is harmless there (the buffer has 64 bytes of slack),
+// so four unconditional reads replace the seven predicated ones (r02m: K3 8.68 -> 7.91 ms). The same trick on the store side -- a
+// predicated-off store redirected to a per-lane sink slot instead of being branched around -- LOST (9.08 ms: the branchy form skips
+// whole stores when no lane of the wave needs them, the sink form always issues all seven).
+ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])              // same contract as zd_ld32: r[3] = the last 8 bytes, or all of them below 8
+{
+    r[0] = zh_ld64(q); r[1] = zh_ld64(q + 8); r[2] = zh_ld64(q + 16);
+    r[3] = zh_ld64(q + (len >= 8 ? len - 8 : 0u));
+}
+
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
@@ -792,18 +803,17 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // loads fly together with the short ones.
             uint64_t rl[4], rm[4];
             const bool shortL = act && myLL > 0 && myLL <= ZD_COOP_LEN;
-            const bool shortFar = farM && myML <= ZD_COOP_LEN;
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
-            if (shortFar) zd_ld32(dst + sAbs, myML, rm);
             // a near match whose source starts before the batch: that part is global memory too and is fetched here like a far
-            // match (byte by byte in the dependency rounds it was a memory round trip per byte)
+            // match (byte by byte in the dependency rounds it was a memory round trip per byte). A lane has one or the other, so
+            // both go through ONE pair of piece loads / stores (r02l: K3's time is its instruction count, a pair is ~85 of ~770 per batch)
             const bool pre = hasM && !farM && sAbs < (int32_t)op;
             const uint32_t preLen = pre ? (uint32_t)((int32_t)op - sAbs) : 0u;
             nearSkip = preLen;
-            const bool shortPre = pre && preLen <= ZD_COOP_LEN;
-            if (shortPre) zd_ld32(dst + sAbs, preLen, rm);
-            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM && myML > ZD_COOP_LEN) || (pre && !shortPre);
             const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
+            const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN;
+            if (shortM) zd_ld32(dst + sAbs, lenMi, rm);
+            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM || pre) && !shortM;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
             const uint32_t ue = zh_scan_add(uL + uM);
             const uint32_t U = zh_shfl(ue, 63);
@@ -819,12 +829,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : dst + L.srcM[j_] + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
                 if (lane < U) ZP_UNIT(lane);
             }
-            if (shortL) {
-                if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }
-                zd_st32(asmb + oRel, myLL, rl);
-            }
-            if (shortFar) zd_st32(asmb + mRel, myML, rm);
-            if (shortPre) zd_st32(asmb + mRel, preLen, rm);
+            if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }      // (frame-uniform)
+            if (shortL) zd_st32(asmb + oRel, myLL, rl);
+            if (shortM) zd_st32(asmb + mRel, lenMi, rm);
             if (U) {
                 if (lane < U) { zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
                 for (uint32_t u = lane + 64; u < U; u += 64) { ZP_UNIT(u); zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
@@ -895,7 +902,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
                     if (myOF >= nLen) {
                         uint64_t rr[4];
-                        zd_ld32(asmb + nSrc, nLen, rr);
+                        zp_ld32_lds(asmb + nSrc, nLen, rr);
                         zd_st32(asmb + nDst, nLen, rr);
                     } else {
                         // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
@@ -905,7 +912,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                             const uint32_t ph = done % myOF;
                             uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
                             uint64_t rr[4];
-                            zd_ld32(asmb + nSrc + ph, c, rr);
+                            zp_ld32_lds(asmb + nSrc + ph, c, rr);
                             zd_st32(asmb + nDst + done, c, rr);
                             done += c;
                         }
@@ -930,7 +937,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
                     if (myOF >= nLen) {
                         uint64_t rr[4];
-                        zd_ld32(asmb + nSrc, nLen, rr);
+                        zp_ld32_lds(asmb + nSrc, nLen, rr);
                         zd_st32(asmb + nDst, nLen, rr);
                     } else {
                         // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
@@ -940,7 +947,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                             const uint32_t ph = done % myOF;
                             uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
                             uint64_t rr[4];
-                            zd_ld32(asmb + nSrc + ph, c, rr);
+                            zp_ld32_lds(asmb + nSrc + ph, c, rr);
                             zd_st32(asmb + nDst + done, c, rr);
                             done += c;
                         }
