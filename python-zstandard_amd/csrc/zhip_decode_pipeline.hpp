@@ -803,6 +803,16 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // loads fly together with the short ones.
             uint64_t rl[4], rm[4];
             const bool shortL = act && myLL > 0 && myLL <= ZD_COOP_LEN;
+#ifndef ZP_K3_NO_GLD
+            // the same economy on the global side where reading past the item cannot leave mapped memory: decoded literals live in our own
+            // arena (256 bytes of slack per frame); a match source at least 32 bytes below the end of the frame's output slot stays inside it.
+            // Lanes without an item read their frame's first bytes. Raw literals (read from the caller's source) keep the exact form.
+            const bool arenaLit = m.litMode != 0;                                   // (frame-uniform)
+            if (arenaLit && !litRLE) {
+                const uint8_t* q = litPtr + (shortL ? litStart : 0u);
+                rl[0] = zh_ld64(q); rl[1] = zh_ld64(q + 8); rl[2] = zh_ld64(q + 16); rl[3] = zh_ld64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
+            } else
+#endif
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
             // a near match whose source starts before the batch: that part is global memory too and is fetched here like a far
             // match (byte by byte in the dependency rounds it was a memory round trip per byte). A lane has one or the other, so
@@ -812,6 +822,12 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             nearSkip = preLen;
             const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
             const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN;
+#ifndef ZP_K3_NO_GLD
+            if (!zh_ballot(shortM && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {
+                const uint8_t* q = dst + (shortM ? (uint32_t)sAbs : 0u);
+                rm[0] = zh_ld64(q); rm[1] = zh_ld64(q + 8); rm[2] = zh_ld64(q + 16); rm[3] = zh_ld64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
+            } else
+#endif
             if (shortM) zd_ld32(dst + sAbs, lenMi, rm);
             const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM || pre) && !shortM;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
