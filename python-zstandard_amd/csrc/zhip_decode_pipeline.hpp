@@ -603,7 +603,8 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) dstw[lane + 64 * q] = r[q];
         }
         uint32_t* const col = L.ring + (active ? slot : 0u);
-        const uint16_t* const Tm = isSpare ? (const uint16_t*)&L.spare : (const uint16_t*)(L.tab + (size_t)(active ? slot : 0u) * ZP_K2_STRIDE) + tabOff;
+        const bool idle = isSpare || !active;                                      // idle lanes decode the one-cell table: no bits, the same state for ever
+        const uint16_t* const Tm = idle ? (const uint16_t*)&L.spare : (const uint16_t*)(L.tab + (size_t)slot * ZP_K2_STRIDE) + tabOff;
         ZdMeta* const m = a.meta + (active ? i : 0u);
         const uint32_t f = a.first + (active ? i : 0u);
         uint32_t nbSeq = 0, logs = 0;
@@ -633,11 +634,14 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         if (ok) { zq_commit(col, tb - 16 * (int32_t)role, v0); zq_commit(col, tb - 16 * (int32_t)(role + 4), v1); }
         zh_sync();
         const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
-        const uint32_t myLog = role == 0 ? ofLog : role == 1 ? mlLog : role == 2 ? llLog : 9u;
-        const uint32_t kk = 31 - myLog, mask = isSpare ? 0u : (1u << myLog) - 1;
+        const uint32_t myLog = idle ? 9u : role == 0 ? ofLog : role == 1 ? mlLog : llLog;
+        const uint32_t kk = 31 - myLog, size = 1u << myLog;
+        // `state` is kept as table index + table size: the update (x << nbBits) + bits lands in [size, 2 size) by construction, so the cell
+        // pointer is biased by -size instead of masking every step (the spare lane's one cell answers x = 512, no bits: always index 512)
+        const uint16_t* const Tb = Tm - size;
         uint32_t state;
         {   const uint32_t initOff = role == 0 ? llLog : role == 1 ? llLog + ofLog : 0u;       // initial states: LL, OF, ML
-            state = zq_field(col, pos - (int32_t)(initOff + myLog), myLog) & mask;
+            state = idle ? size : size + zq_field(col, pos - (int32_t)(initOff + myLog), myLog);
             pos -= (int32_t)(llLog + ofLog + mlLog); }
         const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 1;                  // + 1: the loop is software-pipelined, the last trip drains it
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
@@ -664,7 +668,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t n = n0 + u;
-                const uint32_t cell = Tm[state];
+                const uint32_t cell = Tb[state];
                 ZH_SCHED_FENCE();
                 // ---- sequence n - 1: value, choice of the offset (RFC 8878 3.1.1.5: idx 0 / 1 / 2 = a repeat offset, 3 = rep0 - 1 or a new one)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
@@ -703,7 +707,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 pos = pE - (int32_t)totN;
                 pbase = isOF ? 1u << (sym & 31) : inf & 0xFFFFFFu;
                 ZH_SCHED_FENCE();
-                state = ((x << nb) + zh_bfe(zh_alignbit(s1, s0, (uint32_t)qS), 0, nb)) & mask;
+                state = (x << nb) + zh_bfe(zh_alignbit(s1, s0, (uint32_t)qS), 0, nb);
             }
         }
         const uint32_t bad = maxOff >> 30;
