@@ -4,6 +4,7 @@
 #   libzstd_hip_huf{16,4}.so      -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
 #   libzstd_hip_longone.so        -DZP_K3_LONGONE     K3: one ready long match per dependency round (round 1's form)
 #   libzstd_hip_nogld.so          -DZP_K3_NO_GLD      K3: the exact (predicated) piece loads from global memory everywhere (r02n)
+#   libzstd_hip_zqf{1,0}.so       -DZQ_FENCES=n       K2: fewer / no scheduling fences around the hand-placed pipeline sections (r02q)
 #   libzstd_hip_tab3.so           -DZE_TAB3           entropy kernel: the three sequence tables built by three lanes at once
 #   libzstd_hip_e1l{16,32,64}.so  -DZE_E1_LANES=n     lane-serial match kernel (dictionary / fast-strategy batches): n frames per wave instead of 8
 #   libzstd_hip_pf.so             -DZP_K3_PREFETCH    K3: the next batch's far-match source lines touched a batch ahead
@@ -28,6 +29,8 @@ for v in $ALL; do
     huf4) build huf4 -DZP_HUF_FRAMES=4 & ;;
     longone) build longone -DZP_K3_LONGONE & ;;
     nogld) build nogld -DZP_K3_NO_GLD & ;;
+    zqf1) build zqf1 -DZQ_FENCES=1 & ;;
+    zqf0) build zqf0 -DZQ_FENCES=0 & ;;
     tab3) build tab3 -DZE_TAB3 & ;;
     co40p) build co40p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=40 -DZP_K2_PRIO=3 & ;;
     co44p) build co44p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=44 -DZP_K2_PRIO=3 & ;;

@@ -193,10 +193,14 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
     for (uint32_t b = lane; b < 256; b += 64) L.hist[b] = 0;
     zh_sync();
 #define ZP_BIN_KEY(m) (lit ? (((m)->litMode & 255u) == 3u ? 1u + ((m)->litSize >> ZP_LITBIN_SHIFT) : 0u) : ((m)->nbSeq ? 1u + ((m)->nbSeq >> ZP_BIN_SHIFT) : 0u))
-    for (uint32_t i = lane; i < a.count; i += 64) {
-        const ZdMeta* m = a.meta + i;
-        const uint32_t k = m->path == 1 ? ZP_BIN_KEY(m) : 0u;
-        if (k) zh_lds_atomic_inc(&L.hist[256 - (k > 256 ? 256 : k)]);
+    // two waves walk the whole chunk's meta records: eight records per lane in flight per trip (one at a time it was a memory round trip
+    // per 64 frames: 0.49 ms per 32 768 -- r02 kernel trace)
+    for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
+        uint32_t k[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 64 * u; const ZdMeta* m = a.meta + (i < a.count ? i : 0u); k[u] = i < a.count && m->path == 1 ? ZP_BIN_KEY(m) : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) if (k[u]) zh_lds_atomic_inc(&L.hist[256 - (k[u] > 256 ? 256 : k[u])]);
     }
     zh_sync();
     if (zh_opaque(lane) == 0) {
@@ -205,10 +209,12 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
         a.counters[lit ? 4 : 1] = run;
     }
     zh_sync();
-    for (uint32_t i = lane; i < a.count; i += 64) {
-        const ZdMeta* m = a.meta + i;
-        const uint32_t k = m->path == 1 ? ZP_BIN_KEY(m) : 0u;
-        if (k) order[zh_lds_atomic_add(&L.base[256 - (k > 256 ? 256 : k)], 1u)] = i;
+    for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
+        uint32_t k[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 64 * u; const ZdMeta* m = a.meta + (i < a.count ? i : 0u); k[u] = i < a.count && m->path == 1 ? ZP_BIN_KEY(m) : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) if (k[u]) order[zh_lds_atomic_add(&L.base[256 - (k[u] > 256 ? 256 : k[u])], 1u)] = i0 + 64 * u;
     }
 #undef ZP_BIN_KEY
     zd_fence();
@@ -572,6 +578,19 @@ ZH_DEV void zq_commit(uint32_t* col, int32_t off, const ZpVec16& v)             
 }
 ZH_DEV ZpVec16 zq_fetch(const uint8_t* p0, int32_t off) { return *(const ZpVec16*)(p0 + (uint32_t)(off < 0 ? 0 : off)); }
 
+#ifndef ZQ_FENCES
+#define ZQ_FENCES 1             // 2: every hand-placed section stays where it is; 1: only "cell request first" (r02q: 6.64 ms against 6.89 / 6.88); 0: the scheduler's order
+#endif
+#if ZQ_FENCES >= 1
+#define ZQ_F1() ZH_SCHED_FENCE()
+#else
+#define ZQ_F1() do { } while (0)
+#endif
+#if ZQ_FENCES >= 2
+#define ZQ_F2() ZH_SCHED_FENCE()
+#else
+#define ZQ_F2() do { } while (0)
+#endif
 ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 {
     const uint32_t lane = zh_lane(), role = lane & 3, slot = lane >> 2;
@@ -669,7 +688,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t n = n0 + u;
                 const uint32_t cell = Tb[state];
-                ZH_SCHED_FENCE();
+                ZQ_F1();
                 // ---- sequence n - 1: value, choice of the offset (RFC 8878 3.1.1.5: idx 0 / 1 / 2 = a repeat offset, 3 = rep0 - 1 or a new one)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
                 const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
@@ -677,18 +696,18 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t r0m1 = rep0 - 1 > 1u ? rep0 - 1 : 1u;
                 const uint32_t c3 = val <= 3 ? r0m1 : val - 3;
                 uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
-                ZH_SCHED_FENCE();
+                ZQ_F2();
                 // ---- the chain: cell -> bit counts -> where my state bits are -> next state
                 const uint32_t sym = cell >> 10, x = cell & 1023;
                 const uint32_t inf = info[sym];                                    // baseline | extra-bit count << 24
                 const uint32_t nb = (uint32_t)__builtin_clz(x) - kk;
-                ZH_SCHED_FENCE();
+                ZQ_F2();
                 // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
                 rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
                 maxOff = offset > maxOff ? offset : maxOff;
                 *outp = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
                 outp += outStep;
-                ZH_SCHED_FENCE();
+                ZQ_F2();
                 // ---- chain. Fields lie in the stream in the order OF, ML, LL extra bits, then LL, ML, OF state bits: inclusive prefix sums over
                 // the quad in two DPP adds each (the spare lane contributes zeros)
                 const uint32_t bits = isOF ? sym : inf >> 24;
@@ -701,12 +720,12 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t* const wE = (const uint32_t*)((const uint8_t*)col + (zh_bfe((uint32_t)qE, 5, 5) << 6));
                 const uint32_t s0 = wS[0], s1 = wS[16];
                 pe0 = wE[0]; pe1 = wE[16];
-                ZH_SCHED_FENCE();
+                ZQ_F2();
                 pqE = (uint32_t)qE; pbits = bits;
                 posEnd = n + 1 == nbSeq ? pE : posEnd;         // no state update after the last sequence: the stream must end here
                 pos = pE - (int32_t)totN;
                 pbase = isOF ? 1u << (sym & 31) : inf & 0xFFFFFFu;
-                ZH_SCHED_FENCE();
+                ZQ_F2();
                 state = (x << nb) + zh_bfe(zh_alignbit(s1, s0, (uint32_t)qS), 0, nb);
             }
         }
