@@ -132,7 +132,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 m.nbSeq = nbSeq;
                 if (nbSeq == 0) { if (sp != send) { err = ZE_CORRUPTION; break; } }
                 else {
-                    if (nbSeq > ZP_SEQ_CAP - 8) { err = ZE_CORRUPTION; break; }      // (> 43 690 cannot fit a block; K2 stores a few slots past the longest frame of its wave and parks idle lanes' stores in the last)
+                    if (nbSeq > ZP_SEQ_CAP - 16) { err = ZE_CORRUPTION; break; }      // (> 43 690 cannot fit a block; K2 stores a few slots past the longest frame of its wave and parks idle lanes' stores in the last)
                     if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
                     const uint32_t modes = *sp++;
                     if (modes & 3) { err = ZE_CORRUPTION; break; }
@@ -192,13 +192,18 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
     uint32_t* const order = lit ? a.orderLit : a.order;
     for (uint32_t b = lane; b < 256; b += 64) L.hist[b] = 0;
     zh_sync();
-#define ZP_BIN_KEY(m) (lit ? (((m)->litMode & 255u) == 3u ? 1u + ((m)->litSize >> ZP_LITBIN_SHIFT) : 0u) : ((m)->nbSeq ? 1u + ((m)->nbSeq >> ZP_BIN_SHIFT) : 0u))
+    // the sort key of eight records per lane: every field is loaded before any is looked at (written as nested conditions the loads were
+    // four dependent round trips per record: r02 kernel trace 0.49 ms per 32 768 frames for two waves)
+#define ZP_BIN_KEYS(k, i0) do { uint32_t pa_[8], ns_[8], lm_[8], ls_[8]; \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < 8; u_++) { const uint32_t i_ = (i0) + 64 * u_; const ZdMeta* m_ = a.meta + (i_ < a.count ? i_ : 0u); \
+            pa_[u_] = m_->path; ns_[u_] = m_->nbSeq; lm_[u_] = m_->litMode; ls_[u_] = m_->litSize; } \
+        _Pragma("unroll") for (uint32_t u_ = 0; u_ < 8; u_++) { const uint32_t kl_ = (lm_[u_] & 255u) == 3u ? 1u + (ls_[u_] >> ZP_LITBIN_SHIFT) : 0u, ks_ = ns_[u_] ? 1u + (ns_[u_] >> ZP_BIN_SHIFT) : 0u; \
+            (k)[u_] = (i0) + 64 * u_ < a.count && pa_[u_] == 1 ? (lit ? kl_ : ks_) : 0u; } } while (0)
     // two waves walk the whole chunk's meta records: eight records per lane in flight per trip (one at a time it was a memory round trip
     // per 64 frames: 0.49 ms per 32 768 -- r02 kernel trace)
     for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
         uint32_t k[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 64 * u; const ZdMeta* m = a.meta + (i < a.count ? i : 0u); k[u] = i < a.count && m->path == 1 ? ZP_BIN_KEY(m) : 0u; }
+        ZP_BIN_KEYS(k, i0);
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) if (k[u]) zh_lds_atomic_inc(&L.hist[256 - (k[u] > 256 ? 256 : k[u])]);
     }
@@ -211,12 +216,11 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
     zh_sync();
     for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
         uint32_t k[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) { const uint32_t i = i0 + 64 * u; const ZdMeta* m = a.meta + (i < a.count ? i : 0u); k[u] = i < a.count && m->path == 1 ? ZP_BIN_KEY(m) : 0u; }
+        ZP_BIN_KEYS(k, i0);
 #pragma unroll
         for (uint32_t u = 0; u < 8; u++) if (k[u]) order[zh_lds_atomic_add(&L.base[256 - (k[u] > 256 ? 256 : k[u])], 1u)] = i0 + 64 * u;
     }
-#undef ZP_BIN_KEY
+#undef ZP_BIN_KEYS
     zd_fence();
 }
 
@@ -327,14 +331,20 @@ ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t
         const uint32_t ib_ = top_ >> sh; sb = symTab[ib_]; B.used += la_ + ZP_LEN(ib_); zb_refill(B); } while (0)
     const uint32_t sh = 32 - log;
     uint32_t i = 0;
+    // vmcnt counts loads AND stores on gfx9 and the compiler waits conservatively once both are in flight: a store issued right before
+    // a burst made the burst's "blocks have arrived" wait sit out the store's own round trip every trip (r02r: the same effect was 17 %
+    // of K2). So a trip's eight symbols are stored at the top of the NEXT trip, behind the burst's commits and requests.
+    uint64_t pend = 0;
     while (i + 8 <= count) {                    // two symbols (<= 22 bits) per window, eight per trip and per 8-byte store
         zb_burst(B);
+        if (i) zh_st64(out + i - 8, pend);
         uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
         ZP_PAIR(s0, s1); ZP_PAIR(s2, s3); ZP_PAIR(s4, s5); ZP_PAIR(s6, s7);
-        zh_st64(out + i, (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32));
+        pend = (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32);
         i += 8;
     }
     zb_burst(B);                                // the tail (<= 7 symbols) reads what the last burst requested
+    if (i) zh_st64(out + i - 8, pend);
     while (i < count) {
         const uint32_t ix = zb_top(B) >> sh;
         B.used += ZP_LEN(ix);
@@ -662,15 +672,18 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         {   const uint32_t initOff = role == 0 ? llLog : role == 1 ? llLog + ofLog : 0u;       // initial states: LL, OF, ML
             state = idle ? size : size + zq_field(col, pos - (int32_t)(initOff + myLog), myLog);
             pos -= (int32_t)(llLog + ofLog + mlLog); }
-        const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 1;                  // + 1: the loop is software-pipelined, the last trip drains it
+        const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 5;                  // trip n produces sequence n - 1 (software pipeline); a group of four is stored at the next group's first trip
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
         // the offset lane resolves the repeat offsets and stores; the other lanes' stores go to the frame's last arena slot (never a sequence:
-        // K1 refuses blocks of more than ZP_SEQ_CAP - 8), so the loop body has no branch. Lanes past their frame's last sequence run on
+        // K1 refuses blocks of more than ZP_SEQ_CAP - 16), so the loop body has no branch. Lanes past their frame's last sequence run on
         // harmlessly: every LDS access is masked, every fetch clamped, and their stores land in the unused tail of the frame's own arena slot.
-        // Trip n stores sequence n - 1: the offset lane starts one slot BEFORE its frame's -- the previous frame's parking slot, or the
-        // arena's front padding -- and simply advances by one every trip.
-        uint64_t* outp = a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 1;
-        const uint32_t outStep = isOF && active ? 1u : 0u;
+        // Sequences leave in groups of four -- 32 aligned bytes, two 16-byte stores (one 8-byte store per step was a partial-sector write
+        // each: r02 WRITE_SIZE 242 KB per frame for ~80 KB of sequences). Sequences 4g .. 4g + 3 come out of trips 4g + 1 .. 4g + 4, so a
+        // group is stored at the first trip of the NEXT group; the very first store holds nothing and lands four slots before the
+        // frame's -- the previous frame's unused tail, or the arena's front padding.
+        ZpVec16* outp = (ZpVec16*)(a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 4);
+        const uint32_t outStep = isOF && active ? 2u : 0u;
+        uint32_t g1lo = 0, g1hi = 0, g2lo = 0, g2hi = 0, g3lo = 0, g3hi = 0;       // the group's first three packed sequences
         int32_t boff = ZP_NOBLK, posEnd = pos; ZpVec16 blk = v0;
         // The wave is alone on its SIMD and issues one instruction every ~6.5 cycles whatever it is (r02l: time = instructions x steps), so
         // the body is written for instruction count first -- then software-pipelined by hand (as K2 above) so the LDS round trips of the
@@ -705,8 +718,11 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
                 rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
                 maxOff = offset > maxOff ? offset : maxOff;
-                *outp = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
-                outp += outStep;
+                {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 2);
+                    if (u == 0) {                                                     // (compile-time: the loop is unrolled)
+                        ZpVec16 w0, w1; w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
+                        outp[0] = w0; outp[1] = w1; outp += outStep;
+                    } else if (u == 1) { g1lo = plo; g1hi = phi; } else if (u == 2) { g2lo = plo; g2hi = phi; } else { g3lo = plo; g3hi = phi; } }
                 ZQ_F2();
                 // ---- chain. Fields lie in the stream in the order OF, ML, LL extra bits, then LL, ML, OF state bits: inclusive prefix sums over
                 // the quad in two DPP adds each (the spare lane contributes zeros)
@@ -1035,6 +1051,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             if (nML && nOF && nSrc >= 0 && nSrc < (int64_t)op) pfWord = dst[nSrc];
         }
 #endif
+        // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
+        // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
+        qNext = zh_opaque64(qNext);
         {
             uint8_t* out = dst + op;
             for (uint32_t j = lane * 16; j < totT; j += 1024) {
