@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_boundary.py -m gpu -x -q > $O/r02r_pytest.log 2>&1; tail -3 $O/r02r_pytest.log
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/r02r_pytest.log 2>&1; tail -3 $O/r02r_pytest.log
 run() { tag=$1; shift
   env "$@" timeout 400 python bench.py --config decompress --no-cpu-baseline --steps 5 > $O/r02r_$tag.json 2> $O/r02r_$tag.err
   python - $tag $O/r02r_$tag.json <<'PY'
@@ -15,14 +15,3 @@ PY
 }
 run iso ZHIP_NSLOT=1
 run full ZHIP_X=1
-P=$O/prof_r02r; rm -rf $P; mkdir -p $P
-timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P -- python bench.py --frames 32768 --warmup 1 --no-cpu-baseline --steps 1 --compress-frames 0 > $P/bench.json 2> $P/err.log
-python - $P <<'PY'
-import csv, glob, sys, collections
-acc = collections.defaultdict(list)
-for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(path)):
-        if "zhip_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "WRITE_SIZE": acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-for k, v in acc.items(): print(k, "WRITE_SIZE KiB per launch", sum(v) / len(v), "per frame KB", sum(v) / len(v) * 1024 / 32768 / 1000)
-PY
-rm -rf $P
