@@ -962,14 +962,16 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     } else {
                         // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
                         // step can copy as much as is already final -- the copied length doubles instead of advancing a byte at a time
-                        uint32_t done = 0;
+                        // (what has been written is final and periodic, so the source is simply the `span` bytes before the write
+                        // position, span a multiple of the period that doubles while whole spans are copied -- no division)
+                        uint32_t done = 0, span = myOF;
                         while (done < nLen) {
-                            const uint32_t ph = done % myOF;
-                            uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
+                            uint32_t c = span; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
                             uint64_t rr[4];
-                            zp_ld32_lds(asmb + nSrc + ph, c, rr);
+                            zp_ld32_lds(asmb + nDst + done - span, c, rr);
                             zd_st32(asmb + nDst + done, c, rr);
                             done += c;
+                            if (c == span) span += span;
                         }
                     }
                     pending = false;
@@ -997,14 +999,16 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     } else {
                         // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
                         // step can copy as much as is already final -- the copied length doubles instead of advancing a byte at a time
-                        uint32_t done = 0;
+                        // (what has been written is final and periodic, so the source is simply the `span` bytes before the write
+                        // position, span a multiple of the period that doubles while whole spans are copied -- no division)
+                        uint32_t done = 0, span = myOF;
                         while (done < nLen) {
-                            const uint32_t ph = done % myOF;
-                            uint32_t c = myOF + done - ph; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
+                            uint32_t c = span; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
                             uint64_t rr[4];
-                            zp_ld32_lds(asmb + nSrc + ph, c, rr);
+                            zp_ld32_lds(asmb + nDst + done - span, c, rr);
                             zd_st32(asmb + nDst + done, c, rr);
                             done += c;
+                            if (c == span) span += span;
                         }
                     }
                     pending = false;

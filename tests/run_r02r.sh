@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=gpurun_out; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/r02r_pytest.log 2>&1; tail -3 $O/r02r_pytest.log
+timeout 900 python -m pytest tests/test_gpu_decompress.py -m gpu -x -q > $O/r02r_pytest.log 2>&1; tail -3 $O/r02r_pytest.log
 run() { tag=$1; shift
   env "$@" timeout 400 python bench.py --config decompress --no-cpu-baseline --steps 5 > $O/r02r_$tag.json 2> $O/r02r_$tag.err
   python - $tag $O/r02r_$tag.json <<'PY'

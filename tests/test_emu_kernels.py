@@ -217,6 +217,13 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
         else: r = bytes(rng.integers(0, 5, n, dtype=np.uint8))
         raws.append(r)
     raws += [b"ab" * 40000, b"x" * 100000, b"0123456789" * 9000]
+    # short self-overlapping matches (offset < length <= 32: K3's doubling copy, capped and uncapped): periods 1..9, runs of 5..60 bytes
+    for _ in range(2):
+        parts = []
+        for k in range(3000):
+            per = int(rng.integers(1, 10)); run = int(rng.integers(5, 61))
+            parts.append((rng.bytes(per) * (run // per + 2))[:run]); parts.append(rng.bytes(int(rng.integers(1, 6))))
+        raws.append(b"".join(parts)[:131072])
     frames = [ref.compress(r, level=3, flags=7 if i % 2 else 5) for i, r in enumerate(raws)]
     outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws], n_blocks=3, chunk=0)
     assert not any(st) and nfb == 0
