@@ -1411,3 +1411,26 @@ int64_t zo_compress_frame(void* dstv, size_t dstCap, const void* srcv, size_t sr
     zo_cdict_free(cd);
     return (int64_t)pos;
 }
+
+/* ------------------------------------------------------------------ test hooks (tests/test_emu_kernels.py): the table builders on their own,
+ * so that the wave-parallel builders of the HIP encoder can be checked against this serial restatement on arbitrary histograms */
+int zo_test_fse_tables(const unsigned* count, unsigned maxSym, unsigned total, unsigned log, int useLowProb,
+                       int16_t* normOut /* 64 */, uint8_t* ncountOut /* 512 */, unsigned* ncountSize, uint16_t* cellOf /* 66 */, uint16_t* next /* 512 */)
+{
+    int16_t norm[64]; memset(norm, 0, sizeof norm);
+    if (fse_normalize(norm, log, count, total, maxSym, useLowProb) < 0) return -1;
+    memcpy(normOut, norm, sizeof norm);
+    *ncountSize = (unsigned)fse_write_ncount(ncountOut, norm, maxSym, log);
+    fse_ctab t; memset(&t, 0, sizeof t);
+    fse_build_ctab(&t, norm, maxSym, log);
+    for (unsigned s = 0; s <= maxSym + 1; s++) cellOf[s] = t.cellOf[s];
+    for (unsigned u = 0; u < (1u << log); u++) next[u] = t.next[u];
+    return 0;
+}
+unsigned zo_test_huf_build(const unsigned* count, unsigned maxSym, unsigned maxBits, uint8_t* nbBits /* 256 */, uint16_t* code /* 256 */)
+{
+    huf_ctab ct; memset(&ct, 0, sizeof ct);
+    const unsigned log = huf_build(&ct, count, maxSym, maxBits);
+    memcpy(nbBits, ct.nbBits, 256); memcpy(code, ct.code, 512);
+    return log;
+}

@@ -5,7 +5,6 @@
 #   libzstd_hip_longone.so        -DZP_K3_LONGONE     K3: one ready long match per dependency round (round 1's form)
 #   libzstd_hip_nogld.so          -DZP_K3_NO_GLD      K3: the exact (predicated) piece loads from global memory everywhere (r02n)
 #   libzstd_hip_zqf{1,0}.so       -DZQ_FENCES=n       K2: fewer / no scheduling fences around the hand-placed pipeline sections (r02q)
-#   libzstd_hip_tab3.so           -DZE_TAB3           entropy kernel: the three sequence tables built by three lanes at once
 #   libzstd_hip_e1l{16,32,64}.so  -DZE_E1_LANES=n     lane-serial match kernel (dictionary / fast-strategy batches): n frames per wave instead of 8
 #   libzstd_hip_pf.so             -DZP_K3_PREFETCH    K3: the next batch's far-match source lines touched a batch ahead
 #   libzstd_hip_asm2k.so          -DZP_ASM_BYTES=2048 K3: 2 KiB batch assembly buffer (3.7 KiB of LDS per wave instead of 5.7)
@@ -18,7 +17,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 B="$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared"
 want() { [ $# -eq 0 ] && return 0; }
 build() { name=$1; shift; $B "$@" -o libzstd_hip_$name.so zhip_lib.hip; }
-ALL="k2l30 k2l15 k2l7 huf16 huf4 longone tab3 asm2k co36 co40 co44 co48 pf co40p co44p co48p basep e1l16 e1l32 e1l64"
+ALL="k2l30 k2l15 k2l7 huf16 huf4 longone asm2k co36 co40 co44 co48 pf co40p co44p co48p basep e1l16 e1l32 e1l64"
 [ $# -gt 0 ] && ALL="$*"
 for v in $ALL; do
   case $v in
@@ -31,7 +30,6 @@ for v in $ALL; do
     nogld) build nogld -DZP_K3_NO_GLD & ;;
     zqf1) build zqf1 -DZQ_FENCES=1 & ;;
     zqf0) build zqf0 -DZQ_FENCES=0 & ;;
-    tab3) build tab3 -DZE_TAB3 & ;;
     co40p) build co40p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=40 -DZP_K2_PRIO=3 & ;;
     co44p) build co44p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=44 -DZP_K2_PRIO=3 & ;;
     co48p) build co48p -DZP_ASM_BYTES=2048 -DZP_K2_LANES=48 -DZP_K2_PRIO=3 & ;;

@@ -85,7 +85,7 @@ ZH_DEV uint32_t ze_bw_close(ZeBits& b)      // end mark + padding; 0 on overflow
     return b.pos > b.cap ? 0 : b.pos;
 }
 
-// ------------------------------------------------------------------------------------------ FSE, compression side (lane 0)
+// ------------------------------------------------------------------------------------------ FSE, compression side
 // FSE_optimalTableLog_internal, zstd.c:16294
 ZH_DEV uint32_t ze_fse_optimal_log(uint32_t maxLog, uint32_t n, uint32_t maxSym, uint32_t minus)
 {
@@ -100,135 +100,6 @@ ZH_DEV uint32_t ze_fse_optimal_log(uint32_t maxLog, uint32_t n, uint32_t maxSym,
     return lg;
 }
 
-// FSE_normalizeM2, zstd.c:16316
-ZH_DEVFN int ze_fse_normalize_m2(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, int lowProb)
-{
-    const int16_t UNSET = -2;
-    uint32_t distributed = 0;
-    uint32_t lowThreshold = total >> lg;
-    uint32_t lowOne = (uint32_t)(((uint64_t)total * 3) >> (lg + 1));
-    for (uint32_t s = 0; s <= maxSym; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = (int16_t)lowProb; distributed++; total -= count[s]; continue; }
-        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
-        norm[s] = UNSET;
-    }
-    uint32_t toDistribute = (1u << lg) - distributed;
-    if (toDistribute == 0) return 0;
-    if ((total / toDistribute) > lowOne) {
-        lowOne = (uint32_t)(((uint64_t)total * 3) / (toDistribute * 2));
-        for (uint32_t s = 0; s <= maxSym; s++)
-            if (norm[s] == UNSET && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
-        toDistribute = (1u << lg) - distributed;
-    }
-    if (distributed == maxSym + 1) {
-        uint32_t maxV = 0, maxC = 0;
-        for (uint32_t s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
-        norm[maxV] = (int16_t)(norm[maxV] + (int16_t)toDistribute);
-        return 0;
-    }
-    if (total == 0) {
-        for (uint32_t s = 0; toDistribute > 0; s = (s + 1) % (maxSym + 1))
-            if (norm[s] > 0) { toDistribute--; norm[s]++; }
-        return 0;
-    }
-    {
-        const uint64_t vStepLog = 62 - lg, mid = (1ull << (vStepLog - 1)) - 1;
-        const uint64_t rStep = (((1ull << vStepLog) * toDistribute) + mid) / total;
-        uint64_t tmpTotal = mid;
-        for (uint32_t s = 0; s <= maxSym; s++) if (norm[s] == UNSET) {
-            uint64_t end = tmpTotal + (uint64_t)count[s] * rStep;
-            uint32_t weight = (uint32_t)(end >> vStepLog) - (uint32_t)(tmpTotal >> vStepLog);
-            if (weight < 1) return -1;
-            norm[s] = (int16_t)weight;
-            tmpTotal = end;
-        }
-    }
-    return 0;
-}
-
-ZH_CONST uint32_t ze_rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
-// FSE_normalizeCount, zstd.c:16402
-ZH_DEVFN int ze_fse_normalize(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, int useLowProb)
-{
-    const uint32_t* rtb = ze_rtb;
-    const int lowProb = useLowProb ? -1 : 1;
-    const uint64_t scale = 62 - lg, step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
-    int still = 1 << lg;
-    uint32_t largest = 0; int16_t largestP = 0;
-    const uint32_t lowThreshold = total >> lg;
-    for (uint32_t s = 0; s <= maxSym; s++) {
-        if (count[s] == total) return 0;
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = (int16_t)lowProb; still--; }
-        else {
-            int16_t proba = (int16_t)(((uint64_t)count[s] * step) >> scale);
-            if (proba < 8) {
-                uint64_t restToBeat = vStep * rtb[proba];
-                proba = (int16_t)(proba + ((((uint64_t)count[s] * step) - ((uint64_t)proba << scale)) > restToBeat));
-            }
-            if (proba > largestP) { largestP = proba; largest = s; }
-            norm[s] = proba; still -= proba;
-        }
-    }
-    if (-still >= (norm[largest] >> 1)) return ze_fse_normalize_m2(norm, lg, count, total, maxSym, lowProb);
-    norm[largest] = (int16_t)(norm[largest] + (int16_t)still);
-    return 0;
-}
-
-// FSE_writeNCount_generic, zstd.c:16170. Returns bytes written.
-ZH_DEVFN uint32_t ze_fse_write_ncount(uint8_t* out, const int16_t* norm, uint32_t maxSym, uint32_t lg)
-{
-    ZeBits b; ze_bw_init(b, out, 512);
-    const uint32_t alphabet = maxSym + 1;
-    int remaining = (1 << lg) + 1, threshold = 1 << lg, nbBits = (int)lg + 1;
-    uint32_t sym = 0; int prev0 = 0;
-    ze_bw_add(b, lg - 5, 4);
-    while (sym < alphabet && remaining > 1) {
-        if (prev0) {
-            uint32_t start = sym;
-            while (sym < alphabet && !norm[sym]) sym++;
-            if (sym == alphabet) break;
-            while (sym >= start + 24) { start += 24; ze_bw_add(b, 0xFFFF, 16); }
-            while (sym >= start + 3) { start += 3; ze_bw_add(b, 3, 2); }
-            ze_bw_add(b, sym - start, 2);
-        }
-        {
-            int count = norm[sym++];
-            int max = (2 * threshold - 1) - remaining;
-            remaining -= count < 0 ? -count : count;
-            count++;
-            if (count >= threshold) count += max;
-            ze_bw_add(b, (uint32_t)count, (uint32_t)(nbBits - (count < max)));
-            prev0 = (count == 1);
-            if (remaining < 1) break;
-            while (remaining < threshold) { nbBits--; threshold >>= 1; }
-        }
-    }
-    if (b.n) { b.p[b.pos++] = (uint8_t)b.acc; }
-    return b.pos;
-}
-
-// FSE_buildCTable_wksp, zstd.c:16005 (same symbol spread as the decoding table; per symbol the sorted cell list)
-ZH_DEVFN void ze_fse_build_ctab(ZeCTab& t, uint8_t* cellSym, uint16_t* fill /* 64 entries of fast scratch */, const int16_t* norm, uint32_t maxSym, uint32_t lg)
-{
-    const uint32_t size = 1u << lg, step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
-    uint32_t high = size - 1, pos = 0;
-    t.log = (int32_t)lg; t.maxSym = maxSym;
-    for (uint32_t s = 0; s <= maxSym; s++) { t.norm[s] = norm[s]; if (norm[s] == -1) cellSym[high--] = (uint8_t)s; }
-    for (uint32_t s = 0; s <= maxSym; s++)
-        for (int i = 0; i < norm[s]; i++) {
-            cellSym[pos] = (uint8_t)s;
-            do { pos = (pos + step) & mask; } while (pos > high);
-        }
-    uint32_t cum = 0;
-    for (uint32_t s = 0; s <= maxSym; s++) { t.cellOf[s] = (uint16_t)cum; cum += norm[s] == -1 ? 1u : (uint32_t)norm[s]; }
-    t.cellOf[maxSym + 1] = (uint16_t)cum;
-    // second pass needs a running fill pointer per symbol: reuse cellOf by walking cells in order per symbol
-    for (uint32_t u = 0, filled = 0; filled < size && u < 1; u++) { (void)filled; }
-    for (uint32_t s = 0; s <= maxSym; s++) fill[s] = t.cellOf[s];
-    for (uint32_t u = 0; u < size; u++) { uint32_t s = cellSym[u]; t.next[fill[s]++] = (uint16_t)(size + u); }
-}
 ZH_DEV void ze_fse_build_rle(ZeCTab& t, uint32_t sym)      // FSE_buildCTable_rle, zstd.c:16465
 {
     t.log = 0; t.maxSym = sym;
@@ -256,6 +127,205 @@ ZH_DEV uint32_t ze_fse_encode(const ZeCTab& t, ZeBits& b, uint32_t v, uint32_t s
     else { const uint32_t maxBits = (uint32_t)t.log - (uint32_t)zh_highbit32(c - 1); nb = v >= (c << maxBits) ? maxBits : maxBits - 1; }
     ze_bw_add(b, v, nb);
     return t.next[t.cellOf[s] + (v >> nb) - c];
+}
+
+// ------------------------------------------------------------------------------------------ FSE tables by the whole wave
+// The table of an alphabet of <= 64 symbols is built with LANE s OWNING SYMBOL s: a symbol's share of the table is its own arithmetic,
+// what the symbols owe each other (cells left over, who absorbs the rounding error, where a description's field starts) is a wave sum,
+// a wave maximum or a prefix sum. All lanes call; arrays (count, norm, tables, scratch) are in LDS.
+ZH_DEV uint32_t ze_wave_sum(uint32_t v) { return zh_shfl(zh_scan_add(v), 63); }
+ZH_DEV uint64_t ze_scan_add64(uint64_t v)                           // inclusive, only on the rare normalisation fallback
+{
+    const uint32_t lane = zh_lane();
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = zh_shfl_up((uint32_t)v, d), hi = zh_shfl_up((uint32_t)(v >> 32), d);
+        if (lane >= d) v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+ZH_CONST uint32_t ze_rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};     // FSE_normalizeCount's rounding thresholds (zstd.c:16405)
+
+// The fallback distribution (FSE_normalizeM2, zstd.c:16316), entered when plain rounding would take more than half of the largest
+// symbol's cells away: rare symbols get their minimum first, the rest share what is left in proportion, by running sums of
+// count x rStep (each symbol's cell count is a difference of two consecutive sums -- a 64-bit prefix sum here).
+ZH_DEVFN int ze_fse_normalize_m2_wave(int16_t* norm, uint32_t lg, uint32_t c, uint32_t total, uint32_t maxSym, int32_t lowProb)
+{
+    const uint32_t lane = zh_lane();
+    const bool in = lane <= maxSym;
+    const uint64_t lt = zh_lt_mask();
+    const int32_t UNSET = -2;
+    const uint32_t size = 1u << lg;
+    uint32_t lowOne = (uint32_t)(((uint64_t)total * 3) >> (lg + 1));
+    int32_t v = 0;
+    bool given = false;
+    if (in && c) {
+        if (c <= (total >> lg)) { v = lowProb; given = true; }
+        else if (c <= lowOne) { v = 1; given = true; }
+        else v = UNSET;
+    }
+    uint32_t distributed = (uint32_t)zh_popc64(zh_ballot(given));
+    total -= ze_wave_sum(given ? c : 0u);
+    uint32_t toDistribute = size - distributed;
+    if (toDistribute) {
+        if (total / toDistribute > lowOne) {                       // plenty left: one more round of "small enough for a single cell"
+            lowOne = (uint32_t)(((uint64_t)total * 3) / (toDistribute * 2));
+            const bool more = v == UNSET && c <= lowOne;
+            if (more) v = 1;
+            distributed += (uint32_t)zh_popc64(zh_ballot(more));
+            total -= ze_wave_sum(more ? c : 0u);
+            toDistribute = size - distributed;
+        }
+        if (distributed == maxSym + 1) {                           // every symbol is small: the first most frequent one takes the rest
+            const uint32_t best = 255u - (zh_wave_max(in ? (c << 8) | (255u - lane) : 0u) & 255u);
+            if (lane == best) v += (int32_t)toDistribute;
+        } else if (total == 0) {                                   // only single-cell symbols left: one more cell each, in turn, from symbol 0
+            const uint64_t has = zh_ballot(v > 0);
+            const uint32_t P = (uint32_t)zh_popc64(has), rank = (uint32_t)zh_popc64(has & lt);
+            if (v > 0) v += (int32_t)(toDistribute / P + (rank < toDistribute % P));
+        } else {
+            const uint32_t vStepLog = 62 - lg;
+            const uint64_t mid = (1ull << (vStepLog - 1)) - 1;
+            const uint64_t rStep = (((1ull << vStepLog) * toDistribute) + mid) / total;
+            const uint64_t mine = v == UNSET ? (uint64_t)c * rStep : 0ull;
+            const uint64_t end = mid + ze_scan_add64(mine);
+            const uint32_t weight = (uint32_t)(end >> vStepLog) - (uint32_t)((end - mine) >> vStepLog);
+            if (zh_ballot(v == UNSET && weight < 1)) return -1;
+            if (v == UNSET) v = (int32_t)weight;
+        }
+    }
+    if (in) norm[lane] = (int16_t)v;
+    return 0;
+}
+// FSE_normalizeCount (zstd.c:16402): count[] -> norm[] summing to 1 << lg. 0, or -1 when no distribution exists.
+ZH_DEVFN int ze_fse_normalize_wave(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, bool useLowProb)
+{
+    const uint32_t lane = zh_lane();
+    const bool in = lane <= maxSym;
+    const uint32_t c = in ? count[lane] : 0u;
+    const int32_t lowProb = useLowProb ? -1 : 1;
+    if (zh_ballot(in && c == total)) return 0;                     // a single symbol: the callers code that as RLE before getting here
+    const uint32_t scale = 62 - lg;
+    const uint64_t step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
+    const bool low = c != 0 && c <= (total >> lg);
+    int32_t p = 0;                                                   // my share, rounded down -- or up, past a threshold that depends on the share
+    if (c && !low) {
+        const uint64_t cs = (uint64_t)c * step;
+        p = (int32_t)(cs >> scale);
+        if (p < 8) p += (cs - ((uint64_t)p << scale)) > vStep * ze_rtb[p];
+    }
+    const int32_t still = (int32_t)(1u << lg) - (int32_t)ze_wave_sum(low ? 1u : (uint32_t)p);       // cells the rounding left over (or overdrew)
+    const uint32_t key = zh_wave_max(p > 0 ? ((uint32_t)p << 8) | (255u - lane) : 0u);            // the first symbol with the largest share absorbs it
+    const uint32_t largest = key ? 255u - (key & 255u) : 0u;
+    const int32_t mine = !c ? 0 : low ? lowProb : p;
+    const int32_t atLargest = (int32_t)zh_shfl((uint32_t)mine, largest);
+    if (-still >= (atLargest >> 1)) return ze_fse_normalize_m2_wave(norm, lg, c, total, maxSym, lowProb);
+    if (in) norm[lane] = (int16_t)(lane == largest ? mine + still : mine);
+    return 0;
+}
+
+// The table description (FSE_writeNCount_generic, zstd.c:16170). A symbol's field is its count + 1 in as many bits as the cells still
+// unassigned before it allow -- a prefix sum of the cell counts gives every lane that number directly; the zeros that follow a zero
+// are counted by a run code in front of the next symbol that has cells. Every lane shifts its bits to its prefix-sum offset in a zeroed
+// LDS strip; the strip is then copied out. asm32: 32 dwords of scratch. Returns bytes written.
+ZH_DEVFN uint32_t ze_fse_write_ncount_wave(uint8_t* out, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint32_t* asm32)
+{
+    const uint32_t lane = zh_lane();
+    const bool in = lane <= maxSym;
+    const int32_t n = in ? (int32_t)norm[lane] : 0;
+    const uint32_t cells = n < 0 ? 1u : (uint32_t)n;
+    const uint32_t remaining = (1u << lg) + 1 - (zh_scan_add(cells) - cells);      // cells (+ 1) not yet given out when my field is written
+    const uint64_t zeros = zh_ballot(in && n == 0);
+    const bool afterZero = lane > 0 && ((zeros >> (lane - 1)) & 1);
+    // written: every symbol while cells remain, except the zeros behind a zero
+    const bool written = in && remaining > 1 && !(n == 0 && afterZero);
+    uint64_t bits = 0; uint32_t len = 0;
+    if (lane < 32) asm32[lane] = 0;
+    if (written) {
+        if (afterZero) {                                                           // run code: the zeros between the run's first one and me
+            const uint64_t below = ~zeros & zh_lt_mask();                         // symbols with cells below me
+            const uint32_t first = below ? 64u - (uint32_t)zh_clz64(below) : 0u;  // the run's first zero (written like any symbol)
+            const uint32_t z = lane - 1 - first;
+            const uint32_t k24 = z / 24, k3 = (z % 24) / 3;
+            bits = (k24 ? (1ull << (16 * k24)) - 1 : 0ull) | (((1ull << (2 * k3)) - 1) << (16 * k24)) | ((uint64_t)(z % 3) << (16 * k24 + 2 * k3));
+            len = 16 * k24 + 2 * k3 + 2;
+        }
+        const uint32_t hb = (uint32_t)zh_highbit32(remaining), threshold = 1u << hb;
+        const uint32_t max = 2 * threshold - 1 - remaining;
+        uint32_t v = (uint32_t)(n + 1);
+        if (v >= threshold) v += max;
+        const uint32_t nb = hb + 1 - (v < max);
+        bits |= (uint64_t)(v & ((1u << nb) - 1)) << len; len += nb;
+        if (lane == 0) { bits = (bits << 4) | (lg - 5); len += 4; }
+    }
+    zh_sync();
+    const uint32_t end = zh_scan_add(len), off = end - len;
+    if (len) {
+        const uint32_t w = off >> 5, sh = off & 31;                              // up to 61 bits shifted by up to 31: three dwords
+        const uint64_t lo = bits << sh;
+        const uint32_t top = sh ? (uint32_t)(bits >> (64 - sh)) : 0u;
+        zh_lds_atomic_or(&asm32[w], (uint32_t)lo);
+        if (lo >> 32) zh_lds_atomic_or(&asm32[w + 1], (uint32_t)(lo >> 32));
+        if (top) zh_lds_atomic_or(&asm32[w + 2], top);
+    }
+    zh_sync();
+    const uint32_t bytes = (zh_shfl(end, 63) + 7) >> 3;
+    for (uint32_t i = lane; i < bytes; i += 64) out[i] = ((const uint8_t*)asm32)[i];
+    return bytes;
+}
+
+// The encoding table (FSE_buildCTable_wksp, zstd.c:16005): the same symbol spread as the decoding side (the k-th cell handed out sits at
+// (k x step) mod size, low-probability symbols take the top cells), then every symbol's cells listed in table order. One lane per symbol
+// for the bookkeeping, one lane per cell for spreading and listing. cellSym: 512 bytes, ends / run: 64 x u16 each, all LDS scratch.
+ZH_DEVFN void ze_fse_build_ctab_wave(ZeCTab& t, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint8_t* cellSym, uint16_t* ends, uint16_t* run)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t S = 1u << lg, mask = S - 1, step = (S >> 1) + (S >> 3) + 3;
+    const uint64_t lt = zh_lt_mask();
+    const bool in = lane <= maxSym;
+    const int32_t n = in ? (int32_t)norm[lane] : 0;
+    const bool low = n == -1;
+    const uint64_t lowMask = zh_ballot(low);
+    const uint32_t high = S - 1 - (uint32_t)zh_popc64(lowMask);
+    const uint32_t cnt = n > 0 ? (uint32_t)n : 0u, cells = low ? 1u : cnt;
+    const uint32_t inclCells = zh_scan_add(cells), incl = zh_scan_add(cnt);
+    if (lane == 0) { t.log = (int32_t)lg; t.maxSym = maxSym; }
+    if (in) { t.norm[lane] = (int16_t)n; t.cellOf[lane] = (uint16_t)(inclCells - cells); }
+    if (lane == maxSym) t.cellOf[lane + 1] = (uint16_t)inclCells;
+    if (low) cellSym[S - 1 - (uint32_t)zh_popc64(lowMask & lt)] = (uint8_t)lane;
+    ends[lane] = (uint16_t)incl; run[lane] = 0;
+    ze_fence();
+    zh_sync();
+    uint32_t jbase = 0;
+    for (uint32_t c = 0; c < S; c += 64) {                                         // spread: a visit above `high` hands out nothing
+        const uint32_t k = c + lane, p = (k * step) & mask;
+        const bool valid = k < S && p <= high;
+        const uint64_t m = zh_ballot(valid);
+        if (valid) {
+            const uint32_t j = jbase + (uint32_t)zh_popc64(m & lt);
+            uint32_t pos = 0;                                                       // the symbol whose cells include the j-th one handed out
+            for (uint32_t sb = 32; sb; sb >>= 1) if (ends[pos + sb - 1] <= j) pos += sb;
+            cellSym[p] = (uint8_t)pos;
+        }
+        jbase += (uint32_t)zh_popc64(m);
+    }
+    ze_fence();
+    zh_sync();
+    for (uint32_t c = 0; c < S; c += 64) {                                         // list: cell u is the (cells of its symbol below u)-th of that symbol
+        const uint32_t u = c + lane;
+        const bool act = u < S;
+        const uint32_t sy = act ? cellSym[u] : 0u;
+        uint64_t same = zh_ballot(act);
+        for (int b = 0; b < 6; b++) { const uint64_t bm = zh_ballot(((sy >> b) & 1) != 0); same &= ((sy >> b) & 1) ? bm : ~bm; }
+        uint32_t r = 0;
+        if (act) r = (uint32_t)run[sy] + (uint32_t)zh_popc64(same & lt);
+        zh_sync();
+        if (act) {
+            if ((same >> lane) >> 1 == 0) run[sy] = (uint16_t)(r + 1);           // the highest lane of its group keeps the count
+            t.next[t.cellOf[sy] + r] = (uint16_t)(S + u);
+        }
+        ze_fence();
+        zh_sync();
+    }
 }
 
 // ------------------------------------------------------------------------------------------ Huffman, compression side (lane 0)
@@ -299,139 +369,216 @@ ZH_DEVFN void ze_huf_quicksort(ZeNode* a, int low0, int high0, uint32_t* stack)
     }
 }
 
-// HUF_buildCTable_wksp (zstd.c:17513): HUF_sort :17377, HUF_buildTree :17438, HUF_setMaxHeight :17133,
-// HUF_buildCTableFromTree :17487. counts in L.hist -> L.hufBits / L.hufCode. Returns the maximum code length.
+// lanes of the wave that hold the same `bits`-bit key as the caller (among lanes with act set)
+ZH_DEV uint64_t ze_same_key(uint32_t key, int bits, bool act)
+{
+    uint64_t same = zh_ballot(act);
+    for (int b = 0; b < bits; b++) { const uint64_t bm = zh_ballot(((key >> b) & 1) != 0); same &= ((key >> b) & 1) ? bm : ~bm; }
+    return same;
+}
+
+// Huffman code lengths and codes for the literals (HUF_buildCTable_wksp, zstd.c:17513). counts in L.hist -> L.hufBits / L.hufCode.
+// All lanes call; returns the maximum code length. What is a per-symbol or per-node affair runs on all lanes -- clearing, the bucket
+// histogram and its suffix sums, placing the symbols in sorted order (rank inside a bucket = symbols of the same bucket below, by
+// match-any ballots), depths (every leaf walks up to the root), the per-length code numbering. What is one chain stays on lane 0:
+// the quicksort of the wide buckets (its order among equal counts IS the format's tie-break, so it is the reference's algorithm,
+// zstd.c:17312-17375), the two-queue merge of the tree (:17438) and the height limiter (:17133), which rarely runs.
 ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
 {
+    const uint32_t lane = zh_lane();
+    const uint64_t lt = zh_lt_mask();
     ZeNode* const tbl = L.node;
-    for (uint32_t i = 0; i < 2 * 256 + 2; i++) { tbl[i].count = 0; tbl[i].parent = 0; tbl[i].byte = 0; tbl[i].nbBits = 0; }
     ZeNode* const node = tbl + 1;
     const uint32_t* count = L.hist;
-    {   // bucket sort by decreasing count; L.cnt doubles as the 193-entry base/cur arrays
-        uint32_t* base = &L.cnt[0][0];          // 192 entries available (3 x 64)
-        uint16_t* cur = L.tab[2].next;          // scratch: free until the sequence tables are built
-        for (int n = 0; n < 192; n++) base[n] = 0;
-        const uint32_t n1 = maxSym + 1;
-        for (uint32_t n = 0; n < n1; n++) base[ze_huf_bucket(count[n])]++;
-        for (int n = 191; n > 0; n--) base[n - 1] += base[n];
-        for (int n = 0; n < 192; n++) cur[n] = (uint16_t)base[n];
-        cur[192] = 0;
-        for (uint32_t n = 0; n < n1; n++) {
-            const uint32_t r = ze_huf_bucket(count[n]) + 1;
-            const uint32_t pos = r < 192 ? cur[r]++ : 0;
+    uint32_t* base = &L.cnt[0][0];          // 192 entries (3 x 64): symbols in this bucket or a higher one
+    uint16_t* cur = L.tab[2].next;          // scratch (free until the sequence tables are built): the next free slot of every bucket
+    zh_sync();
+    for (uint32_t i = lane; i < 2 * 256 + 2; i += 64) { tbl[i].count = 0; tbl[i].parent = 0; tbl[i].byte = 0; tbl[i].nbBits = 0; }
+    for (uint32_t i = lane; i < 192; i += 64) base[i] = 0;
+    ze_fence(); zh_sync();
+    for (uint32_t n = lane; n <= maxSym; n += 64) zh_lds_atomic_inc(&base[ze_huf_bucket(count[n])]);
+    ze_fence(); zh_sync();
+    {   // suffix sums over the 192 buckets, three per lane
+        const uint32_t a0 = base[3 * lane], a1 = base[3 * lane + 1], a2 = base[3 * lane + 2];
+        const uint32_t incl = zh_scan_add(a0 + a1 + a2);
+        const uint32_t above = zh_shfl(incl, 63) - incl;
+        const uint32_t b2 = a2 + above, b1 = a1 + b2, b0 = a0 + b1;
+        zh_sync();
+        base[3 * lane] = b0; base[3 * lane + 1] = b1; base[3 * lane + 2] = b2;
+        cur[3 * lane] = (uint16_t)b0; cur[3 * lane + 1] = (uint16_t)b1; cur[3 * lane + 2] = (uint16_t)b2;
+        if (lane == 0) cur[192] = 0;
+    }
+    ze_fence(); zh_sync();
+    for (uint32_t c0 = 0; c0 <= maxSym; c0 += 64) {                                // sorted position = symbols in higher buckets + same-bucket symbols below
+        const uint32_t n = c0 + lane;
+        const bool act = n <= maxSym;
+        const uint32_t r = act ? ze_huf_bucket(count[n]) + 1 : 0u;
+        const uint64_t same = ze_same_key(r, 8, act);
+        uint32_t pos = 0;
+        if (act) pos = (uint32_t)cur[r] + (uint32_t)zh_popc64(same & lt);
+        zh_sync();
+        if (act) {
+            if ((same >> lane) >> 1 == 0) cur[r] = (uint16_t)(pos + 1);
             node[pos].count = count[n]; node[pos].byte = (uint8_t)n;
         }
+        ze_fence(); zh_sync();
+    }
+    if (zh_opaque(lane) == 0) {
         for (uint32_t r = 166; r < 191; r++) {
             const int bsize = (int)cur[r] - (int)base[r];
             if (bsize > 1) ze_huf_quicksort(node + base[r], 0, bsize - 1, L.stack);
         }
-    }
-    int last = (int)maxSym;
-    while (node[last].count == 0) last--;
-    int lowS = last, nodeNb = 256, nodeRoot = nodeNb + lowS - 1, lowN = nodeNb;
-    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
-    node[lowS].parent = node[lowS - 1].parent = (uint16_t)nodeNb;
-    nodeNb++; lowS -= 2;
-    for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
-    node[-1].count = 1u << 31;
-    while (nodeNb <= nodeRoot) {
-        const int n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        const int n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        node[nodeNb].count = node[n1].count + node[n2].count;
-        node[n1].parent = node[n2].parent = (uint16_t)nodeNb;
-        nodeNb++;
-    }
-    node[nodeRoot].nbBits = 0;
-    for (int n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = (uint8_t)(node[node[n].parent].nbBits + 1);
-    for (int n = 0; n <= last; n++) node[n].nbBits = (uint8_t)(node[node[n].parent].nbBits + 1);
-    uint32_t largest = node[last].nbBits;
-    if (largest > maxBits) {
-        int totalCost = 0; const uint32_t baseCost = 1u << (largest - maxBits);
-        int n = last;
-        while (node[n].nbBits > maxBits) { totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits))); node[n].nbBits = (uint8_t)maxBits; n--; }
-        while (node[n].nbBits == maxBits) --n;
-        totalCost >>= (largest - maxBits);
-        const uint32_t none = 0xF0F0F0F0u; uint32_t* const rankLast = L.stack;      // 14 entries; the quicksort's stack is idle now
-        for (int i = 0; i < 14; i++) rankLast[i] = none;
-        {   uint32_t curBits = maxBits;
-            for (int pos = n; pos >= 0; pos--) { if (node[pos].nbBits >= curBits) continue; curBits = node[pos].nbBits; rankLast[maxBits - curBits] = (uint32_t)pos; } }
-        while (totalCost > 0) {
-            uint32_t dec = (uint32_t)zh_highbit32((uint32_t)totalCost) + 1;
-            for (; dec > 1; dec--) {
-                const uint32_t highPos = rankLast[dec], lowPos = rankLast[dec - 1];
-                if (highPos == none) continue;
-                if (lowPos == none) break;
-                if (node[highPos].count <= 2 * node[lowPos].count) break;
-            }
-            while (dec <= 12 && rankLast[dec] == none) dec++;
-            totalCost -= 1 << (dec - 1);
-            node[rankLast[dec]].nbBits++;
-            if (rankLast[dec - 1] == none) rankLast[dec - 1] = rankLast[dec];
-            if (rankLast[dec] == 0) rankLast[dec] = none;
-            else { rankLast[dec]--; if (node[rankLast[dec]].nbBits != maxBits - dec) rankLast[dec] = none; }
+        // the tree: leaves are taken from the small end of the sorted list, parents from the queue of nodes made so far (both in rising
+        // count order); a tie takes the parent
+        int last = (int)maxSym;
+        while (node[last].count == 0) last--;
+        int leaf = last, made = 256, root = made + leaf - 1, parent = made;
+        node[made].count = node[leaf].count + node[leaf - 1].count;
+        node[leaf].parent = node[leaf - 1].parent = (uint16_t)made;
+        made++; leaf -= 2;
+        for (int n = made; n <= root; n++) node[n].count = 1u << 30;
+        node[-1].count = 1u << 31;                                                  // sentinel below leaf 0
+        while (made <= root) {
+            const int n1 = (node[leaf].count < node[parent].count) ? leaf-- : parent++;
+            const int n2 = (node[leaf].count < node[parent].count) ? leaf-- : parent++;
+            node[made].count = node[n1].count + node[n2].count;
+            node[n1].parent = node[n2].parent = (uint16_t)made;
+            made++;
         }
-        while (totalCost < 0) {
-            if (rankLast[1] == none) {
-                while (node[n].nbBits == maxBits) n--;
-                node[n + 1].nbBits--; rankLast[1] = (uint32_t)(n + 1); totalCost++;
-                continue;
+        L.misc[12] = (uint32_t)last; L.misc[13] = (uint32_t)root;
+    }
+    ze_fence(); zh_sync();
+    const int last = (int)zh_first(L.misc[12]); const uint32_t root = zh_first(L.misc[13]);
+    for (int n = (int)lane; n <= last; n += 64) {                                  // depth of every leaf
+        uint32_t d = 0, q = (uint32_t)n;
+        while (q != root) { q = node[q].parent; d++; }
+        node[n].nbBits = (uint8_t)d;
+    }
+    ze_fence(); zh_sync();
+    uint32_t largest = node[last].nbBits;
+    zh_sync();                                                                      // (everyone has read it before lane 0 starts changing lengths)
+    if (largest > maxBits) {
+        if (zh_opaque(lane) == 0) {
+            int totalCost = 0; const uint32_t baseCost = 1u << (largest - maxBits);
+            int n = last;
+            while (node[n].nbBits > maxBits) { totalCost += (int)(baseCost - (1u << (largest - node[n].nbBits))); node[n].nbBits = (uint8_t)maxBits; n--; }
+            while (node[n].nbBits == maxBits) --n;
+            totalCost >>= (largest - maxBits);
+            const uint32_t none = 0xF0F0F0F0u; uint32_t* const rankLast = L.stack;      // 14 entries; the quicksort's stack is idle now
+            for (int i = 0; i < 14; i++) rankLast[i] = none;
+            {   uint32_t curBits = maxBits;
+                for (int pos = n; pos >= 0; pos--) { if (node[pos].nbBits >= curBits) continue; curBits = node[pos].nbBits; rankLast[maxBits - curBits] = (uint32_t)pos; } }
+            while (totalCost > 0) {
+                uint32_t dec = (uint32_t)zh_highbit32((uint32_t)totalCost) + 1;
+                for (; dec > 1; dec--) {
+                    const uint32_t highPos = rankLast[dec], lowPos = rankLast[dec - 1];
+                    if (highPos == none) continue;
+                    if (lowPos == none) break;
+                    if (node[highPos].count <= 2 * node[lowPos].count) break;
+                }
+                while (dec <= 12 && rankLast[dec] == none) dec++;
+                totalCost -= 1 << (dec - 1);
+                node[rankLast[dec]].nbBits++;
+                if (rankLast[dec - 1] == none) rankLast[dec - 1] = rankLast[dec];
+                if (rankLast[dec] == 0) rankLast[dec] = none;
+                else { rankLast[dec]--; if (node[rankLast[dec]].nbBits != maxBits - dec) rankLast[dec] = none; }
             }
-            node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+            while (totalCost < 0) {
+                if (rankLast[1] == none) {
+                    while (node[n].nbBits == maxBits) n--;
+                    node[n + 1].nbBits--; rankLast[1] = (uint32_t)(n + 1); totalCost++;
+                    continue;
+                }
+                node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+            }
         }
         largest = maxBits;
+        ze_fence(); zh_sync();
     }
+    // codes: per length, numbered in symbol order from a start value that comes from the counts of the longer lengths
     uint16_t* const perRank = (uint16_t*)(L.stack + 16); uint16_t* const start = perRank + 16;
-    for (int i = 0; i < 14; i++) { perRank[i] = 0; start[i] = 0; }
-    for (int n = 0; n <= last; n++) perRank[node[n].nbBits]++;
-    {   uint16_t mn = 0; for (int r = (int)largest; r > 0; r--) { start[r] = mn; mn = (uint16_t)((mn + perRank[r]) >> 1); } }
-    for (uint32_t s = 0; s < 256; s++) { L.hufBits[s] = 0; L.hufCode[s] = 0; }
-    for (uint32_t n = 0; n <= maxSym; n++) L.hufBits[node[n].byte] = node[n].nbBits;
-    for (uint32_t s = 0; s <= maxSym; s++) { const uint32_t nb = L.hufBits[s]; L.hufCode[s] = nb ? start[nb]++ : (uint16_t)0; }
+    if (lane < 16) { perRank[lane] = 0; start[lane] = 0; }
+    for (uint32_t i = lane; i < 256; i += 64) { L.hufBits[i] = 0; L.hufCode[i] = 0; }
+    ze_fence(); zh_sync();
+    {   uint32_t* const pr32 = (uint32_t*)(L.stack + 32);                          // 16 counters for the atomics
+        if (lane < 16) pr32[lane] = 0;
+        ze_fence(); zh_sync();
+        for (int n = (int)lane; n <= last; n += 64) zh_lds_atomic_inc(&pr32[node[n].nbBits]);
+        for (uint32_t n = lane; n <= maxSym; n += 64) L.hufBits[node[n].byte] = node[n].nbBits;
+        ze_fence(); zh_sync();
+        if (zh_opaque(lane) == 0) { uint16_t mn = 0; for (int r = (int)largest; r > 0; r--) { start[r] = mn; mn = (uint16_t)((mn + pr32[r]) >> 1); } }
+        ze_fence(); zh_sync();
+    }
+    for (uint32_t c0 = 0; c0 <= maxSym; c0 += 64) {
+        const uint32_t sy = c0 + lane;
+        const bool act = sy <= maxSym;
+        const uint32_t nb = act ? L.hufBits[sy] : 0u;
+        const uint64_t same = ze_same_key(nb, 4, act);
+        uint32_t code = 0;
+        if (act && nb) code = (uint32_t)start[nb] + (uint32_t)zh_popc64(same & lt);
+        zh_sync();
+        if (act && nb) { if ((same >> lane) >> 1 == 0) start[nb] = (uint16_t)(code + 1); L.hufCode[sy] = (uint16_t)code; }
+        ze_fence(); zh_sync();
+    }
     return largest;
 }
 
-// HUF_compressWeights (zstd.c:16904) + FSE_compress_usingCTable_generic (:16488). 0 = not compressible, 1 = one symbol.
+// The Huffman table description (HUF_writeCTable_wksp, zstd.c:17005): weights = log + 1 - code length, FSE-compressed when that is
+// shorter (HUF_compressWeights :16904), else 4 bits each. All lanes call; 0 = cannot be described, 1 = one weight value only.
 ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t* w, uint32_t n)
 {
+    const uint32_t lane = zh_lane();
     uint32_t* const count = &L.cnt[0][0];           // free here: the bucket sort is over, the sequence histograms come later
-    uint32_t maxSym = 0, maxCount = 0;
     if (n <= 1) return 0;
-    for (int s = 0; s < 13; s++) count[s] = 0;
-    for (uint32_t i = 0; i < n; i++) count[w[i]]++;
-    for (uint32_t s = 0; s <= 12; s++) { if (count[s]) maxSym = s; if (count[s] > maxCount) maxCount = count[s]; }
+    zh_sync();
+    if (lane < 13) count[lane] = 0;
+    ze_fence(); zh_sync();
+    for (uint32_t i = lane; i < n; i += 64) zh_lds_atomic_inc(&count[w[i]]);
+    ze_fence(); zh_sync();
+    const uint32_t c = lane <= 12 ? count[lane] : 0u;
+    const uint64_t present = zh_ballot(c != 0);
+    const uint32_t maxSym = present ? 63u - (uint32_t)zh_clz64(present) : 0u, maxCount = zh_wave_max(c);
     if (maxCount == n) return 1;
     if (maxCount == 1) return 0;
     const uint32_t lg = ze_fse_optimal_log(6, n, maxSym, 2);
     int16_t* const norm = ze_norm_area(L);
-    if (ze_fse_normalize(norm, lg, count, n, maxSym, 0) < 0) return 0;
-    const uint32_t h = ze_fse_write_ncount(out, norm, maxSym, lg);
+    if (ze_fse_normalize_wave(norm, lg, count, n, maxSym, false) < 0) return 0;
+    ze_fence(); zh_sync();
+    const uint32_t h = ze_fse_write_ncount_wave(out, norm, maxSym, lg, (uint32_t*)((uint8_t*)L.node + 2048));
     ZeCTab& t = L.tab[0];
-    ze_fse_build_ctab(t, ze_cell_sym(L), ze_fill_area(L), norm, maxSym, lg);
+    ze_fse_build_ctab_wave(t, norm, maxSym, lg, ze_cell_sym(L), (uint16_t*)L.stack, ze_fill_area(L));
     if (n <= 2) return 0;
-    ZeBits b; ze_bw_init(b, out + h, 512);
-    uint32_t ip = n, s1, s2;
-    if (n & 1) { s1 = ze_fse_first_state(t, w[--ip]); s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_encode(t, b, s1, w[--ip]); }
-    else { s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_first_state(t, w[--ip]); }
-    while (ip > 0) {
-        s2 = ze_fse_encode(t, b, s2, w[--ip]);
-        s1 = ze_fse_encode(t, b, s1, w[--ip]);
+    if (zh_opaque(lane) == 0) {                     // the weights themselves: two interleaved tANS states, last weight first (FSE_compress_usingCTable_generic, zstd.c:16488)
+        ZeBits b; ze_bw_init(b, out + h, 512);
+        uint32_t ip = n, s1, s2;
+        if (n & 1) { s1 = ze_fse_first_state(t, w[--ip]); s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_encode(t, b, s1, w[--ip]); }
+        else { s2 = ze_fse_first_state(t, w[--ip]); s1 = ze_fse_first_state(t, w[--ip]); }
+        while (ip > 0) {
+            s2 = ze_fse_encode(t, b, s2, w[--ip]);
+            s1 = ze_fse_encode(t, b, s1, w[--ip]);
+        }
+        ze_bw_add(b, s2, lg); ze_bw_add(b, s1, lg);
+        L.misc[12] = ze_bw_close(b);
     }
-    ze_bw_add(b, s2, lg); ze_bw_add(b, s1, lg);
-    const uint32_t c = ze_bw_close(b);
-    return c ? h + c : 0;
+    ze_fence(); zh_sync();
+    const uint32_t c2 = zh_first(L.misc[12]);
+    zh_sync();
+    return c2 ? h + c2 : 0;
 }
-
-// HUF_writeCTable_wksp (zstd.c:17005). 0 = cannot be described.
 ZH_DEVFN uint32_t ze_huf_write_table(ZeLDS& L, uint8_t* out, uint32_t maxSym, uint32_t lg)
 {
+    const uint32_t lane = zh_lane();
     uint8_t* w = ze_weights(L);
-    for (uint32_t n = 0; n < maxSym; n++) w[n] = L.hufBits[n] ? (uint8_t)(lg + 1 - L.hufBits[n]) : (uint8_t)0;
+    zh_sync();
+    for (uint32_t n = lane; n < maxSym; n += 64) w[n] = L.hufBits[n] ? (uint8_t)(lg + 1 - L.hufBits[n]) : (uint8_t)0;
+    ze_fence(); zh_sync();
     const uint32_t h = ze_huf_compress_weights(L, out + 1, w, maxSym);
-    if (h > 1 && h < maxSym / 2) { out[0] = (uint8_t)h; return h + 1; }
+    if (h > 1 && h < maxSym / 2) { if (zh_opaque(lane) == 0) out[0] = (uint8_t)h; ze_fence(); zh_sync(); return h + 1; }
     if (maxSym > 128) return 0;
-    out[0] = (uint8_t)(128 + (maxSym - 1));
-    w[maxSym] = 0;
-    for (uint32_t n = 0; n < maxSym; n += 2) out[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
+    if (zh_opaque(lane) == 0) { out[0] = (uint8_t)(128 + (maxSym - 1)); w[maxSym] = 0; }
+    ze_fence(); zh_sync();
+    for (uint32_t n = 2 * lane; n < maxSym; n += 128) out[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
+    ze_fence(); zh_sync();
     return (maxSym + 1) / 2 + 1;
 }
 
@@ -679,13 +826,9 @@ ZH_DEVFN uint32_t ze_compress_literals(ZeLDS& L, uint8_t* out, uint32_t cap, con
         else if (decision == 2) {
             uint32_t lg = 0;
             ZE_T(P, ZEP_LITSTAT);
-            if (zh_opaque(lane) == 0) {
-                lg = ze_fse_optimal_log(11, n, maxSym, 1);
-                lg = ze_huf_build(L, maxSym, lg);
-                L.misc[0] = ze_huf_write_table(L, out + lh, maxSym, lg);
-            }
-            zh_sync();
-            h = zh_first(L.misc[0]);
+            lg = ze_fse_optimal_log(11, n, maxSym, 1);
+            lg = ze_huf_build(L, maxSym, lg);
+            h = ze_huf_write_table(L, out + lh, maxSym, lg);
             zh_sync();
             ZE_T(P, ZEP_HUFBUILD);
             builtMaxSym = maxSym;
@@ -1634,30 +1777,47 @@ ZH_DEV int ze_select_mode(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defLog
     }
     return 2;
 }
-// ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML. lane 0. Returns header bytes written.
-ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, const uint32_t* fseRep, uint32_t strat,
-                                     uint8_t* cellSym, uint16_t* fill, int16_t* norm)
+// ZSTD_buildCTable (zstd.c:21338) for one of LL / OF / ML, by the whole wave (all lanes call; results are wave-uniform). Returns the
+// header bytes written at `out`.
+ZH_DEVFN uint32_t ze_build_seq_table(ZeLDS& L, int which, uint8_t* out, int* mode, uint32_t firstCode, uint32_t lastCode, uint32_t nbSeq, const ZeCDict* cd, const uint32_t* fseRep, uint32_t strat)
 {
+    const uint32_t lane = zh_lane();
     const uint32_t maxCode = which == 0 ? 35 : which == 1 ? 31 : 52;
     const uint32_t fseLog = which == 1 ? 8 : 9, defLog = which == 1 ? 5 : 6, defMax = which == 0 ? 35 : which == 1 ? 28 : 52;
     const int16_t* defNorm = which == 0 ? ze_llDef : which == 1 ? ze_ofDef : ze_mlDef;
     uint32_t* count = L.cnt[which];
-    uint32_t max = 0, most = 0;
-    for (uint32_t s = 0; s <= maxCode; s++) { if (count[s]) max = s; if (count[s] > most) most = count[s]; }
+    int16_t* const norm = ze_norm_area(L);
+    const uint32_t c = lane <= maxCode ? count[lane] : 0u;
+    const uint64_t present = zh_ballot(c != 0);
+    const uint32_t max = present ? 63u - (uint32_t)zh_clz64(present) : 0u, most = zh_wave_max(c);
     const bool defaultAllowed = which != 1 || max <= 28;
     const uint32_t repeatMode = fseRep ? fseRep[which] : !cd ? 0u : which == 0 ? cd->llRepeat : which == 1 ? cd->ofRepeat : cd->mlRepeat;   // (fseRep: a later block's view)
     *mode = ze_select_mode(most, nbSeq, defLog, defaultAllowed, repeatMode, strat);
     ZeCTab& t = L.tab[which];
-    if (*mode == 3) return 0;        // set_repeat: the dictionary's table, copied into LDS by the whole wave (ze_copy_dict_tables) -- a lane-0
-                                     // copy is ~1 500 dependent global round trips per frame (r02d: most of the entropy kernel on 4 KiB inputs)
-    if (*mode == 1) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; return 1; }
-    if (*mode == 0) { for (uint32_t s = 0; s <= defMax; s++) norm[s] = defNorm[s]; ze_fse_build_ctab(t, cellSym, fill, norm, defMax, defLog); return 0; }
+    if (*mode == 3) return 0;        // set_repeat: the dictionary's table, copied into LDS by the whole wave (ze_copy_dict_tables)
+    if (*mode == 1) {
+        if (zh_opaque(lane) == 0) { ze_fse_build_rle(t, firstCode); out[0] = (uint8_t)firstCode; }
+        ze_fence(); zh_sync();
+        return 1;
+    }
+    if (*mode == 0) {
+        if (lane <= defMax) norm[lane] = defNorm[lane];
+        ze_fence(); zh_sync();
+        ze_fse_build_ctab_wave(t, norm, defMax, defLog, ze_cell_sym(L), (uint16_t*)L.stack, ze_fill_area(L));
+        return 0;
+    }
     const uint32_t lg = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
     uint32_t n1 = nbSeq;
-    if (count[lastCode] > 1) { count[lastCode]--; n1--; }
-    ze_fse_normalize(norm, lg, count, n1, max, n1 >= 2048);
-    const uint32_t h = ze_fse_write_ncount(out, norm, max, lg);
-    ze_fse_build_ctab(t, cellSym, fill, norm, max, lg);
+    if (zh_first(count[lastCode]) > 1) {                                          // the last sequence's symbols are never decoded FROM: one count less
+        zh_sync();
+        if (zh_opaque(lane) == 0) count[lastCode]--;
+        n1--;
+        ze_fence(); zh_sync();
+    }
+    ze_fse_normalize_wave(norm, lg, count, n1, max, n1 >= 2048);
+    ze_fence(); zh_sync();
+    const uint32_t h = ze_fse_write_ncount_wave(out, norm, max, lg, (uint32_t*)((uint8_t*)L.node + 2048));
+    ze_fse_build_ctab_wave(t, norm, max, lg, ze_cell_sym(L), (uint16_t*)L.stack, ze_fill_area(L));
     return h;
 }
 // the tables whose mode is set_repeat (3): dictionary -> LDS, 4 bytes per lane per step, all loads of a table in flight together
@@ -1988,64 +2148,33 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     ze_fence();
     zh_sync();
     ZE_T(P, ZEP_SEQSTAT);
-#ifndef ZE_TAB3
-    if (zh_opaque(lane) == 0) {
-        uint8_t* op = out + pos;
-        uint32_t lastCount = 0;
-        if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
-        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
-        else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
-        if (nbSeq) {
-            uint8_t* seqHead = op++;
-            int mLL, mOF, mML; uint32_t h;
-            const uint32_t c0 = L.misc[8], c1 = L.misc[9];
-            h = ze_build_seq_table(L, 0, op, &mLL, c0 & 255, c1 & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mLL == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 1, op, &mOF, (c0 >> 8) & 255, (c1 >> 8) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mOF == 2) lastCount = h; op += h;
-            h = ze_build_seq_table(L, 2, op, &mML, (c0 >> 16) & 255, (c1 >> 16) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat, ze_cell_sym(L), ze_fill_area(L), ze_norm_area(L)); if (mML == 2) lastCount = h; op += h;
-            *seqHead = (uint8_t)((mLL << 6) + (mOF << 4) + (mML << 2));
-            L.misc[7] = (uint32_t)mLL | ((uint32_t)mOF << 2) | ((uint32_t)mML << 4);
+    uint32_t seqStart, lastCount = 0, seqModes = 0;
+    {   // sequences header, then the three table descriptions, each built by the whole wave (r01: lane 0 built them, 17 % of the kernel)
+        const uint32_t hb = nbSeq < 128 ? 1u : nbSeq < 0x7F00 ? 2u : 3u;
+        if (zh_opaque(lane) == 0) {
+            uint8_t* op = out + pos;
+            if (nbSeq < 128) op[0] = (uint8_t)nbSeq;
+            else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; }
+            else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); }
         }
-        L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
-    }
-#else
-    // EXPERIMENTAL (-DZE_TAB3; emulator-verified, not yet measured on hardware): the three tables are independent, so lanes 0..2 build
-    // LL / OF / ML at the same time, each with its own scratch inside the tree-node area and its table description written to an
-    // LDS slot; lane 0 then lays the descriptions out in order.
-    if (nbSeq && zh_opaque(lane) < 3) {
-        uint8_t* const nodeB = (uint8_t*)L.node;
-        const uint32_t c0 = L.misc[8], c1 = L.misc[9];
-        int md = 0;
-        const uint32_t h = ze_build_seq_table(L, (int)lane, nodeB + 3328 + 80 * lane, &md, (c0 >> (8 * lane)) & 255, (c1 >> (8 * lane)) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat,
-                                              nodeB + 1024 + 512 * lane, (uint16_t*)(nodeB + 2560 + 128 * lane), (int16_t*)(nodeB + 2944 + 128 * lane));
-        L.misc[4 + lane] = h | ((uint32_t)md << 16);
-    }
-    zh_sync();
-    if (zh_opaque(lane) == 0) {
-        uint8_t* op = out + pos;
-        uint32_t lastCount = 0;
-        if (nbSeq < 128) *op++ = (uint8_t)nbSeq;
-        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; op += 2; }
-        else { op[0] = 0xFF; zh_st16(op + 1, (uint16_t)(nbSeq - 0x7F00)); op += 3; }
+        uint32_t at = pos + hb;
         if (nbSeq) {
-            uint8_t* seqHead = op++;
-            uint32_t modes[3];
-            for (uint32_t t = 0; t < 3; t++) {
-                const uint32_t h = L.misc[4 + t] & 0xFFFF; modes[t] = L.misc[4 + t] >> 16;
-                const uint8_t* hd = (const uint8_t*)L.node + 3328 + 80 * t;
-                for (uint32_t k = 0; k < h; k++) op[k] = hd[k];
-                if (modes[t] == 2) lastCount = h;
-                op += h;
+            const uint32_t head = at++;
+            int md[3]; 
+            const uint32_t c0 = zh_first(L.misc[8]), c1 = zh_first(L.misc[9]);
+            for (int w = 0; w < 3; w++) {
+                const uint32_t h = ze_build_seq_table(L, w, out + at, &md[w], (c0 >> (8 * w)) & 255, (c1 >> (8 * w)) & 255, nbSeq, cd, fseRep, (uint32_t)cp.strat);
+                if (md[w] == 2) lastCount = h;
+                at += h;
+                ze_fence(); zh_sync();
             }
-            *seqHead = (uint8_t)((modes[0] << 6) + (modes[1] << 4) + (modes[2] << 2));
-            L.misc[7] = modes[0] | (modes[1] << 2) | (modes[2] << 4);
+            if (zh_opaque(lane) == 0) out[head] = (uint8_t)((md[0] << 6) + (md[1] << 4) + (md[2] << 2));
+            seqModes = (uint32_t)md[0] | ((uint32_t)md[1] << 2) | ((uint32_t)md[2] << 4);
         }
-        L.misc[10] = (uint32_t)(op - out); L.misc[3] = lastCount;
+        seqStart = at;
     }
-#endif
     ze_fence();
     zh_sync();
-    const uint32_t seqStart = zh_first(L.misc[10]), lastCount = zh_first(L.misc[3]);
-    const uint32_t seqModes = nbSeq ? zh_first(L.misc[7]) : 0u;
     zh_sync();
     if (cd && seqModes) { ze_copy_dict_tables(L, cd, seqModes); ze_fence(); zh_sync(); }
     ZE_T(P, ZEP_SEQTAB);
@@ -2369,6 +2498,7 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
         cd->contentSize = dictSize < 8 ? 0u : cs; cd->dictID = hasEntropy ? de->dictID : 0u;
         cd->rep[0] = 1; cd->rep[1] = 4; cd->rep[2] = 8;
         cd->hufRepeat = cd->llRepeat = cd->ofRepeat = cd->mlRepeat = 0; cd->hufMaxSym = 0;
+        L.misc[5] = 0;
         if (!st && hasEntropy) {
             // HUF_readCTable (zstd.c:17048): code lengths from weights, canonical values per length in symbol order
             const uint32_t cnt = de->hufCount;
@@ -2385,18 +2515,12 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
                 for (uint32_t s = 0; s < cnt; s++) { const uint32_t nb = cd->hufBits[s]; cd->hufCode[s] = nb ? start[nb]++ : (uint16_t)0; }
                 cd->hufMaxSym = cnt - 1;
                 cd->hufRepeat = (!zero && cnt == 256) ? 2u : 1u;
-                int16_t norm[64];
-                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->ofMax && s < 32 ? de->ofNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[1], ze_cell_sym(L), ze_fill_area(L), norm, ZF_MAXOFF, de->ofLog);      // all offset codes, like the reference
                 {   const uint32_t need = (uint32_t)zh_highbit32(cs + 128u * 1024);
-                    cd->ofRepeat = ze_ncount_repeat(norm, de->ofMax, need < ZF_MAXOFF ? need : ZF_MAXOFF); }
-                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->mlMax && s < 53 ? de->mlNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[2], ze_cell_sym(L), ze_fill_area(L), norm, de->mlMax, de->mlLog);
-                cd->mlRepeat = ze_ncount_repeat(norm, de->mlMax, ZF_MAXML);
-                for (uint32_t s = 0; s < 64; s++) norm[s] = s <= de->llMax && s < 36 ? de->llNorm[s] : (int16_t)0;
-                ze_fse_build_ctab(cd->tab[0], ze_cell_sym(L), ze_fill_area(L), norm, de->llMax, de->llLog);
-                cd->llRepeat = ze_ncount_repeat(norm, de->llMax, ZF_MAXLL);
+                    cd->ofRepeat = ze_ncount_repeat(de->ofNorm, de->ofMax, need < ZF_MAXOFF ? need : ZF_MAXOFF); }
+                cd->mlRepeat = ze_ncount_repeat(de->mlNorm, de->mlMax, ZF_MAXML);
+                cd->llRepeat = ze_ncount_repeat(de->llNorm, de->llMax, ZF_MAXLL);
                 for (int i = 0; i < 3; i++) cd->rep[i] = de->rep[i];
+                L.misc[5] = 1;                                                      // the three encoding tables follow, built by the whole wave
             }
         }
         cd->status = st;
@@ -2407,8 +2531,23 @@ ZH_DEVFN void ze_cdict_body(const uint8_t* dict, uint32_t dictSize, const ZhipDi
     const uint32_t st = zh_first(L.misc[0]);
     const int hlog = (int)zh_first(L.misc[1]), clog = (int)zh_first(L.misc[2]), mml = (int)zh_first(L.misc[3]);
     const bool fast = zh_first(L.misc[4]) == 1;          // ZSTD_fillHashTableForCDict (zstd.c:31730): ONE table, hashed on minMatch bytes, same fill rule as the long table
+    const bool tables = zh_first(L.misc[5]) != 0;
     zh_sync();
     if (st) return;
+    if (tables) {                                        // FSE encoding tables of the dictionary's distributions (all offset codes, like the reference)
+        int16_t* const norm = ze_norm_area(L);
+        for (int w = 0; w < 3; w++) {
+            const int16_t* src = w == 0 ? de->llNorm : w == 1 ? de->ofNorm : de->mlNorm;
+            const uint32_t mx = w == 0 ? de->llMax : w == 1 ? de->ofMax : de->mlMax, lim = w == 0 ? 36u : w == 1 ? 32u : 53u;
+            norm[lane] = lane <= mx && lane < lim ? src[lane] : (int16_t)0;
+            ze_fence(); zh_sync();
+            ze_fse_build_ctab_wave(L.tab[w], norm, w == 1 ? (uint32_t)ZF_MAXOFF : mx, w == 0 ? de->llLog : w == 1 ? de->ofLog : de->mlLog, ze_cell_sym(L), (uint16_t*)L.stack, ze_fill_area(L));
+            ze_fence(); zh_sync();
+            {   const uint32_t* s4 = (const uint32_t*)&L.tab[w]; uint32_t* d4 = (uint32_t*)&cd->tab[w];       // built in LDS, copied out as dwords
+                for (uint32_t i = lane; i < sizeof(ZeCTab) / 4; i += 64) d4[i] = s4[i]; }
+            ze_fence(); zh_sync();
+        }
+    }
     for (uint32_t i = lane; i < (1u << hlog); i += 64) { hashLong[i] = 0; tmpLong[i] = 0; }
     if (!fast) for (uint32_t i = lane; i < (1u << clog); i += 64) hashSmall[i] = 0;
     ze_fence();

@@ -243,3 +243,58 @@ extern "C" int emu_check_code_formulas(void)
     }
     return bad;
 }
+
+// ---- the entropy kernel's wave-parallel table builders on their own (checked against the oracle's serial restatement on arbitrary histograms)
+static ZeLDS g_tbL;
+struct TbFse { uint32_t count[64]; uint32_t total, maxSym, lg; int useLow; int16_t norm[64]; uint8_t out[128]; uint32_t h; ZeCTab tab; int rc; };
+static void tbfse_lane(void* p)
+{
+    TbFse* d = (TbFse*)p;
+    const uint32_t lane = zh_lane();
+    ZeLDS& L = g_tbL;
+    L.cnt[0][lane] = d->count[lane];
+    zh_sync();
+    int16_t* norm = ze_norm_area(L);
+    const int rc = ze_fse_normalize_wave(norm, d->lg, L.cnt[0], d->total, d->maxSym, d->useLow != 0);
+    ze_fence(); zh_sync();
+    if (lane == 0) d->rc = rc;
+    if (rc < 0) return;
+    d->norm[lane] = lane <= d->maxSym ? norm[lane] : 0;
+    const uint32_t h = ze_fse_write_ncount_wave(d->out, norm, d->maxSym, d->lg, (uint32_t*)((uint8_t*)L.node + 2048));
+    if (lane == 0) d->h = h;
+    ze_fse_build_ctab_wave(L.tab[0], norm, d->maxSym, d->lg, ze_cell_sym(L), (uint16_t*)L.stack, ze_fill_area(L));
+    zh_sync();
+    if (lane == 0) d->tab = L.tab[0];
+}
+extern "C" int emu_fse_tables(const uint32_t* count, uint32_t maxSym, uint32_t total, uint32_t lg, int useLow,
+                              int16_t* normOut, uint8_t* ncountOut, uint32_t* ncountSize, uint16_t* cellOf, uint16_t* next)
+{
+    static TbFse d; memset(&d, 0, sizeof d);
+    for (uint32_t s = 0; s <= maxSym; s++) d.count[s] = count[s];
+    d.total = total; d.maxSym = maxSym; d.lg = lg; d.useLow = useLow;
+    memset(&g_tbL, 0xA5, sizeof g_tbL);
+    zhemu::run_grid(1, tbfse_lane, &d);
+    if (d.rc < 0) return -1;
+    memcpy(normOut, d.norm, sizeof d.norm); memcpy(ncountOut, d.out, d.h); *ncountSize = d.h;
+    for (uint32_t s = 0; s <= maxSym + 1; s++) cellOf[s] = d.tab.cellOf[s];
+    for (uint32_t u = 0; u < (1u << lg); u++) next[u] = d.tab.next[u];
+    return 0;
+}
+struct TbHuf { uint32_t hist[256]; uint32_t maxSym, maxBits; uint8_t bits[256]; uint16_t code[256]; uint32_t lg; };
+static void tbhuf_lane(void* p)
+{
+    TbHuf* d = (TbHuf*)p; ZeLDS& L = g_tbL; const uint32_t lane = zh_lane();
+    for (uint32_t i = lane; i < 256; i += 64) L.hist[i] = d->hist[i];
+    zh_sync();
+    const uint32_t lg = ze_huf_build(L, d->maxSym, d->maxBits);
+    zh_sync();
+    if (lane == 0) { d->lg = lg; memcpy(d->bits, L.hufBits, 256); memcpy(d->code, L.hufCode, 512); }
+}
+extern "C" uint32_t emu_huf_build(const uint32_t* hist, uint32_t maxSym, uint32_t maxBits, uint8_t* bits, uint16_t* code)
+{
+    static TbHuf d; memset(&d, 0, sizeof d); memcpy(d.hist, hist, 1024); d.maxSym = maxSym; d.maxBits = maxBits;
+    memset(&g_tbL, 0xA5, sizeof g_tbL);
+    zhemu::run_grid(1, tbhuf_lane, &d);
+    memcpy(bits, d.bits, 256); memcpy(code, d.code, 512);
+    return d.lg;
+}

@@ -188,6 +188,62 @@ def test_computed_sequence_codes_match_the_format_tables(emu):
     assert emu.lib.emu_check_code_formulas() == 0
 
 
+def test_wave_parallel_table_builders_match_the_serial_restatement(emu, oracle, corpus):
+    """The entropy kernel builds its FSE tables (normalisation incl. the fallback distribution, the table description, the encoding
+    table) and its Huffman code with one lane per symbol / cell; the oracle does the same serially, the way libzstd does
+    (zstd.c:16402, :16316, :16170, :16005, :17513). Same histograms in, same tables out -- on far more shapes than whole frames reach."""
+    import ctypes as C
+    import numpy as np
+    rng = np.random.default_rng(1)
+    e, o = emu.lib, oracle.lib
+    done = 0
+    for it in range(1500):
+        max_sym = int(rng.integers(1, 53))
+        kind = it % 4
+        if kind == 0: cnt = rng.integers(0, 50, max_sym + 1)
+        elif kind == 1: cnt = (rng.pareto(1.0, max_sym + 1) * 20).astype(np.int64)
+        elif kind == 2: cnt = rng.integers(0, 3, max_sym + 1) * rng.integers(1, 2000, max_sym + 1)
+        else: cnt = rng.integers(0, 5000, max_sym + 1)
+        cnt = cnt.astype(np.uint32); cnt[max_sym] = max(1, cnt[max_sym])
+        if np.count_nonzero(cnt) < 2: cnt[0] = 3
+        total = int(cnt.sum())
+        nz = int(np.count_nonzero(cnt))
+        if cnt.max() == total: continue
+        lg = int(rng.integers(max(5, int(np.ceil(np.log2(nz))) + 1), 10))
+        if lg > 9 or (1 << lg) < nz: continue
+        outs = []
+        for lib, fn in ((e, "emu_fse_tables"), (o, "zo_test_fse_tables")):
+            norm = np.zeros(64, dtype=np.int16); nc = np.zeros(512, dtype=np.uint8); h = C.c_uint32(0)
+            cell_of = np.zeros(66, dtype=np.uint16); nxt = np.zeros(512, dtype=np.uint16)
+            rc = getattr(lib, fn)(cnt.ctypes.data_as(C.c_void_p), C.c_uint32(max_sym), C.c_uint32(total), C.c_uint32(lg), C.c_int(int(total >= 2048)),
+                                  norm.ctypes.data_as(C.c_void_p), nc.ctypes.data_as(C.c_void_p), C.byref(h), cell_of.ctypes.data_as(C.c_void_p), nxt.ctypes.data_as(C.c_void_p))
+            outs.append((rc, norm[: max_sym + 1].tolist(), nc[: h.value].tobytes(), cell_of[: max_sym + 2].tolist(), nxt[: 1 << lg].tolist()) if rc == 0 else (rc,))
+        assert outs[0] == outs[1], (it, max_sym, lg, cnt.tolist())
+        done += 1
+    assert done > 1000
+    done = 0
+    for it in range(400):
+        kind = it % 5
+        if kind == 0: data = np.frombuffer(corpus.frame_bytes(it)[: int(rng.integers(300, 131072))], dtype=np.uint8)
+        elif kind == 1: data = rng.integers(0, int(rng.integers(2, 256)), int(rng.integers(100, 100000))).astype(np.uint8)
+        elif kind == 2: data = (rng.pareto(0.7, int(rng.integers(100, 130000))) * 3).clip(0, 255).astype(np.uint8)
+        elif kind == 3: data = (rng.geometric(0.02 + rng.random() * 0.3, int(rng.integers(100, 130000))) % 256).astype(np.uint8)
+        else: data = np.repeat(np.arange(200, dtype=np.uint8), 300)[: int(rng.integers(1000, 60000))]      # many equal counts: the sort's tie order
+        hist = np.bincount(data, minlength=256).astype(np.uint32)
+        nz = int(np.count_nonzero(hist))
+        max_bits = int(rng.integers(7, 12))                                         # low limits force the height limiter
+        if nz < 2 or (1 << max_bits) < nz: continue
+        max_sym = int(np.nonzero(hist)[0].max())
+        outs = []
+        for lib, fn in ((e, "emu_huf_build"), (o, "zo_test_huf_build")):
+            bits = np.zeros(256, dtype=np.uint8); code = np.zeros(256, dtype=np.uint16)
+            lg = getattr(lib, fn)(hist.ctypes.data_as(C.c_void_p), C.c_uint32(max_sym), C.c_uint32(max_bits), bits.ctypes.data_as(C.c_void_p), code.ctypes.data_as(C.c_void_p))
+            outs.append((lg, bits.tolist(), code.tolist()))
+        assert outs[0] == outs[1], (it, kind, max_sym, max_bits)
+        done += 1
+    assert done > 300
+
+
 def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
     """K1 -> KB -> K1b -> K2 -> K3 on libzstd frames that reach the staging paths of K3: literal runs and far matches above and below
     32 bytes, near matches that start before their batch, overlapped matches (offset < length), raw and RLE blocks, checksums"""
@@ -231,12 +287,12 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
 
 
 def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
-    """-DZE_TAB3 (three-lane sequence-table build in the entropy kernel) and -DZP_K3_LONGONE (round 1's one-long-match-per-round form of
+    """-DZP_K3_LONGONE (round 1's one-long-match-per-round form of
     K3; the all-ready-long-matches form became the default after the r02c measurement) are compiled out of the product: keep them
     bit-exact so that a GPU session can A/B them straight away"""
     import numpy as np
     from tests import emulib
-    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZE_TAB3", "-DZP_K3_LONGONE"])
+    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZP_K3_LONGONE"])
     emu = emulib.Emu(so)
     rng = np.random.default_rng(11)
     blk = rng.bytes(600)
