@@ -62,7 +62,6 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             const uint32_t hs = mg + 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
             if (fhd & 8) { err = ZE_FRAMEPARAM_UNSUPPORTED; break; }
             if (srcSize < hs) { err = ZE_SRC_SIZE_WRONG; break; }
-            if (dictCode) { fallback = true; break; }                       // dictionary frames: generic kernel decides
             uint32_t pos = mg + 1;
             uint64_t windowSize = 0;
             if (!single) {
@@ -70,6 +69,9 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 if (wl > 31) { err = ZE_WINDOW_TOO_LARGE; break; }
                 windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wd & 7);
             }
+            {   const uint32_t dictID = dictCode == 0 ? 0u : dictCode == 1 ? src[pos] : dictCode == 2 ? zh_ld16(src + pos) : zh_ld32(src + pos);
+                pos += dictBytes;
+                if (dictID && dictID != a.dictID) { err = ZE_DICT_WRONG; break; } }     // ZSTD_decompressFrame's check (zstd.c:44246)
             uint64_t fcs = ~0ull;
             if (fcsCode == 0) { if (single) fcs = src[pos]; }
             else if (fcsCode == 1) fcs = (uint64_t)zh_ld16(src + pos) + 256;
@@ -113,7 +115,13 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
             ZD_T(P, ZP_HEADER);
             ZdLitDefer df; df.table = a.hufTables + (size_t)i * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
-            df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src;
+            df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = nullptr; df.prevLog = 0;
+            const ZhipDictEntropy* const de = a.dictEntropy;
+            if (de) {                                                       // a dictionary with entropy tables: they are the block's "previous" tables
+                st.hufCount = de->hufCount;
+                if (a.dictTables->hufLog <= ZP_HUF_LOGMAX) { df.prevTable = a.dictTables->huf; df.prevLog = a.dictTables->hufLog; }
+                else { zh_sync(); for (uint32_t k = lane; k < 256; k += 64) L.weights[k] = de->hufWeights[k]; zh_sync(); }
+            }
             const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
             if (r < 0) { err = -r; break; }
             m.litSize = st.litSize;
@@ -136,6 +144,14 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                     if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
                     const uint32_t modes = *sp++;
                     if (modes & 3) { err = ZE_CORRUPTION; break; }
+                    if (de) {                                               // "repeat" takes the dictionary's table: drop it into its LDS place
+                        zh_sync();
+                        const uint32_t* T = a.dictTables->fse;
+                        if ((modes >> 6) == 3) { for (uint32_t k = lane; k < (1u << de->llLog); k += 64) L.fse[ZD_FSE_LL + k] = T[ZD_FSE_LL + k]; st.llLog = de->llLog; }
+                        if (((modes >> 4) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->ofLog); k += 64) L.fse[ZD_FSE_OF + k] = T[ZD_FSE_OF + k]; st.ofLog = de->ofLog; }
+                        if (((modes >> 2) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->mlLog); k += 64) L.fse[ZD_FSE_ML + k] = T[ZD_FSE_ML + k]; st.mlLog = de->mlLog; }
+                        zh_sync();
+                    }
                     int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
                     q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
                     q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
@@ -179,6 +195,37 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         zd_fence();
         if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + q, P.acc[q]); }
     }
+}
+
+// ------------------------------------------------------------------------------------------ dictionary tables (one wave, once per dictionary)
+ZH_DEVFN void zp_dict_tables_body(const ZhipDictEntropy* de, ZhipDictTables* out, ZdLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
+    if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
+    zh_sync();
+    int st = 0;
+    for (uint32_t k = lane; k < 256; k += 64) L.weights[k] = de->hufWeights[k];
+    zh_sync();
+    const int lg = zd_build_huf(L, de->hufCount);
+    if (lg < 0) st = ZE_DICT_CORRUPTED;
+    else {
+        for (uint32_t k = lane; k < (1u << lg); k += 64) out->huf[k] = L.u.huf[k];
+        if (lane == 0) out->hufLog = (uint32_t)lg;
+    }
+    zh_sync();
+    L.norm[lane] = lane < 36 ? de->llNorm[lane] : (int16_t)0;
+    if (zd_build_fse(L, L.fse + ZD_FSE_LL, de->llMax, de->llLog, ZD_KIND_LL) < 0) st = ZE_DICT_CORRUPTED;
+    zh_sync();
+    L.norm[lane] = lane < 32 ? de->ofNorm[lane] : (int16_t)0;
+    if (zd_build_fse(L, L.fse + ZD_FSE_OF, de->ofMax, de->ofLog, ZD_KIND_OF) < 0) st = ZE_DICT_CORRUPTED;
+    zh_sync();
+    L.norm[lane] = lane < 53 ? de->mlNorm[lane] : (int16_t)0;
+    if (zd_build_fse(L, L.fse + ZD_FSE_ML, de->mlMax, de->mlLog, ZD_KIND_ML) < 0) st = ZE_DICT_CORRUPTED;
+    zh_sync();
+    for (uint32_t k = lane; k < 1280; k += 64) out->fse[k] = L.fse[k];
+    if (lane == 0) out->status = st;
+    zd_fence();
 }
 
 // ------------------------------------------------------------------------------------------ KB (work order for K2)
@@ -434,7 +481,7 @@ typedef ZpBits<ZP_SEQ_RING, 4, ZP_K2_LS> ZpSeqBits;
 struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t ring[ZP_SEQ_RING << ZP_K2_LS]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
 
 ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8_t* T, const uint32_t* llInfo, const uint32_t* mlInfo,
-                               uint32_t logs, uint32_t nbSeq, uint64_t* out, uint32_t* ringCol)
+                               uint32_t logs, uint32_t nbSeq, uint64_t* out, uint32_t* ringCol, const uint32_t* rep)
 {
     const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
     // Bit window (ZpBits above): hi:lo are the current dwords, `used` bits of hi are gone; invariant at every group start:
@@ -454,7 +501,7 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
     uint32_t sM = zh_bfe(top, 32 - mlLog, mlLog);
     B.used += mlLog;
     zb_refill(B);
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8, bad = 0;
+    uint32_t rep0 = rep[0], rep1 = rep[1], rep2 = rep[2], bad = 0;
     // Software-pipelined by hand: a lone wave issues one instruction every ~4 cycles (~8 when it depends on the previous one) and waits
     // out every LDS round trip (tests/ubench), so the order of the body matters more than its length. The cells of sequence n + 1 are
     // requested as soon as the new states exist; the work that is NOT on the state chain -- values, repeat offsets, packing, the store
@@ -517,6 +564,8 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
     if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
     if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
     zh_sync();
+    uint32_t startRep[3] = {1, 4, 8};
+    if (a.dictEntropy) { startRep[0] = a.dictEntropy->rep[0]; startRep[1] = a.dictEntropy->rep[1]; startRep[2] = a.dictEntropy->rep[2]; }
     const uint32_t total = a.counters[1];
     const uint32_t nGroups = (total + ZP_K2_LANES - 1) / ZP_K2_LANES;
     for (;;) {
@@ -544,7 +593,7 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
             const uint32_t f = a.first + i;
             const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
             const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, L.tab + (size_t)lane * ZP_K2_STRIDE, L.llInfo, L.mlInfo,
-                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP, L.ring + lane);
+                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP, L.ring + lane, startRep);
             if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
                 m->path = 2;
                 const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
@@ -674,6 +723,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             pos -= (int32_t)(llLog + ofLog + mlLog); }
         const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 5;                  // trip n produces sequence n - 1 (software pipeline); a group of four is stored at the next group's first trip
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
+        if (a.dictEntropy) { rep0 = a.dictEntropy->rep[0]; rep1 = a.dictEntropy->rep[1]; rep2 = a.dictEntropy->rep[2]; }     // ZSTD_loadDEntropy's start history
         // the offset lane resolves the repeat offsets and stores; the other lanes' stores go to the frame's last arena slot (never a sequence:
         // K1 refuses blocks of more than ZP_SEQ_CAP - 16), so the loop body has no branch. Lanes past their frame's last sequence run on
         // harmlessly: every LDS access is masked, every fetch clamped, and their stores land in the unused tail of the frame's own arena slot.
@@ -791,7 +841,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const bool litRLE = m.litMode == 2;
     const uint32_t rleByte = m.litOff;
     const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)i * ZP_LIT_STRIDE;
-    const uint8_t* dictEnd = dst;                         // no dictionary on this path
+    const uint8_t* const dictEnd = a.dictContent ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
+    const uint32_t dictSize = a.dictContent ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;
     uint32_t op = 0, lp = 0, done = 0;
     const uint32_t nbSeq = m.nbSeq;
@@ -818,7 +869,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         if (op + totT > m.blockMax) return ZE_CORRUPTION;
         const uint32_t litStart = lp + incL - myLL;
         const uint32_t oRel = incT - (myLL + myML), mRel = oRel + myLL;
-        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)op + mRel)) return ZE_CORRUPTION;
+        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)op + mRel + dictSize)) return ZE_CORRUPTION;
         if (big) {
             const uint32_t bll = zh_shfl(myLL, 0), bml = zh_shfl(myML, 0), bof = zh_shfl(myOF, 0);
             if (litRLE) zd_fill_wave(dst + op, rleByte, bll); else zd_copy_wave(dst + op, litPtr + lp, bll);
@@ -860,15 +911,19 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const uint32_t preLen = pre ? (uint32_t)((int32_t)op - sAbs) : 0u;
             nearSkip = preLen;
             const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
-            const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN;
+            // with a dictionary a source may start below the frame's first byte: wholly there, it is read from the dictionary's content;
+            // the rare item that straddles the boundary is copied byte by byte by the whole wave, after the others
+            const bool strad = (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
+            const uint8_t* const mSrc = sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
+            const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN && !strad;
 #ifndef ZP_K3_NO_GLD
-            if (!zh_ballot(shortM && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {
-                const uint8_t* q = dst + (shortM ? (uint32_t)sAbs : 0u);
+            if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
+                const uint8_t* q = shortM ? mSrc : dst;
                 rm[0] = zh_ld64(q); rm[1] = zh_ld64(q + 8); rm[2] = zh_ld64(q + 16); rm[3] = zh_ld64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
             } else
 #endif
-            if (shortM) zd_ld32(dst + sAbs, lenMi, rm);
-            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM || pre) && !shortM;
+            if (shortM) zd_ld32(mSrc, lenMi, rm);
+            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM || pre) && !shortM && !strad;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
             const uint32_t ue = zh_scan_add(uL + uM);
             const uint32_t U = zh_shfl(ue, 63);
@@ -881,12 +936,19 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #define ZP_UNIT(u) do { uint32_t j_ = 0; for (uint32_t stp_ = 32; stp_; stp_ >>= 1) if (L.uEnd[j_ + stp_ - 1] <= (u)) j_ += stp_; \
                     uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
                     const uint32_t len_ = isL_ ? L.lenL[j_] : L.lenM[j_]; const uint32_t off_ = 16 * k_ + 16 <= len_ ? 16 * k_ : len_ - 16; \
-                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : dst + L.srcM[j_] + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
+                    const int32_t sm_ = (int32_t)L.srcM[j_]; \
+                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : (sm_ >= 0 ? dst + sm_ : dictEnd + sm_) + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
                 if (lane < U) ZP_UNIT(lane);
             }
             if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }      // (frame-uniform)
             if (shortL) zd_st32(asmb + oRel, myLL, rl);
             if (shortM) zd_st32(asmb + mRel, lenMi, rm);
+            for (uint64_t mk = zh_ballot(strad); mk; mk &= mk - 1) {               // dictionary / frame straddlers (at most a few per frame)
+                const uint32_t l = (uint32_t)zh_ctz64(mk);
+                const uint32_t d = zh_shfl(mRel, l), nn = zh_shfl(lenMi, l);
+                const int32_t s0 = (int32_t)zh_shfl((uint32_t)sAbs, l);
+                for (uint32_t j = lane; j < nn; j += 64) asmb[d + j] = (uint8_t)zd_hist_byte(dst, dictEnd, s0 + (int32_t)j);
+            }
             if (U) {
                 if (lane < U) { zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
                 for (uint32_t u = lane + 64; u < U; u += 64) { ZP_UNIT(u); zh_st64(udp, uv.lo); zh_st64(udp + 8, uv.hi); }
@@ -937,14 +999,14 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 if (fof >= 64) {
                     for (uint32_t c = 0; c < fml; c += 64) {
                         const uint32_t j = c + lane;
-                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp]; }
+                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp); }
                         if (fof < fml) zh_sync();
                     }
                 } else {
                     uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                     for (uint32_t j = lane; j < fml; j += 64) {
                         const int32_t sp = fs + (int32_t)idx;
-                        asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp];
+                        asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
                         idx += adv; if (idx >= fof) idx -= fof;
                     }
                 }
@@ -1022,14 +1084,14 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     if (fof >= 64) {
                         for (uint32_t c = 0; c < fml; c += 64) {
                             const uint32_t j = c + lane;
-                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp]; }
+                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp); }
                             if (fof < fml) zh_sync();
                         }
                     } else {
                         uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                         for (uint32_t j = lane; j < fml; j += 64) {
                             const int32_t sp = fs + (int32_t)idx;
-                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : dst[sp];
+                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
                             idx += adv; if (idx >= fof) idx -= fof;
                         }
                     }

@@ -37,6 +37,11 @@ struct ZhipDictEntropy {
     int32_t  status;            // 0 or a zstd error code (ZE_DICT_CORRUPTED)
 };
 
+// What the decode pipeline takes from a dictionary's entropy section, built ONCE per dictionary (zhip_dict_tables_kernel): the three
+// tANS decoding tables in the builder's LDS cell format (K1 drops them into its LDS when a frame's table mode is "repeat") and the
+// Huffman decoding table in K1b's cell format (copied into the frame's table slot when its literals are "treeless").
+struct ZhipDictTables { uint32_t fse[1280]; uint16_t huf[4096]; uint32_t hufLog; int32_t status; };
+
 struct ZhipDecodeArgs {
     const uint8_t* src;             // all frames
     const uint64_t* srcSegs;        // n x (offset, length)
@@ -226,4 +231,9 @@ struct ZhipPipeArgs {
     uint64_t maxWindowSize;
     uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
     unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases
+    // dictionary (all null / 0 without one): id, raw content (match sources before the frame's first byte), parsed entropy section, its tables
+    uint32_t dictID, dictContentSize;
+    const uint8_t* dictContent;
+    const ZhipDictEntropy* dictEntropy;     // null for a raw-content dictionary
+    const ZhipDictTables* dictTables;       // non-null iff dictEntropy is
 };

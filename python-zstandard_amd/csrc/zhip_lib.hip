@@ -86,6 +86,11 @@ ZH_GLOBAL void zhip_selftest_kernel(uint32_t* out)
     uint64_t m = zh_ballot((zh_lane() & 1) != 0);
     out[zh_lane()] = v + (uint32_t)zh_popc64(m) + zh_shfl(zh_lane(), 63) + zh_first(zh_lane() + 7);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_dict_tables_kernel(const ZhipDictEntropy* de, ZhipDictTables* out)
+{
+    __shared__ ZdLDS L;
+    zp_dict_tables_body(de, out, L);
+}
 ZH_GLOBAL __launch_bounds__(64) void zhip_parse_dict_kernel(const uint8_t* dict, uint32_t dictSize, ZhipDictEntropy* de)
 {
     __shared__ ZdLDS L;
@@ -244,7 +249,7 @@ struct zhip_ctx {
     bool hasCDict = false; uint32_t cdictContentOffset = 0, cdictAttachMax = ZE_DICT_ATTACH_MAX; int cdictHlog = 0, cdictClog = 0, cdictStrat = 2;
     uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
-    DevBuf dictBlob, dictEntropy;
+    DevBuf dictBlob, dictEntropy, dictTables;
     uint32_t dictSize = 0, dictID = 0, dictContentOffset = 0; bool dictHasEntropy = false;
     uint64_t maxWindowSize = (1ull << 27) + 1;
     int dformat = ZHIP_FORMAT_ZSTD1;
@@ -328,7 +333,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -386,7 +391,7 @@ extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dict
     // unless a full dictionary was demanded, which is then "Dictionary is corrupted"
     const bool hasMagic = dictSize >= 8 && rd32((const uint8_t*)hostDict) == ZF_DICT_MAGIC;
     if (dictType == ZHIP_DICT_FULLDICT && !hasMagic) { c->ddictKey = 0; return -ZE_DICT_CORRUPTED; }
-    if (c->dictBlob.reserve(dictSize + 16)) { c->ddictKey = 0; return g_reserveRc; }
+    if (c->dictBlob.reserve(dictSize + 64)) { c->ddictKey = 0; return g_reserveRc; }       // (+ 64: K3 reads whole 32-byte windows)
     if (c->dictEntropy.reserve(sizeof(ZhipDictEntropy))) { c->ddictKey = 0; return g_reserveRc; }
     HIP_TRY(hipMemcpy(c->dictBlob.p, hostDict, dictSize, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(c->dictEntropy.p, 0, sizeof(ZhipDictEntropy)));
@@ -397,6 +402,14 @@ extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dict
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(&de, c->dictEntropy.p, sizeof de, hipMemcpyDeviceToHost));
         if (de.status) { c->ddictKey = 0; return -de.status; }            // negative zstd error code: dictionary corrupted
+        if (de.hufCount) {                                                // the decode pipeline's ready-made tables
+            if (c->dictTables.reserve(sizeof(ZhipDictTables))) { c->ddictKey = 0; return g_reserveRc; }
+            hipLaunchKernelGGL(zhip_dict_tables_kernel, dim3(1), dim3(64), 0, 0, (const ZhipDictEntropy*)c->dictEntropy.p, (ZhipDictTables*)c->dictTables.p);
+            HIP_TRY(hipGetLastError());
+            int32_t tst = 0;
+            HIP_TRY(hipMemcpy(&tst, (const uint8_t*)c->dictTables.p + offsetof(ZhipDictTables, status), 4, hipMemcpyDeviceToHost));
+            if (tst) { c->ddictKey = 0; return -ZE_DICT_CORRUPTED; }
+        }
     }
     c->dictSize = (uint32_t)dictSize; c->dictID = de.dictID; c->dictContentOffset = de.contentOffset;
     c->dictHasEntropy = de.hufCount != 0;
@@ -504,7 +517,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->counter.reserve(64)) return g_reserveRc;
     HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
     const uint32_t* d_fallbackList = nullptr; const uint32_t* d_fallbackCount = nullptr;
-    const bool usePipeline = c->dictSize == 0 && !c->knob.noPipeline;
+    const bool usePipeline = !c->knob.noPipeline;
     if (usePipeline) {
         // phase-split fast path for single-block, dictionary-less frames (zhip_decode_pipeline.hpp); everything it declines
         // lands in the fallback list consumed by the generic kernel below.
@@ -529,6 +542,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
         pa.outSizes = d_outSizes; pa.status = d_status; pa.fallbackList = (uint32_t*)c->pipeFallback.p;
         pa.maxWindowSize = c->maxWindowSize; pa.magicless = c->dformat == ZHIP_FORMAT_ZSTD1_MAGICLESS;
+        if (c->dictSize) {                                  // dictionary frames take the pipeline too (r02v; the generic kernel rebuilt the dictionary's tables per frame)
+            pa.dictID = c->dictID;
+            pa.dictContent = (const uint8_t*)c->dictBlob.p + c->dictContentOffset;
+            pa.dictContentSize = c->dictSize - c->dictContentOffset;
+            pa.dictEntropy = c->dictHasEntropy ? (const ZhipDictEntropy*)c->dictEntropy.p : nullptr;
+            pa.dictTables = c->dictHasEntropy ? (const ZhipDictTables*)c->dictTables.p : nullptr;
+        }
         if (c->knob.prof) {
             if (!c->profPipe) HIP_TRY(hipMalloc((void**)&c->profPipe, 32 * 8));
             HIP_TRY(hipMemsetAsync(c->profPipe, 0, 32 * 8, stream));

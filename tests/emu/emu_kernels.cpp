@@ -135,6 +135,32 @@ static ZpSeqQLDS g_seqqlds;
 static void k2_lane(void* p) { zp_seqq_body(*(const ZhipPipeArgs*)p, g_seqqlds); }
 #endif
 static void k3_lane(void* p) { zp_exec_body(*(const ZhipPipeArgs*)p, g_xlds); }
+// decompression dictionary for the pipeline harness (mirrors zhip_ctx_set_ddict): blob, parsed entropy section, ready-made tables
+static std::vector<uint8_t> g_ddBlob; static ZhipDictEntropy g_ddEntropy; static ZhipDictTables g_ddTables; static bool g_ddHas = false, g_ddEnt = false;
+struct DTLaunch { const ZhipDictEntropy* de; ZhipDictTables* out; };
+static void dt_lane(void* p) { DTLaunch* l = (DTLaunch*)p; zp_dict_tables_body(l->de, l->out, g_lds); }
+extern "C" int emu_set_ddict(const uint8_t* dict, uint32_t size, int rawContent)
+{
+    g_ddHas = g_ddEnt = false;
+    if (!dict || !size) return 0;
+    g_ddBlob.assign(dict, dict + size); g_ddBlob.resize(size + 64, 0);
+    memset(&g_ddEntropy, 0, sizeof g_ddEntropy); memset(&g_ddTables, 0, sizeof g_ddTables);
+    if (!rawContent && size >= 8 && zh_ld32(dict) == 0xEC30A437u) {
+        memset(&g_lds, 0xA5, sizeof g_lds);
+        DictLaunch l = { g_ddBlob.data(), size, &g_ddEntropy };
+        zhemu::run_grid(1, dict_lane, &l);
+        if (g_ddEntropy.status) return g_ddEntropy.status;
+        if (g_ddEntropy.hufCount) {
+            memset(&g_lds, 0xA5, sizeof g_lds);
+            DTLaunch t = { &g_ddEntropy, &g_ddTables };
+            zhemu::run_grid(1, dt_lane, &t);
+            if (g_ddTables.status) return g_ddTables.status;
+            g_ddEnt = true;
+        }
+    }
+    g_ddHas = true;
+    return 0;
+}
 extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst,
                                        const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status, uint32_t nBlocks, uint32_t chunk)
 {
@@ -151,6 +177,11 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     a.orderLit = (uint32_t*)calloc(chunk, 4);
     a.counters = counters; a.fallbackCount = &counters[8]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
+    if (g_ddHas) {
+        const uint32_t co = g_ddEnt ? g_ddEntropy.contentOffset : 0u;
+        a.dictID = g_ddEnt ? g_ddEntropy.dictID : 0u; a.dictContent = g_ddBlob.data() + co; a.dictContentSize = (uint32_t)(g_ddBlob.size() - 64) - co;
+        a.dictEntropy = g_ddEnt ? &g_ddEntropy : nullptr; a.dictTables = g_ddEnt ? &g_ddTables : nullptr;
+    }
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (int q = 0; q < 8; q++) counters[q] = 0;
@@ -173,6 +204,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     g.src = src; g.srcSegs = srcSegs; g.dst = dst; g.dstSegs = dstSegs; g.outSizes = outSizes; g.status = status;
     g.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
     g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.magicless = g_magicless; g.frameList = a.fallbackList; g.listCount = &counters[8];
+    g.dictID = a.dictID; g.dictContent = a.dictContent; g.dictContentSize = a.dictContentSize; g.dictEntropy = a.dictEntropy;
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[8];

@@ -131,3 +131,14 @@ def _emu_decompress_pipeline(self, frames, sizes, n_blocks=2, chunk=0):
 
 
 Emu.decompress_pipeline = _emu_decompress_pipeline
+
+
+def _emu_set_ddict(self, dict_data, raw_content=False):
+    """decompression dictionary of the pipeline harness (None: no dictionary); returns the zstd error code of its digestion, 0 = fine"""
+    if not dict_data:
+        return self.lib.emu_set_ddict(None, C.c_uint32(0), C.c_int(0))
+    d = np.frombuffer(dict_data, dtype=np.uint8).copy()
+    return self.lib.emu_set_ddict(d.ctypes.data_as(C.c_void_p), C.c_uint32(len(d)), C.c_int(1 if raw_content else 0))
+
+
+Emu.set_ddict = _emu_set_ddict

@@ -286,6 +286,43 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
     assert outs == raws
 
 
+def test_emulated_decode_pipeline_with_dictionaries(emu, ref, corpus):
+    """dictionary frames through K1 -> KB -> K1b -> K2 -> K3 (r02v; before, every one went to the generic kernel, which rebuilt the
+    dictionary's tables per frame): treeless literals and "repeat" sequence tables take the dictionary's ready-made tables, the repeat
+    offsets start from the dictionary's, match sources below the frame's first byte come from its content -- wholly, or straddling
+    the boundary. Trained and raw-content dictionaries, frames that ignore the dictionary, wrong / missing dictionary."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    docs = [corpus.frame_bytes(700 + i)[j * 4096:(j + 1) * 4096] for i in range(24) for j in range(4)]
+    trained = ref.train_dictionary(16384, [corpus.frame_bytes(900 + i)[:3000] for i in range(400)])
+    rawd = corpus.frame_bytes(600)[:6000]
+    try:
+        for dd in (trained, rawd):
+            content = dd[-4000:]
+            b30 = rng.bytes(30)
+            straddlers = [b30 + content[-20:] + b30[:15] + rng.bytes(10) + content[-40:] + b30[:25],      # sources that start in the dictionary and end in the frame
+                          content[-300:] + content[-300:] + rng.bytes(5) + content[-64:] + content[-300:-250]]
+            raws = docs + [b"", b"a", corpus.frame_bytes(5)[:40000], rawd[1000:5000] + rng.bytes(50) + rawd[:800], (dd[-3000:] + docs[3])[:6000]] + straddlers
+            for level in (3, 1):
+                frames = [ref.compress(r, level=level, dict_data=dd) for r in raws]
+                frames += [ref.compress(docs[0], level=level), ref.compress(rng.bytes(700), level=level, dict_data=dd)]      # a frame made without it; raw block
+                want = raws + [docs[0], None]
+                assert emu.set_ddict(dd) == 0
+                for chunk in (0, 7):
+                    outs, st, nfb = emu.decompress_pipeline(frames, [len(r) if r is not None else 700 for r in want], n_blocks=3, chunk=chunk)
+                    assert not any(st) and nfb == 0
+                    assert all(w is None or o == w for o, w in zip(outs, want)), (level, chunk)
+        # wrong dictionary (another id), no dictionary at all: dictionary_wrong (32) for frames that name one, the others still decode
+        other = ref.train_dictionary(8192, [corpus.frame_bytes(300 + i)[:2000] for i in range(300)])
+        frames = [ref.compress(docs[1], level=3, dict_data=trained), ref.compress(docs[2], level=3)]
+        for dd in (other, None):
+            assert emu.set_ddict(dd) == 0
+            outs, st, nfb = emu.decompress_pipeline(frames, [4096, 4096], n_blocks=2, chunk=0)
+            assert st == [32, 0] and outs[1] == docs[2]
+    finally:
+        emu.set_ddict(None)
+
+
 def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     """-DZP_K3_LONGONE (round 1's one-long-match-per-round form of
     K3; the all-ready-long-matches form became the default after the r02c measurement) are compiled out of the product: keep them
