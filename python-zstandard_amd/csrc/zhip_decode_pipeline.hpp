@@ -188,6 +188,13 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         if (err) { m.status = err; m.path = 0; }
         zh_sync();
         if (zh_opaque(lane) == 0) {
+            if (m.path == 1) {
+                // the frame's place in K2's and K1b's work orders (KB below): its bin, and its rank inside the bin -- the atomic's return value
+                const uint32_t ks = m.nbSeq ? 1u + (m.nbSeq >> ZP_BIN_SHIFT) : 0u;
+                const uint32_t kl = (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
+                if (ks) m.pad = zh_atomic_add(a.counters + ZP_CNT_BINS + (256 - (ks > 256 ? 256u : ks)), 1u);
+                if (kl) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + (256 - (kl > 256 ? 256u : kl)), 1u) << 1;
+            }
             a.meta[i] = m;
             if (m.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
@@ -228,46 +235,32 @@ ZH_DEVFN void zp_dict_tables_body(const ZhipDictEntropy* de, ZhipDictTables* out
     zd_fence();
 }
 
-// ------------------------------------------------------------------------------------------ KB (work order for K2)
-// One wave per chunk: 256-bin counting sort of the frames that have sequences to decode, by decreasing sequence count.
-struct ZpBinLDS { uint32_t hist[256]; uint32_t base[256]; };
-// block 0: K2's order (frames with sequences, by sequence count); block 1: K1b's order (frames with Huffman literals, by literal count)
+// ------------------------------------------------------------------------------------------ KB (work orders for K2 and K1b)
+// Counting sorts by sequence count (K2's order) and by literal count (K1b's), so that lanes sharing a wave run equally long. K1 has done
+// the counting: every fast-path frame added itself to its bin's counter and kept the counter's old value as its rank in the bin. What is
+// left is a prefix sum over 256 bins (every wave does its own, it is tiny) and one scattered store per frame -- any number of waves.
+// (Rounds 1-2 had two waves walk the whole chunk's meta records twice: 0.36-0.49 ms per 32 768 frames, 18 % of a dictionary batch's decode.)
+// Blocks [0, gridDim / 2) write K2's order, the others K1b's.
+struct ZpBinLDS { uint32_t base[256]; };
 ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
 {
     const uint32_t lane = zh_lane();
-    const bool lit = zh_block() != 0;
+    const uint32_t half = zh_nblocks() / 2;
+    const bool lit = zh_block() >= half;
+    const uint32_t blk = lit ? zh_block() - half : zh_block();
     uint32_t* const order = lit ? a.orderLit : a.order;
-    for (uint32_t b = lane; b < 256; b += 64) L.hist[b] = 0;
+    const uint32_t* hist = a.counters + ZP_CNT_BINS + (lit ? 256u : 0u);
+    {   const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const uint32_t incl = zh_scan_add(h0 + h1 + h2 + h3), b0 = incl - (h0 + h1 + h2 + h3);
+        L.base[4 * lane] = b0; L.base[4 * lane + 1] = b0 + h0; L.base[4 * lane + 2] = b0 + h0 + h1; L.base[4 * lane + 3] = b0 + h0 + h1 + h2;
+        if (blk == 0 && lane == 63) a.counters[lit ? 4 : 1] = incl; }
     zh_sync();
-    // the sort key of eight records per lane: every field is loaded before any is looked at (written as nested conditions the loads were
-    // four dependent round trips per record: r02 kernel trace 0.49 ms per 32 768 frames for two waves)
-#define ZP_BIN_KEYS(k, i0) do { uint32_t pa_[8], ns_[8], lm_[8], ls_[8]; \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < 8; u_++) { const uint32_t i_ = (i0) + 64 * u_; const ZdMeta* m_ = a.meta + (i_ < a.count ? i_ : 0u); \
-            pa_[u_] = m_->path; ns_[u_] = m_->nbSeq; lm_[u_] = m_->litMode; ls_[u_] = m_->litSize; } \
-        _Pragma("unroll") for (uint32_t u_ = 0; u_ < 8; u_++) { const uint32_t kl_ = (lm_[u_] & 255u) == 3u ? 1u + (ls_[u_] >> ZP_LITBIN_SHIFT) : 0u, ks_ = ns_[u_] ? 1u + (ns_[u_] >> ZP_BIN_SHIFT) : 0u; \
-            (k)[u_] = (i0) + 64 * u_ < a.count && pa_[u_] == 1 ? (lit ? kl_ : ks_) : 0u; } } while (0)
-    // two waves walk the whole chunk's meta records: eight records per lane in flight per trip (one at a time it was a memory round trip
-    // per 64 frames: 0.49 ms per 32 768 -- r02 kernel trace)
-    for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
-        uint32_t k[8];
-        ZP_BIN_KEYS(k, i0);
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) if (k[u]) zh_lds_atomic_inc(&L.hist[256 - (k[u] > 256 ? 256 : k[u])]);
+    for (uint32_t i = blk * 64 + lane; i < a.count; i += half * 64) {
+        const ZdMeta* m = a.meta + i;
+        const uint32_t path = m->path, ns = m->nbSeq, lm = m->litMode, ls = m->litSize, rs = m->pad, rl = m->hasChecksum >> 1;
+        const uint32_t k = path != 1 ? 0u : lit ? ((lm & 255u) == 3u ? 1u + (ls >> ZP_LITBIN_SHIFT) : 0u) : (ns ? 1u + (ns >> ZP_BIN_SHIFT) : 0u);
+        if (k) order[L.base[256 - (k > 256 ? 256u : k)] + (lit ? rl : rs)] = i;
     }
-    zh_sync();
-    if (zh_opaque(lane) == 0) {
-        uint32_t run = 0;
-        for (uint32_t b = 0; b < 256; b++) { L.base[b] = run; run += L.hist[b]; }
-        a.counters[lit ? 4 : 1] = run;
-    }
-    zh_sync();
-    for (uint32_t i0 = lane; i0 < a.count; i0 += 512) {
-        uint32_t k[8];
-        ZP_BIN_KEYS(k, i0);
-#pragma unroll
-        for (uint32_t u = 0; u < 8; u++) if (k[u]) order[zh_lds_atomic_add(&L.base[256 - (k[u] > 256 ? 256 : k[u])], 1u)] = i0 + 64 * u;
-    }
-#undef ZP_BIN_KEYS
     zd_fence();
 }
 
@@ -1143,7 +1136,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     op += rest;
     const uint64_t fcs = (uint64_t)m.fcsLo | ((uint64_t)m.fcsHi << 32);
     if (fcs != ~0ull && fcs != op) return ZE_CORRUPTION;
-    if (m.hasChecksum) {
+    if (m.hasChecksum & 1) {
         zd_fence();
         zh_sync();
         if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, op);

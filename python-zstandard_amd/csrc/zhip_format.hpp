@@ -183,9 +183,9 @@ struct ZdMeta {
     uint32_t blockMax;
     uint32_t fcsLo, fcsHi;  // frame content size (0xFFFFFFFF/0xFFFFFFFF when absent)
     uint32_t produced;
-    uint32_t hasChecksum, checksum;   // content checksum to verify after execution
+    uint32_t hasChecksum, checksum;   // bit 0: a content checksum to verify after execution (the value); bits 1..: rank in K1b's work-order bin
     uint32_t logs;          // llLog | ofLog << 8 | mlLog << 16 of the frame's FSE tables (built by K1 into the table arena)
-    uint32_t pad;
+    uint32_t pad;           // rank in K2's work-order bin
 };
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
 #define ZP_SEQ_FRONT 16u                               // slots of padding before the first frame's (K2's pipelined store of "sequence -1" lands there)
@@ -212,6 +212,8 @@ struct ZdMeta {
 #define ZP_LITBIN_SHIFT 9                               // K1b work order: frames binned by litSize >> 9
 #define ZP_BIN_SHIFT 7                                  // K2 work order: frames binned by nbSeq >> 7 (256 bins), longest first
 
+#define ZP_CNT_BINS 8u                                  // counters[8 .. 8 + 512): the 256 + 256 bin counters of the two work orders
+#define ZP_CNT_WORDS (8u + 512u)
 struct ZhipPipeArgs {
     const uint8_t* src; const uint64_t* srcSegs;
     uint8_t* dst; const uint64_t* dstSegs;
@@ -223,7 +225,7 @@ struct ZhipPipeArgs {
     uint32_t* order;            // chunk : K2's work list (chunk-local frame indices sorted by decreasing sequence count)
     uint16_t* hufTables;        // chunk x ZP_HUF_CELLS : Huffman decoding tables (symbol | nbBits << 8) for K1b
     uint32_t* orderLit;         // chunk : K1b's work list (frames with Huffman literals, by decreasing literal count)
-    uint32_t* counters;         // per chunk slot: [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
+    uint32_t* counters;         // per chunk slot (ZP_CNT_WORDS words): [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
                                 //                 [4] length of `orderLit`, [5] K1b group counter
     uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel

@@ -529,11 +529,11 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
         if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
-            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve(256) || c->pipeFallback.reserve(n * 4 + 16) ||
+            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return g_reserveRc;
         for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
-        HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, 256, stream));
+        HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, (8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(evStart, stream));
         for (int sidx = 0; sidx < nslot; sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
@@ -569,8 +569,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * chunk;
             pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * chunk * ZP_HUF_CELLS;
             pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * chunk;
-            pa.counters = counters + 8 + 8 * sidx;
-            if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, 32, ss));
+            pa.counters = counters + 8 + ZP_CNT_WORDS * sidx;
+            if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, ZP_CNT_WORDS * 4, ss));
             size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
             if (c->knob.k3PerCU) g3m = (size_t)c->numCU * (size_t)c->knob.k3PerCU;
             if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
@@ -589,7 +589,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 HIP_TRY(hipEventRecord(ev[0], ss));
             }
             hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
-            hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2), dim3(64), 0, ss, pa);      // tiny; timed with K1
+            hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2 * (cnt < 4096 ? 1u : 64u)), dim3(64), 0, ss, pa);      // tiny; timed with K1
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[1], ss));

@@ -165,7 +165,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
                                        const uint64_t* dstSegs, uint64_t* outSizes, int32_t* status, uint32_t nBlocks, uint32_t chunk)
 {
     ZhipPipeArgs a; memset(&a, 0, sizeof(a));
-    uint32_t counters[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // [0..7] per-slot words, [8] fallback length
+    static uint32_t counters[ZP_CNT_WORDS + 1]; memset(counters, 0, sizeof counters);      // the slot's words (incl. the work orders' bin counters), then the fallback length
     if (chunk == 0 || chunk > n) chunk = n ? n : 1;
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
@@ -175,7 +175,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     a.order = (uint32_t*)calloc(chunk, 4);
     a.hufTables = (uint16_t*)malloc((size_t)chunk * ZP_HUF_CELLS * 2 + 64);
     a.orderLit = (uint32_t*)calloc(chunk, 4);
-    a.counters = counters; a.fallbackCount = &counters[8]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
+    a.counters = counters; a.fallbackCount = &counters[ZP_CNT_WORDS]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
     if (g_ddHas) {
         const uint32_t co = g_ddEnt ? g_ddEntropy.contentOffset : 0u;
@@ -184,10 +184,10 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     }
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
-        for (int q = 0; q < 8; q++) counters[q] = 0;
+        for (uint32_t q = 0; q < ZP_CNT_WORDS; q++) counters[q] = 0;
         memset(&g_lds, 0xA5, sizeof g_lds); memset(&g_xlds, 0xA5, sizeof g_xlds); memset(&g_binlds, 0xA5, sizeof g_binlds);   // LDS is not zeroed on hardware
         zhemu::run_grid(nBlocks, k1_lane, &a);
-        zhemu::run_grid(2, kb_lane, &a);
+        zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
         zhemu::run_grid(nBlocks, kh_lane, &a);
 #ifdef ZP_K2_LANEWISE
@@ -203,11 +203,11 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     uint32_t counter = 0;
     g.src = src; g.srcSegs = srcSegs; g.dst = dst; g.dstSegs = dstSegs; g.outSizes = outSizes; g.status = status;
     g.scratch = (uint8_t*)malloc((size_t)nBlocks * ZHIP_LIT_STRIDE);
-    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.magicless = g_magicless; g.frameList = a.fallbackList; g.listCount = &counters[8];
+    g.counter = &counter; g.n = n; g.maxWindowSize = a.maxWindowSize; g.magicless = g_magicless; g.frameList = a.fallbackList; g.listCount = &counters[ZP_CNT_WORDS];
     g.dictID = a.dictID; g.dictContent = a.dictContent; g.dictContentSize = a.dictContentSize; g.dictEntropy = a.dictEntropy;
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
-    int nfb = (int)counters[8];
+    int nfb = (int)counters[ZP_CNT_WORDS];
     free(g.scratch); free(a.meta); free(a.litArena); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
     return nfb;
 }
