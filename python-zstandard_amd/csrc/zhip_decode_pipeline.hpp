@@ -717,6 +717,9 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 5;                  // trip n produces sequence n - 1 (software pipeline); a group of four is stored at the next group's first trip
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
         if (a.dictEntropy) { rep0 = a.dictEntropy->rep[0]; rep1 = a.dictEntropy->rep[1]; rep2 = a.dictEntropy->rep[2]; }     // ZSTD_loadDEntropy's start history
+        // (taken into registers HERE: left pending, the loads made the waitcnt pass put a conservative vmcnt wait at the loop's first use of
+        // the history -- behind the ring's block load, whose round trip it then sat out every four steps: 5.6 -> 8.2 ms, r02x)
+        rep0 = zh_opaque(rep0); rep1 = zh_opaque(rep1); rep2 = zh_opaque(rep2);
         // the offset lane resolves the repeat offsets and stores; the other lanes' stores go to the frame's last arena slot (never a sequence:
         // K1 refuses blocks of more than ZP_SEQ_CAP - 16), so the loop body has no branch. Lanes past their frame's last sequence run on
         // harmlessly: every LDS access is masked, every fetch clamped, and their stores land in the unused tail of the frame's own arena slot.
@@ -727,6 +730,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         ZpVec16* outp = (ZpVec16*)(a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 4);
         const uint32_t outStep = isOF && active ? 2u : 0u;
         uint32_t g1lo = 0, g1hi = 0, g2lo = 0, g2hi = 0, g3lo = 0, g3hi = 0;       // the group's first three packed sequences
+        ZpVec16 w0, w1; w0.a = w0.b = w0.c = w0.d = 0; w1 = w0;                       // the group as stored
         int32_t boff = ZP_NOBLK, posEnd = pos; ZpVec16 blk = v0;
         // The wave is alone on its SIMD and issues one instruction every ~6.5 cycles whatever it is (r02l: time = instructions x steps), so
         // the body is written for instruction count first -- then software-pipelined by hand (as K2 above) so the LDS round trips of the
@@ -763,7 +767,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 maxOff = offset > maxOff ? offset : maxOff;
                 {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 2);
                     if (u == 0) {                                                     // (compile-time: the loop is unrolled)
-                        ZpVec16 w0, w1; w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
+                        w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
                         outp[0] = w0; outp[1] = w1; outp += outStep;
                     } else if (u == 1) { g1lo = plo; g1hi = phi; } else if (u == 2) { g2lo = plo; g2hi = phi; } else { g3lo = plo; g3hi = phi; } }
                 ZQ_F2();
@@ -787,6 +791,9 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 ZQ_F2();
                 state = (x << nb) + zh_bfe(zh_alignbit(s1, s0, (uint32_t)qS), 0, nb);
             }
+            // the stores' source registers stay untouched to here: reused as temporaries right behind the store, the write-after-read
+            // wait (vmcnt counts in order) also sat out the ring's block load issued just before it -- a load round trip per group (r02x)
+            ZH_KEEP4(w0.a, w0.b, w0.c, w0.d); ZH_KEEP4(w1.a, w1.b, w1.c, w1.d);
         }
         const uint32_t bad = maxOff >> 30;
         if (active && isOF) {
@@ -821,6 +828,9 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
     r[3] = zh_ld64(q + (len >= 8 ? len - 8 : 0u));
 }
 
+// DICT = false: no dictionary in the context -- every dictionary term folds away (K3 sits at its 128-register cap: carrying the
+// dictionary's pointer and size through the dictionary-less kernel spilled 200 bytes per lane and made it 2.6 x slower, r02x)
+template <bool DICT>
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
@@ -834,8 +844,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const bool litRLE = m.litMode == 2;
     const uint32_t rleByte = m.litOff;
     const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)i * ZP_LIT_STRIDE;
-    const uint8_t* const dictEnd = a.dictContent ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
-    const uint32_t dictSize = a.dictContent ? a.dictContentSize : 0u;
+    const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
+    const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;
     uint32_t op = 0, lp = 0, done = 0;
     const uint32_t nbSeq = m.nbSeq;
@@ -906,8 +916,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
             // with a dictionary a source may start below the frame's first byte: wholly there, it is read from the dictionary's content;
             // the rare item that straddles the boundary is copied byte by byte by the whole wave, after the others
-            const bool strad = (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
-            const uint8_t* const mSrc = sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
+            const bool strad = DICT && (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
+            const uint8_t* const mSrc = !DICT || sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
             const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN && !strad;
 #ifndef ZP_K3_NO_GLD
             if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
@@ -930,13 +940,13 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
                     const uint32_t len_ = isL_ ? L.lenL[j_] : L.lenM[j_]; const uint32_t off_ = 16 * k_ + 16 <= len_ ? 16 * k_ : len_ - 16; \
                     const int32_t sm_ = (int32_t)L.srcM[j_]; \
-                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : (sm_ >= 0 ? dst + sm_ : dictEnd + sm_) + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
+                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : (!DICT || sm_ >= 0 ? dst + sm_ : dictEnd + sm_) + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
                 if (lane < U) ZP_UNIT(lane);
             }
             if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }      // (frame-uniform)
             if (shortL) zd_st32(asmb + oRel, myLL, rl);
             if (shortM) zd_st32(asmb + mRel, lenMi, rm);
-            for (uint64_t mk = zh_ballot(strad); mk; mk &= mk - 1) {               // dictionary / frame straddlers (at most a few per frame)
+            if (DICT) for (uint64_t mk = zh_ballot(strad); mk; mk &= mk - 1) {      // dictionary / frame straddlers (at most a few per frame)
                 const uint32_t l = (uint32_t)zh_ctz64(mk);
                 const uint32_t d = zh_shfl(mRel, l), nn = zh_shfl(lenMi, l);
                 const int32_t s0 = (int32_t)zh_shfl((uint32_t)sAbs, l);
@@ -992,14 +1002,14 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 if (fof >= 64) {
                     for (uint32_t c = 0; c < fml; c += 64) {
                         const uint32_t j = c + lane;
-                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp); }
+                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
                         if (fof < fml) zh_sync();
                     }
                 } else {
                     uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                     for (uint32_t j = lane; j < fml; j += 64) {
                         const int32_t sp = fs + (int32_t)idx;
-                        asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
+                        asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
                         idx += adv; if (idx >= fof) idx -= fof;
                     }
                 }
@@ -1077,14 +1087,14 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     if (fof >= 64) {
                         for (uint32_t c = 0; c < fml; c += 64) {
                             const uint32_t j = c + lane;
-                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp); }
+                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
                             if (fof < fml) zh_sync();
                         }
                     } else {
                         uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                         for (uint32_t j = lane; j < fml; j += 64) {
                             const int32_t sp = fs + (int32_t)idx;
-                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (uint8_t)zd_hist_byte(dst, dictEnd, sp);
+                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
                             idx += adv; if (idx >= fof) idx -= fof;
                         }
                     }
@@ -1152,6 +1162,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     return 0;
 }
 
+template <bool DICT>
 ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -1166,7 +1177,7 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
         uint32_t produced = 0;
         ZdProf P; P.on = a.prof != nullptr;
         if (P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
-        const int err = zp_exec_frame(a, L, i, &produced, P);
+        const int err = zp_exec_frame<DICT>(a, L, i, &produced, P);
         if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }

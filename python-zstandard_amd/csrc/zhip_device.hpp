@@ -55,6 +55,8 @@ ZH_DEV int zh_clz64(uint64_t v) { return __clzll((long long)v); }               
 ZH_DEV int zh_highbit32(uint32_t v) { return 31 - __clz((int)v); }               // v != 0
 // the machine scheduler moves nothing across this point (hand-placed software pipelining stays where it was put)
 #define ZH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the four registers are considered read here: their values (and so their registers) live on to this point
+#define ZH_KEEP4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
 // v_bfe_u32: (v >> (off & 31)) & ((1 << (width & 31)) - 1); width 0 gives 0 whatever off is
 ZH_DEV uint32_t zh_bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 // v_alignbit_b32: low 32 bits of ((hi:lo) >> (sh & 31))
@@ -130,6 +132,7 @@ ZH_DEV uint32_t zh_wave_max(uint32_t v)
 }
 ZH_DEV void ze_fence() { zhemu::collective_wait(); }
 #define ZH_SCHED_FENCE() do { } while (0)
+#define ZH_KEEP4(a, b, c, d) do { } while (0)
 ZH_DEV int zh_popc64(uint64_t v) { return __builtin_popcountll(v); }
 ZH_DEV int zh_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 ZH_DEV int zh_clz64(uint64_t v) { return __builtin_clzll(v); }

@@ -56,7 +56,12 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)    
 ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpExecLDS L;
-    zp_exec_body(a, L);
+    zp_exec_body<false>(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_dict_kernel(ZhipPipeArgs a)      // the context has a dictionary
+{
+    __shared__ ZpExecLDS L;
+    zp_exec_body<true>(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
@@ -596,7 +601,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
             else hipLaunchKernelGGL(zhip_decode_seq1_kernel, dim3(g2), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
-            hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
             if (tm) {
