@@ -58,7 +58,10 @@ ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(Zhi
     __shared__ ZpExecLDS L;
     zp_exec_body<false>(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_dict_kernel(ZhipPipeArgs a)      // the context has a dictionary
+#ifndef ZP_K3D_MINWAVES
+#define ZP_K3D_MINWAVES 3        // three waves per SIMD: 168 registers instead of 128 -- the dictionary's terms spill 208 bytes per lane at four (r02y: 1.15 -> 0.67 ms per 32 768 documents)
+#endif
+ZH_GLOBAL __launch_bounds__(64, ZP_K3D_MINWAVES) void zhip_decode_exec_dict_kernel(ZhipPipeArgs a)      // the context has a dictionary
 {
     __shared__ ZpExecLDS L;
     zp_exec_body<true>(a, L);
