@@ -345,10 +345,12 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     assert not any(st) and dec == big
 
 
-@pytest.mark.parametrize("defines", [["-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANES=7", "-DZP_HUF_FRAMES=4"], ["-DZP_K2_LANES=36", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"]])
+@pytest.mark.parametrize("defines", [["-DZP_K2_LANEWISE", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANEWISE", "-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=4"],
+                                     ["-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
-    """K2 / K1b with fewer frames per wave (several one-wave workgroups per CU share its LDS; the bit reader's ring stride follows), K3 with a
-    smaller assembly buffer: the shapes csrc/build_variants.sh builds for A/B runs decode the same bytes"""
+    """the A/B shapes decode the same bytes: K2's lane-per-frame form of rounds 1-2 (ZHIP_K2_QUAD=0 in the product; -DZP_K2_LANEWISE selects it
+    under emulation) with 60 / 15 frames per wave, the quad form with fewer frames per wave, K1b with 16 / 4 frames per wave, K3 with a smaller
+    assembly buffer and the far-match prefetch"""
     import numpy as np
     from tests import emulib
     emu = emulib.Emu(emulib.build_variant(str(tmp_path / "libzhip_emu_shape.so"), defines))
