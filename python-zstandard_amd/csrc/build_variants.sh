@@ -3,6 +3,7 @@
 #   libzstd_hip_k2l{30,15,7}.so   -DZP_K2_LANES=n     K2: n frames per wave -> 2 / 4 / 8 one-wave workgroups per CU instead of 1   (r02c: all slower)
 #   libzstd_hip_huf{16,4}.so      -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
 #   libzstd_hip_k3d{4,2}.so       -DZP_K3D_MINWAVES=n K3's dictionary instantiation with 4 / 2 waves per SIMD instead of 3 (r02y: 89 / 111 against 113 GB/s)
+#   libzstd_hip_k3w3.so           -DZP_K3_MINWAVES=3  K3 (no dictionary) at three waves per SIMD / 168 registers (r02za)
 #   libzstd_hip_longone.so        -DZP_K3_LONGONE     K3: one ready long match per dependency round (round 1's form)
 #   libzstd_hip_nogld.so          -DZP_K3_NO_GLD      K3: the exact (predicated) piece loads from global memory everywhere (r02n)
 #   libzstd_hip_zqf{1,0}.so       -DZQ_FENCES=n       K2: fewer / no scheduling fences around the hand-placed pipeline sections (r02q)
@@ -28,6 +29,7 @@ for v in $ALL; do
     huf16) build huf16 -DZP_HUF_FRAMES=16 & ;;
     huf4) build huf4 -DZP_HUF_FRAMES=4 & ;;
     longone) build longone -DZP_K3_LONGONE & ;;
+    k3w3) build k3w3 -DZP_K3_MINWAVES=3 & ;;
     k3d4) build k3d4 -DZP_K3D_MINWAVES=4 & ;;
     k3d2) build k3d2 -DZP_K3D_MINWAVES=2 & ;;
     nogld) build nogld -DZP_K3_NO_GLD & ;;
