@@ -2,4 +2,4 @@
 # builds tests/emu/libzhip_emu.so : product kernel sources compiled for the host wave emulator (debug aid)
 set -e
 cd "$(dirname "$0")"
-g++ -O1 -g -fPIC -shared -std=c++17 -Wall -Wno-unused-function -Wno-unused-variable -o libzhip_emu.so zhemu.cpp emu_kernels.cpp
+g++ -O1 -g -fPIC -shared -std=c++17 -I. -Wall -Wno-unused-function -Wno-unused-variable -o libzhip_emu.so zhemu.cpp emu_kernels.cpp

@@ -4,4 +4,4 @@
 #       ZHIP_EMU_SO=/tmp/libzhip_emu_asan.so python tests/stress_emu_encode.py 1 p 3
 set -e
 cd "$(dirname "$0")"
-g++ -O1 -g -fPIC -shared -std=c++17 -fsanitize=address -fno-omit-frame-pointer -Wno-unused-function -Wno-unused-variable -o ${1:-/tmp/libzhip_emu_asan.so} zhemu.cpp emu_kernels.cpp
+g++ -O1 -g -fPIC -shared -std=c++17 -I. -fsanitize=address -fno-omit-frame-pointer -Wno-unused-function -Wno-unused-variable -o ${1:-/tmp/libzhip_emu_asan.so} zhemu.cpp emu_kernels.cpp

@@ -15,7 +15,7 @@ def build():
 
 def build_variant(out_path, defines):
     """the same sources with extra -D flags (experimental kernel variants), e.g. ["-DZP_K3_LONGONE"]"""
-    subprocess.check_call(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable"] + list(defines) +
+    subprocess.check_call(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-I" + _DIR, "-Wno-unused-function", "-Wno-unused-variable"] + list(defines) +
                           ["-o", out_path, os.path.join(_DIR, "zhemu.cpp"), os.path.join(_DIR, "emu_kernels.cpp")])
     return out_path
 
