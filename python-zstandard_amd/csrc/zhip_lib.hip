@@ -269,7 +269,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -294,6 +294,8 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
+        if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
+        if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
     zh_resolve_rows(&c->rows, 3, nullptr);
@@ -1084,13 +1086,15 @@ extern "C" void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload)
 
 // chunk boundaries [cut[k], cut[k+1]) over n items: a chunk closes when its input or output bytes reach maxBytes or it holds maxItems
 // items. segs: [0,n) source, [n,2n) destination.
-static std::vector<size_t> host_chunks(const zhip_segment* segs, size_t n, uint64_t maxBytes, size_t maxItems)
+// firstItems (0: like the others): a smaller first chunk shortens the pipeline's fill -- the time before the first kernel can start
+static std::vector<size_t> host_chunks(const zhip_segment* segs, size_t n, uint64_t maxBytes, size_t maxItems, size_t firstItems = 0)
 {
     std::vector<size_t> cut(1, 0);
     uint64_t in = 0, out = 0; size_t cnt = 0;
     for (size_t i = 0; i < n; i++) {
         in += segs[i].length; out += segs[n + i].length; cnt++;
-        if (in >= maxBytes || out >= maxBytes || cnt >= maxItems) { cut.push_back(i + 1); in = out = 0; cnt = 0; }
+        const size_t lim = cut.size() == 1 && firstItems ? firstItems : maxItems;
+        if (in >= maxBytes || out >= maxBytes || cnt >= lim) { cut.push_back(i + 1); in = out = 0; cnt = 0; }
     }
     if (cut.back() != n) cut.push_back(n);
     return cut;
@@ -1235,7 +1239,7 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // the match kernel is a per-frame latency chain (its time barely depends on the batch below ~16 K frames), so compress chunks are
     // large: two of them overlap one's upload with the other's kernels, more would only add chains end to end
-    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)4 << 30, 32768);
+    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)4 << 30, c->knob.hchunkE, n > c->knob.hchunkE ? c->knob.hchunkE0 : 0);
     const size_t nChunks = cut.size() - 1;
     // device: sources, slots, dense frames, segment table, [sizes | offsets | chunk totals | status]
     const size_t metaBytes = n * (2 * sizeof(uint64_t) + sizeof(int32_t)) + (nChunks + 1) * sizeof(uint64_t) + 32;
