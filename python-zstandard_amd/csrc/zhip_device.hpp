@@ -20,6 +20,7 @@
 #else
 #define ZH_DEVFN __device__
 #endif
+#define ZH_COLD __device__ __attribute__((noinline))     // once-per-frame routines: their own register budget, kept out of the callers' hot loops
 #define ZH_GLOBAL extern "C" __global__
 #define ZH_SHARED __shared__
 #define ZH_CONST __device__ const

@@ -148,7 +148,7 @@ ZH_CONST uint32_t ze_rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000
 // The fallback distribution (FSE_normalizeM2, zstd.c:16316), entered when plain rounding would take more than half of the largest
 // symbol's cells away: rare symbols get their minimum first, the rest share what is left in proportion, by running sums of
 // count x rStep (each symbol's cell count is a difference of two consecutive sums -- a 64-bit prefix sum here).
-ZH_DEVFN int ze_fse_normalize_m2_wave(int16_t* norm, uint32_t lg, uint32_t c, uint32_t total, uint32_t maxSym, int32_t lowProb)
+ZH_COLD int ze_fse_normalize_m2_wave(int16_t* norm, uint32_t lg, uint32_t c, uint32_t total, uint32_t maxSym, int32_t lowProb)
 {
     const uint32_t lane = zh_lane();
     const bool in = lane <= maxSym;
@@ -197,7 +197,7 @@ ZH_DEVFN int ze_fse_normalize_m2_wave(int16_t* norm, uint32_t lg, uint32_t c, ui
     return 0;
 }
 // FSE_normalizeCount (zstd.c:16402): count[] -> norm[] summing to 1 << lg. 0, or -1 when no distribution exists.
-ZH_DEVFN int ze_fse_normalize_wave(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, bool useLowProb)
+ZH_COLD int ze_fse_normalize_wave(int16_t* norm, uint32_t lg, const uint32_t* count, uint32_t total, uint32_t maxSym, bool useLowProb)
 {
     const uint32_t lane = zh_lane();
     const bool in = lane <= maxSym;
@@ -227,7 +227,7 @@ ZH_DEVFN int ze_fse_normalize_wave(int16_t* norm, uint32_t lg, const uint32_t* c
 // unassigned before it allow -- a prefix sum of the cell counts gives every lane that number directly; the zeros that follow a zero
 // are counted by a run code in front of the next symbol that has cells. Every lane shifts its bits to its prefix-sum offset in a zeroed
 // LDS strip; the strip is then copied out. asm32: 32 dwords of scratch. Returns bytes written.
-ZH_DEVFN uint32_t ze_fse_write_ncount_wave(uint8_t* out, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint32_t* asm32)
+ZH_COLD uint32_t ze_fse_write_ncount_wave(uint8_t* out, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint32_t* asm32)
 {
     const uint32_t lane = zh_lane();
     const bool in = lane <= maxSym;
@@ -276,7 +276,7 @@ ZH_DEVFN uint32_t ze_fse_write_ncount_wave(uint8_t* out, const int16_t* norm, ui
 // The encoding table (FSE_buildCTable_wksp, zstd.c:16005): the same symbol spread as the decoding side (the k-th cell handed out sits at
 // (k x step) mod size, low-probability symbols take the top cells), then every symbol's cells listed in table order. One lane per symbol
 // for the bookkeeping, one lane per cell for spreading and listing. cellSym: 512 bytes, ends / run: 64 x u16 each, all LDS scratch.
-ZH_DEVFN void ze_fse_build_ctab_wave(ZeCTab& t, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint8_t* cellSym, uint16_t* ends, uint16_t* run)
+ZH_COLD void ze_fse_build_ctab_wave(ZeCTab& t, const int16_t* norm, uint32_t maxSym, uint32_t lg, uint8_t* cellSym, uint16_t* ends, uint16_t* run)
 {
     const uint32_t lane = zh_lane();
     const uint32_t S = 1u << lg, mask = S - 1, step = (S >> 1) + (S >> 3) + 3;
@@ -383,7 +383,7 @@ ZH_DEV uint64_t ze_same_key(uint32_t key, int bits, bool act)
 // match-any ballots), depths (every leaf walks up to the root), the per-length code numbering. What is one chain stays on lane 0:
 // the quicksort of the wide buckets (its order among equal counts IS the format's tie-break, so it is the reference's algorithm,
 // zstd.c:17312-17375), the two-queue merge of the tree (:17438) and the height limiter (:17133), which rarely runs.
-ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
+ZH_COLD uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
 {
     const uint32_t lane = zh_lane();
     const uint64_t lt = zh_lt_mask();
@@ -525,7 +525,7 @@ ZH_DEVFN uint32_t ze_huf_build(ZeLDS& L, uint32_t maxSym, uint32_t maxBits)
 
 // The Huffman table description (HUF_writeCTable_wksp, zstd.c:17005): weights = log + 1 - code length, FSE-compressed when that is
 // shorter (HUF_compressWeights :16904), else 4 bits each. All lanes call; 0 = cannot be described, 1 = one weight value only.
-ZH_DEVFN uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t* w, uint32_t n)
+ZH_COLD uint32_t ze_huf_compress_weights(ZeLDS& L, uint8_t* out, const uint8_t* w, uint32_t n)
 {
     const uint32_t lane = zh_lane();
     uint32_t* const count = &L.cnt[0][0];           // free here: the bucket sort is over, the sequence histograms come later

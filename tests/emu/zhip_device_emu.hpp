@@ -5,6 +5,7 @@
 #include <string.h>
 #define ZH_DEV static inline
 #define ZH_DEVFN
+#define ZH_COLD
 #define ZH_GLOBAL extern "C"
 #define ZH_SHARED static
 #define ZH_CONST static const
