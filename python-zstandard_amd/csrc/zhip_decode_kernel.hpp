@@ -649,7 +649,7 @@ ZH_DEV uint32_t zd_hist_byte(const uint8_t* dst, const uint8_t* dictEnd, int32_t
 
 // whole-wave match copy straight in global memory, for matches too long for the LDS assembly buffer.
 // All lanes call with uniform arguments.
-ZH_DEVFN void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst, uint32_t off, uint32_t ml)
+ZH_COLD void zd_match_wave(uint8_t* dst, const uint8_t* dictEnd, uint32_t mdst, uint32_t off, uint32_t ml)
 {
     const uint32_t lane = zh_lane();
     const int32_t sbeg = (int32_t)mdst - (int32_t)off;

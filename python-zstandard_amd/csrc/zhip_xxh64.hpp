@@ -4,7 +4,7 @@
 #include "zhip_device.hpp"
 
 // one lane, serial (checksums are opt-in in python-zstandard: write_checksum defaults to False)
-ZH_DEVFN uint64_t ze_xxh64(const uint8_t* p, uint32_t len)
+ZH_COLD uint64_t ze_xxh64(const uint8_t* p, uint32_t len)
 {
     const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
 #define ZE_ROTL(x, r) (((x) << (r)) | ((x) >> (64 - (r))))
