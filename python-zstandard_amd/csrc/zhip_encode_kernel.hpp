@@ -592,7 +592,7 @@ ZH_DEV uint32_t* ze_scratch(ZeLDS& L) { return (uint32_t*)L.node; }
 // offset is the code-length total of the runs behind it (wave prefix sum); lanes write whole dwords they own with plain stores
 // and the two dwords they may share with a neighbour with atomic ORs into a zeroed area. ct = code | nbBits << 16 (LDS).
 // All lanes call. Returns 6 + the four stream sizes, or 0 when a stream is too long for the jump table or the room.
-ZH_DEVFN uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
+ZH_COLD uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
 {
     const uint32_t lane = zh_lane();
     const uint32_t strm = lane >> 4, sub = lane & 15;
@@ -656,7 +656,7 @@ ZH_DEVFN uint32_t ze_huf_encode_4x_wave(const uint32_t* ct, uint8_t* body, uint3
 // lane-0 encoder reads the literals a byte at a time from global memory -- a dependent round trip per literal -- which was 40 % of
 // the entropy kernel on small inputs with a dictionary (sections of fewer than 1 024 literals are single streams; r02d). Returns
 // the stream size, 0 when it does not fit.
-ZH_DEVFN uint32_t ze_huf_encode_1x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
+ZH_COLD uint32_t ze_huf_encode_1x_wave(const uint32_t* ct, uint8_t* body, uint32_t bcap, const uint8_t* lit, uint32_t n)
 {
     const uint32_t lane = zh_lane();
     const uint32_t run = (n + 63) / 64;
@@ -1866,7 +1866,7 @@ ZH_DEV uint32_t ze_ml_bits(uint32_t c) { return c < 32 ? 0u : c < 43 ? (uint32_t
 // to the stream (up to 89 bits) is assembled by its own lane, placed by a wave prefix sum of the bit counts and ORed into an LDS
 // bit buffer that is flushed to the frame in whole bytes (the odd bits carry into the next round). All lanes call.
 // Returns the stream's size, 0 when it does not fit in cap.
-ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq)
+ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq)
 {
     const uint32_t lane = zh_lane();
     uint32_t* const tt = ze_scratch(L);          // per symbol: deltaNbBits, deltaFindState (FSE_symbolCompressionTransform); LL at 0, OF at 36, ML at 68
@@ -1999,7 +1999,7 @@ ZH_DEVFN uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap,
 // literal copy accumulates, zstd.c:19930). The match-finding kernel records sequences only; this runs wave-parallel: 64 sequences
 // per round, two prefix sums place the literal runs, each lane copies its own run when it is short, the wave copies the long
 // ones together. All lanes call. Returns the literal count.
-ZH_DEVFN uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src, uint32_t srcSize, const uint64_t* seqs, uint32_t nbSeq)
+ZH_COLD uint32_t ze_gather_literals(ZeLDS& L, uint8_t* lits, const uint8_t* src, uint32_t srcSize, const uint64_t* seqs, uint32_t nbSeq)
 {
     const uint32_t lane = zh_lane();
     uint32_t* const uend = ze_scratch(L);                                   // per round: inclusive 16-byte-unit ends of the long runs
