@@ -145,3 +145,35 @@ def test_decompress_content_dict_chain(zstd, oracle):
         d.decompress_content_dict_chain([chunks[0], chunks[1][0:12] + chunks[1][15:]])
     with pytest.raises(ValueError, match="chunk 1 missing content size in frame"):
         d.decompress_content_dict_chain([chunks[0], zstd.ZstdCompressor(write_content_size=False).compress(b"foo" * 64)])
+
+
+def test_dictionary_frames_through_the_pipeline(zstd, corpus):
+    """dictionary frames take the phase-split pipeline since r02v (ready-made dictionary tables for treeless literals / repeat-mode sequence
+    tables, repeat offsets from the dictionary, match sources in its content incl. items that straddle the frame's first byte): 1 024
+    documents per dictionary against libzstd's frames, a frame made without the dictionary in the same batch, a wrong / missing dictionary"""
+    import numpy as np
+    from tests import reflib
+    if not reflib.have_ref():
+        pytest.skip("needs oracle/_ref (libzstd 1.5.7) for the frames")
+    ref = reflib.RefZstd()
+    rng = np.random.default_rng(7)
+    docs = [corpus.frame_bytes(700 + i)[j * 4096:(j + 1) * 4096] for i in range(32) for j in range(32)]
+    trained = ref.train_dictionary(16384, [corpus.frame_bytes(900 + i)[:3000] for i in range(400)])
+    rawd = corpus.frame_bytes(600)[:6000]
+    for dd in (trained, rawd):
+        content = dd[-4000:]
+        b30 = rng.bytes(30)
+        straddlers = [b30 + content[-20:] + b30[:15] + rng.bytes(10) + content[-40:] + b30[:25],
+                      content[-300:] + content[-300:] + rng.bytes(5) + content[-64:] + content[-300:-250]]
+        raws = docs + [b"a", corpus.frame_bytes(5)[:40000], (dd[-3000:] + docs[3])[:6000]] + straddlers
+        for level in (3, 1):
+            frames = [ref.compress(r, level=level, dict_data=dd) for r in raws] + [ref.compress(docs[0], level=level)]
+            got = zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(dd)).multi_decompress_to_buffer(frames)
+            assert len(got) == len(frames)
+            for i, r in enumerate(raws + [docs[0]]):
+                assert got[i].tobytes() == r, (level, i)
+    other = ref.train_dictionary(8192, [corpus.frame_bytes(300 + i)[:2000] for i in range(300)])
+    frame = ref.compress(docs[1], level=3, dict_data=trained)
+    for d in (zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(other)), zstd.ZstdDecompressor()):
+        with pytest.raises(zstd.ZstdError, match="Dictionary mismatch"):
+            d.multi_decompress_to_buffer([frame], decompressed_sizes=np.array([4096], dtype=np.uint64).tobytes())
