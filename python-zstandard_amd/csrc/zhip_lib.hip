@@ -795,7 +795,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
         // waves for what the generic kernel takes: inputs above one block, and -- with a dictionary -- inputs above the attach cutoff
-        const size_t gBigMax = c->hasCDict ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : 64;
+        // (with a dictionary: inputs above the attach cutoff too. Every wave of this kernel carries 544 bytes of scratch per lane: a full-chip
+        // grid that finds an empty list still took 2.3 ms of every dictionary batch -- r02zi kernel trace; half a wave per CU is 0.4)
+        const size_t gBigMax = c->hasCDict ? (size_t)c->numCU / 2 : 64;
         const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
             c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
