@@ -214,7 +214,7 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #define ZHIP_NSLOT 3
 #endif
 #ifndef ZHIP_DCHUNK
-#define ZHIP_DCHUNK 32768
+#define ZHIP_DCHUNK 65536        // frames per chunk of the decode pipeline (r02zl: 301 GB/s in one 65 536-frame chunk against 297 in two of 32 768: longer launches amortise their tails, and the two chunk slots overlap little anyway)
 #endif
 static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed DevBuf::reserve failed (ZHIP_ERR_NO_MEMORY or ZHIP_ERR_HIP)
 struct DevBuf {
@@ -534,7 +534,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured best on MI355X (profiles/README.md, r01c / r02f): 32768 frames x 2 slots
+        const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured on MI355X (profiles/README.md, r01c / r02f / r02zl): 65 536 frames per chunk, 2 slots
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
