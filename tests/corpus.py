@@ -252,4 +252,18 @@ class Corpus:
         return out
 
     def frame_bytes(self, i):
-        return self.frames(i, 1)[0].cpu().numpy().tobytes()
+        cache = self.__dict__.setdefault("_cache", {})
+        if i not in cache:
+            if len(cache) >= 1024: cache.clear()
+            cache[i] = self.frames(i, 1)[0].cpu().numpy().tobytes()
+        return cache[i]
+
+    def frame_list(self, start, count):
+        """frames start .. start+count-1 as bytes objects, generated in one batched pass (a frame on its own costs as much as a
+        dozen in a batch: every generator's fixed cost is per call)"""
+        cache = self.__dict__.setdefault("_cache", {})
+        if not all(start + k in cache for k in range(count)):
+            if len(cache) + count > 1024: cache.clear()
+            t = self.frames(start, count).cpu().numpy()
+            for k in range(count): cache[start + k] = t[k].tobytes()
+        return [cache[start + k] for k in range(count)]

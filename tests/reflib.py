@@ -7,6 +7,7 @@
 * ``Oracle``   -- oracle/libzstd_oracle.so, our plain-C restatement (oracle/zo_*.c).
 """
 import ctypes as C
+import hashlib
 import os
 import threading
 
@@ -124,7 +125,9 @@ class RefZstd:
             L.ZSTD_freeDCtx(ctx)
 
     def _cctx(self, level, flags, dict_data):
-        key = (level, flags, id(dict_data))
+        # keyed by the dictionary's CONTENT: id() of a freed bytes object is handed out again, and a cached context would then carry
+        # the wrong dictionary (seen as a rare order-dependent mismatch in the suite)
+        key = (level, flags, hashlib.sha256(dict_data).digest() if dict_data else None)
         cache = getattr(self._tls, "cctx", None)
         if cache is None:
             cache = self._tls.cctx = {}

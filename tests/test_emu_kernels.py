@@ -293,8 +293,8 @@ def test_emulated_decode_pipeline_with_dictionaries(emu, ref, corpus):
     the boundary. Trained and raw-content dictionaries, frames that ignore the dictionary, wrong / missing dictionary."""
     import numpy as np
     rng = np.random.default_rng(7)
-    docs = [corpus.frame_bytes(700 + i)[j * 4096:(j + 1) * 4096] for i in range(24) for j in range(4)]
-    trained = ref.train_dictionary(16384, [corpus.frame_bytes(900 + i)[:3000] for i in range(400)])
+    docs = [f[j * 4096:(j + 1) * 4096] for f in corpus.frame_list(700, 24) for j in range(4)]
+    trained = ref.train_dictionary(16384, [f[:3000] for f in corpus.frame_list(900, 400)])
     rawd = corpus.frame_bytes(600)[:6000]
     try:
         for dd in (trained, rawd):
@@ -313,7 +313,7 @@ def test_emulated_decode_pipeline_with_dictionaries(emu, ref, corpus):
                     assert not any(st) and nfb == 0
                     assert all(w is None or o == w for o, w in zip(outs, want)), (level, chunk)
         # wrong dictionary (another id), no dictionary at all: dictionary_wrong (32) for frames that name one, the others still decode
-        other = ref.train_dictionary(8192, [corpus.frame_bytes(300 + i)[:2000] for i in range(300)])
+        other = ref.train_dictionary(8192, [f[:2000] for f in corpus.frame_list(300, 300)])
         frames = [ref.compress(docs[1], level=3, dict_data=trained), ref.compress(docs[2], level=3)]
         for dd in (other, None):
             assert emu.set_ddict(dd) == 0
@@ -454,3 +454,27 @@ def test_dictionary_multi_block_frames_bit_exact(emu, ref, corpus):
     edge = (big * 2)[:1 << 19]
     outs, st = emu.compress_batch([edge, edge + b"!"], level=1, flags=5, pipeline=True, dict_data=dicts[1])
     assert st == [0, 40] and outs[0] == ref.compress(edge, level=1, dict_data=dicts[1])
+
+
+def test_damaged_frames_through_the_emulated_pipeline(emu, ref, corpus):
+    """libzstd frames with bits flipped, bytes overwritten, pieces cut out or the tail dropped, whole frames as neighbours: what the
+    pipeline accepts is byte-for-byte what libzstd (zstd/zstd.c:44174 ZSTD_decompressFrame) makes of the same bytes, nothing libzstd
+    rejects gets through, the neighbours decode. The other direction is allowed to differ in one documented way (DESIGN.md section 2:
+    damaged Huffman streams libzstd's fast loop lets through are refused) and is bounded here. tests/stress_emu_corrupt.py is the
+    open-ended form, run under AddressSanitizer (tests/emu/build_asan.sh) for the bounds."""
+    import numpy as np
+    from tests.stress_emu_corrupt import one_round
+    tot = {}
+    rng = np.random.default_rng(11)
+    for k in range(3):
+        r = one_round(emu, ref, rng, corpus, count=24, small=(k != 0), big=(k == 2))
+        for a, b in r.items(): tot[a] = tot.get(a, 0) + b
+    trained = ref.train_dictionary(16384, [f[j * 4096:(j + 1) * 4096] for f in corpus.frame_list(900, 24) for j in range(16)])
+    try:
+        assert emu.set_ddict(trained) == 0
+        r = one_round(emu, ref, rng, corpus, count=24, small=True, dict_data=trained)
+        for a, b in r.items(): tot[a] = tot.get(a, 0) + b
+    finally:
+        emu.set_ddict(None)
+    assert tot["wrong"] == 0 and tot["missed"] == 0 and tot["neighbours_bad"] == 0, tot
+    assert tot["rejected"] >= 30 and tot["accepted"] >= 24 and tot["stricter"] <= tot["frames"] // 10, tot

@@ -105,7 +105,7 @@ def test_dictionary_compression_bit_exact(zstd, corpus):
     chk = _checker()
     d = dicts["trained"]
     rng = np.random.default_rng(5)
-    raws = [corpus.frame_bytes(900 + i)[: int(rng.integers(1, 16385))] for i in range(600)]
+    raws = [f[: int(rng.integers(1, 16385))] for f in corpus.frame_list(900, 600)]
     zd = zstd.ZstdCompressionDict(d)
     res = zstd.ZstdCompressor(level=3, dict_data=zd).multi_compress_to_buffer(raws)
     for i, r in enumerate(raws):
@@ -138,7 +138,7 @@ def test_fast_strategy_levels_bit_exact(zstd):
     from tests.corpus import Corpus
     c = Corpus()
     rng = np.random.default_rng(8)
-    more = [c.frame_bytes(700 + i)[: int(rng.integers(1, 131073))] for i in range(200)]
+    more = [f[: int(rng.integers(1, 131073))] for f in c.frame_list(700, 200)]
     for lvl in (1, 2, -3):
         res = zstd.ZstdCompressor(level=lvl, write_checksum=True).multi_compress_to_buffer(more)
         for i, r in enumerate(more):

@@ -158,7 +158,7 @@ def test_dictionary_frames_through_the_pipeline(zstd, corpus):
     ref = reflib.RefZstd()
     rng = np.random.default_rng(7)
     docs = [corpus.frame_bytes(700 + i)[j * 4096:(j + 1) * 4096] for i in range(32) for j in range(32)]
-    trained = ref.train_dictionary(16384, [corpus.frame_bytes(900 + i)[:3000] for i in range(400)])
+    trained = ref.train_dictionary(16384, [f[:3000] for f in corpus.frame_list(900, 400)])
     rawd = corpus.frame_bytes(600)[:6000]
     for dd in (trained, rawd):
         content = dd[-4000:]
@@ -172,7 +172,7 @@ def test_dictionary_frames_through_the_pipeline(zstd, corpus):
             assert len(got) == len(frames)
             for i, r in enumerate(raws + [docs[0]]):
                 assert got[i].tobytes() == r, (level, i)
-    other = ref.train_dictionary(8192, [corpus.frame_bytes(300 + i)[:2000] for i in range(300)])
+    other = ref.train_dictionary(8192, [f[:2000] for f in corpus.frame_list(300, 300)])
     frame = ref.compress(docs[1], level=3, dict_data=trained)
     for d in (zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(other)), zstd.ZstdDecompressor()):
         with pytest.raises(zstd.ZstdError, match="Dictionary mismatch"):
