@@ -2692,6 +2692,48 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     a.meta[i] = m;
 }
 
+// E1 for SMALL batches (one-shot compress(), a few hundred frames): the flat kernel's search with the frame's source in LDS. With few
+// frames nothing hides a probe's latency, and the search is a chain of dependent round trips -- its own bytes, the table cells, the
+// candidates' bytes, then match extension / catch-up / the insertions' bytes, each a round trip of its own. One wave per frame copies
+// the source (<= one block) into LDS, after which only the table cells are global: every other round becomes an LDS read. Same search
+// function, same cells, same sequences -- only where the source bytes are read from differs.
+struct ZeSrcLDS { uint8_t b[ZF_BLOCK_MAX + 64]; };
+ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, ZeSrcLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t i = zh_block();
+    if (i >= a.count) return;
+    const uint32_t f = a.first + i;
+    ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    ZePar cp;
+    if (srcSize64 > ZF_BLOCK_MAX) { if (lane == 0) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; } return; }
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    if (a.cdict || srcSize < 64 || ze_get_cparams(cp, a.rows, srcSize) || cp.strat != 2 ||
+        (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) {
+        if (lane == 0) a.e1List[zh_atomic_add(a.e1Count, 1u)] = i;        // the lane-serial kernel decides (and reports errors)
+        return;
+    }
+    const uint32_t whole = srcSize & ~15u;
+    for (uint32_t k = lane * 16u; k < whole; k += 64u * 16u) {
+        const zh_v16 v = zh_ld128(src + k);
+        *(uint64_t*)(L.b + k) = v.lo; *(uint64_t*)(L.b + k + 8) = v.hi;
+    }
+    if (whole + lane < srcSize) L.b[whole + lane] = src[whole + lane];     // the last partial unit byte-wise: nothing is read past the source
+    zh_sync();
+    if (lane != 0) return;
+    uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
+    uint32_t* hashSmall = hashLong + (1u << cp.hlog);
+    uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
+    m.nbSeq = ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), L.b, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
+    m.mode = 4;
+#ifdef ZHIP_EMU
+    zd_stat[15]++;
+#endif
+    a.meta[i] = m;
+}
+
 // E2: everything after the search (entropy coding + frame assembly), one wave per frame
 ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
 {

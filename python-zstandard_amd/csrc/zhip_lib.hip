@@ -17,6 +17,9 @@
 #include "zhip_cparams.hpp"
 
 #define ZHIP_LDS_BYTES (160u * 1024u)      // per CU on gfx950
+#ifndef ZHIP_E1LDS_PER_CU
+#define ZHIP_E1LDS_PER_CU 2                // batches up to this many frames per CU take the LDS-source match kernel (ZHIP_E1LDS_MAX overrides the frame count)
+#endif
 static_assert(sizeof(ZpSeqLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -74,6 +77,12 @@ ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
+static_assert(sizeof(ZeSrcLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
+{
+    __shared__ ZeSrcLDS L;
+    ze_match_lds_body(a, L);
+}
 #ifndef ZE_E2_MINWAVES
 #define ZE_E2_MINWAVES 4
 #endif
@@ -269,7 +278,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -294,6 +303,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
+        if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -825,7 +835,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (flat) {
                 HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
-                hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
+                // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
+                const size_t ldsMax = c->knob.e1LdsMax >= 0 ? (size_t)c->knob.e1LdsMax : (size_t)c->numCU * ZHIP_E1LDS_PER_CU;
+                if (cnt <= ldsMax) hipLaunchKernelGGL(zhip_encode_match_lds_kernel, dim3((uint32_t)cnt), dim3(64), 0, stream, a);
+                else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
             if (tm) HIP_TRY(hipEventRecord(ev[2], stream));

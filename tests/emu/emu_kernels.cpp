@@ -216,6 +216,10 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
+static ZeSrcLDS g_srclds;
+static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds); }
+static uint32_t g_e1LdsMax = 0;                 // chunks of up to this many frames take the LDS-source match kernel (mirrors zhip_compress_batch_device's choice)
+extern "C" void emu_set_e1lds_max(uint32_t v) { g_e1LdsMax = v; }
 extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
                                      uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks, uint32_t chunk)
 {
@@ -244,7 +248,8 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
         counters[0] = counters[1] = 0; e1Count = 0;
         if (flat) {
             memset(a.flatTables, 0, (size_t)a.count * a.tableStride);
-            zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
+            if (a.count <= g_e1LdsMax) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
+            else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);

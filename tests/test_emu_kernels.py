@@ -181,6 +181,20 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
         for i, (r, o) in enumerate(zip(raws, outs)):
             assert o == oracle.compress(r, level=3, flags=flags), (flags, i, len(r))
     assert emu.lib.emu_stat(15) - before >= 2 * 30, "the flat match kernel did not take these frames"
+    # small batches: the same search with the frame's source copied to LDS by its own wave (ze_match_lds_body) -- sizes around the
+    # 16-byte copy units, the frames it hands on (tiny, above one block), chunks on both sides of the switch
+    raws += [corpus.frame_bytes(9)[:n] for n in (64, 65, 79, 80, 81, 4095, 131071)] + [corpus.frame_bytes(9) + b"tail past one block"]
+    emu.lib.emu_set_e1lds_max(24)
+    try:
+        before = emu.lib.emu_stat(15)
+        for chunk in (17, 30):
+            outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=3, pipeline=True, chunk=chunk)
+            assert not any(st)
+            for i, (r, o) in enumerate(zip(raws, outs)):
+                assert o == oracle.compress(r, level=3, flags=5), (chunk, i, len(r))
+        assert emu.lib.emu_stat(15) - before >= 2 * 36
+    finally:
+        emu.lib.emu_set_e1lds_max(0)
 
 
 def test_computed_sequence_codes_match_the_format_tables(emu):
