@@ -1,5 +1,5 @@
 """Emulator stress of the encoder (product kernels under tests/emu) against libzstd 1.5.7: python tests/stress_emu_encode.py SEED [p|n] [LEVEL]
-(p = two-kernel form with the flat match kernel, n = fused kernel). Not collected by pytest; the bounded versions live in test_emu_kernels.py."""
+(p = two-kernel form with the flat match kernel, l = the same with the LDS-source match kernel of small batches, n = fused kernel). Not collected by pytest; the bounded versions live in test_emu_kernels.py."""
 import sys, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,8 @@ emu = emulib.Emu()
 ref = reflib.RefZstd()
 corpus = Corpus()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-pipeline = (sys.argv[2] == 'p') if len(sys.argv) > 2 else True
+pipeline = (sys.argv[2] in ('p', 'l')) if len(sys.argv) > 2 else True
+if len(sys.argv) > 2 and sys.argv[2] == 'l': emu.lib.emu_set_e1lds_max(1000)
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 raws = []
 for i in range(40):
