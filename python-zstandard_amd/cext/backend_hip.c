@@ -258,7 +258,9 @@ static PySequenceMethods coll_sq = { (lenfunc)coll_length, 0, 0, (ssizeargfunc)c
 static PyMethodDef coll_methods[] = { { "size", (PyCFunction)coll_size, METH_NOARGS, "total size of all segments" }, { NULL, NULL, 0, NULL } };
 
 /* ------------------------------------------------------------------------------------------ ZstdCompressionDict */
-typedef struct { PyObject_HEAD PyObject* data; int dictType; } CompressionDict;
+/* precomputed: precompute_compress() was called -- `pre` holds the parameters the reference's ZSTD_createCDict_advanced would digest the
+ * dictionary with (compressiondict.c:228-286); frames made with this dictionary then follow THEM, not the compressor's level */
+typedef struct { PyObject_HEAD PyObject* data; int dictType; int precomputed; zhip_compression_parameters pre; } CompressionDict;
 static PyTypeObject CompressionDictType = { PyVarObject_HEAD_INIT(NULL, 0) };
 static void dict_dealloc(CompressionDict* self) { Py_CLEAR(self->data); Py_TYPE(self)->tp_free((PyObject*)self); }
 static int dict_init(CompressionDict* self, PyObject* args, PyObject* kwargs)
@@ -273,7 +275,7 @@ static int dict_init(CompressionDict* self, PyObject* args, PyObject* kwargs)
     }
     Py_XSETREF(self->data, PyBytes_FromStringAndSize((const char*)src.buf, src.len));
     PyBuffer_Release(&src);
-    self->dictType = (int)dictType;
+    self->dictType = (int)dictType; self->precomputed = 0; memset(&self->pre, 0, sizeof self->pre);
     return self->data ? 0 : -1;
 }
 static Py_ssize_t dict_length(CompressionDict* self) { return PyBytes_GET_SIZE(self->data); }
@@ -287,17 +289,12 @@ static PyObject* dict_dict_id(CompressionDict* self, PyObject* noargs)
         id = (unsigned long)d[4] | ((unsigned long)d[5] << 8) | ((unsigned long)d[6] << 16) | ((unsigned long)d[7] << 24);
     return PyLong_FromUnsignedLong(id);
 }
-static PyObject* dict_precompute(CompressionDict* self, PyObject* args, PyObject* kwargs)
-{
-    /* CDict tables are built on the device when the dictionary is attached to a compressor (zhip_build_cdict_kernel) */
-    (void)self; (void)args; (void)kwargs;
-    Py_RETURN_NONE;
-}
+static PyObject* dict_precompute(CompressionDict* self, PyObject* args, PyObject* kwargs);      /* below, after ZstdCompressionParameters */
 static PySequenceMethods dict_sq = { (lenfunc)dict_length, 0, 0, 0 };
 static PyMethodDef dict_methods[] = {
     { "as_bytes", (PyCFunction)dict_as_bytes, METH_NOARGS, "raw dictionary bytes" },
     { "dict_id", (PyCFunction)dict_dict_id, METH_NOARGS, "dictionary id" },
-    { "precompute_compress", (PyCFunction)dict_precompute, METH_VARARGS | METH_KEYWORDS, "no-op: tables are built on the device" },
+    { "precompute_compress", (PyCFunction)dict_precompute, METH_VARARGS | METH_KEYWORDS, "precompute_compress(level=0, compression_params=None): digest the dictionary on the device for these parameters" },
     { NULL, NULL, 0, NULL } };
 
 /* ------------------------------------------------------------------------------------------ sources (compressor.c:1369-1466) */
@@ -470,7 +467,9 @@ static PyMethodDef cparams_methods[] = {
     { NULL, NULL, 0, NULL } };
 
 /* ------------------------------------------------------------------------------------------ ZstdCompressor */
-typedef struct { PyObject_HEAD int level; int writeChecksum, writeContentSize, writeDictID; int format, threads; zhip_compression_parameters cp; PyObject* dict; } Compressor;
+typedef struct { PyObject_HEAD int level; int writeChecksum, writeContentSize, writeDictID; int format, threads; zhip_compression_parameters cp; PyObject* dict;
+                 int dictPre; zhip_compression_parameters dictPreCp;      /* the dictionary's precomputed state when this compressor was made: .compress() keeps it (setup_cctx runs once, compressor.c:13-45,241) */
+} Compressor;
 static PyTypeObject CompressorType = { PyVarObject_HEAD_INIT(NULL, 0) };
 static void comp_dealloc(Compressor* self) { Py_CLEAR(self->dict); Py_TYPE(self)->tp_free((PyObject*)self); }
 static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
@@ -511,17 +510,90 @@ static int comp_init(Compressor* self, PyObject* args, PyObject* kwargs)
         self->cp.strategy = q->strategy;
     }
     Py_XINCREF(dict); Py_XSETREF(self->dict, dict);
+    self->dictPre = dict ? ((CompressionDict*)dict)->precomputed : 0;
+    if (dict) self->dictPreCp = ((CompressionDict*)dict)->pre; else memset(&self->dictPreCp, 0, sizeof self->dictPreCp);
     return 0;
 }
-static void comp_params(Compressor* self, zhip_cparams* p)
+/* A precomputed dictionary carries its own parameters: libzstd compresses with the CDict's (ZSTD_CCtx_refCDict; the CDict's level is
+ * "none", so ZSTD_compressBegin_internal zstd.c:28230 always takes ZSTD_resetCCtx_usingCDict) and takes only the frame's window log from
+ * the context -- the level-3 row unless the compressor set one explicitly (ZSTD_CCtx_init_compressStream2, zstd.c:29329). Expressed
+ * through the ABI: level 3 + the dictionary's six non-window fields as explicit parameters. */
+static void apply_precomputed(zhip_cparams* p, const zhip_compression_parameters* pre, uint32_t windowLog)
+{
+    p->level = 3; p->cp = *pre; p->cp.windowLog = windowLog;
+}
+static void comp_params(Compressor* self, zhip_cparams* p, int oneShot)
 {
     memset(p, 0, sizeof *p);
     p->level = self->level; p->contentSizeFlag = self->writeContentSize; p->checksumFlag = self->writeChecksum; p->dictIDFlag = self->writeDictID;
     p->format = self->format; p->cp = self->cp;
     if (self->dict && PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data)) {
-        p->dict = PyBytes_AS_STRING(((CompressionDict*)self->dict)->data); p->dictSize = (size_t)PyBytes_GET_SIZE(((CompressionDict*)self->dict)->data);
-        p->dictType = ((CompressionDict*)self->dict)->dictType;
+        CompressionDict* d = (CompressionDict*)self->dict;
+        p->dict = PyBytes_AS_STRING(d->data); p->dictSize = (size_t)PyBytes_GET_SIZE(d->data);
+        p->dictType = d->dictType;
+        /* .compress() uses the context set up when the compressor was made; multi_compress_to_buffer() sets its worker contexts up per
+         * call and sees a CDict precomputed since (compressor.c:1147) */
+        if (oneShot ? self->dictPre : d->precomputed) apply_precomputed(p, oneShot ? &self->dictPreCp : &d->pre, self->cp.windowLog);
     }
+}
+/* ZstdCompressionDict.precompute_compress (compressiondict.c:228-286): the parameters come from ZSTD_getCParams(level, 0, dictSize) or from
+ * a ZstdCompressionParameters object; ZSTD_createCDict_advanced then adjusts them for "a dictionary of this size, source unknown"
+ * (ZSTD_adjustCParams_internal in ZSTD_cpm_createCDict mode, zstd.c:24426: the table logs are clamped against the window log GIVEN HERE).
+ * The device repeats that adjustment with the frame's window row, which is never smaller than min(given window, log2(dict + 513)), so
+ * the clamp is applied here and the six non-window fields travel as explicit parameters. The dictionary is digested on the device
+ * right away (an empty batch runs zhip_ctx_set_cparams): what libzstd refuses here ("unable to precompute dictionary") is refused here. */
+static uint32_t hb32(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; return r; }
+static PyObject* dict_precompute(CompressionDict* self, PyObject* args, PyObject* kwargs)
+{
+    static char* kwlist[] = { "level", "compression_params", NULL };
+    int level = 0; PyObject* params = NULL;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "|iO!:precompute_compress", kwlist, &level, &CompressionParametersType, &params)) return NULL;
+    if (level && params) { PyErr_SetString(PyExc_ValueError, "must only specify one of level or compression_params"); return NULL; }
+    if (!level && !params) { PyErr_SetString(PyExc_ValueError, "must specify one of level or compression_params"); return NULL; }
+    const size_t dictSize = (size_t)PyBytes_GET_SIZE(self->data);
+    zhip_compression_parameters pre, row;
+    if (level) Z.get_cparams(level, 0, dictSize, &pre);
+    else {
+        const CompressionParameters* q = (const CompressionParameters*)params;
+        Z.get_cparams(3, 0, dictSize, &row);                               /* unset fields: the default level's row (the CDict's level is "none") */
+        pre.windowLog = q->windowLog ? (uint32_t)q->windowLog : row.windowLog; pre.chainLog = q->chainLog ? (uint32_t)q->chainLog : row.chainLog;
+        pre.hashLog = q->hashLog ? (uint32_t)q->hashLog : row.hashLog; pre.searchLog = q->searchLog ? (uint32_t)q->searchLog : row.searchLog;
+        pre.minMatch = q->minMatch ? (uint32_t)q->minMatch : row.minMatch; pre.targetLength = q->targetLength ? (uint32_t)q->targetLength : row.targetLength;
+        pre.strategy = q->strategy > 0 ? q->strategy : row.strategy;
+    }
+    if (pre.strategy != 1 && pre.strategy != 2) {
+        PyErr_SetString(ZstdError, "unable to precompute dictionary: strategies above double-fast (levels >= 5) are not implemented by the HIP backend");
+        return NULL;
+    }
+    if (dictSize) {                                                        /* the createCDict-mode clamp, against the window given here */
+        const uint64_t tSize = 513 + (uint64_t)dictSize;
+        /* a window that cannot hold the dictionary stays with the CDict and shrinks every frame's working tables
+         * (ZSTD_resetCCtx_byAttachingCDict, zstd.c:25299): not carried through the ABI -- refused, never encoded differently */
+        if (pre.windowLog < 31 && ((uint64_t)1 << pre.windowLog) < tSize) {
+            PyErr_SetString(ZstdError, "unable to precompute dictionary: a window_log smaller than the dictionary is not supported by the HIP backend");
+            return NULL;
+        }
+        const uint32_t srcLog = tSize < 64 ? 6 : hb32(tSize - 1) + 1;
+        uint32_t w = pre.windowLog > srcLog ? srcLog : pre.windowLog;
+        const uint64_t windowSize = (uint64_t)1 << w;
+        const uint32_t dw = windowSize >= tSize ? w : (dictSize + windowSize >= ((uint64_t)1 << 31) ? 31 : hb32(dictSize + windowSize - 1) + 1);
+        if (pre.hashLog > dw + 1) pre.hashLog = dw + 1;
+        if (pre.chainLog > dw) pre.chainLog = dw;
+    }
+    pre.windowLog = 0;
+    zhip_cparams p; memset(&p, 0, sizeof p);
+    p.contentSizeFlag = 1; p.dictIDFlag = 1; p.dict = PyBytes_AS_STRING(self->data); p.dictSize = dictSize; p.dictType = self->dictType;
+    apply_precomputed(&p, &pre, 0);
+    zhip_outbuf* out = NULL; size_t nOut = 0; zhip_error err; int rc;
+    memset(&err, 0, sizeof err);
+    Py_BEGIN_ALLOW_THREADS
+    rc = Z.compress_batch(&p, NULL, 0, &out, &nOut, &err);
+    Py_END_ALLOW_THREADS
+    if (rc == ZHIP_ERR_NONE) Z.free_outbufs(out, nOut, 1);
+    else if (rc == ZHIP_ERR_ZSTD) { PyErr_Format(ZstdError, "unable to precompute dictionary: %s", Z.error_name(err.zstdErr)); return NULL; }
+    else { PyErr_Format(ZstdError, "unable to precompute dictionary: %s", Z.last_error()); return NULL; }
+    self->pre = pre; self->precomputed = 1;
+    Py_RETURN_NONE;
 }
 static void comp_raise(int rc, const zhip_error* err, int oneShot)
 {
@@ -541,7 +613,7 @@ static PyObject* comp_compress(Compressor* self, PyObject* args, PyObject* kwarg
     Py_buffer src;
     if (!PyArg_ParseTupleAndKeywords(args, kwargs, "y*:compress", kwlist, &src)) return NULL;
     zhip_item item = { src.buf, (size_t)src.len, 0 };
-    zhip_cparams p; comp_params(self, &p);
+    zhip_cparams p; comp_params(self, &p, 1);
     zhip_outbuf* out = NULL; size_t nOut = 0; zhip_error err; int rc;
     memset(&err, 0, sizeof err);
     Py_BEGIN_ALLOW_THREADS
@@ -562,7 +634,7 @@ static PyObject* comp_multi(Compressor* self, PyObject* args, PyObject* kwargs)
     if (sources_collect(&s, data, "argument must be list of BufferWithSegments") != 0) return NULL;
     if (s.n == 0) { sources_free(&s); PyErr_SetString(PyExc_ValueError, "no source elements found"); return NULL; }
     if (s.totalSize == 0) { sources_free(&s); PyErr_SetString(PyExc_ValueError, "source elements are empty"); return NULL; }
-    zhip_cparams p; comp_params(self, &p);
+    zhip_cparams p; comp_params(self, &p, 0);
     zhip_outbuf* out = NULL; size_t nOut = 0; zhip_error err; int rc;
     memset(&err, 0, sizeof err);
     Py_BEGIN_ALLOW_THREADS

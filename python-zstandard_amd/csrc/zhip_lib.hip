@@ -1237,6 +1237,12 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     int r = zhip_ctx_set_cparams(c, params ? params : &defaults);
     if (r < 0) return set_err(err, ZHIP_ERR_ZSTD, 0, -r);
     if (r) return set_err(err, r, 0, 0);
+    if (n == 0) {                                     // nothing to compress: the parameters / dictionary have been digested (what precompute_compress asks for)
+        zhip_outbuf* e = (zhip_outbuf*)calloc(1, sizeof(zhip_outbuf));
+        if (!e) return set_err(err, ZHIP_ERR_NO_MEMORY, 0, 0);
+        empty_outbuf(e); *out = e; *nOut = 1;
+        return ZHIP_ERR_NONE;
+    }
     // like compress_worker (compressor.c:913-947) every item gets a ZSTD_compressBound-sized slot; the frames are compacted on the
     // device, chunk by chunk, and only they travel back
     std::vector<zhip_segment> segs(2 * n);

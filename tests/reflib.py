@@ -26,6 +26,15 @@ class _Buf(C.Structure):
     _fields_ = [("p", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
 
 
+class _CParams(C.Structure):      # ZSTD_compressionParameters (zstd.h)
+    _fields_ = [("windowLog", C.c_uint), ("chainLog", C.c_uint), ("hashLog", C.c_uint), ("searchLog", C.c_uint), ("minMatch", C.c_uint),
+                ("targetLength", C.c_uint), ("strategy", C.c_int)]
+
+
+class _CMem(C.Structure):         # ZSTD_customMem: all NULL = the default allocator
+    _fields_ = [("customAlloc", C.c_void_p), ("customFree", C.c_void_p), ("opaque", C.c_void_p)]
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 
@@ -59,6 +68,10 @@ class RefZstd:
             ("ZSTD_getErrorName", C.c_char_p, [C.c_size_t]),
             ("ZSTD_getFrameContentSize", C.c_ulonglong, [C.c_void_p, C.c_size_t]),
             ("ZDICT_trainFromBuffer", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_uint]),
+            ("ZSTD_getCParams", _CParams, [C.c_int, C.c_ulonglong, C.c_size_t]),
+            ("ZSTD_createCDict_advanced", C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, _CParams, _CMem]),
+            ("ZSTD_freeCDict", C.c_size_t, [C.c_void_p]),
+            ("ZSTD_CCtx_refCDict", C.c_size_t, [C.c_void_p, C.c_void_p]),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -123,6 +136,53 @@ class RefZstd:
             return dst.raw[: out.pos]
         finally:
             L.ZSTD_freeDCtx(ctx)
+
+    def cdict_params(self, level, dict_size):
+        """ZSTD_getCParams(level, 0, dictSize) as a dict of ZstdCompressionParameters-style keys (what precompute_compress(level=) starts from)"""
+        cp = self.lib.ZSTD_getCParams(level, 0, dict_size)
+        return dict(window_log=cp.windowLog, chain_log=cp.chainLog, hash_log=cp.hashLog, search_log=cp.searchLog, min_match=cp.minMatch,
+                    target_length=cp.targetLength, strategy=cp.strategy)
+
+    def compress_with_cdict(self, data, dict_data, level=3, flags=DEFAULT_FLAGS, cdict_level=0, cdict_params=None, dict_type=0, window_log=0):
+        """one frame through a PRECOMPUTED dictionary, the way the reference does it after ZstdCompressionDict.precompute_compress
+        (c-ext/compressiondict.c:266-278 ZSTD_getCParams / to_cparams + ZSTD_createCDict_advanced, c-ext/compressor.c:29-31 ZSTD_CCtx_refCDict);
+        cdict_params: the seven ZSTD_compressionParameters fields by their ZstdCompressionParameters names (0 = unset)"""
+        L = self.lib
+        data = bytes(data)
+        if cdict_params is None:
+            cp = L.ZSTD_getCParams(cdict_level, 0, len(dict_data))
+        else:
+            q = cdict_params
+            cp = _CParams(q.get("window_log", 0), q.get("chain_log", 0), q.get("hash_log", 0), q.get("search_log", 0), q.get("min_match", 0),
+                          q.get("target_length", 0), q.get("strategy", 0))
+        cd = L.ZSTD_createCDict_advanced(dict_data, len(dict_data), 1, dict_type, cp, _CMem(None, None, None))
+        if not cd:
+            raise RuntimeError("unable to precompute dictionary")
+        ctx = L.ZSTD_createCCtx()
+        try:
+            L.ZSTD_CCtx_setParameter(ctx, _P_LEVEL, level)
+            L.ZSTD_CCtx_setParameter(ctx, _P_CONTENTSIZE, 1 if flags & F_CONTENTSIZE else 0)
+            L.ZSTD_CCtx_setParameter(ctx, _P_CHECKSUM, 1 if flags & F_CHECKSUM else 0)
+            L.ZSTD_CCtx_setParameter(ctx, _P_DICTID, 1 if flags & F_DICTID else 0)
+            if window_log:
+                L.ZSTD_CCtx_setParameter(ctx, self.PARAM_IDS["window_log"], window_log)
+            r = L.ZSTD_CCtx_refCDict(ctx, cd)
+            if L.ZSTD_isError(r):
+                raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            L.ZSTD_CCtx_setPledgedSrcSize(ctx, len(data))
+            cap = L.ZSTD_compressBound(len(data))
+            dst = C.create_string_buffer(max(cap, 1))
+            src = C.create_string_buffer(data, len(data)) if data else C.create_string_buffer(1)
+            out = _Buf(C.addressof(dst), cap, 0)
+            inp = _Buf(C.addressof(src), len(data), 0)
+            r = L.ZSTD_compressStream2(ctx, C.byref(out), C.byref(inp), 2)
+            if L.ZSTD_isError(r):
+                raise RuntimeError(L.ZSTD_getErrorName(r).decode())
+            assert r == 0
+            return dst.raw[: out.pos]
+        finally:
+            L.ZSTD_freeCCtx(ctx)
+            L.ZSTD_freeCDict(cd)
 
     def _cctx(self, level, flags, dict_data):
         # keyed by the dictionary's CONTENT: id() of a freed bytes object is handed out again, and a cached context would then carry

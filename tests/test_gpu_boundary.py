@@ -216,3 +216,57 @@ def test_fast_strategy_with_dictionary(zstd, ref, corpus):
         assert [back[i].tobytes() for i in range(len(several))] == several
     with pytest.raises(zstd.ZstdError):                                           # a source larger than its window (level 1: 512 KiB): libzstd drops the
         zstd.ZstdCompressor(level=1, dict_data=zstd.ZstdCompressionDict(trained)).compress(b"q" * ((1 << 19) + 1))   # dictionary part-way; refused, loudly
+
+
+def test_precomputed_dictionary(zstd, ref, corpus):
+    """ZstdCompressionDict.precompute_compress (c-ext/compressiondict.c:228-286 -> ZSTD_createCDict_advanced; c-ext/compressor.c:29-31,1147
+    ZSTD_CCtx_refCDict): frames made with a precomputed dictionary follow the DICTIONARY's level / parameters, not the compressor's --
+    bit-identical to libzstd driven the same way, in attach mode, table-copy mode and over several blocks; argument errors and a
+    dictionary libzstd refuses to digest are reported as the reference reports them; .compress() keeps the state the compressor was
+    made with, multi_compress_to_buffer() sees a later precompute (setup_cctx runs once, the worker contexts are set up per call)"""
+    pool = corpus.frame_list(40, 6)
+    rng = np.random.default_rng(12)
+    trained = ref.train_dictionary(16384, [f[j * 4096:(j + 1) * 4096] for f in pool for j in range(16)])
+    rawd = pool[3][1000:9000]
+    srcs = [(pool[0] + pool[1] + pool[2])[:n] for n in (1, 300, 4096, 8193, 16385, 60000, 131072, 131073, 250000)] + [rng.bytes(3000), (trained[-3000:] + pool[5])[:30000]]
+    for dd, kw in ((trained, {}), (rawd, dict(dict_type=zstd.DICT_TYPE_RAWCONTENT))):
+        for plevel, clevel in ((1, 3), (3, 1), (-3, 3), (2, 2)):
+            d = zstd.ZstdCompressionDict(dd, **kw)
+            assert d.precompute_compress(level=plevel) is None
+            c = zstd.ZstdCompressor(level=clevel, dict_data=d)
+            want = [ref.compress_with_cdict(s, dd, level=clevel, cdict_level=plevel, dict_type=kw.get("dict_type", 0)) for s in srcs]
+            res = c.multi_compress_to_buffer(srcs)
+            assert [res[i].tobytes() for i in range(len(srcs))] == want, (plevel, clevel)
+            assert [c.compress(s) for s in srcs[2:6]] == want[2:6]
+            # the frames are ordinary dictionary frames
+            back = zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(dd, **kw)).multi_decompress_to_buffer(want)
+            assert [back[i].tobytes() for i in range(len(srcs))] == srcs
+    # the level of the dictionary wins: these differ from the frames of a compressor that was simply given the level
+    plain = [ref.compress(s, level=3, dict_data=trained) for s in srcs]
+    assert plain != [ref.compress_with_cdict(s, trained, level=3, cdict_level=1) for s in srcs]
+    # explicit parameters (to_cparams + ZSTD_createCDict_advanced); unset fields come from the default level's row
+    for q in (dict(hash_log=10, chain_log=9, min_match=6, strategy=zstd.STRATEGY_FAST), dict(min_match=7, window_log=17), dict(chain_log=12)):
+        d = zstd.ZstdCompressionDict(trained)
+        d.precompute_compress(compression_params=zstd.ZstdCompressionParameters(**q))
+        res = zstd.ZstdCompressor(level=3, dict_data=d).multi_compress_to_buffer(srcs)
+        assert [res[i].tobytes() for i in range(len(srcs))] == [ref.compress_with_cdict(s, trained, level=3, cdict_params=q) for s in srcs], q
+    # argument errors (tests/test_train_dictionary.py:77-93), a dictionary libzstd cannot digest (:95-107)
+    d = zstd.ZstdCompressionDict(trained)
+    with pytest.raises(ValueError, match="must specify one of level or "):
+        d.precompute_compress()
+    with pytest.raises(ValueError, match="must only specify one of level or "):
+        d.precompute_compress(level=3, compression_params=zstd.ZstdCompressionParameters())
+    zstd.ZstdCompressionDict(b"dictcontent" * 64, dict_type=zstd.DICT_TYPE_RAWCONTENT).precompute_compress(level=1)
+    with pytest.raises(zstd.ZstdError, match="unable to precompute dictionary"):
+        zstd.ZstdCompressionDict(b"dictcontent" * 64, dict_type=zstd.DICT_TYPE_FULLDICT).precompute_compress(level=1)
+    # what the backend does not implement is refused here, loudly: strategies above double-fast, a window smaller than the dictionary
+    with pytest.raises(zstd.ZstdError, match="unable to precompute dictionary"):
+        zstd.ZstdCompressionDict(trained).precompute_compress(level=19)
+    with pytest.raises(zstd.ZstdError, match="unable to precompute dictionary"):
+        zstd.ZstdCompressionDict(trained).precompute_compress(compression_params=zstd.ZstdCompressionParameters(window_log=11))
+    # order of construction: a compressor made BEFORE the precompute keeps its one-shot context, its batch workers see the CDict
+    d = zstd.ZstdCompressionDict(trained)
+    c = zstd.ZstdCompressor(level=3, dict_data=d)
+    d.precompute_compress(level=1)
+    assert c.compress(srcs[3]) == ref.compress(srcs[3], level=3, dict_data=trained)
+    assert c.multi_compress_to_buffer([srcs[3]])[0].tobytes() == ref.compress_with_cdict(srcs[3], trained, level=3, cdict_level=1)
