@@ -1,5 +1,5 @@
 """Latency of small compress batches through the host-buffer API (one-shot .compress() is the batch of one): the LDS-source match
-kernel (ze_match_lds_body, the default up to two frames per CU) against the flat kernel (ZHIP_E1LDS_MAX=0), every frame checked
+kernel (ze_match_lds_body, the default up to four frames per CU) against the flat kernel (ZHIP_E1LDS_MAX=0), every frame checked
 against libzstd 1.5.7.   Usage: python tests/small_batch_latency.py   (run once per setting of ZHIP_E1LDS_MAX)"""
 import json
 import os
@@ -36,4 +36,19 @@ for n in (16, 128, 256, 512, 1024):
         t0 = time.perf_counter(); r = c.multi_compress_to_buffer(items[:n]); best = min(best, time.perf_counter() - t0)
     assert all(r[i].tobytes() == want[i] for i in range(min(n, 64)))
     out["batch_%d_ms" % n] = round(best * 1e3, 2)
+d = pyz.ZstdDecompressor()
+frames = [ref.compress(x) for x in items[:256]]
+d.decompress(frames[0])
+ts = []
+for k in range(5):
+    t0 = time.perf_counter(); b = d.decompress(frames[k]); ts.append(time.perf_counter() - t0)
+    assert b == items[k]
+out["one_shot_decompress_128KiB_ms"] = round(min(ts) * 1e3, 2)
+for n in (16, 256):
+    d.multi_decompress_to_buffer(frames[:n])
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); r = d.multi_decompress_to_buffer(frames[:n]); best = min(best, time.perf_counter() - t0)
+    assert all(r[i].tobytes() == items[i] for i in range(n))
+    out["decompress_batch_%d_ms" % n] = round(best * 1e3, 2)
 print(json.dumps(out))
