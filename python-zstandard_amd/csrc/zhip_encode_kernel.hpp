@@ -2697,8 +2697,11 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
 // candidates' bytes, then match extension / catch-up / the insertions' bytes, each a round trip of its own. One wave per frame copies
 // the source (<= one block) into LDS, after which only the table cells are global: every other round becomes an LDS read. Same search
 // function, same cells, same sequences -- only where the source bytes are read from differs.
-struct ZeSrcLDS { uint8_t b[ZF_BLOCK_MAX + 64]; };
-ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, ZeSrcLDS& L)
+// The LDS area is sized for the batch's largest source where the caller knows it (the host-buffer API does): small sources leave room
+// for more frames per CU (4 KiB: 32 waves, 16 KiB: 9, 64 KiB: 2, one block: 1). A source above the area (no size hint and a shape picked
+// too small cannot happen -- the host falls back to the one-block shape -- but the kernel does not rely on it) is searched in place.
+template <uint32_t BYTES> struct ZeSrcLDS { uint8_t b[BYTES + 64]; };
+ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t ldsBytes)
 {
     const uint32_t lane = zh_lane();
     const uint32_t i = zh_block();
@@ -2715,18 +2718,22 @@ ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, ZeSrcLDS& L)
         if (lane == 0) a.e1List[zh_atomic_add(a.e1Count, 1u)] = i;        // the lane-serial kernel decides (and reports errors)
         return;
     }
-    const uint32_t whole = srcSize & ~15u;
-    for (uint32_t k = lane * 16u; k < whole; k += 64u * 16u) {
-        const zh_v16 v = zh_ld128(src + k);
-        *(uint64_t*)(L.b + k) = v.lo; *(uint64_t*)(L.b + k + 8) = v.hi;
+    const bool staged = srcSize <= ldsBytes;
+    if (staged) {
+        const uint32_t whole = srcSize & ~15u;
+        for (uint32_t k = lane * 16u; k < whole; k += 64u * 16u) {
+            const zh_v16 v = zh_ld128(src + k);
+            *(uint64_t*)(lds + k) = v.lo; *(uint64_t*)(lds + k + 8) = v.hi;
+        }
+        if (whole + lane < srcSize) lds[whole + lane] = src[whole + lane];     // the last partial unit byte-wise: nothing is read past the source
     }
-    if (whole + lane < srcSize) L.b[whole + lane] = src[whole + lane];     // the last partial unit byte-wise: nothing is read past the source
     zh_sync();
     if (lane != 0) return;
     uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
     uint32_t* hashSmall = hashLong + (1u << cp.hlog);
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    m.nbSeq = ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), L.b, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
+    m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
+                     : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

@@ -77,11 +77,11 @@ ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
-static_assert(sizeof(ZeSrcLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
+static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
+template <uint32_t BYTES> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
 {
-    __shared__ ZeSrcLDS L;
-    ze_match_lds_body(a, L);
+    __shared__ ZeSrcLDS<BYTES> L;
+    ze_match_lds_body(a, L.b, BYTES);
 }
 #ifndef ZE_E2_MINWAVES
 #define ZE_E2_MINWAVES 4
@@ -258,6 +258,7 @@ struct zhip_ctx {
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
     int e1PerCU = 0, e2PerCU = 0;
+    size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
     ZeRows rows = {};                  // cparams resolved per source-size class (zhip_cparams.hpp)
     DevBuf scratch, counter;
@@ -278,7 +279,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -304,6 +305,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
+        if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -836,8 +838,19 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
-                const size_t ldsMax = c->knob.e1LdsMax >= 0 ? (size_t)c->knob.e1LdsMax : (size_t)c->numCU * ZHIP_E1LDS_PER_CU;
-                if (cnt <= ldsMax) hipLaunchKernelGGL(zhip_encode_match_lds_kernel, dim3((uint32_t)cnt), dim3(64), 0, stream, a);
+                // (the LDS area follows the batch's largest source where the caller told us -- the host-buffer API does: more frames per CU)
+                const size_t hint = c->srcMaxHint ? c->srcMaxHint : (size_t)ZF_BLOCK_MAX;
+                const int shape = hint <= 4096 ? 0 : hint <= 16384 ? 1 : hint <= 65536 ? 2 : 3;
+                static const unsigned wavesPerCU[4] = { 32, 9, 2, 1 };          // by LDS (160 KiB per CU) and the 32-wave limit
+                const size_t rounds = shape == 3 ? ZHIP_E1LDS_PER_CU : c->knob.e1LdsRounds;
+                const size_t ldsMax = c->knob.e1LdsMax >= 0 ? (size_t)c->knob.e1LdsMax : (size_t)c->numCU * wavesPerCU[shape] * rounds;
+                if (cnt <= ldsMax) {
+                    const dim3 g((uint32_t)cnt), b(64);
+                    if (shape == 0) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<4096>, g, b, 0, stream, a);
+                    else if (shape == 1) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<16384>, g, b, 0, stream, a);
+                    else if (shape == 2) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<65536>, g, b, 0, stream, a);
+                    else hipLaunchKernelGGL(zhip_encode_match_lds_kernel<ZF_BLOCK_MAX>, g, b, 0, stream, a);
+                }
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
@@ -1307,7 +1320,9 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
         const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
         if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        { size_t mx = 0; for (size_t i = lo; i < hi; i++) if (items[i].srcSize > mx) mx = items[i].srcSize; c->srcMaxHint = mx; }
         r = zhip_compress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
+        c->srcMaxHint = 0;
         if (r) return fail(r);
         hipLaunchKernelGGL(zhip_scan_sizes_kernel, dim3(1), dim3(1024), 0, c->hpCompute, dSizes + lo, dStatus + lo, (uint32_t)cnt, dOffs + lo, dTotals + k);
         const uint32_t gridC = (uint32_t)(cnt < (size_t)c->numCU * 16 ? cnt : (size_t)c->numCU * 16);

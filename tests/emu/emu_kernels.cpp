@@ -216,8 +216,10 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
-static ZeSrcLDS g_srclds;
-static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds); }
+static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
+static uint32_t g_e1LdsBytes = ZF_BLOCK_MAX;       // the LDS shape under emulation (the product picks it from the batch's largest source)
+static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
+extern "C" void emu_set_e1lds_bytes(uint32_t v) { g_e1LdsBytes = v; }
 static uint32_t g_e1LdsMax = 0;                 // chunks of up to this many frames take the LDS-source match kernel (mirrors zhip_compress_batch_device's choice)
 extern "C" void emu_set_e1lds_max(uint32_t v) { g_e1LdsMax = v; }
 extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,

@@ -193,8 +193,12 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
             for i, (r, o) in enumerate(zip(raws, outs)):
                 assert o == oracle.compress(r, level=3, flags=5), (chunk, i, len(r))
         assert emu.lib.emu_stat(15) - before >= 2 * 36
+        # a smaller LDS area (the shape of a batch of small sources); a source above it is searched in place, same frame
+        emu.lib.emu_set_e1lds_bytes(4096)
+        outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=3, pipeline=True, chunk=17)
+        assert not any(st) and all(o == oracle.compress(r, level=3, flags=5) for r, o in zip(raws, outs))
     finally:
-        emu.lib.emu_set_e1lds_max(0)
+        emu.lib.emu_set_e1lds_max(0); emu.lib.emu_set_e1lds_bytes(131072)
 
 
 def test_computed_sequence_codes_match_the_format_tables(emu):
