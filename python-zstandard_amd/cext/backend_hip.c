@@ -550,6 +550,7 @@ static PyObject* dict_precompute(CompressionDict* self, PyObject* args, PyObject
     if (!PyArg_ParseTupleAndKeywords(args, kwargs, "|iO!:precompute_compress", kwlist, &level, &CompressionParametersType, &params)) return NULL;
     if (level && params) { PyErr_SetString(PyExc_ValueError, "must only specify one of level or compression_params"); return NULL; }
     if (!level && !params) { PyErr_SetString(PyExc_ValueError, "must specify one of level or compression_params"); return NULL; }
+    self->precomputed = 0;                                                 /* the reference frees its old CDict first (compressiondict.c:256-264): a failed call leaves none */
     const size_t dictSize = (size_t)PyBytes_GET_SIZE(self->data);
     zhip_compression_parameters pre, row;
     if (level) Z.get_cparams(level, 0, dictSize, &pre);
