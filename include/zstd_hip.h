@@ -106,6 +106,10 @@ int64_t  zhip_find_frame_compressed_size_format(const void* src, size_t srcSize,
 /* level + size hints -> the parameters libzstd would use (ZSTD_getCParams zstd.c:30863; ZstdCompressionParameters.from_level,
  * c-ext/compressionparams.c:231-345). Host only. */
 void     zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out);
+/* bytes of device memory the calling thread's contexts hold (scratch arenas, tables, staging; they grow with the largest batch seen and
+ * are trimmed after very large ones) -- what ZstdCompressor.memory_size() / ZstdDecompressor.memory_size() report here, where the
+ * reference reports ZSTD_sizeof_CCtx / ZSTD_sizeof_DCtx (c-ext/compressor.c:263, c-ext/decompressor.c:128). Host only, no GPU call. */
+size_t   zhip_thread_memory_size(void);
 
 /* ---- host-buffer batch API (drop-in for the reference's workers) ----
  * items are borrowed; *out is an array of *nOut buffers the caller owns -- one per pipeline chunk, like the reference's one per worker

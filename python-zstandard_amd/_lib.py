@@ -83,6 +83,7 @@ def lib():
         "zhip_frame_content_size_format": (u64, [vp, sz, C.c_int]),
         "zhip_find_frame_compressed_size_format": (C.c_int64, [vp, sz, C.c_int]),
         "zhip_get_cparams": (None, [C.c_int, u64, sz, C.POINTER(CompressionParameters)]),
+        "zhip_thread_memory_size": (sz, []),
         "zhip_compress_batch": (C.c_int, [C.POINTER(CParams), C.POINTER(Item), sz, C.POINTER(C.POINTER(OutBuf)),
                                           C.POINTER(sz), C.POINTER(Error)]),
         "zhip_decompress_batch": (C.c_int, [C.POINTER(DParams), C.POINTER(Item), sz, C.c_int,
@@ -115,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "zhip_find_frame_compressed_size_format", "zhip_get_cparams", "zhip_ctx_set_dformat", "zhip_compress_batch",
     "zhip_decompress_batch", "zhip_free_outbufs", "zhip_free_payload", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
-    "zhip_kernel_name", "zhip_ctx_kernel_time",
+    "zhip_kernel_name", "zhip_ctx_kernel_time", "zhip_thread_memory_size",
 ]
 
 

@@ -37,6 +37,7 @@ static struct {
     uint64_t (*frame_content_size_format)(const void*, size_t, int);
     int64_t (*find_frame_compressed_size_format)(const void*, size_t, int);
     void (*get_cparams)(int, uint64_t, size_t, zhip_compression_parameters*);
+    size_t (*thread_memory_size)(void);
 } Z;
 
 static PyObject* ZstdError;
@@ -78,7 +79,7 @@ static int bind_library(PyObject* module)
     BIND(decompress_batch, "zhip_decompress_batch"); BIND(free_outbufs, "zhip_free_outbufs"); BIND(abi_version, "zhip_abi_version");
     BIND(free_payload, "zhip_free_payload");
     BIND(frame_content_size_format, "zhip_frame_content_size_format"); BIND(find_frame_compressed_size_format, "zhip_find_frame_compressed_size_format");
-    BIND(get_cparams, "zhip_get_cparams");
+    BIND(get_cparams, "zhip_get_cparams"); BIND(thread_memory_size, "zhip_thread_memory_size");
 #undef BIND
     if (Z.abi_version() != ZHIP_ABI_VERSION) { PyErr_SetString(PyExc_ImportError, "libzstd_hip.so ABI mismatch"); return -1; }
     return 0;
@@ -645,11 +646,13 @@ static PyObject* comp_multi(Compressor* self, PyObject* args, PyObject* kwargs)
     if (rc != ZHIP_ERR_NONE) { comp_raise(rc, &err, 0); return NULL; }
     return collection_from_outbufs(out, nOut);
 }
-static PyObject* zero_memory_size(PyObject* self, PyObject* noargs) { (void)self; (void)noargs; return PyLong_FromLong(0); }
+/* the reference reports the libzstd context's size (compressor.c:263, decompressor.c:128); here the context lives on the device: the bytes
+ * the calling thread's device contexts hold */
+static PyObject* zero_memory_size(PyObject* self, PyObject* noargs) { (void)self; (void)noargs; return PyLong_FromSize_t(Z.thread_memory_size()); }
 static PyMethodDef comp_methods[] = {
     { "compress", (PyCFunction)comp_compress, METH_VARARGS | METH_KEYWORDS, "compress(data) -> bytes" },
     { "multi_compress_to_buffer", (PyCFunction)comp_multi, METH_VARARGS | METH_KEYWORDS, "compress many inputs into a BufferWithSegmentsCollection" },
-    { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "host memory held by the context" },
+    { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "device memory held by the calling thread's contexts" },
     { NULL, NULL, 0, NULL } };
 
 /* ------------------------------------------------------------------------------------------ ZstdDecompressor */
@@ -821,7 +824,7 @@ static PyMethodDef decomp_methods[] = {
     { "decompress", (PyCFunction)decomp_decompress, METH_VARARGS | METH_KEYWORDS, "decompress(data) -> bytes" },
     { "decompress_content_dict_chain", (PyCFunction)decomp_content_dict_chain, METH_VARARGS | METH_KEYWORDS, "decompress a chain of frames, each using the previous fulltext as its dictionary" },
     { "multi_decompress_to_buffer", (PyCFunction)decomp_multi, METH_VARARGS | METH_KEYWORDS, "decompress many frames into a BufferWithSegmentsCollection" },
-    { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "host memory held by the context" },
+    { "memory_size", (PyCFunction)zero_memory_size, METH_NOARGS, "device memory held by the calling thread's contexts" },
     { NULL, NULL, 0, NULL } };
 
 /* ------------------------------------------------------------------------------------------ FrameParameters (c-ext/frameparams.c) */

@@ -226,21 +226,24 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #define ZHIP_DCHUNK 65536        // frames per chunk of the decode pipeline (r02zl: 301 GB/s in one 65 536-frame chunk against 297 in two of 32 768: longer launches amortise their tails, and the two chunk slots overlap little anyway)
 #endif
 static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed DevBuf::reserve failed (ZHIP_ERR_NO_MEMORY or ZHIP_ERR_HIP)
+static thread_local size_t g_devBytes = 0;               // device bytes held by this thread's contexts (zhip_thread_memory_size)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t n) {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
+        g_devBytes -= cap;
         p = nullptr; cap = 0;
         size_t want = n + (n >> 3) + 4096;
         if (want < n) { g_lastError = "allocation size overflow"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         const hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
-        cap = want; return 0;
+        cap = want; g_devBytes += want; return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); g_devBytes -= cap; p = nullptr; cap = 0; }
 };
+extern "C" size_t zhip_thread_memory_size(void) { return g_devBytes; }
 #define ZHIP_NTIMER 9
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading

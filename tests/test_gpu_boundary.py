@@ -270,3 +270,6 @@ def test_precomputed_dictionary(zstd, ref, corpus):
     d.precompute_compress(level=1)
     assert c.compress(srcs[3]) == ref.compress(srcs[3], level=3, dict_data=trained)
     assert c.multi_compress_to_buffer([srcs[3]])[0].tobytes() == ref.compress_with_cdict(srcs[3], trained, level=3, cdict_level=1)
+    # memory_size(): the reference reports its libzstd context (c-ext/compressor.c:263, decompressor.c:128); here the context lives on the
+    # device -- after a call the calling thread's device arenas are what it reports
+    assert c.memory_size() > 1000 and zstd.ZstdDecompressor().memory_size() == c.memory_size()
