@@ -106,6 +106,9 @@ def cpu_baseline(decompress, blob, offs, n, max_out, unc_bytes, dict_data=None, 
             "host_cores": ncpu}
 
 
+USE_DIST = False      # set by main(): world > 1 (or forced, see there)
+
+
 class Job:
     """one direction's device buffers + the timed loop (barrier + synchronize on both sides, max over ranks)"""
 
@@ -113,7 +116,7 @@ class Job:
         self.world, self.dev = world, dev
 
     def barrier(self):
-        if self.world > 1:
+        if USE_DIST:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +133,7 @@ class Job:
         self.barrier()
         elapsed = time.perf_counter() - t0
         ktimes = {k: ctx.kernel_time(k) for k in kernels if ctx.kernel_name(k)}
-        if self.world > 1:
+        if USE_DIST:
             import torch.distributed as dist
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -313,7 +316,7 @@ def bench_roundtrip(args, rank, world, dev):
     for j, i in enumerate(idx):
         assert bytes(slots_v[int(i), : int(got_sz[i])].cpu().numpy()) == want[j], "frame %d differs from libzstd 1.5.7" % i
     gather_ms = None
-    if world > 1:                                                  # reassemble the compressed output on every rank (north_star's all-gatherv)
+    if USE_DIST:                                                   # reassemble the compressed output on every rank (north_star's all-gatherv)
         import torch.distributed as dist
         dense, dsegs = sharded._compact(slots, slot_segs, csz, dev)
         sizes = sharded._exchange_sizes(csz, None)
@@ -369,9 +372,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    global USE_DIST
+    # ZHIP_BENCH_FORCE_DIST=1: take the process-group path (RCCL init, barriers, max over ranks, the payload all-gatherv) with ONE rank too --
+    # the only way to exercise it on a single-GPU box
+    USE_DIST = world > 1 or bool(os.environ.get("ZHIP_BENCH_FORCE_DIST"))
+    if USE_DIST:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         if config == "dict":
@@ -381,7 +389,7 @@ def main():
         else:
             bench_frames(args, config, rank, world, dev)
     finally:
-        if world > 1:
+        if USE_DIST:
             torch.distributed.destroy_process_group()
 
 
@@ -429,7 +437,7 @@ def bench_frames(args, config, rank, world, dev):
         return
 
     elapsed, ktimes, out_sizes = run_decompress(job, ctx, frames, csizes, raw, FRAME, args.steps, args.warmup)
-    if world > 1:
+    if USE_DIST:
         import torch.distributed as dist
         # the only cross-rank exchange the path needs: the segment table of the sharded result (payload stays per GPU)
         gathered = [torch.zeros_like(out_sizes) for _ in range(world)]
