@@ -1,6 +1,6 @@
 """bring-up probe for the decode pipeline: the edge-frame batch, alone and together, with per-frame pipeline records"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import zstandard_amd as zstd
