@@ -30,6 +30,16 @@ from . import _lib  # noqa: E402,F401   ctypes view of the same library (device-
 backend = "hip"                    # the reference's `zstandard.backend`; backend_hip.backend says "hip_cext"
 
 
+def compress(data, level=3):
+    """one-shot convenience of the reference package (zstandard/__init__.py:184-199): ``ZstdCompressor(level=level).compress(data)``"""
+    return ZstdCompressor(level=level).compress(data)          # noqa: F821  (re-exported from the extension above)
+
+
+def decompress(data, max_output_size=0):
+    """zstandard/__init__.py:202-217: ``ZstdDecompressor().decompress(data, max_output_size=max_output_size)``"""
+    return ZstdDecompressor().decompress(data, max_output_size=max_output_size)          # noqa: F821
+
+
 def load_cext():
     """the extension module itself (kept for callers written against round 1, where it was optional)"""
     return _c

@@ -889,8 +889,28 @@ static PyObject* mod_frame_content_size(PyObject* self, PyObject* args)
     if (v == ZHIP_CONTENTSIZE_UNKNOWN) return PyLong_FromLong(-1);
     return PyLong_FromUnsignedLongLong(v);
 }
+/* frame_header_size (c-ext/backend_c.c:77-104 -> ZSTD_frameHeaderSize, zstd.c:43625): the size the frame header descriptor byte announces;
+ * the magic number is not checked, only that the five bytes up to the descriptor are there */
+static PyObject* mod_frame_header_size(PyObject* self, PyObject* args, PyObject* kwargs)
+{
+    (void)self;
+    static char* kwlist[] = { "source", NULL };
+    Py_buffer src;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "y*:frame_header_size", kwlist, &src)) return NULL;
+    PyObject* r = NULL;
+    if (src.len < 5) PyErr_Format(ZstdError, "could not determine frame header size: %s", Z.error_name(72));       /* srcSize_wrong */
+    else {
+        static const size_t didSize[4] = { 0, 1, 2, 4 }, fcsSize[4] = { 0, 2, 4, 8 };
+        const unsigned fhd = ((const unsigned char*)src.buf)[4];
+        const unsigned single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+        r = PyLong_FromSize_t(5 + !single + didSize[fhd & 3] + fcsSize[fcsId] + (single && !fcsId));
+    }
+    PyBuffer_Release(&src);
+    return r;
+}
 static PyMethodDef module_methods[] = {
     { "frame_content_size", mod_frame_content_size, METH_VARARGS, "content size of a frame, -1 if unknown" },
+    { "frame_header_size", (PyCFunction)mod_frame_header_size, METH_VARARGS | METH_KEYWORDS, "size of a frame's header" },
     { "get_frame_parameters", (PyCFunction)mod_get_frame_parameters, METH_VARARGS | METH_KEYWORDS, "parse a frame header" },
     { NULL, NULL, 0, NULL } };
 static struct PyModuleDef moduledef = { PyModuleDef_HEAD_INIT, "backend_hip", "python-zstandard hot path on MI355X: CPython extension over libzstd_hip.so", -1, module_methods, 0, 0, 0, 0 };

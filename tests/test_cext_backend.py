@@ -146,6 +146,8 @@ def test_cext_compress_and_decompress_match_oracle(cext, oracle, corpus):
     c = cext.ZstdCompressor(level=3)
     res = c.multi_compress_to_buffer(raws)
     assert len(res) == len(raws) and res[0].offset == 0
+    import zstandard_amd            # the package's one-shot conveniences (zstandard/__init__.py:184-217)
+    assert zstandard_amd.compress(raws[3]) == c.compress(raws[3]) and zstandard_amd.decompress(c.compress(raws[3])) == raws[3]
     frames = [res[i].tobytes() for i in range(len(raws))]
     for r, f in zip(raws, frames):
         assert f == oracle.compress(r, level=3)
@@ -238,3 +240,22 @@ def test_get_frame_parameters(cext, ref):
         assert b.content_size == ref.frame_content_size(f)
         m = cext.get_frame_parameters(f[4:], format=cext.FORMAT_ZSTD1_MAGICLESS)           # the same header without its magic number
         assert (m.content_size, m.window_size, m.dict_id, m.has_checksum) == (b.content_size, b.window_size, b.dict_id, b.has_checksum)
+
+
+def test_frame_header_and_content_size(cext, ref):
+    """module helpers of the reference (c-ext/backend_c.c:46-104), expectations of its tests/test_decompressor.py:6-61: the header size is
+    read off the descriptor byte whatever the magic is; errors carry libzstd's texts. Cross-checked with libzstd's own frames."""
+    with pytest.raises(cext.ZstdError, match="could not determine frame header size: Src size is incorrect"):
+        cext.frame_header_size(b"")
+    with pytest.raises(cext.ZstdError, match="could not determine frame header size: Src size is incorrect"):
+        cext.frame_header_size(b"foob")
+    assert cext.frame_header_size(b"long enough but no magic") == 6
+    for bad in (b"", b"foob", b"invalid frame header"):
+        with pytest.raises(cext.ZstdError, match="error when determining content size"):
+            cext.frame_content_size(bad)
+    for data, flags in ((b"foobar", 5), (b"", 5), (b"x" * 300, 7), (b"y" * 70000, 5), (b"z" * 70000, 4)):
+        f = ref.compress(data, flags=flags)
+        p = cext.get_frame_parameters(f)
+        want = 4 + 1 + (0 if f[4] & 0x20 else 1) + (0, 1, 2, 4)[f[4] & 3] + (0, 2, 4, 8)[f[4] >> 6] + (1 if (f[4] & 0x20) and not (f[4] >> 6) else 0)
+        assert cext.frame_header_size(f) == want and cext.frame_header_size(source=f) == want
+        assert cext.frame_content_size(f) == (len(data) if flags & 1 else -1) == (p.content_size if flags & 1 else -1)
