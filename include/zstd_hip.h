@@ -108,7 +108,8 @@ int64_t  zhip_find_frame_compressed_size_format(const void* src, size_t srcSize,
 void     zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out);
 /* bytes of device memory the calling thread's contexts hold (scratch arenas, tables, staging; they grow with the largest batch seen and
  * are trimmed after very large ones) -- what ZstdCompressor.memory_size() / ZstdDecompressor.memory_size() report here, where the
- * reference reports ZSTD_sizeof_CCtx / ZSTD_sizeof_DCtx (c-ext/compressor.c:263, c-ext/decompressor.c:128). Host only, no GPU call. */
+ * reference reports ZSTD_sizeof_CCtx / ZSTD_sizeof_DCtx (c-ext/compressor.c:263, c-ext/decompressor.c:128). Creates the thread's context
+ * (and its launch counters) if it does not exist yet, as the reference's contexts exist from the constructor on; 0 without a GPU. */
 size_t   zhip_thread_memory_size(void);
 
 /* ---- host-buffer batch API (drop-in for the reference's workers) ----

@@ -243,7 +243,6 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); g_devBytes -= cap; p = nullptr; cap = 0; }
 };
-extern "C" size_t zhip_thread_memory_size(void) { return g_devBytes; }
 #define ZHIP_NTIMER 9
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
@@ -1095,6 +1094,14 @@ static zhip_ctx* tls_ctx()
     return g_tls.c;
 }
 // the host-buffer API keeps its scratch between calls (allocation is slow), but not the tens of GiB a 65 536-frame batch needs
+// what memory_size() reports. The reference's contexts exist from the constructor on (ZSTD_sizeof_CCtx > 0 right away, its tests expect that):
+// the calling thread's device context is created here if it is not there yet, with the launch counters every call needs.
+extern "C" size_t zhip_thread_memory_size(void)
+{
+    zhip_ctx* c = tls_ctx();
+    if (c) (void)c->counter.reserve(64);
+    return g_devBytes;
+}
 static void tls_trim(zhip_ctx* c)
 {
     const size_t limit = (size_t)2 << 30;
