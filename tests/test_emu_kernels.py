@@ -496,3 +496,30 @@ def test_damaged_frames_through_the_emulated_pipeline(emu, ref, corpus):
         emu.set_ddict(None)
     assert tot["wrong"] == 0 and tot["missed"] == 0 and tot["neighbours_bad"] == 0, tot
     assert tot["rejected"] >= 30 and tot["accepted"] >= 24 and tot["stricter"] <= tot["frames"] // 10, tot
+
+
+def test_precomputed_dictionary_parameters_through_the_kernels(emu, ref, corpus):
+    """How ZstdCompressionDict.precompute_compress reaches the kernels (cext/backend_hip.c dict_precompute / apply_precomputed): level 3 plus
+    the precomputed dictionary's six non-window fields as explicit parameters, the frame's window the compressor's own. Against libzstd
+    driven the way the reference drives it (ZSTD_createCDict_advanced + ZSTD_CCtx_refCDict, c-ext/compressiondict.c:266-278,
+    compressor.c:29-31): the dictionary's level wins over the compressor's, in attach mode, table-copy mode and over several blocks."""
+    import numpy as np
+    pool = corpus.frame_list(0, 6)
+    rng = np.random.default_rng(3)
+    dicts = [ref.train_dictionary(16384, [f[j * 4096:(j + 1) * 4096] for f in pool for j in range(16)]), pool[3][1000:9000]]
+    differs = 0
+    try:
+        for dd in dicts:
+            raws = [(pool[0] + pool[1] + pool[2])[:n] for n in (1, 300, 4096, 8193, 16385, 60000, 131073, 200000)] + [rng.bytes(3000), (dd[-3000:] + pool[5])[:30000]]
+            for plevel, clevel, window in ((1, 3, 0), (3, 1, 0), (-3, 3, 0), (1, 3, 19)):
+                pre = ref.cdict_params(plevel, len(dd))
+                pre["window_log"] = window                      # 0: the default level's row, else the compressor's explicit window
+                want = [ref.compress_with_cdict(r, dd, level=clevel, cdict_level=plevel, window_log=window) for r in raws]
+                differs += sum(1 for r, w in zip(raws, want) if w != ref.compress(r, level=clevel, dict_data=dd))
+                emu.set_cparams(**pre)
+                for pipe in (True, False):
+                    outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=2, pipeline=pipe, dict_data=dd)
+                    assert not any(st) and outs == want, (len(dd), plevel, clevel, window, pipe)
+    finally:
+        emu.set_cparams()
+    assert differs > 20          # the precomputed level really changes the frames
