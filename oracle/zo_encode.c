@@ -633,7 +633,8 @@ static size_t zo_dfast_g(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uin
     const uint32_t endIndex = (uint32_t)(iend - base);
     const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip = src + (src == frame);                  /* frame position 0 is never searched nor inserted */
+    const uint8_t* ip = src + ((uint32_t)(src - base) == LOW); /* an empty prefix skips its first position (zstd.c:31091): the frame's first block,
+                                                                * or a later block whose window reaches back exactly to its own start */
     uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
     { const uint32_t curr = (uint32_t)(ip - base); uint32_t maxRep = curr - 2 > maxDist ? maxDist : curr - 2;
       if (off2 > maxRep) { saved2 = off2; off2 = 0; } if (off1 > maxRep) { saved1 = off1; off1 = 0; } }
@@ -741,7 +742,7 @@ static size_t zo_fast_g(zo_seq* seqs, uint8_t* lits, size_t* litSize, const uint
     const uint32_t endIndex = (uint32_t)(iend - base);
     const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip0 = src + (src == frame);
+    const uint8_t* ip0 = src + ((uint32_t)(src - base) == LOW);   /* empty prefix (zstd.c:31958), as in zo_dfast */
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
     { const uint32_t curr = (uint32_t)(ip0 - base); uint32_t maxRep = curr - 2 > maxDist ? maxDist : curr - 2;
       if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; } if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }

@@ -932,7 +932,9 @@ ZH_DEVFN uint32_t ze_dfast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, cons
     const uint32_t endIndex = (uint32_t)(iend - base);
     const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip = src + (src == frame ? 1 : 0);
+    // the first position is skipped when the block starts with an EMPTY prefix (zstd.c:31091 `ip += (dictAndPrefixLength == 0)`): the frame's
+    // first block -- and a later block whose window reaches back exactly to its own start (window == block size, explicit window_log 17)
+    const uint8_t* ip = src + ((uint32_t)(src - base) == LOW ? 1 : 0);
     uint32_t off1 = rep[0], off2 = rep[1], saved1 = 0, saved2 = 0;
     {   const uint32_t c0 = (uint32_t)(ip - base); const uint32_t maxRep = c0 - 2 > maxDist ? maxDist : c0 - 2;
         if (off2 > maxRep) { saved2 = off2; off2 = 0; }
@@ -1229,7 +1231,7 @@ ZH_DEVFN uint32_t ze_fast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const
     const uint32_t endIndex = (uint32_t)(iend - base);
     const uint32_t LOW = endIndex - 2 > maxDist ? endIndex - maxDist : 2;
     const uint8_t* anchor = src;
-    const uint8_t* ip0 = src + (src == frame ? 1 : 0);
+    const uint8_t* ip0 = src + ((uint32_t)(src - base) == LOW ? 1 : 0);      // empty prefix (zstd.c:31958 `ip0 += (ip0 == prefixStart)`), see ze_dfast_g
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
     {   const uint32_t c0 = (uint32_t)(ip0 - base); const uint32_t maxRep = c0 - 2 > maxDist ? maxDist : c0 - 2;
         if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }

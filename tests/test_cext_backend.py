@@ -201,10 +201,6 @@ def test_compression_params_object_and_conflicts(cext, ref):
     cext.ZstdCompressor(level=3, dict_data=None, compression_params=None, write_checksum=None, write_content_size=None,
                         write_dict_id=None, threads=0)
 
-    class CP(C.Structure):
-        _fields_ = [(n, C.c_uint) for n in "windowLog chainLog hashLog searchLog minMatch targetLength".split()] + [("strategy", C.c_int)]
-    ref.lib.ZSTD_getCParams.restype = CP
-    ref.lib.ZSTD_getCParams.argtypes = [C.c_int, C.c_ulonglong, C.c_size_t]
     for level in (-5, 1, 3, 4, 7, 19, 22):
         for src, dct in ((0, 0), (1000, 0), (16384, 0), (131072, 0), (131073, 0), (1 << 20, 0), (0, 112640), (4096, 112640)):
             want = ref.lib.ZSTD_getCParams(level, src, dct)

@@ -396,6 +396,15 @@ def test_explicit_parameters_and_magicless_bit_exact(emu, ref, corpus):
                     assert st[i] == 40, (level, kw, i)                                   # ZSTD_error_parameter_unsupported
                 else:
                     assert st[i] == 0 and o == w, (level, kw, i)
+        # a window of exactly one block over several full blocks: every later block starts with an EMPTY prefix and skips its first
+        # position like the frame's first block does (zstd.c:31091 / :31958; tests/stress_emu_params.py seed 740 found the difference)
+        text = b"".join(corpus.frame_list(40, 4))
+        blk = corpus.frame_bytes(3)[:700] + corpus.frame_bytes(4)[:2076]
+        several = [text[:300000], (blk * 120)[:262144], text[:262144], (blk * 200)[:400000]]
+        for strat in (1, 2):
+            emu.set_cparams(window_log=17, strategy=strat)
+            outs, st = emu.compress_batch(several, level=3, flags=1, pipeline=True)
+            assert not any(st) and outs == [ref.compress_advanced(r, level=3, flags=1, window_log=17, strategy=strat) for r in several], strat
         emu.set_cparams(strategy=3)
         assert set(emu.compress_batch(raws[:2], level=3, pipeline=True)[1]) == {40}
         emu.set_cparams(magicless=True)

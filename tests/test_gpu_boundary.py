@@ -72,6 +72,15 @@ def test_compression_parameters_and_format(zstd, ref, corpus):
         rkw = {k: v for k, v in kw.items() if k != "compression_level"}
         for i, r in enumerate(raws):
             assert res[i].tobytes() == ref.compress_advanced(r, level=kw.get("compression_level", 3), flags=7, **rkw), (kw, i)
+    # a window of exactly one block over several full blocks: every later block starts with an EMPTY prefix (zstd.c:31091 `ip += (dictAndPrefixLength == 0)`,
+    # found by tests/stress_emu_params.py seed 740)
+    text = b"".join(corpus.frame_list(40, 4))
+    blk = corpus.frame_bytes(3)[:700] + corpus.frame_bytes(4)[:2076]
+    several = [text[:300000], (blk * 120)[:262144], text[:262144], (blk * 200)[:400000]]
+    for strat in (zstd.STRATEGY_FAST, zstd.STRATEGY_DFAST):
+        res = zstd.ZstdCompressor(compression_params=P(window_log=17, strategy=strat)).multi_compress_to_buffer(several)
+        for i, r in enumerate(several):
+            assert res[i].tobytes() == ref.compress_advanced(r, level=3, flags=1, window_log=17, strategy=strat), (strat, i)
     # from_level: the row of an unknown-size source made explicit -- not the same frames as level=3 (which picks the row per source size)
     fl = zstd.ZstdCompressor(compression_params=P.from_level(3)).multi_compress_to_buffer(raws)
     kw = dict(window_log=21, chain_log=16, hash_log=17, search_log=1, min_match=5, target_length=0, strategy=2)
