@@ -1,4 +1,4 @@
-"""Emulator stress of explicit compression parameters against libzstd 1.5.7: python tests/stress_emu_params.py SEED [N].
+"""Emulator stress of explicit compression parameters against libzstd 1.5.7: python tests/stress_emu_params.py SEED [N] [blocks].
 Random ZstdCompressionParameters fields (window / hash / chain log, minimum match, target length, strategy fast or double-fast) on top
 of random levels, sources below and above one block: an accepted frame is libzstd's with the same parameters
 (c-ext/compressionparams.c -> ZSTD_CCtx_setParameter), what is not implemented is refused with parameter_unsupported (40).
@@ -15,6 +15,7 @@ from tests.corpus import Corpus
 emu = emulib.Emu(); ref = reflib.RefZstd(); corpus = Corpus()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+focus = len(sys.argv) > 3 and sys.argv[3] == 'blocks'      # bias towards windows of a few blocks and sources around whole blocks
 rng = np.random.default_rng(seed)
 pool = corpus.frame_list(24 * (seed % 30), 12)
 bad = refused = ok = 0
@@ -23,6 +24,7 @@ try:
     for it in range(rounds):
         kw = {}
         if rng.integers(0, 2): kw["window_log"] = int(rng.integers(10, 22))
+        if focus and rng.integers(0, 2): kw["window_log"] = int(rng.integers(17, 20))          # windows of one to four blocks
         if rng.integers(0, 2): kw["hash_log"] = int(rng.integers(6, 19))
         if rng.integers(0, 2): kw["chain_log"] = int(rng.integers(6, 18))
         if rng.integers(0, 2): kw["min_match"] = int(rng.integers(3, 8))
@@ -32,6 +34,7 @@ try:
         raws = []
         for i in range(8):
             n = int(rng.choice([rng.integers(1, 2000), rng.integers(2000, 20000), rng.integers(20000, 131073), rng.integers(131073, 280000)]))
+            if focus and rng.integers(0, 2): n = int(rng.integers(1, 6)) * 131072 + int(rng.choice([-1, 0, 1, 2, 4097, 70000]))    # around whole blocks
             k = int(rng.integers(0, 4))
             if k == 0: r = (pool[int(rng.integers(0, 12))] + pool[int(rng.integers(0, 12))] + pool[int(rng.integers(0, 12))])[:n]
             elif k == 1: r = rng.bytes(n)
