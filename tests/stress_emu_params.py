@@ -31,6 +31,7 @@ try:
         if rng.integers(0, 3) == 0: kw["target_length"] = int(rng.integers(0, 64))
         if rng.integers(0, 2): kw["strategy"] = int(rng.integers(1, 3))
         level = int(rng.choice([3, 3, 1, 2, -1, -5, 4]))
+        flags = int(rng.choice([5, 5, 7, 6, 4, 1]))               # content size / checksum / dictionary-id flags
         raws = []
         for i in range(8):
             n = int(rng.choice([rng.integers(1, 2000), rng.integers(2000, 20000), rng.integers(20000, 131073), rng.integers(131073, 280000)]))
@@ -44,11 +45,11 @@ try:
             raws.append(r)
         want = []
         for r in raws:
-            try: want.append(ref.compress_advanced(r, level=level, **kw))
+            try: want.append(ref.compress_advanced(r, level=level, flags=flags, **kw))
             except RuntimeError: want.append(None)
         emu.set_cparams(**kw)
         for pipe in (True, False):
-            outs, st = emu.compress_batch(raws, level=level, flags=5, n_blocks=2, pipeline=pipe)
+            outs, st = emu.compress_batch(raws, level=level, flags=flags, n_blocks=2, pipeline=pipe)
             for i, (o, w) in enumerate(zip(outs, want)):
                 if st[i] == 40:
                     refused += 1
