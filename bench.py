@@ -174,6 +174,81 @@ def roofline(ctx, ktimes, steps, algo_bytes_per_step, ms_per_step, frames_per_st
             "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(algo_bytes_per_step)}}, kdom
 
 
+def frame_sections(frames, limit=8192):
+    """what each pipeline stage owns of a frame (RFC 8878 3.1.1): per-frame MEANS over the first `limit` frames of
+    hdr (frame / block / section headers + table descriptions), huf (compressed literal streams), lit (regenerated literals),
+    rawlit (literals stored raw / RLE), seqs (sequence bitstream), nbseq, out. Plain header arithmetic on the host; used to give every
+    kernel's roofline ITS OWN algorithmic bytes instead of crediting one kernel with the whole frame."""
+    tot = dict(hdr=0, huf=0, lit=0, rawlit=0, seqs=0, nbseq=0, csize=0)
+    n = min(len(frames), limit)
+    for f in frames[:n]:
+        tot["csize"] += len(f)
+        fhd = f[4]
+        single, dcode, fcode = (fhd >> 5) & 1, fhd & 3, fhd >> 6
+        pos = 5 + (0 if single else 1) + (4 if dcode == 3 else dcode) + (single if fcode == 0 else 1 << fcode)
+        while True:
+            bh = f[pos] | (f[pos + 1] << 8) | (f[pos + 2] << 16); pos += 3
+            last, btype, bs = bh & 1, (bh >> 1) & 3, bh >> 3
+            if btype == 2:
+                b0 = f[pos]; lt, sf = b0 & 3, (b0 >> 2) & 3
+                if lt < 2:
+                    hl = 1 if sf in (0, 2) else 2 if sf == 1 else 3
+                    regen = (b0 >> 3) if hl == 1 else ((b0 >> 4) + (f[pos + 1] << 4) + ((f[pos + 2] << 12) if hl == 3 else 0))
+                    body = regen if lt == 0 else 1
+                    tot["rawlit"] += regen
+                else:
+                    hl = 3 if sf < 2 else 4 if sf == 2 else 5
+                    h = int.from_bytes(f[pos:pos + hl], "little")
+                    bits = 10 if hl == 3 else 14 if hl == 4 else 18
+                    regen, body = (h >> 4) & ((1 << bits) - 1), (h >> (4 + bits)) & ((1 << bits) - 1)
+                    tot["huf"] += body; tot["lit"] += regen
+                sp = pos + hl + body
+                nb = f[sp]
+                if nb == 255: nb, sp = f[sp + 1] + (f[sp + 2] << 8) + 0x7F00, sp + 3
+                elif nb > 127: nb, sp = ((nb - 128) << 8) + f[sp + 1], sp + 2
+                else: sp += 1
+                tot["nbseq"] += nb
+                tot["seqs"] += pos + bs - sp
+            pos += bs if btype != 1 else 1
+            if last:
+                break
+    out = {k: v / n for k, v in tot.items()}
+    out["hdr"] = out["csize"] - out["huf"] - out["seqs"]
+    out["sample_frames"] = n
+    return out
+
+
+def per_kernel_roofline(ctx, ktimes, steps, own_bytes_per_step):
+    """every kernel against the HBM peak with ITS OWN algorithmic bytes per launch (own_bytes_per_step: kernel name -> bytes per step)"""
+    out = {}
+    for k, (ms, launches) in ktimes.items():
+        name = ctx.kernel_name(k)
+        if not launches or name not in own_bytes_per_step or ms <= 0:
+            continue
+        per_launch = own_bytes_per_step[name] / max(1, int(launches) // max(1, steps))
+        gbs = per_launch / (ms * 1e-3) / 1e9
+        out[name] = {"algorithmic_bytes_per_launch": int(per_launch), "avg_ms": round(ms, 4), "achieved": round(gbs, 2), "frac": round(gbs / HBM_PEAK_GBS, 5)}
+    return out
+
+
+def decode_own_bytes(sec, F, item):
+    """algorithmic bytes of the decode pipeline's kernels for F frames: K1 parses headers and table descriptions and
+    copies raw literals; K1b reads the Huffman streams and writes the literals; K2 reads the sequence bitstream and writes 8-byte
+    sequences; K3 reads sequences, literals and match sources and writes the output"""
+    return {"zhip_decode_lit_kernel": F * (sec["hdr"] + sec["rawlit"]),
+            "zhip_decode_huf_kernel": F * (sec["huf"] + sec["lit"]),
+            "zhip_decode_seq_kernel": F * (sec["seqs"] + 8 * sec["nbseq"]),
+            "zhip_decode_exec_kernel": F * (8 * sec["nbseq"] + 2 * item),
+            "zhip_decode_exec_dict_kernel": F * (8 * sec["nbseq"] + 2 * item)}
+
+
+def encode_own_bytes(sec, F, item):
+    """the match kernels read the source and write 8-byte sequences; the entropy kernel reads sequences + source (literals) and writes the frame"""
+    m = F * (item + 8 * sec["nbseq"])
+    return {"zhip_encode_match_flat_kernel": m, "zhip_encode_match_kernel": m, "zhip_encode_match_lds_kernel": m,
+            "zhip_encode_entropy_kernel": F * (8 * sec["nbseq"] + sec["lit"] + sec["rawlit"] + sec["csize"])}
+
+
 def kernels_obj(ctx, ktimes):
     return {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
 
@@ -230,8 +305,10 @@ def sample_blob(frames, n):
     return blob, offs
 
 
-def bench_dict(args, rank, world, dev):
-    """BASELINE.json configs[3]: multi_compress_to_buffer with a shared trained dictionary over 262 144 x 4 KiB JSON-like documents."""
+def bench_dict(args, rank, world, dev, steps=None, warmup=None, quiet=False):
+    """BASELINE.json configs[3]: multi_compress_to_buffer with a shared trained dictionary (train_dictionary(112640, 10 000 JSON samples),
+    the reference's default size, c-ext/compressiondict.c:56-61) over 262 144 x 4 KiB JSON-like documents. Returns the line (rank 0)."""
+    steps = steps or args.steps; warmup = args.warmup if warmup is None else warmup
     from zstandard_amd.device import DeviceBatchContext
     from tests.corpus import Corpus
     F = args.docs
@@ -244,47 +321,53 @@ def bench_dict(args, rank, world, dev):
     ctotal = int(csizes.sum())
     job = Job(world, dev)
     ctx = DeviceBatchContext(dict_data=dict_data, level=3)
-    elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, DOC, args.steps, args.warmup)
+    elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, DOC, steps, warmup)
     assert ctot2 == ctotal
-    ms = elapsed / args.steps * 1e3
+    ms = elapsed / steps * 1e3
+    sec = frame_sections(frames)
     line = {
         "metric": "GB/s uncompressed throughput, batch compress of 4 KiB inputs with a shared trained dictionary at level 3 (bit-exact vs libzstd 1.5.7)",
-        "value": round(world * F * DOC * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(world * F * DOC * steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "multi_compress_to_buffer (device-resident) with a shared ZstdCompressionDict (16 KiB, trained on 10 000 JSON samples): "
-                               "%d x 4 KiB JSON-like documents per GPU, level 3" % F,
+        "config": {"workload": "multi_compress_to_buffer (device-resident) with a shared ZstdCompressionDict (%d bytes, train_dictionary on 10 000 JSON samples): "
+                               "%d x 4 KiB JSON-like documents per GPU, level 3" % (len(dict_data), F),
                    "docs_per_gpu": F, "doc_bytes": DOC, "level": 3, "dict_bytes": len(dict_data), "compression_ratio": round(F * DOC / ctotal, 3),
                    "parallelism": "documents sharded by rank, no data-path collective"},
     }
-    d_elapsed, d_k, _ = run_decompress(job, ctx, frames, csizes, raw, DOC, args.steps, args.warmup)
+    d_elapsed, d_k, _ = run_decompress(job, ctx, frames, csizes, raw, DOC, steps, warmup)
     if rank == 0:
         line["kernels"] = kernels_obj(ctx, ktimes)
-        line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * DOC + ctotal, ms)
-        d_ms = d_elapsed / args.steps * 1e3
-        line["decompress"] = {"value": round(world * F * DOC * args.steps / d_elapsed / 1e9, 3), "unit": "GB/s", "ms_per_step": round(d_ms, 3),
+        line["roofline"], _ = roofline(ctx, ktimes, steps, F * DOC + ctotal, ms)
+        line["roofline"]["per_kernel"] = per_kernel_roofline(ctx, ktimes, steps, encode_own_bytes(sec, F, DOC))
+        d_ms = d_elapsed / steps * 1e3
+        line["decompress"] = {"value": round(world * F * DOC * steps / d_elapsed / 1e9, 3), "unit": "GB/s", "ms_per_step": round(d_ms, 3),
                               "round_trip_exact": True, "kernels": kernels_obj(ctx, d_k)}
-        line["decompress"]["roofline"], _ = roofline(ctx, d_k, args.steps, F * DOC + ctotal, d_ms)
+        line["decompress"]["roofline"], _ = roofline(ctx, d_k, steps, F * DOC + ctotal, d_ms)
+        line["decompress"]["roofline"]["per_kernel"] = per_kernel_roofline(ctx, d_k, steps, decode_own_bytes(sec, F, DOC))
         if world == 1 and not args.no_cpu_baseline:
             n = min(F, 65536)
             offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(DOC)
-            cb = cpu_baseline(False, np.ascontiguousarray(raw_np[:n]), offs, n, 0, n * DOC, dict_data)
+            cb = cpu_baseline(False, np.ascontiguousarray(raw_np[:n]), offs, n, 0, n * DOC, dict_data, passes=3 if quiet else 5)
             cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 ZSTD_compressStream2(e_end) level 3 with the shared ZSTD_CDict over the first %d documents "
                                                    "of the same workload; median of %d passes at the better of 64 / all host threads" % (n, cb["passes"])})
             line["cpu_baseline"] = cb
             blob, boffs = sample_blob(frames, n)
-            db = cpu_baseline(True, blob, boffs, n, DOC, n * DOC, dict_data)
+            db = cpu_baseline(True, blob, boffs, n, DOC, n * DOC, dict_data, passes=3 if quiet else 5)
             db.update({"kind": ref_kind, "sample": "ZSTD_decompressStream with the shared ZSTD_DDict, first %d frames" % n})
             line["decompress"]["cpu_baseline"] = db
-        print(json.dumps(line))
+        if not quiet:
+            print(json.dumps(line))
     ctx.close()
+    return line
 
 
-def bench_roundtrip(args, rank, world, dev):
+def bench_roundtrip(args, rank, world, dev, steps=None, warmup=None, quiet=False):
     """BASELINE.json configs[4]: every rank generates its shard of the 1 048 576 x 128 KiB corpus in HBM, compresses it, decompresses
     the frames again and compares in HBM; a sample of frames is compared with libzstd's; N > 1: the compressed payload all-gathered."""
     from zstandard_amd.device import DeviceBatchContext
     from zstandard_amd import sharded
     from tests.corpus import Corpus
+    steps = steps or args.steps; warmup = args.warmup if warmup is None else warmup
     F = args.frames if args.frames != 65536 else 131072            # BASELINE config: 1 048 576 / 8 per GPU
     raw = Corpus(device=dev, mix=args.mix).frames(rank * F, F, chunk=256)
     torch.cuda.synchronize()
@@ -300,10 +383,10 @@ def bench_roundtrip(args, rank, world, dev):
     st2 = torch.zeros(F, dtype=torch.int32, device=dev)
     cctx, dctx = DeviceBatchContext(), DeviceBatchContext()
     src = raw.reshape(-1)
-    c_el, c_k = job.timed(lambda: cctx.compress(src, src_segs, slots, slot_segs, csz, st), cctx, ENC_KERNELS, args.steps, args.warmup)
+    c_el, c_k = job.timed(lambda: cctx.compress(src, src_segs, slots, slot_segs, csz, st), cctx, ENC_KERNELS, steps, warmup)
     assert int(st.abs().max().item()) == 0, "a frame failed to compress"
     frame_segs = torch.stack([slot_segs[:, 0], csz], dim=1).contiguous()                  # the frames where they lie, inside their slots
-    d_el, d_k = job.timed(lambda: dctx.decompress(slots, frame_segs, back, src_segs, bsz, st2), dctx, DEC_KERNELS, args.steps, args.warmup)
+    d_el, d_k = job.timed(lambda: dctx.decompress(slots, frame_segs, back, src_segs, bsz, st2), dctx, DEC_KERNELS, steps, warmup)
     assert int(st2.abs().max().item()) == 0 and bool((bsz == FRAME).all().item()), "a frame failed to decode"
     assert torch.equal(back.view(F, FRAME), raw), "round-trip mismatch"
     ctotal = int(csz.sum().item())
@@ -318,7 +401,7 @@ def bench_roundtrip(args, rank, world, dev):
     gather_ms = None
     if USE_DIST:                                                   # reassemble the compressed output on every rank (north_star's all-gatherv)
         import torch.distributed as dist
-        dense, dsegs = sharded._compact(slots, slot_segs, csz, dev)
+        dense, dsegs = sharded._compact(slots, slot_segs, csz, st, dev)
         sizes = sharded._exchange_sizes(csz, None)
         bounds = [(r * F, (r + 1) * F) for r in range(world)]
         res = sharded.ShardResult(rank, bounds, dense, dsegs, sizes, st)
@@ -327,10 +410,11 @@ def bench_roundtrip(args, rank, world, dev):
         sharded.allgatherv_payload(res)
         job.barrier()
         gather_ms = (time.perf_counter() - t0) * 1e3
-        assert int(res.full_arena.numel()) == int(sizes.sum())
-    step_s = (c_el + d_el) / args.steps
+        assert int(res.full_arena.numel()) >= int(sizes.sum()) and res.slice_stride > 0
+    step_s = (c_el + d_el) / steps
+    sec = frame_sections(want)
     line = {"metric": "GB/s uncompressed throughput, compress + decompress round trip of 128 KiB buffers at level 3 (each step: both directions)",
-            "value": round(world * F * FRAME / step_s / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(world * F * FRAME / step_s / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "round trip on the GPU: %d x 128 KiB mixed-entropy buffers per GPU generated in HBM, multi_compress_to_buffer then "
                                    "multi_decompress_to_buffer (device-resident), level 3" % F, "frames_per_gpu": F, "frame_bytes": FRAME, "level": 3,
@@ -338,14 +422,31 @@ def bench_roundtrip(args, rank, world, dev):
                        "verification": "round trip compared in HBM for every frame; %d evenly spaced frames compared byte for byte with libzstd 1.5.7" % ns,
                        "parallelism": "frames sharded by rank; payload all-gatherv over RCCL after the timed steps" if world > 1 else "single GPU"}}
     if rank == 0:
-        line["compress"] = {"value": round(world * F * FRAME * args.steps / c_el / 1e9, 3), "ms_per_step": round(c_el / args.steps * 1e3, 3), "kernels": kernels_obj(cctx, c_k)}
-        line["decompress"] = {"value": round(world * F * FRAME * args.steps / d_el / 1e9, 3), "ms_per_step": round(d_el / args.steps * 1e3, 3), "kernels": kernels_obj(dctx, d_k)}
+        line["compress"] = {"value": round(world * F * FRAME * steps / c_el / 1e9, 3), "ms_per_step": round(c_el / steps * 1e3, 3), "kernels": kernels_obj(cctx, c_k)}
+        line["decompress"] = {"value": round(world * F * FRAME * steps / d_el / 1e9, 3), "ms_per_step": round(d_el / steps * 1e3, 3), "kernels": kernels_obj(dctx, d_k)}
         allk = dict(c_k)
-        line["roofline"], _ = roofline(cctx, allk, args.steps, 2 * (F * FRAME + ctotal), step_s * 1e3, F)
+        line["roofline"], _ = roofline(cctx, allk, steps, 2 * (F * FRAME + ctotal), step_s * 1e3, F)
+        line["roofline"]["per_kernel"] = per_kernel_roofline(cctx, c_k, steps, encode_own_bytes(sec, F, FRAME))
+        line["roofline"]["per_kernel"].update(per_kernel_roofline(dctx, d_k, steps, decode_own_bytes(sec, F, FRAME)))
+        if world == 1 and not args.no_cpu_baseline:
+            # the same round trip on the host: libzstd compress + decompress over a bounded sample, harmonic combination of the two rates
+            nsb = min(ns, 2048)
+            offs_r = np.arange(nsb + 1, dtype=np.uint64) * np.uint64(FRAME)
+            cbc = cpu_baseline(False, np.ascontiguousarray(sample_raw[:nsb]), offs_r, nsb, 0, nsb * FRAME, passes=3)
+            blob, boffs = sample_blob(want, nsb)
+            cbd = cpu_baseline(True, blob, boffs, nsb, FRAME, nsb * FRAME, passes=3)
+            rt = 1.0 / (1.0 / cbc["value"] + 1.0 / cbd["value"])
+            line["cpu_baseline"] = {"value": round(rt, 3), "unit": "GB/s", "cores": cbc["cores"], "kind": "reference", "compress": cbc["value"], "decompress": cbd["value"],
+                                    "sample": "libzstd 1.5.7 level 3 compress then decompress of %d evenly spaced buffers of the same workload on host threads "
+                                              "(median of 3 passes each at the better of 64 / all threads); value = 1 / (1 / compress + 1 / decompress)" % nsb}
         if gather_ms is not None:
             line["allgatherv"] = {"ms": round(gather_ms, 3), "bytes_per_rank": int(ctotal), "GBps_per_rank_received": round((world - 1) * ctotal / gather_ms / 1e6, 2)}
-        print(json.dumps(line))
+        if not quiet:
+            print(json.dumps(line))
     cctx.close(); dctx.close()
+    del raw, slots, back
+    torch.cuda.empty_cache()
+    return line
 
 
 def main():
@@ -360,6 +461,9 @@ def main():
                     help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
     ap.add_argument("--config", choices=["decompress", "compress", "dict", "roundtrip"], default=None,
                     help="decompress (default) is the BASELINE.json headline; compress / dict / roundtrip are configs[2] / [3] / [4] as their own lines")
+    ap.add_argument("--extra", action="store_true", help="carry the sub-objects at N > 1 too (default: N == 1 only -- the scaling runs keep to the headline)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default config only: skip the 'dict' (configs[3]) and 'roundtrip' (configs[4]) sub-objects the line otherwise carries")
     ap.add_argument("--mix", choices=["silesia", "default"], default="silesia", help="class mix of the 128 KiB corpus (tests/corpus.py)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
     args = ap.parse_args()
@@ -452,9 +556,12 @@ def bench_frames(args, config, rank, world, dev):
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": cfg,
     }
+    sec = frame_sections(frames)
     if rank == 0:
         line["kernels"] = kernels_obj(ctx, ktimes)
         line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * FRAME + ctotal, ms, F)
+        line["roofline"]["per_kernel"] = per_kernel_roofline(ctx, ktimes, args.steps, decode_own_bytes(sec, F, FRAME))
+        line["roofline"]["sections_per_frame"] = {k: round(v, 1) for k, v in sec.items()}
         if world == 1 and not args.no_cpu_baseline:
             blob, boffs = sample_blob(frames, nsample)
             cb = cpu_baseline(True, blob, boffs, nsample, FRAME, nsample * FRAME)
@@ -475,6 +582,7 @@ def bench_frames(args, config, rank, world, dev):
             line["compress"] = {"value": round(world * Fc * FRAME * 3 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 3,
                                 "ms_per_step": round(c_ms, 3), "bit_exact_vs_libzstd": True, "kernels": kernels_obj(ctx, c_k)}
             line["compress"]["roofline"], _ = roofline(ctx, c_k, 3, Fc * FRAME + c_total, c_ms, Fc)
+            line["compress"]["roofline"]["per_kernel"] = per_kernel_roofline(ctx, c_k, 3, encode_own_bytes(sec, Fc, FRAME))
             if world == 1 and not args.no_cpu_baseline:
                 ns = min(Fc, nsample)
                 offs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(FRAME)
@@ -482,9 +590,25 @@ def bench_frames(args, config, rank, world, dev):
                 cb.update({"kind": ref_kind, "sample": "libzstd 1.5.7 level 3, first %d inputs; median of %d passes at the better of 64 / all host threads"
                                                        % (ns, cb["passes"])})
                 line["compress"]["cpu_baseline"] = cb
+    ctx.close()
+    if not args.no_extra and F >= 65536 and (world == 1 or args.extra):
+        # BASELINE.json configs[3] and configs[4] ride on the default line as sub-objects (each with its own roofline and cpu_baseline), so
+        # that the driver's one run records every config; their own timed regions start after this line's is over. A failure there is
+        # reported in the sub-object and never loses the headline.
+        del raw, raw_np, frames
+        torch.cuda.empty_cache()
+        for key, fn in (("dict", bench_dict), ("roundtrip", bench_roundtrip)):
+            t0 = time.time()
+            try:
+                sub = fn(args, rank, world, dev, steps=3, warmup=1, quiet=True)
+                sub["wall_s"] = round(time.time() - t0, 1)
+            except Exception as e:                                  # noqa: BLE001 -- keep the headline
+                sub = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                line[key] = sub
+            torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(line))
-    ctx.close()
 
 
 if __name__ == "__main__":

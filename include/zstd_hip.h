@@ -147,6 +147,12 @@ int zhip_compress_batch_device(zhip_ctx*, const void* d_src, const zhip_segment*
                                void* d_dst, const zhip_segment* d_dstSegs,
                                uint64_t* d_outSizes, int32_t* d_status, void* stream);
 int zhip_ctx_sync(zhip_ctx*, void* stream, const int32_t* d_status, size_t n, zhip_error* err);
+/* The compress direction writes every frame into a zhip_compress_bound-sized slot; what is handed on (a BufferWithSegments, a payload
+ * all-gatherv across GPUs) is the frames back to back. d_offsets[i] = where frame i goes inside d_dense (the caller's exclusive prefix
+ * sum of d_outSizes, 8 bytes per item on the device); items whose d_status is non-zero are skipped. One wave per frame, 16 bytes per
+ * lane. The collection step of c-ext/compressor.c:1407-1496 (per-worker destination buffers -> one result), on the device. */
+int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, const uint64_t* d_outSizes, const int32_t* d_status,
+                        const uint64_t* d_offsets, size_t n, void* d_dense, void* stream);
 
 /* name of the dominant kernel of each direction as it appears in rocprofv3 traces, and its average duration (ms)
  * over the launches since the last call, measured with HIP events on the launch stream (for bench.py's roofline). */

@@ -401,6 +401,11 @@ static int build_seq_table(fse_dtable* dt, int* valid, unsigned mode, unsigned m
     }
 }
 
+/* analysis hook (tests/tools/seq_stats.py): when set, every decoded sequence is appended as (litLength, matchLength, offset) */
+static uint32_t* g_trace; static size_t g_traceCap, g_traceN;
+void zo_set_seq_trace(uint32_t* buf, size_t capTriples) { g_trace = buf; g_traceCap = capTriples; g_traceN = 0; }
+size_t zo_seq_trace_count(void) { return g_traceN; }
+
 static int decode_block(zo_dctx* d, uint8_t* ostart, uint8_t* op, uint8_t* oend, const uint8_t* src, size_t srcSize,
                         size_t blockMax, size_t* produced)
 {
@@ -462,6 +467,7 @@ static int decode_block(zo_dctx* d, uint8_t* ostart, uint8_t* op, uint8_t* oend,
                 so = co.base + (unsigned)bwd_read(&b, co.nbBits);
             }
             if (b.bits < 0) return -ZO_E_CORRUPTION;
+            if (g_trace && g_traceN < g_traceCap) { g_trace[3 * g_traceN] = ll; g_trace[3 * g_traceN + 1] = ml; g_trace[3 * g_traceN + 2] = (uint32_t)offset; g_traceN++; }
             /* execute */
             if ((size_t)(litEnd - lit) < ll) return -ZO_E_CORRUPTION;
             if ((size_t)(oend - op) < (size_t)ll + ml) return -ZO_E_DST_TOO_SMALL;

@@ -646,6 +646,9 @@ ZH_DEV ZpVec16 zq_fetch(const uint8_t* p0, int32_t off) { return *(const ZpVec16
 ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 {
     const uint32_t lane = zh_lane(), role = lane & 3, slot = lane >> 2;
+#if defined(ZP_K2_PRIO) && !defined(ZHIP_EMU)
+    __builtin_amdgcn_s_setprio(ZP_K2_PRIO);      // co-resident with K3 waves (ZHIP_SPLIT): the serial chain wins issue arbitration
+#endif
     if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
     if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
     if (lane == 0) L.spare = 512;                    // the spare lane's one-cell "table": symbol 0, x = 512 -> with a 9-bit log no state bits, no extra bits
@@ -830,6 +833,21 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 
 // DICT = false: no dictionary in the context -- every dictionary term folds away (K3 sits at its 128-register cap: carrying the
 // dictionary's pointer and size through the dictionary-less kernel spilled 200 bytes per lane and made it 2.6 x slower, r02x)
+#ifndef ZP_K3_NT
+#define ZP_K3_NT 0              // bit 0: sequences and decoded literals are read with streaming (nt) loads; bit 1: far-match sources too (A/B, r03b)
+#endif
+#if ZP_K3_NT & 1
+#define ZP_SEQ_LD(p) zh_ldq_nt(p)
+#define ZP_LIT_LD64(p) zh_ld64_nt(p)
+#else
+#define ZP_SEQ_LD(p) (*(p))
+#define ZP_LIT_LD64(p) zh_ld64(p)
+#endif
+#if ZP_K3_NT & 2
+#define ZP_FAR_LD64(p) zh_ld64_nt(p)
+#else
+#define ZP_FAR_LD64(p) zh_ld64(p)
+#endif
 template <bool DICT>
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
@@ -849,7 +867,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     uint8_t* const asmb = L.asmb;
     uint32_t op = 0, lp = 0, done = 0;
     const uint32_t nbSeq = m.nbSeq;
-    uint64_t qNext = lane < nbSeq ? seqs[lane] : 0;      // the next batch's sequences are requested a batch ahead
+    uint64_t qNext = lane < nbSeq ? ZP_SEQ_LD(seqs + lane) : 0;      // the next batch's sequences are requested a batch ahead
 #ifdef ZP_K3_PREFETCH
     uint32_t pfWord = 0, pfSink = 0;                      // EXPERIMENTAL: one byte of the next batch's far-match source per lane, touched a batch ahead
 #endif
@@ -863,7 +881,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         uint32_t cnt = (uint32_t)zh_popc64(fits);          // fits is a prefix mask (incT is monotone)
         const bool big = cnt == 0;
         if (big) cnt = 1;
-        qNext = done + cnt + lane < nbSeq ? seqs[done + cnt + lane] : 0;
+        qNext = done + cnt + lane < nbSeq ? ZP_SEQ_LD(seqs + done + cnt + lane) : 0;
         const bool act = lane < cnt;
         if (!act) { myLL = 0; myML = 0; myOF = 1; }
         const uint32_t totL = zh_shfl(incL, cnt - 1), totT = zh_shfl(incT, cnt - 1);
@@ -903,7 +921,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const bool arenaLit = m.litMode != 0;                                   // (frame-uniform)
             if (arenaLit && !litRLE) {
                 const uint8_t* q = litPtr + (shortL ? litStart : 0u);
-                rl[0] = zh_ld64(q); rl[1] = zh_ld64(q + 8); rl[2] = zh_ld64(q + 16); rl[3] = zh_ld64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
+                rl[0] = ZP_LIT_LD64(q); rl[1] = ZP_LIT_LD64(q + 8); rl[2] = ZP_LIT_LD64(q + 16); rl[3] = ZP_LIT_LD64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
             } else
 #endif
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
@@ -922,7 +940,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #ifndef ZP_K3_NO_GLD
             if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
                 const uint8_t* q = shortM ? mSrc : dst;
-                rm[0] = zh_ld64(q); rm[1] = zh_ld64(q + 8); rm[2] = zh_ld64(q + 16); rm[3] = zh_ld64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
+                rm[0] = ZP_FAR_LD64(q); rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
             } else
 #endif
             if (shortM) zd_ld32(mSrc, lenMi, rm);

@@ -281,7 +281,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -306,6 +306,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
+        if (const char* e = getenv("ZHIP_SPLIT")) k.split = atol(e) != 0;
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
@@ -552,15 +553,21 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
+        // ZHIP_SPLIT=1 (A/B, r03b): the front of the pipeline (K1, KB, K1b, K2: LDS-bound serial chains with idle issue slots) of chunk k + 1 on one
+        // stream, K3 (register- and memory-bound, little LDS) of chunk k on a second one, so that the PAIRING of co-resident kernels is the
+        // complementary one instead of whatever two free-running slot streams drift into; the arenas still alternate over `nslot` slots
+        const bool split = c->knob.split && nslot >= 2;
+        const int nstream = split ? 2 : nslot;
+        std::vector<hipEvent_t> evK3Done;
         if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
             c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return g_reserveRc;
-        for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
+        for (int sidx = 0; sidx < (nslot > nstream ? nslot : nstream); sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, (8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(evStart, stream));
-        for (int sidx = 0; sidx < nslot; sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
+        for (int sidx = 0; sidx < (nslot > nstream ? nslot : nstream); sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
         (void)hipEventDestroy(evStart);
         ZhipPipeArgs pa; memset(&pa, 0, sizeof pa);
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
@@ -583,7 +590,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         size_t ci = 0;
         for (size_t first = 0; first < n; first += chunk, ci++) {
             const int sidx = (int)(ci % nslot);
-            hipStream_t ss = c->slotStream[sidx];
+            hipStream_t ss = split ? c->slotStream[0] : c->slotStream[sidx];
+            hipStream_t sx = split ? c->slotStream[1] : ss;                       // K3's stream
+            if (split && ci >= (size_t)nslot) HIP_TRY(hipStreamWaitEvent(ss, evK3Done[ci - nslot], 0));     // the slot's arenas are free again
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * chunk;
@@ -617,13 +626,30 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
+            hipEvent_t evK2beg = nullptr;
+            if (tm && split) { HIP_TRY(hipEventCreate(&evK2beg)); HIP_TRY(hipEventRecord(evK2beg, ss)); }
             if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
             else hipLaunchKernelGGL(zhip_decode_seq1_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
-            if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
-            else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
-            if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
+            hipEvent_t evK2end = nullptr;
+            if (split) {
+                hipEvent_t evFront; HIP_TRY(hipEventCreateWithFlags(&evFront, hipEventDisableTiming));
+                if (tm) { HIP_TRY(hipEventCreate(&evK2end)); HIP_TRY(hipEventRecord(evK2end, ss)); }
+                HIP_TRY(hipEventRecord(evFront, ss));
+                HIP_TRY(hipStreamWaitEvent(sx, evFront, 0));
+                (void)hipEventDestroy(evFront);
+            }
+            if (tm) HIP_TRY(hipEventRecord(ev[2], sx));
+            if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            if (tm) HIP_TRY(hipEventRecord(ev[3], sx));
+            if (split) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIP_TRY(hipEventRecord(e, sx)); evK3Done.push_back(e); }
             HIP_TRY(hipGetLastError());
+            if (tm && split) {
+                c->timer[2].pending.emplace_back(ev[0], evh);
+                c->timer[7].pending.emplace_back(evh2, ev[1]);
+                c->timer[3].pending.emplace_back(evK2beg, evK2end);
+                c->timer[4].pending.emplace_back(ev[2], ev[3]);
+            } else
             if (tm) {
                 // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
                 // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
@@ -667,7 +693,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 }
             }
         }
-        for (int sidx = 0; sidx < nslot; sidx++) {                 // the caller's stream continues after every slot has drained
+        for (hipEvent_t e : evK3Done) (void)hipEventDestroy(e);
+        for (int sidx = 0; sidx < nstream; sidx++) {                 // the caller's stream continues after every slot has drained
             hipEvent_t evEnd; HIP_TRY(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(evEnd, c->slotStream[sidx]));
             HIP_TRY(hipStreamWaitEvent(stream, evEnd, 0));
@@ -1031,6 +1058,20 @@ __global__ __launch_bounds__(64) void zhip_compact_kernel(const uint8_t* slots, 
         for (uint32_t j = threadIdx.x * 16; j < whole; j += 1024) { const zh_v16 v = zh_ld128(s + j); zh_st64(d + j, v.lo); zh_st64(d + j + 8, v.hi); }
         if (threadIdx.x < size - whole) d[whole + threadIdx.x] = s[whole + threadIdx.x];
     }
+}
+
+extern "C" int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, const uint64_t* d_outSizes, const int32_t* d_status,
+                                   const uint64_t* d_offsets, size_t n, void* d_dense, void* streamv)
+{
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFu) { g_lastError = "too many frames in one launch"; return ZHIP_ERR_UNSUPPORTED; }
+    int dev = 0; hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev)); HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const size_t gmax = (size_t)prop.multiProcessorCount * 16;
+    hipLaunchKernelGGL(zhip_compact_kernel, dim3((uint32_t)(n < gmax ? n : gmax)), dim3(64), 0, (hipStream_t)streamv, (const uint8_t*)d_slots, d_slotSegs, d_outSizes,
+                       d_status, d_offsets, (uint32_t)n, (uint8_t*)d_dense);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // per-context host pipeline state (streams, staging, small pinned metadata)

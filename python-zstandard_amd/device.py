@@ -41,9 +41,16 @@ class DeviceBatchContext:
             setattr(p.cp, names[k], v)
         if raw:
             p.dict, p.dictSize = C.cast(self._dict_buf, C.c_void_p), len(raw)
-        rc = self.L.zhip_ctx_set_cparams(self.ctx, C.byref(p))
-        if rc:
-            raise ZstdError("could not set compression parameters: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
+        # the compression side is set up by the first compress() call: digesting the dictionary for compression (tagged tables, entropy
+        # encoding tables) is work a decode-only context never needs, and a dictionary the compressor refuses must not stop a decoder
+        self._cparams, self._cparams_set = p, False
+
+    def _ensure_cparams(self):
+        if not self._cparams_set:
+            rc = self.L.zhip_ctx_set_cparams(self.ctx, C.byref(self._cparams))
+            if rc:
+                raise ZstdError("could not set compression parameters: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
+            self._cparams_set = True
 
     def close(self):
         if self.ctx:
@@ -74,6 +81,7 @@ class DeviceBatchContext:
             raise ZstdError("HIP backend failure: %s" % _lib.last_error())
 
     def compress(self, src, src_segs, dst, dst_segs, out_sizes, status, stream=None):
+        self._ensure_cparams()
         self._check(src, torch.uint8); self._check(dst, torch.uint8)
         n = src_segs.shape[0]
         s = stream if stream is not None else torch.cuda.current_stream()

@@ -17,7 +17,8 @@ def partition_by_bytes(sizes, workers):
     reaches total/workers, the last worker takes the rest. Returns [(start, end)] with `end` exclusive, one per worker
     (trailing workers may be empty when there are fewer items than workers)."""
     n = len(sizes)
-    workers = max(1, min(workers, n)) if n else 1
+    asked = max(1, int(workers))
+    workers = max(1, min(asked, n)) if n else 1           # the reference's clamp (compressor.c:1151): never more workers than items
     total = int(sum(sizes))
     per = total // workers
     bounds, start, acc, w = [], 0, 0, 0
@@ -27,7 +28,7 @@ def partition_by_bytes(sizes, workers):
             bounds.append((start, i + 1))
             start, acc, w = i + 1, 0, w + 1
     bounds.append((start, n))
-    while len(bounds) < workers:
+    while len(bounds) < asked:                             # one entry per ASKED worker: a rank without items still takes part in the collectives
         bounds.append((n, n))
     return bounds
 

@@ -67,6 +67,13 @@ class _CpuCtx:
             dst[d:d + len(f)] = torch.frombuffer(bytearray(f), dtype=torch.uint8)
             out_sizes[i] = len(f)
 
+    def compact(self, arena, segs, out_sizes, status, offs, dense):
+        """what zhip_compact_device does on the GPU (include/zstd_hip.h): the valid prefix of every slot -> its place in the dense arena"""
+        for i in range(segs.shape[0]):
+            if int(status[i]) == 0:
+                o, n, d = int(segs[i, 0]), int(out_sizes[i]), int(offs[i])
+                dense[d:d + n] = arena[o:o + n]
+
     def decompress(self, src, src_segs, dst, dst_segs, out_sizes, status):
         for i in range(src_segs.shape[0]):
             o, n = (int(v) for v in src_segs[i])
@@ -103,8 +110,34 @@ def _sharded_worker(rank, world, port, q):
         sh.multi_decompress_to_buffer(frames[:5] + [frames[5][:-3] + b"zzz"] + frames[6:], [len(x) for x in items], ctx_factory=_CpuCtx)
     except zstandard_amd.ZstdError as e:
         err = str(e)
+    # fewer items than ranks, and none at all: every rank still takes part in every collective (IndexError + hang before)
+    small = []
+    for sub in (items[3:4], []):
+        r1 = sh.multi_compress_to_buffer(sub, level=3, gather=True, ctx_factory=_CpuCtx)
+        f1 = r1.to_buffer(zstandard_amd)
+        b1 = sh.multi_decompress_to_buffer([f1[i].tobytes() for i in range(len(f1))], [len(x) for x in sub], gather=True, ctx_factory=_CpuCtx)
+        small.append((len(f1), [bytes(b1.full_arena[o:o + n].numpy()) for o, n in b1.global_segments()] == sub, r1.bounds))
+    # a frame that decodes to fewer bytes than announced: reported like an item error on every rank, never a silently misaligned arena
+    short_err = None
+    try:
+        sh.multi_decompress_to_buffer(frames, [len(x) + (7 if i == 2 else 0) for i, x in enumerate(items)], ctx_factory=_CpuCtx)
+    except zstandard_amd.ZstdError as e:
+        short_err = str(e)
+    # every rank brings its OWN shard (uneven: rank 0 three items, rank 1 one -- and then none): compress_shard / decompress_shard
+    shard_ok = []
+    for mine in ((items[:3] if rank == 0 else items[5:6]), (items[:2] if rank == 0 else [])):
+        ctx = _CpuCtx()
+        arena = torch.frombuffer(bytearray(b"".join(mine) or b"\0"), dtype=torch.uint8)
+        lens = torch.tensor([len(x) for x in mine], dtype=torch.int64)
+        segs = torch.stack([torch.cumsum(lens, 0) - lens, lens], dim=1) if mine else torch.zeros((0, 2), dtype=torch.int64)
+        rs = sh.compress_shard(ctx, arena, segs, gather=True)
+        gs = rs.global_segments()
+        allf = [bytes(rs.full_arena[o:o + n].numpy()) for o, n in gs]
+        rd = sh.decompress_shard(ctx, rs.arena, rs.segs, lens, gather=True)
+        back2 = [bytes(rd.full_arena[o:o + n].numpy()) for o, n in rd.global_segments()]
+        shard_ok.append((rs.bounds, len(allf), [ctx.z.decompress(f, 1 << 20) for f in allf] == back2, back2[rs.lo:rs.hi] == list(mine)))
     q.put((rank, res.bounds, [len(f) for f in frames], outs == items, len(local), res.sizes.tolist(), err,
-           [res.local_item(i) == frames[i] for i in range(res.lo, res.hi)]))
+           [res.local_item(i) == frames[i] for i in range(res.lo, res.hi)], small, short_err, shard_ok))
     dist.destroy_process_group()
 
 
@@ -118,7 +151,12 @@ def test_sharded_calls_world2_full_control_flow(oracle):
     res = sorted(q.get(timeout=150) for _ in range(2))
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (r0, b0, l0, ok0, n0, s0, e0, loc0), (r1, b1, l1, ok1, n1, s1, e1, loc1) = res
+    (r0, b0, l0, ok0, n0, s0, e0, loc0, sm0, se0, sh0), (r1, b1, l1, ok1, n1, s1, e1, loc1, sm1, se1, sh1) = res
+    assert sm0 == sm1 and sm0[0][0] == 1 and sm0[0][1] and sm0[1][0] == 0 and sm0[1][1]      # one item / no items over two ranks
+    assert len(sm0[0][2]) == 2 and sm0[0][2][1] == (1, 1) and sm0[1][2] == [(0, 0), (0, 0)]
+    assert se0 == se1 and se0 is not None and "item 2" in se0 and "expected" in se0
+    assert sh0 == sh1 and sh0[0][0] == [(0, 3), (3, 4)] and sh0[0][1] == 4 and sh0[0][2]
+    assert sh0[1][0] == [(0, 2), (2, 2)] and sh0[1][1] == 2 and sh0[1][2]
     assert b0 == b1 and b0[0][0] == 0 and b0[0][1] == b0[1][0] and b0[1][1] == 14        # same contiguous cover on both ranks
     assert l0 == l1 == s0 == s1                                                           # every rank holds every frame + the global table
     assert ok0 and ok1                                                                    # round trip through both sharded calls

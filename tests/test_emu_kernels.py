@@ -429,7 +429,7 @@ def test_fast_strategy_dictionary_bit_exact(emu, ref, corpus):
     for i in range(128):
         samples += [b"foo" * 64, b"bar" * 64, b"foobar" * 64]
     dicts = [ref.train_dictionary(8192, samples), corpus.frame_bytes(600)[:6000],
-             open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict_json4k.bin"), "rb").read()]
+             open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict_json4k_16k.bin"), "rb").read()]
     raws = [corpus.frame_bytes(i)[: int(rng.integers(40, 8193))] for i in range(24)] + [b"foo bar foobar foo bar foobar", b"", b"x", b"abcdefgh", b"foobar" * 900]
     for dd in dicts:
         for level in (1, -3):

@@ -153,9 +153,11 @@ def test_hostile_content_sizes(zstd):
 
 
 def test_dictionary_batch_config4_shape(zstd):
-    """BASELINE.json configs[3] at a sixteenth of its size: 16 384 x 4 KiB JSON-like documents with the trained dictionary of
-    tests/golden/dict_json4k.bin -- every compressed frame equals the reference build's (native ZSTD_CCtx_refCDict workers, the
-    reference's own call), every frame decodes back with the dictionary; plus the pinned probe vectors of the fixture"""
+    """BASELINE.json configs[3] at a sixteenth of its document count and at its full dictionary: 16 384 x 4 KiB JSON-like documents with
+    the 112 640-byte dictionary train_dictionary(112640, 10 000 samples) makes (tests/golden/dict_json4k.bin, SURVEY.md 8(d)4: a CDict of
+    W17 / C15 / H16 = 384 KiB of tagged tables and 110 KiB of content behind every frame) -- every compressed frame equals the reference
+    build's (native ZSTD_CCtx_refCDict workers, the reference's own call), every frame decodes back with the dictionary; the pinned probe
+    vectors of the fixture; and sources that straddle into / reach deep inside the 110 KiB of dictionary content, both directions"""
     import json
     import os
     import bench
@@ -183,6 +185,23 @@ def test_dictionary_batch_config4_shape(zstd):
     assert len(back) == n and back.size() == n * 4096
     for i in range(n):
         assert back[i].tobytes() == items[i], "document %d does not round-trip" % i
+    # straddlers: sources that continue the dictionary's last bytes, quote pieces from its start / middle / end (offsets up to ~110 KiB
+    # below the frame's first byte), tiny and empty sources, and sizes on both sides of the attach cutoff (16 KiB for double-fast)
+    assert len(blob) == 112640 and meta["dict_size"] == 112640
+    ref = reflib.RefZstd()
+    content = blob[-100000:]
+    extra = [content[-3000:] + items[0][:1000], content[5000:6500] + items[1][:2000] + content[60000:61000], content[-100:], b"", b"x",
+             content[:4096], content[40000:44096], items[2][:100] + content[-50000:-46000] + items[3][:100],
+             content[-16384:], content[-16385:] + b"!", content[1000:1000 + 16000] + items[4][:384], (content[-700:] * 30)[:16384], items[5] * 4, items[6] * 5]
+    got2 = zstd.ZstdCompressor(level=3, dict_data=zd).multi_compress_to_buffer(extra)
+    for i, r in enumerate(extra):
+        assert got2[i].tobytes() == ref.compress(r, level=3, dict_data=blob), "straddler %d: frame differs from libzstd's" % i
+    back2 = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(got2)
+    assert [back2[i].tobytes() for i in range(len(extra))] == extra
+    # frames made by libzstd at other levels against the same dictionary (long offsets into the content) decode identically
+    deep = [ref.compress(r, level=lv, dict_data=blob) for lv in (1, 3, 9, 19) for r in extra[:8]]
+    back3 = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(deep)
+    assert [back3[i].tobytes() for i in range(len(deep))] == [r for lv in (1, 3, 9, 19) for r in extra[:8]]
 
 
 def test_fast_strategy_with_dictionary(zstd, ref, corpus):

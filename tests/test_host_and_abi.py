@@ -130,7 +130,11 @@ def test_partition_by_bytes_matches_reference_rule():
     assert par.partition_by_bytes(sizes, 2) == [(0, 5), (5, 10)]
     assert par.partition_by_bytes(sizes, 3) == [(0, 4), (4, 8), (8, 10)]          # cut once a worker reaches total/workers
     assert par.partition_by_bytes([100, 1, 1, 1], 2) == [(0, 1), (1, 4)]
-    assert par.partition_by_bytes([5], 4) == [(0, 1)]
+    # fewer items than workers: the reference clamps the worker count (compressor.c:1151); here every ASKED worker (= rank) still gets an
+    # entry, empty beyond the items, because a rank without work must take part in the collectives (IndexError + hang)
+    assert par.partition_by_bytes([5], 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+    assert par.partition_by_bytes([10, 20, 30], 8) == [(0, 2), (2, 3)] + [(3, 3)] * 6
+    assert par.partition_by_bytes([], 4) == [(0, 0)] * 4
     bounds = par.partition_by_bytes(list(range(1, 100)), 8)
     assert bounds[0][0] == 0 and bounds[-1][1] == 99 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
 
