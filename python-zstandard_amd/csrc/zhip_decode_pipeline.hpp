@@ -939,7 +939,11 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN && !strad;
 #ifndef ZP_K3_NO_GLD
             if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
+#ifdef ZP_K3_DIAG_NOFAR          // DIAGNOSTIC ONLY (wrong output): far matches read the frame's first bytes -- what K3 costs without its random gathers
+                const uint8_t* q = dst + 64 * lane;
+#else
                 const uint8_t* q = shortM ? mSrc : dst;
+#endif
                 rm[0] = ZP_FAR_LD64(q); rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
             } else
 #endif

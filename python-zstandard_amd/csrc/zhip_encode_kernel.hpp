@@ -1463,6 +1463,150 @@ ZH_DEVFN uint32_t ze_dfast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, c
     return nseq;
 }
 
+// ------------------------------------------------------------------------------------------ double-fast + attached dictionary, FLAT
+// The search of ze_dfast_dict above for the batch shape dictionaries exist for (BASELINE configs[3]: hundreds of thousands of small
+// documents), the way ze_dfast_flat re-expressed the dictionary-less one: one LANE per document, 64 documents per wave, every document of
+// the chunk in flight, ONE loop whose trip examines one probe position in three memory rounds whatever the lanes decide --
+//   round 0: the probe's own bytes (position ip and ip + 1) and the repeat-offset candidate's;
+//   round 1: every table cell the reference could consult for this position: its own long / short cell, the dictionary's tagged long /
+//            short cell, and -- speculatively, they are only reads -- the long cells of position ip + 1 (own and dictionary), which the
+//            reference consults after a short candidate was found (zstd.c:31385-31420);
+//   round 2: the bytes of every candidate that is PLAUSIBLE (own cell in use; dictionary cell carrying the probe's 8-bit tag);
+// then the reference's decision order over what was fetched (repeat offset, own long, dictionary long, short, long at ip + 1). All loads of
+// a round are unconditional with always-valid addresses, so a trip is three round trips instead of the up to six dependent ones of the
+// nested-loop form, and lanes wait for one another only in the match epilogue (count / catch-up / insertions), never to FIND a match.
+// The table writes are the reference's, in its order: own cells of ip always (zstd.c:31308), the long cell of ip + 1 only on the path
+// that consults it (:31391). Sequences only -- the entropy stage gathers the literals from the source (ze_gather_literals).
+// Index space as in ze_dfast_dict: dictionary content byte k is index 2 + k, the source starts at CE = 2 + contentSize.
+ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, const ZePar& cp, const ZeCDict& cd, const uint8_t* content,
+                                   const uint32_t* dHashLong, const uint32_t* dHashSmall, uint32_t* hashLong, uint32_t* hashSmall)
+{
+    const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
+    const uint32_t shL = 64u - (uint32_t)cp.hlog, shDL = 64u - (uint32_t)(cd.hlog + 8);
+    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
+    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
+    // (for mls == 4 the reference hashes 32 bits: (u32 * prime) >> (32 - bits) == ((u << 32) * prime) >> (64 - bits))
+    const uint32_t shS = 64u - (uint32_t)cp.clog, shDS = 64u - (uint32_t)(cd.clog + 8);
+    const uint32_t CE = 2 + cd.contentSize, DS = 2;
+    ZeSpace sp; sp.content = content; sp.src = src; sp.CE = CE; sp.end = CE + srcSize;
+    const uint32_t iend = CE + srcSize;
+    uint32_t ip = CE, anchor = CE, off1 = cd.rep[0], off2 = cd.rep[1], nseq = 0;
+    if (srcSize < 8) return 0;
+    const uint32_t ilimit = iend - 8;
+#define ZE_SRC(i) (src + ((i) - CE))
+    // 8 readable bytes at index i of the index space, or -- when they straddle the end of the dictionary's content -- the probe's own (the
+    // caller re-reads such a candidate byte by byte: ze_sp_rd64)
+#define ZE_SPP(i, fallback) ((i) >= CE ? ZE_SRC(i) : (i) + 8 <= CE ? content + ((i) - 2) : (fallback))
+#define ZE_BACK(LOW) while (ip > anchor && m > (LOW) && ze_sp_byte(sp, ip - 1) == ze_sp_byte(sp, m - 1)) { ip--; m--; mLength++; }
+    while (ip < ilimit) {
+        const uint32_t curr = ip;
+        const uint8_t* const own = ZE_SRC(ip);
+        // ---- round 0
+        const uint64_t w = zh_ld64(own), w1 = zh_ld64(own + 1);
+        const uint32_t repIndex = curr + 1 - off1;
+        const bool repOK = (uint32_t)((CE - 1) - repIndex) >= 3;                // not across the dictionary / source boundary (zstd.c:31312)
+        const uint32_t rp = zh_ld32(repOK ? (repIndex >= CE ? ZE_SRC(repIndex) : content + (repIndex - 2)) : own);
+        const uint64_t pL = w * 0xCF1BBCDCB7A56463ull, pL1 = w1 * 0xCF1BBCDCB7A56463ull, pS = (w << shlS) * primeS;
+        const uint32_t h2 = (uint32_t)(pL >> shL), h = (uint32_t)(pS >> shS), hl3 = (uint32_t)(pL1 >> shL);
+        const uint32_t dTagL = (uint32_t)(pL >> shDL), dTagS = (uint32_t)(pS >> shDS), dTagL3 = (uint32_t)(pL1 >> shDL);
+        // ---- round 1
+        const uint32_t mIdxL = hashLong[h2], mIdxS0 = hashSmall[h], dEntL = dHashLong[dTagL >> 8], dEntS = dHashSmall[dTagS >> 8];
+        uint32_t mIdxL3 = hashLong[hl3]; const uint32_t dEntL3 = dHashLong[dTagL3 >> 8];
+        if (hl3 == h2) mIdxL3 = curr;                                           // what the reference's later read sees after its write below
+        hashLong[h2] = curr; hashSmall[h] = curr;
+        const bool tagL = (dEntL & 255) == (dTagL & 255), tagS = (dEntS & 255) == (dTagS & 255), tagL3 = (dEntL3 & 255) == (dTagL3 & 255);
+        const uint32_t dL = dEntL >> 8, dS = dEntS >> 8, dL3 = dEntL3 >> 8;
+        const bool ownL = mIdxL >= CE, ownS = mIdxS0 > CE, ownL3 = mIdxL3 >= CE;
+        const bool dctL = !ownL && tagL && dL > DS, dctS = !ownS && tagS && dS > DS, dctL3 = tagL3 && dL3 > DS;     // (dctL: consulted only when the own cell fails -- see below)
+        // ---- round 2: candidates' bytes
+        uint64_t cL = zh_ld64(ownL ? ZE_SRC(mIdxL) : own);
+        uint64_t cDL = zh_ld64((tagL && dL > DS) ? ZE_SPP(dL, own) : own);
+        uint32_t cS = zh_ld32(ownS ? ZE_SRC(mIdxS0) : dctS ? ZE_SPP(dS, own) : own);
+        uint64_t cL3 = zh_ld64(ownL3 ? ZE_SRC(mIdxL3) : own + 1);
+        uint64_t cDL3 = zh_ld64(dctL3 ? ZE_SPP(dL3, own + 1) : own + 1);
+        cL = zh_opaque64(cL); cDL = zh_opaque64(cDL); cS = zh_opaque(cS); cL3 = zh_opaque64(cL3); cDL3 = zh_opaque64(cDL3);     // no load sinks into a branch
+        (void)dctL;
+        // candidates across the end of the dictionary's content (a few per batch): byte by byte
+        if (tagL && dL > DS && dL < CE && dL + 8 > CE) cDL = ze_sp_rd64(sp, dL);
+        if (dctS && dS < CE && dS + 8 > CE) cS = ze_sp_rd32(sp, dS);
+        if (dctL3 && dL3 < CE && dL3 + 8 > CE) cDL3 = ze_sp_rd64(sp, dL3);
+        // ---- the reference's decision order (zstd.c:31312-31440)
+        uint32_t mLength = 0, offset = 0;
+        int found = 0;
+        if (repOK && rp == (uint32_t)(w >> 8)) {
+            mLength = ze_sp_count(sp, ip + 1 + 4, repIndex + 4) + 4;
+            ip++;
+            seqs[nseq++] = ZE_SEQ_PACK(1, ip - anchor, mLength);
+            found = 1;
+        } else {
+            if (ownL && cL == w) {
+                uint32_t m = mIdxL;
+                mLength = ze_sp_count(sp, ip + 8, m + 8) + 8;
+                offset = ip - m;
+                ZE_BACK(CE)
+                found = 2;
+            } else if (tagL && dL > DS && cDL == w) {
+                uint32_t m = dL;
+                mLength = ze_sp_count(sp, ip + 8, m + 8) + 8;
+                offset = curr - m;
+                ZE_BACK(DS)
+                found = 2;
+            }
+            if (!found) {
+                const bool shortCand = (ownS || dctS) && cS == (uint32_t)w;
+                if (!shortCand) { ip += ((ip - anchor) >> 8) + 1; continue; }
+                const uint32_t mIdxS = ownS ? mIdxS0 : dS;
+                hashLong[hl3] = curr + 1;                                       // the long table is consulted -- and written -- one position ahead
+                if (ownL3 && cL3 == w1) {
+                    uint32_t m = mIdxL3;
+                    mLength = ze_sp_count(sp, ip + 9, m + 8) + 8;
+                    ip++;
+                    offset = ip - m;
+                    ZE_BACK(CE)
+                } else if (dctL3 && cDL3 == w1) {
+                    uint32_t m = dL3;
+                    mLength = ze_sp_count(sp, ip + 1 + 8, m + 8) + 8;
+                    ip++;
+                    offset = curr + 1 - m;
+                    ZE_BACK(DS)
+                } else {
+                    uint32_t m = mIdxS;
+                    mLength = ze_sp_count(sp, ip + 4, m + 4) + 4;
+                    offset = curr - mIdxS;
+                    if (mIdxS < CE) { ZE_BACK(DS) } else { ZE_BACK(CE) }
+                }
+                found = 2;
+            }
+            off2 = off1; off1 = offset;
+            seqs[nseq++] = ZE_SEQ_PACK(offset + 3, ip - anchor, mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            const uint32_t ins = curr + 2;
+            const uint64_t wI = zh_ld64(ZE_SRC(ins)), wE2 = zh_ld64(ZE_SRC(ip - 2)), wE1 = zh_ld64(ZE_SRC(ip - 1));
+            hashLong[(uint32_t)((wI * 0xCF1BBCDCB7A56463ull) >> shL)] = ins;
+            hashLong[(uint32_t)((wE2 * 0xCF1BBCDCB7A56463ull) >> shL)] = ip - 2;
+            hashSmall[(uint32_t)(((wI << shlS) * primeS) >> shS)] = ins;
+            hashSmall[(uint32_t)(((wE1 << shlS) * primeS) >> shS)] = ip - 1;
+            while (ip <= ilimit) {
+                const uint32_t rep2 = ip - off2;
+                if (!((uint32_t)((CE - 1) - rep2) >= 3 && ze_sp_rd32(sp, rep2) == zh_ld32(ZE_SRC(ip)))) break;
+                const uint32_t r = ze_sp_count(sp, ip + 4, rep2 + 4) + 4;
+                const uint32_t t = off2; off2 = off1; off1 = t;
+                seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
+                const uint64_t wr = zh_ld64(ZE_SRC(ip));
+                hashSmall[(uint32_t)(((wr << shlS) * primeS) >> shS)] = ip;
+                hashLong[(uint32_t)((wr * 0xCF1BBCDCB7A56463ull) >> shL)] = ip;
+                ip += r; anchor = ip;
+            }
+        }
+    }
+#undef ZE_BACK
+#undef ZE_SPP
+#undef ZE_SRC
+    return nseq;
+}
+
 // ------------------------------------------------------------------------------------------ fast search against an attached dictionary
 // ZSTD_compressBlock_fast_dictMatchState_generic (zstd.c:32197) for a frame of one block, in the index space of ze_dfast_dict (dictionary
 // content byte k is index 2 + k, the source starts at CE). The dictionary has ONE tagged table here (ZSTD_fillHashTableForCDict). One lane.
@@ -2668,25 +2812,48 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
 ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
 {
     const uint32_t lane = zh_lane();
-    if (lane >= ZE_FLAT_LANES) return;
     const uint32_t i = zh_block() * ZE_FLAT_LANES + lane;
-    if (i >= a.count) return;
-    const uint32_t f = a.first + i;
+    const bool mine = lane < ZE_FLAT_LANES && i < a.count;
+    const uint32_t f = a.first + (mine ? i : 0u);
     ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
     const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
-    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
-    ZePar cp;
-    if (srcSize64 > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; return; }
+    const uint64_t srcSize64 = mine ? a.srcSegs[2 * (size_t)f + 1] : 0;
     const uint32_t srcSize = (uint32_t)srcSize64;
-    if (a.cdict || srcSize < 64 || ze_get_cparams(cp, a.rows, srcSize) || cp.strat != 2 ||
-        (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) {
-        a.e1List[zh_atomic_add(a.e1Count, 1u)] = i;                       // the lane-serial kernel decides (and reports errors)
-        return;
+    ZePar cp; cp.wlog = cp.clog = cp.hlog = cp.mml = cp.strat = cp.tlen = 0;
+    bool take = mine;
+    if (mine && srcSize64 > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; take = false; }
+    // with an attached dictionary (sources up to the attach cutoff, double-fast row, a dictionary that has content): ze_dfast_dict_flat
+    const bool dict = a.cdict != nullptr;
+    if (take) {
+        bool ok = srcSize >= 64 && ze_get_cparams(cp, a.rows, srcSize) == 0;
+        if (ok && dict) {
+            ok = a.cdict->status == 0 && a.cdict->contentSize != 0 && srcSize <= ze_dict_attach_max(*a.cdict);
+            if (ok) ze_dict_cparams(cp, *a.cdict, srcSize);
+        }
+        ok = ok && cp.strat == 2 && (size_t)(4u << cp.hlog) + (4u << cp.clog) <= a.tableStride;
+        if (!ok) { a.e1List[zh_atomic_add(a.e1Count, 1u)] = i; take = false; }    // the lane-serial kernel decides (and reports errors)
     }
-    uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
-    uint32_t* hashSmall = hashLong + (1u << cp.hlog);
+    uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)(mine ? i : 0u) * a.tableStride);
+    uint32_t* hashSmall = hashLong + (take ? (1u << cp.hlog) : 0u);
+    if (dict) {
+        // dictionary batches: the wave zeroes its documents' tables itself, only the part each one uses (the slots are sized for the attach
+        // cutoff: a host-side memset of whole slots would write four times what 4 KiB documents need)
+        const uint32_t myUnits = take ? ((4u << cp.hlog) + (4u << cp.clog)) / 16u : 0u;
+        for (uint32_t l = 0; l < ZE_FLAT_LANES; l++) {
+            const uint32_t units = zh_shfl(myUnits, l);
+            if (!units) continue;
+            const uint32_t lo = zh_shfl((uint32_t)(uintptr_t)hashLong, l), hi = zh_shfl((uint32_t)((uintptr_t)hashLong >> 32), l);
+            ZdPack16* t = (ZdPack16*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+            ZdPack16 z; z.a = z.b = z.c = z.d = 0;
+            for (uint32_t k = lane; k < units; k += 64) t[k] = z;
+        }
+        zd_fence();
+        zh_sync();
+    }
+    if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    m.nbSeq = ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
+    m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+                   : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

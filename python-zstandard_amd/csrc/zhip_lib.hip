@@ -821,8 +821,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // double-fast without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
         // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
         // and dictionary batches use the lane-serial kernel for the whole chunk.
-        const bool flat = anyDfast && !c->hasCDict && !c->knob.noFlat;
-        size_t chunkMax = flat ? 65536 : c->hasCDict ? 262144 : 32768;
+        // (r03: dictionary batches whose dictionary row is double-fast take the flat kernel too -- ze_dfast_dict_flat; its waves zero the tables)
+        const bool flatDict = c->hasCDict && c->cdictStrat == 2 && !c->knob.noFlat;
+        const bool flat = (anyDfast && !c->hasCDict && !c->knob.noFlat) || flatDict;
+        size_t chunkMax = c->hasCDict ? 262144 : flat ? 65536 : 32768;
         if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         const size_t chunk = n < chunkMax ? n : chunkMax;
@@ -864,7 +866,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
-                HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
+                if (!flatDict) HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
                 // (the LDS area follows the batch's largest source where the caller told us -- the host-buffer API does: more frames per CU)
@@ -873,7 +875,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 static const unsigned wavesPerCU[4] = { 32, 9, 2, 1 };          // by LDS (160 KiB per CU) and the 32-wave limit
                 const size_t rounds = shape == 3 ? ZHIP_E1LDS_PER_CU : c->knob.e1LdsRounds;
                 const size_t ldsMax = c->knob.e1LdsMax >= 0 ? (size_t)c->knob.e1LdsMax : (size_t)c->numCU * wavesPerCU[shape] * rounds;
-                if (cnt <= ldsMax) {
+                if (cnt <= ldsMax && !flatDict) {
                     const dim3 g((uint32_t)cnt), b(64);
                     if (shape == 0) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<4096>, g, b, 0, stream, a);
                     else if (shape == 1) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<16384>, g, b, 0, stream, a);

@@ -242,15 +242,16 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     attach_cdict(a);
     memset(&g_elds, 0xA5, sizeof g_elds);
     bool anyDfast = false; for (int t = 2; t < 4; t++) anyDfast |= a.rows.r[t][6] == 2;
-    const bool flat = anyDfast && !g_hasCD;                 // mirrors zhip_compress_batch_device
+    const bool flatDict = g_hasCD && a.cdict && a.cdict->strat == 2;      // mirrors zhip_compress_batch_device
+    const bool flat = (anyDfast && !g_hasCD) || flatDict;
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0; e1Count = 0;
         if (flat) {
-            memset(a.flatTables, 0, (size_t)a.count * a.tableStride);
-            if (a.count <= g_e1LdsMax) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
+            memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
+            if (a.count <= g_e1LdsMax && !flatDict) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
             else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
