@@ -53,7 +53,9 @@ static inline bool zh_check_cparams(const int32_t r[7])
 static inline void zh_get_cparams(int level, uint64_t srcSizeHint, size_t dictSize, zhip_compression_parameters* out)
 {
     const bool unknown = srcSizeHint == 0;
-    const uint64_t added = unknown && dictSize > 0 ? 500 : 0;
+    // (ZSTD_getCParamRowSize, zstd.c:30820: with the source size unknown libzstd adds ZSTD_CONTENTSIZE_UNKNOWN + dictSize + 500 in 64 bits,
+    // which WRAPS to dictSize + 499 -- the row changes at dictSize 15 885 / 130 573 / 261 645, not one byte later)
+    const uint64_t added = unknown && dictSize > 0 ? 499 : 0;
     const uint64_t rSize = unknown && dictSize == 0 ? ~0ull : srcSizeHint + dictSize + added;
     const int tableID = (rSize <= 256u * 1024) + (rSize <= 128u * 1024) + (rSize <= 16u * 1024);
     int32_t r[7];

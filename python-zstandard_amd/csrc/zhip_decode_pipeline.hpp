@@ -866,6 +866,12 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;
     uint32_t op = 0, lp = 0, done = 0;
+    // The flush writes whole 16-byte units only: the last `carry` (< 16) bytes of a batch stay at the front of the assembly buffer and leave
+    // with the next batch (r03e: the byte-wise tail of every flush -- one lane, up to 15 trips of an LDS read and a byte store -- was a
+    // third of the flush phase, 157 K -> 101 K wave-cycles per frame, and made every later store of the frame unaligned). asmb[0] is the byte
+    // at absolute position ob = op - carry; every batch-relative offset below (oRel, mRel, mBeg / mEnd, a0 / b0) counts from ob. Bytes
+    // below ob are in global memory, bytes from ob on only in LDS: "far" = the whole source lies below ob.
+    uint32_t carry = 0;
     const uint32_t nbSeq = m.nbSeq;
     uint64_t qNext = lane < nbSeq ? ZP_SEQ_LD(seqs + lane) : 0;      // the next batch's sequences are requested a batch ahead
 #ifdef ZP_K3_PREFETCH
@@ -876,8 +882,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         uint32_t myLL = 0, myML = 0, myOF = 1;
         if (lane < avail) { const uint64_t q = qNext; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
-        // how many of these fit the assembly buffer
-        const uint64_t fits = zh_ballot(lane < avail && incT <= ZP_ASM_BYTES);
+        // how many of these fit the assembly buffer (behind the carried bytes)
+        const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES);
         uint32_t cnt = (uint32_t)zh_popc64(fits);          // fits is a prefix mask (incT is monotone)
         const bool big = cnt == 0;
         if (big) cnt = 1;
@@ -889,9 +895,13 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         if ((uint64_t)op + totT > cap) return ZE_DST_TOO_SMALL;
         if (op + totT > m.blockMax) return ZE_CORRUPTION;
         const uint32_t litStart = lp + incL - myLL;
-        const uint32_t oRel = incT - (myLL + myML), mRel = oRel + myLL;
-        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)op + mRel + dictSize)) return ZE_CORRUPTION;
+        const uint32_t ob = op - carry;
+        const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
+        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)ob + mRel + dictSize)) return ZE_CORRUPTION;
         if (big) {
+            if (lane < carry) dst[ob + lane] = asmb[lane];                  // what the last flush held back
+            carry = 0;
+            zd_fence();
             const uint32_t bll = zh_shfl(myLL, 0), bml = zh_shfl(myML, 0), bof = zh_shfl(myOF, 0);
             if (litRLE) zd_fill_wave(dst + op, rleByte, bll); else zd_copy_wave(dst + op, litPtr + lp, bll);
             zd_fence();
@@ -901,9 +911,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             continue;
         }
         ZD_T(P, ZP_STAGE);
-        const int32_t sAbs = (int32_t)(op + mRel) - (int32_t)myOF;
+        const int32_t sAbs = (int32_t)(ob + mRel) - (int32_t)myOF;
         const bool hasM = act && myML > 0;
-        const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)op;
+        const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)ob;
         uint32_t nearSkip = 0;                                              // bytes of a near match that precede the batch (staged with the far data)
         {
             // Everything this batch reads from global memory is requested before anything is waited for: the short literal runs and
@@ -928,8 +938,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // a near match whose source starts before the batch: that part is global memory too and is fetched here like a far
             // match (byte by byte in the dependency rounds it was a memory round trip per byte). A lane has one or the other, so
             // both go through ONE pair of piece loads / stores (r02l: K3's time is its instruction count, a pair is ~85 of ~770 per batch)
-            const bool pre = hasM && !farM && sAbs < (int32_t)op;
-            const uint32_t preLen = pre ? (uint32_t)((int32_t)op - sAbs) : 0u;
+            const bool pre = hasM && !farM && sAbs < (int32_t)ob;
+            const uint32_t preLen = pre ? (uint32_t)((int32_t)ob - sAbs) : 0u;
             nearSkip = preLen;
             const uint32_t lenMi = farM ? myML : preLen;                    // the match item staged here: the whole far match or the part before the batch
             // with a dictionary a source may start below the frame's first byte: wholly there, it is read from the dictionary's content;
@@ -999,8 +1009,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         bool pending = hasM && !farM;
         uint64_t need = 0;
         if (pending) {
-            const uint32_t a0 = sAbs > (int32_t)op ? (uint32_t)(sAbs - (int32_t)op) : 0;          // first batch byte I read
-            uint32_t b0 = (uint32_t)(sAbs + (int32_t)myML - (int32_t)op);                          // one past the last byte I read
+            const uint32_t a0 = sAbs > (int32_t)ob ? (uint32_t)(sAbs - (int32_t)ob) : 0;          // first buffer byte I read
+            uint32_t b0 = (uint32_t)(sAbs + (int32_t)myML - (int32_t)ob);                          // one past the last byte I read
             if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
             uint32_t lo = 0, hi = 0;            // lo = first j with mEnd[j] > a0 ; hi = first j with mBeg[j] >= b0
             for (uint32_t stp = 32; stp; stp >>= 1) { if (lo + stp <= 64 && L.mEnd[lo + stp - 1] <= a0) lo += stp; }
@@ -1020,18 +1030,18 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 // whole wave copies one long ready match
                 const uint32_t pf = (uint32_t)zh_ctz64(longReady);
                 const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
-                const int32_t fs = (int32_t)(op + Frel) - (int32_t)fof;
+                const int32_t fs = (int32_t)(ob + Frel) - (int32_t)fof;
                 if (fof >= 64) {
                     for (uint32_t c = 0; c < fml; c += 64) {
                         const uint32_t j = c + lane;
-                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
+                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
                         if (fof < fml) zh_sync();
                     }
                 } else {
                     uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                     for (uint32_t j = lane; j < fml; j += 64) {
                         const int32_t sp = fs + (int32_t)idx;
-                        asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
+                        asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
                         idx += adv; if (idx >= fof) idx -= fof;
                     }
                 }
@@ -1041,7 +1051,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
                 if (ready) {
                     // what is left of the match lies in the assembly buffer: source nSrc, destination nSrc + myOF, nLen bytes
-                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
+                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)ob), nDst = mRel + nearSkip;
                     if (myOF >= nLen) {
                         uint64_t rr[4];
                         zp_ld32_lds(asmb + nSrc, nLen, rr);
@@ -1078,7 +1088,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                 const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
                 if (ready) {
                     // what is left of the match lies in the assembly buffer: source nSrc, destination nSrc + myOF, nLen bytes
-                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)op), nDst = mRel + nearSkip;
+                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)ob), nDst = mRel + nearSkip;
                     if (myOF >= nLen) {
                         uint64_t rr[4];
                         zp_ld32_lds(asmb + nSrc, nLen, rr);
@@ -1105,18 +1115,18 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
                     const uint32_t pf = (uint32_t)zh_ctz64(lm);
                 // whole wave copies one long ready match
                     const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
-                    const int32_t fs = (int32_t)(op + Frel) - (int32_t)fof;
+                    const int32_t fs = (int32_t)(ob + Frel) - (int32_t)fof;
                     if (fof >= 64) {
                         for (uint32_t c = 0; c < fml; c += 64) {
                             const uint32_t j = c + lane;
-                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
+                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
                             if (fof < fml) zh_sync();
                         }
                     } else {
                         uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                         for (uint32_t j = lane; j < fml; j += 64) {
                             const int32_t sp = fs + (int32_t)idx;
-                            asmb[Frel + j] = sp >= (int32_t)op ? asmb[sp - (int32_t)op] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
+                            asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
                             idx += adv; if (idx >= fof) idx -= fof;
                         }
                     }
@@ -1145,22 +1155,29 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
         // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
         qNext = zh_opaque64(qNext);
+        const uint32_t totB = totT + carry, whole = totB & ~15u;         // bytes in the buffer; the part that leaves now
         {
-            uint8_t* out = dst + op;
-            for (uint32_t j = lane * 16; j < totT; j += 1024) {
-                if (j + 16 <= totT) {
-                    const uint32_t* s4 = (const uint32_t*)(asmb + j);
-                    ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
-                    *(ZdPack16*)(out + j) = v;
-                } else {
-                    for (uint32_t k = j; k < totT; k++) out[k] = asmb[k];
-                }
+            uint8_t* out = dst + ob;
+            for (uint32_t j = lane * 16; j < whole; j += 1024) {
+                const uint32_t* s4 = (const uint32_t*)(asmb + j);
+                ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
+                *(ZdPack16*)(out + j) = v;
             }
+        }
+        carry = totB - whole;
+        zh_sync();
+        if (carry && whole) {                                              // the tail moves to the front (one 16-byte read / write; the sync above: every flush read is done)
+            uint64_t t0 = 0, t1 = 0;
+            if (lane == 0) { t0 = zh_ld64(asmb + whole); t1 = zh_ld64(asmb + whole + 8); }
+            zh_sync();
+            if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
         }
         zh_sync();
         ZD_T(P, ZP_FLUSH);
         op += totT; lp += totL; done += cnt;
     }
+    if (lane < carry) dst[op - carry + lane] = asmb[lane];               // what the last flush held back
+    zd_fence();
     const uint32_t rest = m.litSize - lp;
     if ((uint64_t)op + rest > cap) return ZE_DST_TOO_SMALL;
     if (op + rest > m.blockMax) return ZE_CORRUPTION;

@@ -33,6 +33,8 @@ ZH_DEV uint64_t zh_ballot(bool p) { return __ballot(p); }
 ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl((int)v, (int)srcLane, 64); }
 ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }
 ZH_DEV uint32_t zh_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// lane `l`'s value to every lane, l wave-uniform: v_readlane_b32 (a scalar result -- no LDS crossbar trip as zh_shfl's ds_bpermute)
+ZH_DEV uint32_t zh_bcast(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 // lane K of the caller's quad (lanes 4q .. 4q+3), to all four: a DPP quad_perm operand, no LDS crossbar trip
 template <int K> ZH_DEV uint32_t zh_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, false); }
 // v + (v of quad lane CTRL[2r+1:2r] for lane r of the quad): one v_add_u32_dpp

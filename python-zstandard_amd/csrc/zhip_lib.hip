@@ -226,22 +226,23 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #define ZHIP_DCHUNK 65536        // frames per chunk of the decode pipeline (r02zl: 301 GB/s in one 65 536-frame chunk against 297 in two of 32 768: longer launches amortise their tails, and the two chunk slots overlap little anyway)
 #endif
 static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed DevBuf::reserve failed (ZHIP_ERR_NO_MEMORY or ZHIP_ERR_HIP)
-static thread_local size_t g_devBytes = 0;               // device bytes held by this thread's contexts (zhip_thread_memory_size)
+// (device bytes are accounted per CONTEXT -- zhip_ctx::device_bytes sums its buffers -- not in a thread-local counter: a context may be
+// destroyed, or grown, on another thread than the one that created it, and a counter that is decremented where it was never incremented
+// wraps)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int reserve(size_t n) {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
-        g_devBytes -= cap;
         p = nullptr; cap = 0;
         size_t want = n + (n >> 3) + 4096;
         if (want < n) { g_lastError = "allocation size overflow"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         const hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
-        cap = want; g_devBytes += want; return 0;
+        cap = want; return 0;
     }
-    void release() { if (p) (void)hipFree(p); g_devBytes -= cap; p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 #define ZHIP_NTIMER 9
 struct KTimer {
@@ -288,6 +289,15 @@ struct zhip_ctx {
     unsigned long long* profPipe = nullptr;
     unsigned long long* profEncode = nullptr;
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
+    size_t device_bytes() const
+    {
+        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &encWorkspace, &encMeta, &encArena,
+                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
+                               &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
+        size_t n = 0;
+        for (const DevBuf* b : all) n += b->cap;
+        return n;
+    }
 };
 
 extern "C" zhip_ctx* zhip_ctx_create(void)
@@ -982,7 +992,14 @@ extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status
 #endif
 #define ZHIP_HOST_CHUNK_ITEMS 32768u                  // most items of one pipeline chunk (the scan kernel's bound)
 #define ZHIP_PIN_MIN ((size_t)1 << 20)                // payloads below 1 MiB are plain malloc() (one-shot calls, small batches)
-#define ZHIP_PIN_POOL_KEEP ((size_t)24 << 30)         // idle pinned bytes kept for reuse; beyond that blocks are unpinned on free
+// idle pinned bytes kept for reuse; beyond that blocks are unpinned on free. 24 GiB covers a full-size batch's payloads (pinning costs more than
+// the copy it speeds up); ZHIP_PIN_POOL_KEEP_MB (read once) lowers or raises it, 0 = keep nothing (no way to trim it before)
+static size_t pin_pool_keep()
+{
+    static const size_t keep = [] { const char* e = getenv("ZHIP_PIN_POOL_KEEP_MB"); return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)24 << 30; }();
+    return keep;
+}
+#define ZHIP_PIN_POOL_KEEP pin_pool_keep()
 
 namespace {
 struct PinBlock { size_t cap; bool busy; };
@@ -1143,7 +1160,7 @@ extern "C" size_t zhip_thread_memory_size(void)
 {
     zhip_ctx* c = tls_ctx();
     if (c) (void)c->counter.reserve(64);
-    return g_devBytes;
+    return c ? c->device_bytes() : 0;
 }
 static void tls_trim(zhip_ctx* c)
 {

@@ -48,6 +48,7 @@ ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d)
     return r;
 }
 ZH_DEV uint32_t zh_first(uint32_t v) { return zh_shfl(v, 0); }
+ZH_DEV uint32_t zh_bcast(uint32_t v, uint32_t l) { return zh_shfl(v, l); }
 template <int K> ZH_DEV uint32_t zh_quad(uint32_t v) { return zh_shfl(v, (zhemu::lane & ~3u) | (uint32_t)K); }
 template <int CTRL> ZH_DEV uint32_t zh_quad_add(uint32_t acc, uint32_t v) { return acc + zh_shfl(v, (zhemu::lane & ~3u) | ((CTRL >> (2 * (zhemu::lane & 3))) & 3)); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return __sync_fetch_and_add(p, 1u); }

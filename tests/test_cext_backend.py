@@ -202,7 +202,8 @@ def test_compression_params_object_and_conflicts(cext, ref):
                         write_dict_id=None, threads=0)
 
     for level in (-5, 1, 3, 4, 7, 19, 22):
-        for src, dct in ((0, 0), (1000, 0), (16384, 0), (131072, 0), (131073, 0), (1 << 20, 0), (0, 112640), (4096, 112640)):
+        for src, dct in ((0, 0), (1000, 0), (16384, 0), (131072, 0), (131073, 0), (1 << 20, 0), (0, 112640), (4096, 112640),
+                         (0, 15884), (0, 15885), (0, 15886), (0, 130572), (0, 130573), (0, 130574), (0, 261644), (0, 261645), (0, 261646)):      # row boundaries with the source size unknown
             want = ref.lib.ZSTD_getCParams(level, src, dct)
             got = P.from_level(level, source_size=src, dict_size=dct)
             assert (got.window_log, got.chain_log, got.hash_log, got.search_log, got.min_match, got.target_length, got.strategy) == \
