@@ -1,5 +1,5 @@
 #!/bin/sh
-# builds kernel variants next to the product library, for A/B measurement on the GPU with ZHIP_LIB=<path> (tests/runs/run_r02*.sh):
+# builds kernel variants next to the product library, for A/B measurement on the GPU with ZHIP_LIB=<path> (profiles/runs/run_r02*.sh):
 #   libzstd_hip_k2l{30,15,7}.so   -DZP_K2_LANES=n     K2: n frames per wave -> 2 / 4 / 8 one-wave workgroups per CU instead of 1   (r02c: all slower)
 #   libzstd_hip_huf{16,4}.so      -DZP_HUF_FRAMES=n   K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
 #   libzstd_hip_k3d{4,2}.so       -DZP_K3D_MINWAVES=n K3's dictionary instantiation with 4 / 2 waves per SIMD instead of 3 (r02y: 89 / 111 against 113 GB/s)

@@ -833,6 +833,9 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 
 // DICT = false: no dictionary in the context -- every dictionary term folds away (K3 sits at its 128-register cap: carrying the
 // dictionary's pointer and size through the dictionary-less kernel spilled 200 bytes per lane and made it 2.6 x slower, r02x)
+#ifndef ZP_LIT_SHORT
+#define ZP_LIT_SHORT ZD_COOP_LEN   // literal runs up to this long are copied by their own lane (32: four 8-byte pieces; 16: two -- 4 VGPRs less; longer runs go to the units)
+#endif
 #ifndef ZP_K3_NT
 #define ZP_K3_NT 0              // bit 0: sequences and decoded literals are read with streaming (nt) loads; bit 1: far-match sources too (A/B, r03b)
 #endif
@@ -890,7 +893,9 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         qNext = done + cnt + lane < nbSeq ? ZP_SEQ_LD(seqs + done + cnt + lane) : 0;
         const bool act = lane < cnt;
         if (!act) { myLL = 0; myML = 0; myOF = 1; }
-        const uint32_t totL = zh_shfl(incL, cnt - 1), totT = zh_shfl(incT, cnt - 1);
+        // (wave-uniform lane indices: v_readlane into SGPRs -- written as shuffles these totals, and op / lp / carry computed from them, lived in
+        // VGPRs of a kernel that sits at its 128-register cap: with the carry the kernel spilled into its batch loop, r03f)
+        const uint32_t totL = zh_bcast(incL, cnt - 1), totT = zh_bcast(incT, cnt - 1);
         if (lp + totL > m.litSize) return ZE_CORRUPTION;
         if ((uint64_t)op + totT > cap) return ZE_DST_TOO_SMALL;
         if (op + totT > m.blockMax) return ZE_CORRUPTION;
@@ -902,7 +907,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             if (lane < carry) dst[ob + lane] = asmb[lane];                  // what the last flush held back
             carry = 0;
             zd_fence();
-            const uint32_t bll = zh_shfl(myLL, 0), bml = zh_shfl(myML, 0), bof = zh_shfl(myOF, 0);
+            const uint32_t bll = zh_bcast(myLL, 0), bml = zh_bcast(myML, 0), bof = zh_bcast(myOF, 0);
             if (litRLE) zd_fill_wave(dst + op, rleByte, bll); else zd_copy_wave(dst + op, litPtr + lp, bll);
             zd_fence();
             zd_match_wave(dst, dictEnd, op + bll, bof, bml);
@@ -923,7 +928,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // dealt out to the lanes -- a unit finds its item by a binary search over the unit prefix sums -- and the first 64 units'
             // loads fly together with the short ones.
             uint64_t rl[4], rm[4];
-            const bool shortL = act && myLL > 0 && myLL <= ZD_COOP_LEN;
+            const bool shortL = act && myLL > 0 && myLL <= ZP_LIT_SHORT;
 #ifndef ZP_K3_NO_GLD
             // the same economy on the global side where reading past the item cannot leave mapped memory: decoded literals live in our own
             // arena (256 bytes of slack per frame); a match source at least 32 bytes below the end of the frame's output slot stays inside it.
@@ -931,7 +936,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             const bool arenaLit = m.litMode != 0;                                   // (frame-uniform)
             if (arenaLit && !litRLE) {
                 const uint8_t* q = litPtr + (shortL ? litStart : 0u);
-                rl[0] = ZP_LIT_LD64(q); rl[1] = ZP_LIT_LD64(q + 8); rl[2] = ZP_LIT_LD64(q + 16); rl[3] = ZP_LIT_LD64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
+                rl[0] = ZP_LIT_LD64(q); rl[3] = ZP_LIT_LD64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
+                if (ZP_LIT_SHORT > 16) { rl[1] = ZP_LIT_LD64(q + 8); rl[2] = ZP_LIT_LD64(q + 16); } else { rl[1] = 0; rl[2] = 0; }
             } else
 #endif
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
@@ -958,10 +964,10 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             } else
 #endif
             if (shortM) zd_ld32(mSrc, lenMi, rm);
-            const bool longL = act && myLL > ZD_COOP_LEN && !litRLE, longM = (farM || pre) && !shortM && !strad;
+            const bool longL = act && myLL > ZP_LIT_SHORT && !litRLE, longM = (farM || pre) && !shortM && !strad;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
             const uint32_t ue = zh_scan_add(uL + uM);
-            const uint32_t U = zh_shfl(ue, 63);
+            const uint32_t U = zh_bcast(ue, 63);
             zh_v16 uv; uv.lo = 0; uv.hi = 0; uint8_t* udp = asmb;
             if (U) {
                 L.uEnd[lane] = (uint16_t)ue; L.uLit[lane] = (uint16_t)uL;
@@ -994,7 +1000,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         pfSink |= pfWord;
 #endif
         if (litRLE) {
-            for (uint64_t mk = zh_ballot(act && myLL > ZD_COOP_LEN); mk; mk &= mk - 1) {
+            for (uint64_t mk = zh_ballot(act && myLL > ZP_LIT_SHORT); mk; mk &= mk - 1) {
                 const uint32_t l = (uint32_t)zh_ctz64(mk);
                 const uint32_t d = zh_shfl(oRel, l), n = zh_shfl(myLL, l);
                 for (uint32_t j = lane; j < n; j += 64) asmb[d + j] = (uint8_t)rleByte;
@@ -1205,14 +1211,28 @@ template <bool DICT>
 ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
 {
     const uint32_t lane = zh_lane();
+    // Frames are taken in index order. -DZP_K3_SORTED_ORDER takes them in K2's work order instead (by decreasing sequence count, then the frames
+    // without sequences by index) so that the launch's tail is made of short frames -- MEASURED SLOWER (r03f: 12.95 against 12.18 ms per 65 536
+    // frames): with every wave on a many-sequence frame at the same time the far-match gathers of 4 096 waves peak together (stage phase 758 K ->
+    // 861 K wave-cycles per frame); the corpus' own mix of heavy and light frames spreads them.
+#ifndef ZP_K3_SORTED_ORDER
+    const uint32_t ordered = 0;
+#else
+    const uint32_t ordered = a.counters[1];
+#endif
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 2, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
-        const uint32_t i = zh_first(L.misc[7]);
+        const uint32_t k = zh_first(L.misc[7]);
         zh_sync();
-        if (i >= a.count) break;
+        if (k >= ordered + a.count) break;
+        const uint32_t i = k < ordered ? a.order[k] : k - ordered;
+#ifndef ZP_K3_SORTED_ORDER
         if (a.meta[i].path != 1) continue;
+#else
+        if (a.meta[i].path != 1 || (k >= ordered && a.meta[i].nbSeq != 0)) continue;
+#endif
         uint32_t produced = 0;
         ZdProf P; P.on = a.prof != nullptr;
         if (P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }

@@ -38,6 +38,9 @@ ZH_DEV uint32_t zh_bcast(uint32_t v, uint32_t l) { return (uint32_t)__builtin_am
 // lane K of the caller's quad (lanes 4q .. 4q+3), to all four: a DPP quad_perm operand, no LDS crossbar trip
 template <int K> ZH_DEV uint32_t zh_quad(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, false); }
 // v + (v of quad lane CTRL[2r+1:2r] for lane r of the quad): one v_add_u32_dpp
+// (r03f: written as update_dpp(0, v, CTRL, 0xf, 0xf, bound_ctrl) LLVM's DPP combiner folds 7 of the 32 quad moves of K2's unrolled body into their
+// consumers -- 320 -> 313 instructions -- but the K2 built that way reports corrupt streams on the MI355X where the emulator and this form
+// agree with libzstd: not adopted)
 template <int CTRL> ZH_DEV uint32_t zh_quad_add(uint32_t acc, uint32_t v) { return acc + (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false); }
 ZH_DEV uint32_t zh_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 ZH_DEV uint32_t zh_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -22,7 +22,7 @@ def rows_of(sub, pattern):
 
 
 traffic = collections.defaultdict(float)
-for direction in ("decode", "compress"):
+for direction in ("decode", "compress", "dict"):              # dict: kernel trace only (bench.py --config dict, 262 144 x 4 KiB)
     # kernel trace -> durations
     dur = collections.defaultdict(list)
     for r in rows_of(direction + "_kt", "*kernel_trace.csv"):

@@ -1,12 +1,13 @@
-# Profile collection for profiles/ (run on the GPU box:  gpurun --timeout 1500 -- 'TAG=r02 sh tests/run_profiles.sh'): one rocprofv3 pass
+# Profile collection for profiles/ (run on the GPU box:  gpurun --timeout 1500 -- 'TAG=r03 sh tests/run_profiles.sh'): one rocprofv3 pass
 # per purpose as the guide prescribes -- kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ counters -- for both directions, each over
-# 32 768 frames (one chunk per launch), then tests/prof_traffic.py reduces them (per-kernel summaries + traffic.json) under
-# gpurun_out/summary/; copy those into profiles/.
+# FRAMES frames (default 65 536 = bench.py's default = ONE chunk per launch of every kernel), then tests/prof_traffic.py reduces them
+# (per-kernel summaries + traffic.json) under gpurun_out/summary/; copy those into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
+FRAMES=${FRAMES:-65536}
 P=gpurun_out/prof; rm -rf $P gpurun_out/summary; mkdir -p $P
-B="python bench.py --frames 32768 --warmup 1 --no-cpu-baseline"
+B="python bench.py --frames $FRAMES --warmup 1 --no-cpu-baseline --no-extra"
 run() { d=$P/$1; shift; mkdir -p $d; timeout 500 rocprofv3 "$@" > $d/bench.json 2> $d/err.log; echo "$d rc $?"; }
 run decode_kt --kernel-trace --stats --output-format csv -d $P/decode_kt -- $B --steps 3 --compress-frames 0
 run decode_fetch --pmc FETCH_SIZE --output-format csv -d $P/decode_fetch -- $B --steps 1 --compress-frames 0
@@ -16,7 +17,8 @@ run decode_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLE
 run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- $B --steps 2 --config compress
 run compress_fetch --pmc FETCH_SIZE --output-format csv -d $P/compress_fetch -- $B --steps 1 --warmup 0 --config compress
 run compress_write --pmc WRITE_SIZE --output-format csv -d $P/compress_write -- $B --steps 1 --warmup 0 --config compress
-python tests/prof_traffic.py $P $TAG 32768
-for d in decode_kt compress_kt; do cp $P/$d/bench.json gpurun_out/summary/${TAG}_bench_under_rocprof_${d%_kt}_32768.json; f=$(find $P/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" > gpurun_out/summary/${TAG}_${d}_kernel_stats.csv; done
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/dict_kt -- python bench.py --config dict --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/dict_kt.err; echo "dict_kt rc $?"
+python tests/prof_traffic.py $P $TAG $FRAMES
+for d in decode_kt compress_kt; do cp $P/$d/bench.json gpurun_out/summary/${TAG}_bench_under_rocprof_${d%_kt}_$FRAMES.json; f=$(find $P/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" > gpurun_out/summary/${TAG}_${d}_kernel_stats.csv; done
 rm -rf $P
 ls -la gpurun_out/summary
