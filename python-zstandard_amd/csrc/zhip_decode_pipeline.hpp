@@ -834,7 +834,15 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 // DICT = false: no dictionary in the context -- every dictionary term folds away (K3 sits at its 128-register cap: carrying the
 // dictionary's pointer and size through the dictionary-less kernel spilled 200 bytes per lane and made it 2.6 x slower, r02x)
 #ifndef ZP_LIT_SHORT
-#define ZP_LIT_SHORT ZD_COOP_LEN   // literal runs up to this long are copied by their own lane (32: four 8-byte pieces; 16: two -- 4 VGPRs less; longer runs go to the units)
+// K3's registers decide how many waves a SIMD holds, and K3 is short of waves (3 -> 4 per SIMD was x 1.2 in round 2). Items copied by their own
+// lane sit in registers between the batch's loads and its LDS stores: 32-byte items = four 8-byte pieces each for the literal run and the far
+// match = 16 VGPRs; at 16 bytes (first + last piece) it is 8, longer items ride the 16-byte units, whose pass costs the same for 3 or 30 units.
+// Together with the wave-uniform totals in SGPRs that is 128 (+ spills) -> 96 VGPRs = FIVE waves per SIMD: 12.72 -> 10.76 ms per 65 536 frames
+// (r03g; six waves would need 80: 64 bytes of spills in the batch loop, 13.6 ms).
+#define ZP_LIT_SHORT 16            // literal runs up to this long are copied by their own lane, longer ones as units
+#endif
+#ifndef ZP_FAR_SHORT
+#define ZP_FAR_SHORT 16            // the same for far matches / pre-batch parts staged from global memory
 #endif
 #ifndef ZP_K3_NT
 #define ZP_K3_NT 0              // bit 0: sequences and decoded literals are read with streaming (nt) loads; bit 1: far-match sources too (A/B, r03b)
@@ -952,7 +960,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // the rare item that straddles the boundary is copied byte by byte by the whole wave, after the others
             const bool strad = DICT && (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
             const uint8_t* const mSrc = !DICT || sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
-            const bool shortM = (farM || pre) && lenMi <= ZD_COOP_LEN && !strad;
+            const bool shortM = (farM || pre) && lenMi <= ZP_FAR_SHORT && !strad;
 #ifndef ZP_K3_NO_GLD
             if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
 #ifdef ZP_K3_DIAG_NOFAR          // DIAGNOSTIC ONLY (wrong output): far matches read the frame's first bytes -- what K3 costs without its random gathers
@@ -960,7 +968,8 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #else
                 const uint8_t* q = shortM ? mSrc : dst;
 #endif
-                rm[0] = ZP_FAR_LD64(q); rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
+                rm[0] = ZP_FAR_LD64(q); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
+                if (ZP_FAR_SHORT > 16) { rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); } else { rm[1] = 0; rm[2] = 0; }
             } else
 #endif
             if (shortM) zd_ld32(mSrc, lenMi, rm);

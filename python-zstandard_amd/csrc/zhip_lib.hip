@@ -54,7 +54,7 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)    
     zp_seq_body(a, L);
 }
 #ifndef ZP_K3_MINWAVES
-#define ZP_K3_MINWAVES 4
+#define ZP_K3_MINWAVES 5         // 96 VGPRs (zhip_decode_pipeline.hpp: ZP_LIT_SHORT / ZP_FAR_SHORT); r03g
 #endif
 ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
