@@ -888,7 +888,11 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #ifdef ZP_K3_PREFETCH
     uint32_t pfWord = 0, pfSink = 0;                      // EXPERIMENTAL: one byte of the next batch's far-match source per lane, touched a batch ahead
 #endif
+    const uint32_t lane0 = lane;
     while (done < nbSeq) {
+#ifdef ZP_K3_LANE_OPAQUE
+        const uint32_t lane = zh_opaque(lane0);          // nothing derived from the lane id is hoisted out of the batch loop (registers: r03k)
+#endif
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
         if (lane < avail) { const uint64_t q = qNext; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }

@@ -532,3 +532,47 @@ def test_precomputed_dictionary_parameters_through_the_kernels(emu, ref, corpus)
     finally:
         emu.set_cparams()
     assert differs > 20          # the precomputed level really changes the frames
+
+
+def test_flat_dictionary_search_bit_exact(emu, ref, corpus):
+    """ze_dfast_dict_flat (round 3): the attached-dictionary double-fast search in the flat kernel's form -- one lane per document, unconditional
+    load rounds, tables zeroed by the wave -- against libzstd for the configs[3] dictionary (112 640 bytes: 384 KiB of tagged tables, 110 KiB of
+    content), the 16 KiB one, and raw-content dictionaries; documents, sources that straddle into / quote from deep inside the content, both
+    sides of the 16 KiB attach cutoff, tiny and empty sources (ZSTD_compressBlock_doubleFast_dictMatchState_generic, zstd.c:31262)"""
+    import numpy as np
+    from tests.corpus import Corpus
+    rng = np.random.default_rng(31)
+    here = os.path.dirname(os.path.abspath(__file__))
+    big = open(os.path.join(here, "golden", "dict_json4k.bin"), "rb").read()
+    small = open(os.path.join(here, "golden", "dict_json4k_16k.bin"), "rb").read()
+    docs = Corpus(frame_size=4096).json_docs(0, 40).numpy()
+    raws = [docs[i].tobytes() for i in range(40)]
+    raws += [big[-3000:] + raws[0][:1000], big[5000:6500] + raws[1][:2000] + big[60000:61000], big[-100:], b"", b"x", big[-16384:], big[-16385:] + b"!",
+             (big[-700:] * 30)[:16384], raws[5] * 4, raws[6] * 3 + b"zz"]
+    raws += [corpus.frame_bytes(i)[: int(rng.integers(40, 16385))] for i in range(8)]
+    raws += [bytes(rng.integers(0, 4, int(rng.integers(64, 9000)), dtype=np.uint8)) for _ in range(3)]
+    for dd in (big, small, corpus.frame_bytes(600)[:6000], corpus.frame_bytes(601)[:100000]):
+        want = [ref.compress(r, level=3, dict_data=dd) for r in raws]
+        before = emu.lib.emu_stat(15)
+        outs, st = emu.compress_batch(raws, level=3, flags=5, pipeline=True, dict_data=dd)
+        assert not any(st) and outs == want
+        assert emu.lib.emu_stat(15) - before >= 50          # the flat kernel searched them (sources under 64 bytes go to the lane-serial kernel)
+
+
+def test_decode_pipeline_long_items_and_carried_flush(emu, ref):
+    """K3's paths for items above its own-lane threshold (16-byte units dealt out to the lanes), overlapping matches, and the flush that carries a
+    batch's last < 16 bytes over to the next batch: frames made of long literal runs, long far matches, byte runs and short pieces, levels 1 - 19"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    raws = []
+    for t in range(6):
+        parts = []; pool = [rng.bytes(int(rng.integers(40, 5000))) for _ in range(6)]
+        while sum(map(len, parts)) < 120000:
+            k = int(rng.integers(0, 4))
+            parts.append(rng.bytes(int(rng.integers(1, 3000))) if k == 0 else pool[int(rng.integers(0, 6))] if k == 1
+                         else bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 2500)) if k == 2 else pool[int(rng.integers(0, 6))][: int(rng.integers(1, 60))])
+        raws.append(b"".join(parts)[: int(rng.integers(100000, 131073))])
+    for lv in (1, 3, 19):
+        frames = [ref.compress(r, level=lv) for r in raws]
+        outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws])
+        assert not any(st) and outs == raws and nfb == 0
