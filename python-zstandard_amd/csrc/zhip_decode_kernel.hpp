@@ -500,7 +500,8 @@ ZH_DEVFN bool zd_huf_stream(const uint16_t* huf, uint32_t log, const uint8_t* sr
 // Literals section (RFC 8878 3.1.1.3.1). All lanes call. Returns bytes consumed or -err.
 // `defer` (pipeline K1 only): instead of decoding Huffman streams here, hand the table and the stream location to K1b.
 struct ZdLitDefer { uint16_t* table; uint32_t maxLog; uint32_t taken, log, four, streamBytes; const uint8_t* streams;
-                    const uint16_t* prevTable; uint32_t prevLog; };   // prevTable: the "previous" table of a treeless block, ready-made (a dictionary's)
+                    const uint16_t* prevTable; uint32_t prevLog;      // prevTable: the "previous" table of a treeless block, ready-made (a dictionary's)
+                    uint32_t shared, shareOK; };                      // shareOK: the caller reads prevTable where it lies (no copy into `table`); shared: that happened
 ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t srcSize, uint8_t* lit, uint32_t blockMax, ZdProf& P,
                          ZdLitDefer* defer = nullptr)
 {
@@ -548,8 +549,11 @@ ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t src
             if (left < 10) return -ZE_CORRUPTION;
             if (3 * ((regen + 3) / 4) > regen) return -ZE_CORRUPTION;
         }
-        const uint64_t* t8 = (const uint64_t*)defer->prevTable; uint64_t* g8 = (uint64_t*)defer->table;
-        for (uint32_t i = lane; i < (1u << lgp) / 4 + ((1u << lgp) < 4 ? 1u : 0u); i += 64) g8[i] = t8[i];
+        if (defer->shareOK) defer->shared = 1;
+        else {
+            const uint64_t* t8 = (const uint64_t*)defer->prevTable; uint64_t* g8 = (uint64_t*)defer->table;
+            for (uint32_t i = lane; i < (1u << lgp) / 4 + ((1u << lgp) < 4 ? 1u : 0u); i += 64) g8[i] = t8[i];
+        }
         defer->taken = 1; defer->log = (uint32_t)lgp; defer->four = four; defer->streamBytes = left; defer->streams = p;
         ZD_T(P, ZP_HUFTAB);
         st.litPtr = lit; st.litSize = regen;

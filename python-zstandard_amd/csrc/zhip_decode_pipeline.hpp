@@ -22,6 +22,26 @@
 #pragma once
 #include "zhip_decode_kernel.hpp"
 
+// LDS cells of the table builder (base | nbBits << 10 | ... | symbol << 19) -> K2's 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
+ZH_DEV void zp_pack_fse(ZdLDS& L, uint32_t* T, uint32_t llLog, uint32_t ofLog, uint32_t mlLog)
+{
+    const uint32_t lane = zh_lane();
+    for (uint32_t u = lane; u < ZP_FSE_CELLS / 2; u += 64) {
+        const uint32_t lg = u < 256 ? llLog : u < 512 ? mlLog : ofLog;
+        const uint32_t local = (2 * u) & (u < 512 ? 511u : 255u);
+        uint32_t pair = 0;
+        for (uint32_t k = 0; k < 2; k++) {
+            uint32_t cell = 0;
+            if (local + k < (1u << lg)) {
+                const uint32_t e = L.fse[2 * u + k];
+                cell = ((e >> 19) << 10) | (((e & 1023) + (1u << lg)) >> ((e >> 10) & 15));
+            }
+            pair |= cell << (16 * k);
+        }
+        T[u] = pair;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ K1
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
@@ -115,7 +135,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
             ZD_T(P, ZP_HEADER);
             ZdLitDefer df; df.table = a.hufTables + (size_t)i * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
-            df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = nullptr; df.prevLog = 0;
+            df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = nullptr; df.prevLog = 0; df.shared = 0; df.shareOK = 1;
             const ZhipDictEntropy* const de = a.dictEntropy;
             if (de) {                                                       // a dictionary with entropy tables: they are the block's "previous" tables
                 st.hufCount = de->hufCount;
@@ -125,7 +145,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
             if (r < 0) { err = -r; break; }
             m.litSize = st.litSize;
-            if (df.taken) { m.litMode = 3u | (df.log << 8) | (df.four << 16); m.litOff = (uint32_t)(df.streams - src); m.produced = df.streamBytes; }
+            if (df.taken) { m.litMode = 3u | (df.log << 8) | (df.four << 16) | (df.shared ? ZP_LIT_SHARED : 0u); m.litOff = (uint32_t)(df.streams - src); m.produced = df.streamBytes; }
             else if (st.litRLE) { m.litMode = 2; m.litOff = st.rleByte; }
             else if (st.litPtr == lit) { m.litMode = 1; m.litOff = 0; }
             else { m.litMode = 0; m.litOff = (uint32_t)(st.litPtr - src); }
@@ -144,6 +164,13 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                     if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
                     const uint32_t modes = *sp++;
                     if (modes & 3) { err = ZE_CORRUPTION; break; }
+                    // every table "repeat" in a dictionary frame: the tables ARE the dictionary's, ready-made in K2's form (ZhipDictTables.fseK2):
+                    // nothing to build, nothing to write -- K2 copies them from there
+                    const bool allShared = de && (modes >> 2) == 0x3F;
+                    if (allShared) {
+                        st.llLog = de->llLog; st.ofLog = de->ofLog; st.mlLog = de->mlLog;
+                        if (sp >= send) { err = ZE_CORRUPTION; break; }
+                    } else {
                     if (de) {                                               // "repeat" takes the dictionary's table: drop it into its LDS place
                         zh_sync();
                         const uint32_t* T = a.dictTables->fse;
@@ -159,21 +186,9 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                     zh_sync();
                     // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
                     uint32_t* const T = (uint32_t*)(a.fseTables + (size_t)i * ZP_FSE_CELLS);
-                    for (uint32_t u = lane; u < ZP_FSE_CELLS / 2; u += 64) {
-                        const uint32_t lg = u < 256 ? st.llLog : u < 512 ? st.mlLog : st.ofLog;
-                        const uint32_t local = (2 * u) & (u < 512 ? 511u : 255u);
-                        uint32_t pair = 0;
-                        for (uint32_t k = 0; k < 2; k++) {
-                            uint32_t cell = 0;
-                            if (local + k < (1u << lg)) {
-                                const uint32_t e = L.fse[2 * u + k];
-                                cell = ((e >> 19) << 10) | (((e & 1023) + (1u << lg)) >> ((e >> 10) & 15));
-                            }
-                            pair |= cell << (16 * k);
-                        }
-                        T[u] = pair;
+                    zp_pack_fse(L, T, st.llLog, st.ofLog, st.mlLog);
                     }
-                    m.logs = st.llLog | (st.ofLog << 8) | (st.mlLog << 16);
+                    m.logs = st.llLog | (st.ofLog << 8) | (st.mlLog << 16) | (allShared ? ZP_LOGS_SHARED : 0u);
                 }
                 m.seqOff = (uint32_t)(sp - src); m.seqEnd = pos + bs;
                 ZD_T(P, ZP_SEQTAB);
@@ -199,7 +214,9 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (m.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
         }
-        zd_fence();
+#ifdef ZHIP_EMU
+        zd_fence();              // (orders the emulator's free-running lanes; on the device the wave is in order and what K1 writes is read by LATER kernels --
+#endif                           //  a fence here only made every frame wait out its own stores' round trip: ~2 us of the ~40 a 4 KiB dictionary frame takes, r03l)
         if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + q, P.acc[q]); }
     }
 }
@@ -231,6 +248,7 @@ ZH_DEVFN void zp_dict_tables_body(const ZhipDictEntropy* de, ZhipDictTables* out
     if (zd_build_fse(L, L.fse + ZD_FSE_ML, de->mlMax, de->mlLog, ZD_KIND_ML) < 0) st = ZE_DICT_CORRUPTED;
     zh_sync();
     for (uint32_t k = lane; k < 1280; k += 64) out->fse[k] = L.fse[k];
+    zp_pack_fse(L, (uint32_t*)out->fseK2, de->llLog <= 9 ? de->llLog : 0, de->ofLog <= 8 ? de->ofLog : 0, de->mlLog <= 9 ? de->mlLog : 0);
     if (lane == 0) out->status = st;
     zd_fence();
 }
@@ -417,7 +435,8 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
         for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
             const uint32_t fj = zh_shfl(i, 4 * j);
             if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
-            const ZpVec16* src = (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
+            const bool sharedT = (zh_shfl(mode, 4 * j) & ZP_LIT_SHARED) != 0;      // a treeless block of a dictionary frame: the dictionary's own table
+            const ZpVec16* src = sharedT ? (const ZpVec16*)a.dictTables->huf : (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
             const ZpVec16 r0 = src[lane], r1 = src[lane + 64], r2 = src[lane + 128], r3 = src[lane + 192];
             // eight 2-byte cells (symbol | length << 8) per 16 bytes -> eight symbol bytes + eight length nibbles
 #define ZP_SPLIT(v, q) do { const uint32_t w0_ = (v).a, w1_ = (v).b, w2_ = (v).c, w3_ = (v).d; \
@@ -567,12 +586,14 @@ ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
         const uint32_t k = g * ZP_K2_LANES + lane;
         const bool active = lane < ZP_K2_LANES && k < total;
         const uint32_t i = active ? a.order[k] : 0xFFFFFFFFu;
+        const uint32_t logs0 = active ? a.meta[i].logs : 0u;
         zh_sync();
         // the group's tables, HBM -> LDS, one frame at a time with coalesced dword loads (K1 built them)
         for (uint32_t j = 0; j < ZP_K2_LANES; j++) {
             const uint32_t fj = zh_shfl(i, j);
             if (fj == 0xFFFFFFFFu) break;                                  // active lanes are a prefix
-            const uint32_t* src = (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
+            const bool sharedT = (zh_shfl(logs0, j) & ZP_LOGS_SHARED) != 0;
+            const uint32_t* src = sharedT ? (const uint32_t*)a.dictTables->fseK2 : (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
             uint32_t* dstw = (uint32_t*)(L.tab + (size_t)j * ZP_K2_STRIDE);
             uint32_t r[ZP_FSE_CELLS / 128];                                 // all loads in flight before the first LDS write
 #pragma unroll
@@ -664,11 +685,13 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         const uint32_t k = g * ZQ_FRAMES + slot;
         const bool active = slot < ZQ_FRAMES && k < total;
         const uint32_t i = active ? a.order[k] : 0xFFFFFFFFu;
+        const uint32_t logs0 = active ? a.meta[i].logs : 0u;
         zh_sync();
         for (uint32_t j = 0; j < ZQ_FRAMES; j++) {                                 // the group's tables, HBM -> LDS (K1 built them)
             const uint32_t fj = zh_shfl(i, 4 * j);
             if (fj == 0xFFFFFFFFu) break;                                          // active quads are a prefix
-            const uint32_t* src = (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
+            const bool sharedT = (zh_shfl(logs0, 4 * j) & ZP_LOGS_SHARED) != 0;       // every table "repeat": the dictionary's, one copy for all frames
+            const uint32_t* src = sharedT ? (const uint32_t*)a.dictTables->fseK2 : (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
             uint32_t* dstw = (uint32_t*)(L.tab + (size_t)j * ZP_K2_STRIDE);
             uint32_t r[ZP_FSE_CELLS / 128];
 #pragma unroll

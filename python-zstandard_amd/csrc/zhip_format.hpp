@@ -40,7 +40,12 @@ struct ZhipDictEntropy {
 // What the decode pipeline takes from a dictionary's entropy section, built ONCE per dictionary (zhip_dict_tables_kernel): the three
 // tANS decoding tables in the builder's LDS cell format (K1 drops them into its LDS when a frame's table mode is "repeat") and the
 // Huffman decoding table in K1b's cell format (copied into the frame's table slot when its literals are "treeless").
-struct ZhipDictTables { uint32_t fse[1280]; uint16_t huf[4096]; uint32_t hufLog; int32_t status; };
+// fseK2: the three tables in K2's 2-byte cell form (symbol << 10 | x), laid out like a frame's slot of the table arena. A frame whose
+// three table modes are all "repeat" (every frame of BASELINE configs[3]: 262 144 documents, ONE set of tables) has no slot written at
+// all: K2 copies its LDS tables from here, K1b its Huffman table from `huf` (r03k).
+struct ZhipDictTables { uint32_t fse[1280]; uint16_t huf[4096]; uint32_t hufLog; int32_t status; uint16_t fseK2[2 * 1280]; };
+#define ZP_LOGS_SHARED (1u << 24)       // ZdMeta.logs: the sequence tables are the dictionary's (ZhipDictTables.fseK2), the frame's arena slot is unused
+#define ZP_LIT_SHARED (1u << 24)        // ZdMeta.litMode: the Huffman table is the dictionary's (ZhipDictTables.huf)
 
 struct ZhipDecodeArgs {
     const uint8_t* src;             // all frames
