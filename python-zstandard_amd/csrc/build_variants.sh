@@ -11,6 +11,9 @@
 #   libzstd_hip_pf.so             -DZP_K3_PREFETCH    K3: the next batch's far-match source lines touched a batch ahead
 #   libzstd_hip_asm2k.so          -DZP_ASM_BYTES=2048 K3: 2 KiB batch assembly buffer (3.7 KiB of LDS per wave instead of 5.7)
 #   libzstd_hip_co{36,40,44,48}.so  asm2k + -DZP_K2_LANES=n: a K2 wave of n frames and sixteen (fourteen, ...) K3 waves fit one CU together
+# round 3 (profiles/r03*): -DZP_K3_MINWAVES=4|6 (default 5 = 96 VGPRs), -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32 (own-lane items up to 32 bytes: the round-2 shape, 113 VGPRs),
+#   -DZP_K3_SORTED_ORDER (K3 takes frames in K2's order: slower), -DZP_K3_NT=1|3 (streaming loads: no gain / slower), -DZP_K3_DIAG_NOFAR (diagnostic, wrong bytes),
+#   -DZQ_FRAMES=10..14 -DZP_ASM_BYTES=2048 [-DZP_K2_PRIO=3] with ZHIP_SPLIT=1 (co-resident K2 + K3: slower), -DZP_HUF_FRAMES=10|12|16 (K1b shapes: unchanged)
 # All are emulator-verified (tests/test_emu_kernels.py: test_decode_shape_variants_stay_correct, test_experimental_kernel_variants_stay_correct).
 # usage: build_variants.sh [name ...]   (no names: all)
 set -e
