@@ -882,7 +882,10 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 #else
 #define ZP_FAR_LD64(p) zh_ld64(p)
 #endif
-template <bool DICT>
+// PROF: the phase timers (ZHIP_PROF=1) are a SEPARATE instantiation. As a run-time flag their eleven 64-bit accumulators lived in VGPRs of the
+// production kernel (its 100 SGPRs are taken): 97 -> 77 VGPRs without them, i.e. a sixth wave per SIMD (r03n)
+#define ZD_TP(P, i) do { if (PROF) ZD_T(P, i); } while (0)
+template <bool DICT, bool PROF>
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
@@ -950,7 +953,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             op += totT; lp += totL; done += 1;
             continue;
         }
-        ZD_T(P, ZP_STAGE);
+        ZD_TP(P, ZP_STAGE);
         const int32_t sAbs = (int32_t)(ob + mRel) - (int32_t)myOF;
         const bool hasM = act && myML > 0;
         const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)ob;
@@ -1047,7 +1050,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         // batch-relative match extents), so the number of rounds is the dependency depth, not the batch length.
         L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
         zh_sync();
-        ZD_T(P, ZP_EXEC1);
+        ZD_TP(P, ZP_EXEC1);
         bool pending = hasM && !farM;
         uint64_t need = 0;
         if (pending) {
@@ -1181,7 +1184,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             zh_sync();
         }
 #endif
-        ZD_T(P, ZP_EXEC2);
+        ZD_TP(P, ZP_EXEC2);
 #ifdef ZP_K3_PREFETCH
         {   // the next batch's far matches read output written long ago (HBM / MALL by now): touch their first line now, a batch ahead,
             // so that the staging loads of the next batch find it in L2. Layout of the next batch as its own scan will compute it,
@@ -1215,7 +1218,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
         }
         zh_sync();
-        ZD_T(P, ZP_FLUSH);
+        ZD_TP(P, ZP_FLUSH);
         op += totT; lp += totL; done += cnt;
     }
     if (lane < carry) dst[op - carry + lane] = asmb[lane];               // what the last flush held back
@@ -1243,7 +1246,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     return 0;
 }
 
-template <bool DICT>
+template <bool DICT, bool PROF>
 ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -1270,10 +1273,10 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
         if (a.meta[i].path != 1 || (k >= ordered && a.meta[i].nbSeq != 0)) continue;
 #endif
         uint32_t produced = 0;
-        ZdProf P; P.on = a.prof != nullptr;
-        if (P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
-        const int err = zp_exec_frame<DICT>(a, L, i, &produced, P);
-        if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
+        ZdProf P; P.on = PROF && a.prof != nullptr;
+        if (PROF && P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
+        const int err = zp_exec_frame<DICT, PROF>(a, L, i, &produced, P);
+        if (PROF && P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }
     }

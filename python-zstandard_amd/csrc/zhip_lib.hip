@@ -54,20 +54,26 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)    
     zp_seq_body(a, L);
 }
 #ifndef ZP_K3_MINWAVES
-#define ZP_K3_MINWAVES 5         // 96 VGPRs (zhip_decode_pipeline.hpp: ZP_LIT_SHORT / ZP_FAR_SHORT); r03g
+#define ZP_K3_MINWAVES 6         // 77 VGPRs: own-lane items <= 16 bytes (zhip_decode_pipeline.hpp: ZP_LIT_SHORT / ZP_FAR_SHORT, r03g: 113 -> 96) and the phase timers
+                                 // in their own instantiation (r03n: 96 -> 77). Six waves per SIMD; seven (72 VGPRs) and eight measured the same
 #endif
 ZH_GLOBAL __launch_bounds__(64, ZP_K3_MINWAVES) void zhip_decode_exec_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpExecLDS L;
-    zp_exec_body<false>(a, L);
+    zp_exec_body<false, false>(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64, 4) void zhip_decode_exec_prof_kernel(ZhipPipeArgs a)      // ZHIP_PROF=1: the same kernel with its phase timers
+{
+    __shared__ ZpExecLDS L;
+    zp_exec_body<false, true>(a, L);
 }
 #ifndef ZP_K3D_MINWAVES
-#define ZP_K3D_MINWAVES 3        // three waves per SIMD: 168 registers instead of 128 -- the dictionary's terms spill 208 bytes per lane at four (r02y: 1.15 -> 0.67 ms per 32 768 documents)
+#define ZP_K3D_MINWAVES 4        // 113 VGPRs since round 3 (round 2: 168 at three waves per SIMD, 208 bytes of spills at four, r02y)
 #endif
 ZH_GLOBAL __launch_bounds__(64, ZP_K3D_MINWAVES) void zhip_decode_exec_dict_kernel(ZhipPipeArgs a)      // the context has a dictionary
 {
     __shared__ ZpExecLDS L;
-    zp_exec_body<true>(a, L);
+    zp_exec_body<true, false>(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
@@ -650,6 +656,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             }
             if (tm) HIP_TRY(hipEventRecord(ev[2], sx));
             if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, sx, pa);
             else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, sx, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[3], sx));
             if (split) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIP_TRY(hipEventRecord(e, sx)); evK3Done.push_back(e); }

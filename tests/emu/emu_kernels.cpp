@@ -134,7 +134,7 @@ static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
 static ZpSeqQLDS g_seqqlds;
 static void k2_lane(void* p) { zp_seqq_body(*(const ZhipPipeArgs*)p, g_seqqlds); }
 #endif
-static void k3_lane(void* p) { const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p; if (a.dictContent) zp_exec_body<true>(a, g_xlds); else zp_exec_body<false>(a, g_xlds); }
+static void k3_lane(void* p) { const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p; if (a.dictContent) zp_exec_body<true, false>(a, g_xlds); else zp_exec_body<false, false>(a, g_xlds); }
 // decompression dictionary for the pipeline harness (mirrors zhip_ctx_set_ddict): blob, parsed entropy section, ready-made tables
 static std::vector<uint8_t> g_ddBlob; static ZhipDictEntropy g_ddEntropy; static ZhipDictTables g_ddTables; static bool g_ddHas = false, g_ddEnt = false;
 struct DTLaunch { const ZhipDictEntropy* de; ZhipDictTables* out; };
