@@ -34,7 +34,7 @@ for direction in ("decode", "compress", "dict"):              # dict: kernel tra
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
-    for kind in ("fetch", "write", "sq", "sq2"):
+    for kind in ("fetch", "write", "sq", "sq2", "sq3"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows_of("%s_%s" % (direction, kind), "*counter_collection.csv"):
             if "zhip_" in r.get("Kernel_Name", ""):

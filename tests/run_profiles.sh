@@ -14,6 +14,7 @@ run decode_fetch --pmc FETCH_SIZE --output-format csv -d $P/decode_fetch -- $B -
 run decode_write --pmc WRITE_SIZE --output-format csv -d $P/decode_write -- $B --steps 1 --compress-frames 0
 run decode_sq --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $P/decode_sq -- $B --steps 1 --compress-frames 0
 run decode_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $P/decode_sq2 -- $B --steps 1 --compress-frames 0
+run decode_sq3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU --output-format csv -d $P/decode_sq3 -- $B --steps 1 --compress-frames 0
 run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- $B --steps 2 --config compress
 run compress_fetch --pmc FETCH_SIZE --output-format csv -d $P/compress_fetch -- $B --steps 1 --warmup 0 --config compress
 run compress_write --pmc WRITE_SIZE --output-format csv -d $P/compress_write -- $B --steps 1 --warmup 0 --config compress
