@@ -135,6 +135,10 @@ void      zhip_ctx_destroy(zhip_ctx*);
 int       zhip_ctx_set_ddict(zhip_ctx*, const void* hostDict, size_t dictSize, int dictType);   /* parses + uploads; NULL clears */
 int       zhip_ctx_set_dformat(zhip_ctx*, int format, uint64_t maxWindowSize);     /* frame format + window limit of the next decode calls */
 int       zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams* params);            /* uploads dict / tables */
+/* What a device-API caller knows about the UNCOMPRESSED size of its largest item (0 = nothing; the host-buffer API sees the sizes itself).
+ * Items above one block (128 KiB) are frames of several blocks: they run one wave per frame in the generic kernels, whose grid is a token one
+ * unless the library is told that such items are the batch (the reference has no equivalent: its workers take any size, c-ext/compressor.c:1035). */
+void      zhip_ctx_set_size_hint(zhip_ctx*, uint64_t maxItemBytes);
 
 /* d_src: concatenated frames; d_srcSegs[i] = (offset,length) of frame i in d_src.
  * d_dst: output arena;        d_dstSegs[i] = (offset, capacity) where frame i must be written.

@@ -268,6 +268,8 @@ struct zhip_ctx {
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
+    size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
+    size_t itemHint = 0;               // zhip_ctx_set_size_hint: what a device-API caller says about its items' uncompressed sizes (0 = nothing)
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
     ZeRows rows = {};                  // cparams resolved per source-size class (zhip_cparams.hpp)
     DevBuf scratch, counter;
@@ -719,7 +721,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         }
         d_fallbackList = (const uint32_t*)c->pipeFallback.p; d_fallbackCount = (const uint32_t*)c->pipeCounters.p;
         // the generic kernel only sees the (usually empty) fallback list: a small grid is enough
-        if (grid > 1024) grid = 1024;
+        // (unless the caller says its frames exceed one block: then the list is the whole batch)
+        if (grid > 1024 && !((c->dstMaxHint ? c->dstMaxHint : c->itemHint) > ZF_BLOCK_MAX)) grid = 1024;
     }
     ZhipDecodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
@@ -857,7 +860,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // waves for what the generic kernel takes: inputs above one block, and -- with a dictionary -- inputs above the attach cutoff
         // (with a dictionary: inputs above the attach cutoff too. Every wave of this kernel carries 544 bytes of scratch per lane: a full-chip
         // grid that finds an empty list still took 2.3 ms of every dictionary batch -- r02zi kernel trace; half a wave per CU is 0.4)
-        const size_t gBigMax = c->hasCDict ? (size_t)c->numCU / 2 : 64;
+        // (r03: when the caller says its sources exceed one block -- the host API knows, a device-API caller can tell with zhip_ctx_set_size_hint --
+        // the list is the whole batch and gets the whole chip: 2 048 x 1 MiB took 10.6 s on 64 waves, profiles/r03_multiblock_rate.txt)
+        const size_t sizeHint = c->srcMaxHint ? c->srcMaxHint : c->itemHint;
+        const size_t gBigMax = sizeHint > ZF_BLOCK_MAX ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : c->hasCDict ? (size_t)c->numCU / 2 : 64;
         const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
             c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
@@ -1086,6 +1092,8 @@ __global__ __launch_bounds__(64) void zhip_compact_kernel(const uint8_t* slots, 
     }
 }
 
+extern "C" void zhip_ctx_set_size_hint(zhip_ctx* c, uint64_t maxItemBytes) { if (c) c->itemHint = (size_t)maxItemBytes; }
+
 extern "C" int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, const uint64_t* d_outSizes, const int32_t* d_status,
                                    const uint64_t* d_offsets, size_t n, void* d_dense, void* streamv)
 {
@@ -1287,7 +1295,9 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
         const uint64_t outBytes = segs[n + hi - 1].offset + segs[n + hi - 1].length - segs[n + lo].offset;
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
         if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        { uint64_t mx = 0; for (size_t i = lo; i < hi; i++) if (segs[n + i].length > mx) mx = segs[n + i].length; c->dstMaxHint = (size_t)mx; }
         r = zhip_decompress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
+        c->dstMaxHint = 0;
         if (r) return fail(r);
         if (hipEventRecord(evK, c->hpCompute) != hipSuccess || hipStreamWaitEvent(c->hpD2H, evK, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
         // the chunk's output goes straight into its (pinned) result payload

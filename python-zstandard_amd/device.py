@@ -52,6 +52,11 @@ class DeviceBatchContext:
                 raise ZstdError("could not set compression parameters: %s" % (_lib.error_name(-rc) if rc < 0 else _lib.last_error()))
             self._cparams_set = True
 
+    def set_size_hint(self, max_item_bytes):
+        """largest uncompressed item of the coming calls (0 = unknown): batches of inputs / frames above 128 KiB get a full grid of the
+        one-wave-per-frame kernels that serve frames of several blocks"""
+        self.L.zhip_ctx_set_size_hint(self.ctx, int(max_item_bytes))
+
     def close(self):
         if self.ctx:
             self.L.zhip_ctx_destroy(self.ctx)

@@ -24,10 +24,10 @@ raw_np = raw.cpu().numpy()
 frames, csizes = bench.compress_on_host(raw_np, item)
 out = {"frames": F, "frame_KiB": KIB, "ratio": round(F * item / float(csizes.sum()), 3)}
 job = bench.Job(1, dev)
-ctx = DeviceBatchContext()
+ctx = DeviceBatchContext(); ctx.set_size_hint(item)
 el, _, _ = bench.run_decompress(job, ctx, frames, csizes, raw, item, 3, 1)
 out["decompress_GBps"] = round(F * item * 3 / el / 1e9, 2); out["decompress_ms"] = round(el / 3 * 1e3, 2)
-ctx.close(); ctx = DeviceBatchContext()
+ctx.close(); ctx = DeviceBatchContext(); ctx.set_size_hint(item)
 el, total, _ = bench.run_compress(job, ctx, raw, frames, item, 2, 1)
 out["compress_GBps"] = round(F * item * 2 / el / 1e9, 3); out["compress_ms"] = round(el / 2 * 1e3, 1); out["bit_exact_vs_libzstd"] = True
 ctx.close()
