@@ -44,6 +44,7 @@ int stub_device(const void* dictBytes, size_t dictSize, const void* d_src, const
     zhip_error err;
     if (!ctx) return ZHIP_ERR_HIP;
     zhip_ctx_set_ddict(ctx, dictBytes, dictSize, ZHIP_DICT_AUTO);
+    zhip_ctx_set_size_hint(ctx, 1u << 20);
     int rc = zhip_decompress_batch_device(ctx, d_src, d_srcSegs, n, d_dst, d_dstSegs, d_outSizes, d_status, stream);
     if (!rc) rc = zhip_ctx_sync(ctx, stream, d_status, n, &err);
     zhip_ctx_destroy(ctx);
