@@ -1,24 +1,23 @@
-// zhip_decode_pipeline.hpp -- phase-split batch decoder for the common case (dictionary-less frames made of ONE block,
-// which is every frame multi_compress_to_buffer produces for inputs <= 128 KiB). Profile-driven (profiles/r01a): the
-// fused one-wave-per-frame kernel spends 63 % of its cycles in the single-lane tANS chain and is limited to ~8-11 frames
-// per CU by its 14 KiB of LDS. Splitting the frame loop by phase lets each phase use the mapping that fits it:
+// zhip_decode_pipeline.hpp -- phase-split batch decoder for frames made of ONE block (every frame multi_compress_to_buffer produces for
+// inputs <= 128 KiB), with or without a dictionary. Profile-driven (profiles/r01a): the fused one-wave-per-frame kernel spends 63 % of its
+// cycles in the single-lane tANS chain and is limited to ~8-11 frames per CU by its 14 KiB of LDS. Splitting the frame loop by phase lets
+// each phase use the lane mapping -- and the LDS / register budget -- that fits ITS serial chain (DESIGN.md 4.1 has the measurements):
 //
-//   K1 zhip_decode_lit_kernel   one wave per frame : header + block header + literals section (Huffman, 4 lanes / 4 streams)
-//                                                     -> per-frame literal slot; raw / RLE single-block frames finish here.
-//                                                     Also reads the sequences header and builds the three FSE tables
-//                                                     wave-parallel into the frame's 2.5 KiB slot of the table arena (HBM/L2).
-//                                                     Huffman streams are NOT decoded here: the table goes to an arena for K1b.
-//   KB zhip_decode_bin_kernel   two waves per chunk: 256-bin counting sorts -- frames by decreasing sequence count (K2's order) and
-//                                                     by decreasing literal count (K1b's), so lanes sharing a wave finish together
-//   K1b zhip_decode_huf_kernel  4 LANES per frame  : the (up to) four Huffman streams of 16 frames per wave, tables in LDS
-//   K2 zhip_decode_seq_kernel   one LANE per frame : the serial tANS decode; one 63-lane wave per CU with the 63 frames' tables
-//                                                     (copied from the arena) filling the CU's 160 KiB of LDS; 32-bit-only inner
-//                                                     loop. Emits packed 8-byte sequences to HBM
-//   K3 zhip_decode_exec_kernel  one wave per frame : reads 64 sequences per batch (coalesced), assembles the batch output in
-//                                                     LDS, flushes with 16-byte stores
+//   K1  zhip_decode_lit_kernel   one wave per frame   : frame / block / literals headers; Huffman weights -> decoding table (wave-parallel) into
+//                                                       the frame's slot of the table arena; sequences header -> three FSE tables (wave-parallel)
+//                                                       into its 2.5 KiB slot; raw / RLE single-block frames finish here. Frames of a dictionary
+//                                                       batch whose tables are all "repeat" / "treeless" only get a flag: the tables are the dictionary's
+//   KB  zhip_decode_bin_kernel   128 waves per chunk  : work orders -- frames by decreasing sequence count (K2's) and literal count (K1b's), from
+//                                                       the bin counters K1 filled, so lanes sharing a wave run equally long
+//   K1b zhip_decode_huf_kernel   4 LANES per frame    : the (up to) four Huffman streams, 8 frames per wave, tables in LDS (3 KiB each), 6 waves per CU
+//   K2  zhip_decode_seq_kernel   a QUAD per frame     : the serial tANS chain with its three streams side by side (lanes OF / ML / LL / spare), 15
+//                                                       frames per wave, four waves per CU: the 60 frames' tables ARE the CU's 160 KiB of LDS.
+//                                                       Emits packed 8-byte sequences (zp_seqq_body; zp_seq_body is rounds 1-2's lane-per-frame form)
+//   K3  zhip_decode_exec_kernel  one wave per frame   : 64 sequences per batch, the batch's output assembled in LDS and flushed in whole 16-byte
+//                                                       units; 77 VGPRs, six waves per SIMD (zhip_decode_exec_dict_kernel: with a dictionary)
 //
-// Anything else (multi-block frames, dictionaries, oversize offsets) is routed to the generic fused kernel through a
-// fallback list, so results are identical on every input.
+// Anything else (frames of several blocks, offsets beyond the packed form) goes to the generic fused kernel through a fallback list, so
+// results are identical on every input.
 #pragma once
 #include "zhip_decode_kernel.hpp"
 
