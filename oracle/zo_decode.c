@@ -456,7 +456,7 @@ static int decode_block(zo_dctx* d, uint8_t* ostart, uint8_t* op, uint8_t* oend,
                 if (idx == 0) offset = d->rep[0];
                 else {
                     offset = (idx == 3) ? (uint64_t)d->rep[0] - 1 : d->rep[idx];
-                    if (offset == 0) offset = 1;                   /* libzstd forces a non-zero offset on corrupt input */
+                    if (offset == 0) offset = ~(uint64_t)0;        /* zstd.c:46941 (1.5.7): "0 is not valid: input corrupted => force offset to -1 => corruption detected at execSequence" */
                     if (idx != 1) d->rep[2] = d->rep[1];
                     d->rep[1] = d->rep[0]; d->rep[0] = (uint32_t)offset;
                 }
@@ -585,6 +585,11 @@ int64_t zo_decompress_frame(void* dstv, size_t dstCap, const void* srcv, size_t 
     {
         size_t pos = h.headerSize;
         uint8_t* op = dst; uint8_t* oend = dst + dstCap;
+        /* The reference hands the frame to ZSTD_decompressStream with an output of the declared size (c-ext/decompressor.c:1150). With the
+         * content size in the header and room for it libzstd decodes in ONE PASS (zstd.c:44174 ZSTD_decompressFrame): raw and RLE blocks of any
+         * size pass, a compressed block above the frame's block maximum is srcSize_wrong (zstd.c:47714). Otherwise it streams
+         * (ZSTD_decompressContinue) and every block above the maximum is corruption_detected. */
+        const int onePass = h.contentSize != ZO_CONTENTSIZE_UNKNOWN && (uint64_t)dstCap >= h.contentSize;
         for (;;) {
             if (pos + 3 > srcSize) { result = -ZO_E_SRC_SIZE_WRONG; goto done; }
             uint32_t bh = zo_rd24(src + pos); pos += 3;
@@ -592,19 +597,19 @@ int64_t zo_decompress_frame(void* dstv, size_t dstCap, const void* srcv, size_t 
             if (type == 3) { result = -ZO_E_CORRUPTION; goto done; }
             if (type == 0) {
                 if (pos + bs > srcSize) { result = -ZO_E_SRC_SIZE_WRONG; goto done; }
-                if (bs > h.blockSizeMax) { result = -ZO_E_CORRUPTION; goto done; }
+                if (bs > h.blockSizeMax && !onePass) { result = -ZO_E_CORRUPTION; goto done; }
                 if ((size_t)(oend - op) < bs) { result = -ZO_E_DST_TOO_SMALL; goto done; }
                 if (bs) memcpy(op, src + pos, bs);
                 op += bs; pos += bs;
             } else if (type == 1) {
                 if (pos + 1 > srcSize) { result = -ZO_E_SRC_SIZE_WRONG; goto done; }
-                if (bs > h.blockSizeMax) { result = -ZO_E_CORRUPTION; goto done; }
+                if (bs > h.blockSizeMax && !onePass) { result = -ZO_E_CORRUPTION; goto done; }
                 if ((size_t)(oend - op) < bs) { result = -ZO_E_DST_TOO_SMALL; goto done; }
                 if (bs) memset(op, src[pos], bs);
                 op += bs; pos += 1;
             } else {
                 if (pos + bs > srcSize) { result = -ZO_E_SRC_SIZE_WRONG; goto done; }
-                if (bs > ZO_BLOCK_MAX) { result = -ZO_E_CORRUPTION; goto done; }
+                if (bs > h.blockSizeMax) { result = onePass ? -ZO_E_SRC_SIZE_WRONG : -ZO_E_CORRUPTION; goto done; }
                 size_t produced = 0;
                 e = decode_block(d, dst, op, oend, src + pos, bs, h.blockSizeMax, &produced);
                 if (e < 0) { result = e; goto done; }

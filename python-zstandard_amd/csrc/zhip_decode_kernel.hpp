@@ -807,7 +807,7 @@ ZH_DEVFN int zd_sequences(ZdLDS& L, ZdState& st, const uint8_t* p, const uint8_t
                         if (idx == 0) offset = rep0;
                         else {
                             offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                            if (offset == 0) offset = 1;
+                            if (offset == 0) offset = 0xFFFFFFFFu;          // rep0 - 1 == 0: no such offset -- libzstd 1.5.7 forces -1 and the execution refuses it (zstd.c:46941)
                             if (idx != 1) rep2 = rep1;
                             rep1 = rep0; rep0 = offset;
                         }
@@ -1048,6 +1048,10 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
         st.rep0 = de->rep[0]; st.rep1 = de->rep[1]; st.rep2 = de->rep[2];
     }
     // ---- blocks
+    // The reference hands the frame to ZSTD_decompressStream with an output of the declared size (c-ext/decompressor.c:1150). With the content
+    // size in the header and room for it libzstd decodes in one pass (zstd.c:44174): raw and RLE blocks of any size pass, a compressed block
+    // above the frame's block maximum is srcSize_wrong (zstd.c:47714). Otherwise it streams and any block above the maximum is corruption.
+    const bool onePass = fcs != ~0ull && cap64 >= fcs;
     uint32_t op = 0;
     for (;;) {
         if (pos + 3 > srcSize) return ZE_SRC_SIZE_WRONG;
@@ -1056,7 +1060,7 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
         if (type == 3) return ZE_CORRUPTION;
         if (type == 0) {
             if (pos + bs > srcSize) return ZE_SRC_SIZE_WRONG;
-            if (bs > blockMax) return ZE_CORRUPTION;
+            if (bs > blockMax && !onePass) return ZE_CORRUPTION;
             if ((uint64_t)op + bs > cap) return ZE_DST_TOO_SMALL;
             zd_copy_wave(dst + op, src + pos, bs);
             zd_fence();
@@ -1064,14 +1068,15 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
             op += bs; pos += bs;
         } else if (type == 1) {
             if (pos + 1 > srcSize) return ZE_SRC_SIZE_WRONG;
-            if (bs > blockMax) return ZE_CORRUPTION;
+            if (bs > blockMax && !onePass) return ZE_CORRUPTION;
             if ((uint64_t)op + bs > cap) return ZE_DST_TOO_SMALL;
             zd_fill_wave(dst + op, src[pos], bs);
             zd_fence();
             op += bs; pos += 1;
         } else {
             if (pos + bs > srcSize) return ZE_SRC_SIZE_WRONG;
-            if (bs > ZF_BLOCK_MAX || bs < 2) return ZE_CORRUPTION;
+            if (bs > blockMax) return onePass ? ZE_SRC_SIZE_WRONG : ZE_CORRUPTION;
+            if (bs < 2) return ZE_CORRUPTION;
             ZD_T(P, ZP_HEADER);
             int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P);
             if (r < 0) return -r;

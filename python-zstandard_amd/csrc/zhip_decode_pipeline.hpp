@@ -106,9 +106,11 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             const uint32_t lastBlock = bh & 1, type = (bh >> 1) & 3, bs = bh >> 3;
             if (!lastBlock) { fallback = true; break; }                      // multi-block frame
             if (type == 3) { err = ZE_CORRUPTION; break; }
+            // (block sizes against the frame's maximum: libzstd's one-pass / streaming split, see zd_frame in zhip_decode_kernel.hpp)
+            const bool onePass = fcs != ~0ull && cap64 >= fcs;
             if (type < 2) {                                                 // one raw / RLE block: finish right here
                 if (type == 0 ? pos + bs > srcSize : pos + 1 > srcSize) { err = ZE_SRC_SIZE_WRONG; break; }
-                if (bs > blockMax) { err = ZE_CORRUPTION; break; }
+                if (bs > blockMax && !onePass) { err = ZE_CORRUPTION; break; }
                 if (bs > cap) { err = ZE_DST_TOO_SMALL; break; }
                 if (type == 0) zd_copy_wave(dst, src + pos, bs); else zd_fill_wave(dst, src[pos], bs);
                 if (fcs != ~0ull && fcs != bs) { err = ZE_CORRUPTION; break; }
@@ -127,7 +129,8 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 break;
             }
             if (pos + bs > srcSize) { err = ZE_SRC_SIZE_WRONG; break; }
-            if (bs > ZF_BLOCK_MAX || bs < 2) { err = ZE_CORRUPTION; break; }
+            if (bs > blockMax) { err = onePass ? ZE_SRC_SIZE_WRONG : ZE_CORRUPTION; break; }
+            if (bs < 2) { err = ZE_CORRUPTION; break; }
             ZdState st;
             st.rep0 = 1; st.rep1 = 4; st.rep2 = 8; st.hufCount = 0; st.llLog = st.ofLog = st.mlLog = 0xFF;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
@@ -551,7 +554,7 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         /* repcode resolution (RFC 8878 3.1.1.5), select form */
         const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */
         uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro;
-        ro = ro == 0 ? 1u : ro;
+        ro = ro == 0 ? 0xFFFFFFFFu : ro;                              /* rep0 - 1 == 0 is no offset (zstd.c:46941 forces -1): too large for the packed form -> generic kernel -> refused */
         const bool isRep = ofv <= 3;
         const uint32_t offset = isRep ? ro : ofv - 3;
         const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1);
@@ -778,7 +781,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
                 const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
                 const uint32_t idx = val - 1 + (llv == 0);
-                const uint32_t r0m1 = rep0 - 1 > 1u ? rep0 - 1 : 1u;
+                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); here it trips `bad` below -> generic kernel -> refused
                 const uint32_t c3 = val <= 3 ? r0m1 : val - 3;
                 uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
                 ZQ_F2();

@@ -576,3 +576,17 @@ def test_decode_pipeline_long_items_and_carried_flush(emu, ref):
         frames = [ref.compress(r, level=lv) for r in raws]
         outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws])
         assert not any(st) and outs == raws and nfb == 0
+
+
+def test_frames_no_encoder_writes_through_the_emulated_kernels(emu, ref):
+    """tests/craft.py's hand-made frames (repeat offset 1 minus one = 0, zstd.c:46941; blocks above the frame's block maximum under libzstd's
+    one-pass and streaming decoders, zstd.c:44239-44246 / :47714): K1 / K2 / K3 and the generic kernel accept exactly what libzstd accepts and
+    produce its bytes. The GPU form is tests/test_gpu_decompress.py::test_frames_no_encoder_writes_are_answered_like_libzstd."""
+    from tests import craft
+    cases = craft.edge_frames()
+    outs, st, nfb = emu.decompress_pipeline([c[1] for c in cases], [c[2] for c in cases], n_blocks=3, chunk=0)
+    for (name, f, n, ok), o, s in zip(cases, outs, st):
+        try: want = ref.decompress(f, n)
+        except RuntimeError: want = None
+        assert (want is not None) == ok, name
+        assert (s == 0) == ok and (not ok or o == want), (name, s)

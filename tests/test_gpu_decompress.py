@@ -133,6 +133,33 @@ def test_truncated_and_corrupt_frames_do_not_crash(zstd, corpus):
     assert d.multi_decompress_to_buffer([good, good])[1].tobytes() == corpus.frame_bytes(4)
 
 
+def test_frames_no_encoder_writes_are_answered_like_libzstd(zstd):
+    """tests/craft.py: repeat offset 1 minus one = 0 (zstd.c:46941), blocks above the frame's block maximum in libzstd's one-pass and
+    streaming decoders (zstd.c:44239-44246, :47714) -- accepted exactly when libzstd accepts, with libzstd's bytes; alone (K1 / K2 / K3 or
+    the generic kernel) and all together in one batch."""
+    from tests import craft, reflib
+    cases = craft.edge_frames()
+    ref = reflib.RefZstd() if reflib.have_ref() else None
+    d = zstd.ZstdDecompressor()
+    good = []
+    for name, f, n, ok in cases:
+        want = None
+        if ref is not None:
+            try: want = ref.decompress(f, n)
+            except RuntimeError: want = None
+            assert (want is not None) == ok, name
+        sizes = struct.pack("=Q", n)
+        if ok:
+            got = d.multi_decompress_to_buffer([f], decompressed_sizes=sizes)[0].tobytes()
+            assert len(got) == n and (want is None or got == want), name
+            good.append((f, n, got))
+        else:
+            with pytest.raises(zstd.ZstdError, match="error decompressing item 0"):
+                d.multi_decompress_to_buffer([f], decompressed_sizes=sizes)
+    res = d.multi_decompress_to_buffer([g[0] for g in good] * 3, decompressed_sizes=struct.pack("=%dQ" % (3 * len(good)), *([g[1] for g in good] * 3)))
+    assert [res[i].tobytes() for i in range(len(res))] == [g[2] for g in good] * 3
+
+
 def test_content_checksum_is_verified(zstd):
     from tests import reflib
     if not reflib.have_ref():
