@@ -559,12 +559,12 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         const uint32_t offset = isRep ? ro : ofv - 3;
         const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1);
         rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0;
-        bad |= offset >> 30;
-        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 2)) << 32);
+        bad |= offset >> ZP_SEQ_OFBITS;
+        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 3)) << 32);
         if (last) break;
         n++;
     }
-    if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 1 GiB)
+    if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 512 MiB)
     if (!zb_finished(B)) return ZE_CORRUPTION;
     return 0;
 }
@@ -793,7 +793,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
                 rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
                 maxOff = offset > maxOff ? offset : maxOff;
-                {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 2);
+                {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 3);
                     if (u == 0) {                                                     // (compile-time: the loop is unrolled)
                         w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
                         outp[0] = w0; outp[1] = w1; outp += outStep;
@@ -823,7 +823,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             // wait (vmcnt counts in order) also sat out the ring's block load issued just before it -- a load round trip per group (r02x)
             ZH_KEEP4(w0.a, w0.b, w0.c, w0.d); ZH_KEEP4(w1.a, w1.b, w1.c, w1.d);
         }
-        const uint32_t bad = maxOff >> 30;
+        const uint32_t bad = maxOff >> ZP_SEQ_OFBITS;
         if (active && isOF) {
             const int err = !ok ? ZE_CORRUPTION : bad ? ZE_PARAM_UNSUPPORTED : posEnd != fin ? ZE_CORRUPTION : 0;
             if (err == ZE_PARAM_UNSUPPORTED) {                                 // an offset does not fit the packed form: the generic kernel's
@@ -923,7 +923,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #endif
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
-        if (lane < avail) { const uint64_t q = qNext; myLL = (uint32_t)q & 0x1FFFF; myML = (uint32_t)(q >> 17) & 0x1FFFF; myOF = (uint32_t)(q >> 34); }
+        if (lane < avail) { const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); }
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer (behind the carried bytes)
         const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES);
@@ -1192,7 +1192,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
             // so that the staging loads of the next batch find it in L2. Layout of the next batch as its own scan will compute it,
             // assuming it takes all 64 sequences (an estimate is enough for a prefetch).
             const uint64_t qn = qNext;
-            const uint32_t nLL = (uint32_t)qn & 0x1FFFF, nML = (uint32_t)(qn >> 17) & 0x1FFFF, nOF = (uint32_t)(qn >> 34);
+            const uint32_t nLL = ZP_SEQ_LL(qn), nML = ZP_SEQ_ML(qn), nOF = ZP_SEQ_OF(qn);
             const uint32_t nIncT = zh_scan_add(nLL + nML);
             const int64_t nSrc = (int64_t)op + totT + nIncT - nML - nOF;
             pfWord = 0;

@@ -1907,7 +1907,7 @@ ZH_DEV int ze_dict_copy_cparams(ZePar& cp, const ZeCDict& cd, const ZeRows& rows
     cp.wlog = w; cp.hlog = cd.hlog; cp.clog = cd.clog; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
     // the dictionary stays valid while the SOURCE fits the window (ZSTD_checkDictValidity, zstd.c:19360: block end > dictionary end + window);
     // beyond that libzstd drops it part-way through the frame, which is not implemented: refused
-    if (w > 30 || ((uint64_t)1 << w) < (uint64_t)srcSize) return ZE_PARAM_UNSUPPORTED;
+    if (w > 27 || ((uint64_t)1 << w) < (uint64_t)srcSize) return ZE_PARAM_UNSUPPORTED;
     return 0;
 }
 
@@ -2378,6 +2378,9 @@ ZH_DEV int ze_get_cparams(ZePar& out, const ZeRows& rows, uint32_t srcSize)
     // an explicit window smaller than the source AND smaller than a block makes the match window slide inside a block
     // (ZSTD_getLowestPrefixIndex, zstd.c:19470); the level tables never produce that and the kernels do not implement it: refused
     if (w < 17 && (1u << w) < srcSize) return ZE_PARAM_UNSUPPORTED;
+    // the search kernels' packed sequences (ZE_SEQ_PACK) carry offset + 3 in 28 bits: a window above 128 MiB (explicit window_log >= 28 on a
+    // source that large) is refused rather than truncated
+    if (w > 27) return ZE_PARAM_UNSUPPORTED;
     return 0;
 }
 

@@ -194,7 +194,14 @@ struct ZdMeta {
 };
 #define ZP_SEQ_CAP 45056u                              // >= 131072 / 3 sequences per block
 #define ZP_SEQ_FRONT 16u                               // slots of padding before the first frame's (K2's pipelined store of "sequence -1" lands there)
-#define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:34) offset[34:64)
+#define ZP_SEQ_STRIDE ((size_t)ZP_SEQ_CAP * 8)          // packed sequence = ll[0:17) ml[17:35) offset[35:64)
+// literal lengths end at 131 071 (code 35: 65 536 + 16 bits), match lengths at 131 074 (code 52: 65 539 + 16 bits) -- 18 bits: a whole 128 KiB
+// block can be ONE match into a dictionary (or, in frames of several blocks, into the block before). Offsets of 2^29 and more (windows above
+// 512 MiB) do not fit: those frames are the generic kernel's.
+#define ZP_SEQ_LL(q) ((uint32_t)(q) & 0x1FFFFu)
+#define ZP_SEQ_ML(q) ((uint32_t)((q) >> 17) & 0x3FFFFu)
+#define ZP_SEQ_OF(q) ((uint32_t)((q) >> 35))
+#define ZP_SEQ_OFBITS 29
 #define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
 // per-frame FSE decoding tables in HBM / L2: 2-byte cells (symbol << 10 | x), LL 512 + ML 512 + OF 256 cells
 #define ZP_FSE_LL 0

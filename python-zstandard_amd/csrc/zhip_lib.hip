@@ -707,8 +707,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                     HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + i * ZP_SEQ_CAP, sizeof q, hipMemcpyDeviceToHost));
                     HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
                     fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
-                            (uint32_t)q[0] & 0x1FFFF, (uint32_t)(q[0] >> 17) & 0x1FFFF, (uint32_t)(q[0] >> 34),
-                            (uint32_t)q[1] & 0x1FFFF, (uint32_t)(q[1] >> 17) & 0x1FFFF, (uint32_t)(q[1] >> 34), cells[0], cells[1], cells[2], cells[3]);
+                            ZP_SEQ_LL(q[0]), ZP_SEQ_ML(q[0]), ZP_SEQ_OF(q[0]),
+                            ZP_SEQ_LL(q[1]), ZP_SEQ_ML(q[1]), ZP_SEQ_OF(q[1]), cells[0], cells[1], cells[2], cells[3]);
                 }
             }
         }

@@ -590,3 +590,22 @@ def test_frames_no_encoder_writes_through_the_emulated_kernels(emu, ref):
         except RuntimeError: want = None
         assert (want is not None) == ok, name
         assert (s == 0) == ok and (not ok or o == want), (name, s)
+
+
+def test_a_whole_block_as_one_match_into_the_dictionary(emu, ref):
+    """match length 131 072 (a 128 KiB source that is its own raw-content dictionary): 18 bits in the packed sequences K2 writes for K3.
+    GPU form: tests/test_gpu_boundary.py, same name."""
+    import numpy as np
+    data = np.random.default_rng(5).bytes(131072)
+    blob = b"zz" + data
+    raws = [data, data[:131071], data[:3] + b"Q" + data[:131068]]
+    frames = [ref.compress(r, level=3, dict_data=blob) for r in raws]
+    assert len(frames[0]) < 40
+    try:
+        assert emu.set_ddict(blob, raw_content=True) == 0
+        outs, st, nfb = emu.decompress_pipeline(frames, [len(r) for r in raws], n_blocks=2, chunk=0)
+    finally:
+        emu.set_ddict(None)
+    assert st == [0, 0, 0] and nfb == 0 and outs == raws
+    outs, st = emu.compress_batch(raws[:1], level=3, flags=5, pipeline=True, dict_data=blob)
+    assert st == [0] and outs[0] == frames[0]

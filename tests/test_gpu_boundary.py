@@ -17,6 +17,23 @@ def zstd():
     return zstandard_amd
 
 
+def test_a_whole_block_as_one_match_into_the_dictionary(zstd, ref):
+    """A 128 KiB source that IS its (raw-content) dictionary compresses to one sequence of match length 131 072 -- beyond 17 bits: the
+    packed sequences K2 hands to K3 give the match length 18 (round 3: the 17-bit form dropped the top bit and the frame was refused).
+    Both directions, with the neighbours one and two bytes short and a frame whose match starts after a literal."""
+    rng = np.random.default_rng(5)
+    data = rng.bytes(131072)
+    blob = b"zz" + data
+    raws = [data, data[:131071], data[:131070], data[:70000], data[:3] + b"Q" + data[:131068]] * 3
+    zd = zstd.ZstdCompressionDict(blob, dict_type=zstd.DICT_TYPE_RAWCONTENT)
+    res = zstd.ZstdCompressor(level=3, dict_data=zd).multi_compress_to_buffer(raws)
+    frames = [ref.compress_advanced(r, level=3, dict_data=blob, dict_type=zstd.DICT_TYPE_RAWCONTENT) for r in raws]
+    assert [res[i].tobytes() for i in range(len(raws))] == frames and len(frames[0]) < 40
+    back = zstd.ZstdDecompressor(dict_data=zd).multi_decompress_to_buffer(frames)
+    assert [back[i].tobytes() for i in range(len(raws))] == raws
+    assert zstd.ZstdDecompressor(dict_data=zd).decompress(frames[0]) == data
+
+
 def test_dictionary_content_type(zstd, ref, corpus):
     """c-ext/compressiondict.c:170-191 -> compressor.c:37-52 / compressiondict.c:148-162: DICT_TYPE_RAWCONTENT treats a blob that starts
     with the dictionary magic as plain content (different frames from AUTO!), DICT_TYPE_FULLDICT demands the magic"""
