@@ -42,6 +42,124 @@ ZH_DEV void zp_pack_fse(ZdLDS& L, uint32_t* T, uint32_t llLog, uint32_t ofLog, u
 }
 
 // ------------------------------------------------------------------------------------------ K1
+// frame header (RFC 8878 3.1.1.1; ZSTD_getFrameHeader_advanced zstd.c:43682, the checks of ZSTD_decompressFrame :44174): where the first
+// block header lies, the block maximum, the content size (~0 = not in the header), the checksum flag. 0 or a zstd error code.
+struct ZpHdr { uint32_t pos, blockMax, hasChecksum; uint64_t fcs; };
+ZH_DEV int zp_frame_header(const ZhipPipeArgs& a, const uint8_t* src, uint32_t srcSize, ZpHdr& h)
+{
+    const uint32_t mg = a.magicless ? 0u : 4u;                     // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
+    if (srcSize < mg + 1) return ZE_SRC_SIZE_WRONG;
+    if (mg && zh_ld32(src) != ZF_MAGIC) return ZE_PREFIX_UNKNOWN;
+    const uint32_t fhd = src[mg];
+    const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
+    h.hasChecksum = (fhd >> 2) & 1;
+    const uint32_t dictBytes = dictCode == 3 ? 4 : dictCode;
+    const uint32_t fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
+    const uint32_t hs = mg + 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
+    if (fhd & 8) return ZE_FRAMEPARAM_UNSUPPORTED;
+    if (srcSize < hs) return ZE_SRC_SIZE_WRONG;
+    uint32_t pos = mg + 1;
+    uint64_t windowSize = 0;
+    if (!single) {
+        const uint32_t wd = src[pos++], wl = 10 + (wd >> 3);
+        if (wl > 31) return ZE_WINDOW_TOO_LARGE;
+        windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wd & 7);
+    }
+    {   const uint32_t dictID = dictCode == 0 ? 0u : dictCode == 1 ? src[pos] : dictCode == 2 ? zh_ld16(src + pos) : zh_ld32(src + pos);
+        pos += dictBytes;
+        if (dictID && dictID != a.dictID) return ZE_DICT_WRONG; }     // ZSTD_decompressFrame's check (zstd.c:44246)
+    uint64_t fcs = ~0ull;
+    if (fcsCode == 0) { if (single) fcs = src[pos]; }
+    else if (fcsCode == 1) fcs = (uint64_t)zh_ld16(src + pos) + 256;
+    else if (fcsCode == 2) fcs = zh_ld32(src + pos);
+    else fcs = zh_ld64(src + pos);
+    pos += fcsBytes;
+    if (single) windowSize = fcs;
+    if (windowSize > a.maxWindowSize) return ZE_WINDOW_TOO_LARGE;
+    h.blockMax = windowSize < ZF_BLOCK_MAX ? (uint32_t)windowSize : ZF_BLOCK_MAX;
+    h.fcs = fcs; h.pos = pos;
+    return 0;
+}
+
+// One compressed block, content [pos, pos + bs) of the frame at `src`, for the later kernels: the literals section -> Huffman table into
+// `df.table` (or literals that need no K1b), the sequences header -> the three FSE tables into slot `t` of the table arena; fills the
+// item's record `m` (offsets relative to `src`). `st` carries what a block inherits (the Huffman weights' count, the table logs; the
+// tables themselves lie in L). `share`: a dictionary frame's "repeat" / "treeless" tables may be read where the dictionary's lie.
+// `dictInLds`: the dictionary's FSE tables are already in L.fse (several-block frames load them once). All lanes call; 0 or an error code.
+ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLitDefer& df, const uint8_t* src, uint32_t pos, uint32_t bs,
+                             uint32_t blockMax, uint32_t t, ZdMeta& m, ZdProf& P, bool share, bool dictInLds)
+{
+    const uint32_t lane = zh_lane();
+    uint8_t* lit = a.litArena + (size_t)t * ZP_LIT_STRIDE;
+    st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
+    const ZhipDictEntropy* const de = a.dictEntropy;
+    const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
+    if (r < 0) return -r;
+    m.litSize = st.litSize;
+    if (df.taken) { m.litMode = 3u | (df.log << 8) | (df.four << 16) | (df.shared ? ZP_LIT_SHARED : 0u); m.litOff = (uint32_t)(df.streams - src); m.produced = df.streamBytes; }
+    else if (st.litRLE) { m.litMode = 2; m.litOff = st.rleByte; }
+    else if (st.litPtr == lit) { m.litMode = 1; m.litOff = 0; }
+    else { m.litMode = 0; m.litOff = (uint32_t)(st.litPtr - src); }
+    // sequences header (RFC 8878 3.1.1.3.2): count, compression modes, table descriptions -> FSE tables for K2
+    const uint8_t* sp = src + pos + (uint32_t)r; const uint8_t* const send = src + pos + bs;
+    if (sp >= send) return ZE_SRC_SIZE_WRONG;
+    uint32_t nbSeq = *sp++;
+    if (nbSeq > 127) {
+        if (nbSeq == 255) { if (sp + 2 > send) return ZE_SRC_SIZE_WRONG; nbSeq = zh_ld16(sp) + 0x7F00; sp += 2; }
+        else { if (sp >= send) return ZE_SRC_SIZE_WRONG; nbSeq = ((nbSeq - 128) << 8) + *sp++; }
+    }
+    m.nbSeq = nbSeq;
+    if (nbSeq == 0) { if (sp != send) return ZE_CORRUPTION; }
+    else {
+        if (nbSeq > ZP_SEQ_CAP - 16) return ZE_CORRUPTION;      // (> 43 690 cannot fit a block; K2 stores a few slots past the longest frame of its wave and parks idle lanes' stores in the last)
+        if (sp >= send) return ZE_SRC_SIZE_WRONG;
+        const uint32_t modes = *sp++;
+        if (modes & 3) return ZE_CORRUPTION;
+        // every table "repeat" in a dictionary frame: the tables ARE the dictionary's, ready-made in K2's form (ZhipDictTables.fseK2):
+        // nothing to build, nothing to write -- K2 copies them from there
+        const bool allShared = share && de && (modes >> 2) == 0x3F;
+        if (allShared) {
+            st.llLog = de->llLog; st.ofLog = de->ofLog; st.mlLog = de->mlLog;
+            if (sp >= send) return ZE_CORRUPTION;
+        } else {
+            if (de && !dictInLds) {                                 // "repeat" takes the dictionary's table: drop it into its LDS place
+                zh_sync();
+                const uint32_t* T = a.dictTables->fse;
+                if ((modes >> 6) == 3) { for (uint32_t k = lane; k < (1u << de->llLog); k += 64) L.fse[ZD_FSE_LL + k] = T[ZD_FSE_LL + k]; st.llLog = de->llLog; }
+                if (((modes >> 4) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->ofLog); k += 64) L.fse[ZD_FSE_OF + k] = T[ZD_FSE_OF + k]; st.ofLog = de->ofLog; }
+                if (((modes >> 2) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->mlLog); k += 64) L.fse[ZD_FSE_ML + k] = T[ZD_FSE_ML + k]; st.mlLog = de->mlLog; }
+                zh_sync();
+            }
+            int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, sp, send); if (q < 0) return -q; sp += q;
+            q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, sp, send); if (q < 0) return -q; sp += q;
+            q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, sp, send); if (q < 0) return -q; sp += q;
+            if (sp >= send) return ZE_CORRUPTION;
+            zh_sync();
+            // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
+            uint32_t* const T = (uint32_t*)(a.fseTables + (size_t)t * ZP_FSE_CELLS);
+            zp_pack_fse(L, T, st.llLog, st.ofLog, st.mlLog);
+        }
+        m.logs = st.llLog | (st.ofLog << 8) | (st.mlLog << 16) | (allShared ? ZP_LOGS_SHARED : 0u);
+    }
+    m.seqOff = (uint32_t)(sp - src); m.seqEnd = pos + bs;
+    ZD_T(P, ZP_SEQTAB);
+    return 0;
+}
+
+// the item's place in K2's and K1b's work orders (KB below): its bin, and its rank inside the bin -- the atomic's return value (lane 0 calls)
+ZH_DEV void zp_enter_bins(const ZhipPipeArgs& a, ZdMeta& m)
+{
+    const uint32_t ks = m.nbSeq ? 1u + (m.nbSeq >> ZP_BIN_SHIFT) : 0u;
+    const uint32_t kl = (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
+    if (ks) m.pad = zh_atomic_add(a.counters + ZP_CNT_BINS + (256 - (ks > 256 ? 256u : ks)), 1u);
+    if (kl) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + (256 - (kl > 256 ? 256u : kl)), 1u) << 1;
+}
+ZH_DEV void zp_meta_clear(ZdMeta& m)
+{
+    m.status = 0; m.path = 0; m.seqOff = m.seqEnd = 0; m.litSize = 0; m.litMode = 0; m.litOff = 0; m.nbSeq = 0;
+    m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0; m.logs = 0; m.pad = 0;
+}
+
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -58,8 +176,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         if (i >= a.count) break;
         const uint32_t f = a.first + i;
         ZdMeta m;
-        m.status = 0; m.path = 0; m.seqOff = m.seqEnd = 0; m.litSize = 0; m.litMode = 0; m.litOff = 0; m.nbSeq = 0;
-        m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0; m.logs = 0; m.pad = 0;
+        zp_meta_clear(m);
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
         uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
@@ -71,40 +188,17 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (srcSize64 > 0x7FFFFFFFull) { fallback = true; break; }
             const uint32_t srcSize = (uint32_t)srcSize64;
             const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
-            const uint32_t mg = a.magicless ? 0u : 4u;                     // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
-            if (srcSize < mg + 1) { err = ZE_SRC_SIZE_WRONG; break; }
-            if (mg && zh_ld32(src) != ZF_MAGIC) { err = ZE_PREFIX_UNKNOWN; break; }
-            const uint32_t fhd = src[mg];
-            const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6, hasChecksum = (fhd >> 2) & 1;
-            const uint32_t dictBytes = dictCode == 3 ? 4 : dictCode;
-            const uint32_t fcsBytes = fcsCode == 0 ? single : (1u << fcsCode);
-            const uint32_t hs = mg + 1 + (single ? 0 : 1) + dictBytes + fcsBytes;
-            if (fhd & 8) { err = ZE_FRAMEPARAM_UNSUPPORTED; break; }
-            if (srcSize < hs) { err = ZE_SRC_SIZE_WRONG; break; }
-            uint32_t pos = mg + 1;
-            uint64_t windowSize = 0;
-            if (!single) {
-                const uint32_t wd = src[pos++], wl = 10 + (wd >> 3);
-                if (wl > 31) { err = ZE_WINDOW_TOO_LARGE; break; }
-                windowSize = 1ull << wl; windowSize += (windowSize >> 3) * (wd & 7);
-            }
-            {   const uint32_t dictID = dictCode == 0 ? 0u : dictCode == 1 ? src[pos] : dictCode == 2 ? zh_ld16(src + pos) : zh_ld32(src + pos);
-                pos += dictBytes;
-                if (dictID && dictID != a.dictID) { err = ZE_DICT_WRONG; break; } }     // ZSTD_decompressFrame's check (zstd.c:44246)
-            uint64_t fcs = ~0ull;
-            if (fcsCode == 0) { if (single) fcs = src[pos]; }
-            else if (fcsCode == 1) fcs = (uint64_t)zh_ld16(src + pos) + 256;
-            else if (fcsCode == 2) fcs = zh_ld32(src + pos);
-            else fcs = zh_ld64(src + pos);
-            pos += fcsBytes;
-            if (single) windowSize = fcs;
-            if (windowSize > a.maxWindowSize) { err = ZE_WINDOW_TOO_LARGE; break; }
-            const uint32_t blockMax = windowSize < ZF_BLOCK_MAX ? (uint32_t)windowSize : ZF_BLOCK_MAX;
+            ZpHdr h;
+            err = zp_frame_header(a, src, srcSize, h);
+            if (err) break;
+            const uint32_t blockMax = h.blockMax, hasChecksum = h.hasChecksum;
+            const uint64_t fcs = h.fcs;
+            uint32_t pos = h.pos;
             m.blockMax = blockMax; m.fcsLo = (uint32_t)fcs; m.fcsHi = (uint32_t)(fcs >> 32);
             if (pos + 3 > srcSize) { err = ZE_SRC_SIZE_WRONG; break; }
             const uint32_t bh = zh_ld24(src + pos); pos += 3;
             const uint32_t lastBlock = bh & 1, type = (bh >> 1) & 3, bs = bh >> 3;
-            if (!lastBlock) { fallback = true; break; }                      // multi-block frame
+            if (!lastBlock) { fallback = true; break; }                      // a frame of several blocks (the several-block mode's: zp_lit_mb_body)
             if (type == 3) { err = ZE_CORRUPTION; break; }
             // (block sizes against the frame's maximum: libzstd's one-pass / streaming split, see zd_frame in zhip_decode_kernel.hpp)
             const bool onePass = fcs != ~0ull && cap64 >= fcs;
@@ -133,8 +227,6 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (bs < 2) { err = ZE_CORRUPTION; break; }
             ZdState st;
             st.rep0 = 1; st.rep1 = 4; st.rep2 = 8; st.hufCount = 0; st.llLog = st.ofLog = st.mlLog = 0xFF;
-            uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
-            st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
             ZD_T(P, ZP_HEADER);
             ZdLitDefer df; df.table = a.hufTables + (size_t)i * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
             df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = nullptr; df.prevLog = 0; df.shared = 0; df.shareOK = 1;
@@ -144,57 +236,8 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 if (a.dictTables->hufLog <= ZP_HUF_LOGMAX) { df.prevTable = a.dictTables->huf; df.prevLog = a.dictTables->hufLog; }
                 else { zh_sync(); for (uint32_t k = lane; k < 256; k += 64) L.weights[k] = de->hufWeights[k]; zh_sync(); }
             }
-            const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
-            if (r < 0) { err = -r; break; }
-            m.litSize = st.litSize;
-            if (df.taken) { m.litMode = 3u | (df.log << 8) | (df.four << 16) | (df.shared ? ZP_LIT_SHARED : 0u); m.litOff = (uint32_t)(df.streams - src); m.produced = df.streamBytes; }
-            else if (st.litRLE) { m.litMode = 2; m.litOff = st.rleByte; }
-            else if (st.litPtr == lit) { m.litMode = 1; m.litOff = 0; }
-            else { m.litMode = 0; m.litOff = (uint32_t)(st.litPtr - src); }
-            {   // sequences header (RFC 8878 3.1.1.3.2): count, compression modes, table descriptions -> FSE tables for K2
-                const uint8_t* sp = src + pos + (uint32_t)r; const uint8_t* const send = src + pos + bs;
-                if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
-                uint32_t nbSeq = *sp++;
-                if (nbSeq > 127) {
-                    if (nbSeq == 255) { if (sp + 2 > send) { err = ZE_SRC_SIZE_WRONG; break; } nbSeq = zh_ld16(sp) + 0x7F00; sp += 2; }
-                    else { if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; } nbSeq = ((nbSeq - 128) << 8) + *sp++; }
-                }
-                m.nbSeq = nbSeq;
-                if (nbSeq == 0) { if (sp != send) { err = ZE_CORRUPTION; break; } }
-                else {
-                    if (nbSeq > ZP_SEQ_CAP - 16) { err = ZE_CORRUPTION; break; }      // (> 43 690 cannot fit a block; K2 stores a few slots past the longest frame of its wave and parks idle lanes' stores in the last)
-                    if (sp >= send) { err = ZE_SRC_SIZE_WRONG; break; }
-                    const uint32_t modes = *sp++;
-                    if (modes & 3) { err = ZE_CORRUPTION; break; }
-                    // every table "repeat" in a dictionary frame: the tables ARE the dictionary's, ready-made in K2's form (ZhipDictTables.fseK2):
-                    // nothing to build, nothing to write -- K2 copies them from there
-                    const bool allShared = de && (modes >> 2) == 0x3F;
-                    if (allShared) {
-                        st.llLog = de->llLog; st.ofLog = de->ofLog; st.mlLog = de->mlLog;
-                        if (sp >= send) { err = ZE_CORRUPTION; break; }
-                    } else {
-                    if (de) {                                               // "repeat" takes the dictionary's table: drop it into its LDS place
-                        zh_sync();
-                        const uint32_t* T = a.dictTables->fse;
-                        if ((modes >> 6) == 3) { for (uint32_t k = lane; k < (1u << de->llLog); k += 64) L.fse[ZD_FSE_LL + k] = T[ZD_FSE_LL + k]; st.llLog = de->llLog; }
-                        if (((modes >> 4) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->ofLog); k += 64) L.fse[ZD_FSE_OF + k] = T[ZD_FSE_OF + k]; st.ofLog = de->ofLog; }
-                        if (((modes >> 2) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->mlLog); k += 64) L.fse[ZD_FSE_ML + k] = T[ZD_FSE_ML + k]; st.mlLog = de->mlLog; }
-                        zh_sync();
-                    }
-                    int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
-                    q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
-                    q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, sp, send); if (q < 0) { err = -q; break; } sp += q;
-                    if (sp >= send) { err = ZE_CORRUPTION; break; }
-                    zh_sync();
-                    // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
-                    uint32_t* const T = (uint32_t*)(a.fseTables + (size_t)i * ZP_FSE_CELLS);
-                    zp_pack_fse(L, T, st.llLog, st.ofLog, st.mlLog);
-                    }
-                    m.logs = st.llLog | (st.ofLog << 8) | (st.mlLog << 16) | (allShared ? ZP_LOGS_SHARED : 0u);
-                }
-                m.seqOff = (uint32_t)(sp - src); m.seqEnd = pos + bs;
-                ZD_T(P, ZP_SEQTAB);
-            }
+            err = zp_block_tables(a, L, st, df, src, pos, bs, blockMax, i, m, P, true, false);
+            if (err) break;
             if (hasChecksum) {
                 if (pos + bs + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
                 m.hasChecksum = 1; m.checksum = zh_ld32(src + pos + bs);
@@ -205,13 +248,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         if (err) { m.status = err; m.path = 0; }
         zh_sync();
         if (zh_opaque(lane) == 0) {
-            if (m.path == 1) {
-                // the frame's place in K2's and K1b's work orders (KB below): its bin, and its rank inside the bin -- the atomic's return value
-                const uint32_t ks = m.nbSeq ? 1u + (m.nbSeq >> ZP_BIN_SHIFT) : 0u;
-                const uint32_t kl = (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
-                if (ks) m.pad = zh_atomic_add(a.counters + ZP_CNT_BINS + (256 - (ks > 256 ? 256u : ks)), 1u);
-                if (kl) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + (256 - (kl > 256 ? 256u : kl)), 1u) << 1;
-            }
+            if (m.path == 1) zp_enter_bins(a, m);
             a.meta[i] = m;
             if (m.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
@@ -220,6 +257,136 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         zd_fence();              // (orders the emulator's free-running lanes; on the device the wave is in order and what K1 writes is read by LATER kernels --
 #endif                           //  a fence here only made every frame wait out its own stores' round trip: ~2 us of the ~40 a 4 KiB dictionary frame takes, r03l)
         if (P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + q, P.acc[q]); }
+    }
+}
+
+// K1 of the several-block mode (ZpFrameRec in zhip_format.hpp): a wave per frame walks the block headers, claims one item per block and
+// prepares them in order -- what a block inherits from the one before (Huffman table of a "treeless" literals section, FSE tables in
+// "repeat" mode: RFC 8878 3.1.1.3.1.1 / 3.1.1.3.2.1) is this wave's own earlier work: the FSE tables stay in LDS from block to block, the
+// Huffman table is copied from the slot of the last block that carried one. Anything unusual about the block LAYOUT (truncation, a
+// reserved type, more blocks than item slots) sends the frame to the generic kernel, which answers in stream order like libzstd.
+ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
+    if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
+    zh_sync();
+    for (;;) {
+        const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
+        if (zh_opaque(lane) == 0) L.misc[7] = got;
+        zh_sync();
+        const uint32_t i = zh_first(L.misc[7]);
+        zh_sync();
+        if (i >= a.count) break;
+        const uint32_t f = a.first + i;
+        const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+        const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+        const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
+        ZpFrameRec rec; rec.firstItem = 0; rec.nItems = 0; rec.path = 0; rec.blockMax = 0; rec.fcsLo = rec.fcsHi = 0xFFFFFFFFu; rec.hasChecksum = 0; rec.checksum = 0;
+        int err = 0; bool fallback = false;
+        ZdProf P; P.on = false;
+        do {
+            if (srcSize64 > 0x7FFFFFFFull) { fallback = true; break; }
+            const uint32_t srcSize = (uint32_t)srcSize64;
+            ZpHdr h;
+            err = zp_frame_header(a, src, srcSize, h);
+            if (err) break;
+            const uint32_t blockMax = h.blockMax;
+            const uint64_t fcs = h.fcs;
+            rec.blockMax = blockMax; rec.fcsLo = (uint32_t)fcs; rec.fcsHi = (uint32_t)(fcs >> 32);
+            const bool onePass = fcs != ~0ull && cap64 >= fcs;
+            // ---- the block layout
+            uint32_t nb = 0, end = h.pos;
+            for (;;) {
+                if (end + 3 > srcSize) { fallback = true; break; }
+                const uint32_t bh = zh_ld24(src + end);
+                const uint32_t type = (bh >> 1) & 3, bs = bh >> 3, body = type == 1 ? 1u : bs;
+                if (type == 3 || end + 3 + body > srcSize || ++nb > ZP_MB_MAXBLOCKS) { fallback = true; break; }
+                end += 3 + body;
+                if (bh & 1) break;
+            }
+            if (fallback) break;
+            if (h.hasChecksum) {
+                if (end + 4 > srcSize) { fallback = true; break; }
+                rec.hasChecksum = 1; rec.checksum = zh_ld32(src + end);
+            }
+            // ---- nb consecutive items (a frame that does not get them is the generic kernel's; a partly granted range is marked unused)
+            zh_sync();
+            if (zh_opaque(lane) == 0) L.misc[6] = zh_atomic_add(a.counters + 6, nb);
+            zh_sync();
+            const uint32_t base = zh_first(L.misc[6]);
+            zh_sync();
+            if (base + nb > a.itemCap || base + nb < base) {
+                ZdMeta z; zp_meta_clear(z);
+                for (uint32_t t = base + lane; t < a.itemCap && t - base < nb; t += 64) { a.meta[t] = z; a.itemFrame[t] = i; }
+                fallback = true; break;
+            }
+            rec.firstItem = base; rec.nItems = nb;
+            // ---- the blocks
+            ZdState st;
+            st.rep0 = 1; st.rep1 = 4; st.rep2 = 8; st.hufCount = 0; st.llLog = st.ofLog = st.mlLog = 0xFF;
+            const uint16_t* prevTable = nullptr; uint32_t prevLog = 0;
+            const ZhipDictEntropy* const de = a.dictEntropy;
+            if (de) {                                                       // the dictionary's tables are the first block's "previous" ones
+                st.hufCount = de->hufCount;
+                if (a.dictTables->hufLog <= ZP_HUF_LOGMAX) { prevTable = a.dictTables->huf; prevLog = a.dictTables->hufLog; }
+                zh_sync();
+                for (uint32_t k = lane; k < 256; k += 64) L.weights[k] = de->hufWeights[k];
+                const uint32_t* T = a.dictTables->fse;
+                for (uint32_t k = lane; k < 1280; k += 64) L.fse[k] = T[k];
+                st.llLog = de->llLog; st.ofLog = de->ofLog; st.mlLog = de->mlLog;
+                zh_sync();
+            }
+            uint32_t pos = h.pos;
+            for (uint32_t j = 0; j < nb; j++) {
+                const uint32_t t = base + j;
+                ZdMeta m; zp_meta_clear(m);
+                const uint32_t bh = zh_ld24(src + pos); pos += 3;
+                const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+                if (err) { /* a block before this one failed: the item stays unused */ }
+                else if (type < 2) {
+                    if (bs > blockMax && !onePass) err = ZE_CORRUPTION;
+                    else { m.path = type == 0 ? 3u : 4u; m.litSize = bs; m.litOff = type == 0 ? pos : (uint32_t)src[pos]; }
+                } else if (bs > blockMax) err = onePass ? ZE_SRC_SIZE_WRONG : ZE_CORRUPTION;
+                else if (bs < 2) err = ZE_CORRUPTION;
+                else {
+                    ZdLitDefer df; df.table = a.hufTables + (size_t)t * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
+                    df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = prevTable; df.prevLog = prevLog; df.shared = 0; df.shareOK = 0;
+                    err = zp_block_tables(a, L, st, df, src, pos, bs, blockMax, t, m, P, false, true);
+                    if (!err) {
+                        m.path = 1;
+                        const uint32_t lt = src[pos] & 3;                      // literals block type: 2 = a Huffman table of its own, 3 = treeless
+                        if (lt >= 2) {
+                            // the table a later treeless block inherits: in this item's slot when K1b decodes (df.taken); a table too deep for
+                            // the slots was used right here and the next treeless block rebuilds it from the weights still in LDS
+                            if (df.taken) { prevTable = df.table; prevLog = df.log; } else { prevTable = nullptr; prevLog = 0; }
+                        }
+                    }
+                }
+                if (err && m.status == 0) { m.status = err; m.path = 0; }
+                pos += type == 1 ? 1u : bs;
+                zh_sync();
+                if (zh_opaque(lane) == 0) {
+                    if (m.path == 1) zp_enter_bins(a, m);
+                    a.meta[t] = m; a.itemFrame[t] = i;
+                }
+                zh_sync();
+            }
+            // the first failing block decides the frame's answer -- K3 meets it in stream order (blocks before it may still be refused by K1b / K2)
+            err = 0;
+            rec.path = 1;
+        } while (false);
+        if (fallback) rec.path = 2;
+        if (err) rec.path = 0;
+        zh_sync();
+        if (zh_opaque(lane) == 0) {
+            a.frameRecs[i] = rec;
+            if (rec.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
+            if (rec.path == 0) { a.status[f] = err; a.outSizes[f] = 0; }
+        }
+#ifdef ZHIP_EMU
+        zd_fence();
+#endif
     }
 }
 
@@ -275,7 +442,8 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
         L.base[4 * lane] = b0; L.base[4 * lane + 1] = b0 + h0; L.base[4 * lane + 2] = b0 + h0 + h1; L.base[4 * lane + 3] = b0 + h0 + h1 + h2;
         if (blk == 0 && lane == 63) a.counters[lit ? 4 : 1] = incl; }
     zh_sync();
-    for (uint32_t i = blk * 64 + lane; i < a.count; i += half * 64) {
+    const uint32_t nItems = !a.itemCap ? a.count : a.counters[6] < a.itemCap ? a.counters[6] : a.itemCap;      // several-block mode: the items K1 claimed
+    for (uint32_t i = blk * 64 + lane; i < nItems; i += half * 64) {
         const ZdMeta* m = a.meta + i;
         const uint32_t path = m->path, ns = m->nbSeq, lm = m->litMode, ls = m->litSize, rs = m->pad, rl = m->hasChecksum >> 1;
         const uint32_t k = path != 1 ? 0u : lit ? ((lm & 255u) == 3u ? 1u + (ls >> ZP_LITBIN_SHIFT) : 0u) : (ns ? 1u + (ns >> ZP_BIN_SHIFT) : 0u);
@@ -454,7 +622,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
         zh_sync();
         bool ok = true;
         if (active) {
-            const uint32_t f = a.first + i;
+            const uint32_t f = a.first + (a.itemCap ? a.itemFrame[i] : i);
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
             if (!four) { if (strm == 0) ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p, streamBytes, lit, litSize, L.ring + lane); }
@@ -473,8 +641,8 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
         const uint64_t badMask = zh_ballot(!ok);
         if (active && strm == 0 && ((badMask >> (4 * slot)) & 15)) {
             ZdMeta* m = a.meta + i;
-            const uint32_t f = a.first + i;
-            m->status = ZE_CORRUPTION; m->path = 0; a.status[f] = ZE_CORRUPTION; a.outSizes[f] = 0;
+            m->status = ZE_CORRUPTION; m->path = 0;
+            if (!a.itemCap) { const uint32_t f = a.first + i; a.status[f] = ZE_CORRUPTION; a.outSizes[f] = 0; }      // (several-block mode: K3 answers for the frame when it meets the item)
         }
         zd_fence();
         zh_sync();
@@ -559,7 +727,7 @@ ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8
         const uint32_t offset = isRep ? ro : ofv - 3;
         const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1);
         rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0;
-        bad |= offset >> ZP_SEQ_OFBITS;
+        bad |= offset >= ZP_OF_LIMIT;
         out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 3)) << 32);
         if (last) break;
         n++;
@@ -666,6 +834,10 @@ ZH_DEV ZpVec16 zq_fetch(const uint8_t* p0, int32_t off) { return *(const ZpVec16
 #else
 #define ZQ_F2() do { } while (0)
 #endif
+// MB: the several-block mode (ZpFrameRec, zhip_format.hpp) -- the item is a block: its frame comes from itemFrame, a block that is not its
+// frame's first starts from the SYMBOLIC history, and the history after the block's last sequence is kept for K3 (four more instructions
+// per step: a separate instantiation, the single-block kernel is untouched)
+template <bool MB>
 ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 {
     const uint32_t lane = zh_lane(), role = lane & 3, slot = lane >> 2;
@@ -705,7 +877,8 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         const bool idle = isSpare || !active;                                      // idle lanes decode the one-cell table: no bits, the same state for ever
         const uint16_t* const Tm = idle ? (const uint16_t*)&L.spare : (const uint16_t*)(L.tab + (size_t)slot * ZP_K2_STRIDE) + tabOff;
         ZdMeta* const m = a.meta + (active ? i : 0u);
-        const uint32_t f = a.first + (active ? i : 0u);
+        const uint32_t fi = active ? (MB ? a.itemFrame[i] : i) : 0u;
+        const uint32_t f = a.first + fi;
         uint32_t nbSeq = 0, logs = 0;
         int32_t pos = 0, pb = -(1 << 30), fin = 0;
         const uint8_t* p0 = nullptr;
@@ -745,6 +918,8 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 5;                  // trip n produces sequence n - 1 (software pipeline); a group of four is stored at the next group's first trip
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
         if (a.dictEntropy) { rep0 = a.dictEntropy->rep[0]; rep1 = a.dictEntropy->rep[1]; rep2 = a.dictEntropy->rep[2]; }     // ZSTD_loadDEntropy's start history
+        if (MB && active && a.frameRecs[fi].firstItem != i) { rep0 = ZP_SYM_REP(0); rep1 = ZP_SYM_REP(1); rep2 = ZP_SYM_REP(2); }
+        uint32_t fin0 = rep0, fin1 = rep1, fin2 = rep2, finMax = 0;  // (MB) the history, and the largest value, after the block's LAST sequence (the trips go on to the wave's longest block)
         // (taken into registers HERE: left pending, the loads made the waitcnt pass put a conservative vmcnt wait at the loop's first use of
         // the history -- behind the ring's block load, whose round trip it then sat out every four steps: 5.6 -> 8.2 ms, r02x)
         rep0 = zh_opaque(rep0); rep1 = zh_opaque(rep1); rep2 = zh_opaque(rep2);
@@ -781,7 +956,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
                 const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
                 const uint32_t idx = val - 1 + (llv == 0);
-                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); here it trips `bad` below -> generic kernel -> refused
+                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); here it trips `bad` below -> generic kernel -> refused (MB: K3 refuses it)
                 const uint32_t c3 = val <= 3 ? r0m1 : val - 3;
                 uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
                 ZQ_F2();
@@ -792,6 +967,13 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 ZQ_F2();
                 // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
                 rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
+                if (MB) {
+                    // symbolic entries look like huge offsets: the largest NEW offset is watched instead (value - 3; values 1..3 are the repeat
+                    // codes), "no such offset" travels on to K3 as a value above ZP_SYM_TOP. Trip n has just applied sequence n - 1.
+                    maxOff = val > maxOff ? val : maxOff;
+                    const bool wasLast = n == nbSeq;
+                    fin0 = wasLast ? rep0 : fin0; fin1 = wasLast ? rep1 : fin1; fin2 = wasLast ? rep2 : fin2; finMax = wasLast ? maxOff : finMax;
+                } else
                 maxOff = offset > maxOff ? offset : maxOff;
                 {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 3);
                     if (u == 0) {                                                     // (compile-time: the loop is unrolled)
@@ -823,13 +1005,14 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             // wait (vmcnt counts in order) also sat out the ring's block load issued just before it -- a load round trip per group (r02x)
             ZH_KEEP4(w0.a, w0.b, w0.c, w0.d); ZH_KEEP4(w1.a, w1.b, w1.c, w1.d);
         }
-        const uint32_t bad = maxOff >> ZP_SEQ_OFBITS;
+        const bool bad = MB ? finMax >= ZP_OF_LIMIT + 3 : maxOff >= ZP_OF_LIMIT;
         if (active && isOF) {
             const int err = !ok ? ZE_CORRUPTION : bad ? ZE_PARAM_UNSUPPORTED : posEnd != fin ? ZE_CORRUPTION : 0;
             if (err == ZE_PARAM_UNSUPPORTED) {                                 // an offset does not fit the packed form: the generic kernel's
-                m->path = 2;
-                const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
-            } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
+                m->path = 2;                                                   // (several-block mode: K3 hands the frame over when it meets the item)
+                if (!MB) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f; }
+            } else if (err) { m->status = err; m->path = 0; if (!MB) { a.status[f] = err; a.outSizes[f] = 0; } }
+            if (MB) { uint32_t* r = a.itemReps + 4 * (size_t)i; r[0] = fin0; r[1] = fin1; r[2] = fin2; }
         }
         zh_sync();
     }
@@ -887,24 +1070,34 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 // PROF: the phase timers (ZHIP_PROF=1) are a SEPARATE instantiation. As a run-time flag their eleven 64-bit accumulators lived in VGPRs of the
 // production kernel (its 100 SGPRs are taken): 97 -> 77 VGPRs without them, i.e. a sixth wave per SIMD (r03n)
 #define ZD_TP(P, i) do { if (PROF) ZD_T(P, i); } while (0)
-template <bool DICT, bool PROF>
-ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
+// what a packed offset stands for once the frame's history at the block's start (R0, R1, R2) is known: itself, or -- several-block mode,
+// ZP_SYM_REP in zhip_format.hpp -- entry k of that history minus d; 0xFFFFFFFF = no such offset (libzstd: corruption, zstd.c:46941)
+ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2)
+{
+    if (v <= ZP_OF_LIMIT) return v;
+    if (v > ZP_SYM_TOP) return 0xFFFFFFFFu;
+    const uint32_t k = (v - (ZP_OF_LIMIT + 1)) >> 23;
+    const uint32_t d = ZP_SYM_REP(k) - v;
+    const uint32_t r = k == 0 ? R0 : k == 1 ? R1 : R2;
+    return r > d ? r - d : 0xFFFFFFFFu;
+}
+
+// One compressed block: the sequences K2 left in slot `t`, the literals of slot `t` (or in place), executed at output position `opRef` of
+// the frame at `dst` (MB = false: the frame's only block, position 0). m = the block's record. 0 or a zstd error code.
+template <bool DICT, bool PROF, bool MB>
+ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint8_t* dst, uint32_t cap, uint64_t cap64,
+                           uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
-    const ZdMeta m = a.meta[i];
-    const uint32_t f = a.first + i;
-    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
-    uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
-    const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
-    const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
-    const uint64_t* seqs = a.seqArena + (size_t)i * ZP_SEQ_CAP;
+    const uint64_t* seqs = a.seqArena + (size_t)t * ZP_SEQ_CAP;
     const bool litRLE = m.litMode == 2;
     const uint32_t rleByte = m.litOff;
-    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)i * ZP_LIT_STRIDE;
+    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)t * ZP_LIT_STRIDE;
     const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
     const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;
-    uint32_t op = 0, lp = 0, done = 0;
+    const uint32_t blockStart = MB ? opRef : 0u;
+    uint32_t op = blockStart, lp = 0, done = 0;
     // The flush writes whole 16-byte units only: the last `carry` (< 16) bytes of a batch stay at the front of the assembly buffer and leave
     // with the next batch (r03e: the byte-wise tail of every flush -- one lane, up to 15 trips of an LDS read and a byte store -- was a
     // third of the flush phase, 157 K -> 101 K wave-cycles per frame, and made every later store of the frame unaligned). asmb[0] is the byte
@@ -923,7 +1116,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
 #endif
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
-        if (lane < avail) { const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); }
+        if (lane < avail) { const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); if (MB) myOF = zp_sym_resolve(myOF, R0, R1, R2); }
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer (behind the carried bytes)
         const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES);
@@ -938,7 +1131,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
         const uint32_t totL = zh_bcast(incL, cnt - 1), totT = zh_bcast(incT, cnt - 1);
         if (lp + totL > m.litSize) return ZE_CORRUPTION;
         if ((uint64_t)op + totT > cap) return ZE_DST_TOO_SMALL;
-        if (op + totT > m.blockMax) return ZE_CORRUPTION;
+        if (op + totT - blockStart > blockMax) return ZE_CORRUPTION;
         const uint32_t litStart = lp + incL - myLL;
         const uint32_t ob = op - carry;
         const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
@@ -1227,28 +1420,97 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     zd_fence();
     const uint32_t rest = m.litSize - lp;
     if ((uint64_t)op + rest > cap) return ZE_DST_TOO_SMALL;
-    if (op + rest > m.blockMax) return ZE_CORRUPTION;
+    if (op + rest - blockStart > blockMax) return ZE_CORRUPTION;
     if (litRLE) zd_fill_wave(dst + op, rleByte, rest); else zd_copy_wave(dst + op, litPtr + lp, rest);
     op += rest;
-    const uint64_t fcs = (uint64_t)m.fcsLo | ((uint64_t)m.fcsHi << 32);
+#ifdef ZP_K3_PREFETCH
+    if (pfSink == 0xFFFFFFFFu && op == 0xFFFFFFFFu) dst[0] = 0;          // never: pfSink holds bytes; keeps the prefetch loads alive
+#endif
+    opRef = op;
+    return 0;
+}
+
+// what ends a frame: the content size it announced, its checksum (zstd.c:44264-44277). All lanes call.
+ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, uint32_t fcsLo, uint32_t fcsHi, uint32_t hasChecksum, uint32_t checksum)
+{
+    const uint32_t lane = zh_lane();
+    const uint64_t fcs = (uint64_t)fcsLo | ((uint64_t)fcsHi << 32);
     if (fcs != ~0ull && fcs != op) return ZE_CORRUPTION;
-    if (m.hasChecksum & 1) {
+    if (hasChecksum & 1) {
         zd_fence();
         zh_sync();
         if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, op);
         zh_sync();
         const uint32_t digest = zh_first(L.misc[0]);
         zh_sync();
-        if (digest != m.checksum) return ZE_CHECKSUM_WRONG;
+        if (digest != checksum) return ZE_CHECKSUM_WRONG;
     }
-#ifdef ZP_K3_PREFETCH
-    if (pfSink == 0xFFFFFFFFu && op == 0xFFFFFFFFu) dst[0] = 0;          // never: pfSink holds bytes; keeps the prefetch loads alive
-#endif
-    *pProduced = op;
     return 0;
 }
 
 template <bool DICT, bool PROF>
+ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
+{
+    const ZdMeta m = a.meta[i];
+    const uint32_t f = a.first + i;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
+    const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
+    const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
+    uint32_t op = 0;
+    int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
+    if (e) return e;
+    e = zp_exec_frame_end(L, dst, op, m.fcsLo, m.fcsHi, m.hasChecksum, m.checksum);
+    if (e) return e;
+    *pProduced = op;
+    return 0;
+}
+
+// a frame of the several-block mode (ZpFrameRec, zhip_format.hpp): its items in order. Raw and RLE blocks are copied / filled here; a
+// compressed block's symbolic offsets get their numbers from the history R the blocks before it left, and leave theirs (K2's itemReps).
+// An item K1 / K1b / K2 refused ends the frame with that answer -- the first one in stream order, like libzstd; an item K2 could not
+// pack sends the frame to the generic kernel (ZP_RC_FALLBACK).
+template <bool DICT>
+ZH_DEVFN int zp_exec_frame_mb(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
+{
+    const ZpFrameRec rec = a.frameRecs[i];
+    const uint32_t f = a.first + i;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
+    const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
+    const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
+    uint32_t R0 = 1, R1 = 4, R2 = 8;
+    if (a.dictEntropy) { R0 = a.dictEntropy->rep[0]; R1 = a.dictEntropy->rep[1]; R2 = a.dictEntropy->rep[2]; }
+    uint32_t op = 0;
+    for (uint32_t bi = 0; bi < rec.nItems; bi++) {
+        const uint32_t t = rec.firstItem + bi;
+        const ZdMeta m = a.meta[t];
+        if (m.path == 0) return m.status ? m.status : ZE_CORRUPTION;
+        if (m.path == 2) return ZP_RC_FALLBACK;
+        if (m.path >= 3) {
+            const uint32_t size = m.litSize;
+            if ((uint64_t)op + size > cap) return ZE_DST_TOO_SMALL;
+            if (m.path == 3) zd_copy_wave(dst + op, src + m.litOff, size); else zd_fill_wave(dst + op, m.litOff, size);
+            zd_fence();
+            op += size;
+            continue;
+        }
+        const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
+        if (e) return e;
+        zd_fence();
+        if (m.nbSeq) {
+            const uint32_t* r = a.itemReps + 4 * (size_t)t;
+            const uint32_t n0 = zp_sym_resolve(r[0], R0, R1, R2), n1 = zp_sym_resolve(r[1], R0, R1, R2), n2 = zp_sym_resolve(r[2], R0, R1, R2);
+            R0 = n0; R1 = n1; R2 = n2;
+        }
+    }
+    const int e = zp_exec_frame_end(L, dst, op, rec.fcsLo, rec.fcsHi, rec.hasChecksum, rec.checksum);
+    if (e) return e;
+    *pProduced = op;
+    return 0;
+}
+
+template <bool DICT, bool PROF, bool MB = false>
 ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -1256,10 +1518,10 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
     // without sequences by index) so that the launch's tail is made of short frames -- MEASURED SLOWER (r03f: 12.95 against 12.18 ms per 65 536
     // frames): with every wave on a many-sequence frame at the same time the far-match gathers of 4 096 waves peak together (stage phase 758 K ->
     // 861 K wave-cycles per frame); the corpus' own mix of heavy and light frames spreads them.
-#ifndef ZP_K3_SORTED_ORDER
+#if !defined(ZP_K3_SORTED_ORDER)
     const uint32_t ordered = 0;
 #else
-    const uint32_t ordered = a.counters[1];
+    const uint32_t ordered = MB ? 0u : a.counters[1];
 #endif
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 2, lane == 0 ? 1u : 0u);
@@ -1269,17 +1531,25 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
         zh_sync();
         if (k >= ordered + a.count) break;
         const uint32_t i = k < ordered ? a.order[k] : k - ordered;
+        if (MB) { if (a.frameRecs[i].path != 1) continue; }
+        else {
 #ifndef ZP_K3_SORTED_ORDER
         if (a.meta[i].path != 1) continue;
 #else
         if (a.meta[i].path != 1 || (k >= ordered && a.meta[i].nbSeq != 0)) continue;
 #endif
+        }
         uint32_t produced = 0;
         ZdProf P; P.on = PROF && a.prof != nullptr;
         if (PROF && P.on) { for (int q = 0; q < ZP_N; q++) P.acc[q] = 0; P.t0 = zd_clock(); }
-        const int err = zp_exec_frame<DICT, PROF>(a, L, i, &produced, P);
+        int err;
+        if constexpr (MB) err = zp_exec_frame_mb<DICT>(a, L, i, &produced, P);
+        else err = zp_exec_frame<DICT, PROF>(a, L, i, &produced, P);
         if (PROF && P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
         zh_sync();
-        if (zh_opaque(lane) == 0) { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }
+        if (zh_opaque(lane) == 0) {
+            if (MB && err == ZP_RC_FALLBACK) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = a.first + i; }
+            else { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }
+        }
     }
 }

@@ -226,6 +226,26 @@ struct ZdMeta {
 
 #define ZP_CNT_BINS 8u                                  // counters[8 .. 8 + 512): the 256 + 256 bin counters of the two work orders
 #define ZP_CNT_WORDS (8u + 512u)
+
+// ---- frames of SEVERAL blocks through the same kernels (the chunk's `itemCap` != 0): the work item of K1b / K2 is a BLOCK. K1 (a wave per
+// frame) walks the frame's blocks, claims that many consecutive items and fills one ZdMeta each (offsets still relative to the frame's first
+// byte; path 3 / 4 = a raw / RLE block: litOff = source offset / the byte, litSize = its size), K3 (a wave per frame) executes the frame's
+// items in order. The repeat-offset history crosses block boundaries, K2's items do not wait for each other: the history a later block
+// starts with is SYMBOLIC -- three reserved values in the packed offset field standing for "what the frame's history holds here", minus how
+// often RFC 8878's "repeat offset 1 minus one" was applied to it -- and K3, which knows the history at each block's start, puts the
+// numbers in. K2 leaves each block's final history (same encoding) in itemReps.
+struct ZpFrameRec {
+    uint32_t firstItem, nItems;
+    uint32_t path;              // 1: K3 executes it; 0: finished (status written by K1); 2: the generic kernel's
+    uint32_t blockMax;
+    uint32_t fcsLo, fcsHi;
+    uint32_t hasChecksum, checksum;
+};
+#define ZP_OF_LIMIT 0x1E000000u                           // real offsets stay below this (K2 sends frames with larger ones to the generic kernel)
+#define ZP_SYM_REP(k) (0x1E800000u + ((uint32_t)(k) << 23))   // history entry k of the block's start; minus d = that entry minus d (d < 2^23)
+#define ZP_SYM_TOP ZP_SYM_REP(2)                          // values above it (K2's "no such offset" = 0xFFFFFFFF cut to 29 bits) are refused
+#define ZP_MB_MAXBLOCKS 4096u                             // frames of more blocks are the generic kernel's
+#define ZP_RC_FALLBACK 0x7FFF0002                         // K3's "hand this frame to the generic kernel"
 struct ZhipPipeArgs {
     const uint8_t* src; const uint64_t* srcSegs;
     uint8_t* dst; const uint64_t* dstSegs;
@@ -238,10 +258,15 @@ struct ZhipPipeArgs {
     uint16_t* hufTables;        // chunk x ZP_HUF_CELLS : Huffman decoding tables (symbol | nbBits << 8) for K1b
     uint32_t* orderLit;         // chunk : K1b's work list (frames with Huffman literals, by decreasing literal count)
     uint32_t* counters;         // per chunk slot (ZP_CNT_WORDS words): [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
-                                //                 [4] length of `orderLit`, [5] K1b group counter
+                                //                 [4] length of `orderLit`, [5] K1b group counter, [6] items claimed (several-block mode)
     uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk
+    // several-block mode (see ZpFrameRec): all null / 0 otherwise -- then item == frame and none of these is read
+    uint32_t itemCap;           // item slots of this chunk's arenas (meta, literals, sequences, tables, orders are then per ITEM)
+    uint32_t* itemFrame;        // itemCap : the chunk-local frame an item belongs to
+    uint32_t* itemReps;         // itemCap x 4 : the history after the block's last sequence, as K2 saw it (symbolic entries possible)
+    ZpFrameRec* frameRecs;      // count
     uint64_t maxWindowSize;
     uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
     unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases

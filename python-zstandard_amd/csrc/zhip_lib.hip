@@ -46,7 +46,18 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_huf_kernel(ZhipPipeArgs a)
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)           // K2: a quad of lanes per frame, four waves per CU
 {
     __shared__ ZpSeqQLDS L;
-    zp_seqq_body(a, L);
+    zp_seqq_body<false>(a, L);
+}
+// ---- frames of several blocks (ZpFrameRec in zhip_format.hpp): K1 per frame over its blocks, K2 per block, K3 per frame over its blocks
+ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_mb_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZdLDS L;
+    zp_lit_mb_body(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_mb_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpSeqQLDS L;
+    zp_seqq_body<true>(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)          // rounds 1-2 form (a lane per frame, one wave per CU): ZHIP_K2_QUAD=0, A/B only
 {
@@ -74,6 +85,16 @@ ZH_GLOBAL __launch_bounds__(64, ZP_K3D_MINWAVES) void zhip_decode_exec_dict_kern
 {
     __shared__ ZpExecLDS L;
     zp_exec_body<true, false>(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64, 4) void zhip_decode_exec_mb_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpExecLDS L;
+    zp_exec_body<false, false, true>(a, L);
+}
+ZH_GLOBAL __launch_bounds__(64, 4) void zhip_decode_exec_mb_dict_kernel(ZhipPipeArgs a)
+{
+    __shared__ ZpExecLDS L;
+    zp_exec_body<true, false, true>(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs a)
 {
@@ -263,7 +284,7 @@ struct zhip_ctx {
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
-    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit;
+    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
     int e1PerCU = 0, e2PerCU = 0;
@@ -290,7 +311,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -299,7 +320,7 @@ struct zhip_ctx {
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
     size_t device_bytes() const
     {
-        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &encWorkspace, &encMeta, &encArena,
+        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &encWorkspace, &encMeta, &encArena,
                                &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
@@ -325,6 +346,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
         if (const char* e = getenv("ZHIP_SPLIT")) k.split = atol(e) != 0;
+        if (const char* e = getenv("ZHIP_BLOCKS")) k.blocks = atol(e) != 0;        // 0: frames of several blocks go to the generic kernel as in rounds 1-2 (A/B)
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
@@ -375,7 +397,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
-    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release();
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
@@ -568,7 +590,17 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
         const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured on MI355X (profiles/README.md, r01c / r02f / r02zl): 65 536 frames per chunk, 2 slots
-        const size_t chunk = n < chunkMax ? n : chunkMax;
+        // Frames of several blocks (the caller's size hint says so: the host API sets it from the items it sees): the several-block mode --
+        // the arenas' slots are per BLOCK, a chunk is as many frames as fit `chunkMax` slots at the estimate below (libzstd cuts a block of
+        // 128 KiB in two where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
+        // they are the generic kernel's)
+        const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
+        const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX;
+        const size_t perFrame = mb ? (size_t)(2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2) : 1;
+        const size_t chunkFrames = mb ? (chunkMax / perFrame ? chunkMax / perFrame : 1) : chunkMax;
+        const size_t chunk = n < chunkFrames ? n : chunkFrames;
+        const size_t slots = chunk * perFrame;                                          // item slots per chunk (== frames without the mode)
+        if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
         // ZHIP_SPLIT=1 (A/B, r03b): the front of the pipeline (K1, KB, K1b, K2: LDS-bound serial chains with idle issue slots) of chunk k + 1 on one
@@ -577,10 +609,12 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const bool split = c->knob.split && nslot >= 2;
         const int nstream = split ? 2 : nslot;
         std::vector<hipEvent_t> evK3Done;
-        if (c->pipeMeta.reserve(nslot * chunk * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * chunk * ZP_LIT_STRIDE) ||
-            c->pipeSeq.reserve(nslot * chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
-            c->pipeFse.reserve(nslot * chunk * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * chunk * sizeof(uint32_t)) ||
-            c->pipeHuf.reserve(nslot * chunk * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * chunk * sizeof(uint32_t))) return g_reserveRc;
+        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * slots * ZP_LIT_STRIDE) ||
+            c->pipeSeq.reserve(nslot * slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
+            c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
+            c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
+        if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
+                   c->pipeFrameRecs.reserve(nslot * chunk * sizeof(ZpFrameRec)))) return g_reserveRc;
         for (int sidx = 0; sidx < (nslot > nstream ? nslot : nstream); sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, (8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
@@ -613,13 +647,20 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (split && ci >= (size_t)nslot) HIP_TRY(hipStreamWaitEvent(ss, evK3Done[ci - nslot], 0));     // the slot's arenas are free again
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
-            pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * chunk;
-            pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * chunk * ZP_LIT_STRIDE;
-            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * chunk * ZP_SEQ_CAP;
-            pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * chunk * ZP_FSE_CELLS;
-            pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * chunk;
-            pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * chunk * ZP_HUF_CELLS;
-            pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * chunk;
+            pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * slots;
+            pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * slots * ZP_LIT_STRIDE;
+            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * slots * ZP_SEQ_CAP;
+            pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * slots * ZP_FSE_CELLS;
+            pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * slots;
+            pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * slots * ZP_HUF_CELLS;
+            pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * slots;
+            if (mb) {
+                pa.itemCap = (uint32_t)(cnt * perFrame);
+                pa.itemFrame = (uint32_t*)c->pipeItemFrame.p + (size_t)sidx * slots;
+                pa.itemReps = (uint32_t*)c->pipeItemReps.p + (size_t)sidx * slots * 4;
+                pa.frameRecs = (ZpFrameRec*)c->pipeFrameRecs.p + (size_t)sidx * chunk;
+            }
+            const size_t items = mb ? (size_t)pa.itemCap : cnt;                         // K1b / K2 / KB work items (an upper bound in the several-block mode)
             pa.counters = counters + 8 + ZP_CNT_WORDS * sidx;
             if (ci >= (size_t)nslot) HIP_TRY(hipMemsetAsync(pa.counters, 0, ZP_CNT_WORDS * 4, ss));
             size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
@@ -628,9 +669,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 60 lanes -> 1, 15 -> 4, 7 -> 8)
             const bool quad = c->knob.k2quad;
             const size_t perWave = quad ? ZQ_FRAMES : ZP_K2_LANES;
-            const size_t w2 = (cnt + perWave - 1) / perWave, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / (quad ? sizeof(ZpSeqQLDS) : sizeof(ZpSeqLDS)));
+            const size_t w2 = (items + perWave - 1) / perWave, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / (quad ? sizeof(ZpSeqQLDS) : sizeof(ZpSeqLDS)));
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
-            const size_t wh = (cnt + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
+            const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
             const bool tm = c->timing;
             hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, evh = nullptr, evh2 = nullptr;
@@ -639,14 +680,16 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 HIP_TRY(hipEventCreate(&evh)); HIP_TRY(hipEventCreate(&evh2));
                 HIP_TRY(hipEventRecord(ev[0], ss));
             }
-            hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
-            hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2 * (cnt < 4096 ? 1u : 64u)), dim3(64), 0, ss, pa);      // tiny; timed with K1
+            if (mb) hipLaunchKernelGGL(zhip_decode_lit_mb_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            else hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2 * (items < 4096 ? 1u : 64u)), dim3(64), 0, ss, pa);      // tiny; timed with K1
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
             hipEvent_t evK2beg = nullptr;
             if (tm && split) { HIP_TRY(hipEventCreate(&evK2beg)); HIP_TRY(hipEventRecord(evK2beg, ss)); }
-            if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            else if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
             else hipLaunchKernelGGL(zhip_decode_seq1_kernel, dim3(g2), dim3(64), 0, ss, pa);
             hipEvent_t evK2end = nullptr;
             if (split) {
@@ -657,7 +700,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 (void)hipEventDestroy(evFront);
             }
             if (tm) HIP_TRY(hipEventRecord(ev[2], sx));
-            if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
             else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, sx, pa);
             else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, sx, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[3], sx));
@@ -722,7 +767,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         d_fallbackList = (const uint32_t*)c->pipeFallback.p; d_fallbackCount = (const uint32_t*)c->pipeCounters.p;
         // the generic kernel only sees the (usually empty) fallback list: a small grid is enough
         // (unless the caller says its frames exceed one block: then the list is the whole batch)
-        if (grid > 1024 && !((c->dstMaxHint ? c->dstMaxHint : c->itemHint) > ZF_BLOCK_MAX)) grid = 1024;
+        if (grid > 1024 && (mb || !(sizeHint > ZF_BLOCK_MAX))) grid = 1024;
     }
     ZhipDecodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;

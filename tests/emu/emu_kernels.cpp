@@ -132,9 +132,17 @@ static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
 static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
 #else
 static ZpSeqQLDS g_seqqlds;
-static void k2_lane(void* p) { zp_seqq_body(*(const ZhipPipeArgs*)p, g_seqqlds); }
+static void k2_lane(void* p) { const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p; if (a.itemCap) zp_seqq_body<true>(a, g_seqqlds); else zp_seqq_body<false>(a, g_seqqlds); }
 #endif
-static void k3_lane(void* p) { const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p; if (a.dictContent) zp_exec_body<true, false>(a, g_xlds); else zp_exec_body<false, false>(a, g_xlds); }
+static void k3_lane(void* p)
+{
+    const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p;
+    if (a.itemCap) { if (a.dictContent) zp_exec_body<true, false, true>(a, g_xlds); else zp_exec_body<false, false, true>(a, g_xlds); }
+    else if (a.dictContent) zp_exec_body<true, false>(a, g_xlds); else zp_exec_body<false, false>(a, g_xlds);
+}
+static void k1mb_lane(void* p) { zp_lit_mb_body(*(const ZhipPipeArgs*)p, g_lds); }
+static uint32_t g_mbPerFrame = 0;              // several-block mode of the pipeline harness: item slots per frame (0 = off), mirrors zhip_decompress_batch_device
+extern "C" void emu_set_blocks(uint32_t perFrame) { g_mbPerFrame = perFrame; }
 // decompression dictionary for the pipeline harness (mirrors zhip_ctx_set_ddict): blob, parsed entropy section, ready-made tables
 static std::vector<uint8_t> g_ddBlob; static ZhipDictEntropy g_ddEntropy; static ZhipDictTables g_ddTables; static bool g_ddHas = false, g_ddEnt = false;
 struct DTLaunch { const ZhipDictEntropy* de; ZhipDictTables* out; };
@@ -167,14 +175,18 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     ZhipPipeArgs a; memset(&a, 0, sizeof(a));
     static uint32_t counters[ZP_CNT_WORDS + 1]; memset(counters, 0, sizeof counters);      // the slot's words (incl. the work orders' bin counters), then the fallback length
     if (chunk == 0 || chunk > n) chunk = n ? n : 1;
+    const bool mb = g_mbPerFrame != 0;
+    const size_t slots = (size_t)chunk * (mb ? g_mbPerFrame : 1u);
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
-    a.meta = (ZdMeta*)calloc(chunk, sizeof(ZdMeta));
-    a.litArena = (uint8_t*)malloc((size_t)chunk * ZP_LIT_STRIDE);
-    uint64_t* const seqAlloc = (uint64_t*)malloc((size_t)chunk * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8); a.seqArena = seqAlloc + ZP_SEQ_FRONT;
-    a.fseTables = (uint16_t*)malloc((size_t)chunk * ZP_FSE_CELLS * 2);
-    a.order = (uint32_t*)calloc(chunk, 4);
-    a.hufTables = (uint16_t*)malloc((size_t)chunk * ZP_HUF_CELLS * 2 + 64);
-    a.orderLit = (uint32_t*)calloc(chunk, 4);
+    a.meta = (ZdMeta*)calloc(slots, sizeof(ZdMeta));
+    a.litArena = (uint8_t*)malloc(slots * ZP_LIT_STRIDE);
+    uint64_t* const seqAlloc = (uint64_t*)malloc(slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8); a.seqArena = seqAlloc + ZP_SEQ_FRONT;
+    a.fseTables = (uint16_t*)malloc(slots * ZP_FSE_CELLS * 2);
+    a.order = (uint32_t*)calloc(slots, 4);
+    a.hufTables = (uint16_t*)malloc(slots * ZP_HUF_CELLS * 2 + 64);
+    a.orderLit = (uint32_t*)calloc(slots, 4);
+    if (mb) { a.itemFrame = (uint32_t*)malloc(slots * 4); a.itemReps = (uint32_t*)malloc(slots * 16); a.frameRecs = (ZpFrameRec*)malloc((size_t)chunk * sizeof(ZpFrameRec));
+              memset(a.itemFrame, 0xA5, slots * 4); memset(a.itemReps, 0xA5, slots * 16); memset(a.frameRecs, 0xA5, (size_t)chunk * sizeof(ZpFrameRec)); }
     a.counters = counters; a.fallbackCount = &counters[ZP_CNT_WORDS]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
     if (g_ddHas) {
@@ -186,7 +198,8 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (uint32_t q = 0; q < ZP_CNT_WORDS; q++) counters[q] = 0;
         memset(&g_lds, 0xA5, sizeof g_lds); memset(&g_xlds, 0xA5, sizeof g_xlds); memset(&g_binlds, 0xA5, sizeof g_binlds);   // LDS is not zeroed on hardware
-        zhemu::run_grid(nBlocks, k1_lane, &a);
+        a.itemCap = mb ? a.count * g_mbPerFrame : 0u;
+        zhemu::run_grid(nBlocks, mb ? k1mb_lane : k1_lane, &a);
         zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
         zhemu::run_grid(nBlocks, kh_lane, &a);
@@ -209,6 +222,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[ZP_CNT_WORDS];
     free(g.scratch); free(a.meta); free(a.litArena); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
+    free(a.itemFrame); free(a.itemReps); free(a.frameRecs);
     return nfb;
 }
 

@@ -142,3 +142,11 @@ def _emu_set_ddict(self, dict_data, raw_content=False):
 
 
 Emu.set_ddict = _emu_set_ddict
+
+
+def _emu_set_blocks(self, per_frame):
+    """several-block mode of the decode pipeline harness: item slots per frame (0 = off: frames of several blocks go to the generic kernel)"""
+    self.lib.emu_set_blocks(C.c_uint32(per_frame))
+
+
+Emu.set_blocks = _emu_set_blocks

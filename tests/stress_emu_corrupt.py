@@ -98,6 +98,8 @@ if __name__ == "__main__":
     emu = emulib.Emu(); ref = reflib.RefZstd(); corpus = Corpus()
     rng = np.random.default_rng(seed)
     dict_data = None
+    blocks = int(os.environ.get("ZHIP_EMU_BLOCKS", "0"))          # several-block mode of the pipeline: item slots per frame (then every other round has big frames)
+    emu.set_blocks(blocks)
     if use_dict:
         samples = [f[:4096] for f in corpus.frame_list(0, 400)]
         dict_data = ref.train_dictionary(16384, samples)
@@ -105,7 +107,7 @@ if __name__ == "__main__":
     tot = {}
     t0 = time.time()
     for k in range(rounds):
-        r = one_round(emu, ref, rng, corpus, small=use_dict or k % 2 == 1, dict_data=dict_data, big=(k % 4 == 2))
+        r = one_round(emu, ref, rng, corpus, small=use_dict or k % 2 == 1, dict_data=dict_data, big=(k % 4 == 2 or (blocks and k % 2 == 0)))
         for a, b in r.items(): tot[a] = tot.get(a, 0) + b
     print("corrupt stress seed", seed, tot, "%.1fs" % (time.time() - t0))
     sys.exit(1 if tot["wrong"] or tot["missed"] or tot["neighbours_bad"] else 0)

@@ -1,6 +1,6 @@
 """Emulator stress of the DECODERS on whatever libzstd 1.5.7 can produce: python tests/stress_emu_decode_any.py SEED.
 Frames of random levels (-5 ... 19), explicit parameters (small windows: headers with a window descriptor, offsets across blocks), with
-and without checksum / content size, sources from a few bytes to several blocks -- through the emulated pipeline (single-block frames) and
+and without checksum / content size, sources from a few bytes to several blocks -- through the emulated pipeline (single-block frames; again in its several-block mode) and
 the generic kernel (everything else). Every frame must decode to its source. Not collected by pytest."""
 import os
 import sys
@@ -42,6 +42,14 @@ outs, st, nfb = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=0)
 bad = sum(1 for r, o, s in zip(raws, outs, st) if s or o != r)
 outs2, st2 = emu.decompress_batch(frames, sizes, n_blocks=2)
 bad2 = sum(1 for r, o, s in zip(raws, outs2, st2) if s or o != r)
+# the several-block mode of the pipeline (the item is a block): enough slots for every frame, then so few that some frames overflow into the generic kernel
+for per_frame in (int(rng.integers(5, 12)), 2):
+    emu.set_blocks(per_frame)
+    outs3, st3, nfb3 = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=int(rng.choice([0, 7])))
+    emu.set_blocks(0)
+    for i, (r, o, s) in enumerate(zip(raws, outs3, st3)):
+        if s or o != r: print("BLOCK-MODE MISMATCH", seed, per_frame, i, len(r), s); bad2 += 1
+    print("  block mode, %d slots per frame: fallback %d" % (per_frame, nfb3))
 for i, (r, o, s) in enumerate(zip(raws, outs, st)):
     if s or o != r: print("PIPELINE MISMATCH", seed, i, len(r), s)
 for i, (r, o, s) in enumerate(zip(raws, outs2, st2)):
