@@ -502,6 +502,11 @@ int zo_get_frame_header(zo_frame_header* h, const void* srcv, size_t srcSize)
     const uint8_t* src = (const uint8_t*)srcv;
     memset(h, 0, sizeof(*h));
     if (srcSize < 5) return -ZO_E_SRC_SIZE_WRONG;
+    if ((zo_rd32(src) & 0xFFFFFFF0u) == 0x184D2A50u) {              /* skippable frame (zstd.c:43706-43715): magic, 4-byte size, that many bytes */
+        if (srcSize < 8) return -ZO_E_SRC_SIZE_WRONG;
+        h->skippable = 1; h->headerSize = 8; h->windowSize = zo_rd32(src + 4); h->contentSize = 0;   /* ZSTD_getFrameContentSize: 0 (zstd.c:43773) */
+        return 0;
+    }
     if (zo_rd32(src) != ZO_MAGIC) return -ZO_E_PREFIX_UNKNOWN;
     unsigned fhd = src[4];
     unsigned dictCode = fhd & 3, checksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
@@ -550,6 +555,7 @@ int64_t zo_find_frame_compressed_size(const void* srcv, size_t srcSize)
 {
     const uint8_t* src = (const uint8_t*)srcv;
     zo_frame_header h; int e = zo_get_frame_header(&h, src, srcSize); if (e < 0) return e;
+    if (h.skippable) return 8 + h.windowSize > srcSize ? -ZO_E_SRC_SIZE_WRONG : (int64_t)(8 + h.windowSize);     /* readSkippableFrameSize, zstd.c:43795 */
     size_t pos = h.headerSize;
     for (;;) {
         if (pos + 3 > srcSize) return -ZO_E_SRC_SIZE_WRONG;
@@ -571,6 +577,11 @@ int64_t zo_decompress_frame(void* dstv, size_t dstCap, const void* srcv, size_t 
     const uint8_t* src = (const uint8_t*)srcv;
     uint8_t* dst = (uint8_t*)dstv;
     zo_frame_header h; int e = zo_get_frame_header(&h, src, srcSize); if (e < 0) return e;
+    if (h.skippable) {              /* ZSTD_decompressStream passes over it and stops at the frame boundary: nothing produced (incomplete: the caller sees a non-zero hint) */
+        if (8 + h.windowSize > srcSize) return -ZO_E_SRC_SIZE_WRONG;
+        if (srcConsumed) *srcConsumed = 8 + (size_t)h.windowSize;
+        return 0;
+    }
     zo_dctx* d = (zo_dctx*)calloc(1, sizeof(zo_dctx));
     if (!d) return -ZO_E_MEMORY;
     d->lit = (uint8_t*)malloc(ZO_BLOCK_MAX + 64);

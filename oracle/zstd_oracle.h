@@ -20,6 +20,7 @@ typedef struct {
     uint32_t headerSize;
     uint32_t dictID;
     uint32_t hasChecksum;
+    uint32_t skippable;     /* 1: a skippable frame (magic 0x184D2A5?): headerSize = 8, windowSize = its payload size, contentSize = 0 */
 } zo_frame_header;
 
 /* decode side (zo_decode.c) -- negative return = -(zstd error code) */

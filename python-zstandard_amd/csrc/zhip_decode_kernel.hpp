@@ -996,6 +996,8 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
     // ---- frame header (RFC 8878 3.1.1.1)
     const uint32_t mg = a.magicless ? 0u : 4u;             // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
     if (srcSize < mg + 1) return ZE_SRC_SIZE_WRONG;
+    if (mg && (zh_ld32(src) & 0xFFFFFFF0u) == ZF_MAGIC_SKIPPABLE)        // a skippable frame: passed over, nothing produced (zstd.c:43706, :44731)
+        return srcSize < 8 || (uint64_t)zh_ld32(src + 4) + 8 > srcSize ? ZE_SRC_SIZE_WRONG : ZE_OK;
     if (mg && zh_ld32(src) != ZF_MAGIC) return ZE_PREFIX_UNKNOWN;
     const uint32_t fhd = src[mg];
     const uint32_t dictCode = fhd & 3, hasChecksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;

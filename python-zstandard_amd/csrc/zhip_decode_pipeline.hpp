@@ -44,11 +44,17 @@ ZH_DEV void zp_pack_fse(ZdLDS& L, uint32_t* T, uint32_t llLog, uint32_t ofLog, u
 // ------------------------------------------------------------------------------------------ K1
 // frame header (RFC 8878 3.1.1.1; ZSTD_getFrameHeader_advanced zstd.c:43682, the checks of ZSTD_decompressFrame :44174): where the first
 // block header lies, the block maximum, the content size (~0 = not in the header), the checksum flag. 0 or a zstd error code.
-struct ZpHdr { uint32_t pos, blockMax, hasChecksum; uint64_t fcs; };
+struct ZpHdr { uint32_t pos, blockMax, hasChecksum, skippable; uint64_t fcs; };
 ZH_DEV int zp_frame_header(const ZhipPipeArgs& a, const uint8_t* src, uint32_t srcSize, ZpHdr& h)
 {
     const uint32_t mg = a.magicless ? 0u : 4u;                     // ZSTD_f_zstd1_magicless: the frame starts at its descriptor byte
+    h.skippable = 0;
     if (srcSize < mg + 1) return ZE_SRC_SIZE_WRONG;
+    if (mg && (zh_ld32(src) & 0xFFFFFFF0u) == ZF_MAGIC_SKIPPABLE) {  // a skippable frame: ZSTD_decompressStream passes over it and stops at the frame
+        if (srcSize < 8 || (uint64_t)zh_ld32(src + 4) + 8 > srcSize) return ZE_SRC_SIZE_WRONG;     // boundary -- nothing produced (zstd.c:43706, :44731)
+        h.skippable = 1; h.pos = 0; h.blockMax = 0; h.hasChecksum = 0; h.fcs = 0;
+        return 0;
+    }
     if (mg && zh_ld32(src) != ZF_MAGIC) return ZE_PREFIX_UNKNOWN;
     const uint32_t fhd = src[mg];
     const uint32_t dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
@@ -190,7 +196,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
             ZpHdr h;
             err = zp_frame_header(a, src, srcSize, h);
-            if (err) break;
+            if (err || h.skippable) break;                                  // (a skippable frame: done, nothing produced)
             const uint32_t blockMax = h.blockMax, hasChecksum = h.hasChecksum;
             const uint64_t fcs = h.fcs;
             uint32_t pos = h.pos;
@@ -290,7 +296,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
             const uint32_t srcSize = (uint32_t)srcSize64;
             ZpHdr h;
             err = zp_frame_header(a, src, srcSize, h);
-            if (err) break;
+            if (err || h.skippable) break;                                  // (a skippable frame: done, nothing produced -- path 0, status 0)
             const uint32_t blockMax = h.blockMax;
             const uint64_t fcs = h.fcs;
             rec.blockMax = blockMax; rec.fcsLo = (uint32_t)fcs; rec.fcsHi = (uint32_t)(fcs >> 32);
@@ -916,10 +922,10 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             state = idle ? size : size + zq_field(col, pos - (int32_t)(initOff + myLog), myLog);
             pos -= (int32_t)(llLog + ofLog + mlLog); }
         const uint32_t nTrips = zh_first(zh_wave_max(nbSeq)) + 5;                  // trip n produces sequence n - 1 (software pipeline); a group of four is stored at the next group's first trip
-        uint32_t rep0 = 1, rep1 = 4, rep2 = 8, maxOff = 0;
+        uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
         if (a.dictEntropy) { rep0 = a.dictEntropy->rep[0]; rep1 = a.dictEntropy->rep[1]; rep2 = a.dictEntropy->rep[2]; }     // ZSTD_loadDEntropy's start history
         if (MB && active && a.frameRecs[fi].firstItem != i) { rep0 = ZP_SYM_REP(0); rep1 = ZP_SYM_REP(1); rep2 = ZP_SYM_REP(2); }
-        uint32_t fin0 = rep0, fin1 = rep1, fin2 = rep2, finMax = 0;  // (MB) the history, and the largest value, after the block's LAST sequence (the trips go on to the wave's longest block)
+        uint32_t fin0 = rep0, fin1 = rep1, fin2 = rep2;              // (MB) the history after the block's LAST sequence (the trips go on to the wave's longest block)
         // (taken into registers HERE: left pending, the loads made the waitcnt pass put a conservative vmcnt wait at the loop's first use of
         // the history -- behind the ring's block load, whose round trip it then sat out every four steps: 5.6 -> 8.2 ms, r02x)
         rep0 = zh_opaque(rep0); rep1 = zh_opaque(rep1); rep2 = zh_opaque(rep2);
@@ -956,8 +962,8 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
                 const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
                 const uint32_t idx = val - 1 + (llv == 0);
-                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); here it trips `bad` below -> generic kernel -> refused (MB: K3 refuses it)
-                const uint32_t c3 = val <= 3 ? r0m1 : val - 3;
+                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); packed it is the largest offset there is and K3 refuses it
+                const uint32_t c3 = val <= 3 ? r0m1 : val - 3 < ZP_OF_LIMIT ? val - 3 : ZP_OF_LIMIT;     // (a new offset beyond the packed form: saturated, K3 knows what to do)
                 uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
                 ZQ_F2();
                 // ---- the chain: cell -> bit counts -> where my state bits are -> next state
@@ -967,14 +973,10 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 ZQ_F2();
                 // ---- sequence n - 1: history (idx 0: as it was, 1: swap the first two, else: push), pack, store
                 rep2 = idx <= 1 ? rep2 : rep1; rep1 = idx == 0 ? rep1 : rep0; rep0 = offset;
-                if (MB) {
-                    // symbolic entries look like huge offsets: the largest NEW offset is watched instead (value - 3; values 1..3 are the repeat
-                    // codes), "no such offset" travels on to K3 as a value above ZP_SYM_TOP. Trip n has just applied sequence n - 1.
-                    maxOff = val > maxOff ? val : maxOff;
+                if (MB) {                                                   // trip n has just applied sequence n - 1
                     const bool wasLast = n == nbSeq;
-                    fin0 = wasLast ? rep0 : fin0; fin1 = wasLast ? rep1 : fin1; fin2 = wasLast ? rep2 : fin2; finMax = wasLast ? maxOff : finMax;
-                } else
-                maxOff = offset > maxOff ? offset : maxOff;
+                    fin0 = wasLast ? rep0 : fin0; fin1 = wasLast ? rep1 : fin1; fin2 = wasLast ? rep2 : fin2;
+                }
                 {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 3);
                     if (u == 0) {                                                     // (compile-time: the loop is unrolled)
                         w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
@@ -1005,13 +1007,14 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
             // wait (vmcnt counts in order) also sat out the ring's block load issued just before it -- a load round trip per group (r02x)
             ZH_KEEP4(w0.a, w0.b, w0.c, w0.d); ZH_KEEP4(w1.a, w1.b, w1.c, w1.d);
         }
-        const bool bad = MB ? finMax >= ZP_OF_LIMIT + 3 : maxOff >= ZP_OF_LIMIT;
+        // Offsets the packed form cannot hold never stop K2: a new offset of ZP_OF_LIMIT or more is stored AS ZP_OF_LIMIT, "repeat offset 1
+        // minus one" = 0 as the largest value there is (r0m1). In a single-block frame both are beyond anything the frame has produced -- K3
+        // answers corruption_detected, libzstd's answer (zstd.c:46941, :46558) --, in the several-block mode K3 hands a frame with a saturated
+        // offset to the generic kernel. (Watching the largest offset HERE instead sent frames there for nothing: the trips past a block's
+        // last sequence decode garbage, and a garbage offset code of 28+ looked like one, r03s.)
         if (active && isOF) {
-            const int err = !ok ? ZE_CORRUPTION : bad ? ZE_PARAM_UNSUPPORTED : posEnd != fin ? ZE_CORRUPTION : 0;
-            if (err == ZE_PARAM_UNSUPPORTED) {                                 // an offset does not fit the packed form: the generic kernel's
-                m->path = 2;                                                   // (several-block mode: K3 hands the frame over when it meets the item)
-                if (!MB) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f; }
-            } else if (err) { m->status = err; m->path = 0; if (!MB) { a.status[f] = err; a.outSizes[f] = 0; } }
+            const int err = !ok ? ZE_CORRUPTION : posEnd != fin ? ZE_CORRUPTION : 0;
+            if (err) { m->status = err; m->path = 0; if (!MB) { a.status[f] = err; a.outSizes[f] = 0; } }
             if (MB) { uint32_t* r = a.itemReps + 4 * (size_t)i; r[0] = fin0; r[1] = fin1; r[2] = fin2; }
         }
         zh_sync();
@@ -1074,7 +1077,7 @@ ZH_DEV void zp_ld32_lds(const uint8_t* q, uint32_t len, uint64_t r[4])          
 // ZP_SYM_REP in zhip_format.hpp -- entry k of that history minus d; 0xFFFFFFFF = no such offset (libzstd: corruption, zstd.c:46941)
 ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2)
 {
-    if (v <= ZP_OF_LIMIT) return v;
+    if (v <= ZP_OF_LIMIT) return v;                              // (ZP_OF_LIMIT itself: K2's "too large for the packed form", the caller looks for it)
     if (v > ZP_SYM_TOP) return 0xFFFFFFFFu;
     const uint32_t k = (v - (ZP_OF_LIMIT + 1)) >> 23;
     const uint32_t d = ZP_SYM_REP(k) - v;
@@ -1117,6 +1120,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
         if (lane < avail) { const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); if (MB) myOF = zp_sym_resolve(myOF, R0, R1, R2); }
+        if (MB && zh_ballot(lane < avail && myOF == ZP_OF_LIMIT)) return ZP_RC_FALLBACK;      // an offset K2 could not pack: the generic kernel's frame
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer (behind the carried bytes)
         const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES);

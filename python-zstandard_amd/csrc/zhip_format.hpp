@@ -11,6 +11,7 @@ enum {
 };
 
 #define ZF_MAGIC 0xFD2FB528u
+#define ZF_MAGIC_SKIPPABLE 0x184D2A50u                    // .. 0x184D2A5F: skippable frames (magic, 4-byte size, payload)
 #define ZF_DICT_MAGIC 0xEC30A437u
 #define ZF_BLOCK_MAX (1u << 17)
 #define ZF_MAXLL 35

@@ -195,12 +195,18 @@ static inline uint32_t rd24(const uint8_t* p) { return rd16(p) | ((uint32_t)p[2]
 static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
-struct HostFrameHeader { uint64_t contentSize; uint32_t headerSize; uint32_t hasChecksum; };
+struct HostFrameHeader { uint64_t contentSize; uint32_t headerSize; uint32_t hasChecksum; uint32_t skippable, skipSize; };
 // RFC 8878 3.1.1.1; restates ZSTD_getFrameHeader_advanced (zstd.c:43668) for the fields the dispatcher needs.
 static int host_frame_header(HostFrameHeader* h, const uint8_t* src, size_t n, int format)
 {
     const size_t mg = format == ZHIP_FORMAT_ZSTD1_MAGICLESS ? 0 : 4;
+    h->skippable = 0; h->skipSize = 0;
     if (n < mg + 1) return -ZE_SRC_SIZE_WRONG;
+    if (mg && (rd32(src) & 0xFFFFFFF0u) == ZF_MAGIC_SKIPPABLE) {          // skippable frame: content size 0 (ZSTD_getFrameContentSize, zstd.c:43773)
+        if (n < 8) return -ZE_SRC_SIZE_WRONG;
+        h->skippable = 1; h->skipSize = rd32(src + 4); h->contentSize = 0; h->headerSize = 8; h->hasChecksum = 0;
+        return 0;
+    }
     if (mg && rd32(src) != ZF_MAGIC) return -ZE_PREFIX_UNKNOWN;
     src += mg; n -= mg;
     uint32_t fhd = src[0], dictCode = fhd & 3, single = (fhd >> 5) & 1, fcsCode = fhd >> 6;
@@ -228,6 +234,7 @@ extern "C" int64_t zhip_find_frame_compressed_size_format(const void* srcv, size
 {
     const uint8_t* src = (const uint8_t*)srcv;
     HostFrameHeader h; int e = host_frame_header(&h, src, n, format); if (e < 0) return e;
+    if (h.skippable) return (uint64_t)h.skipSize + 8 > n ? -ZE_SRC_SIZE_WRONG : (int64_t)h.skipSize + 8;      // readSkippableFrameSize (zstd.c:43795)
     size_t pos = h.headerSize;
     for (;;) {
         if (pos + 3 > n) return -ZE_SRC_SIZE_WRONG;

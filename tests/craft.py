@@ -52,11 +52,16 @@ def _code(value, base):
     return c
 
 
-def sequences_block(literals, seqs, last=True):
-    """One compressed block: raw literals + `seqs` = [(ll, ml, offset_value)] on predefined tables. Returns block header + content."""
+def sequences_block(literals, seqs, last=True, of_rle=False):
+    """One compressed block: raw literals + `seqs` = [(ll, ml, offset_value)] on predefined tables. Returns block header + content.
+    of_rle: the offset codes in RLE mode (one code for every sequence, any of 0..31 -- the predefined table ends at 28)."""
     assert len(literals) < 32 and 0 < len(seqs) < 128
     tabs = [(_decode_table(_defnorm("zo_ll_defnorm", 36), 6), 6), (_decode_table(_defnorm("zo_of_defnorm", 29), 5), 5),
             (_decode_table(_defnorm("zo_ml_defnorm", 53), 6), 6)]
+    if of_rle:
+        oc = seqs[0][2].bit_length() - 1
+        assert all(q[2].bit_length() - 1 == oc for q in seqs)
+        tabs[1] = ([(oc, 0, 0)], 0)
     codes = []
     for ll, ml, ofv in seqs:
         lc, mc, oc = _code(ll, _LL_BASE), _code(ml, _ML_BASE), ofv.bit_length() - 1
@@ -75,7 +80,7 @@ def sequences_block(literals, seqs, last=True):
             st.append((x, bits))
         states[n] = st
     # the fields in the order the decoder reads them (from the top of the stream down)
-    reads = [(states[0][0][0], 6), (states[0][1][0], 5), (states[0][2][0], 6)]
+    reads = [(states[0][0][0], 6), (states[0][1][0], tabs[1][1]), (states[0][2][0], 6)]
     for n in range(len(seqs)):
         (_, lx, lb), (_, ox, ob), (_, mx, mb) = codes[n]
         reads += [(ox, ob), (mx, mb), (lx, lb)]
@@ -83,7 +88,7 @@ def sequences_block(literals, seqs, last=True):
     acc = 1
     for v, nb in reads: acc = (acc << nb) | v
     stream = acc.to_bytes((acc.bit_length() + 7) // 8, "little")
-    content = bytes([len(literals) << 3]) + bytes(literals) + bytes([len(seqs), 0]) + stream
+    content = bytes([len(literals) << 3]) + bytes(literals) + (bytes([len(seqs), 0x10, tabs[1][0][0][0]]) if of_rle else bytes([len(seqs), 0])) + stream
     bh = (1 if last else 0) | (2 << 1) | (len(content) << 3)
     return bh.to_bytes(3, "little") + content
 
@@ -135,5 +140,28 @@ def edge_frames():
         ("RLE block above 128 KiB, size unknown", _hdr(None, 20) + rle_block(9, 200000), 200000, False),
         ("raw block above 128 KiB, size known", _hdr(200000, 20) + raw_block((pat * 98)[:200000], True), 200000, True),
         ("raw blocks then RLE above the window", _hdr(5000, 10) + raw_block(pat[:1500]) + raw_block(pat[:1500]) + rle_block(3, 2000), 5000, True),
+        # offsets the decode kernels' packed sequences cannot hold (2^29 and up): never valid in a frame this small
+        ("offset codes in RLE mode", frame([sequences_block(lit, [(4, 5, 4), (4, 3, 6)], of_rle=True)], 16), 16, True),
+        ("an offset of 768 MiB", frame([sequences_block(lit, [(8, 30, 0x30000003)], of_rle=True)], 38), 38, False),
+        ("an offset of 3 GiB in a second block", frame([raw_block(lit), sequences_block(b"xy", [(1, 4, 0x80000007), (1, 3, 0xC0000003)], of_rle=True)], 17), 17, False),
+        ("offsets around the packed form's limit", frame([sequences_block(lit, [(4, 3, 0x1E000002), (4, 3, 0x1E000003)], of_rle=True)], 14), 14, False),
     ]
     return out
+
+
+def skippable_frames():
+    """(name, item bytes, declared size, accepted) -- skippable frames (RFC 8878 3.1.2) as batch items: ZSTD_decompressStream passes over one
+    and stops at the frame boundary with nothing produced (zstd.c:43706-43715, :44731), so the reference returns an empty segment;
+    what follows the first frame of an item is never looked at (c-ext/decompressor.c:1150-1163)."""
+    skip = b"\x50\x2a\x4d\x18" + (5).to_bytes(4, "little") + b"hello"
+    whole = frame([sequences_block(b"abcdefgh", [(8, 30, 5), (0, 3, 3)])], 41)
+    return [
+        ("skippable frame", skip, 0, True),
+        ("skippable frame, last magic, no payload", b"\x5f\x2a\x4d\x18" + bytes(4), 0, True),
+        ("skippable frame, then a frame", skip + whole, 0, True),
+        ("a frame, then a skippable frame", whole + skip, 41, True),
+        ("a frame, then bytes that are no frame", whole + b"garbage!", 41, True),
+        ("skippable frame, payload cut short", skip[:-2], 0, False),
+        ("skippable frame, header cut short", skip[:6], 0, False),
+        ("one past the skippable magics", b"\x60\x2a\x4d\x18" + skip[4:], 0, False),
+    ]

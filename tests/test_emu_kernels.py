@@ -583,13 +583,15 @@ def test_frames_no_encoder_writes_through_the_emulated_kernels(emu, ref):
     one-pass and streaming decoders, zstd.c:44239-44246 / :47714): K1 / K2 / K3 and the generic kernel accept exactly what libzstd accepts and
     produce its bytes. The GPU form is tests/test_gpu_decompress.py::test_frames_no_encoder_writes_are_answered_like_libzstd."""
     from tests import craft
-    cases = craft.edge_frames()
+    cases = craft.edge_frames() + craft.skippable_frames()
     outs, st, nfb = emu.decompress_pipeline([c[1] for c in cases], [c[2] for c in cases], n_blocks=3, chunk=0)
-    for (name, f, n, ok), o, s in zip(cases, outs, st):
+    outs2, st2 = emu.decompress_batch([c[1] for c in cases], [c[2] for c in cases], n_blocks=2)          # every one through the generic kernel too
+    for (name, f, n, ok), o, s, o2, s2 in zip(cases, outs, st, outs2, st2):
         try: want = ref.decompress(f, n)
         except RuntimeError: want = None
         assert (want is not None) == ok, name
         assert (s == 0) == ok and (not ok or o == want), (name, s)
+        assert (s2 == 0) == ok and (not ok or o2 == want), (name, s2, "generic kernel")
 
 
 def test_a_whole_block_as_one_match_into_the_dictionary(emu, ref):
@@ -609,3 +611,40 @@ def test_a_whole_block_as_one_match_into_the_dictionary(emu, ref):
     assert st == [0, 0, 0] and nfb == 0 and outs == raws
     outs, st = emu.compress_batch(raws[:1], level=3, flags=5, pipeline=True, dict_data=blob)
     assert st == [0] and outs[0] == frames[0]
+
+
+def test_frames_of_several_blocks_through_the_pipeline(emu, ref, corpus):
+    """The decode pipeline's several-block mode (zhip_format.hpp ZpFrameRec: K1 per frame over its blocks, K1b / K2 per block, K3 per frame
+    over its blocks, the repeat-offset history symbolic across block boundaries): frames of 2-4 blocks of libzstd (ZSTD_compress_frameChunk,
+    zstd/zstd.c:27545 -- pre-split blocks, raw and RLE blocks, 'treeless' and 'repeat' entropy tables, checksums) decode to their sources;
+    with too few item slots the overflowing frames are the generic kernel's; tests/craft.py's hand-made frames get libzstd's answers in this
+    mode too; damaged frames: nothing wrong gets through. tests/stress_emu_decode_any.py / stress_emu_corrupt.py (ZHIP_EMU_BLOCKS) go on."""
+    import numpy as np
+    from tests import craft
+    from tests.stress_emu_corrupt import one_round
+    rng = np.random.default_rng(21)
+    raws = [b"".join(corpus.frame_bytes(300 + 4 * i + k) for k in range(4))[: int(rng.integers(140000, 400000))] for i in range(3)]
+    raws += [corpus.frame_bytes(7)[:50000], rng.bytes(280000), b"\x07" * 300000, (corpus.frame_bytes(9)[:700] + rng.bytes(90)) * 400]
+    frames = [ref.compress(r, level=[3, 1, 3, 5, 3, 3, 3][i], flags=7 if i % 2 else 5) for i, r in enumerate(raws)]
+    sizes = [len(r) for r in raws]
+    try:
+        for per_frame, chunk in ((8, 0), (2, 3)):
+            emu.set_blocks(per_frame)
+            outs, st, nfb = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=chunk)
+            assert st == [0] * len(raws) and outs == raws, (per_frame, st)
+            assert (nfb == 0) if per_frame == 8 else (nfb >= 3), (per_frame, nfb)
+        emu.set_blocks(6)
+        cases = craft.edge_frames()
+        outs, st, nfb = emu.decompress_pipeline([c[1] for c in cases], [c[2] for c in cases], n_blocks=3, chunk=0)
+        for (name, f, n, ok), o, s in zip(cases, outs, st):
+            assert (s == 0) == ok and (not ok or o == ref.decompress(f, n)), (name, s)
+        r = one_round(emu, ref, rng, corpus, count=24, small=False, big=True)
+        assert r["wrong"] == 0 and r["missed"] == 0 and r["neighbours_bad"] == 0 and r["accepted"] >= 6, r
+        dd = corpus.frame_bytes(950)[:60000]                                          # a raw-content dictionary: matches reach below the frame's first byte from any block
+        draws = [raws[0], dd[200:9000] * 20]
+        dframes = [ref.compress(x, level=3, flags=7, dict_data=dd) for x in draws]
+        assert emu.set_ddict(dd, raw_content=True) == 0
+        outs, st, nfb = emu.decompress_pipeline(dframes, [len(x) for x in draws], n_blocks=2, chunk=0)
+        assert st == [0, 0] and outs == draws and nfb == 0
+    finally:
+        emu.set_blocks(0); emu.set_ddict(None)

@@ -138,7 +138,7 @@ def test_frames_no_encoder_writes_are_answered_like_libzstd(zstd):
     streaming decoders (zstd.c:44239-44246, :47714) -- accepted exactly when libzstd accepts, with libzstd's bytes; alone (K1 / K2 / K3 or
     the generic kernel) and all together in one batch."""
     from tests import craft, reflib
-    cases = craft.edge_frames()
+    cases = craft.edge_frames() + craft.skippable_frames()      # (skippable frames as items: passed over, an empty segment; c-ext/decompressor.c:986-988 reads their size 0)
     ref = reflib.RefZstd() if reflib.have_ref() else None
     d = zstd.ZstdDecompressor()
     good = []
@@ -158,6 +158,41 @@ def test_frames_no_encoder_writes_are_answered_like_libzstd(zstd):
                 d.multi_decompress_to_buffer([f], decompressed_sizes=sizes)
     res = d.multi_decompress_to_buffer([g[0] for g in good] * 3, decompressed_sizes=struct.pack("=%dQ" % (3 * len(good)), *([g[1] for g in good] * 3)))
     assert [res[i].tobytes() for i in range(len(res))] == [g[2] for g in good] * 3
+
+
+def test_frames_of_several_blocks_take_the_phase_split_kernels(zstd, corpus):
+    """Batches whose items exceed 128 KiB run the pipeline's several-block mode (zhip_format.hpp ZpFrameRec; the host API's size hint turns it
+    on): libzstd frames of 1-8 blocks at several levels with and without checksum next to single-block ones; hand-made frames of many tiny
+    blocks that exhaust the chunk's block slots (those are the generic kernel's); a frame damaged in a middle block is the item reported.
+    Reference behaviour: ZSTD_decompressFrame's block loop, zstd/zstd.c:44207-44262."""
+    from tests import craft, reflib
+    if not reflib.have_ref():
+        pytest.skip("needs reference libzstd for frames of other levels")
+    ref = reflib.RefZstd()
+    rng = np.random.default_rng(77)
+    raws = []
+    for i in range(40):
+        n = int(rng.choice([rng.integers(1, 5000), rng.integers(100000, 131073), rng.integers(131073, 1048577)]))
+        raws.append(b"".join(corpus.frame_bytes(400 + 8 * i + k) for k in range(n // 131072 + 1))[:n])
+    raws += [rng.bytes(400000), b"\x05" * 700000, (corpus.frame_bytes(9)[:700] + rng.bytes(90)) * 900]
+    frames = [ref.compress(r, level=int(rng.choice([1, 3, 3, 3, 5, 9])), flags=7 if i % 3 == 0 else 5) for i, r in enumerate(raws)]
+    tiny = [bytes([65 + (k % 26)]) * 9 for k in range(120)]                                   # 120 raw blocks of nine bytes
+    many = craft._hdr(9 * 120 + 12, 17) + b"".join(craft.raw_block(t) for t in tiny) + craft.sequences_block(b"xy", [(1, 4, 2), (0, 3, 2), (1, 3, 1)])
+    want_many = ref.decompress(many, 9 * 120 + 12)
+    assert want_many[:1080] == b"".join(tiny)
+    frames += [many] * 60; raws += [want_many] * 60
+    d = zstd.ZstdDecompressor()
+    sizes = struct.pack("=%dQ" % len(raws), *map(len, raws))
+    res = d.multi_decompress_to_buffer(frames, decompressed_sizes=sizes)
+    for i, r in enumerate(raws):
+        assert res[i].tobytes() == r, "frame %d (%d bytes)" % (i, len(r))
+    k = max(range(40), key=lambda i: len(frames[i]))                                          # the largest frame: damage a byte two thirds in
+    bad = bytearray(frames[k]); bad[2 * len(bad) // 3] ^= 0x55
+    try: ref.decompress(bytes(bad), len(raws[k])); pytest.skip("the damage went unnoticed by libzstd")
+    except RuntimeError: pass
+    broken = list(frames); broken[k] = bytes(bad)
+    with pytest.raises(zstd.ZstdError, match="error decompressing item %d" % k):
+        d.multi_decompress_to_buffer(broken, decompressed_sizes=sizes)
 
 
 def test_content_checksum_is_verified(zstd):
