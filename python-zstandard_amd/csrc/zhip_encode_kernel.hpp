@@ -1066,18 +1066,32 @@ ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_
 // pass the reference's byte comparison, so its bytes are never fetched: the decisions are the reference's, most failed probes
 // cost no candidate read (libzstd does the same for dictionary tables, ZSTD_SHORT_CACHE_TAG_BITS zstd.c:20636).
 #define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
-ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
+// PB = the position's bits in a cell (18: sources of one block; 22: frames of several blocks up to 4 MiB - 2, the tag then has 10 bits).
+// BLK = true searches ONE BLOCK [bs, be) of a larger frame -- tables as the blocks before left them, `rep` = the repeat offsets in and out
+// (ZSTD_compressBlock_doubleFast_noDict_generic's entry and _cleanup, zstd.c:31091-31098 / :31252-31258); false: a whole source [0, be).
+template <int PB, bool BLK>
+ZH_DEV uint32_t ze_dfast_flat_t(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep)
 {
+    constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
+#undef ZE_CELL_IDX
+#define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
     const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
     const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
     const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
     const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
 #define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))                       /* long table: high half of the product */
 #define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))                            /* short table */
-#define ZE_TL(ph) ((((ph) >> (shL - 14)) & 0x3FFFu) << 18)                               /* tag = the 14 product bits below the index */
-#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - 14)) & 0x3FFFu) << 18)       /* tag over the first 4 bytes only */
-    const uint32_t ilimit = srcSize - 8;
-    uint32_t ip = 1, anchor = 0, off1 = 1, off2 = 0, nseq = 0;        // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
+#define ZE_TL(ph) ((((ph) >> (shL - TB)) & TM) << PB)                               /* tag = the TB product bits below the index */
+#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB)       /* tag over the first 4 bytes only */
+    const uint32_t ilimit = be - 8, srcSize = be;                     // (matches end with the block: ZSTD_count's iend)
+    uint32_t ip = BLK ? bs + (bs == 0 ? 1u : 0u) : 1u, anchor = BLK ? bs : 0u, off1 = 1, off2 = 0, nseq = 0;        // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
+    uint32_t saved1 = 0, saved2 = 0;
+    if (BLK) {                                                        // a repeat offset that reaches before the frame's first byte is parked for the block
+        off1 = rep[0]; off2 = rep[1];
+        if (off2 > ip) { saved2 = off2; off2 = 0; }
+        if (off1 > ip) { saved1 = off1; off1 = 0; }
+        if (be < bs + 8) { return 0; }                                // (nothing to search: the loop's bound check would wrap)
+    }
     uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
     bool fresh = true;
     // Every trip examines TWO consecutive probe positions, A = ip and B = ip + step, in the same three memory rounds: four probes in
@@ -1114,11 +1128,11 @@ ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSi
         hashLong[hlA] = newLA; hashSmall[hsA] = newSA;
         const uint32_t idxl0 = ZE_CELL_IDX(cellL0), idxsA = ZE_CELL_IDX(cSA), idxlB = ZE_CELL_IDX(cLB), idxsB = ZE_CELL_IDX(cSB), idxlC = ZE_CELL_IDX(cLC);
         // plausible = the cell is in use and carries the probe's tag
-        if (fresh) pl0 = (idxl0 >= 2 && (cellL0 >> 18) == (ZE_TL(pLA) >> 18)) ? 1u : 0u;
-        const bool psA = idxsA >= 2 && (cSA >> 18) == (ZE_TS(wA) >> 18);
-        const uint32_t plB = (idxlB >= 2 && (cLB >> 18) == (ZE_TL(pLB) >> 18)) ? 1u : 0u;
-        const bool psB = idxsB >= 2 && (cSB >> 18) == (ZE_TS(wB) >> 18);
-        const uint32_t plC = (idxlC >= 2 && (cLC >> 18) == (ZE_TL(pLC) >> 18)) ? 1u : 0u;
+        if (fresh) pl0 = (idxl0 >= 2 && (cellL0 >> PB) == (ZE_TL(pLA) >> PB)) ? 1u : 0u;
+        const bool psA = idxsA >= 2 && (cSA >> PB) == (ZE_TS(wA) >> PB);
+        const uint32_t plB = (idxlB >= 2 && (cLB >> PB) == (ZE_TL(pLB) >> PB)) ? 1u : 0u;
+        const bool psB = idxsB >= 2 && (cSB >> PB) == (ZE_TS(wB) >> PB);
+        const uint32_t plC = (idxlC >= 2 && (cLC >> PB) == (ZE_TL(pLC) >> PB)) ? 1u : 0u;
         // round 2: the bytes of the plausible candidates (the others read the probe position itself: a cache hit, and ignored)
         uint64_t xl0 = zh_ld64(src + ((fresh && pl0) ? idxl0 - 2 : ipA));
         uint32_t csA = zh_ld32(src + (psA ? idxsA - 2 : ipA));
@@ -1209,7 +1223,17 @@ ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSi
 #undef ZE_PS
 #undef ZE_TL
 #undef ZE_TS
+#undef ZE_CELL_IDX
+#define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
+    if (BLK) {                                                        // zstd.c:31252-31258
+        saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+        rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
+    }
     return nseq;
+}
+ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
+{
+    return ze_dfast_flat_t<18, false>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr);
 }
 
 
@@ -2434,8 +2458,44 @@ ZH_DEVFN uint32_t ze_split_block(ZeLDS& L, const uint8_t* p, int strat)
     return B;
 }
 
+// The block layout of a source of several blocks for the flat match kernel (ZeMbBlock in zhip_format.hpp): ZSTD_compress_frameChunk's loop
+// (zstd.c:27545) on the assumption that every block after the first is split-checked. One wave per frame; frames the flat search does not
+// cover (dictionary, strategy, window below the source, tables above the slot, 4 MiB and more, more blocks than slots) get a count of 0.
+ZH_DEVFN void ze_split_body(const ZhipEncodeArgs& a, ZeLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    for (uint32_t i = zh_block(); i < a.count; i += zh_nblocks()) {
+        const uint32_t f = a.first + i;
+        const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+        const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+        uint32_t count = 0;
+        ZePar cp;
+        if (srcSize64 > ZF_BLOCK_MAX && srcSize64 < (1ull << ZE_MB_POS_BITS) - 8 && !a.cdict && ze_get_cparams(cp, a.rows, (uint32_t)srcSize64) == 0 &&
+            cp.strat == 2 && (1ull << cp.wlog) >= srcSize64 && (size_t)(4u << cp.hlog) + (4u << cp.clog) <= a.tableStride) {
+            const uint32_t srcSize = (uint32_t)srcSize64;
+            ZeMbBlock* const blk = a.mbBlocks + (size_t)i * a.mbMaxBlocks;
+            uint32_t ip = 0;
+            while (ip < srcSize) {
+                const uint32_t remaining = srcSize - ip;
+                uint32_t blockSize = remaining < ZF_BLOCK_MAX ? remaining : ZF_BLOCK_MAX;
+                if (remaining >= ZF_BLOCK_MAX && count >= 1) blockSize = ze_split_block(L, src + ip, cp.strat);
+                ip += blockSize;
+                if (count == a.mbMaxBlocks) { count = 0; break; }
+                if (zh_opaque(lane) == 0) blk[count].end = ip;
+                count++;
+            }
+        }
+        zh_sync();
+        if (zh_opaque(lane) == 0) a.mbCount[i] = count;
+    }
+    ze_fence();
+}
+
 // A frame of several blocks (ZSTD_compress_frameChunk, zstd.c:27545): sources above 128 KiB. All lanes call.
-ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, uint32_t f, uint8_t* ws, uint64_t* produced)
+// useFlat: take the flat match kernel's sequences where it left some (ZeMbBlock, zhip_format.hpp) -- returns ZE_MB_RETRY when what really
+// happened to the blocks is not what that search assumed; the caller then runs the frame again with useFlat = false.
+#define ZE_MB_RETRY 0x7FFF0003
+ZH_DEVFN int ze_frame_multi_impl(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, uint32_t f, uint8_t* ws, uint64_t* produced, bool useFlat)
 {
     const uint32_t lane = zh_lane();
     *produced = 0;
@@ -2486,14 +2546,32 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     zh_sync();
     ZeMulti mb; mb.frame = src; mb.firstBlock = true; mb.st = ms; mb.blkOff = 0;
     uint32_t ip = 0; int32_t savings = 0;
+    // the flat match kernel's work on this frame, if any (chunk-local index: the kernel runs per chunk when that search is on)
+    const uint32_t ci = f - a.first;
+    const uint32_t nFlat = useFlat && a.mbCount && f >= a.first && ci < a.count && a.meta[ci].mode == 5 ? a.mbCount[ci] : 0u;
+    const ZeMbBlock* const blk = nFlat ? a.mbBlocks + (size_t)ci * a.mbMaxBlocks : nullptr;
+    uint32_t bj = 0;
     while (ip < srcSize) {
         const uint32_t remaining = srcSize - ip;
         uint32_t blockSize = remaining < ZF_BLOCK_MAX ? remaining : ZF_BLOCK_MAX;
-        if (remaining >= ZF_BLOCK_MAX && savings >= 3) blockSize = ze_split_block(L, src + ip, cp.strat);
+        if (remaining >= ZF_BLOCK_MAX && savings >= 3) blockSize = nFlat && bj ? blk[bj].end - ip : ze_split_block(L, src + ip, cp.strat);   // (the split kernel's answer for this position)
         const uint32_t last = blockSize == remaining ? 1u : 0u;
         const uint64_t room = cap64 - pos - 3;                      // never let a block's scratch output run past this frame's slot
         const uint32_t want = blockSize + (blockSize >> 7) + 512;
-        const uint32_t c = ze_compress_block<true>(L, dst + pos + 3, room < want ? (uint32_t)room : want, src + ip, blockSize, cp, ws, nullptr, a, &mb);
+        ZePre pre; const ZePre* prep = nullptr;
+        if (nFlat) {
+            // the search assumed: this block ends where the split kernel put it (it split-checked every block after the first), and starts
+            // from the repeat offsets the block before ended with (every block confirmed, i.e. emitted compressed)
+            const uint32_t s0 = bj ? blk[bj - 1].rep0 : 1u, s1 = bj ? blk[bj - 1].rep1 : 4u;
+            if (bj >= nFlat || blk[bj].end != ip + blockSize || zh_first(ms->mrep[0]) != s0 || zh_first(ms->mrep[1]) != s1) return ZE_MB_RETRY;
+            pre.seqs = a.mbSeqs + (size_t)ci * a.mbSeqCap + blk[bj].seqStart; pre.lits = nullptr; pre.nbSeq = blk[bj].nbSeq; pre.litSize = 0;
+            prep = &pre;
+            zh_sync();
+            if (zh_opaque(lane) == 0) { L.misc[5] = blk[bj].rep0; L.misc[6] = blk[bj].rep1; }      // what ze_compress_block confirms when the block is emitted compressed
+            zh_sync();
+            bj++;
+        }
+        const uint32_t c = ze_compress_block<true>(L, dst + pos + 3, room < want ? (uint32_t)room : want, src + ip, blockSize, cp, ws, prep, a, &mb);
         uint32_t total, bh;
         if (c == 0) {
             bh = last + (0u << 1) + (blockSize << 3);
@@ -2514,6 +2592,17 @@ ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, u
     ze_fence();
     *produced = pos;
     return ZE_OK;
+}
+ZH_DEVFN int ze_frame_multi(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* ms, uint32_t f, uint8_t* ws, uint64_t* produced)
+{
+    int r = ze_frame_multi_impl(a, L, ms, f, ws, produced, true);
+    if (r == ZE_MB_RETRY) {
+#ifdef ZHIP_EMU
+        if (zh_lane() == 0) zd_stat[9]++;                                           // (test hook [9]: frames redone)
+#endif
+        zh_sync(); r = ze_frame_multi_impl(a, L, ms, f, ws, produced, false);
+    }
+    return r;
 }
 
 // one frame: header (ZSTD_writeFrameHeader zstd.c:27649), the block, optional checksum. All lanes call.
@@ -2824,7 +2913,10 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     const uint32_t srcSize = (uint32_t)srcSize64;
     ZePar cp; cp.wlog = cp.clog = cp.hlog = cp.mml = cp.strat = cp.tlen = 0;
     bool take = mine;
-    if (mine && srcSize64 > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; take = false; }
+    if (mine && srcSize64 > ZF_BLOCK_MAX) {                       // (sources the split kernel laid out are ze_match_flat_mb_body's: it lists them itself)
+        if (!(a.mbCount && a.mbCount[i])) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; }
+        take = false;
+    }
     // with an attached dictionary (sources up to the attach cutoff, double-fast row, a dictionary that has content): ze_dfast_dict_flat
     const bool dict = a.cdict != nullptr;
     if (take) {
@@ -2862,6 +2954,39 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     zd_stat[15]++;
 #endif
     a.meta[i] = m;
+}
+
+// The flat search on sources of SEVERAL BLOCKS (ZeMbBlock in zhip_format.hpp): one lane per source the split kernel laid out, over all its
+// blocks -- the hash tables (the frame's slot of the flat tables, zeroed by the host) and the repeat offsets carry from block to block as in
+// ZSTD_compress_frameChunk (zstd.c:27545). A kernel of its own: the single-block kernel's registers and code stay what they were.
+ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t i = zh_block() * ZE_FLAT_LANES + lane;
+    if (!(lane < ZE_FLAT_LANES && i < a.count)) return;
+    const uint32_t nb = a.mbCount[i];
+    if (!nb) return;
+    const uint32_t f = a.first + i;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint32_t srcSize = (uint32_t)a.srcSegs[2 * (size_t)f + 1];
+    ZePar cp;
+    ze_get_cparams(cp, a.rows, srcSize);                            // (the split kernel checked it)
+    uint32_t* const hl = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
+    ZeMbBlock* const blk = a.mbBlocks + (size_t)i * a.mbMaxBlocks;
+    uint64_t* const sq = a.mbSeqs + (size_t)i * a.mbSeqCap;
+    uint32_t rep[2] = {1, 4}, bs = 0, start = 0;
+    for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t be = blk[j].end;
+        // (blocks too small to compress are not searched at all: ZSTD_buildSeqStore, zstd.c:26335)
+        const uint32_t ns = be - bs < 7 ? 0u : ze_dfast_flat_t<ZE_MB_POS_BITS, true>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep);
+        blk[j].seqStart = start; blk[j].nbSeq = ns; blk[j].rep0 = rep[0]; blk[j].rep1 = rep[1];
+        start += ns; bs = be;
+    }
+    ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 5; m.pad = 0;
+#ifdef ZHIP_EMU
+    zd_stat[8]++;                                                   // (test hook [8]: sources of several blocks searched here)
+#endif
+    a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
 }
 
 // E1 for SMALL batches (one-shot compress(), a few hundred frames): the flat kernel's search with the frame's source in LDS. With few
@@ -2928,7 +3053,7 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         if (i >= a.count) break;
         const uint32_t f = a.first + i;
         const ZeMeta m = a.meta[i];
-        if (m.mode == 3) continue;                                         // listed for the generic kernel
+        if (m.mode == 3 || m.mode == 5) continue;                          // listed for the generic kernel
         const uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
         ZePre pre; pre.seqs = (const uint64_t*)(fr + ZE_ARENA_SEQ); pre.lits = m.mode == 4 ? nullptr : fr + a.arenaLit; pre.nbSeq = m.nbSeq; pre.litSize = m.litSize;
         uint64_t produced = 0;

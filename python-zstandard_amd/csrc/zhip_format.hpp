@@ -122,6 +122,11 @@ struct ZhipEncodeArgs {
     uint8_t* flatTables;            // count x tableStride, zeroed by the host before the launch
     uint32_t* e1List; uint32_t* e1Count;
     uint32_t useE1List;             // lane-serial match kernel: 1 = work is e1List[0 .. *e1Count), 0 = the whole chunk
+    // sources of several blocks searched by the flat kernel (all null / 0 otherwise; see ZeMbBlock)
+    struct ZeMbBlock* mbBlocks;     // count x mbMaxBlocks
+    uint32_t* mbCount;              // count : blocks of the frame as the split kernel laid them out; 0 = the generic kernel searches it itself
+    uint64_t* mbSeqs;               // count x mbSeqCap packed sequences, block after block
+    uint32_t mbMaxBlocks, mbSeqCap;
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;
@@ -129,7 +134,17 @@ struct ZhipEncodeArgs {
     const uint32_t* cdictHashSmall;
 };
 struct ZeMeta { uint32_t nbSeq, litSize, mode, pad; };      // mode 0: searched (sequences + literals); 1: store raw (too small); 2: error in status;
-                                                            // 3: multi-block, listed for the generic kernel; 4: searched, sequences only (flat kernel)
+                                                            // 3: multi-block, listed for the generic kernel; 4: searched, sequences only (flat kernel);
+                                                            // 5: multi-block, listed for the generic kernel WITH the flat kernel's sequences (mbBlocks)
+// A source of several blocks in the flat match kernel (one lane walks the whole frame: the hash tables and the repeat offsets carry from block
+// to block). libzstd decides where a block ends while it compresses -- ZSTD_optimalBlockSize splits a full block only once the blocks before
+// have SAVED three bytes (zstd.c:27573), and a block that ends up raw does not pass its repeat offsets on (zstd.c:27361) -- so the search
+// runs on an assumption: every block after the first sees savings >= 3, every block is emitted compressed. The split kernel lays the blocks
+// out on that assumption, the flat kernel leaves per block where its sequences start, how many, and the repeat offsets after it; the generic
+// kernel, which does the entropy coding block by block, checks the assumption against what really happened and searches the frame itself
+// where it fails (incompressible data, mostly).
+struct ZeMbBlock { uint32_t end, seqStart, nbSeq, rep0, rep1, pad[3]; };
+#define ZE_MB_POS_BITS 22                                   // cells of that search: position + 2 in 22 bits, a 10-bit tag (sources below 4 MiB - 8)
 #ifndef ZE_FLAT_LANES
 #define ZE_FLAT_LANES 64
 #endif

@@ -103,7 +103,13 @@ ZH_GLOBAL __launch_bounds__(64, 3) void zhip_encode_frames_kernel(ZhipEncodeArgs
     ze_kernel_body(a, L, M);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_kernel(ZhipEncodeArgs a) { ze_match_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a)          // block layout of sources of several blocks for the flat match kernel
+{
+    __shared__ ZeLDS L;
+    ze_split_body(a, L);
+}
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }      // sources of several blocks (after the split kernel)
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 template <uint32_t BYTES> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
 {
@@ -293,7 +299,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
-    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List;
+    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
@@ -328,7 +334,7 @@ struct zhip_ctx {
     size_t device_bytes() const
     {
         const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &encWorkspace, &encMeta, &encArena,
-                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
+                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
         for (const DevBuf* b : all) n += b->cap;
@@ -405,7 +411,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -875,6 +881,18 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (bytes > stride) stride = bytes;
             anyDfast |= r[6] == 2;
         }
+        // (sources of several blocks in the flat kernel -- `mbc` below: the rows of the larger size classes count too, at the hint's size)
+        const size_t sizeHint = c->srcMaxHint ? c->srcMaxHint : c->itemHint;
+        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
+        if (mbcWanted) for (int t = 0; t < 2; t++) {
+            const int32_t* r = a.rows.r[t];
+            if (r[6] != 2) continue;
+            int w = 17; while (((size_t)1 << w) < sizeHint) w++;
+            if (w > r[0]) w = r[0];
+            const int h = r[2] > w + 1 ? w + 1 : r[2], cl = r[1] > w ? w : r[1];
+            const uint32_t bytes = (4u << h) + (4u << cl);
+            if (bytes > stride && bytes <= (12u << 17)) stride = bytes;
+        }
         if (stride < (4u << 10)) stride = 4u << 10;
         if (stride > (12u << 17)) stride = 12u << 17;                  // larger tables: the frame is refused loudly by the match kernels
         a.arenaStride = (uint32_t)ZE_ARENA_STRIDE; a.arenaLit = ZE_ARENA_LIT;
@@ -899,6 +917,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         size_t chunkMax = c->hasCDict ? 262144 : flat ? 65536 : 32768;
         if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
+        // Sources of several blocks (the caller's size hint says so) in a double-fast batch without dictionary: the flat kernel searches them
+        // too, a lane per frame over all its blocks (ZeMbBlock, zhip_format.hpp); the generic kernel then only does their entropy coding and
+        // runs once per chunk. Per frame: block records and room for its sequences (a sequence covers three bytes or more).
+        const bool mbc = flat && !flatDict && mbcWanted;
+        const size_t mbMaxBlocks = mbc ? 2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2 : 0;
+        const size_t mbSeqCap = mbc ? sizeHint / 3 + mbMaxBlocks + 64 : 0;
+        if (mbc) { const size_t byMem = ((size_t)8 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
         const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;
@@ -914,13 +939,19 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // grid that finds an empty list still took 2.3 ms of every dictionary batch -- r02zi kernel trace; half a wave per CU is 0.4)
         // (r03: when the caller says its sources exceed one block -- the host API knows, a device-API caller can tell with zhip_ctx_set_size_hint --
         // the list is the whole batch and gets the whole chip: 2 048 x 1 MiB took 10.6 s on 64 waves, profiles/r03_multiblock_rate.txt)
-        const size_t sizeHint = c->srcMaxHint ? c->srcMaxHint : c->itemHint;
         const size_t gBigMax = sizeHint > ZF_BLOCK_MAX ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : c->hasCDict ? (size_t)c->numCU / 2 : 64;
         const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
         if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
             c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
             c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
             (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return g_reserveRc;
+        if (mbc) {
+            if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
+                c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
+            a.mbBlocks = (ZeMbBlock*)c->encMbBlocks.p; a.mbCount = (uint32_t*)c->encMbCount.p; a.mbSeqs = (uint64_t*)c->encMbSeqs.p;
+            a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap;
+            if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
+        }
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
         a.flatTables = (uint8_t*)c->encFlatTables.p; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)((uint8_t*)c->counter.p + 32);
@@ -950,7 +981,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 static const unsigned wavesPerCU[4] = { 32, 9, 2, 1 };          // by LDS (160 KiB per CU) and the 32-wave limit
                 const size_t rounds = shape == 3 ? ZHIP_E1LDS_PER_CU : c->knob.e1LdsRounds;
                 const size_t ldsMax = c->knob.e1LdsMax >= 0 ? (size_t)c->knob.e1LdsMax : (size_t)c->numCU * wavesPerCU[shape] * rounds;
-                if (cnt <= ldsMax && !flatDict) {
+                if (mbc) hipLaunchKernelGGL(zhip_encode_split_kernel, dim3((uint32_t)(cnt < (size_t)c->numCU * 8 ? cnt : (size_t)c->numCU * 8)), dim3(64), 0, stream, a);
+                if (cnt <= ldsMax && !flatDict && !mbc) {
                     const dim3 g((uint32_t)cnt), b(64);
                     if (shape == 0) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<4096>, g, b, 0, stream, a);
                     else if (shape == 1) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<16384>, g, b, 0, stream, a);
@@ -958,6 +990,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     else hipLaunchKernelGGL(zhip_encode_match_lds_kernel<ZF_BLOCK_MAX>, g, b, 0, stream, a);
                 }
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
+                if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
             if (tm) HIP_TRY(hipEventRecord(ev[2], stream));
@@ -965,6 +998,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (tm) { HIP_TRY(hipEventRecord(ev[3], stream)); HIP_TRY(hipEventRecord(ev[4], stream)); }
             hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
             if (tm) HIP_TRY(hipEventRecord(ev[5], stream));
+            if (mbc) {      // this chunk's sources of several blocks: the generic kernel over the list the flat kernel just made (it reads the chunk's arenas)
+                ZhipEncodeArgs b = a;
+                b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);
+                b.frameList = a.bigList; b.listCount = a.bigCount;
+                hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
+                HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));          // list length and the kernel's work counter: fresh for the next chunk
+            }
             HIP_TRY(hipGetLastError());
             if (tm) {
                 if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
@@ -983,7 +1023,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             for (int q = 0; q < ZEP_N; q++) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[q] / (tot ? tot : 1), (double)h[q] / (double)n);
             a.prof = nullptr;
         }
-        {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
+        if (!mbc) {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
             ZhipEncodeArgs b = a;
             b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);

@@ -7,6 +7,7 @@ extern "C" { long zd_trace_pos = -1; long zd_cur_frame = -1; long zd_stat[16]; }
 #include "../../python-zstandard_amd/csrc/zhip_encode_kernel.hpp"
 #include "../../python-zstandard_amd/csrc/zhip_cparams.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 static ZdLDS g_lds;
@@ -230,6 +231,10 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
+static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
+static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
+static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
+extern "C" void emu_set_mb_compress(uint32_t v) { g_mbCompress = v; }
 static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
 static uint32_t g_e1LdsBytes = ZF_BLOCK_MAX;       // the LDS shape under emulation (the product picks it from the batch's largest source)
 static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
@@ -248,6 +253,17 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     a.contentSizeFlag = flags & 1; a.checksumFlag = (flags >> 1) & 1; a.dictIDFlag = (flags >> 2) & 1;
     free(a.workspace); a.workspace = (uint8_t*)malloc((size_t)nBlocks * ZE_E2_STRIDE + ZHIP_ENC_STRIDE);
     a.tableStride = emu_table_stride(a.rows);
+    uint64_t maxSrc = 0; for (uint32_t i = 0; i < n; i++) if (srcSegs[2 * (size_t)i + 1] > maxSrc) maxSrc = srcSegs[2 * (size_t)i + 1];
+    if (!g_hasCD && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8)          // mirrors zhip_compress_batch_device (mbcWanted)
+        for (int t = 0; t < 2; t++) {
+            const int32_t* r = a.rows.r[t];
+            if (r[6] != 2) continue;
+            int w = 17; while ((1ull << w) < maxSrc) w++;
+            if (w > r[0]) w = r[0];
+            const int h = r[2] > w + 1 ? w + 1 : r[2], cl = r[1] > w ? w : r[1];
+            const uint32_t bytes = (4u << h) + (4u << cl);
+            if (bytes > a.tableStride && bytes <= (12u << 17)) a.tableStride = bytes;
+        }
     a.e1Lanes = g_hasCD ? ZE_E1_LANES_DICT : ZE_E1_LANES;
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * a.e1Lanes * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
@@ -260,18 +276,36 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     const bool flat = (anyDfast && !g_hasCD) || flatDict;
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
+    // sources of several blocks in the flat kernel (mirrors zhip_compress_batch_device: the size hint is the batch's largest source)
+    const bool mbc = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
+    if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] mbc %d flat %d maxSrc %llu\n", (int)mbc, (int)flat, (unsigned long long)maxSrc);
+    if (mbc) {
+        a.mbMaxBlocks = g_mbCompress > 1 ? g_mbCompress : (uint32_t)(2 * ((maxSrc + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2); a.mbSeqCap = (uint32_t)(maxSrc / 3 + a.mbMaxBlocks + 64);
+        a.mbBlocks = (ZeMbBlock*)malloc((size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); a.mbCount = (uint32_t*)malloc((size_t)chunk * 4); a.mbSeqs = (uint64_t*)malloc((size_t)chunk * a.mbSeqCap * 8);
+        memset(a.mbBlocks, 0xA5, (size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); memset(a.mbCount, 0xA5, (size_t)chunk * 4);
+    }
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0; e1Count = 0;
         if (flat) {
             memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
-            if (a.count <= g_e1LdsMax && !flatDict) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
+            if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
+            if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
             else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
+            if (mbc) zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1fmb_lane, &a);
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);
+        if (mbc && bigCount) {                   // the chunk's sources of several blocks: the generic kernel right away (it reads the chunk's arenas)
+            ZhipEncodeArgs b = a; uint32_t bc = 0;
+            b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;
+            EncLaunch l = { &b };
+            zhemu::run_grid(nBlocks, enc_lane, &l);
+            free(b.workspace);
+            bigCount = 0;
+        }
     }
-    free(a.e1List); free(a.flatTables);
+    free(a.e1List); free(a.flatTables); free(a.mbBlocks); free(a.mbCount); free(a.mbSeqs);
     if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
         ZhipEncodeArgs b = a; uint32_t bc = 0;
         b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;

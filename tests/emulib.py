@@ -150,3 +150,18 @@ def _emu_set_blocks(self, per_frame):
 
 
 Emu.set_blocks = _emu_set_blocks
+
+
+def _emu_set_mb_compress(self, v):
+    """sources of several blocks in the flat match kernel of the compress pipeline harness: 0 off (the generic kernel searches them), 1 on,
+    > 1 on with that many block slots per frame"""
+    self.lib.emu_set_mb_compress(C.c_uint32(v))
+
+
+def _emu_stat(self, i):
+    self.lib.emu_stat.restype = C.c_long
+    return int(self.lib.emu_stat(C.c_int(i)))
+
+
+Emu.set_mb_compress = _emu_set_mb_compress
+Emu.stat = _emu_stat
