@@ -324,7 +324,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -360,6 +360,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
         if (const char* e = getenv("ZHIP_SPLIT")) k.split = atol(e) != 0;
         if (const char* e = getenv("ZHIP_BLOCKS")) k.blocks = atol(e) != 0;        // 0: frames of several blocks go to the generic kernel as in rounds 1-2 (A/B)
+        if (const char* e = getenv("ZHIP_MBC_MIN")) k.mbcMin = (size_t)atol(e);     // compress: batches of at least this many sources take the flat search for sources of several blocks
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
@@ -883,7 +884,12 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         // (sources of several blocks in the flat kernel -- `mbc` below: the rows of the larger size classes count too, at the hint's size)
         const size_t sizeHint = c->srcMaxHint ? c->srcMaxHint : c->itemHint;
-        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
+        // (worth it from ~8 000 sources on. Either kernel's time is a source's serial chain of probes -- ~0.2 s per 128 KiB of source at these
+        // batch sizes -- times the ROUNDS it needs: the generic kernel holds ~4 096 searches at a time (one per wave), the flat one a whole chunk
+        // (64 per wave, whose every trip waits for the slowest of 64 requests and runs every lane's branch: ~10 % slower per round at 256 KiB,
+        // 50 % at 512 KiB+). r03u / r03v, flat against generic: 2 048 x 1 MiB 2.5 s / 1.04 s, 4 096 x 512 KiB 1.31 / 0.85, 4 096 x 256 KiB
+        // 0.44 / 0.42, 8 192 x 256 KiB 0.47 / 0.68, 16 384 x 256 KiB 0.94 (two chunks then; one now) / 1.24)
+        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && n >= c->knob.mbcMin && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
         if (mbcWanted) for (int t = 0; t < 2; t++) {
             const int32_t* r = a.rows.r[t];
             if (r[6] != 2) continue;
@@ -919,11 +925,11 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         // Sources of several blocks (the caller's size hint says so) in a double-fast batch without dictionary: the flat kernel searches them
         // too, a lane per frame over all its blocks (ZeMbBlock, zhip_format.hpp); the generic kernel then only does their entropy coding and
-        // runs once per chunk. Per frame: block records and room for its sequences (a sequence covers three bytes or more).
+        // runs once per chunk. Per frame: block records and room for its sequences (a sequence covers four bytes or more).
         const bool mbc = flat && !flatDict && mbcWanted;
         const size_t mbMaxBlocks = mbc ? 2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2 : 0;
-        const size_t mbSeqCap = mbc ? sizeHint / 3 + mbMaxBlocks + 64 : 0;
-        if (mbc) { const size_t byMem = ((size_t)8 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
+        const size_t mbSeqCap = mbc ? sizeHint / 4 + mbMaxBlocks + 64 : 0;          // (double-fast matches are four bytes or more: zstd.c:31167 / :31150)
+        if (mbc) { const size_t byMem = ((size_t)32 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
         const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;

@@ -280,7 +280,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     const bool mbc = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
     if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] mbc %d flat %d maxSrc %llu\n", (int)mbc, (int)flat, (unsigned long long)maxSrc);
     if (mbc) {
-        a.mbMaxBlocks = g_mbCompress > 1 ? g_mbCompress : (uint32_t)(2 * ((maxSrc + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2); a.mbSeqCap = (uint32_t)(maxSrc / 3 + a.mbMaxBlocks + 64);
+        a.mbMaxBlocks = g_mbCompress > 1 ? g_mbCompress : (uint32_t)(2 * ((maxSrc + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2); a.mbSeqCap = (uint32_t)(maxSrc / 4 + a.mbMaxBlocks + 64);
         a.mbBlocks = (ZeMbBlock*)malloc((size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); a.mbCount = (uint32_t*)malloc((size_t)chunk * 4); a.mbSeqs = (uint64_t*)malloc((size_t)chunk * a.mbSeqCap * 8);
         memset(a.mbBlocks, 0xA5, (size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); memset(a.mbCount, 0xA5, (size_t)chunk * 4);
     }

@@ -648,3 +648,24 @@ def test_frames_of_several_blocks_through_the_pipeline(emu, ref, corpus):
         assert st == [0, 0] and outs == draws and nfb == 0
     finally:
         emu.set_blocks(0); emu.set_ddict(None)
+
+
+def test_sources_of_several_blocks_in_the_flat_search(emu, ref, corpus):
+    """The compress pipeline on sources above 128 KiB with the flat match kernel searching them (ZeMbBlock, zhip_format.hpp; the split kernel's
+    block layout, the generic kernel's entropy coding + check of the search's assumption + redo): bit-exact against libzstd
+    (ZSTD_compress_frameChunk, zstd/zstd.c:27545) on sources built to break the assumption now and then; too few block slots send a source to
+    the generic kernel's own search. tests/stress_emu_encode_blocks.py is the open-ended form; GPU: tests/test_gpu_compress.py, same name."""
+    import numpy as np
+    from tests.stress_emu_encode_blocks import make
+    rng = np.random.default_rng(8)
+    raws = [make(rng, corpus) for _ in range(10)] + [corpus.frame_bytes(3)[:70000]]
+    want = [ref.compress(r, level=3, flags=7) for r in raws]
+    s0, r0 = emu.stat(8), emu.stat(9)
+    try:
+        for slots, chunk in ((1, 0), (3, 4)):
+            emu.set_mb_compress(slots)
+            outs, st = emu.compress_batch(raws, level=3, flags=7, n_blocks=2, pipeline=True, chunk=chunk)
+            assert st == [0] * len(raws) and outs == want, (slots, st)
+    finally:
+        emu.set_mb_compress(1)
+    assert emu.stat(8) - s0 >= 8 and emu.stat(9) - r0 >= 1          # most sources searched by the flat kernel, at least one redone

@@ -165,3 +165,42 @@ def test_multiblock_frames_bit_exact(zstd):
                 assert len(fr) == want["size"] and hashlib.sha256(fr).hexdigest() == want["sha256"], (n, lvl, tag)
     back = zstd.ZstdDecompressor().multi_decompress_to_buffer(res)
     assert [back[i].tobytes() for i in range(len(names))] == [data[n] for n in names]
+
+
+def test_sources_of_several_blocks_in_the_flat_search(zstd, corpus):
+    """Batches of thousands of sources above 128 KiB take the flat match kernel for those too (ZeMbBlock, zhip_format.hpp: block layout by the
+    split kernel, one lane per source over all its blocks, entropy coding and the check of the search's assumption in the generic kernel).
+    ZHIP_MBC_MIN=0 turns it on for a small batch -- read when a thread's context is created, so the calls run in a fresh thread. Every frame
+    against libzstd (ZSTD_compress_frameChunk, zstd/zstd.c:27545): compressible sources, incompressible stretches (raw blocks: the redo path),
+    a block that repeats the one before, runs of one byte, tails of a few bytes, a small neighbour."""
+    import os
+    import threading
+    from tests import reflib
+    from tests.stress_emu_encode_blocks import make
+    if not reflib.have_ref():
+        pytest.skip("needs reference libzstd")
+    ref = reflib.RefZstd()
+    rng = np.random.default_rng(123)
+    raws = [make(rng, corpus) for _ in range(40)] + [corpus.frame_bytes(3)[:70000], b"tiny"]
+    box = {}
+
+    def run():
+        try:
+            for flags, kw in ((5, {}), (7, {"write_checksum": True})):
+                res = zstd.ZstdCompressor(level=3, **kw).multi_compress_to_buffer(raws)
+                box[flags] = [res[i].tobytes() for i in range(len(raws))]
+            box["back"] = zstd.ZstdDecompressor().multi_decompress_to_buffer(box[7])
+            box["back"] = [box["back"][i].tobytes() for i in range(len(raws))]
+        except Exception as e:              # noqa: BLE001 -- reported by the assertion below
+            box["error"] = e
+
+    os.environ["ZHIP_MBC_MIN"] = "0"
+    try:
+        t = threading.Thread(target=run); t.start(); t.join()
+    finally:
+        del os.environ["ZHIP_MBC_MIN"]
+    assert "error" not in box, box.get("error")
+    for flags in (5, 7):
+        for i, r in enumerate(raws):
+            assert box[flags][i] == ref.compress(r, level=3, flags=flags), (flags, i, len(r))
+    assert box["back"] == raws
