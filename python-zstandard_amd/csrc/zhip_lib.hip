@@ -888,8 +888,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // batch sizes -- times the ROUNDS it needs: the generic kernel holds ~4 096 searches at a time (one per wave), the flat one a whole chunk
         // (64 per wave, whose every trip waits for the slowest of 64 requests and runs every lane's branch: ~10 % slower per round at 256 KiB,
         // 50 % at 512 KiB+). r03u / r03v, flat against generic: 2 048 x 1 MiB 2.5 s / 1.04 s, 4 096 x 512 KiB 1.31 / 0.85, 4 096 x 256 KiB
-        // 0.44 / 0.42, 8 192 x 256 KiB 0.47 / 0.68, 16 384 x 256 KiB 0.94 (two chunks then; one now) / 1.24)
-        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && n >= c->knob.mbcMin && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
+        // 0.44 / 0.42, 8 192 x 256 KiB 0.47 / 0.68, 16 384 x 256 KiB 0.51 / 1.24, 8 192 x 1 MiB 3.3 / ~2.1: the longer the sources the more
+        // rounds of the generic kernel it takes to lose, hence the threshold grows with the size hint -- ZHIP_MBC_MIN sources per 256 KiB of it)
+        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && n >= c->knob.mbcMin * ((sizeHint + (256u << 10) - 1) / (256u << 10)) && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
         if (mbcWanted) for (int t = 0; t < 2; t++) {
             const int32_t* r = a.rows.r[t];
             if (r[6] != 2) continue;
