@@ -136,8 +136,10 @@ int       zhip_ctx_set_ddict(zhip_ctx*, const void* hostDict, size_t dictSize, i
 int       zhip_ctx_set_dformat(zhip_ctx*, int format, uint64_t maxWindowSize);     /* frame format + window limit of the next decode calls */
 int       zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams* params);            /* uploads dict / tables */
 /* What a device-API caller knows about the UNCOMPRESSED size of its largest item (0 = nothing; the host-buffer API sees the sizes itself).
- * Items above one block (128 KiB) are frames of several blocks: they run one wave per frame in the generic kernels, whose grid is a token one
- * unless the library is told that such items are the batch (the reference has no equivalent: its workers take any size, c-ext/compressor.c:1035). */
+ * Items above one block (128 KiB) are frames of several blocks. Told so, decompression runs the phase-split kernels in their several-block
+ * mode (a block is the work item) and compression gives the generic kernel the whole chip -- or, in batches of thousands of such sources, the
+ * flat match kernel searches them too. Untold, they are decoded / encoded one wave per frame by a token grid of the generic kernels: correct,
+ * slow (the reference has no equivalent: its workers take any size, c-ext/compressor.c:1035). */
 void      zhip_ctx_set_size_hint(zhip_ctx*, uint64_t maxItemBytes);
 
 /* d_src: concatenated frames; d_srcSegs[i] = (offset,length) of frame i in d_src.

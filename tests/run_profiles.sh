@@ -19,7 +19,10 @@ run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- 
 run compress_fetch --pmc FETCH_SIZE --output-format csv -d $P/compress_fetch -- $B --steps 1 --warmup 0 --config compress
 run compress_write --pmc WRITE_SIZE --output-format csv -d $P/compress_write -- $B --steps 1 --warmup 0 --config compress
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/dict_kt -- python bench.py --config dict --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/dict_kt.err; echo "dict_kt rc $?"
+# frames of several blocks (2 048 x 1 MiB): the several-block mode's kernels by name
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/blocks_kt -- python tests/multiblock_rate.py 2048 1024 > $P/blocks_kt.json 2> $P/blocks_kt.err; echo "blocks_kt rc $?"
 python tests/prof_traffic.py $P $TAG $FRAMES
+f=$(find $P/blocks_kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" > gpurun_out/summary/${TAG}_blocks_2048x1MiB_kernel_stats.csv
 for d in decode_kt compress_kt; do cp $P/$d/bench.json gpurun_out/summary/${TAG}_bench_under_rocprof_${d%_kt}_$FRAMES.json; f=$(find $P/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" > gpurun_out/summary/${TAG}_${d}_kernel_stats.csv; done
 rm -rf $P
 ls -la gpurun_out/summary

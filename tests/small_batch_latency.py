@@ -51,4 +51,20 @@ for n in (16, 256):
         t0 = time.perf_counter(); r = d.multi_decompress_to_buffer(frames[:n]); best = min(best, time.perf_counter() - t0)
     assert all(r[i].tobytes() == items[i] for i in range(n))
     out["decompress_batch_%d_ms" % n] = round(best * 1e3, 2)
+# one large frame (several blocks): the several-block mode of the decode kernels (ZHIP_BLOCKS=0: the generic kernel, one wave)
+for mib in (1, 8):
+    big = b"".join(items[: 8 * mib])
+    fb = ref.compress(big)
+    d.decompress(fb)
+    ts = []
+    for k in range(3):
+        t0 = time.perf_counter(); b = d.decompress(fb); ts.append(time.perf_counter() - t0)
+    assert b == big
+    out["one_shot_decompress_%dMiB_ms" % mib] = round(min(ts) * 1e3, 2)
+    ts = []
+    c.compress(big)
+    for k in range(2):
+        t0 = time.perf_counter(); f = c.compress(big); ts.append(time.perf_counter() - t0)
+    assert f == fb
+    out["one_shot_compress_%dMiB_ms" % mib] = round(min(ts) * 1e3, 2)
 print(json.dumps(out))
