@@ -606,11 +606,11 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured on MI355X (profiles/README.md, r01c / r02f / r02zl): 65 536 frames per chunk, 2 slots
         // Frames of several blocks (the caller's size hint says so: the host API sets it from the items it sees): the several-block mode --
         // the arenas' slots are per BLOCK, a chunk is as many frames as fit `chunkMax` slots at the estimate below (libzstd cuts a block of
-        // 128 KiB in two where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
+        // 128 KiB where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
         // they are the generic kernel's)
         const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
         const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX;
-        const size_t perFrame = mb ? (size_t)(2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2) : 1;
+        const size_t perFrame = mb ? (size_t)(4 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 4) : 1;     // (r03x: 64 x 128 KiB of changing data came as 235 blocks)
         const size_t chunkFrames = mb ? (chunkMax / perFrame ? chunkMax / perFrame : 1) : chunkMax;
         const size_t chunk = n < chunkFrames ? n : chunkFrames;
         const size_t slots = chunk * perFrame;                                          // item slots per chunk (== frames without the mode)
