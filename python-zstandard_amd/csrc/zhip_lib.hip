@@ -610,10 +610,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // they are the generic kernel's)
         const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
         const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX;
-        const size_t perFrame = mb ? (size_t)(4 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 4) : 1;     // (r03x: 64 x 128 KiB of changing data came as 235 blocks)
+        // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
+        // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
+        const size_t perFrame = mb ? (size_t)(2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2) : 1;
         const size_t chunkFrames = mb ? (chunkMax / perFrame ? chunkMax / perFrame : 1) : chunkMax;
         const size_t chunk = n < chunkFrames ? n : chunkFrames;
-        const size_t slots = chunk * perFrame;                                          // item slots per chunk (== frames without the mode)
+        auto slotsFor = [&](size_t frames) { const size_t lo = frames * perFrame, hi = 2 * lo < chunkMax ? 2 * lo : chunkMax; return !mb ? frames : lo > hi ? lo : hi; };
+        const size_t slots = slotsFor(chunk);                                           // item slots per chunk (== frames without the mode)
         if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
@@ -669,7 +672,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * slots * ZP_HUF_CELLS;
             pa.orderLit = (uint32_t*)c->pipeOrderLit.p + (size_t)sidx * slots;
             if (mb) {
-                pa.itemCap = (uint32_t)(cnt * perFrame);
+                pa.itemCap = (uint32_t)slotsFor(cnt);
                 pa.itemFrame = (uint32_t*)c->pipeItemFrame.p + (size_t)sidx * slots;
                 pa.itemReps = (uint32_t*)c->pipeItemReps.p + (size_t)sidx * slots * 4;
                 pa.frameRecs = (ZpFrameRec*)c->pipeFrameRecs.p + (size_t)sidx * chunk;
