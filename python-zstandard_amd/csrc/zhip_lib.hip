@@ -609,7 +609,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // 128 KiB where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
         // they are the generic kernel's)
         const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
-        const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX;
+        const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
         const size_t perFrame = mb ? (size_t)(2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2) : 1;
