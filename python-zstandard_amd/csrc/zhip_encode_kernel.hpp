@@ -2962,8 +2962,8 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
 ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
 {
     const uint32_t lane = zh_lane();
-    const uint32_t i = zh_block() * ZE_FLAT_LANES + lane;
-    if (!(lane < ZE_FLAT_LANES && i < a.count)) return;
+    const uint32_t i = zh_block() * a.mbLanes + lane;
+    if (!(lane < a.mbLanes && i < a.count)) return;
     const uint32_t nb = a.mbCount[i];
     if (!nb) return;
     const uint32_t f = a.first + i;

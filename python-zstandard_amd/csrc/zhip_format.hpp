@@ -127,6 +127,7 @@ struct ZhipEncodeArgs {
     uint32_t* mbCount;              // count : blocks of the frame as the split kernel laid them out; 0 = the generic kernel searches it itself
     uint64_t* mbSeqs;               // count x mbSeqCap packed sequences, block after block
     uint32_t mbMaxBlocks, mbSeqCap;
+    uint32_t mbLanes;               // sources per wave of the several-block flat search (<= 64)
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;

@@ -292,7 +292,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
             else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
-            if (mbc) zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1fmb_lane, &a);
+            if (mbc) { a.mbLanes = 16; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);
