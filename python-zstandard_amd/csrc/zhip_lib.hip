@@ -324,7 +324,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32;      // (sources per wave of that search: 64 / 32 / 16 / 8 measured within 10-30 % of each other, r03z; 32 best at the threshold) size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
