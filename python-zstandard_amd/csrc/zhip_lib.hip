@@ -466,7 +466,9 @@ extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dict
     } else c->ddictKey = 0;
     c->dictSize = 0; c->dictID = 0; c->dictContentOffset = 0; c->dictHasEntropy = false;
     if (!hostDict || !dictSize) return 0;
-    if (dictSize > 0x7FFFFFFFu) { g_lastError = "dictionary too large"; c->ddictKey = 0; return ZHIP_ERR_UNSUPPORTED; }
+    // (the decode kernels pack an offset in 29 bits and keep the values from ZP_OF_LIMIT = 480 MiB up for other purposes: a dictionary must end
+    // below that for "offset beyond everything decoded so far" to stay decidable from the packed value -- zhip_decode_pipeline.hpp, K2)
+    if (dictSize >= (256u << 20)) { g_lastError = "dictionary too large"; c->ddictKey = 0; return ZHIP_ERR_UNSUPPORTED; }
     // ZSTD_loadEntropy_intoDDict (zstd.c:42716): raw content when asked for, when shorter than 8 bytes or when the magic is absent --
     // unless a full dictionary was demanded, which is then "Dictionary is corrupted"
     const bool hasMagic = dictSize >= 8 && rd32((const uint8_t*)hostDict) == ZF_DICT_MAGIC;
