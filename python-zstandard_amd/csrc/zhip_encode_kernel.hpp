@@ -2989,155 +2989,6 @@ ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
     a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
 }
 
-// The double-fast search of ONE source by a whole WAVE (small batches: ze_match_lds_body, source in LDS). The reference's loop is a chain of
-// probes -- ~45 K per 128 KiB on the bench corpus, a table round trip each -- but a stretch of probes WITHOUT a match is fully determined in
-// advance: positions (ip, ip + step, ...; the step grows every 256 bytes, zstd.c:31207), what each probe inserts, and -- by forwarding --
-// what each probe finds in the tables after the inserts of the probes before it. So lanes 0 .. n-1 take the next n probes (n <= 15, fewer
-// when the step is about to change or the block ends), lane n looks ahead (the reference reads the long-table cell of ip + step one
-// iteration early, zstd.c:31163), all cells come back in ONE round trip, and the lowest lane with a hit is the reference's next match: the
-// probes up to it are committed in order, the rest is dropped. A match every 4-5 probes on the bench corpus -> a fifth of the round trips.
-// Match extension, the backward catch-up and the insertions after a match are the reference's, done once by the whole wave (64 x 8 bytes
-// per compare round). Cells: position + 2, no tags (candidates' bytes are LDS reads). Reads up to 7 bytes past the source's end are masked
-// (the LDS area has 64 bytes of slack). srcSize >= 64; tables zeroed. All lanes call; every lane returns the sequence count.
-ZH_DEV uint32_t ze_wave_count(const uint8_t* src, uint32_t a, uint32_t b, uint32_t srcSize)        // ZSTD_count over [a, srcSize) against [b, ...): b < a
-{
-    const uint32_t lane = zh_lane();
-    uint32_t len = 0;
-    for (;;) {
-        const uint32_t pa = a + len + 8 * lane;
-        const uint32_t nv = pa < srcSize ? (srcSize - pa < 8 ? srcSize - pa : 8u) : 0u;
-        uint32_t e = 0;
-        if (nv) { const uint64_t d = zh_ld64(src + pa) ^ zh_ld64(src + b + len + 8 * lane); e = d ? (uint32_t)(zh_ctz64(d) >> 3) : 8u; if (e > nv) e = nv; }
-        const uint64_t stop = zh_ballot(e < 8);
-        if (stop) { const uint32_t l = (uint32_t)zh_ctz64(stop); return len + 8 * l + zh_shfl(e, l); }
-        len += 512;
-    }
-}
-ZH_DEVFN uint32_t ze_dfast_wave(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
-{
-    const uint32_t lane = zh_lane();
-    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
-    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
-    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
-    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
-#define ZW_HL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32) >> shL)
-#define ZW_HS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32) >> shS)
-    const uint32_t ilimit = srcSize - 8, K = 15;
-    uint32_t ip = 1, anchor = 0, off1 = 1, off2 = 0, nseq = 0;        // (wave-uniform) repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
-    for (;;) {                                                        // a search begins at ip (zstd.c:31117)
-        uint32_t step = 1, nextStep = ip + 256;
-        if (ip + step > ilimit) break;
-        for (;;) {                                                    // trips of up to K probes, all with this step
-            const uint32_t p = ip + lane * step;
-            // probe k runs iff its ip1 = p + step stays inside the block and no probe before it pushed the step up (that one ends the trip)
-            const bool probe = lane < K && p + step <= ilimit && (lane == 0 || p < nextStep);
-            const uint32_t n = (uint32_t)zh_popc64(zh_ballot(probe));              // probes are lanes 0 .. n-1 (n >= 1); lane n looks ahead (p = the last probe's ip1 <= ilimit)
-            const bool look = lane <= n;
-            uint64_t w = 0; uint32_t hl = 0, hs = 0, idxl = 0, idxs = 0;
-            if (look) { w = zh_ld64(src + p); hl = ZW_HL(w); hs = ZW_HS(w); idxl = hashLong[hl]; }
-            if (lane < n) idxs = hashSmall[hs];
-            // what the probes before this one inserted (zstd.c:31121 precedes every later read): the nearest earlier lane with the same cell wins
-            // -- and, the other way round, the nearest LATER probe that writes the same cell (of two inserts the later one must stay: no order
-            // between lanes' stores is relied upon)
-            uint32_t nextL = 64, nextS = 64;
-            {   bool gotL = false, gotS = false;
-                for (uint32_t d = 1; d <= n; d++) {
-                    const uint32_t hlp = zh_shfl_up(hl, d), hsp = zh_shfl_up(hs, d);
-                    const uint32_t hln = zh_shfl(hl, (lane + d) & 63), hsn = zh_shfl(hs, (lane + d) & 63);
-                    if (lane >= d && look) {
-                        if (!gotL && hlp == hl) { idxl = p - d * step + 2; gotL = true; }
-                        if (!gotS && hsp == hs) { idxs = p - d * step + 2; gotS = true; }
-                    }
-                    if (lane + d < n) {
-                        if (nextL == 64 && hln == hl) nextL = lane + d;
-                        if (nextS == 64 && hsn == hs) nextS = lane + d;
-                    }
-                }
-            }
-            int found = 0;
-            if (lane < n) {
-                if (off1 > 0 && zh_ld32(src + p + 1 - off1) == (uint32_t)(w >> 8)) found = 1;
-                else if (idxl > 2 && zh_ld64(src + idxl - 2) == w) found = 2;
-                else if (idxs > 2 && zh_ld32(src + idxs - 2) == (uint32_t)w) found = 3;
-            }
-            const uint64_t fm = zh_ballot(found != 0);
-            const uint32_t k = fm ? (uint32_t)zh_ctz64(fm) : n - 1;                 // the probes 0 .. k really happen
-            if (lane <= k) {                                                        // (a probe whose cell a later committed probe writes too leaves it alone)
-                if (nextL > k) hashLong[hl] = p + 2;
-                if (nextS > k) hashSmall[hs] = p + 2;
-            }
-            zh_sync();                                                              // the commits precede lane 0's inserts below and the next trip's reads
-            if (!fm) {
-                const uint32_t ip1 = ip + n * step;                                 // (only the trip's last probe can have reached nextStep)
-                if (ip1 >= nextStep) { step++; nextStep += 256; }
-                ip = ip1;
-                if (ip + step > ilimit) goto done;
-                continue;
-            }
-            // ---- the match at probe k (zstd.c:31126-31215), by the whole wave
-            const uint32_t pk = ip + k * step, ip1 = pk + step;
-            const int f = (int)zh_shfl((uint32_t)found, k);
-            const uint32_t idxlk = zh_shfl(idxl, k), idxsk = zh_shfl(idxs, k);
-            const uint32_t hl1 = zh_shfl(hl, k + 1), idxl1 = zh_shfl(idxl, k + 1);
-            const uint32_t w1lo = zh_shfl((uint32_t)w, k + 1), w1hi = zh_shfl((uint32_t)(w >> 32), k + 1);
-            uint32_t ipm = pk, mpos = 0, mLength, offBase = 1;
-            if (f == 1) { ipm = pk + 1; mLength = ze_wave_count(src, pk + 5, pk + 5 - off1, srcSize) + 4; }
-            else {
-                if (f == 2) { mpos = idxlk - 2; mLength = ze_wave_count(src, pk + 8, mpos + 8, srcSize) + 8; }
-                else {
-                    mpos = idxsk - 2; mLength = ze_wave_count(src, pk + 4, mpos + 4, srcSize) + 4;
-                    // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
-                    if (idxl1 > 2 && zh_ld64(src + idxl1 - 2) == ((uint64_t)w1lo | ((uint64_t)w1hi << 32))) {
-                        const uint32_t m1 = idxl1 - 2;
-                        const uint32_t l1 = ze_wave_count(src, ip1 + 8, m1 + 8, srcSize) + 8;
-                        if (l1 > mLength) { ipm = ip1; mLength = l1; mpos = m1; }
-                    }
-                }
-                const uint32_t offset = ipm - mpos;
-                for (;;) {                                                          // catch up (zstd.c:31182, :31204)
-                    const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
-                    if (!room) break;
-                    const bool same = lane < room && src[ipm - 1 - lane] == src[mpos - 1 - lane];
-                    const uint64_t diff = zh_ballot(!same);
-                    const uint32_t c = diff ? (uint32_t)zh_ctz64(diff) : 64u;
-                    ipm -= c; mpos -= c; mLength += c;
-                    if (c < 64) break;
-                }
-                off2 = off1; off1 = offset;
-                if (step < 4 && lane == 0) hashLong[hl1] = ip1 + 2;
-                offBase = offset + 3;
-            }
-            if (lane == 0) seqs[nseq] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
-            nseq++;
-            ip = ipm + mLength; anchor = ip;
-            if (ip <= ilimit) {
-                // complementary insertions (zstd.c:31222-31229), then the immediate repeat-offset matches (:31236-31250)
-                const uint32_t pI = pk + 2;
-                const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
-                if (lane == 0) {
-                    hashLong[ZW_HL(wI)] = pI + 2;
-                    hashLong[ZW_HL(wE2)] = ip;
-                    hashSmall[ZW_HS(wI)] = pI + 2;
-                    hashSmall[ZW_HS(wE1)] = ip + 1;
-                }
-                while (ip <= ilimit && off2 > 0 && zh_ld32(src + ip) == zh_ld32(src + ip - off2)) {
-                    const uint32_t r = ze_wave_count(src, ip + 4, ip + 4 - off2, srcSize) + 4;
-                    const uint32_t t = off2; off2 = off1; off1 = t;
-                    const uint64_t wr = zh_ld64(src + ip);
-                    if (lane == 0) { hashSmall[ZW_HS(wr)] = ip + 2; hashLong[ZW_HL(wr)] = ip + 2; seqs[nseq] = ZE_SEQ_PACK(1, 0, r); }
-                    nseq++;
-                    ip += r; anchor = ip;
-                }
-            }
-            break;                                                                  // the next search begins at ip
-        }
-    }
-done:
-#undef ZW_HL
-#undef ZW_HS
-    return nseq;
-}
-
 // E1 for SMALL batches (one-shot compress(), a few hundred frames): the flat kernel's search with the frame's source in LDS. With few
 // frames nothing hides a probe's latency, and the search is a chain of dependent round trips -- its own bytes, the table cells, the
 // candidates' bytes, then match extension / catch-up / the insertions' bytes, each a round trip of its own. One wave per frame copies
@@ -3177,14 +3028,14 @@ ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t 
     uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
     uint32_t* hashSmall = hashLong + (1u << cp.hlog);
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    if (staged && a.ldsWave) {                                      // the whole wave searches (ze_dfast_wave): a fifth of the round trips
-        m.nbSeq = ze_dfast_wave((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
-        if (lane != 0) return;
-    } else {
+    // (one lane searches. Round 3 also tried the whole wave on one source -- lanes 0..14 take the next 15 probes of a no-match stretch, one table
+    // round trip for all of them, forwarding of the earlier lanes' inserts, the lowest lane with a hit is the reference's next match; bit-exact,
+    // and SLOWER: one-shot 128 KiB 40.5 ms against 16.0, 256 inputs 60.7 against 47.1 (r03zb; commit f4216c1 has the code). A match ends the
+    // stretch every 4.5 probes on the bench corpus and the one-lane search already takes two probes per round trip, so the wave form saves
+    // little more than half the round trips and pays shuffles, ballots and a wave-wide match extension for each.)
     if (lane != 0) return;
     m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
                      : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall);
-    }
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

@@ -128,7 +128,6 @@ struct ZhipEncodeArgs {
     uint64_t* mbSeqs;               // count x mbSeqCap packed sequences, block after block
     uint32_t mbMaxBlocks, mbSeqCap;
     uint32_t mbLanes;               // sources per wave of the several-block flat search (<= 64)
-    uint32_t ldsWave;               // LDS-source match kernel (small batches): 1 = the whole wave searches a source (ze_dfast_wave), 0 = one lane (the flat search)
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;

@@ -241,8 +241,6 @@ static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_s
 extern "C" void emu_set_e1lds_bytes(uint32_t v) { g_e1LdsBytes = v; }
 static uint32_t g_e1LdsMax = 0;                 // chunks of up to this many frames take the LDS-source match kernel (mirrors zhip_compress_batch_device's choice)
 extern "C" void emu_set_e1lds_max(uint32_t v) { g_e1LdsMax = v; }
-static uint32_t g_ldsWave = 1;                 // LDS-source match kernel: 1 = ze_dfast_wave (the whole wave searches), 0 = one lane
-extern "C" void emu_set_lds_wave(uint32_t v) { g_ldsWave = v; }
 extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs, uint32_t n, uint8_t* dst, const uint64_t* dstSegs,
                                      uint64_t* outSizes, int32_t* status, int level, uint32_t flags, uint32_t nBlocks, uint32_t chunk)
 {
@@ -276,7 +274,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     bool anyDfast = false; for (int t = 2; t < 4; t++) anyDfast |= a.rows.r[t][6] == 2;
     const bool flatDict = g_hasCD && a.cdict && a.cdict->strat == 2;      // mirrors zhip_compress_batch_device
     const bool flat = (anyDfast && !g_hasCD) || flatDict;
-    uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u; a.ldsWave = g_ldsWave;
+    uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
     // sources of several blocks in the flat kernel (mirrors zhip_compress_batch_device: the size hint is the batch's largest source)
     const bool mbc = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
