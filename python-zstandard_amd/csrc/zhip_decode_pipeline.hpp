@@ -1,5 +1,6 @@
-// zhip_decode_pipeline.hpp -- phase-split batch decoder for frames made of ONE block (every frame multi_compress_to_buffer produces for
-// inputs <= 128 KiB), with or without a dictionary. Profile-driven (profiles/r01a): the fused one-wave-per-frame kernel spends 63 % of its
+// zhip_decode_pipeline.hpp -- phase-split batch decoder: frames made of ONE block (every frame multi_compress_to_buffer produces for
+// inputs <= 128 KiB) in the kernels listed below, frames of SEVERAL blocks in their several-block instantiations (the work item of K1b / K2
+// is a block; zhip_format.hpp, ZpFrameRec), with or without a dictionary. Profile-driven (profiles/r01a): the fused one-wave-per-frame kernel spends 63 % of its
 // cycles in the single-lane tANS chain and is limited to ~8-11 frames per CU by its 14 KiB of LDS. Splitting the frame loop by phase lets
 // each phase use the lane mapping -- and the LDS / register budget -- that fits ITS serial chain (DESIGN.md 4.1 has the measurements):
 //
@@ -16,7 +17,10 @@
 //   K3  zhip_decode_exec_kernel  one wave per frame   : 64 sequences per batch, the batch's output assembled in LDS and flushed in whole 16-byte
 //                                                       units; 77 VGPRs, six waves per SIMD (zhip_decode_exec_dict_kernel: with a dictionary)
 //
-// Anything else (frames of several blocks, offsets beyond the packed form) goes to the generic fused kernel through a fallback list, so
+// Several-block mode (the caller's size hint exceeds one block): zhip_decode_lit_mb_kernel (K1, a wave per frame over its blocks),
+// zhip_decode_seq_mb_kernel (K2 per block, symbolic repeat-offset history), zhip_decode_exec_mb_kernel (K3, a wave per frame over its blocks).
+// Anything else (sources of 2 GiB and more, frames that find the chunk's block slots used up, offsets the packed form cannot hold in a
+// frame of several blocks, frames of several blocks without the size hint) goes to the generic fused kernel through a fallback list, so
 // results are identical on every input.
 #pragma once
 #include "zhip_decode_kernel.hpp"
