@@ -59,5 +59,5 @@ try:
                 else: ok += 1
 finally:
     emu.set_cparams()
-print("params stress", seed, "ok", ok, "refused", refused, "bad", bad, "%.1fs" % (time.time() - t0))
+print("params stress", seed, "ok", ok, "refused", refused, "bad", bad, "searched by the flat kernel over several blocks", emu.stat(8), "redone", emu.stat(9), "%.1fs" % (time.time() - t0))
 sys.exit(1 if bad else 0)
