@@ -303,6 +303,7 @@ struct zhip_ctx {
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
+    size_t dstSlotsHint = 0;           // decode, host-buffer API: block slots the frames of the batch being launched are expected to need (1 per frame of one block, 2 per 128 KiB + 2 above), else 0
     size_t itemHint = 0;               // zhip_ctx_set_size_hint: what a device-API caller says about its items' uncompressed sizes (0 = nothing)
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
     ZeRows rows = {};                  // cparams resolved per source-size class (zhip_cparams.hpp)
@@ -615,10 +616,17 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
+        // (the host-buffer API knows every frame's size and says how many slots the batch should need in all -- a batch of mostly small frames
+        // with a few large ones is then not cut into chunks sized for the large ones: chunks are made for half the pool, the pool is twice
+        // what the chunk is expected to use)
         const size_t perFrame = mb ? (size_t)(2 * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2) : 1;
-        const size_t chunkFrames = mb ? (chunkMax / perFrame ? chunkMax / perFrame : 1) : chunkMax;
+        const size_t slotsHint = mb ? c->dstSlotsHint : 0;
+        const size_t chunkFrames = !mb ? chunkMax : slotsHint ? (size_t)((double)n * (double)(chunkMax / 2) / (double)slotsHint) + 1 : (chunkMax / perFrame ? chunkMax / perFrame : 1);
         const size_t chunk = n < chunkFrames ? n : chunkFrames;
-        auto slotsFor = [&](size_t frames) { const size_t lo = frames * perFrame, hi = 2 * lo < chunkMax ? 2 * lo : chunkMax; return !mb ? frames : lo > hi ? lo : hi; };
+        auto slotsFor = [&](size_t frames) {
+            if (!mb) return frames;
+            if (slotsHint) { const size_t want = 2 * (size_t)((double)frames * (double)slotsHint / (double)n + 1.0) + 64; return want < frames ? frames : want; }
+            const size_t lo = frames * perFrame, hi = 2 * lo < chunkMax ? 2 * lo : chunkMax; return lo > hi ? lo : hi; };
         const size_t slots = slotsFor(chunk);                                           // item slots per chunk (== frames without the mode)
         if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
@@ -1400,9 +1408,15 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
         const uint64_t outBytes = segs[n + hi - 1].offset + segs[n + hi - 1].length - segs[n + lo].offset;
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
         if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
-        { uint64_t mx = 0; for (size_t i = lo; i < hi; i++) if (segs[n + i].length > mx) mx = segs[n + i].length; c->dstMaxHint = (size_t)mx; }
+        {   uint64_t mx = 0, slotsWanted = 0;
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t len = segs[n + i].length;
+                if (len > mx) mx = len;
+                slotsWanted += len <= ZF_BLOCK_MAX ? 1 : 2 * ((len + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2;
+            }
+            c->dstMaxHint = (size_t)mx; c->dstSlotsHint = (size_t)slotsWanted; }
         r = zhip_decompress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
-        c->dstMaxHint = 0;
+        c->dstMaxHint = 0; c->dstSlotsHint = 0;
         if (r) return fail(r);
         if (hipEventRecord(evK, c->hpCompute) != hipSuccess || hipStreamWaitEvent(c->hpD2H, evK, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
         // the chunk's output goes straight into its (pinned) result payload
