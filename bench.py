@@ -451,6 +451,40 @@ def bench_roundtrip(args, rank, world, dev, steps=None, warmup=None, quiet=False
     return line
 
 
+def bench_blocks(args, rank, world, dev, steps=None, warmup=None, quiet=False):
+    """Frames of SEVERAL blocks (inputs above 128 KiB; not a BASELINE.json config -- configs[0]'s 1 MiB size as a batch): 2 048 x 1 MiB per GPU,
+    each source eight consecutive 128 KiB corpus pieces. Decompression runs the phase-split kernels' several-block mode; compression of a batch
+    this small stays in the generic kernel. Every frame compared with libzstd's, every byte with the input."""
+    from zstandard_amd.device import DeviceBatchContext
+    from tests.corpus import Corpus
+    steps = steps or args.steps; warmup = args.warmup if warmup is None else warmup
+    F, item = 2048, 1 << 20
+    per = item // FRAME
+    raw = Corpus(device=dev, mix=args.mix).frames(rank * F * per, F * per, chunk=256).reshape(F, item).contiguous()
+    raw_np = raw.cpu().numpy()
+    frames, csizes = compress_on_host(raw_np, item)
+    job = Job(world, dev)
+    ctx = DeviceBatchContext(); ctx.set_size_hint(item)
+    d_el, d_k, _ = run_decompress(job, ctx, frames, csizes, raw, item, steps, warmup)
+    ctx.close(); ctx = DeviceBatchContext(); ctx.set_size_hint(item)
+    c_steps = min(steps, 2)
+    c_el, ctotal, c_k = run_compress(job, ctx, raw, frames, item, c_steps, 1)
+    line = {"metric": "GB/s uncompressed throughput, batch decompress of 1 MiB level-3 frames (several blocks each)", "value": round(world * F * item * steps / d_el / 1e9, 3),
+            "unit": "GB/s", "n_gpus": world, "steps": steps, "ms_per_step": round(d_el / steps * 1e3, 3),
+            "config": {"workload": "multi_decompress_to_buffer / multi_compress_to_buffer (device-resident): %d x 1 MiB sources per GPU, level 3, frames of several blocks" % F,
+                       "frames_per_gpu": F, "frame_bytes": item, "level": 3, "compression_ratio": round(F * item / float(csizes.sum()), 3)}}
+    if rank == 0:
+        line["kernels"] = kernels_obj(ctx, d_k)
+        line["compress"] = {"value": round(world * F * item * c_steps / c_el / 1e9, 3), "ms_per_step": round(c_el / c_steps * 1e3, 1), "bit_exact_vs_libzstd": True,
+                            "kernel": "zhip_encode_frames_kernel (one wave per source: batches below ~8 192 sources per 256 KiB stay at the search's latency bound)"}
+        if not quiet:
+            print(json.dumps(line))
+    ctx.close()
+    del raw
+    torch.cuda.empty_cache()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -461,11 +495,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compress-frames", type=int, default=65536,
                     help="after the timed decompress steps, also time multi_compress_to_buffer on this many of the same inputs (0 = skip)")
-    ap.add_argument("--config", choices=["decompress", "compress", "dict", "roundtrip"], default=None,
+    ap.add_argument("--config", choices=["decompress", "compress", "dict", "roundtrip", "blocks"], default=None,
                     help="decompress (default) is the BASELINE.json headline; compress / dict / roundtrip are configs[2] / [3] / [4] as their own lines")
     ap.add_argument("--extra", action="store_true", help="carry the sub-objects at N > 1 too (default: N == 1 only -- the scaling runs keep to the headline)")
     ap.add_argument("--no-extra", action="store_true",
-                    help="default config only: skip the 'dict' (configs[3]) and 'roundtrip' (configs[4]) sub-objects the line otherwise carries")
+                    help="default config only: skip the 'dict' (configs[3]), 'roundtrip' (configs[4]) and 'blocks' (frames of several blocks) sub-objects the line otherwise carries")
     ap.add_argument("--mix", choices=["silesia", "default"], default="silesia", help="class mix of the 128 KiB corpus (tests/corpus.py)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
     args = ap.parse_args()
@@ -492,6 +526,8 @@ def main():
             bench_dict(args, rank, world, dev)
         elif config == "roundtrip":
             bench_roundtrip(args, rank, world, dev)
+        elif config == "blocks":
+            bench_blocks(args, rank, world, dev)
         else:
             bench_frames(args, config, rank, world, dev)
     finally:
@@ -599,7 +635,7 @@ def bench_frames(args, config, rank, world, dev):
         # reported in the sub-object and never loses the headline.
         del raw, raw_np, frames
         torch.cuda.empty_cache()
-        for key, fn in (("dict", bench_dict), ("roundtrip", bench_roundtrip)):
+        for key, fn in (("dict", bench_dict), ("roundtrip", bench_roundtrip), ("blocks", bench_blocks)):
             t0 = time.time()
             try:
                 sub = fn(args, rank, world, dev, steps=3, warmup=1, quiet=True)
