@@ -41,6 +41,12 @@ if t and "error" not in t:
                  "**%.1f GB/s** per round trip (compress %.1f + decompress %.1f GB/s); N > 1 all-gatherv leg unmeasured (no multi-GPU hardware)"
                  % (t["value"], t["compress"]["value"], t["decompress"]["value"]),
                  "%.1f GB/s (compress %.1f, decompress %.1f)" % (tc.get("value", 0), tc.get("compress", 0), tc.get("decompress", 0))))
+b = line.get("blocks")
+if b and "error" not in b:
+    rows.append(("[-] frames of several blocks: %d x 1 MiB (not a BASELINE config)" % b["config"]["frames_per_gpu"],
+                 "decompress **%.1f GB/s** (%.1f ms per step: the phase-split kernels' several-block mode), compress %.1f GB/s (the generic kernel; large batches of "
+                 "such sources take the flat search, DESIGN.md 4.2); every frame libzstd's, every byte back" % (b["value"], b["ms_per_step"], b["compress"]["value"]),
+                 "24-30 / 6 GB/s (rows 1-2)"))
 print("| workload (BASELINE.json config) | this backend, one MI355X, buffers resident in HBM | reference libzstd 1.5.7 on the same box's host cores |")
 print("|---|---|---|")
 for a, b, c_ in rows:
