@@ -53,8 +53,9 @@ class DeviceBatchContext:
             self._cparams_set = True
 
     def set_size_hint(self, max_item_bytes):
-        """largest uncompressed item of the coming calls (0 = unknown): batches of inputs / frames above 128 KiB get a full grid of the
-        one-wave-per-frame kernels that serve frames of several blocks"""
+        """largest uncompressed item of the coming calls (0 = unknown): with items above 128 KiB (frames of several blocks) decompression
+        runs the phase-split kernels in their several-block mode and compression of large batches gives those sources to the flat match
+        kernel; untold, such items are served one wave each by a token grid of the generic kernels (correct, slow)"""
         self.L.zhip_ctx_set_size_hint(self.ctx, int(max_item_bytes))
 
     def close(self):

@@ -176,6 +176,13 @@ def _cdev(group):
     return _device() if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+def _hint(ctx, largest):
+    """tell the context how large this rank's largest (uncompressed) item is: items above one block take the kernels' several-block modes
+    (zhip_ctx_set_size_hint); stand-in contexts of the CPU tests need not know the call"""
+    if hasattr(ctx, "set_size_hint"):
+        ctx.set_size_hint(int(largest))
+
+
 def compress_shard(ctx, src, src_segs, gather=False, group=None):
     """Every rank compresses the shard IT holds (src / src_segs: device arena + int64 [k, 2] segments; ranks may hold different
     counts, none included); global item order = rank order. Returns a ShardResult like multi_compress_to_buffer. Nothing but the
@@ -192,6 +199,7 @@ def compress_shard(ctx, src, src_segs, gather=False, group=None):
     out_sizes = torch.zeros(k, dtype=torch.int64, device=dev)
     status = torch.zeros(k, dtype=torch.int32, device=dev)
     if k:
+        _hint(ctx, lens.max().item())
         ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
     _raise_on_error(status, bounds[rank][0], "compressing", group)
     arena, segs = _compact(dst, dst_segs, out_sizes, status, dev, getattr(ctx, "compact", None))
@@ -212,6 +220,7 @@ def decompress_shard(ctx, src, src_segs, sizes, gather=False, group=None):
     out_sizes = torch.zeros(k, dtype=torch.int64, device=dev)
     status = torch.zeros(k, dtype=torch.int32, device=dev)
     if k:
+        _hint(ctx, want.max().item())
         ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
     _raise_on_error(status, bounds[rank][0], "decompressing", group, out_sizes, want)
     res = ShardResult(rank, bounds, dst, torch.stack([offs, out_sizes], dim=1) if k else dst_segs, _exchange_sizes(out_sizes, group), status)
@@ -238,6 +247,7 @@ def multi_decompress_to_buffer(frames, decompressed_sizes, dict_data=None, gathe
     out_sizes = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
     status = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
     if hi > lo:
+        _hint(ctx, want.max())
         ctx.decompress(src, src_segs, dst, dst_segs, out_sizes, status)
     # a frame that produces fewer bytes than announced would leave a hole in the dense arena the global table assumes: the host API's
     # "decompressed N bytes; expected M" (c-ext/decompressor.c:1131-1140), agreed on across ranks like any other item error
@@ -268,6 +278,7 @@ def multi_compress_to_buffer(items, level=3, dict_data=None, gather=False, group
     out_sizes = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
     status = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
     if hi > lo:
+        _hint(ctx, max(int(n) for n in lens))
         ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)
     _raise_on_error(status, lo, "compressing", group)
     arena, segs = _compact(dst, dst_segs, out_sizes, status, dev, getattr(ctx, "compact", None))
