@@ -165,3 +165,41 @@ def skippable_frames():
         ("skippable frame, header cut short", skip[:6], 0, False),
         ("one past the skippable magics", b"\x60\x2a\x4d\x18" + skip[4:], 0, False),
     ]
+
+
+def encoding_variants():
+    """(name, frame, declared size, accepted) -- legal but non-minimal encodings and small illegal ones around the section headers: literal
+    sizes in the longer header forms, the sequence count in its 2- and 3-byte forms, RLE-mode tables with symbols beyond the alphabets,
+    reserved mode bits, degenerate block sizes, a treeless literals section with nothing to inherit. All agreed with libzstd when they were
+    written (round 3); they stay as a fence."""
+    magic = b"\x28\xb5\x2f\xfd"
+
+    def blk(content, last=True): return ((1 if last else 0) | (2 << 1) | (len(content) << 3)).to_bytes(3, "little") + content
+
+    def frm(blocks): return magic + bytes([0x00, (17 - 10) << 3]) + b"".join(blocks)
+    lits = b"abcdefgh"
+    seqpart = sequences_block(lits, [(8, 30, 5), (0, 3, 3)])[3:][1 + 8:]              # count, modes, stream
+    rl_seq = sequences_block(b"aaaaaaaa", [(8, 30, 5), (0, 3, 3)])[3:][1 + 8:]
+
+    def seq_rle(ll, of, ml, stream): return bytes([1, (1 << 6) | (1 << 4) | (1 << 2), ll, of, ml]) + stream
+    h1 = bytes([8 << 3])
+    out = [
+        ("raw literals, 2-byte header", frm([blk(((8 << 4) | (1 << 2)).to_bytes(2, "little") + lits + seqpart)]), 41, True),
+        ("raw literals, 3-byte header", frm([blk(((8 << 4) | (3 << 2)).to_bytes(3, "little") + lits + seqpart)]), 41, True),
+        ("RLE literals, 1-byte header", frm([blk(bytes([(8 << 3) | 1]) + b"a" + rl_seq)]), 41, True),
+        ("RLE literals, 2-byte header", frm([blk(((8 << 4) | (1 << 2) | 1).to_bytes(2, "little") + b"a" + rl_seq)]), 41, True),
+        ("RLE literals, 3-byte header", frm([blk(((8 << 4) | (3 << 2) | 1).to_bytes(3, "little") + b"a" + rl_seq)]), 41, True),
+        ("sequence count in the 2-byte form", frm([blk(h1 + lits + bytes([0x80, 2]) + seqpart[1:])]), 41, True),
+        ("sequence count in the 3-byte form, far too many", frm([blk(h1 + lits + bytes([0xFF, 0x02, 0x81]) + seqpart[1:])]), 41, False),
+        ("no sequences, count in the 2-byte form", frm([blk(h1 + lits + bytes([0x80, 0]))]), 8, True),
+        ("no sequences but bytes after the count", frm([blk(h1 + lits + bytes([0, 0]))]), 8, False),
+        ("RLE-mode tables", frm([blk(h1 + lits + seq_rle(8, 2, 0, bytes([0b100])))]), 11, True),
+        ("RLE-mode literal-length symbol 36", frm([blk(h1 + lits + seq_rle(36, 2, 0, bytes([1])))]), 11, False),
+        ("RLE-mode offset symbol 32", frm([blk(h1 + lits + seq_rle(8, 32, 0, bytes([1])))]), 11, False),
+        ("RLE-mode match-length symbol 53", frm([blk(h1 + lits + seq_rle(8, 2, 53, bytes([1])))]), 11, False),
+        ("reserved mode bits set", frm([blk(h1 + lits + bytes([2, 1]) + seqpart[2:])]), 41, False),
+        ("compressed block of one byte", _hdr(0, 17) + blk(b"\x00"), 0, False),                       # (content size 0 in the header: a batch item needs one)
+        ("compressed block without literals or sequences", _hdr(0, 17) + blk(b"\x00\x00"), 0, True),
+        ("treeless literals with nothing to inherit", frm([blk(bytes([0x83, 0x40, 0x01]) + b"\x01\x02\x03\x04\x05" + bytes([0]))]), 8, False),
+    ]
+    return out

@@ -13,7 +13,7 @@ from tests import craft, reflib
 def main():
     ref = reflib.RefZstd()
     rows = []
-    for name, f, n, ok in craft.edge_frames() + craft.skippable_frames():
+    for name, f, n, ok in craft.edge_frames() + craft.skippable_frames() + craft.encoding_variants():
         try: out = ref.decompress(f, n)
         except RuntimeError: out = None
         assert (out is not None) == ok, name

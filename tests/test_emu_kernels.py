@@ -583,7 +583,7 @@ def test_frames_no_encoder_writes_through_the_emulated_kernels(emu, ref):
     one-pass and streaming decoders, zstd.c:44239-44246 / :47714): K1 / K2 / K3 and the generic kernel accept exactly what libzstd accepts and
     produce its bytes. The GPU form is tests/test_gpu_decompress.py::test_frames_no_encoder_writes_are_answered_like_libzstd."""
     from tests import craft
-    cases = craft.edge_frames() + craft.skippable_frames()
+    cases = craft.edge_frames() + craft.skippable_frames() + craft.encoding_variants()
     outs, st, nfb = emu.decompress_pipeline([c[1] for c in cases], [c[2] for c in cases], n_blocks=3, chunk=0)
     outs2, st2 = emu.decompress_batch([c[1] for c in cases], [c[2] for c in cases], n_blocks=2)          # every one through the generic kernel too
     for (name, f, n, ok), o, s, o2, s2 in zip(cases, outs, st, outs2, st2):

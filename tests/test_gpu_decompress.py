@@ -138,7 +138,7 @@ def test_frames_no_encoder_writes_are_answered_like_libzstd(zstd):
     streaming decoders (zstd.c:44239-44246, :47714) -- accepted exactly when libzstd accepts, with libzstd's bytes; alone (K1 / K2 / K3 or
     the generic kernel) and all together in one batch."""
     from tests import craft, reflib
-    cases = craft.edge_frames() + craft.skippable_frames()      # (skippable frames as items: passed over, an empty segment; c-ext/decompressor.c:986-988 reads their size 0)
+    cases = craft.edge_frames() + craft.skippable_frames() + craft.encoding_variants()      # (skippable frames as items: passed over, an empty segment; c-ext/decompressor.c:986-988 reads their size 0)
     ref = reflib.RefZstd() if reflib.have_ref() else None
     d = zstd.ZstdDecompressor()
     good = []
