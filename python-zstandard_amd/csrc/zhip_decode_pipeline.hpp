@@ -1029,6 +1029,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #ifndef ZP_ASM_BYTES
 #define ZP_ASM_BYTES ZD_ASM_BYTES       // K3's batch assembly buffer (LDS per wave = this + 1.6 KiB): smaller buffers leave room for a K2 wave beside sixteen K3 waves
 #endif
+#ifdef ZP_K3_V1
 struct ZpExecLDS {
     uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
@@ -1438,6 +1439,271 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
     return 0;
 }
 
+#else
+// ------------------------------------------------------------------------------------------ K3, round-4 form
+// Round 3's batch loop spent 45 % of its instructions on the matches that read the batch's own output (binary searches for the need-masks,
+// ~4.3 dependency rounds per batch on the bench corpus, predicated piece copies) and 25 % on dealing the long items out to the lanes.
+// This form drops both mechanisms:
+//   * items of up to 32 bytes (literal runs, far matches: 99 % / 97 %) are copied by their own lane from two 16-byte loads -- the item's
+//     FIRST 16 bytes and the 16 bytes that END with it -- so every length class is two unconditional stores from the same registers
+//     (1: a byte; 2-3: two 2-byte pieces; 4-7: two dwords; 8-15: two 8-byte pieces; 16-32: two 16-byte pieces), no shifts, no cascade;
+//   * longer items (~2 per batch) are cut into 16-byte units by a SCALAR loop that hands each item a range of lanes: all units of all items
+//     load together, a unit fetches its item's numbers from the owning lane by ds_bpermute;
+//   * matches that read the batch's own output are executed ONE AFTER THE OTHER, in stream order, by the whole wave (lanes = dwords of the
+//     match): everything a match reads is final when its turn comes, so there are no need-masks, no rounds, no LDS index arrays -- per match
+//     two v_readlane, ~5 vector instructions and an LDS read -> write; all control is scalar.
+// 16 bytes of padding precede the assembly buffer: a piece that ends with an item shorter than 16 bytes is addressed from 16 bytes below the item's end.
+struct ZpExecLDS { uint8_t pad[16]; uint8_t asmb[ZP_ASM_BYTES + 64]; uint32_t misc[8]; };
+#ifndef ZP_OWN_MAX
+#define ZP_OWN_MAX 32u             // items up to this long are copied by their own lane
+#endif
+#define ZP_SMALL_MAX 1023u          // a sequence of more bytes ends the batch before it and is executed alone (its sums would not fit the packed scan)
+#define ZD_TP(P, i) do { if (PROF) ZD_T(P, i); } while (0)
+ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2)
+{
+    if (v <= ZP_OF_LIMIT) return v;                              // (ZP_OF_LIMIT itself: K2's "too large for the packed form", the caller looks for it)
+    if (v > ZP_SYM_TOP) return 0xFFFFFFFFu;
+    const uint32_t k = (v - (ZP_OF_LIMIT + 1)) >> 23;
+    const uint32_t d = ZP_SYM_REP(k) - v;
+    const uint32_t r = k == 0 ? R0 : k == 1 ? R1 : R2;
+    return r > d ? r - d : 0xFFFFFFFFu;
+}
+struct zh_q4 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(1))) zh_q4u { uint32_t a, b, c, d; };
+ZH_DEV zh_q4 zp_ldq(const uint8_t* p) { const zh_q4u v = *(const zh_q4u*)p; zh_q4 r; r.a = v.a; r.b = v.b; r.c = v.c; r.d = v.d; return r; }
+// `len` bytes (1 .. 32; 0: nothing) to LDS at q: A = the item's first 16 bytes, Z = the 16 bytes that end with it
+ZH_DEV void zp_put32(uint8_t* q, uint32_t len, const zh_q4& A, const zh_q4& Z)
+{
+    uint8_t* const qe = q + len;                           // (pieces addressed from the end: qe - 16 .. qe, at least q - 15 -> the padding)
+    if (len >= 16) {
+        zh_st64(q, (uint64_t)A.a | ((uint64_t)A.b << 32)); zh_st64(q + 8, (uint64_t)A.c | ((uint64_t)A.d << 32));
+        zh_st64(qe - 16, (uint64_t)Z.a | ((uint64_t)Z.b << 32)); zh_st64(qe - 8, (uint64_t)Z.c | ((uint64_t)Z.d << 32));
+    } else if (len >= 8) {
+        zh_st64(q, (uint64_t)A.a | ((uint64_t)A.b << 32)); zh_st64(qe - 8, (uint64_t)Z.c | ((uint64_t)Z.d << 32));
+    } else if (len >= 4) {
+        zh_st32(q, A.a); zh_st32(qe - 4, Z.d);
+    } else if (len >= 2) {
+        zh_st16(q, (uint16_t)A.a); zh_st16(qe - 2, (uint16_t)(Z.d >> 16));
+    } else if (len) q[0] = (uint8_t)A.a;
+}
+// One match of the sequential pass whose source is not plainly inside the assembly buffer: it starts below the batch (global memory / the
+// dictionary), or overlaps its own output (offset < length), or is longer than 256 bytes. Uniform arguments; d / sR batch-relative.
+template <bool DICT>
+ZH_DEVFN void zp_seq_match_generic(uint8_t* asmb, const uint8_t* dst, const uint8_t* dictEnd, uint32_t ob, uint32_t d, int32_t sR, uint32_t n)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t ofs = (uint32_t)((int32_t)d - sR);
+    if (ofs >= 64 || ofs >= n) {
+        for (uint32_t c = 0; c < n; c += 64) {
+            const uint32_t j = c + lane;
+            if (j < n) { const int32_t sp = sR + (int32_t)j; asmb[d + j] = sp >= 0 ? asmb[sp] : (uint8_t)zd_hist_byte(dst, dictEnd, (int32_t)ob + sp); }
+            if (ofs < n) zh_wave_fence();                  // the next 64 bytes read these
+        }
+    } else {                                               // period `ofs` < 64: every source byte precedes d
+        uint32_t idx = lane % ofs; const uint32_t adv = 64 % ofs;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const int32_t sp = sR + (int32_t)idx;
+            asmb[d + j] = sp >= 0 ? asmb[sp] : (uint8_t)zd_hist_byte(dst, dictEnd, (int32_t)ob + sp);
+            idx += adv; if (idx >= ofs) idx -= ofs;
+        }
+    }
+}
+
+// One compressed block: the sequences K2 left in slot `t`, the literals of slot `t` (or in place), executed at output position `opRef` of
+// the frame at `dst` (MB = false: the frame's only block, position 0). m = the block's record; srcOff / srcSize: where the frame lies in the
+// caller's source arena (raw literals are read in place). 0 or a zstd error code. Reference semantics: ZSTD_execSequence zstd.c:46634.
+template <bool DICT, bool PROF, bool MB>
+ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint64_t srcOff, uint64_t srcSize, uint8_t* dst,
+                           uint32_t cap, uint64_t cap64, uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
+{
+    const uint32_t lane = zh_lane();
+    const uint64_t* seqs = a.seqArena + (size_t)t * ZP_SEQ_CAP;
+    const bool litRLE = m.litMode == 2, litRaw = m.litMode == 0;
+    const uint32_t rleByte = m.litOff;
+    const uint8_t* litPtr = litRaw ? src + m.litOff : a.litArena + (size_t)t * ZP_LIT_STRIDE;
+    const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
+    const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
+    uint8_t* const asmb = L.asmb;
+    const uint32_t blockStart = MB ? opRef : 0u;
+    uint32_t op = blockStart, lp = 0, done = 0;
+    // The flush writes whole 16-byte units only: the last `carry` (< 16) bytes of a batch stay at the front of the assembly buffer and leave
+    // with the next batch. asmb[0] is the byte at absolute position ob = op - carry; every batch-relative offset below counts from ob.
+    uint32_t carry = 0;
+    const uint32_t nbSeq = m.nbSeq;
+    uint64_t qNext = lane < nbSeq ? *(seqs + lane) : 0;                  // the next batch's sequences are requested a batch ahead
+    zh_q4 rleQ; rleQ.a = rleQ.b = rleQ.c = rleQ.d = 0x01010101u * (rleByte & 255u);
+    while (done < nbSeq) {
+        const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
+        uint32_t myLL, myML, myOF;
+        {   const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); if (MB) myOF = zp_sym_resolve(myOF, R0, R1, R2); }
+        const bool inb = lane < avail;
+        if (MB && zh_ballot(inb && myOF == ZP_OF_LIMIT)) return ZP_RC_FALLBACK;      // an offset K2 could not pack: the generic kernel's frame
+        // a sequence of more than ZP_SMALL_MAX bytes ends the batch in front of it; first in line, it is executed alone, straight in global memory
+        const uint64_t bigMask = zh_ballot(inb && myLL + myML > ZP_SMALL_MAX);
+        const uint32_t n1 = bigMask ? (uint32_t)zh_ctz64(bigMask) : avail;
+        if (n1 == 0) {
+            const uint32_t bll = zh_bcast(myLL, 0), bml = zh_bcast(myML, 0), bof = zh_bcast(myOF, 0);
+            if (lp + bll > m.litSize) return ZE_CORRUPTION;
+            if ((uint64_t)op + bll + bml > cap) return ZE_DST_TOO_SMALL;
+            if (op + bll + bml - blockStart > blockMax) return ZE_CORRUPTION;
+            if ((uint64_t)bof > (uint64_t)op + bll + dictSize) return ZE_CORRUPTION;
+            if (lane < carry) dst[op - carry + lane] = asmb[lane];      // what the last flush held back
+            carry = 0;
+            zd_fence();
+            if (litRLE) zd_fill_wave(dst + op, rleByte, bll); else zd_copy_wave(dst + op, litPtr + lp, bll);
+            zd_fence();
+            zd_match_wave(dst, dictEnd, op + bll, bof, bml);
+            zd_fence();
+            op += bll + bml; lp += bll; done += 1;
+            qNext = done + lane < nbSeq ? *(seqs + done + lane) : 0;
+            continue;
+        }
+        {   const bool a1 = lane < n1; myLL = a1 ? myLL : 0u; myML = a1 ? myML : 0u; }
+        // ONE scan for both running sums: total bytes in the low half, literal bytes in the high half (64 x 1023 < 2^16)
+        const uint32_t pk = zh_scan_add((myLL + myML) | (myLL << 16));
+        const uint32_t incT = pk & 0xFFFFu, incL = pk >> 16;
+        const uint64_t fits = zh_ballot(lane < n1 && incT + carry <= ZP_ASM_BYTES);     // a prefix mask (incT is monotone); its first bit is set
+        const uint32_t cnt = (uint32_t)zh_popc64(fits);
+        qNext = done + cnt + lane < nbSeq ? *(seqs + done + cnt + lane) : 0;
+        const bool act = lane < cnt;
+        if (!act) { myLL = 0; myML = 0; myOF = 1; }
+        const uint32_t totL = zh_bcast(incL, cnt - 1), totT = zh_bcast(incT, cnt - 1);
+        if (lp + totL > m.litSize) return ZE_CORRUPTION;
+        if ((uint64_t)op + totT > cap) return ZE_DST_TOO_SMALL;
+        if (op + totT - blockStart > blockMax) return ZE_CORRUPTION;
+        const uint32_t ob = op - carry;
+        const uint32_t litStart = act ? lp + incL - myLL : lp;
+        const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
+        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)ob + mRel + dictSize)) return ZE_CORRUPTION;
+        ZD_TP(P, ZP_STAGE);
+        const int32_t sRel = (int32_t)mRel - (int32_t)myOF;               // the match source, batch-relative (below 0: before the batch)
+        const int32_t sEnd = sRel + (int32_t)myML;
+        const int32_t sAbs = (int32_t)ob + sRel;                          // frame-relative (below 0: the dictionary)
+        const bool hasM = act && myML > 0;
+        const bool farM = hasM && sEnd <= 0;                              // the whole source lies below the batch: global memory
+        // ---- literal runs of 1 .. ZP_OWN_MAX bytes by their own lanes. Reading 16 bytes around a run is harmless where the memory is ours:
+        // the literal arena (256 bytes of padding on both sides); literals left in the caller's frame only where the batch's runs keep 16
+        // bytes from both ends of the source arena / the frame -- otherwise this batch's runs are copied byte by byte (litOdd)
+        bool litOK = true;
+        if (litRaw) litOK = srcOff + m.litOff + lp >= 16 && (uint64_t)m.litOff + lp + totL + 16 <= srcSize;
+        const bool ownL = myLL > 0 && myLL <= ZP_OWN_MAX;                 // (inactive lanes: myLL == 0)
+        zh_q4 la, lz; la = rleQ; lz = rleQ;
+        if (!litRLE && litOK) { const uint8_t* q = litPtr + litStart; la = zp_ldq(q); lz = zp_ldq(q + myLL - 16); }
+        // ---- far matches of up to ZP_OWN_MAX bytes likewise, where 16 bytes before the match's end and behind its start are this frame's
+        // (or the dictionary's) bytes; the others join the sequential pass below
+        bool ownM;
+        const uint8_t* mp = dst;
+        {
+            bool reg = farM && myML <= ZP_OWN_MAX && sAbs >= 0 && sAbs + (int32_t)myML >= 16 && (uint64_t)(uint32_t)sAbs + 16 <= cap64;
+            if (DICT) {
+                const bool inDict = farM && myML <= ZP_OWN_MAX && sAbs + (int32_t)myML <= 0 && (uint32_t)(-sAbs) + 16 - myML <= dictSize && (uint32_t)(-sAbs) >= 16;
+                if (inDict) mp = dictEnd;
+                reg = reg || inDict;
+            }
+            ownM = reg;
+        }
+        zh_q4 ma, mz;
+        {   const uint8_t* q = ownM ? mp + sAbs : (const uint8_t*)seqs;            // (lanes without such a match read 16 bytes that are always there)
+            ma = zp_ldq(q); mz = zp_ldq(ownM ? q + myML - 16 : q); }
+        // ---- long items: each gets a range of lanes, one 16-byte unit per lane (the last one shifted back to end with the item)
+        const bool longL = myLL > ZP_OWN_MAX;
+        const bool longM = farM && myML > ZP_OWN_MAX && (sAbs >= 0 || (DICT && sAbs + (int32_t)myML <= 0));
+        const uint64_t longLMask = zh_ballot(longL), longMMask = zh_ballot(longM);
+        const bool seqM = hasM && !ownM && !longM;                        // reads the batch's own output, or is irregular: the sequential pass
+        if (longLMask | longMMask) {
+            for (int kind = 0; kind < 2; kind++) {
+                uint64_t mk = kind ? longMMask : longLMask;
+                const uint32_t vLen = kind ? myML : myLL;
+                const uint32_t vSrc = kind ? (uint32_t)sAbs : litStart;
+                const uint32_t vDst = kind ? mRel : oRel;
+                while (mk) {
+                    // hand out lanes: item after item while they fit
+                    uint32_t u0 = 0, owner = 0xFFFFFFFFu, ubase = 0;
+                    while (mk) {
+                        const uint32_t l = (uint32_t)zh_ctz64(mk);
+                        const uint32_t n = (zh_bcast(vLen, l) + 15) >> 4;              // <= 64
+                        if (u0 + n > 64) break;
+                        const bool mine = lane >= u0 && lane < u0 + n;
+                        owner = mine ? l : owner; ubase = mine ? u0 : ubase;
+                        u0 += n; mk &= mk - 1;
+                    }
+                    const bool have = owner != 0xFFFFFFFFu;
+                    const uint32_t ol = have ? owner : lane;
+                    const uint32_t len = zh_shfl(vLen, ol), so = zh_shfl(vSrc, ol), dd = zh_shfl(vDst, ol);
+                    if (have) {
+                        const uint32_t k = lane - ubase;
+                        const uint32_t off = 16 * k + 16 <= len ? 16 * k : len - 16;
+                        zh_q4 v;
+                        if (kind == 0) { if (litRLE) v = rleQ; else v = zp_ldq(litPtr + so + off); }
+                        else { const int32_t sm = (int32_t)so; v = zp_ldq((!DICT || sm >= 0 ? dst + sm : dictEnd + sm) + off); }
+                        uint8_t* q = asmb + dd + off;
+                        zh_st64(q, (uint64_t)v.a | ((uint64_t)v.b << 32)); zh_st64(q + 8, (uint64_t)v.c | ((uint64_t)v.d << 32));
+                    }
+                }
+            }
+        }
+        // ---- the own-lane items into the buffer
+        if (litOK) zp_put32(asmb + oRel, ownL ? myLL : 0u, la, lz);
+        else {                                                             // (rare: raw literals next to the ends of the caller's buffer)
+            for (uint64_t mk = zh_ballot(ownL); mk; mk &= mk - 1) {
+                const uint32_t l = (uint32_t)zh_ctz64(mk);
+                const uint32_t n = zh_bcast(myLL, l), so = zh_bcast(litStart, l), dd = zh_bcast(oRel, l);
+                if (lane < n) asmb[dd + lane] = litPtr[so + lane];
+            }
+        }
+        zp_put32(asmb + mRel, ownM ? myML : 0u, ma, mz);
+        zh_wave_fence();
+        ZD_TP(P, ZP_EXEC1);
+        // ---- the matches that read this batch's own output (and the irregular ones), one after the other in stream order: when a match's
+        // turn comes every byte it reads is final. The whole wave copies it, a dword per lane (the last one shifted back to end with it).
+        for (uint64_t mk = zh_ballot(seqM); mk; mk &= mk - 1) {
+            const uint32_t l = (uint32_t)zh_ctz64(mk);
+            const uint32_t pk2 = zh_bcast(mRel | (myML << 16), l);
+            const int32_t sR = (int32_t)zh_bcast((uint32_t)sRel, l);
+            const uint32_t d = pk2 & 0xFFFFu, n = pk2 >> 16;
+            if (sR >= 0 && (uint32_t)sR + n <= d && n <= 256 && n >= 4) {      // plainly inside the buffer, not overlapping its own output
+                const uint32_t off = 4 * lane + 4 <= n ? 4 * lane : n - 4;
+                if (4 * lane < n) { const uint32_t w = zh_ld32(asmb + sR + off); zh_st32(asmb + d + off, w); }
+            } else zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
+            zh_wave_fence();
+        }
+        ZD_TP(P, ZP_EXEC2);
+        // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
+        // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
+        qNext = zh_opaque64(qNext);
+        const uint32_t totB = totT + carry, whole = totB & ~15u;         // bytes in the buffer; the part that leaves now
+        {
+            uint8_t* out = dst + ob;
+            for (uint32_t j = lane * 16; j < whole; j += 1024) {
+                const uint32_t* s4 = (const uint32_t*)(asmb + j);
+                ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
+                *(ZdPack16*)(out + j) = v;
+            }
+        }
+        carry = totB - whole;
+        zh_wave_fence();
+        if (carry && whole) {                                              // the tail moves to the front (one 16-byte read / write; every flush read is done)
+            uint64_t t0 = 0, t1 = 0;
+            if (lane == 0) { t0 = zh_ld64(asmb + whole); t1 = zh_ld64(asmb + whole + 8); }
+            zh_wave_fence();
+            if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
+        }
+        zh_wave_fence();
+        ZD_TP(P, ZP_FLUSH);
+        op += totT; lp += totL; done += cnt;
+    }
+    if (lane < carry) dst[op - carry + lane] = asmb[lane];               // what the last flush held back
+    zd_fence();
+    const uint32_t rest = m.litSize - lp;
+    if ((uint64_t)op + rest > cap) return ZE_DST_TOO_SMALL;
+    if (op + rest - blockStart > blockMax) return ZE_CORRUPTION;
+    if (litRLE) zd_fill_wave(dst + op, rleByte, rest); else zd_copy_wave(dst + op, litPtr + lp, rest);
+    op += rest;
+    opRef = op;
+    return 0;
+}
+#endif
+
 // what ends a frame: the content size it announced, its checksum (zstd.c:44264-44277). All lanes call.
 ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, uint32_t fcsLo, uint32_t fcsHi, uint32_t hasChecksum, uint32_t checksum)
 {
@@ -1466,7 +1732,11 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
     const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
     uint32_t op = 0;
+#ifdef ZP_K3_V1
     int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
+#else
+    int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
+#endif
     if (e) return e;
     e = zp_exec_frame_end(L, dst, op, m.fcsLo, m.fcsHi, m.hasChecksum, m.checksum);
     if (e) return e;
@@ -1503,7 +1773,11 @@ ZH_DEVFN int zp_exec_frame_mb(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, u
             op += size;
             continue;
         }
+#ifdef ZP_K3_V1
         const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
+#else
+        const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
+#endif
         if (e) return e;
         zd_fence();
         if (m.nbSeq) {

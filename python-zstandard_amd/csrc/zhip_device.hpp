@@ -29,6 +29,9 @@ ZH_DEV uint32_t zh_lane() { return threadIdx.x; }
 ZH_DEV uint32_t zh_block() { return blockIdx.x; }
 ZH_DEV uint32_t zh_nblocks() { return gridDim.x; }
 ZH_DEV void zh_sync() { __syncthreads(); }
+// LDS hand-off between lanes of ONE wave: the wave's LDS instructions execute in issue order, so all this has to do is keep the compiler
+// from moving LDS accesses across it (no s_barrier, no vmcnt wait -- __syncthreads() also waits for the wave's global stores)
+ZH_DEV void zh_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 ZH_DEV uint64_t zh_ballot(bool p) { return __ballot(p); }
 ZH_DEV uint32_t zh_shfl(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl((int)v, (int)srcLane, 64); }
 ZH_DEV uint32_t zh_shfl_up(uint32_t v, uint32_t d) { return (uint32_t)__shfl_up((int)v, d, 64); }

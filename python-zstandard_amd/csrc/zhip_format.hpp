@@ -220,6 +220,7 @@ struct ZdMeta {
 #define ZP_SEQ_OF(q) ((uint32_t)((q) >> 35))
 #define ZP_SEQ_OFBITS 29
 #define ZP_LIT_STRIDE ((size_t)ZF_BLOCK_MAX + 256)
+#define ZP_LIT_FRONT 256u                               // bytes of padding before the first literal slot (K3 reads the 16 bytes that END with a literal run)
 // per-frame FSE decoding tables in HBM / L2: 2-byte cells (symbol << 10 | x), LL 512 + ML 512 + OF 256 cells
 #define ZP_FSE_LL 0
 #define ZP_FSE_ML 512

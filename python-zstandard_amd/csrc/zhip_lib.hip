@@ -637,7 +637,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const bool split = c->knob.split && nslot >= 2;
         const int nstream = split ? 2 : nslot;
         std::vector<hipEvent_t> evK3Done;
-        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * slots * ZP_LIT_STRIDE) ||
+        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * slots * ZP_LIT_STRIDE + ZP_LIT_FRONT) ||
             c->pipeSeq.reserve(nslot * slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
@@ -676,7 +676,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * slots;
-            pa.litArena = (uint8_t*)c->pipeLit.p + (size_t)sidx * slots * ZP_LIT_STRIDE;
+            pa.litArena = (uint8_t*)c->pipeLit.p + ZP_LIT_FRONT + (size_t)sidx * slots * ZP_LIT_STRIDE;
             pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * slots * ZP_SEQ_CAP;
             pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * slots * ZP_FSE_CELLS;
             pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * slots;

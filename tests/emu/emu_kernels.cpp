@@ -180,7 +180,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     const size_t slots = (size_t)chunk * (mb ? g_mbPerFrame : 1u);
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.meta = (ZdMeta*)calloc(slots, sizeof(ZdMeta));
-    a.litArena = (uint8_t*)malloc(slots * ZP_LIT_STRIDE);
+    uint8_t* const litAlloc = (uint8_t*)malloc(slots * ZP_LIT_STRIDE + ZP_LIT_FRONT); a.litArena = litAlloc + ZP_LIT_FRONT;
     uint64_t* const seqAlloc = (uint64_t*)malloc(slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8); a.seqArena = seqAlloc + ZP_SEQ_FRONT;
     a.fseTables = (uint16_t*)malloc(slots * ZP_FSE_CELLS * 2);
     a.order = (uint32_t*)calloc(slots, 4);
@@ -222,7 +222,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[ZP_CNT_WORDS];
-    free(g.scratch); free(a.meta); free(a.litArena); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
+    free(g.scratch); free(a.meta); free(litAlloc); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
     free(a.itemFrame); free(a.itemReps); free(a.frameRecs);
     return nfb;
 }

@@ -22,6 +22,7 @@ ZH_DEV uint32_t zh_lane() { return zhemu::lane; }
 ZH_DEV uint32_t zh_block() { return zhemu::block; }
 ZH_DEV uint32_t zh_nblocks() { return zhemu::nblocks; }
 ZH_DEV void zh_sync() { zhemu::collective_wait(); }
+ZH_DEV void zh_wave_fence() { zhemu::collective_wait(); }
 ZH_DEV uint64_t zh_ballot(bool p)
 {
     zhemu::slot[zhemu::lane] = p ? 1 : 0;
