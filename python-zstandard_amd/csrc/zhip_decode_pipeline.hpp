@@ -594,7 +594,253 @@ ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t
     return zb_finished(B);
 }
 
-ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
+// ---- round 4: the lean form (ZP_K1B_V1 keeps round 3's). K1b is a chain per lane on a SIMD that holds one or two waves: its time is its
+// instruction count per symbol (r03 SQ counters: 37 vector instructions per symbol step; two LDS reads per symbol -- a symbol byte, a
+// length nibble -- nibble extraction, a 3-register window with its selects). Here
+//   * the table stays in K1's 2-byte cells (symbol | length << 8): ONE ds_read_u16 per symbol, and the HBM -> LDS copy is a plain copy
+//     (4 KiB per frame instead of 3: four waves of 8 frames per CU instead of six);
+//   * the bit reader is K2's: an absolute bit cursor over the lane's LDS ring, the two dwords around the cursor fetched with one
+//     ds_read2_b32 per PAIR of symbols (two codes are at most 22 bits), one v_alignbit, one v_bfe per symbol -- no window registers;
+//   * eight symbols are packed with byte permutes and stored behind the next burst's requests (vmcnt counts stores as well).
+struct __attribute__((packed, aligned(1))) zh_q4u { uint32_t a, b, c, d; };
+#define ZH2_ROWS 32             // ring rows (dwords) per lane: 128 bytes; row ZH2_ROWS mirrors row 0 (ds_read2_b32 of rows d, d + 1)
+// (the ring comes first: ds_read2_b32's two offsets are 8 bits each, so only a base within 1 KiB folds into the instruction)
+struct ZpHuf2LDS { alignas(16) uint32_t ring[((ZH2_ROWS + 1) << ZP_HUF_LS) + 3 & ~3u]; alignas(16) uint16_t tab[ZP_HUF_FRAMES][ZP_HUF_CELLS]; };
+struct ZpHuf2Bits {
+    int32_t pos;                // absolute bit index (from p0) one past the next unread bit; the stream is read downwards
+    int32_t pb;                 // offset of the next 16-byte block to request
+    int32_t s0;                 // offset of the stream's first byte
+    int32_t bo[2]; ZpVec16 blk[2];
+    const uint8_t* p0; uint32_t* col;
+};
+ZH_DEV void zh2_commit(ZpHuf2Bits& B, int32_t off, const ZpVec16& v)               // off % 16 == 0: four consecutive rows, no wrap inside
+{
+    const uint32_t r0 = ((uint32_t)off >> 2) & (ZH2_ROWS - 1);
+    uint32_t* q = B.col + (r0 << ZP_HUF_LS);
+    q[0] = v.a; q[1u << ZP_HUF_LS] = v.b; q[2u << ZP_HUF_LS] = v.c; q[3u << ZP_HUF_LS] = v.d;
+    if (r0 == 0) B.col[ZH2_ROWS << ZP_HUF_LS] = v.a;
+}
+ZH_DEV ZpVec16 zh2_fetch(const ZpHuf2Bits& B, int32_t off) { return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off)); }
+// the 32 stream bits [q, q + 32) (q may be negative on a damaged stream: the row index is masked, whatever comes back fails the end check)
+ZH_DEV uint32_t zh2_bits(const ZpHuf2Bits& B, int32_t q)
+{
+    const uint32_t* w = B.col + (zh_bfe((uint32_t)q, 5, 5) << ZP_HUF_LS);
+    return zh_alignbit(w[1u << ZP_HUF_LS], w[0], (uint32_t)q);
+}
+// write what the previous burst requested; request what may now replace ring rows nothing will read again. A block at offset b lands on the
+// rows of bytes [b + 128, b + 144); every later read touches bytes below 4 * ((pos - 1) >> 5) + 4 only (bits at and above pos are masked away).
+// A trip of 16 symbols consumes at most 22 bytes: what burst k - 1 requested (down to 108 bytes below its cursor, two blocks per burst keep
+// up with 22 bytes per trip) is written by burst k, whose trip reads no lower than 48 bytes below burst k - 1's cursor.
+ZH_DEV void zh2_burst(ZpHuf2Bits& B)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) if (B.bo[k] != ZP_NOBLK) { zh2_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
+    const int32_t cur = ((B.pos - 1) >> 5) << 2;
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+        if (B.pb + (int32_t)(ZH2_ROWS * 4 - 4) >= cur) { B.bo[k] = B.pb; B.blk[k] = zh2_fetch(B, B.pb); B.pb -= 16; }
+    }
+}
+ZH_DEV bool zp_huf_stream2(const uint16_t* tab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count, uint32_t* ringCol)
+{
+    ZpHuf2Bits B;
+    B.col = ringCol;
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
+    B.p0 = p - mis; B.s0 = (int32_t)mis;
+    B.bo[0] = B.bo[1] = ZP_NOBLK; B.blk[0].a = B.blk[0].b = B.blk[0].c = B.blk[0].d = 0; B.blk[1] = B.blk[0];
+    if (size == 0) return false;
+    const uint32_t last = p[size - 1];
+    if (last == 0) return false;                               // missing end mark
+    const int32_t topByte = (int32_t)(mis + size) - 1, tb = topByte & ~15;
+    {   ZpVec16 f[ZH2_ROWS / 4];                               // the top 64 bytes of the stream, straight into the ring (all loads in flight before the first write)
+#pragma unroll
+        for (uint32_t k = 0; k < ZH2_ROWS / 4; k++) f[k] = zh2_fetch(B, tb - 16 * (int32_t)k);
+#pragma unroll
+        for (uint32_t k = 0; k < ZH2_ROWS / 4; k++) zh2_commit(B, tb - 16 * (int32_t)k, f[k]); }
+    B.pb = tb - (int32_t)(ZH2_ROWS * 4);
+    B.pos = 8 * topByte + zh_highbit32(last);
+    const int32_t log2x = (int32_t)(2 * log);
+    uint32_t i = 0;
+    ZpVec16 pend; pend.a = pend.b = pend.c = pend.d = 0;
+    // two symbols per window: T = bits [pos - 2 log, pos + ..): the first code is T's bits [log, 2 log), the second, once the first one's
+    // length l is known, bits [log - l, 2 log - l). Sixteen symbols per trip, one 16-byte store.
+#define ZH2_PAIR(ca, cb) do { const uint32_t T_ = zh2_bits(B, B.pos - log2x); ca = tab[zh_bfe(T_, log, log)]; const uint32_t la_ = ca >> 8; \
+        cb = tab[zh_bfe(T_, log - la_, log)]; B.pos -= (int32_t)(la_ + (cb >> 8)); } while (0)
+#define ZH2_QUAD(dw) do { uint32_t c0_, c1_, c2_, c3_; ZH2_PAIR(c0_, c1_); ZH2_PAIR(c2_, c3_); \
+        dw = (c0_ & 255u) | ((c1_ & 255u) << 8) | ((c2_ & 255u) << 16) | (c3_ << 24); } while (0)
+    while (i + 16 <= count) {
+        zh2_burst(B);
+        if (i) *(zh_q4u*)(out + i - 16) = *(const zh_q4u*)&pend;
+        uint32_t d0, d1, d2, d3;
+        ZH2_QUAD(d0); ZH2_QUAD(d1); ZH2_QUAD(d2); ZH2_QUAD(d3);
+        pend.a = d0; pend.b = d1; pend.c = d2; pend.d = d3;
+        i += 16;
+    }
+    zh2_burst(B);                               // the tail (<= 15 symbols) reads what the last burst requested
+    if (i) *(zh_q4u*)(out + i - 16) = *(const zh_q4u*)&pend;
+    while (i < count) {
+        const uint32_t c = tab[zh_bfe(zh2_bits(B, B.pos - (int32_t)log), 0, log)];
+        B.pos -= (int32_t)(c >> 8);
+        out[i++] = (uint8_t)c;
+    }
+#undef ZH2_QUAD
+#undef ZH2_PAIR
+    return B.pos == 8 * B.s0;                   // every bit consumed, no more
+}
+
+// ---- round 4, second form (ZP_K1B_R4B): K1b is (chains resident on the CU) / (latency of a symbol step), and residency is LDS: 3 KiB of
+// table per frame = 48 frames = 192 chains per CU (r04b: the lean loop above on 4 KiB tables -- 32 frames -- is 25 % FASTER per chain and 13 %
+// slower overall). A Huffman table does not need 2^11 cells: codes of up to 8 bits are decoded by a DIRECT table of 256 two-byte cells indexed
+// by the window's first 8 bits; a longer code (9-11 bits: weights 1-3, the table's first cells) is computed from the canonical layout K1's table
+// has (RFC 8878 4.2.1: cells sorted by weight, symbols in order inside a weight, 2^(w-1) cells each): its weight from two comparisons of the
+// 11-bit index with where weights 2 and 3 begin, its symbol from a 256-byte list of the long symbols. 768 bytes per frame, 16 frames per
+// wave, nine waves per CU: 576 chains. The long path's arithmetic depends on the index only, so it runs beside the direct lookup; the chain is
+// one LDS read per symbol. K1b derives both tables from K1's full table while loading it (K1 and the table arena are unchanged).
+#define ZH3_ROWS 16             // ring rows (dwords) per lane: 64 bytes; row ZH3_ROWS mirrors row 0
+#define ZH3_D 8u                // bits the direct table decodes
+struct ZpHuf3LDS {
+    alignas(16) uint32_t ring[(ZH3_ROWS + 1) << ZP_HUF_LS];
+    uint32_t par[ZP_HUF_FRAMES][2];                 // T2 | T3 << 16 (the table indices where weights 2 / 3 begin), S2 | S3 << 16 (how many long symbols precede them)
+    alignas(16) uint16_t direct[ZP_HUF_FRAMES][256];
+    alignas(16) uint8_t symLong[ZP_HUF_FRAMES][256];
+};
+struct ZpHuf3Bits { int32_t pos, pb, s0; int32_t bo[2]; ZpVec16 blk[2]; const uint8_t* p0; uint32_t* col; };
+ZH_DEV void zh3_commit(ZpHuf3Bits& B, int32_t off, const ZpVec16& v)
+{
+    const uint32_t r0 = ((uint32_t)off >> 2) & (ZH3_ROWS - 1);
+    uint32_t* q = B.col + (r0 << ZP_HUF_LS);
+    q[0] = v.a; q[1u << ZP_HUF_LS] = v.b; q[2u << ZP_HUF_LS] = v.c; q[3u << ZP_HUF_LS] = v.d;
+    if (r0 == 0) B.col[ZH3_ROWS << ZP_HUF_LS] = v.a;
+}
+ZH_DEV ZpVec16 zh3_fetch(const ZpHuf3Bits& B, int32_t off) { return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off)); }
+ZH_DEV uint32_t zh3_bits(const ZpHuf3Bits& B, int32_t q)
+{
+    const uint32_t* w = B.col + (zh_bfe((uint32_t)q, 5, 4) << ZP_HUF_LS);
+    return zh_alignbit(w[1u << ZP_HUF_LS], w[0], (uint32_t)q);
+}
+// a block at offset b lands on the rows of bytes [b + 64, b + 80); every later read touches bytes below 4 * ((pos - 1) >> 5) + 4 only. A trip
+// of 8 symbols consumes at most 11 bytes: what burst k - 1 requested (down to 44 bytes below its cursor) is written by burst k, whose trip
+// reads no lower than 30 bytes below burst k - 1's cursor.
+ZH_DEV void zh3_burst(ZpHuf3Bits& B)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) if (B.bo[k] != ZP_NOBLK) { zh3_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
+    const int32_t cur = ((B.pos - 1) >> 5) << 2;
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+        if (B.pb + (int32_t)(ZH3_ROWS * 4 - 4) >= cur) { B.bo[k] = B.pb; B.blk[k] = zh3_fetch(B, B.pb); B.pb -= 16; }
+    }
+}
+// one code at table index idx (log bits): its length (-> len) and symbol (-> sym). cell = the direct table's answer (0: a long code)
+#define ZH3_RESOLVE(idx, cell, len, sym) do { \
+        const uint32_t e_ = (uint32_t)((idx) >= T2) + (uint32_t)((idx) >= T3);                 /* weight - 1 of a long code */ \
+        const uint32_t b_ = e_ == 0 ? 0u : e_ == 1 ? T2 : T3, s_ = e_ == 0 ? 0u : e_ == 1 ? S2 : S3; \
+        const uint32_t symL_ = symLong[(s_ + (((idx) - b_) >> e_)) & 255u];      /* (a short code's index leads anywhere: masked, unused) */ \
+        const bool long_ = (cell) == 0; \
+        len = long_ ? log - e_ : (cell) >> 8; sym = long_ ? symL_ : (cell) & 255u; } while (0)
+ZH_DEV bool zp_huf_stream3(const uint16_t* direct, const uint8_t* symLong, uint32_t par0, uint32_t par1, uint32_t log, const uint8_t* p, uint32_t size,
+                           uint8_t* out, uint32_t count, uint32_t* ringCol)
+{
+    ZpHuf3Bits B;
+    B.col = ringCol;
+    const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
+    B.p0 = p - mis; B.s0 = (int32_t)mis;
+    B.bo[0] = B.bo[1] = ZP_NOBLK; B.blk[0].a = B.blk[0].b = B.blk[0].c = B.blk[0].d = 0; B.blk[1] = B.blk[0];
+    if (size == 0) return false;
+    const uint32_t last = p[size - 1];
+    if (last == 0) return false;                               // missing end mark
+    const int32_t topByte = (int32_t)(mis + size) - 1, tb = topByte & ~15;
+    {   ZpVec16 f[ZH3_ROWS / 4];                               // the top 64 bytes of the stream, straight into the ring
+#pragma unroll
+        for (uint32_t k = 0; k < ZH3_ROWS / 4; k++) f[k] = zh3_fetch(B, tb - 16 * (int32_t)k);
+#pragma unroll
+        for (uint32_t k = 0; k < ZH3_ROWS / 4; k++) zh3_commit(B, tb - 16 * (int32_t)k, f[k]); }
+    B.pb = tb - (int32_t)(ZH3_ROWS * 4);
+    B.pos = 8 * topByte + zh_highbit32(last);
+    const uint32_t T2 = par0 & 0xFFFFu, T3 = par0 >> 16, S2 = par1 & 0xFFFFu, S3 = par1 >> 16;
+    const uint32_t sh = log > ZH3_D ? log - ZH3_D : 0u;       // the direct table is indexed by the code's first min(log, 8) bits
+    const int32_t log2x = (int32_t)(2 * log);
+    uint32_t i = 0;
+    uint64_t pend = 0;
+#define ZH3_PAIR(sa, sb) do { const uint32_t T_ = zh3_bits(B, B.pos - log2x); const uint32_t ia_ = zh_bfe(T_, log, log); const uint32_t ca_ = direct[ia_ >> sh]; \
+        uint32_t la_; ZH3_RESOLVE(ia_, ca_, la_, sa); const uint32_t ib_ = zh_bfe(T_, log - la_, log); const uint32_t cb_ = direct[ib_ >> sh]; \
+        uint32_t lb_; ZH3_RESOLVE(ib_, cb_, lb_, sb); B.pos -= (int32_t)(la_ + lb_); } while (0)
+    while (i + 8 <= count) {
+        zh3_burst(B);
+        if (i) zh_st64(out + i - 8, pend);
+        uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
+        ZH3_PAIR(s0, s1); ZH3_PAIR(s2, s3); ZH3_PAIR(s4, s5); ZH3_PAIR(s6, s7);
+        pend = (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32);
+        i += 8;
+    }
+    zh3_burst(B);
+    if (i) zh_st64(out + i - 8, pend);
+    while (i < count) {
+        const uint32_t ix = zh_bfe(zh3_bits(B, B.pos - (int32_t)log), 0, log);
+        const uint32_t c = direct[ix >> sh];
+        uint32_t l, sy; ZH3_RESOLVE(ix, c, l, sy);
+        B.pos -= (int32_t)l;
+        out[i++] = (uint8_t)sy;
+    }
+#undef ZH3_PAIR
+    return B.pos == 8 * B.s0;                   // every bit consumed, no more
+}
+// frame slot j's two tables from K1's full table `src` (2^log cells of symbol | length << 8, sorted by weight). All lanes call.
+ZH_DEV void zp_huf3_load(ZpHuf3LDS& L, uint32_t j, const ZpVec16* src, uint32_t log)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t nv = ((2u << log) + 15) >> 4;                  // 16-byte pieces (8 cells) of the table
+    ZpVec16 r[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) { r[q].a = r[q].b = r[q].c = r[q].d = 0; if (lane + 64 * q < nv) r[q] = src[lane + 64 * q]; }
+    uint32_t T2 = 0, T3 = 0, T4 = 0;
+    if (log > ZH3_D) {
+        // where the weights begin: T2 = cells of length log, T3 = T2 + cells of length log - 1, T4 = T3 + cells of length log - 2
+        uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t w[4] = { r[q].a, r[q].b, r[q].c, r[q].d };
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t len = (w[k >> 1] >> (8 + 16 * (k & 1))) & 255u;
+                const uint32_t e = log - len;                      // (unused cells: length 0, e = log > 8)
+                c1 += e < 1 ? 1u : 0u; c2 += e < 2 ? 1u : 0u; c3 += e < 3 ? 1u : 0u;
+            }
+        }
+        const uint32_t tot = zh_shfl(zh_scan_add(c1 | (c2 << 10) | (c3 << 20)), 63);          // (each at most 2^11 / 2: codes of the longest three lengths fill at most half... the sums stay below 2^10 + carry room)
+        T2 = tot & 1023u; T3 = (tot >> 10) & 1023u; T4 = tot >> 20;
+    }
+    const uint32_t S2 = T2, S3 = T2 + ((T3 - T2) >> 1);
+    if (lane == 0) { L.par[j][0] = T2 | (T3 << 16); L.par[j][1] = S2 | (S3 << 16); }
+    const uint32_t sh = log > ZH3_D ? log - ZH3_D : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t pc = lane + 64 * q;                              // piece: cells 8 pc .. 8 pc + 7
+        if (pc >= nv) continue;
+        const uint32_t w[4] = { r[q].a, r[q].b, r[q].c, r[q].d };
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t idx = 8 * pc + k;
+            const uint32_t cell = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const uint32_t len = cell >> 8;
+            if ((idx & ((1u << sh) - 1)) == 0 && idx < (1u << log)) L.direct[j][idx >> sh] = (uint16_t)(len > ZH3_D ? 0u : cell);
+            if (idx < T4 && len) {
+                const uint32_t e = log - len;                            // 0 .. 2
+                const uint32_t b = e == 0 ? 0u : e == 1 ? T2 : T3, s = e == 0 ? 0u : e == 1 ? S2 : S3;
+                if (((idx - b) & ((1u << e) - 1)) == 0) L.symLong[j][(s + ((idx - b) >> e)) & 255u] = (uint8_t)cell;
+            }
+        }
+    }
+}
+
+#if defined(ZP_K1B_R4B)
+typedef ZpHuf3LDS ZpHufKernelLDS;
+#elif defined(ZP_K1B_R4A)
+typedef ZpHuf2LDS ZpHufKernelLDS;
+#else
+typedef ZpHufLDS ZpHufKernelLDS;
+#endif
+ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
 {
     const uint32_t lane = zh_lane(), slot = lane >> 2, strm = lane & 3;
     const uint32_t total = a.counters[4];
@@ -611,6 +857,16 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
         zh_sync();
         // the group's tables, HBM -> LDS: whole 4 KiB slots (cells past 2^log are never indexed), 16 bytes per lane, the four loads of a
         // frame in flight before its first LDS write
+#if defined(ZP_K1B_R4B)
+        for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
+            const uint32_t fj = zh_shfl(i, 4 * j);
+            if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
+            const uint32_t mj = zh_shfl(mode, 4 * j);
+            const bool sharedT = (mj & ZP_LIT_SHARED) != 0;
+            const ZpVec16* src = sharedT ? (const ZpVec16*)a.dictTables->huf : (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
+            zp_huf3_load(L, j, src, (mj >> 8) & 255u);
+        }
+#elif !defined(ZP_K1B_R4A)
 #pragma unroll 2
         for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
             const uint32_t fj = zh_shfl(i, 4 * j);
@@ -629,13 +885,42 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
             ZP_SPLIT(r0, 0); ZP_SPLIT(r1, 1); ZP_SPLIT(r2, 2); ZP_SPLIT(r3, 3);
 #undef ZP_SPLIT
         }
+#else
+#pragma unroll 2
+        for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
+            const uint32_t fj = zh_shfl(i, 4 * j);
+            if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
+            const uint32_t mj = zh_shfl(mode, 4 * j);
+            const bool sharedT = (mj & ZP_LIT_SHARED) != 0;                // a treeless block of a dictionary frame: the dictionary's own table
+            const ZpVec16* src = sharedT ? (const ZpVec16*)a.dictTables->huf : (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
+            const uint32_t nv = ((2u << ((mj >> 8) & 255u)) + 15) >> 4;      // 16-byte pieces of a table of 2^log cells (cells past it are never indexed)
+            ZpVec16* dstv = (ZpVec16*)L.tab[j];
+            ZpVec16 r0, r1, r2, r3; r0.a = r0.b = r0.c = r0.d = 0; r1 = r0; r2 = r0; r3 = r0;
+            if (lane < nv) r0 = src[lane];
+            if (lane + 64 < nv) r1 = src[lane + 64];
+            if (lane + 128 < nv) r2 = src[lane + 128];
+            if (lane + 192 < nv) r3 = src[lane + 192];
+            if (lane < nv) dstv[lane] = r0;
+            if (lane + 64 < nv) dstv[lane + 64] = r1;
+            if (lane + 128 < nv) dstv[lane + 128] = r2;
+            if (lane + 192 < nv) dstv[lane + 192] = r3;
+        }
+#endif
         zh_sync();
         bool ok = true;
         if (active) {
             const uint32_t f = a.first + (a.itemCap ? a.itemFrame[i] : i);
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
-            if (!four) { if (strm == 0) ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p, streamBytes, lit, litSize, L.ring + lane); }
+#if defined(ZP_K1B_R4B)
+            const uint32_t par0 = L.par[slot][0], par1 = L.par[slot][1];
+#define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream3(L.direct[slot], L.symLong[slot], par0, par1, log, pp, sz, oo, nn, L.ring + lane)
+#elif !defined(ZP_K1B_R4A)
+#define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream(L.sym[slot], L.len[slot], log, pp, sz, oo, nn, L.ring + lane)
+#else
+#define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream2(L.tab[slot], log, pp, sz, oo, nn, L.ring + lane)
+#endif
+            if (!four) { if (strm == 0) ok = ZP_HUF_STREAM(p, streamBytes, lit, litSize); }
             else {
                 const uint32_t s1 = zh_ld16(p), s2 = zh_ld16(p + 2), s3 = zh_ld16(p + 4);
                 if (6 + s1 + s2 + s3 > streamBytes) ok = false;
@@ -644,7 +929,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufLDS& L)
                     const uint32_t so = strm == 0 ? 0 : strm == 1 ? s1 : strm == 2 ? s1 + s2 : s1 + s2 + s3;
                     const uint32_t sz = strm == 0 ? s1 : strm == 1 ? s2 : strm == 2 ? s3 : streamBytes - 6 - s1 - s2 - s3;
                     const uint32_t n = strm < 3 ? seg : litSize - 3 * seg;
-                    ok = zp_huf_stream(L.sym[slot], L.len[slot], log, p + 6 + so, sz, lit + strm * seg, n, L.ring + lane);
+                    ok = ZP_HUF_STREAM(p + 6 + so, sz, lit + strm * seg, n);
                 }
             }
         }
@@ -1029,7 +1314,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #ifndef ZP_ASM_BYTES
 #define ZP_ASM_BYTES ZD_ASM_BYTES       // K3's batch assembly buffer (LDS per wave = this + 1.6 KiB): smaller buffers leave room for a K2 wave beside sixteen K3 waves
 #endif
-#ifdef ZP_K3_V1
+#ifndef ZP_K3_R4
 struct ZpExecLDS {
     uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
@@ -1453,7 +1738,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
 //     match): everything a match reads is final when its turn comes, so there are no need-masks, no rounds, no LDS index arrays -- per match
 //     two v_readlane, ~5 vector instructions and an LDS read -> write; all control is scalar.
 // 16 bytes of padding precede the assembly buffer: a piece that ends with an item shorter than 16 bytes is addressed from 16 bytes below the item's end.
-struct ZpExecLDS { uint8_t pad[16]; uint8_t asmb[ZP_ASM_BYTES + 64]; uint32_t misc[8]; };
+struct ZpExecLDS { uint8_t pad[16]; uint8_t asmb[ZP_ASM_BYTES + 64]; uint32_t misc[8]; uint16_t mBeg[64]; uint16_t mEnd[64]; };
 #ifndef ZP_OWN_MAX
 #define ZP_OWN_MAX 32u             // items up to this long are copied by their own lane
 #endif
@@ -1469,7 +1754,6 @@ ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2
     return r > d ? r - d : 0xFFFFFFFFu;
 }
 struct zh_q4 { uint32_t a, b, c, d; };
-struct __attribute__((packed, aligned(1))) zh_q4u { uint32_t a, b, c, d; };
 ZH_DEV zh_q4 zp_ldq(const uint8_t* p) { const zh_q4u v = *(const zh_q4u*)p; zh_q4 r; r.a = v.a; r.b = v.b; r.c = v.c; r.d = v.d; return r; }
 // `len` bytes (1 .. 32; 0: nothing) to LDS at q: A = the item's first 16 bytes, Z = the 16 bytes that end with it
 ZH_DEV void zp_put32(uint8_t* q, uint32_t len, const zh_q4& A, const zh_q4& Z)
@@ -1654,6 +1938,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         zp_put32(asmb + mRel, ownM ? myML : 0u, ma, mz);
         zh_wave_fence();
         ZD_TP(P, ZP_EXEC1);
+#ifdef ZP_K3_SEQNEAR
         // ---- the matches that read this batch's own output (and the irregular ones), one after the other in stream order: when a match's
         // turn comes every byte it reads is final. The whole wave copies it, a dword per lane (the last one shifted back to end with it).
         for (uint64_t mk = zh_ballot(seqM); mk; mk &= mk - 1) {
@@ -1667,6 +1952,57 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             } else zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
             zh_wave_fence();
         }
+#else
+        // ---- the matches that read this batch's own output (and the irregular ones). A match may start as soon as every earlier such match
+        // whose output it reads is done: `need` = the set of those (a contiguous index range, found by binary search over the batch-relative
+        // match extents), so the number of rounds is the dependency depth (4.3 on the bench corpus), not the number of matches (14): executed
+        // one after the other by the whole wave (r04a: ~37 instructions per match, 520 per batch) they cost more than the rounds' bookkeeping.
+        // A round serves its ready plain matches of up to ZP_OWN_MAX bytes by their own lanes (two 16-byte LDS reads, the same length classes
+        // as above) and every other ready match -- longer, overlapping its own output, or starting below the batch -- by the whole wave.
+        L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
+        zh_wave_fence();
+        bool pending = seqM;
+        const bool plain = seqM && sRel >= 0 && myML <= ZP_OWN_MAX && myOF >= myML;
+        uint64_t need = 0;
+        if (pending) {
+            const uint32_t a0 = sRel > 0 ? (uint32_t)sRel : 0u;                                    // first buffer byte I read
+            uint32_t b0 = sEnd > 0 ? (uint32_t)sEnd : 0u;                                          // one past the last byte I read
+            if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
+            uint32_t lo = 0, hi = 0;            // lo = first j with mEnd[j] > a0 ; hi = first j with mBeg[j] >= b0
+            for (uint32_t stp = 32; stp; stp >>= 1) { if (lo + stp <= 64 && L.mEnd[lo + stp - 1] <= a0) lo += stp; }
+            for (uint32_t stp = 32; stp; stp >>= 1) { if (hi + stp <= 64 && L.mBeg[hi + stp - 1] < b0) hi += stp; }
+            if (hi > lane) hi = lane;           // only earlier sequences can feed me
+            if (lo < hi) need = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
+        }
+        const uint64_t seqMask = zh_ballot(pending);
+        need &= seqMask;                        // literals and staged matches are already in the buffer
+        uint64_t doneMask = ~seqMask;
+        for (;;) {
+            const uint64_t pend = zh_ballot(pending);
+            if (!pend) break;
+            const bool ready = pending && (need & ~doneMask) == 0;
+            const uint64_t waveReady = zh_ballot(ready && !plain);
+            const bool own = ready && plain;
+            {   zh_q4 ra, rz;
+                const uint8_t* q = asmb + (own ? (uint32_t)sRel : 0u);
+                ra = zp_ldq(q); rz = zp_ldq(q + (own ? myML : 16u) - 16);
+                zp_put32(asmb + mRel, own ? myML : 0u, ra, rz); }
+            uint64_t newDone = zh_ballot(own);
+            if (own) pending = false;
+            for (uint64_t lm = waveReady; lm; lm &= lm - 1) {
+                const uint32_t pf = (uint32_t)zh_ctz64(lm);
+                // (ds_bpermute, not v_readlane: a readlane'd value that feeds an LDS address crashes this LLVM)
+                const uint32_t d = zh_shfl(mRel, pf), n = zh_shfl(myML, pf);
+                const int32_t sR = (int32_t)zh_shfl((uint32_t)sRel, pf);
+                zh_wave_fence();
+                zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
+                if (lane == pf) pending = false;
+                newDone |= 1ull << pf;
+            }
+            doneMask |= newDone;
+            zh_wave_fence();
+        }
+#endif
         ZD_TP(P, ZP_EXEC2);
         // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
         // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
@@ -1732,7 +2068,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
     const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
     uint32_t op = 0;
-#ifdef ZP_K3_V1
+#ifndef ZP_K3_R4
     int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
 #else
     int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
@@ -1773,7 +2109,7 @@ ZH_DEVFN int zp_exec_frame_mb(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, u
             op += size;
             continue;
         }
-#ifdef ZP_K3_V1
+#ifndef ZP_K3_R4
         const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
 #else
         const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);

@@ -235,6 +235,9 @@ struct ZdMeta {
 #define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
 #define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
 #define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)
+#if defined(ZP_K1B_R4B) && !defined(ZP_HUF_FRAMES)
+#define ZP_HUF_FRAMES 16                                // the two-level form (768 bytes of tables per frame): a full wave, four lanes per frame
+#endif
 #ifndef ZP_HUF_FRAMES
 #define ZP_HUF_FRAMES 8                                 // frames per K1b wave: 4 lanes (the 4 streams) each; 3 KiB of tables per frame, so 16 -> 3 waves
 #endif                                                  // per CU, 8 -> 6, 4 -> 12 (48 frames per CU either way; r02c: 8 is 7 % faster than 16 alone, 4 is slower)

@@ -20,7 +20,7 @@
 #ifndef ZHIP_E1LDS_PER_CU
 #define ZHIP_E1LDS_PER_CU 4                // batches up to this many frames per CU take the LDS-source match kernel (ZHIP_E1LDS_MAX overrides the frame count); r02zq: 1 024 frames 147 ms against 159-163 with the flat kernel, 512: 89 against 146
 #endif
-static_assert(sizeof(ZpSeqLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
+static_assert(sizeof(ZpSeqLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufKernelLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 
 // ------------------------------------------------------------------------------------------ kernels
 ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
@@ -40,7 +40,7 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_bin_kernel(ZhipPipeArgs a)
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_huf_kernel(ZhipPipeArgs a)
 {
-    __shared__ ZpHufLDS L;
+    __shared__ ZpHufKernelLDS L;
     zp_huf_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_kernel(ZhipPipeArgs a)           // K2: a quad of lanes per frame, four waves per CU
@@ -699,7 +699,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             const size_t perWave = quad ? ZQ_FRAMES : ZP_K2_LANES;
             const size_t w2 = (items + perWave - 1) / perWave, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / (quad ? sizeof(ZpSeqQLDS) : sizeof(ZpSeqLDS)));
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
-            const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufLDS));
+            const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
             const bool tm = c->timing;
             hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, evh = nullptr, evh2 = nullptr;

@@ -127,7 +127,7 @@ static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBit
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
 static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
 static ZpSeqLDS g_seqlds;
-static ZpHufLDS g_huflds;
+static ZpHufKernelLDS g_huflds;
 static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
 #ifdef ZP_K2_LANEWISE          // the lane-per-frame form kept for A/B (ZHIP_K2_QUAD=0 in the product)
 static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
