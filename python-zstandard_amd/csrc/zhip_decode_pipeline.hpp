@@ -1938,19 +1938,56 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         zp_put32(asmb + mRel, ownM ? myML : 0u, ma, mz);
         zh_wave_fence();
         ZD_TP(P, ZP_EXEC1);
-#ifdef ZP_K3_SEQNEAR
+#ifndef ZP_K3_ROUNDS
         // ---- the matches that read this batch's own output (and the irregular ones), one after the other in stream order: when a match's
-        // turn comes every byte it reads is final. The whole wave copies it, a dword per lane (the last one shifted back to end with it).
-        for (uint64_t mk = zh_ballot(seqM); mk; mk &= mk - 1) {
-            const uint32_t l = (uint32_t)zh_ctz64(mk);
-            const uint32_t pk2 = zh_bcast(mRel | (myML << 16), l);
-            const int32_t sR = (int32_t)zh_bcast((uint32_t)sRel, l);
-            const uint32_t d = pk2 & 0xFFFFu, n = pk2 >> 16;
-            if (sR >= 0 && (uint32_t)sR + n <= d && n <= 256 && n >= 4) {      // plainly inside the buffer, not overlapping its own output
-                const uint32_t off = 4 * lane + 4 <= n ? 4 * lane : n - 4;
-                if (4 * lane < n) { const uint32_t w = zh_ld32(asmb + sR + off); zh_st32(asmb + d + off, w); }
-            } else zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
-            zh_wave_fence();
+        // turn comes every byte it reads is final. Every instruction of this loop is paid ~14 times per batch, so the common case -- every such
+        // match of the batch lies plainly inside the buffer, does not overlap its own output and is 4 .. 64 bytes long -- is a loop without
+        // branches or exec changes: one v_readlane brings (destination | offset << 13 | length << 26), the wave copies a dword per lane with
+        // the offset clamped to length - 4 (lanes past the match repeat its last dword; sixteen lanes take part).
+        {
+            const bool plainS = seqM && sRel >= 0 && myOF >= myML && myML >= 4 && myML <= 63;
+            const uint64_t seqMask = zh_ballot(seqM);
+            const uint32_t pk3 = mRel | (myOF << 13) | (myML << 26);            // (plain: mRel < 8192, offset <= mRel, length < 64)
+            const uint32_t lane4 = 4 * lane;
+            if (seqMask == zh_ballot(plainS)) {
+                // (sixteen lanes cover 64 bytes; r04e: with all 64 lanes storing, 48 of them the SAME last dword, every store was a 48-way LDS
+                // conflict -- K3 14.2 ms instead of 11.1. On the device the exec mask is set ONCE around the loop -- v_readlane does not care --;
+                // the emulator's collectives want every lane, so there the lane test sits inside)
+#ifndef ZHIP_EMU
+                // (pk3 is pinned HERE, under the full exec mask: left to itself LLVM computes it inside the sixteen-lane region -- for sixteen lanes --
+                // and the v_readlane of a lane above them reads garbage: r04f, wrong bytes on the MI355X only)
+                const uint32_t pk3x = zh_opaque(pk3);
+                if (lane < 16) {
+                    for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
+                        const uint32_t v = zh_bcast(pk3x, (uint32_t)zh_ctz64(mk));
+                        const uint32_t d = v & 0x1FFFu, so = d - ((v >> 13) & 0x1FFFu), n4 = (v >> 26) - 4;
+                        const uint32_t off = lane4 < n4 ? lane4 : n4;
+                        const uint32_t w = zh_ld32(asmb + so + off);
+                        zh_st32(asmb + d + off, w);
+                    }
+                }
+                zh_wave_fence();
+#else
+                for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
+                    const uint32_t v = zh_bcast(pk3, (uint32_t)zh_ctz64(mk));
+                    const uint32_t d = v & 0x1FFFu, so = d - ((v >> 13) & 0x1FFFu), n4 = (v >> 26) - 4;
+                    const uint32_t off = lane4 < n4 ? lane4 : n4;
+                    if (lane < 16) { const uint32_t w = zh_ld32(asmb + so + off); zh_st32(asmb + d + off, w); }
+                    zh_wave_fence();
+                }
+#endif
+            } else {
+                for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
+                    const uint32_t l = (uint32_t)zh_ctz64(mk);
+                    const uint32_t d = zh_shfl(mRel, l), n = zh_shfl(myML, l);
+                    const int32_t sR = (int32_t)zh_shfl((uint32_t)sRel, l);
+                    if (sR >= 0 && (uint32_t)sR + n <= d && n <= 256 && n >= 4) {      // plainly inside the buffer, not overlapping its own output
+                        const uint32_t off = 4 * lane + 4 <= n ? 4 * lane : n - 4;
+                        if (4 * lane < n) { const uint32_t w = zh_ld32(asmb + sR + off); zh_st32(asmb + d + off, w); }
+                    } else zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
+                    zh_wave_fence();
+                }
+            }
         }
 #else
         // ---- the matches that read this batch's own output (and the irregular ones). A match may start as soon as every earlier such match

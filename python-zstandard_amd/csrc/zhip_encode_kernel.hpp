@@ -2471,7 +2471,10 @@ ZH_DEVFN void ze_split_body(const ZhipEncodeArgs& a, ZeLDS& L)
         uint32_t count = 0;
         ZePar cp;
         if (srcSize64 > ZF_BLOCK_MAX && srcSize64 < (1ull << ZE_MB_POS_BITS) - 8 && !a.cdict && ze_get_cparams(cp, a.rows, (uint32_t)srcSize64) == 0 &&
-            cp.strat == 2 && (1ull << cp.wlog) >= srcSize64 && (size_t)(4u << cp.hlog) + (4u << cp.clog) <= a.tableStride) {
+            cp.strat == 2 && (1ull << cp.wlog) >= srcSize64 && (size_t)(4u << cp.hlog) + (4u << cp.clog) <= a.tableStride &&
+            // the sequence slice was sized from the caller's size HINT (srcSize / 4 + blocks + 64 sequences at most: matches are four bytes or
+            // more); a source the hint understated would write past its slice -- it is the generic kernel's
+            srcSize64 / 4 + a.mbMaxBlocks + 64 <= a.mbSeqCap) {
             const uint32_t srcSize = (uint32_t)srcSize64;
             ZeMbBlock* const blk = a.mbBlocks + (size_t)i * a.mbMaxBlocks;
             uint32_t ip = 0;

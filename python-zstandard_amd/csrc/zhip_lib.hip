@@ -467,8 +467,10 @@ extern "C" int zhip_ctx_set_ddict(zhip_ctx* c, const void* hostDict, size_t dict
     } else c->ddictKey = 0;
     c->dictSize = 0; c->dictID = 0; c->dictContentOffset = 0; c->dictHasEntropy = false;
     if (!hostDict || !dictSize) return 0;
-    // (the decode kernels pack an offset in 29 bits and keep the values from ZP_OF_LIMIT = 480 MiB up for other purposes: a dictionary must end
-    // below that for "offset beyond everything decoded so far" to stay decidable from the packed value -- zhip_decode_pipeline.hpp, K2)
+    // (the decode kernels pack an offset in 29 bits and keep the values from ZP_OF_LIMIT = 480 MiB up for other purposes: dictionary + one
+    // frame's window must stay below that for "offset beyond everything decoded so far" to be decidable from the packed value --
+    // zhip_decode_pipeline.hpp, K2. The limit is set at 256 MiB, half of it, leaving the other half to the frames' own windows (up to 2^27
+    // here); the reference takes any size: larger dictionaries are refused loudly, INTEGRATION.md section 4 lists the limit)
     if (dictSize >= (256u << 20)) { g_lastError = "dictionary too large"; c->ddictKey = 0; return ZHIP_ERR_UNSUPPORTED; }
     // ZSTD_loadEntropy_intoDDict (zstd.c:42716): raw content when asked for, when shorter than 8 bytes or when the magic is absent --
     // unless a full dictionary was demanded, which is then "Dictionary is corrupted"
@@ -661,6 +663,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.dictTables = c->dictHasEntropy ? (const ZhipDictTables*)c->dictTables.p : nullptr;
         }
         if (c->knob.prof) {
+            if (!c->profPipe && (c->dictSize || mb))
+                fprintf(stderr, "[zhip-prof] K3's phase timers exist in the dictionary-less single-block kernel only: with a dictionary or frames of several blocks they read zero\n");
             if (!c->profPipe) HIP_TRY(hipMalloc((void**)&c->profPipe, 32 * 8));
             HIP_TRY(hipMemsetAsync(c->profPipe, 0, 32 * 8, stream));
             pa.prof = c->profPipe;
@@ -731,7 +735,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
             else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, sx, pa);
             else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
-            else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, sx, pa);
+            else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, sx, pa);      // (ZHIP_PROF with a dictionary or frames of several blocks: K3's timers read zero -- said once at context creation)
             else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, sx, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[3], sx));
             if (split) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIP_TRY(hipEventRecord(e, sx)); evK3Done.push_back(e); }
@@ -1212,9 +1216,13 @@ extern "C" int zhip_compact_device(const void* d_slots, const zhip_segment* d_sl
 {
     if (n == 0) return 0;
     if (n > 0x7FFFFFFFu) { g_lastError = "too many frames in one launch"; return ZHIP_ERR_UNSUPPORTED; }
-    int dev = 0; hipDeviceProp_t prop;
-    HIP_TRY(hipGetDevice(&dev)); HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    const size_t gmax = (size_t)prop.multiProcessorCount * 16;
+    // (the CU count per device is looked up once: hipGetDeviceProperties is slow and this sits on the sharded compress path)
+    static thread_local int cuOf[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int cus = dev >= 0 && dev < 64 ? cuOf[dev] : 0;
+    if (!cus) { HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); if (dev >= 0 && dev < 64) cuOf[dev] = cus; }
+    const size_t gmax = (size_t)cus * 16;
     hipLaunchKernelGGL(zhip_compact_kernel, dim3((uint32_t)(n < gmax ? n : gmax)), dim3(64), 0, (hipStream_t)streamv, (const uint8_t*)d_slots, d_slotSegs, d_outSizes,
                        d_status, d_offsets, (uint32_t)n, (uint8_t*)d_dense);
     HIP_TRY(hipGetLastError());

@@ -235,6 +235,8 @@ static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
 extern "C" void emu_set_mb_compress(uint32_t v) { g_mbCompress = v; }
+static uint64_t g_mbHint = 0;                   // != 0: the several-block arenas are sized from this size HINT instead of the batch's largest source (a device-API caller's stale hint)
+extern "C" void emu_set_mb_hint(uint64_t v) { g_mbHint = v; }
 static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
 static uint32_t g_e1LdsBytes = ZF_BLOCK_MAX;       // the LDS shape under emulation (the product picks it from the batch's largest source)
 static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
@@ -280,7 +282,8 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     const bool mbc = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
     if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] mbc %d flat %d maxSrc %llu\n", (int)mbc, (int)flat, (unsigned long long)maxSrc);
     if (mbc) {
-        a.mbMaxBlocks = g_mbCompress > 1 ? g_mbCompress : (uint32_t)(2 * ((maxSrc + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2); a.mbSeqCap = (uint32_t)(maxSrc / 4 + a.mbMaxBlocks + 64);
+        const uint64_t hint = g_mbHint ? g_mbHint : maxSrc;
+        a.mbMaxBlocks = g_mbCompress > 1 ? g_mbCompress : (uint32_t)(2 * ((hint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2); a.mbSeqCap = (uint32_t)(hint / 4 + a.mbMaxBlocks + 64);
         a.mbBlocks = (ZeMbBlock*)malloc((size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); a.mbCount = (uint32_t*)malloc((size_t)chunk * 4); a.mbSeqs = (uint64_t*)malloc((size_t)chunk * a.mbSeqCap * 8);
         memset(a.mbBlocks, 0xA5, (size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); memset(a.mbCount, 0xA5, (size_t)chunk * 4);
     }

@@ -158,10 +158,17 @@ def _emu_set_mb_compress(self, v):
     self.lib.emu_set_mb_compress(C.c_uint32(v))
 
 
+def _emu_set_mb_hint(self, v):
+    """size the several-block compress arenas from this hint instead of the batch's largest source (0 = the largest source): what a device-API
+    caller's stale zhip_ctx_set_size_hint does"""
+    self.lib.emu_set_mb_hint(C.c_uint64(v))
+
+
 def _emu_stat(self, i):
     self.lib.emu_stat.restype = C.c_long
     return int(self.lib.emu_stat(C.c_int(i)))
 
 
 Emu.set_mb_compress = _emu_set_mb_compress
+Emu.set_mb_hint = _emu_set_mb_hint
 Emu.stat = _emu_stat

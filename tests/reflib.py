@@ -35,8 +35,36 @@ class _CMem(C.Structure):         # ZSTD_customMem: all NULL = the default alloc
     _fields_ = [("customAlloc", C.c_void_p), ("customFree", C.c_void_p), ("opaque", C.c_void_p)]
 
 
+REF_KIND = None     # which libzstd 1.5.7 the checker is: "reference build" (oracle/_ref, compiled from /root/reference/zstd/zstd.c) or "image copy"
+
+
+def _image_libzstd():
+    """the stock libzstd 1.5.7 inside this image (byte-identical level-3 frames to the reference build)"""
+    import glob
+    cands = sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd-*.so.1.5.7"))
+    return cands[0] if cands else None
+
+
 def have_ref():
-    return os.path.exists(REF_SO)
+    """True when a REAL libzstd 1.5.7 can be the checker: the reference build (oracle/_ref/libzstd_ref.so, git-ignored: it reaches the GPU
+    box only with the working tree) or, failing that, the image's own copy. Never the restatement (a clone-based run must not
+    quietly compare the kernels with builder-written code)."""
+    global REF_SO, REF_KIND
+    if os.path.exists(os.path.join(_ROOT, "oracle", "_ref", "libzstd_ref.so")):
+        REF_SO = os.path.join(_ROOT, "oracle", "_ref", "libzstd_ref.so"); REF_KIND = "reference build (oracle/_ref)"
+        return True
+    alt = _image_libzstd()
+    if alt:
+        REF_SO = alt; REF_KIND = "image copy (%s)" % alt
+        return True
+    return False
+
+
+def checker():
+    """the GPU suites' encoder / checker: libzstd 1.5.7 itself, or an error -- not a skip, not the restatement"""
+    if not have_ref():
+        raise RuntimeError("no libzstd 1.5.7 to check against: neither oracle/_ref/libzstd_ref.so (make -C oracle ref) nor the image's copy")
+    return RefZstd()
 
 
 def have_oracle():

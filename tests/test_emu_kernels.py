@@ -363,6 +363,25 @@ def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
     assert not any(st) and dec == big
 
 
+def test_several_block_search_with_an_understated_size_hint(emu, oracle, corpus):
+    """the flat search's per-source sequence slices are sized from the caller's size HINT; a source larger than the hint would write
+    past its slice. ze_split_body leaves such a source to the generic kernel: frames stay bit-exact, nothing is written out of bounds (the
+    ASan build of the emulator runs this too)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    raws = [corpus.frame_bytes(i) + corpus.frame_bytes(i + 50)[: 20000 + 30000 * i] for i in range(4)]            # ~150 - 240 KiB
+    raws += [corpus.frame_bytes(7) + corpus.frame_bytes(8) + corpus.frame_bytes(9)[:50000], corpus.frame_bytes(11) * 3]          # ~310 / 384 KiB: beyond the hint
+    want = [oracle.compress(r, level=3, flags=7) for r in raws]
+    s0 = emu.stat(8)
+    try:
+        emu.set_mb_hint(200 << 10)
+        outs, st = emu.compress_batch(raws, level=3, flags=7, n_blocks=2, pipeline=True, chunk=0)
+        assert st == [0] * len(raws) and outs == want
+    finally:
+        emu.set_mb_hint(0)
+    assert emu.stat(8) - s0 >= 2                 # the sources within the hint were still searched by the flat kernel
+
+
 @pytest.mark.parametrize("defines", [["-DZP_K2_LANEWISE", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANEWISE", "-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=4"],
                                      ["-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):

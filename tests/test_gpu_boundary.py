@@ -181,7 +181,7 @@ def test_dictionary_batch_config4_shape(zstd):
     from tests import reflib
     from tests.corpus import Corpus
     if not reflib.have_ref():
-        pytest.skip("needs the reference build")
+        pytest.fail("no libzstd 1.5.7 to check against: " + "needs the reference build")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     blob = open(os.path.join(root, "tests", "golden", "dict_json4k.bin"), "rb").read()
     meta = json.load(open(os.path.join(root, "tests", "golden", "dict_json4k.json")))
