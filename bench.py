@@ -360,6 +360,7 @@ def bench_dict(args, rank, world, dev, steps=None, warmup=None, quiet=False):
     ctotal = int(csizes.sum())
     job = Job(world, dev)
     ctx = DeviceBatchContext(dict_data=dict_data, level=3)
+    ctx.set_size_hint(DOC)                                         # what the host API tells the library by itself: the batch's largest source (slots of 48 KiB instead of the attach cutoff's 192: one launch)
     elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, DOC, steps, warmup)
     assert ctot2 == ctotal
     ms = elapsed / steps * 1e3

@@ -1915,6 +1915,9 @@ ZH_DEV void ze_dict_cparams(ZePar& cp, const ZeCDict& cd, uint32_t srcSize)
     cp.hlog = h; cp.clog = c; cp.mml = cd.mml; cp.strat = cd.strat; cp.tlen = cd.tlen;
 }
 ZH_DEV uint32_t ze_dict_attach_max(const ZeCDict& cd) { return cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX; }
+// what the match kernels of a dictionary batch take: sources up to the attach cutoff -- or up to what their table / arena slots were sized
+// for, where the caller's size hint made them smaller (262 144 slots of 48 KiB instead of 192 KiB: configs[3] in ONE launch); the rest is the generic kernel's
+ZH_DEV uint32_t ze_dict_slot_max(const ZhipEncodeArgs& a) { const uint32_t m = ze_dict_attach_max(*a.cdict); return a.slotSrcMax && a.slotSrcMax < m ? a.slotSrcMax : m; }
 // working parameters of libzstd's table-copy mode (ZSTD_resetCCtx_byCopyingCDict, zstd.c:25368-25373): everything from the dictionary's
 // row UNCHANGED, the window log as ZSTD_getCParamsFromCCtxParams chooses it for source + dictionary content (row of that total size,
 // clamped to its log2). 0, or parameter_unsupported when the window would drop the dictionary before the frame ends.
@@ -2874,7 +2877,7 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         bool bad = ze_get_cparams(cp, a.rows, srcSize) != 0;
         if (!bad && a.cdict) {
             if (a.cdict->status) bad = true;
-            else if (a.cdict->contentSize && srcSize > ze_dict_attach_max(*a.cdict)) {   // table-copy mode (needs tables of the dictionary's own size and a
+            else if (a.cdict->contentSize && srcSize > ze_dict_slot_max(a)) {            // table-copy mode (needs tables of the dictionary's own size and a
                 m.mode = 3; a.meta[i] = m;                                              // 128 KiB arena slot): one wave per frame in the generic kernel
                 a.bigList[zh_atomic_add(a.bigCount, 1u)] = f;
                 continue;
@@ -2925,7 +2928,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     if (take) {
         bool ok = srcSize >= 64 && ze_get_cparams(cp, a.rows, srcSize) == 0;
         if (ok && dict) {
-            ok = a.cdict->status == 0 && a.cdict->contentSize != 0 && srcSize <= ze_dict_attach_max(*a.cdict);
+            ok = a.cdict->status == 0 && a.cdict->contentSize != 0 && srcSize <= ze_dict_slot_max(a);
             if (ok) ze_dict_cparams(cp, *a.cdict, srcSize);
         }
         ok = ok && cp.strat == 2 && (size_t)(4u << cp.hlog) + (4u << cp.clog) <= a.tableStride;

@@ -113,6 +113,7 @@ struct ZhipEncodeArgs {
     uint8_t* laneTables;            // (gridDim.x * e1Lanes) x tableStride : hash tables of the frames being searched
     uint32_t e1Lanes;               // frames per wave of the lane-serial match kernel: ZE_E1_LANES (8), ZE_E1_LANES_DICT (32) for dictionary batches
     uint32_t tableStride;
+    uint32_t slotSrcMax;            // != 0: table and arena slots of a dictionary batch are sized for sources up to this (the caller's size hint); larger ones are the generic kernel's
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
     // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
     uint32_t* bigList; uint32_t* bigCount;

@@ -321,11 +321,16 @@ struct zhip_ctx {
     DevBuf hSrc, hDst, hSegs, hStatus, hDense;
     void* pinned = nullptr; size_t pinnedCap = 0;
     bool hpReady = false; hipStream_t hpH2D = nullptr, hpCompute = nullptr, hpD2H = nullptr;     // host pipeline: copy-in, kernels, copy-out
+    // compress chunk SLOTS (round 4): the host pipeline's compress chunks run on their own streams, side by side, each in its own part of the
+    // encode arenas -- the match kernel wants every frame of the batch in flight (two launches of 32 768 frames take 2 x 270 ms, one of 65 536
+    // takes 424), and a chunk can start as soon as ITS sources have arrived
+    hipStream_t hpComputeS[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t encSlots = 1, encSlot = 0, encSlotCap = 0;
     void* hpStage[2] = {nullptr, nullptr}; size_t hpStageCap[2] = {0, 0}; hipEvent_t hpStageFree[2] = {nullptr, nullptr}; int hpNextSlot = 0;
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 2, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -366,6 +371,9 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
+        if (const char* e = getenv("ZHIP_ESLOTS")) { const long v = atol(e); if (v >= 1 && v <= 4) k.eslots = (size_t)v; }
+        if (const char* e = getenv("ZHIP_ESLOT_MIN")) { const long v = atol(e); if (v >= 2) k.eslotMin = (size_t)v; }
+        if (const char* e = getenv("ZHIP_ESLOT_ITEMS")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.eslotItems = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
@@ -424,6 +432,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < 2; i++) { if (c->hpStage[i]) (void)hipHostFree(c->hpStage[i]); if (c->hpStageFree[i]) (void)hipEventDestroy(c->hpStageFree[i]); }
     if (c->hpH2D) (void)hipStreamDestroy(c->hpH2D);
     if (c->hpCompute) (void)hipStreamDestroy(c->hpCompute);
+    for (int i = 0; i < 4; i++) if (c->hpComputeS[i]) (void)hipStreamDestroy(c->hpComputeS[i]);
     if (c->hpD2H) (void)hipStreamDestroy(c->hpD2H);
     delete c;
 }
@@ -869,12 +878,15 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     hipStream_t stream = (hipStream_t)streamv;
     size_t maxBlocks = (size_t)c->numCU * (size_t)c->encBlocksPerCU;
     uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
-    if (c->counter.reserve(64)) return g_reserveRc;
-    HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 4, stream));
+    // (chunk slots of the host pipeline: this call's counters and arena parts are slot `encSlot`'s of `encSlots`; 1 / 0 for everybody else)
+    const size_t S = c->encSlots > 1 && !c->hasCDict && !c->knob.noPipeline ? c->encSlots : 1, slot = S > 1 ? c->encSlot : 0;
+    if (c->counter.reserve(64 * 8)) return g_reserveRc;
+    uint8_t* const cbase = (uint8_t*)c->counter.p + 64 * slot;
+    HIP_TRY(hipMemsetAsync(cbase + 8, 0, 4, stream));
     ZhipEncodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
     a.dstSegs = (const uint64_t*)d_dstSegs; a.outSizes = d_outSizes; a.status = d_status;
-    a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)((uint8_t*)c->counter.p + 8); a.n = (uint32_t)n;
+    a.workspace = (uint8_t*)c->encWorkspace.p; a.counter = (uint32_t*)(cbase + 8); a.n = (uint32_t)n;
     a.level = c->cparams.level == 0 ? 3 : c->cparams.level;
     a.rows = c->rows; a.magicless = c->cparams.format == ZHIP_FORMAT_ZSTD1_MAGICLESS;
     a.contentSizeFlag = c->cparams.contentSizeFlag != 0; a.checksumFlag = c->cparams.checksumFlag != 0; a.dictIDFlag = c->cparams.dictIDFlag != 0;
@@ -925,12 +937,18 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             // dictionary batches: every source is below the attach cutoff, so the per-lane tables are the dictionary row's shrunk to that
             // size (ze_dict_cparams) and a frame's sequences + literals fit a slot of the cutoff's size -- a tenth of the 128 KiB shapes,
             // which is what lets a whole 262 144-document batch be one chunk
-            const int w = c->cdictAttachMax > (8u << 10) ? 14 : 13;
+            // (round 4: where the caller says how large its sources are -- the host API knows, a device-API caller can tell with
+            // zhip_ctx_set_size_hint -- the slots are sized for THAT: 4 KiB documents need 48 KiB of tables, not the cutoff's 192, and 262 144 of
+            // them are one launch instead of two. A source above the hint is the generic kernel's: correct, slower)
+            size_t lim = c->cdictAttachMax;
+            if (sizeHint && sizeHint < lim) { lim = 1024; while (lim < sizeHint) lim <<= 1; }
+            if (lim < c->cdictAttachMax) a.slotSrcMax = (uint32_t)lim; else lim = c->cdictAttachMax;
+            int w = 10; while (((size_t)1 << w) < lim) w++;
             const int h = c->cdictHlog > w + 1 ? w + 1 : c->cdictHlog, cl = c->cdictClog > w ? w : c->cdictClog;
             stride = (4u << h) + (c->cdictStrat == 2 ? (4u << cl) : 0u);
             if (stride < (4u << 10)) stride = 4u << 10;
-            a.arenaLit = (8u * (c->cdictAttachMax / 3 + 16) + 15) & ~15u;
-            a.arenaStride = (a.arenaLit + c->cdictAttachMax + 256 + 15) & ~15u;
+            a.arenaLit = (8u * ((uint32_t)lim / 3 + 16) + 15) & ~15u;
+            a.arenaStride = (a.arenaLit + (uint32_t)lim + 256 + 15) & ~15u;
         }
         a.tableStride = stride;
         // double-fast without a dictionary: the flat match kernel (one lane per frame, the whole chunk in flight, tables zeroed by a
@@ -950,6 +968,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const size_t mbSeqCap = mbc ? sizeHint / 4 + mbMaxBlocks + 64 : 0;          // (double-fast matches are four bytes or more: zstd.c:31167 / :31150)
         if (mbc) { const size_t byMem = ((size_t)32 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
+        if (S > 1 && (mbc || n > c->encSlotCap || n > chunkMax)) { g_lastError = "compress chunk slots: a chunk the slots were not sized for"; return ZHIP_ERR_UNSUPPORTED; }
+        const size_t cap = S > 1 ? c->encSlotCap : chunk;                      // items a slot's arena parts are sized for
         const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
         const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;
         a.e1Lanes = (uint32_t)e1Lanes;
@@ -958,7 +978,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const size_t w1 = (chunk + e1Lanes - 1) / e1Lanes;
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
+        if (S > 1) g2max = (g2max + S - 1) / S;                                   // the slots' entropy kernels share the chip
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
+        const size_t w1cap = (cap + e1Lanes - 1) / e1Lanes, g1cap = w1cap < g1max ? w1cap : g1max, g2cap = cap < g2max ? cap : g2max;
         // waves for what the generic kernel takes: inputs above one block, and -- with a dictionary -- inputs above the attach cutoff
         // (with a dictionary: inputs above the attach cutoff too. Every wave of this kernel carries 544 bytes of scratch per lane: a full-chip
         // grid that finds an empty list still took 2.3 ms of every dictionary batch -- r02zi kernel trace; half a wave per CU is 0.4)
@@ -966,10 +988,12 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // the list is the whole batch and gets the whole chip: 2 048 x 1 MiB took 10.6 s on 64 waves, profiles/r03_multiblock_rate.txt)
         const size_t gBigMax = sizeHint > ZF_BLOCK_MAX ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : c->hasCDict ? (size_t)c->numCU / 2 : 64;
         const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
-        if (c->encMeta.reserve(chunk * sizeof(ZeMeta)) || c->encArena.reserve(chunk * (size_t)a.arenaStride) ||
-            c->encTables.reserve((size_t)g1 * e1Lanes * a.tableStride) || c->encWorkspace.reserve((size_t)g2 * ZE_E2_STRIDE + ZHIP_ENC_STRIDE) ||
-            c->encBigList.reserve(n * sizeof(uint32_t) + 16) || c->encE1List.reserve(chunk * sizeof(uint32_t) + 16) ||
-            (flat && c->encFlatTables.reserve(chunk * (size_t)a.tableStride))) return g_reserveRc;
+        const size_t tabPer = g1cap * e1Lanes * a.tableStride, wsPer = g2cap * ZE_E2_STRIDE + ZHIP_ENC_STRIDE, bigListPer = (S > 1 ? cap : n) * sizeof(uint32_t) + 16,
+                     e1ListPer = cap * sizeof(uint32_t) + 16, bigWsPer = (size_t)gBig * ZHIP_ENC_STRIDE;
+        if (c->encMeta.reserve(S * cap * sizeof(ZeMeta)) || c->encArena.reserve(S * cap * (size_t)a.arenaStride) ||
+            c->encTables.reserve(S * tabPer) || c->encWorkspace.reserve(S * wsPer) ||
+            c->encBigList.reserve(S * bigListPer) || c->encE1List.reserve(S * e1ListPer) ||
+            (flat && c->encFlatTables.reserve(S * cap * (size_t)a.tableStride))) return g_reserveRc;
         if (mbc) {
             if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
                 c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
@@ -977,12 +1001,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes;
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
         }
-        a.workspace = (uint8_t*)c->encWorkspace.p;
-        a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
-        a.flatTables = (uint8_t*)c->encFlatTables.p; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)((uint8_t*)c->counter.p + 32);
+        a.workspace = (uint8_t*)c->encWorkspace.p + slot * wsPer;
+        a.meta = (ZeMeta*)c->encMeta.p + slot * cap; a.arena = (uint8_t*)c->encArena.p + slot * cap * (size_t)a.arenaStride; a.laneTables = (uint8_t*)c->encTables.p + slot * tabPer;
+        uint8_t* const flatTables = flat ? (uint8_t*)c->encFlatTables.p + slot * cap * (size_t)a.tableStride : nullptr;
+        a.flatTables = flatTables; a.e1List = (uint32_t*)((uint8_t*)c->encE1List.p + slot * e1ListPer); a.e1Count = (uint32_t*)(cbase + 32);
         a.useE1List = flat ? 1u : 0u;
-        a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)((uint8_t*)c->counter.p + 24);
-        HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));
+        a.bigList = (uint32_t*)((uint8_t*)c->encBigList.p + slot * bigListPer); a.bigCount = (uint32_t*)(cbase + 24);
+        HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
             if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
             HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
@@ -991,13 +1016,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
-            HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 8, 0, 8, stream));
-            HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 32, 0, 4, stream));
+            HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream));
+            HIP_TRY(hipMemsetAsync(cbase + 32, 0, 4, stream));
             const bool tm = c->timing;
             hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
-                if (!flatDict) HIP_TRY(hipMemsetAsync(c->encFlatTables.p, 0, cnt * (size_t)a.tableStride, stream));
+                if (!flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
                 // (the LDS area follows the batch's largest source where the caller told us -- the host-buffer API does: more frames per CU)
@@ -1025,10 +1050,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (tm) HIP_TRY(hipEventRecord(ev[5], stream));
             if (mbc) {      // this chunk's sources of several blocks: the generic kernel over the list the flat kernel just made (it reads the chunk's arenas)
                 ZhipEncodeArgs b = a;
-                b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);
+                b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)(cbase + 28);
                 b.frameList = a.bigList; b.listCount = a.bigCount;
                 hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
-                HIP_TRY(hipMemsetAsync((uint8_t*)c->counter.p + 24, 0, 8, stream));          // list length and the kernel's work counter: fresh for the next chunk
+                HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));          // list length and the kernel's work counter: fresh for the next chunk
             }
             HIP_TRY(hipGetLastError());
             if (tm) {
@@ -1049,9 +1074,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.prof = nullptr;
         }
         if (!mbc) {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
-            if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
+            if (c->encBigWs.reserve(S * bigWsPer)) return g_reserveRc;
             ZhipEncodeArgs b = a;
-            b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)((uint8_t*)c->counter.p + 28);
+            b.workspace = (uint8_t*)c->encBigWs.p + slot * bigWsPer; b.counter = (uint32_t*)(cbase + 28);
             b.frameList = a.bigList; b.listCount = a.bigCount;
             hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
             HIP_TRY(hipGetLastError());
@@ -1235,6 +1260,7 @@ static int host_pipe_init(zhip_ctx* c)
     if (c->hpReady) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->hpH2D, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->hpCompute, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipStreamCreateWithFlags(&c->hpComputeS[i], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->hpD2H, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->hpStageFree[i], hipEventDisableTiming));
     c->hpReady = true;
@@ -1487,8 +1513,23 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // the match kernel is a per-frame latency chain (its time barely depends on the batch below ~16 K frames), so compress chunks are
     // large: two of them overlap one's upload with the other's kernels, more would only add chains end to end
-    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)4 << 30, c->knob.hchunkE, n > c->knob.hchunkE ? c->knob.hchunkE0 : 0);
+    // Chunk SLOTS (round 4): a batch of one-block sources without a dictionary -- BASELINE's shape -- is cut into chunks that run side by side on
+    // their own streams, each in its own part of the encode arenas: a chunk starts as soon as ITS sources have arrived instead of after the chunk
+    // before it. Measured on 65 536 x 128 KiB through Python (profiles/r04h-r04m): one slot (two serial chunks, round 3's form) 11.6-11.8 GB/s;
+    // TWO slots of half the batch 12.7 -- the default; four slots of 16 384 on HIP's 4 hardware queues 12.1-12.3 (the fourth slot's queue is the
+    // first one's: it waits for it, r04j timeline); three slots on their own queues 2.4 and four with GPU_MAX_HW_QUEUES=8 2.3 (!) outside the
+    // profiler, 12.1 under its kernel trace (r04m: the three searches overlap, 475-493 ms each against 424 for ONE launch of the whole
+    // batch) -- not understood, not shipped. The ceiling of this shape is ~14 GB/s anyway: the search of 65 536 frames is 424-480 ms of
+    // transaction-bound work however it is cut, in front of it the first chunk's upload, behind it entropy coding, compaction, D2H.
+    size_t maxItem = 0; for (size_t i = 0; i < n; i++) if (items[i].srcSize > maxItem) maxItem = items[i].srcSize;
+    const size_t S = !c->hasCDict && !c->knob.noPipeline && !c->knob.noFlat && maxItem <= ZF_BLOCK_MAX && c->knob.eslots > 1 && n >= c->knob.eslotMin ? c->knob.eslots : 1;
+    const size_t slotItems = c->knob.eslotItems ? c->knob.eslotItems : (n + S - 1) / S;
+    const std::vector<size_t> cut = S > 1 ? host_chunks(segs.data(), n, (uint64_t)4 << 30, slotItems)
+                                          : host_chunks(segs.data(), n, (uint64_t)4 << 30, c->knob.hchunkE, n > c->knob.hchunkE ? c->knob.hchunkE0 : 0);
     const size_t nChunks = cut.size() - 1;
+    struct SlotGuard { zhip_ctx* c; ~SlotGuard() { c->encSlots = 1; c->encSlot = 0; } } slotGuard{c};
+    c->encSlots = S; c->encSlotCap = S > 1 ? slotItems : 0;
+    auto slotStream = [&](size_t q) -> hipStream_t { return q == 0 ? c->hpCompute : q == 1 ? c->hpD2H : c->hpComputeS[q - 2]; };
     // device: sources, slots, dense frames, segment table, [sizes | offsets | chunk totals | status]
     const size_t metaBytes = n * (2 * sizeof(uint64_t) + sizeof(int32_t)) + (nChunks + 1) * sizeof(uint64_t) + 32;
     if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hDense.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment) + 16) ||
@@ -1527,31 +1568,36 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
         uint64_t o = 0;
         for (size_t i = lo; i < hi; i++) { ob[k].segs[i - lo].offset = o; ob[k].segs[i - lo].length = hSizes[i]; o += hSizes[i]; }
         // the compaction finished before evMeta (same stream), so the copy needs no further dependency
-        if (total && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDense.p + segs[n + lo].offset, total, hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        if (total && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDense.p + segs[n + lo].offset, total, hipMemcpyDeviceToHost, S > 1 ? slotStream(k % S) : c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
         return 0;
     };
     for (size_t k = 0; k < nChunks; k++) {
         const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
+        hipStream_t sk = S > 1 ? slotStream(k % S) : c->hpCompute;           // (a slot's next chunk follows its last one in stream order: the arena part is free again)
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
-        if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        // (slots: the frames of the chunk that used this slot before travel back on the slot's stream AHEAD of this chunk's kernels)
+        if (S > 1 && k >= S) { const int e = collect(k - S); if (e) return e; }
+        if (hipStreamWaitEvent(sk, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
         { size_t mx = 0; for (size_t i = lo; i < hi; i++) if (items[i].srcSize > mx) mx = items[i].srcSize; c->srcMaxHint = mx; }
-        r = zhip_compress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
+        c->encSlot = k % S;
+        r = zhip_compress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, sk);
         c->srcMaxHint = 0;
         if (r) return fail(r);
-        hipLaunchKernelGGL(zhip_scan_sizes_kernel, dim3(1), dim3(1024), 0, c->hpCompute, dSizes + lo, dStatus + lo, (uint32_t)cnt, dOffs + lo, dTotals + k);
+        hipLaunchKernelGGL(zhip_scan_sizes_kernel, dim3(1), dim3(1024), 0, sk, dSizes + lo, dStatus + lo, (uint32_t)cnt, dOffs + lo, dTotals + k);
         const uint32_t gridC = (uint32_t)(cnt < (size_t)c->numCU * 16 ? cnt : (size_t)c->numCU * 16);
-        hipLaunchKernelGGL(zhip_compact_kernel, dim3(gridC ? gridC : 1), dim3(64), 0, c->hpCompute, (const uint8_t*)c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo,
+        hipLaunchKernelGGL(zhip_compact_kernel, dim3(gridC ? gridC : 1), dim3(64), 0, sk, (const uint8_t*)c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo,
                            dOffs + lo, (uint32_t)cnt, (uint8_t*)c->hDense.p + segs[n + lo].offset);
         // sizes, status and the chunk total ride the compute stream (a few hundred KiB) so that nothing queues behind a later chunk's kernels
         if (hipGetLastError() != hipSuccess ||
-            hipMemcpyAsync(hSizes + lo, dSizes + lo, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
-            hipMemcpyAsync(hStatus + lo, dStatus + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
-            hipMemcpyAsync(hTotals + k, dTotals + k, sizeof(uint64_t), hipMemcpyDeviceToHost, c->hpCompute) != hipSuccess ||
-            hipEventCreateWithFlags(&evMeta[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(evMeta[k], c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
-        if (k >= 1) { const int e = collect(k - 1); if (e) return e; }
+            hipMemcpyAsync(hSizes + lo, dSizes + lo, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, sk) != hipSuccess ||
+            hipMemcpyAsync(hStatus + lo, dStatus + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, sk) != hipSuccess ||
+            hipMemcpyAsync(hTotals + k, dTotals + k, sizeof(uint64_t), hipMemcpyDeviceToHost, sk) != hipSuccess ||
+            hipEventCreateWithFlags(&evMeta[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(evMeta[k], sk) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        if (S == 1 && k >= 1) { const int e = collect(k - 1); if (e) return e; }
     }
-    if (nChunks) { const int e = collect(nChunks - 1); if (e) return e; }
+    for (size_t j = nChunks > S ? nChunks - S : 0; j < nChunks; j++) { const int e = collect(j); if (e) return e; }
     if (hipStreamSynchronize(c->hpD2H) != hipSuccess || hipStreamSynchronize(c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
+    for (size_t q = 0; q < S && S > 1; q++) if (hipStreamSynchronize(slotStream(q)) != hipSuccess) return fail(ZHIP_ERR_HIP);
     (void)hipEventDestroy(evUp);
     if (nChunks == 0) empty_outbuf(&ob[0]);
     *out = ob; *nOut = nChunks ? nChunks : 1;

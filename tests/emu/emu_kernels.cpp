@@ -235,6 +235,8 @@ static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
 extern "C" void emu_set_mb_compress(uint32_t v) { g_mbCompress = v; }
+static uint32_t g_dictSlotMax = 0;              // != 0: ZhipEncodeArgs.slotSrcMax of dictionary batches (sources above it are the generic kernel's)
+extern "C" void emu_set_dict_slot_max(uint32_t v) { g_dictSlotMax = v; }
 static uint64_t g_mbHint = 0;                   // != 0: the several-block arenas are sized from this size HINT instead of the batch's largest source (a device-API caller's stale hint)
 extern "C" void emu_set_mb_hint(uint64_t v) { g_mbHint = v; }
 static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
@@ -267,6 +269,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             if (bytes > a.tableStride && bytes <= (12u << 17)) a.tableStride = bytes;
         }
     a.e1Lanes = g_hasCD ? ZE_E1_LANES_DICT : ZE_E1_LANES;
+    a.slotSrcMax = g_hasCD ? g_dictSlotMax : 0u;
     a.laneTables = (uint8_t*)malloc((size_t)nBlocks * a.e1Lanes * a.tableStride);
     a.meta = (ZeMeta*)calloc(chunk, sizeof(ZeMeta));
     a.arena = (uint8_t*)malloc((size_t)chunk * ZE_ARENA_STRIDE); a.arenaStride = (uint32_t)ZE_ARENA_STRIDE; a.arenaLit = ZE_ARENA_LIT;

@@ -164,6 +164,11 @@ def _emu_set_mb_hint(self, v):
     self.lib.emu_set_mb_hint(C.c_uint64(v))
 
 
+def _emu_set_dict_slot_max(self, v):
+    """dictionary batches: the match kernels take sources up to v bytes (their slots' size under a caller's size hint), larger ones go to the generic kernel; 0 = the attach cutoff"""
+    self.lib.emu_set_dict_slot_max(C.c_uint32(v))
+
+
 def _emu_stat(self, i):
     self.lib.emu_stat.restype = C.c_long
     return int(self.lib.emu_stat(C.c_int(i)))
@@ -171,4 +176,5 @@ def _emu_stat(self, i):
 
 Emu.set_mb_compress = _emu_set_mb_compress
 Emu.set_mb_hint = _emu_set_mb_hint
+Emu.set_dict_slot_max = _emu_set_dict_slot_max
 Emu.stat = _emu_stat

@@ -576,6 +576,17 @@ def test_flat_dictionary_search_bit_exact(emu, ref, corpus):
         outs, st = emu.compress_batch(raws, level=3, flags=5, pipeline=True, dict_data=dd)
         assert not any(st) and outs == want
         assert emu.lib.emu_stat(15) - before >= 50          # the flat kernel searched them (sources under 64 bytes go to the lane-serial kernel)
+    # round 4: table / arena slots sized from the caller's size hint (ZhipEncodeArgs.slotSrcMax): the match kernels take sources up to 4 KiB,
+    # the rest -- also sources BELOW the attach cutoff -- goes to the generic kernel; the frames are libzstd's either way
+    try:
+        emu.set_dict_slot_max(4096)
+        want = [ref.compress(r, level=3, dict_data=big) for r in raws]
+        before = emu.lib.emu_stat(15)
+        outs, st = emu.compress_batch(raws, level=3, flags=5, pipeline=True, dict_data=big)
+        assert not any(st) and outs == want
+        assert 40 <= emu.lib.emu_stat(15) - before < 50
+    finally:
+        emu.set_dict_slot_max(0)
 
 
 def test_decode_pipeline_long_items_and_carried_flush(emu, ref):

@@ -204,3 +204,43 @@ def test_sources_of_several_blocks_in_the_flat_search(zstd, corpus):
         for i, r in enumerate(raws):
             assert box[flags][i] == ref.compress(r, level=3, flags=flags), (flags, i, len(r))
     assert box["back"] == raws
+
+
+def test_host_pipeline_compress_chunk_slots(zstd, corpus):
+    """multi_compress_to_buffer on host buffers cuts a large batch of one-block sources into chunks that run SIDE BY SIDE on their own streams,
+    each in its own part of the encode arenas (zhip_compress_batch, round 4: the match kernel wants every frame in flight, a chunk starts as
+    soon as its sources have arrived). ZHIP_ESLOT_ITEMS=256 / ZHIP_ESLOT_MIN=512 turn that on for a batch of 1 500 inputs (read when a thread's context is
+    created: fresh thread): every frame against libzstd 1.5.7 (ZSTD_compressStream2(e_end), c-ext/compressor.c:1035-1043), sizes from empty to
+    128 KiB, a second call on the same context (the slots' arenas reused), and a fast-strategy level (the lane-serial match kernel in slots)."""
+    import os
+    import threading
+    from tests import reflib
+    ref = reflib.checker()
+    rng = np.random.default_rng(77)
+    raws = []
+    for i in range(1500):
+        n = int(rng.choice([0, 3, 100, 4096, 30000, 131072], p=[0.01, 0.01, 0.08, 0.3, 0.3, 0.3]))
+        r = corpus.frame_bytes(i % 400)[:n] if i % 7 else rng.bytes(n)
+        raws.append(r)
+    box = {}
+
+    def run():
+        try:
+            c = zstd.ZstdCompressor(level=3)
+            for rep in range(2):
+                res = c.multi_compress_to_buffer(raws)
+                box[rep] = [res[i].tobytes() for i in range(len(raws))]
+            res = zstd.ZstdCompressor(level=1).multi_compress_to_buffer(raws)
+            box["l1"] = [res[i].tobytes() for i in range(len(raws))]
+        except Exception as e:              # noqa: BLE001 -- reported by the assertion below
+            box["error"] = e
+
+    os.environ["ZHIP_ESLOT_ITEMS"] = "256"; os.environ["ZHIP_ESLOT_MIN"] = "512"
+    try:
+        t = threading.Thread(target=run); t.start(); t.join()
+    finally:
+        del os.environ["ZHIP_ESLOT_ITEMS"]; del os.environ["ZHIP_ESLOT_MIN"]
+    assert "error" not in box, box.get("error")
+    want = [ref.compress(r, level=3) for r in raws]
+    assert box[0] == want and box[1] == want
+    assert box["l1"] == [ref.compress(r, level=1) for r in raws]
