@@ -330,7 +330,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 2, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -1513,14 +1513,16 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // the match kernel is a per-frame latency chain (its time barely depends on the batch below ~16 K frames), so compress chunks are
     // large: two of them overlap one's upload with the other's kernels, more would only add chains end to end
-    // Chunk SLOTS (round 4): a batch of one-block sources without a dictionary -- BASELINE's shape -- is cut into chunks that run side by side on
-    // their own streams, each in its own part of the encode arenas: a chunk starts as soon as ITS sources have arrived instead of after the chunk
-    // before it. Measured on 65 536 x 128 KiB through Python (profiles/r04h-r04m): one slot (two serial chunks, round 3's form) 11.6-11.8 GB/s;
-    // TWO slots of half the batch 12.7 -- the default; four slots of 16 384 on HIP's 4 hardware queues 12.1-12.3 (the fourth slot's queue is the
-    // first one's: it waits for it, r04j timeline); three slots on their own queues 2.4 and four with GPU_MAX_HW_QUEUES=8 2.3 (!) outside the
-    // profiler, 12.1 under its kernel trace (r04m: the three searches overlap, 475-493 ms each against 424 for ONE launch of the whole
-    // batch) -- not understood, not shipped. The ceiling of this shape is ~14 GB/s anyway: the search of 65 536 frames is 424-480 ms of
-    // transaction-bound work however it is cut, in front of it the first chunk's upload, behind it entropy coding, compaction, D2H.
+    // Chunk SLOTS (round 4, OFF by default: ZHIP_ESLOTS=2..4 turns them on): a batch of one-block sources without a dictionary -- BASELINE's
+    // shape -- cut into chunks that run side by side on their own streams, each in its own part of the encode arenas, so that a chunk starts as
+    // soon as ITS sources have arrived instead of after the chunk before it. Measured on 65 536 x 128 KiB through Python (profiles/r04h-r04n):
+    // one slot (two serial chunks, round 3's form) 11.6-11.8 GB/s; two slots of half the batch 12.7; four slots of 16 384 12.1-12.3 (HIP drives 4
+    // hardware queues: the fourth slot's queue is the first one's and it waits for it, r04j timeline). But the concurrent form has a SLOW MODE
+    // nobody has explained: three slots 2.4 GB/s, four with GPU_MAX_HW_QUEUES=8 2.3, and TWO slots inside bench.py's process 2.3 -- always
+    // ~3.7 s per call, ~8 x the search's 0.42-0.48 s, while the same three-slot call under rocprofv3's kernel trace takes 0.71 s with the three
+    // searches overlapping as intended (r04m). An intermittent 5 x loss is worse than the 7 % gain: off. The ceiling of this shape is ~14 GB/s
+    // anyway -- the search of 65 536 frames is 424-480 ms of transaction-bound work however it is cut, in front of it the first
+    // chunk's upload, behind it entropy coding, compaction and the copy back.
     size_t maxItem = 0; for (size_t i = 0; i < n; i++) if (items[i].srcSize > maxItem) maxItem = items[i].srcSize;
     const size_t S = !c->hasCDict && !c->knob.noPipeline && !c->knob.noFlat && maxItem <= ZF_BLOCK_MAX && c->knob.eslots > 1 && n >= c->knob.eslotMin ? c->knob.eslots : 1;
     const size_t slotItems = c->knob.eslotItems ? c->knob.eslotItems : (n + S - 1) / S;

@@ -207,7 +207,7 @@ def test_sources_of_several_blocks_in_the_flat_search(zstd, corpus):
 
 
 def test_host_pipeline_compress_chunk_slots(zstd, corpus):
-    """multi_compress_to_buffer on host buffers cuts a large batch of one-block sources into chunks that run SIDE BY SIDE on their own streams,
+    """(off by default, ZHIP_ESLOTS turns it on) multi_compress_to_buffer on host buffers cuts a large batch of one-block sources into chunks that run SIDE BY SIDE on their own streams,
     each in its own part of the encode arenas (zhip_compress_batch, round 4: the match kernel wants every frame in flight, a chunk starts as
     soon as its sources have arrived). ZHIP_ESLOT_ITEMS=256 / ZHIP_ESLOT_MIN=512 turn that on for a batch of 1 500 inputs (read when a thread's context is
     created: fresh thread): every frame against libzstd 1.5.7 (ZSTD_compressStream2(e_end), c-ext/compressor.c:1035-1043), sizes from empty to
@@ -235,11 +235,11 @@ def test_host_pipeline_compress_chunk_slots(zstd, corpus):
         except Exception as e:              # noqa: BLE001 -- reported by the assertion below
             box["error"] = e
 
-    os.environ["ZHIP_ESLOT_ITEMS"] = "256"; os.environ["ZHIP_ESLOT_MIN"] = "512"
+    os.environ["ZHIP_ESLOT_ITEMS"] = "256"; os.environ["ZHIP_ESLOT_MIN"] = "512"; os.environ["ZHIP_ESLOTS"] = "3"
     try:
         t = threading.Thread(target=run); t.start(); t.join()
     finally:
-        del os.environ["ZHIP_ESLOT_ITEMS"]; del os.environ["ZHIP_ESLOT_MIN"]
+        del os.environ["ZHIP_ESLOT_ITEMS"]; del os.environ["ZHIP_ESLOT_MIN"]; del os.environ["ZHIP_ESLOTS"]
     assert "error" not in box, box.get("error")
     want = [ref.compress(r, level=3) for r in raws]
     assert box[0] == want and box[1] == want
