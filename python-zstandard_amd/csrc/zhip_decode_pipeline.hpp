@@ -1251,8 +1251,13 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 const uint32_t val = pbase + zh_bfe(zh_alignbit(pe1, pe0, pqE), 0, pbits);
                 const uint32_t mlv = zh_quad<1>(val), llv = zh_quad<2>(val);
                 const uint32_t idx = val - 1 + (llv == 0);
-                const uint32_t r0m1 = rep0 != 1u ? rep0 - 1 : 0xFFFFFFFFu;        // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941); packed it is the largest offset there is and K3 refuses it
-                const uint32_t c3 = val <= 3 ? r0m1 : val - 3 < ZP_OF_LIMIT ? val - 3 : ZP_OF_LIMIT;     // (a new offset beyond the packed form: saturated, K3 knows what to do)
+                // rep0 - 1 == 0 is no offset: libzstd 1.5.7 forces -1 (zstd.c:46941). It travels as offset 0, which K3 refuses (its range check is on
+                // offset - 1: zero wraps to the largest value there is). A new offset beyond the packed form is saturated; K3 knows what to do.
+                // (round 4: straight-line selects -- the nested ternary became an exec-mask if / else of 4 scalar instructions + 2 s_nop per step, in a
+                // kernel that pays 5.7 cycles for every instruction of its 84-instruction step)
+                const uint32_t vm3 = val - 3;
+                const uint32_t newOff = vm3 < ZP_OF_LIMIT ? vm3 : ZP_OF_LIMIT;
+                const uint32_t c3 = val > 3 ? newOff : rep0 - 1;
                 uint32_t offset = idx == 2 ? rep2 : c3; offset = idx == 1 ? rep1 : offset; offset = idx == 0 ? rep0 : offset;
                 ZQ_F2();
                 // ---- the chain: cell -> bit counts -> where my state bits are -> next state
@@ -1429,7 +1434,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         const uint32_t litStart = lp + incL - myLL;
         const uint32_t ob = op - carry;
         const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
-        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)ob + mRel + dictSize)) return ZE_CORRUPTION;
+        if (zh_ballot(act && myOF - 1 >= ob + mRel + dictSize)) return ZE_CORRUPTION;      // (offset 0 = K2's "repeat offset 1 minus one = 0": wraps to the largest value; ob < 2^31, dictionary < 2^28)
         if (big) {
             if (lane < carry) dst[ob + lane] = asmb[lane];                  // what the last flush held back
             carry = 0;
@@ -1830,7 +1835,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             if (lp + bll > m.litSize) return ZE_CORRUPTION;
             if ((uint64_t)op + bll + bml > cap) return ZE_DST_TOO_SMALL;
             if (op + bll + bml - blockStart > blockMax) return ZE_CORRUPTION;
-            if ((uint64_t)bof > (uint64_t)op + bll + dictSize) return ZE_CORRUPTION;
+            if (bof - 1 >= op + bll + dictSize) return ZE_CORRUPTION;              // (offset 0: K2's "repeat offset 1 minus one = 0")
             if (lane < carry) dst[op - carry + lane] = asmb[lane];      // what the last flush held back
             carry = 0;
             zd_fence();
@@ -1858,7 +1863,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         const uint32_t ob = op - carry;
         const uint32_t litStart = act ? lp + incL - myLL : lp;
         const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
-        if (zh_ballot(act && (uint64_t)myOF > (uint64_t)ob + mRel + dictSize)) return ZE_CORRUPTION;
+        if (zh_ballot(act && myOF - 1 >= ob + mRel + dictSize)) return ZE_CORRUPTION;      // (offset 0 = K2's "repeat offset 1 minus one = 0": wraps to the largest value; ob < 2^31, dictionary < 2^28)
         ZD_TP(P, ZP_STAGE);
         const int32_t sRel = (int32_t)mRel - (int32_t)myOF;               // the match source, batch-relative (below 0: before the batch)
         const int32_t sEnd = sRel + (int32_t)myML;
