@@ -1322,6 +1322,7 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #ifndef ZP_K3_R4
 struct ZpExecLDS {
     uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
+    uint8_t cellSeq[(ZP_ASM_BYTES >> 4) + 8];        // round 4: which sequence of the batch holds byte 16 c of the buffer (the need-masks' index, below)
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
     uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
 };
@@ -1382,6 +1383,13 @@ ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2
 
 // One compressed block: the sequences K2 left in slot `t`, the literals of slot `t` (or in place), executed at output position `opRef` of
 // the frame at `dst` (MB = false: the frame's only block, position 0). m = the block's record. 0 or a zstd error code.
+// LDS hand-offs inside the batch loop: __syncthreads() also waits for the wave's global stores and loads (s_waitcnt vmcnt(0)); -DZP_K3_LIGHT_SYNC
+// makes them wave-level fences (the LDS executes a wave's instructions in order), as the round-4 form has them
+#ifdef ZP_K3_LIGHT_SYNC
+#define ZP_BSYNC() zh_wave_fence()
+#else
+#define ZP_BSYNC() zh_sync()
+#endif
 template <bool DICT, bool PROF, bool MB>
 ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint8_t* dst, uint32_t cap, uint64_t cap64,
                            uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
@@ -1506,7 +1514,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                 L.uEnd[lane] = (uint16_t)ue; L.uLit[lane] = (uint16_t)uL;
                 L.srcL[lane] = litStart; L.dstL[lane] = (uint16_t)oRel; L.lenL[lane] = (uint16_t)myLL;
                 L.srcM[lane] = (uint32_t)sAbs; L.dstM[lane] = (uint16_t)mRel; L.lenM[lane] = (uint16_t)lenMi;
-                zh_sync();
+                ZP_BSYNC();
 #define ZP_UNIT(u) do { uint32_t j_ = 0; for (uint32_t stp_ = 32; stp_; stp_ >>= 1) if (L.uEnd[j_ + stp_ - 1] <= (u)) j_ += stp_; \
                     uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
                     const uint32_t len_ = isL_ ? L.lenL[j_] : L.lenM[j_]; const uint32_t off_ = 16 * k_ + 16 <= len_ ? 16 * k_ : len_ - 16; \
@@ -1542,8 +1550,10 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         // ---- matches that read this batch's own output. A match may start as soon as every near match whose output
         // it reads is done: `need` = the set of those sequences (contiguous index range found by binary search over the
         // batch-relative match extents), so the number of rounds is the dependency depth, not the batch length.
+#ifndef ZP_K3_NEED_CELLS     // exact need-masks from two binary searches over the batch's match extents (12 dependent LDS reads, ~86 instructions per batch): the default.
+                             // -DZP_K3_NEED_CELLS: the 16-byte cell map below -- measured r04p / r04q: K3 10.09-10.13 ms against 9.95-10.06 (its supersets cost a round now and then; the scalar count rose by what the vector count fell)
         L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
-        zh_sync();
+        ZP_BSYNC();
         ZD_TP(P, ZP_EXEC1);
         bool pending = hasM && !farM;
         uint64_t need = 0;
@@ -1557,6 +1567,38 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             if (hi > lane) hi = lane;           // only earlier sequences can feed me
             if (lo < hi) need = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
         }
+#else
+        // Round 4: K3's time is its total instruction count, and the two searches were ~86 instructions + 12 dependent LDS reads of every batch.
+        // The sequences of a batch tile its buffer [carry, totB) in order, so "which sequence holds byte 16 c" (cellSeq) answers both ends of
+        // a source range with ONE read each: the sequence holding the 16-byte boundary at or below the range's first byte is the first one
+        // that can reach into it, the one holding the boundary above its last byte is the last. The masks come out as SUPERSETS of the exact
+        // ones (up to a few neighbouring sequences more): a match may wait a round longer than it must, never less.
+        {
+            const uint32_t sEndRel = oRel + myLL + myML;
+            uint32_t c0 = (oRel + 15) >> 4, c1 = (sEndRel + 15) >> 4;            // my boundaries: 16 c in [oRel, sEndRel)
+            if (lane == 0) c0 = 0;                                                // (the carried bytes in front of the first sequence: final, any index does)
+            if (lane + 1 == cnt) c1 += 2;                                         // (reads reach one boundary past the last byte)
+            if (!act) c1 = c0;
+            // (a sequence holds two boundaries at most unless it is longer than 32 bytes: two plain stores, the loop only when some lane needs it.
+            // Written as a plain loop LLVM turns it into a memset -- 8-byte stores, a remainder loop, 40 instructions)
+            if (c0 < c1) L.cellSeq[c0] = (uint8_t)lane;
+            if (c0 + 1 < c1) L.cellSeq[c0 + 1] = (uint8_t)lane;
+            if (zh_ballot(c0 + 2 < c1)) for (uint32_t c = c0 + 2; c < c1; c++) L.cellSeq[zh_opaque(c)] = (uint8_t)lane;
+        }
+        ZP_BSYNC();
+        ZD_TP(P, ZP_EXEC1);
+        bool pending = hasM && !farM;
+        uint64_t need = 0;
+        if (pending) {
+            const uint32_t a0 = sAbs > (int32_t)ob ? (uint32_t)(sAbs - (int32_t)ob) : 0;          // first buffer byte I read
+            uint32_t b0 = (uint32_t)(sAbs + (int32_t)myML - (int32_t)ob);                          // one past the last byte I read
+            if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
+            const uint32_t lo = L.cellSeq[a0 >> 4];
+            uint32_t hi = b0 ? (uint32_t)L.cellSeq[((b0 - 1) >> 4) + 1] + 1 : 0u;                  // (b0 == 0: a match at the buffer's first byte reads nothing of the batch but itself)
+            if (hi > lane) hi = lane;           // only earlier sequences can feed me
+            if (lo < hi) need = ((1ull << hi) - 1) & ~((1ull << lo) - 1);                          // (hi <= lane <= 63)
+        }
+#endif
         const uint64_t nearMask = zh_ballot(pending);
         need &= nearMask;                       // literals and far matches are already in the buffer
         uint64_t doneMask = ~nearMask;
@@ -1574,7 +1616,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                     for (uint32_t c = 0; c < fml; c += 64) {
                         const uint32_t j = c + lane;
                         if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
-                        if (fof < fml) zh_sync();
+                        if (fof < fml) ZP_BSYNC();
                     }
                 } else {
                     uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
@@ -1614,7 +1656,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                 }
                 doneMask |= zh_ballot(ready);
             }
-            zh_sync();
+            ZP_BSYNC();
         }
 #else
         // a round serves its ready short matches AND every ready long match (one after the other by the whole wave): what is ready at
@@ -1659,7 +1701,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                         for (uint32_t c = 0; c < fml; c += 64) {
                             const uint32_t j = c + lane;
                             if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
-                            if (fof < fml) zh_sync();
+                            if (fof < fml) ZP_BSYNC();
                         }
                     } else {
                         uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
@@ -1671,11 +1713,11 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                     }
                     if (lane == pf) pending = false;
                     newDone |= 1ull << pf;
-                    if (lm & (lm - 1)) zh_sync();
+                    if (lm & (lm - 1)) ZP_BSYNC();
                 }
                 doneMask |= newDone;
             }
-            zh_sync();
+            ZP_BSYNC();
         }
 #endif
         ZD_TP(P, ZP_EXEC2);
@@ -1696,22 +1738,22 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         qNext = zh_opaque64(qNext);
         const uint32_t totB = totT + carry, whole = totB & ~15u;         // bytes in the buffer; the part that leaves now
         {
+            // (round 4: the first 1 KiB -- nearly always all of it -- as straight-line code, the loop only behind a uniform test. As one loop the
+            // compiler unrolled it by two with eight 4-byte stores per trip and a remainder loop: 63 instructions of the batch's ~700)
             uint8_t* out = dst + ob;
-            for (uint32_t j = lane * 16; j < whole; j += 1024) {
-                const uint32_t* s4 = (const uint32_t*)(asmb + j);
-                ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
-                *(ZdPack16*)(out + j) = v;
-            }
+            const uint32_t j0 = lane * 16;
+            if (j0 < whole) { const zh_v16 v = *(const zh_v16*)(asmb + j0); *(zh_v16*)(out + j0) = v; }
+            if (whole > 1024) for (uint32_t j = j0 + 1024; j < whole; j += 1024) { const zh_v16 v = *(const zh_v16*)(asmb + zh_opaque(j)); *(zh_v16*)(out + j) = v; }
         }
         carry = totB - whole;
-        zh_sync();
+        ZP_BSYNC();
         if (carry && whole) {                                              // the tail moves to the front (one 16-byte read / write; the sync above: every flush read is done)
             uint64_t t0 = 0, t1 = 0;
             if (lane == 0) { t0 = zh_ld64(asmb + whole); t1 = zh_ld64(asmb + whole + 8); }
-            zh_sync();
+            ZP_BSYNC();
             if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
         }
-        zh_sync();
+        ZP_BSYNC();
         ZD_TP(P, ZP_FLUSH);
         op += totT; lp += totL; done += cnt;
     }
