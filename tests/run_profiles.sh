@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 TAG=${TAG:-r03}
 FRAMES=${FRAMES:-65536}
 P=gpurun_out/prof; rm -rf $P gpurun_out/summary; mkdir -p $P
-B="python bench.py --frames $FRAMES --warmup 1 --no-cpu-baseline --no-extra"
+B="python bench.py --frames $FRAMES --warmup 1 --no-cpu-baseline --no-extra --no-host-api"
 run() { d=$P/$1; shift; mkdir -p $d; timeout 500 rocprofv3 "$@" > $d/bench.json 2> $d/err.log; echo "$d rc $?"; }
 run decode_kt --kernel-trace --stats --output-format csv -d $P/decode_kt -- $B --steps 3 --compress-frames 0
 run decode_fetch --pmc FETCH_SIZE --output-format csv -d $P/decode_fetch -- $B --steps 1 --compress-frames 0

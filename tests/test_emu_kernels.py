@@ -383,7 +383,11 @@ def test_several_block_search_with_an_understated_size_hint(emu, oracle, corpus)
 
 
 @pytest.mark.parametrize("defines", [["-DZP_K2_LANEWISE", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANEWISE", "-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=4"],
-                                     ["-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"]])
+                                     ["-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"],
+                                     # round 4's forms (measured slower or neutral on the MI355X, kept selectable -- DESIGN.md 4.1): K3 with own-lane items up to 32
+                                     # bytes + sequential in-batch matches, the lean K1b; the same K3 staging with dependency rounds, the two-level K1b;
+                                     # round 3's K3 with need-masks from the 16-byte cell map and wave-level fences
+                                     ["-DZP_K3_R4", "-DZP_K1B_R4A"], ["-DZP_K3_R4", "-DZP_K3_ROUNDS", "-DZP_K1B_R4B"], ["-DZP_K3_NEED_CELLS", "-DZP_K3_LIGHT_SYNC"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
     """the A/B shapes decode the same bytes: K2's lane-per-frame form of rounds 1-2 (ZHIP_K2_QUAD=0 in the product; -DZP_K2_LANEWISE selects it
     under emulation) with 60 / 15 frames per wave, the quad form with fewer frames per wave, K1b with 16 / 4 frames per wave, K3 with a smaller
