@@ -360,9 +360,17 @@ ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize,
     } else {
         used = 1 + hb;
         if (used > srcSize || hb < 2) return -ZE_CORRUPTION;
+        // Round 4: the description (< 128 bytes) is copied to LDS by the whole wave and lane 0 parses THAT. Parsed in place, every field of the
+        // distribution and every refill of the weights' bit reader below was a dependent global-memory round trip (~300 of them per frame with
+        // the three sequence tables, ~500 cycles each): K1's time is frames per resident wave x the latency of ONE frame's chain (210 K cycles).
+        // The staging area is the upper half of the union: free until zd_build_huf writes the table (wfse / symAt lie in its first 2.5 KiB).
+        uint8_t* const stg = (uint8_t*)L.u.huf + 4096;
+        zh_sync();
+        zd_stage_wave(stg, src + 1, hb);
+        zh_sync();
         if (lane == 0) {
             uint32_t maxS = 255 > 63 ? 63 : 255, tl = 0;     // weights alphabet is 0..12; 63 is plenty
-            int r = zd_read_ncount(L, src + 1, src + 1 + hb, &maxS, &tl);
+            int r = zd_read_ncount(L, stg, stg + hb, &maxS, &tl);
             L.misc[0] = (uint32_t)r; L.misc[1] = maxS; L.misc[2] = tl;
         }
         zh_sync();
@@ -371,7 +379,7 @@ ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize,
         if (zd_build_fse(L, L.u.b.wfse, maxS, tl, ZD_KIND_W) < 0) return -ZE_CORRUPTION;
         if (lane == 0) {
             ZdBits b; uint32_t cnt = 0; int bad = 0;
-            if (!zd_bits_init(b, src + 1 + r, hb - (uint32_t)r)) bad = 1;
+            if (!zd_bits_init(b, stg + r, hb - (uint32_t)r)) bad = 1;
             else {
                 // two interleaved states; stop when the stream over-reads (RFC 8878 4.2.1.2)
                 zd_bits_reload(b);

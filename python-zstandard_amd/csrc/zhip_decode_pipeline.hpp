@@ -140,9 +140,18 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
                 if (((modes >> 2) & 3) == 3) { for (uint32_t k = lane; k < (1u << de->mlLog); k += 64) L.fse[ZD_FSE_ML + k] = T[ZD_FSE_ML + k]; st.mlLog = de->mlLog; }
                 zh_sync();
             }
-            int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, sp, send); if (q < 0) return -q; sp += q;
-            q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, sp, send); if (q < 0) return -q; sp += q;
-            q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, sp, send); if (q < 0) return -q; sp += q;
+            // (round 4: the three table descriptions -- at most ~150 bytes together, the format bounds them -- are parsed from an LDS copy: in
+            // place every field was a dependent global-memory round trip of lane 0, zd_read_huf_weights has the arithmetic. The upper half of the
+            // union is free here: the Huffman table has left for the table arena, zd_build_fse uses symAt in the lower half)
+            const uint32_t hn = (uint32_t)(send - sp) < 256u ? (uint32_t)(send - sp) : 256u;
+            uint8_t* const stg = (uint8_t*)L.u.huf + 4096;
+            zh_sync();
+            zd_stage_wave(stg, sp, hn);
+            zh_sync();
+            const uint8_t* lp = stg; const uint8_t* const lend = stg + hn;
+            int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
+            q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
+            q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
             if (sp >= send) return ZE_CORRUPTION;
             zh_sync();
             // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
