@@ -153,19 +153,23 @@ ZH_DEV void zd_fence() { zhemu::collective_wait(); }   // emulated lanes are not
 
 // ------------------------------------------------------------------------------------------ FSE tables
 // forward bit reader used only by lane 0 for table descriptions (a few dozen bytes)
-struct ZdFwd { const uint8_t* p; const uint8_t* end; uint32_t bitpos; };
-ZH_DEV uint32_t zd_fwd_peek(const ZdFwd& f, uint32_t n)
+// (round 4: the reader keeps the 8 bytes around its cursor in registers and loads again only when a field would run past them -- every ~5
+// fields instead of one or two loads per field: the parse is a serial chain of lane 0 and K1's time is the latency of that chain)
+struct ZdFwd { const uint8_t* p; const uint8_t* end; uint32_t bitpos; uint64_t w; uint32_t wbit; };      // w = the 8 bytes at bit offset wbit (a multiple of 8)
+ZH_DEV void zd_fwd_init(ZdFwd& f, const uint8_t* p, const uint8_t* end) { f.p = p; f.end = end; f.bitpos = 0; f.wbit = 0; f.w = zd_ld64_bounded(p, end); }
+ZH_DEV uint32_t zd_fwd_peek(ZdFwd& f, uint32_t n)                     // n <= 16
 {
-    uint64_t v = zd_ld64_bounded(f.p + (f.bitpos >> 3), f.end);
-    return (uint32_t)((v >> (f.bitpos & 7)) & ((1ull << n) - 1));
+    uint32_t off = f.bitpos - f.wbit;
+    if (off + n > 64) { f.wbit = f.bitpos & ~7u; f.w = zd_ld64_bounded(f.p + (f.wbit >> 3), f.end); off = f.bitpos - f.wbit; }
+    return (uint32_t)(f.w >> off) & ((1u << n) - 1);
 }
 
 // lane 0 only. Parses an FSE distribution (RFC 8878 4.1.1) into L.norm[]. Returns bytes used or -err.
 // *pMax in: alphabet limit, out: last symbol present. *pLog out.
 ZH_DEVFN int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, uint32_t* pMax, uint32_t* pLog)
 {
-    ZdFwd f = { src, end, 0 };
     if (src >= end) return -ZE_SRC_SIZE_WRONG;
+    ZdFwd f; zd_fwd_init(f, src, end);
     uint32_t srcBits = (uint32_t)(end - src) * 8;
     int al = (int)zd_fwd_peek(f, 4) + 5; f.bitpos += 4;
     if (al > 15) return -ZE_TABLELOG_TOO_LARGE;
@@ -388,7 +392,7 @@ ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize,
                 if (tl == 0) { s1 = s2 = 0; }
                 int64_t left;   // bits still unread (may go negative)
                 for (;;) {
-                    zd_bits_reload(b);
+                    if (b.used >= 32) zd_bits_reload(b);            // (two weights take at most 12 bits: a refill every few trips, not a load in each)
                     left = (int64_t)(b.ptr - b.start) * 8 + 64 - (int64_t)b.used;
                     uint32_t e1 = L.u.b.wfse[s1], nb1 = (e1 >> 10) & 15;
                     if (cnt > 253) { bad = 1; break; }
