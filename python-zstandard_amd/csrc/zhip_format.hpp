@@ -129,6 +129,10 @@ struct ZhipEncodeArgs {
     uint64_t* mbSeqs;               // count x mbSeqCap packed sequences, block after block
     uint32_t mbMaxBlocks, mbSeqCap;
     uint32_t mbLanes;               // sources per wave of the several-block flat search (<= 64)
+    // the link form of the double-fast search (null / 0: the table form): one 8-byte record per source position, written by the pre-pass
+    uint8_t* linkRecs;              // count x linkStride
+    uint32_t linkStride;            // bytes per frame (8 x the largest source of the chunk, rounded)
+    uint32_t linkLanes;             // frames per wave of the link search (<= 64)
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;

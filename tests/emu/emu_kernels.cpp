@@ -233,6 +233,10 @@ static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds
 static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
+static void lpre_lane(void* p) { ze_links_pre_lane_body(*(const ZhipEncodeArgs*)p); }
+static void e1k_lane(void* p) { ze_match_links_body(*(const ZhipEncodeArgs*)p); }
+static uint32_t g_links = 0;                    // double-fast batches without dictionary: 0 the table form, 1 the link form with the plain pre-pass, 2 with the LDS pre-pass
+extern "C" void emu_set_links(uint32_t v) { g_links = v; }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
 extern "C" void emu_set_mb_compress(uint32_t v) { g_mbCompress = v; }
 static uint32_t g_dictSlotMax = 0;              // != 0: ZhipEncodeArgs.slotSrcMax of dictionary batches (sources above it are the generic kernel's)
@@ -290,10 +294,17 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
         a.mbBlocks = (ZeMbBlock*)malloc((size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); a.mbCount = (uint32_t*)malloc((size_t)chunk * 4); a.mbSeqs = (uint64_t*)malloc((size_t)chunk * a.mbSeqCap * 8);
         memset(a.mbBlocks, 0xA5, (size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); memset(a.mbCount, 0xA5, (size_t)chunk * 4);
     }
+    const bool links = flat && !flatDict && !mbc && g_links;
+    if (links) { a.linkStride = ZL_REC_BYTES * ZF_BLOCK_MAX; a.linkLanes = 16; a.linkRecs = (uint8_t*)malloc((size_t)chunk * a.linkStride); }
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0; e1Count = 0;
-        if (flat) {
+        if (links) {
+            memset(a.flatTables, 0, (size_t)a.count * a.tableStride); memset(a.linkRecs, 0xA5, (size_t)a.count * a.linkStride);
+            zhemu::run_grid((a.count + 63) / 64, lpre_lane, &a);
+            zhemu::run_grid((a.count + a.linkLanes - 1) / a.linkLanes, e1k_lane, &a);
+        }
+        else if (flat) {
             memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
@@ -311,6 +322,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             bigCount = 0;
         }
     }
+    free(a.linkRecs);
     free(a.e1List); free(a.flatTables); free(a.mbBlocks); free(a.mbCount); free(a.mbSeqs);
     if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
         ZhipEncodeArgs b = a; uint32_t bc = 0;

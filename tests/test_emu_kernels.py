@@ -140,17 +140,11 @@ def test_emulated_multiblock_encode_matches_golden(emu):
             assert len(o) == want["size"] and hashlib.sha256(o).hexdigest() == want["sha256"], (n, lvl)
 
 
-def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
-    """two-kernel form at level 3: the flat double-fast kernel (one lane per frame, tagged cells, two probes per trip, sequences
-    only) + the wave-parallel entropy kernel (literals gathered from the sequence list, 16-lane Huffman streams, 3-lane tANS
-    chains) against the oracle on inputs that reach every branch: long literal runs (> 63), long matches (> 130), far and
-    repeated offsets, matches that run into the end of the input, incompressible and single-byte inputs, tiny inputs that the
-    flat kernel hands to the lane-serial kernel (< 64 bytes), full 128 KiB blocks"""
-    import ctypes
+def _flat_search_inputs(corpus, seed=77, count=36):
     import numpy as np
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(seed)
     raws = []
-    for i in range(36):
+    for i in range(count):
         kind = i % 9
         n = int(rng.integers(64, 131073)) if i % 4 else int(rng.integers(1, 4000))
         if kind == 0: r = corpus.frame_bytes(int(rng.integers(0, 500)))[:n]
@@ -173,6 +167,18 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
             blk = rng.bytes(300); r = (blk + rng.bytes(40000) + blk * 3 + rng.bytes(50000) + blk)[:n]   # offsets beyond 64 KiB
         raws.append(r)
     raws += [corpus.frame_bytes(7), b"x" * 63, b"y" * 64, b"hello " * 11]
+    return raws
+
+
+def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
+    """two-kernel form at level 3: the flat double-fast kernel (one lane per frame, tagged cells, two probes per trip, sequences
+    only) + the wave-parallel entropy kernel (literals gathered from the sequence list, 16-lane Huffman streams, 3-lane tANS
+    chains) against the oracle on inputs that reach every branch: long literal runs (> 63), long matches (> 130), far and
+    repeated offsets, matches that run into the end of the input, incompressible and single-byte inputs, tiny inputs that the
+    flat kernel hands to the lane-serial kernel (< 64 bytes), full 128 KiB blocks"""
+    import ctypes
+    import numpy as np
+    raws = _flat_search_inputs(corpus)
     emu.lib.emu_stat.restype = ctypes.c_long
     before = emu.lib.emu_stat(15)
     for flags in (5, 7):
@@ -199,6 +205,27 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
         assert not any(st) and all(o == oracle.compress(r, level=3, flags=5) for r, o in zip(raws, outs))
     finally:
         emu.lib.emu_set_e1lds_max(0); emu.lib.emu_set_e1lds_bytes(131072)
+
+
+def test_emulated_link_form_of_the_double_fast_search(emu, oracle, corpus):
+    """The double-fast search without hash tables (ze_dfast_links, round 4): a pre-pass links every position to the nearest earlier one
+    with the same long / short hash, the search follows the links to the first position it has flagged as written. Same inputs as the
+    flat kernel's test (every branch: repeat offsets, long / short / long-at-the-next-position matches, catch-up, matches into the end
+    of the source, runs, tiny inputs handed to the lane-serial kernel), same frames as the oracle's table search, byte for byte."""
+    import ctypes
+    raws = _flat_search_inputs(corpus) + _flat_search_inputs(corpus, seed=5, count=18)
+    emu.lib.emu_stat.restype = ctypes.c_long
+    emu.lib.emu_set_links(1)
+    try:
+        before = emu.lib.emu_stat(15)
+        for flags, chunk in ((5, 17), (7, 64)):
+            outs, st = emu.compress_batch(raws, level=3, flags=flags, n_blocks=3, pipeline=True, chunk=chunk)
+            assert not any(st)
+            for i, (r, o) in enumerate(zip(raws, outs)):
+                assert o == oracle.compress(r, level=3, flags=flags), (flags, i, len(r))
+        assert emu.lib.emu_stat(15) - before >= 2 * 45, "the link-form kernel did not take these frames"
+    finally:
+        emu.lib.emu_set_links(0)
 
 
 def test_computed_sequence_codes_match_the_format_tables(emu):
