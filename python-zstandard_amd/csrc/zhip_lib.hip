@@ -109,7 +109,10 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a) 
     ze_split_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }      // sources of several blocks (after the split kernel)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }
+// the double-fast search in its link form (round 4): the records' pre-pass, then the search that follows them (ze_dfast_links)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_links_pre_lane_kernel(ZhipEncodeArgs a) { ze_links_pre_lane_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_links_kernel(ZhipEncodeArgs a) { ze_match_links_body(a); }      // sources of several blocks (after the split kernel)
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 template <uint32_t BYTES> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
 {
@@ -284,7 +287,7 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-#define ZHIP_NTIMER 9
+#define ZHIP_NTIMER 11
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
     std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
@@ -299,7 +302,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
-    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
+    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs, encLinkRecs;
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
@@ -331,6 +334,7 @@ struct zhip_ctx {
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
         size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        int links = 0 /* the double-fast search's link form: 0 off, 1 with the plain pre-pass, 2 with the LDS pre-pass */; unsigned linkLanes = 16;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -340,7 +344,7 @@ struct zhip_ctx {
     size_t device_bytes() const
     {
         const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &encWorkspace, &encMeta, &encArena,
-                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
+                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &encLinkRecs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
         for (const DevBuf* b : all) n += b->cap;
@@ -375,6 +379,8 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_ESLOT_MIN")) { const long v = atol(e); if (v >= 2) k.eslotMin = (size_t)v; }
         if (const char* e = getenv("ZHIP_ESLOT_ITEMS")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.eslotItems = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
+        if (const char* e = getenv("ZHIP_E1LINKS")) { const long v = atol(e); if (v >= 0 && v <= 2) k.links = (int)v; }
+        if (const char* e = getenv("ZHIP_E1LINK_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.linkLanes = (unsigned)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
     zh_resolve_rows(&c->rows, 3, nullptr);
@@ -440,7 +446,8 @@ extern "C" const char* zhip_kernel_name(int k)
 {
     static const char* names[ZHIP_NTIMER] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
                                    "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
-                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel"};
+                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel",
+                                   "zhip_encode_links_pre_kernel", "zhip_encode_match_links_kernel"};
     return k >= 0 && k < ZHIP_NTIMER ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
@@ -1001,6 +1008,15 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes;
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
         }
+        // the link form (ZHIP_E1LINKS): 8 bytes of records per source position instead of -- with the LDS pre-pass -- the tables
+        const bool links = flat && !flatDict && !mbc && c->knob.links != 0 && S == 1;
+        if (links) {
+            const size_t hintL = c->srcMaxHint ? c->srcMaxHint : sizeHint ? sizeHint : (size_t)ZF_BLOCK_MAX;
+            size_t per = ZF_BLOCK_MAX; if (hintL < per) { per = 4096; while (per < hintL) per <<= 1; }
+            a.linkStride = (uint32_t)(per * ZL_REC_BYTES); a.linkLanes = c->knob.linkLanes;
+            if (c->encLinkRecs.reserve(cap * (size_t)a.linkStride)) return g_reserveRc;
+            a.linkRecs = (uint8_t*)c->encLinkRecs.p;
+        }
         a.workspace = (uint8_t*)c->encWorkspace.p + slot * wsPer;
         a.meta = (ZeMeta*)c->encMeta.p + slot * cap; a.arena = (uint8_t*)c->encArena.p + slot * cap * (size_t)a.arenaStride; a.laneTables = (uint8_t*)c->encTables.p + slot * tabPer;
         uint8_t* const flatTables = flat ? (uint8_t*)c->encFlatTables.p + slot * cap * (size_t)a.tableStride : nullptr;
@@ -1019,7 +1035,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream));
             HIP_TRY(hipMemsetAsync(cbase + 32, 0, 4, stream));
             const bool tm = c->timing;
-            hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evL[3] = {nullptr, nullptr, nullptr}; bool usedLinks = false;
             if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
                 if (!flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
@@ -1039,6 +1055,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     else if (shape == 2) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<65536>, g, b, 0, stream, a);
                     else hipLaunchKernelGGL(zhip_encode_match_lds_kernel<ZF_BLOCK_MAX>, g, b, 0, stream, a);
                 }
+                else if (links) {
+                    if (tm) { for (int q = 0; q < 3; q++) HIP_TRY(hipEventCreate(&evL[q])); HIP_TRY(hipEventRecord(evL[0], stream)); }
+                    hipLaunchKernelGGL(zhip_encode_links_pre_lane_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, stream, a);
+                    if (tm) { HIP_TRY(hipEventRecord(evL[1], stream)); HIP_TRY(hipEventRecord(evL[2], stream)); }
+                    hipLaunchKernelGGL(zhip_encode_match_links_kernel, dim3((uint32_t)((cnt + a.linkLanes - 1) / a.linkLanes)), dim3(64), 0, stream, a);
+                    usedLinks = true;
+                }
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -1057,7 +1080,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             }
             HIP_TRY(hipGetLastError());
             if (tm) {
-                if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
+                if (flat && usedLinks) { c->timer[9].pending.emplace_back(evL[0], evL[1]); c->timer[10].pending.emplace_back(evL[2], ev[1]); (void)hipEventDestroy(ev[0]); }
+                else if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
                 else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
                 c->timer[5].pending.emplace_back(ev[2], ev[3]);
                 c->timer[6].pending.emplace_back(ev[4], ev[5]);

@@ -244,3 +244,39 @@ def test_host_pipeline_compress_chunk_slots(zstd, corpus):
     want = [ref.compress(r, level=3) for r in raws]
     assert box[0] == want and box[1] == want
     assert box["l1"] == [ref.compress(r, level=1) for r in raws]
+
+
+def test_link_form_of_the_double_fast_search(zstd, corpus):
+    """(off by default, ZHIP_E1LINKS=1 turns it on) the double-fast search without hash tables -- a pre-pass links every position to the nearest
+    earlier one with the same long / short hash, the search follows the links to the first position it has flagged as written (ze_dfast_links,
+    DESIGN 4.2, round 4). Kept as the record of a measured experiment; its frames must be libzstd's, byte for byte. ZHIP_E1LDS_MAX=0 keeps the
+    small-batch LDS kernel out of the way so that this batch takes the big-batch path (read when a thread's context is created: fresh thread)."""
+    import os
+    import threading
+    from tests import reflib
+    ref = reflib.checker()
+    rng = np.random.default_rng(5)
+    raws = []
+    for i in range(300):
+        n = int(rng.choice([63, 64, 100, 4096, 30000, 131071, 131072], p=[0.02, 0.02, 0.06, 0.2, 0.2, 0.1, 0.4]))
+        kind = i % 6
+        r = (corpus.frame_bytes(i)[:n] if kind < 3 else rng.bytes(n) if kind == 3 else bytes(rng.integers(0, 3, n, dtype=np.uint8)) if kind == 4
+             else (rng.bytes(int(rng.integers(1, 900))) * (n + 1))[:n])
+        raws.append(r)
+    box = {}
+
+    def run():
+        try:
+            res = zstd.ZstdCompressor(level=3).multi_compress_to_buffer(raws)
+            box["out"] = [res[i].tobytes() for i in range(len(raws))]
+        except Exception as e:              # noqa: BLE001 -- reported by the assertion below
+            box["error"] = e
+
+    os.environ["ZHIP_E1LINKS"] = "1"; os.environ["ZHIP_E1LDS_MAX"] = "0"
+    try:
+        t = threading.Thread(target=run); t.start(); t.join()
+    finally:
+        del os.environ["ZHIP_E1LINKS"]; del os.environ["ZHIP_E1LDS_MAX"]
+    assert "error" not in box, box.get("error")
+    for i, r in enumerate(raws):
+        assert box["out"][i] == ref.compress(r, level=3), (i, len(r))
