@@ -641,6 +641,10 @@ def bench_frames(args, config, rank, world, dev):
     nsample = min(F, 16384)
 
     if config == "compress":
+        if os.environ.get("ZHIP_BENCH_PREFRAG"):                    # experiment toggle (DESIGN 4.2, E1f's two regimes): VRAM the size of the decode arenas allocated and released first
+            junk = [torch.empty(int(g) << 30, dtype=torch.uint8, device=dev) for g in os.environ["ZHIP_BENCH_PREFRAG"].split(",")]
+            for t in junk: t.fill_(1)
+            torch.cuda.synchronize(); del junk, t; torch.cuda.empty_cache()
         elapsed, ctot2, ktimes = run_compress(job, ctx, raw, frames, FRAME, args.steps, args.warmup)
         ms = elapsed / args.steps * 1e3
         cfg["workload"] = "multi_compress_to_buffer (device-resident): %d x 128 KiB Silesia-like inputs per GPU, level 3" % F
@@ -693,7 +697,10 @@ def bench_frames(args, config, rank, world, dev):
         # the other half of BASELINE.json's metric, on the same inputs (the timed decompress region above is over). The compressor is
         # its own object in the reference API: release the decode direction's working set and start from a fresh context
         Fc = min(F, args.compress_frames)
-        ctx.close()
+        if os.environ.get("ZHIP_BENCH_KEEP_DECODE_CTX"):           # experiment toggle (DESIGN 4.2, E1f's two regimes): the tables come from VRAM the decode arenas never used
+            keep_ctx = ctx
+        else:
+            ctx.close()
         torch.cuda.empty_cache()
         ctx = DeviceBatchContext()
         c_elapsed, c_total, c_k = run_compress(job, ctx, raw[:Fc], frames[:Fc], FRAME, 3, 2)

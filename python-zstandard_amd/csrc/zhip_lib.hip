@@ -274,18 +274,58 @@ static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed 
 // wraps)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    bool contiguous = false;       // experiment (r04v): ask for physically contiguous memory (hipDeviceMallocContiguous); falls back to hipMalloc where that is refused
+    // chunkBytes != 0: a reserved address range backed by separately created physical chunks of that size (hipMemCreate / hipMemMap) instead of
+    // one hipMalloc. For memory that is accessed at RANDOM by a whole chunk of frames -- the flat match kernel's hash tables -- this is worth
+    // 29 % of the access rate on the MI355X (tests/ubench/allocbench, profiles/r04x_allocbench.txt: 25.9 against 20.1 G cells/s for chunks of
+    // 2 - 64 MiB, 23.6 for 1 GiB chunks; hipMalloc's memory behaves like the largest chunks whether the VRAM is fresh, recycled or asked
+    // for as contiguous). Falls back to hipMalloc where the virtual-memory calls are refused.
+    size_t chunkBytes = 0, mapped = 0;      // mapped != 0: p is such a range of `mapped` bytes
+    int map_chunks(size_t want)
+    {
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return -1;
+        hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        size_t gran = 0; if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return -1;
+        size_t chunk = (chunkBytes + gran - 1) / gran * gran;
+        const size_t nChunks = (want + chunk - 1) / chunk, total = nChunks * chunk;
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) return -1;
+        size_t done = 0; bool ok = true;
+        for (; done < nChunks && ok; done++) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
+            if (hipMemMap((char*)va + done * chunk, chunk, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
+            (void)hipMemRelease(h);                                   // the mapping keeps the chunk alive
+        }
+        if (ok) {
+            hipMemAccessDesc ad; memset(&ad, 0, sizeof ad); ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+            ok = hipMemSetAccess(va, total, &ad, 1) == hipSuccess;
+        }
+        if (!ok) { if (done) (void)hipMemUnmap(va, done * chunk); (void)hipMemAddressFree(va, total); (void)hipGetLastError(); return -1; }
+        p = va; cap = total; mapped = total; return 0;
+    }
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
         size_t want = n + (n >> 3) + 4096;
         if (want < n) { g_lastError = "allocation size overflow"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
+        if (chunkBytes && want >= chunkBytes && map_chunks(want) == 0) return 0;
+        if (contiguous) {
+            if (hipExtMallocWithFlags(&p, want, hipDeviceMallocContiguous) == hipSuccess) { cap = want; return 0; }
+            (void)hipGetLastError(); p = nullptr;
+        }
         const hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
         cap = want; return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p && mapped) { (void)hipMemUnmap(p, mapped); (void)hipMemAddressFree(p, mapped); }
+        else if (p) (void)hipFree(p);
+        p = nullptr; cap = 0; mapped = 0;
+    }
 };
 #define ZHIP_NTIMER 11
 struct KTimer {
@@ -379,6 +419,8 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_ESLOT_MIN")) { const long v = atol(e); if (v >= 2) k.eslotMin = (size_t)v; }
         if (const char* e = getenv("ZHIP_ESLOT_ITEMS")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.eslotItems = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
+        if (const char* e = getenv("ZHIP_TABLES_CONTIG")) c->encFlatTables.contiguous = atol(e) != 0;
+        if (const char* e = getenv("ZHIP_TABLES_VMM")) { const long v = atol(e); if (v >= 0 && v <= 4096) c->encFlatTables.chunkBytes = (size_t)v << 20; }      // MiB per physical chunk, 0 = one hipMalloc
         if (const char* e = getenv("ZHIP_E1LINKS")) { const long v = atol(e); if (v >= 0 && v <= 2) k.links = (int)v; }
         if (const char* e = getenv("ZHIP_E1LINK_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.linkLanes = (unsigned)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -428,7 +470,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->encLinkRecs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);

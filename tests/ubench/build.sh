@@ -3,4 +3,4 @@
 # lane-per-frame executor mock), tablebench (the flat match kernel's table traffic)
 set -e
 cd "$(dirname "$0")"
-for b in ubench membench tablebench; do ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -o $b $b.hip; done
+for b in ubench membench tablebench allocbench; do ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -o $b $b.hip; done
