@@ -373,7 +373,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
         int links = 0 /* the double-fast search's link form: 0 off, 1 with the plain pre-pass, 2 with the LDS pre-pass */; unsigned linkLanes = 16;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
@@ -404,6 +404,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         k.debugPipe = getenv("ZHIP_DEBUG_PIPE") != nullptr; k.watchdog = getenv("ZHIP_WATCHDOG") != nullptr; k.noFlat = getenv("ZHIP_NO_FLAT") != nullptr;
         if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) k.dchunk = (size_t)v; }
         if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) k.nslot = (int)v; }
+        if (const char* e = getenv("ZHIP_ECHUNK_MAX")) { const long v = atol(e); if (v >= 65536 && v <= 262144) k.echunkMax = (size_t)v; }
         if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
@@ -1006,8 +1007,20 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // (r03: dictionary batches whose dictionary row is double-fast take the flat kernel too -- ze_dfast_dict_flat; its waves zero the tables)
         const bool flatDict = c->hasCDict && c->cdictStrat == 2 && !c->knob.noFlat;
         const bool flat = (anyDfast && !c->hasCDict && !c->knob.noFlat) || flatDict;
-        size_t chunkMax = c->hasCDict ? 262144 : flat ? 65536 : 32768;
-        if (flat) { const size_t byMem = ((size_t)32 << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
+        // frames per launch of the flat match kernel: the search is a latency chain per frame, so its rate grows with the frames in flight -- 16 384: 204 ms,
+        // 32 768: 270, 65 536: 417, 131 072: 760 (r04za: 9 % less per frame than two launches of 65 536, a second wave per SIMD) -- and what it costs
+        // is memory, 384 KiB of tables + 196 KiB of arena per frame. Batches above 65 536 take 131 072 per launch where the device has that free.
+        size_t flatMax = c->knob.echunkMax;
+        if (!flatMax) {
+            flatMax = 65536;
+            size_t freeB = 0, totalB = 0;
+            if (flat && !c->hasCDict && n > 65536 && hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                const size_t need = (size_t)131072 * ((size_t)a.tableStride + (size_t)a.arenaStride) / 8 * 9 + ((size_t)4 << 30);
+                if (freeB + c->encFlatTables.cap + c->encArena.cap >= need) flatMax = 131072;
+            }
+        }
+        size_t chunkMax = c->hasCDict ? 262144 : flat ? flatMax : 32768;
+        if (flat) { const size_t byMem = ((size_t)(flatMax > 65536 ? 96 : 32) << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         // Sources of several blocks (the caller's size hint says so) in a double-fast batch without dictionary: the flat kernel searches them
         // too, a lane per frame over all its blocks (ZeMbBlock, zhip_format.hpp); the generic kernel then only does their entropy coding and
