@@ -1234,6 +1234,198 @@ ZH_DEV uint32_t ze_dfast_flat_t(uint64_t* seqs, const uint8_t* src, uint32_t bs,
     }
     return nseq;
 }
+// The same search with NP probes per trip (NP = 4): for batches that are bound by a source's serial chain rather than by the memory system -- one-shot
+// calls and small batches in the LDS-source kernel, a few thousand sources in the flat kernel -- a trip's three memory rounds are what a probe
+// costs, and four probes in five fail: with four consecutive probes in flight a trip consumes 2.95 probes on average instead of 1.8, at twice the loads
+// (most of them dropped), which is why large batches -- bound by transactions -- keep two. The order of table reads and writes is the reference's:
+// probe k's cell reads see the writes of the probes before it in the trip through forwarding selects, probe k's writes happen only if every probe
+// before it failed. BLK as in ze_dfast_flat_t.
+template <int PB, bool BLK, int NP>
+ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle)
+{
+    constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
+#undef ZE_CELL_IDX
+#define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
+    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
+    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
+    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
+    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
+#define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))
+#define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))
+#define ZE_TL(ph) ((((ph) >> (shL - TB)) & TM) << PB)
+#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB)
+    const uint32_t ilimit = be - 8, srcSize = be;
+    uint32_t ip = BLK ? bs + (bs == 0 ? 1u : 0u) : 1u, anchor = BLK ? bs : 0u, off1 = 1, off2 = 0, nseq = 0;
+    uint32_t saved1 = 0, saved2 = 0;
+    if (BLK) {                                                        // as ze_dfast_flat_t: one block [bs, be) of a larger frame, repeat offsets in and out
+        off1 = rep[0]; off2 = rep[1];
+        if (off2 > ip) { saved2 = off2; off2 = 0; }
+        if (off1 > ip) { saved1 = off1; off1 = 0; }
+        if (be < bs + 8) { return 0; }
+    }
+    uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
+    bool fresh = true;
+    for (;;) {
+        if (fresh) { step = 1; nextStep = ip + 256; }
+        // the trip's positions: probe k at pos[k], with the step a failed probe k - 1 leaves behind (zstd.c:31207); pos[NP] is where the search goes on
+        uint32_t pos[NP + 1], st[NP + 1], nx[NP + 1];
+        pos[0] = ip; st[0] = step; nx[0] = nextStep;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            pos[k + 1] = pos[k] + st[k]; st[k + 1] = st[k]; nx[k + 1] = nx[k];
+            if (pos[k + 1] >= nx[k]) { st[k + 1]++; nx[k + 1] += 256; }
+        }
+        if (pos[1] > ilimit) break;
+        // R = the probes of this trip that are real if all before them fail: probe k needs pos[k + 1] <= ilimit (the reference's loop condition)
+        uint32_t R = 1;
+#pragma unroll
+        for (int k = 1; k < NP; k++) if (R == (uint32_t)k && pos[k + 1] <= ilimit) R = (uint32_t)k + 1;
+        ZE_STAT(10);
+        // round 0: the probes' own bytes (positions beyond the last real one read the last valid position: ignored)
+        uint64_t w[NP + 1]; uint32_t rp[NP], pL[NP + 1], hl[NP + 1], hs[NP];
+#pragma unroll
+        for (int k = 0; k <= NP; k++) { const uint32_t q = pos[k] <= ilimit ? pos[k] : ilimit; w[k] = zh_ld64(src + q); }
+#pragma unroll
+        for (int k = 0; k < NP; k++) { const uint32_t q = pos[k] <= ilimit ? pos[k] : ilimit; rp[k] = zh_ld32(src + q + 1 - off1); }
+#pragma unroll
+        for (int k = 0; k <= NP; k++) { pL[k] = ZE_PL(w[k]); hl[k] = pL[k] >> shL; }
+#pragma unroll
+        for (int k = 0; k < NP; k++) hs[k] = ZE_PS(w[k]) >> shS;
+        // round 1: the table cells, all in flight together. The long cell of probe 0 was read one trip earlier unless the trip is fresh.
+        uint32_t cL[NP + 1], cS[NP], newL[NP + 1], newS[NP];
+        const uint32_t tA = hashLong[fresh ? hl[0] : hl[1]];
+#pragma unroll
+        for (int k = 0; k < NP; k++) cS[k] = hashSmall[hs[k]];
+#pragma unroll
+        for (int k = 1; k <= NP; k++) cL[k] = hashLong[hl[k]];
+        if (fresh) cellL0 = tA;
+        cL[0] = cellL0;
+#pragma unroll
+        for (int k = 0; k <= NP; k++) newL[k] = (pos[k] + 2) | ZE_TL(pL[k]);
+#pragma unroll
+        for (int k = 0; k < NP; k++) newS[k] = (pos[k] + 2) | ZE_TS(w[k]);
+        // what the reference's later reads see after its earlier writes of this trip (zstd.c:31121 then :31163): the latest earlier probe with the same cell wins
+#pragma unroll
+        for (int k = 1; k <= NP; k++) {
+#pragma unroll
+            for (int j = 0; j < k; j++) {
+                if (hl[k] == hl[j]) cL[k] = newL[j];
+                if (k < NP && hs[k < NP ? k : 0] == hs[j]) cS[k < NP ? k : 0] = newS[j];
+            }
+        }
+        hashLong[hl[0]] = newL[0]; hashSmall[hs[0]] = newS[0];
+        uint32_t idxl[NP + 1], idxs[NP], pl[NP + 1]; bool psv[NP];
+#pragma unroll
+        for (int k = 0; k <= NP; k++) { idxl[k] = ZE_CELL_IDX(cL[k]); pl[k] = (idxl[k] >= 2 && (cL[k] >> PB) == (ZE_TL(pL[k]) >> PB)) ? 1u : 0u; }
+#pragma unroll
+        for (int k = 0; k < NP; k++) { idxs[k] = ZE_CELL_IDX(cS[k]); psv[k] = idxs[k] >= 2 && (cS[k] >> PB) == (ZE_TS(w[k]) >> PB); }
+        if (!fresh) pl[0] = pl0;
+        // round 2: the bytes of the plausible candidates (the others read one address the whole wave shares)
+        uint64_t xl[NP + 1]; uint32_t cs[NP];
+#pragma unroll
+        for (int k = 0; k <= NP; k++) xl[k] = zh_ld64((pl[k] && (k > 0 || fresh)) ? src + (idxl[k] - 2) : idle);
+#pragma unroll
+        for (int k = 0; k < NP; k++) cs[k] = zh_ld32(psv[k] ? src + (idxs[k] - 2) : idle);
+#pragma unroll
+        for (int k = 0; k <= NP; k++) xl[k] = zh_opaque64(xl[k]);                 // no load sinks into a branch
+#pragma unroll
+        for (int k = 0; k < NP; k++) cs[k] = zh_opaque(cs[k]);
+        if (!fresh) xl[0] = cl0;
+        int fnd[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+            fnd[k] = (off1 > 0 && rp[k] == (uint32_t)(w[k] >> 8)) ? 1 : (pl[k] && xl[k] == w[k]) ? 2 : (psv[k] && cs[k] == (uint32_t)w[k]) ? 3 : 0;
+        uint32_t P = NP; int found = 0;                                            // the first real probe that matched
+#pragma unroll
+        for (int k = NP - 1; k >= 0; k--) if ((uint32_t)k < R && fnd[k]) { P = (uint32_t)k; found = fnd[k]; }
+        // the table writes of the probes that really happened: 1 .. P (a match at P) or 1 .. R - 1 (none), in the reference's order
+#pragma unroll
+        for (int k = 1; k < NP; k++) if ((uint32_t)k <= P && (uint32_t)k < R) { hashLong[hl[k]] = newL[k]; hashSmall[hs[k]] = newS[k]; }
+        if (found) {
+            ZE_STAT(11);
+            uint32_t ipP = pos[0], ipP1 = pos[1], stepP = st[0], idxlP = idxl[0], idxsP = idxs[0], idxl1 = idxl[1], pl1 = pl[1], hl1 = hl[1], newL1 = newL[1];
+            uint64_t w1 = w[1], cl1 = xl[1];
+#pragma unroll
+            for (int k = 1; k < NP; k++) if (P == (uint32_t)k) { ipP = pos[k]; ipP1 = pos[k + 1]; stepP = st[k]; idxlP = idxl[k]; idxsP = idxs[k]; idxl1 = idxl[k + 1]; pl1 = pl[k + 1]; hl1 = hl[k + 1]; newL1 = newL[k + 1]; w1 = w[k + 1]; cl1 = xl[k + 1]; }
+            uint32_t ipm = ipP, mpos = 0, ca, cb, add;
+            if (found == 1) { ipm = ipP + 1; ca = ipP + 5; cb = ipP + 5 - off1; add = 4; }
+            else if (found == 2) { mpos = idxlP - 2; ca = ipP + 8; cb = mpos + 8; add = 8; }
+            else { mpos = idxsP - 2; ca = ipP + 4; cb = mpos + 4; add = 4; }
+            uint32_t mLength = ze_count_fwd(src, ca, cb, srcSize) + add;
+            if (found == 3 && pl1 && idxl1 > 2 && cl1 == w1) {          // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
+                const uint32_t m1 = idxl1 - 2;
+                const uint32_t l1 = ze_count_fwd(src, ipP1 + 8, m1 + 8, srcSize) + 8;
+                if (l1 > mLength) { ipm = ipP1; mLength = l1; mpos = m1; }
+            }
+            uint32_t offBase = 1;
+            if (found >= 2) {
+                const uint32_t offset = ipm - mpos;
+                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204), 8 bytes a round
+                    ZE_STAT(13);
+                    const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
+                    if (mpos >= 8) {
+                        const uint64_t d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8);
+                        uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
+                        if (k > room) k = room;
+                        ipm -= k; mpos -= k; mLength += k;
+                        if (k < 8) break;
+                    } else {
+                        if (src[ipm - 1] != src[mpos - 1]) break;
+                        ipm--; mpos--; mLength++;
+                    }
+                }
+                off2 = off1; off1 = offset;
+                if (stepP < 4) hashLong[hl1] = newL1;
+                offBase = offset + 3;
+            }
+            seqs[nseq++] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
+            const uint32_t pI = ipP + 2;
+            ip = ipm + mLength; anchor = ip;
+            if (ip <= ilimit) {
+                const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
+                uint64_t wr = zh_ld64(src + ip); uint32_t r2 = zh_ld32(src + ip - off2);
+                const uint32_t qI = ZE_PL(wI), qE = ZE_PL(wE2);
+                hashLong[qI >> shL] = (pI + 2) | ZE_TL(qI);
+                hashLong[qE >> shL] = ip | ZE_TL(qE);
+                hashSmall[ZE_PS(wI) >> shS] = (pI + 2) | ZE_TS(wI);
+                hashSmall[ZE_PS(wE1) >> shS] = (ip + 1) | ZE_TS(wE1);
+                while (off2 > 0 && (uint32_t)wr == r2) {                // immediate repeat-offset matches (zstd.c:31236-31250)
+                    ZE_STAT(14);
+                    const uint32_t r = ze_count_fwd(src, ip + 4, ip + 4 - off2, srcSize) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    const uint32_t qr = ZE_PL(wr);
+                    hashSmall[ZE_PS(wr) >> shS] = (ip + 2) | ZE_TS(wr);
+                    hashLong[qr >> shL] = (ip + 2) | ZE_TL(qr);
+                    seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
+                    ip += r; anchor = ip;
+                    if (ip > ilimit) break;
+                    wr = zh_ld64(src + ip); r2 = zh_ld32(src + ip - off2);
+                }
+            }
+            fresh = true;
+        } else {                                                        // every real probe failed: go on from pos[R] with its long cell and candidate in hand
+            ip = pos[1]; step = st[1]; nextStep = nx[1]; cellL0 = cL[1]; pl0 = pl[1]; cl0 = xl[1];
+#pragma unroll
+            for (int k = 2; k <= NP; k++) if (R == (uint32_t)k) { ip = pos[k]; step = st[k]; nextStep = nx[k]; cellL0 = cL[k]; pl0 = pl[k]; cl0 = xl[k]; }
+            fresh = false;
+        }
+    }
+#undef ZE_PL
+#undef ZE_PS
+#undef ZE_TL
+#undef ZE_TS
+#undef ZE_CELL_IDX
+#define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
+    if (BLK) {                                                        // zstd.c:31252-31258
+        saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+        rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
+    }
+    return nseq;
+}
+ZH_DEV uint32_t ze_dfast_flat4(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
+{
+    return ze_dfast_flat_np<18, false, 4>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src);
+}
 ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
 {
     return ze_dfast_flat_t<18, false>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle);
@@ -3144,6 +3336,7 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
 
 // E1 flat: one lane per frame, statically assigned, every frame of the chunk in flight (ze_dfast_flat). Frames it does not cover are
 // listed for the lane-serial kernel above (chunk-local index) or, above one block, for the generic kernel.
+template <int NPROBE = 2>
 ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
 {
     const uint32_t lane = zh_lane();
@@ -3191,7 +3384,8 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
-                   : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
+                   : NPROBE == 4 ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src)
+                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;
@@ -3259,7 +3453,9 @@ ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
     for (uint32_t j = 0; j < nb; j++) {
         const uint32_t be = blk[j].end;
         // (blocks too small to compress are not searched at all: ZSTD_buildSeqStore, zstd.c:26335)
-        const uint32_t ns = be - bs < 7 ? 0u : ze_dfast_flat_t<ZE_MB_POS_BITS, true>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep);
+        const uint32_t ns = be - bs < 7 ? 0u
+                          : a.mbProbes == 4 ? ze_dfast_flat_np<ZE_MB_POS_BITS, true, 4>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep, a.src)
+                                            : ze_dfast_flat_t<ZE_MB_POS_BITS, true>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep);
         blk[j].seqStart = start; blk[j].nbSeq = ns; blk[j].rep0 = rep[0]; blk[j].rep1 = rep[1];
         start += ns; bs = be;
     }
@@ -3279,6 +3475,7 @@ ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
 // for more frames per CU (4 KiB: 32 waves, 16 KiB: 9, 64 KiB: 2, one block: 1). A source above the area (no size hint and a shape picked
 // too small cannot happen -- the host falls back to the one-block shape -- but the kernel does not rely on it) is searched in place.
 template <uint32_t BYTES> struct ZeSrcLDS { uint8_t b[BYTES + 64]; };
+template <int NPROBE = 2>
 ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t ldsBytes)
 {
     const uint32_t lane = zh_lane();
@@ -3315,6 +3512,10 @@ ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t 
     // stretch every 4.5 probes on the bench corpus and the one-lane search already takes two probes per round trip, so the wave form saves
     // little more than half the round trips and pays shuffles, ballots and a wave-wide match extension for each.)
     if (lane != 0) return;
+    if (NPROBE == 4)
+        m.nbSeq = staged ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
+                         : ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
+    else
     m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
                      : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
     m.mode = 4;

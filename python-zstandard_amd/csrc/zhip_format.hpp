@@ -129,6 +129,7 @@ struct ZhipEncodeArgs {
     uint64_t* mbSeqs;               // count x mbSeqCap packed sequences, block after block
     uint32_t mbMaxBlocks, mbSeqCap;
     uint32_t mbLanes;               // sources per wave of the several-block flat search (<= 64)
+    uint32_t mbProbes;              // probes per trip of that search: 2, or 4 for batches bound by a source's serial chain (ze_dfast_flat_np)
     // the link form of the double-fast search (null / 0: the table form): one 8-byte record per source position, written by the pre-pass
     uint8_t* linkRecs;              // count x linkStride
     uint32_t linkStride;            // bytes per frame (8 x the largest source of the chunk, rounded)

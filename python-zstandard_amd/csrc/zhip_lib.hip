@@ -108,16 +108,18 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a) 
     __shared__ ZeLDS L;
     ze_split_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
+// four probes per trip: chunks small enough to be bound by a source's serial chain rather than by the memory system (ze_dfast_flat_np)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }
 // the double-fast search in its link form (round 4): the records' pre-pass, then the search that follows them (ze_dfast_links)
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_links_pre_lane_kernel(ZhipEncodeArgs a) { ze_links_pre_lane_body(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_links_kernel(ZhipEncodeArgs a) { ze_match_links_body(a); }      // sources of several blocks (after the split kernel)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_links_kernel(ZhipEncodeArgs a) { ze_match_links_body(a); }
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
-template <uint32_t BYTES> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
+template <uint32_t BYTES, int NPROBE> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
 {
     __shared__ ZeSrcLDS<BYTES> L;
-    ze_match_lds_body(a, L.b, BYTES);
+    ze_match_lds_body<NPROBE>(a, L.b, BYTES);
 }
 #ifndef ZE_E2_MINWAVES
 #define ZE_E2_MINWAVES 4
@@ -374,6 +376,10 @@ struct zhip_ctx {
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
         size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
+        // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
+        // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
+        int e1lProbes = 2; size_t flat4Max = 32768;
         int links = 0 /* the double-fast search's link form: 0 off, 1 with the plain pre-pass, 2 with the LDS pre-pass */; unsigned linkLanes = 16;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
@@ -422,6 +428,8 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_TABLES_CONTIG")) c->encFlatTables.contiguous = atol(e) != 0;
         if (const char* e = getenv("ZHIP_TABLES_VMM")) { const long v = atol(e); if (v >= 0 && v <= 4096) c->encFlatTables.chunkBytes = (size_t)v << 20; }      // MiB per physical chunk, 0 = one hipMalloc
+        if (const char* e = getenv("ZHIP_E1L_PROBES")) { const long v = atol(e); if (v == 2 || v == 4) k.e1lProbes = (int)v; }
+        if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_E1LINKS")) { const long v = atol(e); if (v >= 0 && v <= 2) k.links = (int)v; }
         if (const char* e = getenv("ZHIP_E1LINK_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.linkLanes = (unsigned)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -1060,7 +1068,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
                 c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
             a.mbBlocks = (ZeMbBlock*)c->encMbBlocks.p; a.mbCount = (uint32_t*)c->encMbCount.p; a.mbSeqs = (uint64_t*)c->encMbSeqs.p;
-            a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes;
+            a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes; a.mbProbes = chunk <= c->knob.flat4Max ? 4u : 2u;
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
         }
         // the link form (ZHIP_E1LINKS): 8 bytes of records per source position instead of -- with the LDS pre-pass -- the tables
@@ -1105,10 +1113,17 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 if (mbc) hipLaunchKernelGGL(zhip_encode_split_kernel, dim3((uint32_t)(cnt < (size_t)c->numCU * 8 ? cnt : (size_t)c->numCU * 8)), dim3(64), 0, stream, a);
                 if (cnt <= ldsMax && !flatDict && !mbc) {
                     const dim3 g((uint32_t)cnt), b(64);
-                    if (shape == 0) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<4096>, g, b, 0, stream, a);
-                    else if (shape == 1) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<16384>, g, b, 0, stream, a);
-                    else if (shape == 2) hipLaunchKernelGGL(zhip_encode_match_lds_kernel<65536>, g, b, 0, stream, a);
-                    else hipLaunchKernelGGL(zhip_encode_match_lds_kernel<ZF_BLOCK_MAX>, g, b, 0, stream, a);
+                    if (c->knob.e1lProbes == 4) {
+                        if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 4>), g, b, 0, stream, a);
+                        else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 4>), g, b, 0, stream, a);
+                        else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 4>), g, b, 0, stream, a);
+                        else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 4>), g, b, 0, stream, a);
+                    } else {
+                        if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 2>), g, b, 0, stream, a);
+                        else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 2>), g, b, 0, stream, a);
+                        else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
+                        else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
+                    }
                 }
                 else if (links) {
                     if (tm) { for (int q = 0; q < 3; q++) HIP_TRY(hipEventCreate(&evL[q])); HIP_TRY(hipEventRecord(evL[0], stream)); }
@@ -1117,6 +1132,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     hipLaunchKernelGGL(zhip_encode_match_links_kernel, dim3((uint32_t)((cnt + a.linkLanes - 1) / a.linkLanes)), dim3(64), 0, stream, a);
                     usedLinks = true;
                 }
+                else if (!flatDict && !mbc && cnt <= c->knob.flat4Max) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));

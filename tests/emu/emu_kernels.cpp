@@ -230,7 +230,9 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 // ---- two-kernel encoder under emulation
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
-static void e1f_lane(void* p) { ze_match_flat_body(*(const ZhipEncodeArgs*)p); }
+static uint32_t g_probes = 2;                   // probes per trip of the flat search (2, or 4: the latency-bound batches' form)
+extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
+static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static void lpre_lane(void* p) { ze_links_pre_lane_body(*(const ZhipEncodeArgs*)p); }
@@ -245,7 +247,7 @@ static uint64_t g_mbHint = 0;                   // != 0: the several-block arena
 extern "C" void emu_set_mb_hint(uint64_t v) { g_mbHint = v; }
 static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
 static uint32_t g_e1LdsBytes = ZF_BLOCK_MAX;       // the LDS shape under emulation (the product picks it from the batch's largest source)
-static void e1l_lane(void* p) { ze_match_lds_body(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
+static void e1l_lane(void* p) { if (g_probes == 4) ze_match_lds_body<4>(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); else ze_match_lds_body<2>(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
 extern "C" void emu_set_e1lds_bytes(uint32_t v) { g_e1LdsBytes = v; }
 static uint32_t g_e1LdsMax = 0;                 // chunks of up to this many frames take the LDS-source match kernel (mirrors zhip_compress_batch_device's choice)
 extern "C" void emu_set_e1lds_max(uint32_t v) { g_e1LdsMax = v; }
@@ -309,7 +311,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
             else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
-            if (mbc) { a.mbLanes = 16; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
+            if (mbc) { a.mbLanes = 16; a.mbProbes = g_probes; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
         zhemu::run_grid(nBlocks, e2_lane, &a);

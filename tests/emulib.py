@@ -26,6 +26,8 @@ class Emu:
         if not os.path.exists(path):
             build()
         self.lib = C.CDLL(path)
+        if os.environ.get("ZHIP_EMU_PROBES"):                    # stress campaigns: the flat search at four probes per trip (the product's form for chunks up to 32 768 sources)
+            self.lib.emu_set_probes(C.c_uint32(int(os.environ["ZHIP_EMU_PROBES"])))
 
     def set_cparams(self, window_log=0, chain_log=0, hash_log=0, search_log=0, min_match=0, target_length=0, strategy=0, magicless=False):
         """explicit compression parameters / frame format of the following emulated launches (all zero / False = defaults)"""

@@ -228,6 +228,30 @@ def test_emulated_link_form_of_the_double_fast_search(emu, oracle, corpus):
         emu.lib.emu_set_links(0)
 
 
+def test_emulated_four_probe_flat_search(emu, oracle, corpus):
+    """The flat double-fast search with FOUR probes per trip (ze_dfast_flat_np, round 4: the form chunks of up to 32 768 sources take -- they are bound
+    by a source's serial chain, and a trip of four speculative probes consumes 2.95 of them on average instead of 1.8): the same inputs as the
+    two-probe kernel's test, through the flat kernel and through the LDS-source kernel, byte for byte the oracle's frames; and fewer trips."""
+    import ctypes
+    raws = _flat_search_inputs(corpus) + _flat_search_inputs(corpus, seed=11, count=27)
+    emu.lib.emu_stat.restype = ctypes.c_long
+    trips = {}
+    try:
+        for probes in (2, 4):
+            emu.lib.emu_set_probes(probes)
+            for ldsmax in (0, 64):
+                emu.lib.emu_set_e1lds_max(ldsmax)
+                t0 = emu.lib.emu_stat(10)
+                outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=3, pipeline=True, chunk=40)
+                assert not any(st)
+                for i, (r, o) in enumerate(zip(raws, outs)):
+                    assert o == oracle.compress(r, level=3, flags=5), (probes, ldsmax, i, len(r))
+                trips[(probes, ldsmax)] = emu.lib.emu_stat(10) - t0
+    finally:
+        emu.lib.emu_set_probes(2); emu.lib.emu_set_e1lds_max(0)
+    assert trips[(4, 0)] < 0.75 * trips[(2, 0)] and trips[(4, 64)] < 0.75 * trips[(2, 64)], trips
+
+
 def test_computed_sequence_codes_match_the_format_tables(emu):
     """the entropy kernel computes LL / ML codes and extra-bit counts instead of reading tables: every length up to one block"""
     assert emu.lib.emu_check_code_formulas() == 0
