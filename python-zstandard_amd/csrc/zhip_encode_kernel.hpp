@@ -1422,9 +1422,14 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
     }
     return nseq;
 }
+template <int NP>
+ZH_DEV uint32_t ze_dfast_flatn(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
+{
+    return ze_dfast_flat_np<18, false, NP>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src);
+}
 ZH_DEV uint32_t ze_dfast_flat4(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
 {
-    return ze_dfast_flat_np<18, false, 4>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src);
+    return ze_dfast_flatn<4>(seqs, src, srcSize, hlog, clog, mml, hashLong, hashSmall, idle);
 }
 ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
 {
@@ -3384,7 +3389,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
-                   : NPROBE == 4 ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src)
+                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src)
                                  : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
     m.mode = 4;
 #ifdef ZHIP_EMU

@@ -232,7 +232,7 @@ static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_probes = 2;                   // probes per trip of the flat search (2, or 4: the latency-bound batches' form)
 extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
-static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
+static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static void lpre_lane(void* p) { ze_links_pre_lane_body(*(const ZhipEncodeArgs*)p); }

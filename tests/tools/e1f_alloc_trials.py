@@ -36,7 +36,13 @@ src = raw.reshape(-1)
 first = None
 for r in range(rounds):
     for sname in settings:
-        os.environ["ZHIP_TABLES_VMM"] = sname
+        for k in ("ZHIP_TABLES_VMM", "ZHIP_FLAT3", "ZHIP_FLAT4_MAX"):
+            os.environ.pop(k, None)
+        if "=" in sname:                                              # NAME=VALUE[+NAME=VALUE]: any knob that is read when a context is created
+            for kv in sname.split("+"):
+                os.environ[kv.split("=")[0]] = kv.split("=")[1]
+        else:
+            os.environ["ZHIP_TABLES_VMM"] = sname
         ctx = dev_mod.DeviceBatchContext()
         ctx.compress(src, src_segs, dst, dst_segs, out_sizes, status)        # warm-up: allocations, first touch
         torch.cuda.synchronize()
@@ -49,6 +55,6 @@ for r in range(rounds):
         if first is None:
             first = total
         free, tot = torch.cuda.mem_get_info()
-        print("round %d  ZHIP_TABLES_VMM=%-4s  E1f %7.2f ms (%d launches)  compressed bytes %s  free VRAM %.1f GiB" % (r, sname, ms, n, "same" if total == first else "DIFFERENT", free / 2**30), flush=True)
+        print("round %d  %-22s  E1f %7.2f ms (%d launches)  compressed bytes %s  free VRAM %.1f GiB" % (r, sname if "=" in sname else "ZHIP_TABLES_VMM=" + sname, ms, n, "same" if total == first else "DIFFERENT", free / 2**30), flush=True)
         assert int(status.abs().max().item()) == 0
         ctx.close()
