@@ -380,7 +380,7 @@ struct zhip_ctx {
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
-        int e1lProbes = 2; size_t flat4Max = 32768; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
+        int e1lProbes = 2; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
         int links = 0 /* the double-fast search's link form: 0 off, 1 with the plain pre-pass, 2 with the LDS pre-pass */; unsigned linkLanes = 16;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
@@ -430,6 +430,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_TABLES_CONTIG")) c->encFlatTables.contiguous = atol(e) != 0;
         if (const char* e = getenv("ZHIP_TABLES_VMM")) { const long v = atol(e); if (v >= 0 && v <= 4096) c->encFlatTables.chunkBytes = (size_t)v << 20; }      // MiB per physical chunk, 0 = one hipMalloc
         if (const char* e = getenv("ZHIP_E1L_PROBES")) { const long v = atol(e); if (v == 2 || v == 4) k.e1lProbes = (int)v; }
+        if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
         if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_E1LINKS")) { const long v = atol(e); if (v >= 0 && v <= 2) k.links = (int)v; }
@@ -1135,7 +1136,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     usedLinks = true;
                 }
                 else if (!flatDict && !mbc && cnt <= c->knob.flat4Max) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
-                else if (!flatDict && !mbc && c->knob.flat3 && cnt <= 65536) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
+                else if (!flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));

@@ -16,9 +16,13 @@ os.makedirs(out_dir, exist_ok=True)
 
 
 def rows_of(sub, pattern):
+    """(the flat match kernel's three- and four-probe instantiations are reported under the kernel's one name, as the library's own timers do)"""
     for path in glob.glob(os.path.join(prof, sub, "**", pattern), recursive=True):
         with open(path, newline="") as fh:
-            yield from csv.DictReader(fh)
+            for r in csv.DictReader(fh):
+                if "Kernel_Name" in r:
+                    r["Kernel_Name"] = r["Kernel_Name"].replace("match_flat3_kernel", "match_flat_kernel").replace("match_flat4_kernel", "match_flat_kernel")
+                yield r
 
 
 traffic = collections.defaultdict(float)
