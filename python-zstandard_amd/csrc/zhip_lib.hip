@@ -1071,7 +1071,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
                 c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
             a.mbBlocks = (ZeMbBlock*)c->encMbBlocks.p; a.mbCount = (uint32_t*)c->encMbCount.p; a.mbSeqs = (uint64_t*)c->encMbSeqs.p;
-            a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes; a.mbProbes = chunk <= c->knob.flat4Max ? 4u : 2u;
+            a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes; a.mbProbes = chunk * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) <= c->knob.flat4Max ? 4u : 2u;        // (the traffic in flight is sources x blocks each: 16 384 x 256 KiB 7.9 -> 8.9 GB/s with four probes, 32 768 x 256 KiB 12.0 -> 11.8, r04zj)
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
         }
         // the link form (ZHIP_E1LINKS): 8 bytes of records per source position instead of -- with the LDS pre-pass -- the tables
