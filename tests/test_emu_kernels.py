@@ -747,10 +747,10 @@ def test_sources_of_several_blocks_in_the_flat_search(emu, ref, corpus):
     want = [ref.compress(r, level=3, flags=7) for r in raws]
     s0, r0 = emu.stat(8), emu.stat(9)
     try:
-        for slots, chunk in ((1, 0), (3, 4)):
-            emu.set_mb_compress(slots)
+        for slots, chunk, probes in ((1, 0, 2), (3, 4, 2), (1, 0, 4)):          # (four probes per trip: the form chunks of up to 32 768 block-sized pieces take)
+            emu.set_mb_compress(slots); emu.lib.emu_set_probes(probes)
             outs, st = emu.compress_batch(raws, level=3, flags=7, n_blocks=2, pipeline=True, chunk=chunk)
-            assert st == [0] * len(raws) and outs == want, (slots, st)
+            assert st == [0] * len(raws) and outs == want, (slots, probes, st)
     finally:
-        emu.set_mb_compress(1)
+        emu.set_mb_compress(1); emu.lib.emu_set_probes(2)
     assert emu.stat(8) - s0 >= 8 and emu.stat(9) - r0 >= 1          # most sources searched by the flat kernel, at least one redone
