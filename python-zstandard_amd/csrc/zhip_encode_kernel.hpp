@@ -1069,177 +1069,14 @@ ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_
 // PB = the position's bits in a cell (18: sources of one block; 22: frames of several blocks up to 4 MiB - 2, the tag then has 10 bits).
 // BLK = true searches ONE BLOCK [bs, be) of a larger frame -- tables as the blocks before left them, `rep` = the repeat offsets in and out
 // (ZSTD_compressBlock_doubleFast_noDict_generic's entry and _cleanup, zstd.c:31091-31098 / :31252-31258); false: a whole source [0, be).
-template <int PB, bool BLK>
-ZH_DEV uint32_t ze_dfast_flat_t(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle = nullptr)
-{
-    constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
-#undef ZE_CELL_IDX
-#define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
-    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
-    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
-    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
-    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
-#define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))                       /* long table: high half of the product */
-#define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))                            /* short table */
-#define ZE_TL(ph) ((((ph) >> (shL - TB)) & TM) << PB)                               /* tag = the TB product bits below the index */
-#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB)       /* tag over the first 4 bytes only */
-    const uint32_t ilimit = be - 8, srcSize = be;                     // (matches end with the block: ZSTD_count's iend)
-    uint32_t ip = BLK ? bs + (bs == 0 ? 1u : 0u) : 1u, anchor = BLK ? bs : 0u, off1 = 1, off2 = 0, nseq = 0;        // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
-    uint32_t saved1 = 0, saved2 = 0;
-    if (BLK) {                                                        // a repeat offset that reaches before the frame's first byte is parked for the block
-        off1 = rep[0]; off2 = rep[1];
-        if (off2 > ip) { saved2 = off2; off2 = 0; }
-        if (off1 > ip) { saved1 = off1; off1 = 0; }
-        if (be < bs + 8) { return 0; }                                // (nothing to search: the loop's bound check would wrap)
-    }
-    uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
-    bool fresh = true;
-    // Every trip examines TWO consecutive probe positions, A = ip and B = ip + step, in the same three memory rounds: four probes in
-    // five fail, and after a failed probe the next one is fully determined (its position, its step, and -- through the forwarding
-    // selects below -- the table state it must see), so B is probed speculatively and simply dropped when A matches. A's table
-    // writes always happen; B's only when A failed. This is the reference's sequential order, two steps at a time.
-    for (;;) {
-        if (fresh) { step = 1; nextStep = ip + 256; }
-        const uint32_t ipA = ip, ipB = ip + step;
-        if (ipB > ilimit) break;
-        uint32_t stepB = step, nextB = nextStep;
-        if (ipB >= nextStep) { stepB++; nextB += 256; }                 // the step update a failed probe at A makes (zstd.c:31207)
-        const uint32_t ipC = ipB + stepB;
-        const bool hasB = ipC <= ilimit;                                // B is probed only if the search goes on after A
-        const uint32_t ipCs = hasB ? ipC : ipB;
-        ZE_STAT(10);
-        // round 0: the probes' own bytes
-        const uint64_t wA = zh_ld64(src + ipA), wB = zh_ld64(src + ipB), wC = zh_ld64(src + ipCs);
-        const uint32_t rpA = zh_ld32(src + ipA + 1 - off1), rpB = zh_ld32(src + ipB + 1 - off1);
-        const uint32_t pLA = ZE_PL(wA), pLB = ZE_PL(wB), pLC = ZE_PL(wC);
-        const uint32_t hlA = pLA >> shL, hlB = pLB >> shL, hlC = pLC >> shL, hsA = ZE_PS(wA) >> shS, hsB = ZE_PS(wB) >> shS;
-        // round 1: the table cells, all in flight together (every load unconditional with an always-valid address, so the compiler
-        // keeps them in one straight line behind a single wait). The long cell of A was read one trip earlier unless A is fresh.
-        const uint32_t tA = hashLong[fresh ? hlA : hlB];
-        const uint32_t cSA = hashSmall[hsA];
-        uint32_t cSB = hashSmall[hsB], cLB = hashLong[hlB], cLC = hashLong[hlC];
-        if (fresh) cellL0 = tA;
-        const uint32_t newLA = (ipA + 2) | ZE_TL(pLA), newSA = (ipA + 2) | ZE_TS(wA), newLB = (ipB + 2) | ZE_TL(pLB), newSB = (ipB + 2) | ZE_TS(wB);
-        // what the reference's later reads would see after its earlier writes of this trip (zstd.c:31121 then :31163, twice)
-        if (hlB == hlA) cLB = newLA;
-        if (hsB == hsA) cSB = newSA;
-        if (hlC == hlA) cLC = newLA;
-        if (hlC == hlB) cLC = newLB;
-        hashLong[hlA] = newLA; hashSmall[hsA] = newSA;
-        const uint32_t idxl0 = ZE_CELL_IDX(cellL0), idxsA = ZE_CELL_IDX(cSA), idxlB = ZE_CELL_IDX(cLB), idxsB = ZE_CELL_IDX(cSB), idxlC = ZE_CELL_IDX(cLC);
-        // plausible = the cell is in use and carries the probe's tag
-        if (fresh) pl0 = (idxl0 >= 2 && (cellL0 >> PB) == (ZE_TL(pLA) >> PB)) ? 1u : 0u;
-        const bool psA = idxsA >= 2 && (cSA >> PB) == (ZE_TS(wA) >> PB);
-        const uint32_t plB = (idxlB >= 2 && (cLB >> PB) == (ZE_TL(pLB) >> PB)) ? 1u : 0u;
-        const bool psB = idxsB >= 2 && (cSB >> PB) == (ZE_TS(wB) >> PB);
-        const uint32_t plC = (idxlC >= 2 && (cLC >> PB) == (ZE_TL(pLC) >> PB)) ? 1u : 0u;
-        // round 2: the bytes of the plausible candidates (the others read the probe position itself: a cache hit, and ignored)
-        // (a candidate that is not plausible reads ONE address the whole wave shares -- `idle`, where the caller has one -- instead of the lane's own probe
-        // position: one line per instruction for the idle lanes instead of up to 64. r04zb: 421 / 418 -> 413 / 412 ms)
-        const uint8_t* const idA = idle ? idle : src + ipA; const uint8_t* const idB = idle ? idle : src + ipB; const uint8_t* const idC = idle ? idle : src + ipCs;
-        uint64_t xl0 = zh_ld64((fresh && pl0) ? src + (idxl0 - 2) : idA);
-        uint32_t csA = zh_ld32(psA ? src + (idxsA - 2) : idA);
-        uint64_t clB = zh_ld64(plB ? src + (idxlB - 2) : idB);
-        uint32_t csB = zh_ld32(psB ? src + (idxsB - 2) : idB);
-        uint64_t clC = zh_ld64(plC ? src + (idxlC - 2) : idC);
-        xl0 = zh_opaque64(xl0); csA = zh_opaque(csA); clB = zh_opaque64(clB); csB = zh_opaque(csB); clC = zh_opaque64(clC);   // no load sinks into a branch
-        if (fresh) cl0 = xl0;
-        const int foundA = (off1 > 0 && rpA == (uint32_t)(wA >> 8)) ? 1 : (pl0 && cl0 == wA) ? 2 : (psA && csA == (uint32_t)wA) ? 3 : 0;
-        const int foundB = !hasB ? 0 : (off1 > 0 && rpB == (uint32_t)(wB >> 8)) ? 1 : (plB && clB == wB) ? 2 : (psB && csB == (uint32_t)wB) ? 3 : 0;
-        const bool tookB = !foundA && hasB;                             // A failed and the search goes on: B is a real probe
-        if (tookB) { hashLong[hlB] = newLB; hashSmall[hsB] = newSB; }
-        const int found = foundA ? foundA : foundB;
-        if (found) {
-            ZE_STAT(11);
-            const bool atB = !foundA;
-            // the matching probe P, the position after it P1, and what was fetched for them
-            const uint32_t ipP = atB ? ipB : ipA, ipP1 = atB ? ipC : ipB, stepP = atB ? stepB : step;
-            const uint32_t idxlP = atB ? idxlB : idxl0, idxsP = atB ? idxsB : idxsA, idxl1 = atB ? idxlC : idxlB, pl1 = atB ? plC : plB;
-            const uint64_t w1 = atB ? wC : wB, cl1 = atB ? clC : clB;
-            const uint32_t hl1 = atB ? hlC : hlB, newL1 = atB ? ((ipC + 2) | ZE_TL(pLC)) : newLB;
-            uint32_t ipm = ipP, mpos = 0, ca, cb, add;
-            if (found == 1) { ipm = ipP + 1; ca = ipP + 5; cb = ipP + 5 - off1; add = 4; }
-            else if (found == 2) { mpos = idxlP - 2; ca = ipP + 8; cb = mpos + 8; add = 8; }
-            else { mpos = idxsP - 2; ca = ipP + 4; cb = mpos + 4; add = 4; }
-            uint32_t mLength = ze_count_fwd(src, ca, cb, srcSize) + add;
-            if (found == 3 && pl1 && idxl1 > 2 && cl1 == w1) {          // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
-                const uint32_t m1 = idxl1 - 2;
-                const uint32_t l1 = ze_count_fwd(src, ipP1 + 8, m1 + 8, srcSize) + 8;
-                if (l1 > mLength) { ipm = ipP1; mLength = l1; mpos = m1; }
-            }
-            uint32_t offBase = 1;
-            if (found >= 2) {
-                const uint32_t offset = ipm - mpos;
-                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204), 8 bytes a round
-                    ZE_STAT(13);
-                    const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
-                    if (mpos >= 8) {                                    // both 8-byte reads stay inside the frame; bytes beyond `room` are ignored
-                        const uint64_t d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8);
-                        uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
-                        if (k > room) k = room;
-                        ipm -= k; mpos -= k; mLength += k;
-                        if (k < 8) break;
-                    } else {
-                        if (src[ipm - 1] != src[mpos - 1]) break;
-                        ipm--; mpos--; mLength++;
-                    }
-                }
-                off2 = off1; off1 = offset;
-                if (stepP < 4) hashLong[hl1] = newL1;
-                offBase = offset + 3;
-            }
-            seqs[nseq++] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
-            const uint32_t pI = ipP + 2;                                // curr + 2 as a position
-            ip = ipm + mLength; anchor = ip;
-            if (ip <= ilimit) {
-                // one round for the insertions' bytes and the first repeat-offset test
-                const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
-                uint64_t wr = zh_ld64(src + ip); uint32_t r2 = zh_ld32(src + ip - off2);
-                const uint32_t qI = ZE_PL(wI), qE = ZE_PL(wE2);
-                hashLong[qI >> shL] = (pI + 2) | ZE_TL(qI);
-                hashLong[qE >> shL] = ip | ZE_TL(qE);
-                hashSmall[ZE_PS(wI) >> shS] = (pI + 2) | ZE_TS(wI);
-                hashSmall[ZE_PS(wE1) >> shS] = (ip + 1) | ZE_TS(wE1);
-                while (off2 > 0 && (uint32_t)wr == r2) {                // immediate repeat-offset matches (zstd.c:31236-31250)
-                    ZE_STAT(14);
-                    const uint32_t r = ze_count_fwd(src, ip + 4, ip + 4 - off2, srcSize) + 4;
-                    const uint32_t t = off2; off2 = off1; off1 = t;
-                    const uint32_t qr = ZE_PL(wr);
-                    hashSmall[ZE_PS(wr) >> shS] = (ip + 2) | ZE_TS(wr);
-                    hashLong[qr >> shL] = (ip + 2) | ZE_TL(qr);
-                    seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
-                    ip += r; anchor = ip;
-                    if (ip > ilimit) break;
-                    wr = zh_ld64(src + ip); r2 = zh_ld32(src + ip - off2);
-                }
-            }
-            fresh = true;
-        } else if (!hasB) {                                             // A failed and the search ends at the next bound check
-            step = stepB; nextStep = nextB; ip = ipB; cellL0 = cLB; pl0 = plB; cl0 = clB; fresh = false;
-        } else {                                                        // A and B failed: go on from C
-            step = stepB; nextStep = nextB;
-            if (ipC >= nextStep) { step++; nextStep += 256; }
-            ip = ipC; cellL0 = cLC; pl0 = plC; cl0 = clC; fresh = false;
-        }
-    }
-#undef ZE_PL
-#undef ZE_PS
-#undef ZE_TL
-#undef ZE_TS
-#undef ZE_CELL_IDX
-#define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
-    if (BLK) {                                                        // zstd.c:31252-31258
-        saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
-        rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
-    }
-    return nseq;
-}
-// The same search with NP probes per trip (NP = 4): for batches that are bound by a source's serial chain rather than by the memory system -- one-shot
-// calls and small batches in the LDS-source kernel, a few thousand sources in the flat kernel -- a trip's three memory rounds are what a probe
-// costs, and four probes in five fail: with four consecutive probes in flight a trip consumes 2.95 probes on average instead of 1.8, at twice the loads
-// (most of them dropped), which is why large batches -- bound by transactions -- keep two. The order of table reads and writes is the reference's:
-// probe k's cell reads see the writes of the probes before it in the trip through forwarding selects, probe k's writes happen only if every probe
-// before it failed. BLK as in ze_dfast_flat_t.
+// Every trip examines NP consecutive probe positions in the same three memory rounds (own bytes -> table cells -> plausible candidates' bytes): four
+// probes in five fail, and after a failed probe the next one is fully determined (its position, its step, and -- through the forwarding selects below --
+// the table state it must see), so the probes after the first are speculative and simply dropped when an earlier one matches. The order of table reads
+// and writes is the reference's: probe k's cell reads see the writes of the probes before it in the trip, probe k's writes happen only if every probe
+// before it failed. NP = 2 consumes 1.8 probes per trip on the bench corpus, 3: 2.44, 4: 2.95 -- for 1.5 x / 2 x the loads, most of them dropped: batches bound
+// by ONE source's serial chain (up to ~32 768 sources per launch) take four, launches of up to 65 536 three, larger ones -- bound by transactions -- two
+// (r04zd / r04zg). The function was written for two probes in round 1 and generalised in round 4; at NP = 2 it compiles to the same kernel (4 573 against
+// 4 569 instructions, 85 against 84 VGPRs).
 template <int PB, bool BLK, int NP>
 ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle)
 {
@@ -1421,6 +1258,11 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
         rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
     }
     return nseq;
+}
+template <int PB, bool BLK>
+ZH_DEV uint32_t ze_dfast_flat_t(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle = nullptr)
+{
+    return ze_dfast_flat_np<PB, BLK, 2>(seqs, src, bs, be, hlog, clog, mml, hashLong, hashSmall, rep, idle ? idle : src);
 }
 template <int NP>
 ZH_DEV uint32_t ze_dfast_flatn(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
