@@ -18,7 +18,9 @@ roofline = (compressed + uncompressed bytes) / time vs the HBM peak, for the dom
 end to end. cpu_baseline = the reference libzstd 1.5.7 (oracle/_ref) on host threads over a bounded sample of the same workload.
 
   python bench.py [--gpus N --steps K --warmup W --frames F --config ...]
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either `python bench.py --gpus N ...` (it starts its own N ranks through torch.distributed.run on 127.0.0.1) or the driver's
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`;
+  --dry-launch stops after the process group is formed and the partition agreed (tests/test_distributed_gloo.py runs it at N = 2 on CPU).
 """
 import argparse
 import ctypes as C
@@ -64,6 +66,9 @@ def _mtbench():
     return lib
 
 
+HOST_THREADS = min(os.cpu_count() or 1, 64)      # input preparation on the host; main() divides the host's cores among the ranks of a node
+
+
 def compress_on_host(raw_np, item, dict_data=None, level=3):
     """level-3 frames of every row of raw_np [F, item] with the reference library (native threads, contiguous partition).
     Returns (list of frames, int64 sizes)."""
@@ -74,7 +79,7 @@ def compress_on_host(raw_np, item, dict_data=None, level=3):
     slot = item + (item >> 7) + 512
     out = np.empty((F, slot), dtype=np.uint8)
     sizes = np.zeros(F, dtype=np.uint64)
-    rc = _mtbench().zo_mt_compress_all(reflib.REF_SO.encode(), raw_np.ctypes.data, offs.ctypes.data, F, level, min(os.cpu_count() or 1, 64),
+    rc = _mtbench().zo_mt_compress_all(reflib.REF_SO.encode(), raw_np.ctypes.data, offs.ctypes.data, F, level, HOST_THREADS,
                                        dict_data, len(dict_data) if dict_data else 0, out.ctypes.data, slot, sizes.ctypes.data)
     assert rc == 0, "reference compression of the bench input failed (%d)" % rc
     sizes = sizes.astype(np.int64)
@@ -204,7 +209,7 @@ def roofline(ctx, ktimes, steps, algo_bytes_per_step, ms_per_step, frames_per_st
     e2e = algo_bytes_per_step / (ms_per_step * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "pipeline: " + " + ".join(ctx.kernel_name(k) for k, v in ktimes.items() if v[1] and v[0] >= 0.05),
             "achieved": round(pipe, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": tsrc, "kernel_ms_per_step": round(pipe_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes_per_step),
+            "traffic": traffic, "traffic_source": tsrc, "traffic_measured_in_run": False,       # read from profiles/traffic.json (separate rocprofv3 --pmc passes), scaled to the step "kernel_ms_per_step": round(pipe_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes_per_step),
             "dominant_kernel": {"kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": ktraffic,
                                 "kernel_ms": round(kernel_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes),
                                 "note": "the step's whole algorithmic bytes over ONE kernel's duration (the prescribed formula): it credits this kernel with bytes the other kernels move"},
@@ -566,6 +571,57 @@ def bench_blocks(args, rank, world, dev, steps=None, warmup=None, quiet=False):
     return line
 
 
+def spawn_ranks(n):
+    """re-run this command line as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <a free one> bench.py <the same arguments>. Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, rank, local_rank, world):
+    """--dry-launch: everything a multi-rank run does BEFORE it touches a kernel -- the process group (RCCL where there are GPUs, gloo where there are
+    none: the CPU test of the launch path), every rank's shard of the workload (frames [rank * F, (rank + 1) * F), the reference's contiguous
+    partition, c-ext/compressor.c:1127-1216), agreement on it across ranks, a barrier -- then rank 0 prints one JSON line and everybody leaves."""
+    import torch.distributed as dist
+    have_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dev = torch.device("cuda", local_rank)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cpu")
+    try:
+        F = args.frames
+        mine = torch.tensor([rank * F, (rank + 1) * F, HOST_THREADS], dtype=torch.int64, device=dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        bounds = [(int(t[0]), int(t[1])) for t in got]
+        assert bounds[rank] == (rank * F, (rank + 1) * F)
+        assert bounds[0][0] == 0 and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1)) and bounds[-1][1] == world * F, \
+            "the ranks' shards do not tile the workload: %r" % (bounds,)
+        t = torch.tensor([float(rank)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the collective the timed region ends with
+        assert int(t.item()) == world - 1
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": "nccl" if have_gpu else "gloo", "frames_per_gpu": F,
+                              "partition": bounds, "host_threads_per_rank": int(got[0][2])}))
+    finally:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -584,13 +640,22 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the 'host_api' sub-object (the Python-visible calls on host buffers, PCIe inclusive)")
     ap.add_argument("--mix", choices=["silesia", "default"], default="silesia", help="class mix of the 128 KiB corpus (tests/corpus.py)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
+    ap.add_argument("--dry-launch", action="store_true", help="form the process group, agree on the partition, exit (no kernels; gloo where there is no GPU)")
     args = ap.parse_args()
     config = args.config or args.direction or "decompress"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: one rank per GPU through torch.distributed.run on this node (what the driver's own command line does);
+        # rank 0 prints the one JSON line, the launcher's chatter goes to stderr, this process only waits and hands the exit code on
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert world == args.gpus, "WORLD_SIZE (%d) and --gpus (%d) disagree: launch with --nproc-per-node == --gpus, or let bench.py spawn its ranks" % (world, args.gpus)
+    global HOST_THREADS
+    HOST_THREADS = max(1, min(64, (os.cpu_count() or 1) // world))
+    if args.dry_launch:
+        return dry_launch(args, rank, local_rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -718,6 +783,11 @@ def bench_frames(args, config, rank, world, dev):
                                                        % (ns, cb["passes"])})
                 line["compress"]["cpu_baseline"] = cb
     ctx.close()
+    if rank == 0 and isinstance(line.get("compress"), dict) and line["compress"].get("frames_per_gpu") == F:
+        # BASELINE.json's metric is "compress+decompress": both directions over the same bytes, one after the other -- the harmonic combination
+        cv, dv = line["compress"]["value"], line["value"]
+        line["combined"] = {"value": round(1.0 / (1.0 / cv + 1.0 / dv), 3), "unit": "GB/s", "compress": cv, "decompress": dv,
+                            "formula": "1 / (1 / compress + 1 / decompress): uncompressed GB/s of a batch compressed and then decompressed on the same GPU(s)"}
     if world == 1 and rank == 0 and not args.no_host_api and F >= 8192:
         torch.cuda.empty_cache()
         t0 = time.time()

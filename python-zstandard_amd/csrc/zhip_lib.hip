@@ -1018,6 +1018,11 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // (r03: dictionary batches whose dictionary row is double-fast take the flat kernel too -- ze_dfast_dict_flat; its waves zero the tables)
         const bool flatDict = c->hasCDict && c->cdictStrat == 2 && !c->knob.noFlat;
         const bool flat = (anyDfast && !c->hasCDict && !c->knob.noFlat) || flatDict;
+        // (round 5) every row double-fast, no dictionary: the flat kernel takes every one-block source of 64 bytes and more and writes sequences only, and what
+        // it declines -- sources below 64 bytes, parameter errors -- needs a literal area of its own size at most: the slot is the sequence area + 512 bytes
+        // instead of + 128 KiB (21.4 GiB of arena per 65 536 sources instead of 30; it is what lets 262 144 sources be one launch, 88 + 96 GiB)
+        bool allDfast = anyDfast && !c->hasCDict; for (int t = 0; t < 4; t++) allDfast = allDfast && a.rows.r[t][6] == 2;
+        if (flat && allDfast) a.arenaStride = (uint32_t)(ZE_ARENA_LIT + 512);
         // frames per launch of the flat match kernel: the search is a latency chain per frame, so its rate grows with the frames in flight -- 16 384: 204 ms,
         // 32 768: 270, 65 536: 417, 131 072: 760 (r04za: 9 % less per frame than two launches of 65 536, a second wave per SIMD) -- and what it costs
         // is memory, 384 KiB of tables + 196 KiB of arena per frame. Batches above 65 536 take 131 072 per launch where the device has that free.

@@ -167,3 +167,33 @@ def test_sharded_calls_world2_full_control_flow(oracle):
     from tests.corpus import Corpus
     enc = reflib.RefZstd() if reflib.have_ref() else oracle
     assert l0[3] == len(enc.compress(Corpus().frame_bytes(3)[: 500 + 3100 * 3], level=3))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the launch path of bench.py at N = 2: `python bench.py --gpus 2` must start its own ranks, and the driver's
+# `python -m torch.distributed.run ... bench.py --gpus 2` must keep working. --dry-launch runs everything up to "process group formed,
+# partition agreed" (gloo here: no GPU) and rank 0 prints the one JSON line.
+def _dry_line(cmd):
+    import json
+    import subprocess
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["CUDA_VISIBLE_DEVICES"] = ""; env["HIP_VISIBLE_DEVICES"] = ""          # the CPU launch path, whatever the box has
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln[ln.index("{"):] for ln in p.stdout.splitlines() if '"dry_launch"' in ln]
+    assert len(lines) == 1, p.stdout                                          # rank 0 alone speaks
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks():
+    line = _dry_line([sys.executable, "bench.py", "--gpus", "2", "--dry-launch", "--frames", "4096"])
+    assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert line["partition"] == [[0, 4096], [4096, 8192]]
+    assert 1 <= line["host_threads_per_rank"] <= max(1, (os.cpu_count() or 1) // 2)
+
+
+def test_bench_under_the_drivers_launcher():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    line = _dry_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), "bench.py", "--gpus", "2", "--dry-launch", "--frames", "65536"])
+    assert line["n_gpus"] == 2 and line["partition"] == [[0, 65536], [65536, 131072]]
