@@ -287,9 +287,7 @@ def decode_own_bytes(sec, F, item):
 def encode_own_bytes(sec, F, item):
     """the match kernels read the source and write 8-byte sequences; the entropy kernel reads sequences + source (literals) and writes the frame"""
     m = F * (item + 8 * sec["nbseq"])
-    return {"zhip_encode_match_flat_kernel": m, "zhip_encode_match_kernel": m, "zhip_encode_match_lds_kernel": m, "zhip_encode_match_links_kernel": m,
-            "zhip_encode_links_pre_kernel": F * 9 * item,         # the link form (ZHIP_E1LINKS): the pre-pass reads the source and writes 8 bytes per position
-
+    return {"zhip_encode_match_flat_kernel": m, "zhip_encode_match_kernel": m, "zhip_encode_match_lds_kernel": m,
             "zhip_encode_entropy_kernel": F * (8 * sec["nbseq"] + sec["lit"] + sec["rawlit"] + sec["csize"])}
 
 
@@ -298,7 +296,7 @@ def kernels_obj(ctx, ktimes):
 
 
 DEC_KERNELS = (0, 2, 7, 3, 4)         # generic, K1, K1b, K2, K3
-ENC_KERNELS = (1, 5, 6, 8, 9, 10)
+ENC_KERNELS = (1, 5, 6, 8)
 
 
 def run_decompress(job, ctx, frames, csizes, raw, item, steps, warmup):

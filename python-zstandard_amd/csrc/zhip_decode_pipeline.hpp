@@ -13,7 +13,7 @@
 //   K1b zhip_decode_huf_kernel   4 LANES per frame    : the (up to) four Huffman streams, 8 frames per wave, tables in LDS (3 KiB each), 6 waves per CU
 //   K2  zhip_decode_seq_kernel   a QUAD per frame     : the serial tANS chain with its three streams side by side (lanes OF / ML / LL / spare), 15
 //                                                       frames per wave, four waves per CU: the 60 frames' tables ARE the CU's 160 KiB of LDS.
-//                                                       Emits packed 8-byte sequences (zp_seqq_body; zp_seq_body is rounds 1-2's lane-per-frame form)
+//                                                       Emits packed 8-byte sequences (zp_seqq_body)
 //   K3  zhip_decode_exec_kernel  one wave per frame   : 64 sequences per batch, the batch's output assembled in LDS and flushed in whole 16-byte
 //                                                       units; 77 VGPRs, six waves per SIMD (zhip_decode_exec_dict_kernel: with a dictionary)
 //
@@ -603,252 +603,8 @@ ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t
     return zb_finished(B);
 }
 
-// ---- round 4: the lean form (ZP_K1B_V1 keeps round 3's). K1b is a chain per lane on a SIMD that holds one or two waves: its time is its
-// instruction count per symbol (r03 SQ counters: 37 vector instructions per symbol step; two LDS reads per symbol -- a symbol byte, a
-// length nibble -- nibble extraction, a 3-register window with its selects). Here
-//   * the table stays in K1's 2-byte cells (symbol | length << 8): ONE ds_read_u16 per symbol, and the HBM -> LDS copy is a plain copy
-//     (4 KiB per frame instead of 3: four waves of 8 frames per CU instead of six);
-//   * the bit reader is K2's: an absolute bit cursor over the lane's LDS ring, the two dwords around the cursor fetched with one
-//     ds_read2_b32 per PAIR of symbols (two codes are at most 22 bits), one v_alignbit, one v_bfe per symbol -- no window registers;
-//   * eight symbols are packed with byte permutes and stored behind the next burst's requests (vmcnt counts stores as well).
-struct __attribute__((packed, aligned(1))) zh_q4u { uint32_t a, b, c, d; };
-#define ZH2_ROWS 32             // ring rows (dwords) per lane: 128 bytes; row ZH2_ROWS mirrors row 0 (ds_read2_b32 of rows d, d + 1)
-// (the ring comes first: ds_read2_b32's two offsets are 8 bits each, so only a base within 1 KiB folds into the instruction)
-struct ZpHuf2LDS { alignas(16) uint32_t ring[((ZH2_ROWS + 1) << ZP_HUF_LS) + 3 & ~3u]; alignas(16) uint16_t tab[ZP_HUF_FRAMES][ZP_HUF_CELLS]; };
-struct ZpHuf2Bits {
-    int32_t pos;                // absolute bit index (from p0) one past the next unread bit; the stream is read downwards
-    int32_t pb;                 // offset of the next 16-byte block to request
-    int32_t s0;                 // offset of the stream's first byte
-    int32_t bo[2]; ZpVec16 blk[2];
-    const uint8_t* p0; uint32_t* col;
-};
-ZH_DEV void zh2_commit(ZpHuf2Bits& B, int32_t off, const ZpVec16& v)               // off % 16 == 0: four consecutive rows, no wrap inside
-{
-    const uint32_t r0 = ((uint32_t)off >> 2) & (ZH2_ROWS - 1);
-    uint32_t* q = B.col + (r0 << ZP_HUF_LS);
-    q[0] = v.a; q[1u << ZP_HUF_LS] = v.b; q[2u << ZP_HUF_LS] = v.c; q[3u << ZP_HUF_LS] = v.d;
-    if (r0 == 0) B.col[ZH2_ROWS << ZP_HUF_LS] = v.a;
-}
-ZH_DEV ZpVec16 zh2_fetch(const ZpHuf2Bits& B, int32_t off) { return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off)); }
-// the 32 stream bits [q, q + 32) (q may be negative on a damaged stream: the row index is masked, whatever comes back fails the end check)
-ZH_DEV uint32_t zh2_bits(const ZpHuf2Bits& B, int32_t q)
-{
-    const uint32_t* w = B.col + (zh_bfe((uint32_t)q, 5, 5) << ZP_HUF_LS);
-    return zh_alignbit(w[1u << ZP_HUF_LS], w[0], (uint32_t)q);
-}
-// write what the previous burst requested; request what may now replace ring rows nothing will read again. A block at offset b lands on the
-// rows of bytes [b + 128, b + 144); every later read touches bytes below 4 * ((pos - 1) >> 5) + 4 only (bits at and above pos are masked away).
-// A trip of 16 symbols consumes at most 22 bytes: what burst k - 1 requested (down to 108 bytes below its cursor, two blocks per burst keep
-// up with 22 bytes per trip) is written by burst k, whose trip reads no lower than 48 bytes below burst k - 1's cursor.
-ZH_DEV void zh2_burst(ZpHuf2Bits& B)
-{
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) if (B.bo[k] != ZP_NOBLK) { zh2_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
-    const int32_t cur = ((B.pos - 1) >> 5) << 2;
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) {
-        if (B.pb + (int32_t)(ZH2_ROWS * 4 - 4) >= cur) { B.bo[k] = B.pb; B.blk[k] = zh2_fetch(B, B.pb); B.pb -= 16; }
-    }
-}
-ZH_DEV bool zp_huf_stream2(const uint16_t* tab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count, uint32_t* ringCol)
-{
-    ZpHuf2Bits B;
-    B.col = ringCol;
-    const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
-    B.p0 = p - mis; B.s0 = (int32_t)mis;
-    B.bo[0] = B.bo[1] = ZP_NOBLK; B.blk[0].a = B.blk[0].b = B.blk[0].c = B.blk[0].d = 0; B.blk[1] = B.blk[0];
-    if (size == 0) return false;
-    const uint32_t last = p[size - 1];
-    if (last == 0) return false;                               // missing end mark
-    const int32_t topByte = (int32_t)(mis + size) - 1, tb = topByte & ~15;
-    {   ZpVec16 f[ZH2_ROWS / 4];                               // the top 64 bytes of the stream, straight into the ring (all loads in flight before the first write)
-#pragma unroll
-        for (uint32_t k = 0; k < ZH2_ROWS / 4; k++) f[k] = zh2_fetch(B, tb - 16 * (int32_t)k);
-#pragma unroll
-        for (uint32_t k = 0; k < ZH2_ROWS / 4; k++) zh2_commit(B, tb - 16 * (int32_t)k, f[k]); }
-    B.pb = tb - (int32_t)(ZH2_ROWS * 4);
-    B.pos = 8 * topByte + zh_highbit32(last);
-    const int32_t log2x = (int32_t)(2 * log);
-    uint32_t i = 0;
-    ZpVec16 pend; pend.a = pend.b = pend.c = pend.d = 0;
-    // two symbols per window: T = bits [pos - 2 log, pos + ..): the first code is T's bits [log, 2 log), the second, once the first one's
-    // length l is known, bits [log - l, 2 log - l). Sixteen symbols per trip, one 16-byte store.
-#define ZH2_PAIR(ca, cb) do { const uint32_t T_ = zh2_bits(B, B.pos - log2x); ca = tab[zh_bfe(T_, log, log)]; const uint32_t la_ = ca >> 8; \
-        cb = tab[zh_bfe(T_, log - la_, log)]; B.pos -= (int32_t)(la_ + (cb >> 8)); } while (0)
-#define ZH2_QUAD(dw) do { uint32_t c0_, c1_, c2_, c3_; ZH2_PAIR(c0_, c1_); ZH2_PAIR(c2_, c3_); \
-        dw = (c0_ & 255u) | ((c1_ & 255u) << 8) | ((c2_ & 255u) << 16) | (c3_ << 24); } while (0)
-    while (i + 16 <= count) {
-        zh2_burst(B);
-        if (i) *(zh_q4u*)(out + i - 16) = *(const zh_q4u*)&pend;
-        uint32_t d0, d1, d2, d3;
-        ZH2_QUAD(d0); ZH2_QUAD(d1); ZH2_QUAD(d2); ZH2_QUAD(d3);
-        pend.a = d0; pend.b = d1; pend.c = d2; pend.d = d3;
-        i += 16;
-    }
-    zh2_burst(B);                               // the tail (<= 15 symbols) reads what the last burst requested
-    if (i) *(zh_q4u*)(out + i - 16) = *(const zh_q4u*)&pend;
-    while (i < count) {
-        const uint32_t c = tab[zh_bfe(zh2_bits(B, B.pos - (int32_t)log), 0, log)];
-        B.pos -= (int32_t)(c >> 8);
-        out[i++] = (uint8_t)c;
-    }
-#undef ZH2_QUAD
-#undef ZH2_PAIR
-    return B.pos == 8 * B.s0;                   // every bit consumed, no more
-}
 
-// ---- round 4, second form (ZP_K1B_R4B): K1b is (chains resident on the CU) / (latency of a symbol step), and residency is LDS: 3 KiB of
-// table per frame = 48 frames = 192 chains per CU (r04b: the lean loop above on 4 KiB tables -- 32 frames -- is 25 % FASTER per chain and 13 %
-// slower overall). A Huffman table does not need 2^11 cells: codes of up to 8 bits are decoded by a DIRECT table of 256 two-byte cells indexed
-// by the window's first 8 bits; a longer code (9-11 bits: weights 1-3, the table's first cells) is computed from the canonical layout K1's table
-// has (RFC 8878 4.2.1: cells sorted by weight, symbols in order inside a weight, 2^(w-1) cells each): its weight from two comparisons of the
-// 11-bit index with where weights 2 and 3 begin, its symbol from a 256-byte list of the long symbols. 768 bytes per frame, 16 frames per
-// wave, nine waves per CU: 576 chains. The long path's arithmetic depends on the index only, so it runs beside the direct lookup; the chain is
-// one LDS read per symbol. K1b derives both tables from K1's full table while loading it (K1 and the table arena are unchanged).
-#define ZH3_ROWS 16             // ring rows (dwords) per lane: 64 bytes; row ZH3_ROWS mirrors row 0
-#define ZH3_D 8u                // bits the direct table decodes
-struct ZpHuf3LDS {
-    alignas(16) uint32_t ring[(ZH3_ROWS + 1) << ZP_HUF_LS];
-    uint32_t par[ZP_HUF_FRAMES][2];                 // T2 | T3 << 16 (the table indices where weights 2 / 3 begin), S2 | S3 << 16 (how many long symbols precede them)
-    alignas(16) uint16_t direct[ZP_HUF_FRAMES][256];
-    alignas(16) uint8_t symLong[ZP_HUF_FRAMES][256];
-};
-struct ZpHuf3Bits { int32_t pos, pb, s0; int32_t bo[2]; ZpVec16 blk[2]; const uint8_t* p0; uint32_t* col; };
-ZH_DEV void zh3_commit(ZpHuf3Bits& B, int32_t off, const ZpVec16& v)
-{
-    const uint32_t r0 = ((uint32_t)off >> 2) & (ZH3_ROWS - 1);
-    uint32_t* q = B.col + (r0 << ZP_HUF_LS);
-    q[0] = v.a; q[1u << ZP_HUF_LS] = v.b; q[2u << ZP_HUF_LS] = v.c; q[3u << ZP_HUF_LS] = v.d;
-    if (r0 == 0) B.col[ZH3_ROWS << ZP_HUF_LS] = v.a;
-}
-ZH_DEV ZpVec16 zh3_fetch(const ZpHuf3Bits& B, int32_t off) { return *(const ZpVec16*)(B.p0 + (uint32_t)(off < 0 ? 0 : off)); }
-ZH_DEV uint32_t zh3_bits(const ZpHuf3Bits& B, int32_t q)
-{
-    const uint32_t* w = B.col + (zh_bfe((uint32_t)q, 5, 4) << ZP_HUF_LS);
-    return zh_alignbit(w[1u << ZP_HUF_LS], w[0], (uint32_t)q);
-}
-// a block at offset b lands on the rows of bytes [b + 64, b + 80); every later read touches bytes below 4 * ((pos - 1) >> 5) + 4 only. A trip
-// of 8 symbols consumes at most 11 bytes: what burst k - 1 requested (down to 44 bytes below its cursor) is written by burst k, whose trip
-// reads no lower than 30 bytes below burst k - 1's cursor.
-ZH_DEV void zh3_burst(ZpHuf3Bits& B)
-{
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) if (B.bo[k] != ZP_NOBLK) { zh3_commit(B, B.bo[k], B.blk[k]); B.bo[k] = ZP_NOBLK; }
-    const int32_t cur = ((B.pos - 1) >> 5) << 2;
-#pragma unroll
-    for (uint32_t k = 0; k < 2; k++) {
-        if (B.pb + (int32_t)(ZH3_ROWS * 4 - 4) >= cur) { B.bo[k] = B.pb; B.blk[k] = zh3_fetch(B, B.pb); B.pb -= 16; }
-    }
-}
-// one code at table index idx (log bits): its length (-> len) and symbol (-> sym). cell = the direct table's answer (0: a long code)
-#define ZH3_RESOLVE(idx, cell, len, sym) do { \
-        const uint32_t e_ = (uint32_t)((idx) >= T2) + (uint32_t)((idx) >= T3);                 /* weight - 1 of a long code */ \
-        const uint32_t b_ = e_ == 0 ? 0u : e_ == 1 ? T2 : T3, s_ = e_ == 0 ? 0u : e_ == 1 ? S2 : S3; \
-        const uint32_t symL_ = symLong[(s_ + (((idx) - b_) >> e_)) & 255u];      /* (a short code's index leads anywhere: masked, unused) */ \
-        const bool long_ = (cell) == 0; \
-        len = long_ ? log - e_ : (cell) >> 8; sym = long_ ? symL_ : (cell) & 255u; } while (0)
-ZH_DEV bool zp_huf_stream3(const uint16_t* direct, const uint8_t* symLong, uint32_t par0, uint32_t par1, uint32_t log, const uint8_t* p, uint32_t size,
-                           uint8_t* out, uint32_t count, uint32_t* ringCol)
-{
-    ZpHuf3Bits B;
-    B.col = ringCol;
-    const uint32_t mis = (uint32_t)((uintptr_t)p & 15);
-    B.p0 = p - mis; B.s0 = (int32_t)mis;
-    B.bo[0] = B.bo[1] = ZP_NOBLK; B.blk[0].a = B.blk[0].b = B.blk[0].c = B.blk[0].d = 0; B.blk[1] = B.blk[0];
-    if (size == 0) return false;
-    const uint32_t last = p[size - 1];
-    if (last == 0) return false;                               // missing end mark
-    const int32_t topByte = (int32_t)(mis + size) - 1, tb = topByte & ~15;
-    {   ZpVec16 f[ZH3_ROWS / 4];                               // the top 64 bytes of the stream, straight into the ring
-#pragma unroll
-        for (uint32_t k = 0; k < ZH3_ROWS / 4; k++) f[k] = zh3_fetch(B, tb - 16 * (int32_t)k);
-#pragma unroll
-        for (uint32_t k = 0; k < ZH3_ROWS / 4; k++) zh3_commit(B, tb - 16 * (int32_t)k, f[k]); }
-    B.pb = tb - (int32_t)(ZH3_ROWS * 4);
-    B.pos = 8 * topByte + zh_highbit32(last);
-    const uint32_t T2 = par0 & 0xFFFFu, T3 = par0 >> 16, S2 = par1 & 0xFFFFu, S3 = par1 >> 16;
-    const uint32_t sh = log > ZH3_D ? log - ZH3_D : 0u;       // the direct table is indexed by the code's first min(log, 8) bits
-    const int32_t log2x = (int32_t)(2 * log);
-    uint32_t i = 0;
-    uint64_t pend = 0;
-#define ZH3_PAIR(sa, sb) do { const uint32_t T_ = zh3_bits(B, B.pos - log2x); const uint32_t ia_ = zh_bfe(T_, log, log); const uint32_t ca_ = direct[ia_ >> sh]; \
-        uint32_t la_; ZH3_RESOLVE(ia_, ca_, la_, sa); const uint32_t ib_ = zh_bfe(T_, log - la_, log); const uint32_t cb_ = direct[ib_ >> sh]; \
-        uint32_t lb_; ZH3_RESOLVE(ib_, cb_, lb_, sb); B.pos -= (int32_t)(la_ + lb_); } while (0)
-    while (i + 8 <= count) {
-        zh3_burst(B);
-        if (i) zh_st64(out + i - 8, pend);
-        uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
-        ZH3_PAIR(s0, s1); ZH3_PAIR(s2, s3); ZH3_PAIR(s4, s5); ZH3_PAIR(s6, s7);
-        pend = (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32);
-        i += 8;
-    }
-    zh3_burst(B);
-    if (i) zh_st64(out + i - 8, pend);
-    while (i < count) {
-        const uint32_t ix = zh_bfe(zh3_bits(B, B.pos - (int32_t)log), 0, log);
-        const uint32_t c = direct[ix >> sh];
-        uint32_t l, sy; ZH3_RESOLVE(ix, c, l, sy);
-        B.pos -= (int32_t)l;
-        out[i++] = (uint8_t)sy;
-    }
-#undef ZH3_PAIR
-    return B.pos == 8 * B.s0;                   // every bit consumed, no more
-}
-// frame slot j's two tables from K1's full table `src` (2^log cells of symbol | length << 8, sorted by weight). All lanes call.
-ZH_DEV void zp_huf3_load(ZpHuf3LDS& L, uint32_t j, const ZpVec16* src, uint32_t log)
-{
-    const uint32_t lane = zh_lane();
-    const uint32_t nv = ((2u << log) + 15) >> 4;                  // 16-byte pieces (8 cells) of the table
-    ZpVec16 r[4];
-#pragma unroll
-    for (uint32_t q = 0; q < 4; q++) { r[q].a = r[q].b = r[q].c = r[q].d = 0; if (lane + 64 * q < nv) r[q] = src[lane + 64 * q]; }
-    uint32_t T2 = 0, T3 = 0, T4 = 0;
-    if (log > ZH3_D) {
-        // where the weights begin: T2 = cells of length log, T3 = T2 + cells of length log - 1, T4 = T3 + cells of length log - 2
-        uint32_t c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t w[4] = { r[q].a, r[q].b, r[q].c, r[q].d };
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t len = (w[k >> 1] >> (8 + 16 * (k & 1))) & 255u;
-                const uint32_t e = log - len;                      // (unused cells: length 0, e = log > 8)
-                c1 += e < 1 ? 1u : 0u; c2 += e < 2 ? 1u : 0u; c3 += e < 3 ? 1u : 0u;
-            }
-        }
-        const uint32_t tot = zh_shfl(zh_scan_add(c1 | (c2 << 10) | (c3 << 20)), 63);          // (each at most 2^11 / 2: codes of the longest three lengths fill at most half... the sums stay below 2^10 + carry room)
-        T2 = tot & 1023u; T3 = (tot >> 10) & 1023u; T4 = tot >> 20;
-    }
-    const uint32_t S2 = T2, S3 = T2 + ((T3 - T2) >> 1);
-    if (lane == 0) { L.par[j][0] = T2 | (T3 << 16); L.par[j][1] = S2 | (S3 << 16); }
-    const uint32_t sh = log > ZH3_D ? log - ZH3_D : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < 4; q++) {
-        const uint32_t pc = lane + 64 * q;                              // piece: cells 8 pc .. 8 pc + 7
-        if (pc >= nv) continue;
-        const uint32_t w[4] = { r[q].a, r[q].b, r[q].c, r[q].d };
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t idx = 8 * pc + k;
-            const uint32_t cell = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-            const uint32_t len = cell >> 8;
-            if ((idx & ((1u << sh) - 1)) == 0 && idx < (1u << log)) L.direct[j][idx >> sh] = (uint16_t)(len > ZH3_D ? 0u : cell);
-            if (idx < T4 && len) {
-                const uint32_t e = log - len;                            // 0 .. 2
-                const uint32_t b = e == 0 ? 0u : e == 1 ? T2 : T3, s = e == 0 ? 0u : e == 1 ? S2 : S3;
-                if (((idx - b) & ((1u << e) - 1)) == 0) L.symLong[j][(s + ((idx - b) >> e)) & 255u] = (uint8_t)cell;
-            }
-        }
-    }
-}
-
-#if defined(ZP_K1B_R4B)
-typedef ZpHuf3LDS ZpHufKernelLDS;
-#elif defined(ZP_K1B_R4A)
-typedef ZpHuf2LDS ZpHufKernelLDS;
-#else
 typedef ZpHufLDS ZpHufKernelLDS;
-#endif
 ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
 {
     const uint32_t lane = zh_lane(), slot = lane >> 2, strm = lane & 3;
@@ -866,16 +622,6 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
         zh_sync();
         // the group's tables, HBM -> LDS: whole 4 KiB slots (cells past 2^log are never indexed), 16 bytes per lane, the four loads of a
         // frame in flight before its first LDS write
-#if defined(ZP_K1B_R4B)
-        for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
-            const uint32_t fj = zh_shfl(i, 4 * j);
-            if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
-            const uint32_t mj = zh_shfl(mode, 4 * j);
-            const bool sharedT = (mj & ZP_LIT_SHARED) != 0;
-            const ZpVec16* src = sharedT ? (const ZpVec16*)a.dictTables->huf : (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
-            zp_huf3_load(L, j, src, (mj >> 8) & 255u);
-        }
-#elif !defined(ZP_K1B_R4A)
 #pragma unroll 2
         for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
             const uint32_t fj = zh_shfl(i, 4 * j);
@@ -894,41 +640,13 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
             ZP_SPLIT(r0, 0); ZP_SPLIT(r1, 1); ZP_SPLIT(r2, 2); ZP_SPLIT(r3, 3);
 #undef ZP_SPLIT
         }
-#else
-#pragma unroll 2
-        for (uint32_t j = 0; j < ZP_HUF_FRAMES; j++) {
-            const uint32_t fj = zh_shfl(i, 4 * j);
-            if (fj == 0xFFFFFFFFu) break;                                  // active slots are a prefix
-            const uint32_t mj = zh_shfl(mode, 4 * j);
-            const bool sharedT = (mj & ZP_LIT_SHARED) != 0;                // a treeless block of a dictionary frame: the dictionary's own table
-            const ZpVec16* src = sharedT ? (const ZpVec16*)a.dictTables->huf : (const ZpVec16*)(a.hufTables + (size_t)fj * ZP_HUF_CELLS);
-            const uint32_t nv = ((2u << ((mj >> 8) & 255u)) + 15) >> 4;      // 16-byte pieces of a table of 2^log cells (cells past it are never indexed)
-            ZpVec16* dstv = (ZpVec16*)L.tab[j];
-            ZpVec16 r0, r1, r2, r3; r0.a = r0.b = r0.c = r0.d = 0; r1 = r0; r2 = r0; r3 = r0;
-            if (lane < nv) r0 = src[lane];
-            if (lane + 64 < nv) r1 = src[lane + 64];
-            if (lane + 128 < nv) r2 = src[lane + 128];
-            if (lane + 192 < nv) r3 = src[lane + 192];
-            if (lane < nv) dstv[lane] = r0;
-            if (lane + 64 < nv) dstv[lane + 64] = r1;
-            if (lane + 128 < nv) dstv[lane + 128] = r2;
-            if (lane + 192 < nv) dstv[lane + 192] = r3;
-        }
-#endif
         zh_sync();
         bool ok = true;
         if (active) {
             const uint32_t f = a.first + (a.itemCap ? a.itemFrame[i] : i);
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
             uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
-#if defined(ZP_K1B_R4B)
-            const uint32_t par0 = L.par[slot][0], par1 = L.par[slot][1];
-#define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream3(L.direct[slot], L.symLong[slot], par0, par1, log, pp, sz, oo, nn, L.ring + lane)
-#elif !defined(ZP_K1B_R4A)
 #define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream(L.sym[slot], L.len[slot], log, pp, sz, oo, nn, L.ring + lane)
-#else
-#define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream2(L.tab[slot], log, pp, sz, oo, nn, L.ring + lane)
-#endif
             if (!four) { if (strm == 0) ok = ZP_HUF_STREAM(p, streamBytes, lit, litSize); }
             else {
                 const uint32_t s1 = zh_ld16(p), s2 = zh_ld16(p + 2), s3 = zh_ld16(p + 4);
@@ -949,144 +667,6 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
             if (!a.itemCap) { const uint32_t f = a.first + i; a.status[f] = ZE_CORRUPTION; a.outSizes[f] = 0; }      // (several-block mode: K3 answers for the frame when it meets the item)
         }
         zd_fence();
-        zh_sync();
-    }
-}
-
-// ------------------------------------------------------------------------------------------ K2 (one lane == one frame)
-// The tANS chain of a frame is serial and needs its three tables (2.5 KiB as 2-byte cells) at LDS latency: a CU's 160 KiB hold 63
-// frames' tables, so K2 runs ONE wave per CU with 63 active lanes, each decoding its own frame in lockstep; what is left to
-// optimise is the length of the per-sequence dependent instruction chain, so the loop is written with 32-bit operations only:
-//   * 2-byte cell = symbol[10:16) | x[0:10), x = normalized count + rank; nbBits = log - highbit(x); next state = (x << nbBits) + bits
-//   * bit window = two dwords (hi:lo) + two prefetched dwords; a group of fields (<= 32 bits) is one v_alignbit + one v_bfe per field;
-//     the window advances a dword at a time at two fixed points per sequence (after the extra bits, after the state bits)
-//   * per-symbol {baseline, extra-bit count} come from one 4-byte LDS word; repcodes are resolved with selects
-// Frames of a wave come from the KB order (similar sequence counts), so lanes finish together.
-#define ZP_SEQ_RING 32          // K2: dwords of ring per lane (128 bytes), 4 blocks per burst, a burst every 4 sequences
-typedef ZpBits<ZP_SEQ_RING, 4, ZP_K2_LS> ZpSeqBits;
-struct ZpSeqLDS { uint8_t tab[ZP_K2_LANES * ZP_K2_STRIDE]; uint32_t ring[ZP_SEQ_RING << ZP_K2_LS]; uint32_t llInfo[36]; uint32_t mlInfo[53]; };
-
-ZH_DEV int zp_decode_sequences(const uint8_t* p, const uint8_t* end, const uint8_t* T, const uint32_t* llInfo, const uint32_t* mlInfo,
-                               uint32_t logs, uint32_t nbSeq, uint64_t* out, uint32_t* ringCol, const uint32_t* rep)
-{
-    const uint32_t llLog = logs & 255, ofLog = (logs >> 8) & 255, mlLog = (logs >> 16) & 255;
-    // Bit window (ZpBits above): hi:lo are the current dwords, `used` bits of hi are gone; invariant at every group start:
-    // 1 <= used <= 32, so the next 32 stream bits are one v_alignbit away (zb_top) and fields totalling <= 32 bits are cut from that
-    // with v_bfe. After a group zb_refill advances by at most one dword, served from the lane's LDS ring.
-    ZpSeqBits B;
-    if (!zb_init(B, p, (uint32_t)(end - p), ringCol)) return ZE_CORRUPTION;
-    const uint32_t maskL = (1u << llLog) - 1, maskO = (1u << ofLog) - 1, maskM = (1u << mlLog) - 1;
-    const uint32_t kL = 31 - llLog, kO = 31 - ofLog, kM = 31 - mlLog;
-    const uint16_t* const TL = (const uint16_t*)(T + 2 * ZP_FSE_LL); const uint16_t* const TM = (const uint16_t*)(T + 2 * ZP_FSE_ML);
-    const uint16_t* const TO = (const uint16_t*)(T + 2 * ZP_FSE_OF);
-    uint32_t top = zb_top(B);
-    uint32_t sL = zh_bfe(top, 32 - llLog, llLog), sO = zh_bfe(top, 32 - llLog - ofLog, ofLog);      // <= 17 bits
-    B.used += llLog + ofLog;
-    zb_refill(B);
-    top = zb_top(B);
-    uint32_t sM = zh_bfe(top, 32 - mlLog, mlLog);
-    B.used += mlLog;
-    zb_refill(B);
-    uint32_t rep0 = rep[0], rep1 = rep[1], rep2 = rep[2], bad = 0;
-    // Software-pipelined by hand: a lone wave issues one instruction every ~4 cycles (~8 when it depends on the previous one) and waits
-    // out every LDS round trip (tests/ubench), so the order of the body matters more than its length. The cells of sequence n + 1 are
-    // requested as soon as the new states exist; the work that is NOT on the state chain -- values, repeat offsets, packing, the store
-    // of sequence n -- is placed behind that request and runs while the lookups are in flight.
-    uint32_t cL = TL[sL], cM = TM[sM], cO = TO[sO];
-    for (uint32_t n = 0;;) {
-        if ((n & 3) == 0) zb_burst(B);
-        const uint32_t symO = cO >> 10, symL = cL >> 10, symM = cM >> 10;
-        // baseline | extra-bit count << 24 of the length codes (RFC 8878 3.1.1.3.2.1.1) from a 89-word LDS table shared by the wave:
-        // one more LDS round on the chain, a tenth of the instructions of computing them
-        const uint32_t iL = llInfo[symL], iM = mlInfo[symM];
-        // (independent of the info words: the state chain's own arithmetic fills the wait)
-        const uint32_t xL = cL & 1023, xM = cM & 1023, xO = cO & 1023;
-        const uint32_t nbL = (uint32_t)__builtin_clz(xL) - kL, nbM = (uint32_t)__builtin_clz(xM) - kM, nbO = (uint32_t)__builtin_clz(xO) - kO;
-        const uint32_t bitsL = iL >> 24, baseL = iL & 0xFFFFFFu, bitsM = iM >> 24, baseM = iM & 0xFFFFFFu;
-        top = zb_top(B);
-        const uint32_t xo = zh_bfe(top, 32 - symO, symO);
-        uint32_t cum = symO;
-        if (symO + bitsM + bitsL > 32) { B.used += symO; zb_refill(B); top = zb_top(B); cum = 0; }     /* rare: far offset with long lengths */
-        const uint32_t xm = zh_bfe(top, 32 - cum - bitsM, bitsM); cum += bitsM;
-        const uint32_t xl = zh_bfe(top, 32 - cum - bitsL, bitsL); cum += bitsL;
-        B.used += cum;
-        zb_refill(B);
-        const bool last = n + 1 >= nbSeq;
-        if (!last) {
-            // state update: the three fields total <= 26 bits; then straight to the next cells
-            top = zb_top(B);
-            const uint32_t tL = zh_bfe(top, 32 - nbL, nbL), tM = zh_bfe(top, 32 - nbL - nbM, nbM), tO = zh_bfe(top, 32 - nbL - nbM - nbO, nbO);
-            B.used += nbL + nbM + nbO;
-            sL = ((xL << nbL) + tL) & maskL; sM = ((xM << nbM) + tM) & maskM; sO = ((xO << nbO) + tO) & maskO;
-            cL = TL[sL]; cM = TM[sM]; cO = TO[sO];
-            zb_refill(B);
-        }
-        // ---- off the chain: sequence n's values
-        const uint32_t ofv = (1u << symO) + xo, mlv = baseM + xm, llv = baseL + xl;
-        /* repcode resolution (RFC 8878 3.1.1.5), select form */
-        const uint32_t idx = ofv - 1 + (llv == 0);                   /* meaningful when ofv <= 3 */
-        uint32_t ro = rep0; ro = idx == 1 ? rep1 : ro; ro = idx == 2 ? rep2 : ro; ro = idx == 3 ? rep0 - 1 : ro;
-        ro = ro == 0 ? 0xFFFFFFFFu : ro;                              /* rep0 - 1 == 0 is no offset (zstd.c:46941 forces -1): too large for the packed form -> generic kernel -> refused */
-        const bool isRep = ofv <= 3;
-        const uint32_t offset = isRep ? ro : ofv - 3;
-        const bool shift3 = !isRep | (idx >= 2), shift2 = !isRep | (idx >= 1);
-        rep2 = shift3 ? rep1 : rep2; rep1 = shift2 ? rep0 : rep1; rep0 = shift2 ? offset : rep0;
-        bad |= offset >= ZP_OF_LIMIT;
-        out[n] = (uint64_t)(llv | (mlv << 17)) | ((uint64_t)((mlv >> 15) | (offset << 3)) << 32);
-        if (last) break;
-        n++;
-    }
-    if (bad) return ZE_PARAM_UNSUPPORTED;                   // an offset does not fit the packed form (window > 512 MiB)
-    if (!zb_finished(B)) return ZE_CORRUPTION;
-    return 0;
-}
-
-ZH_DEVFN void zp_seq_body(const ZhipPipeArgs& a, ZpSeqLDS& L)
-{
-    const uint32_t lane = zh_lane();
-#if defined(ZP_K2_PRIO) && !defined(ZHIP_EMU)
-    __builtin_amdgcn_s_setprio(ZP_K2_PRIO);      // the serial chain is the pipeline's critical path: its wave wins issue arbitration over co-resident K3 / K1b waves
-#endif
-    if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
-    if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
-    zh_sync();
-    uint32_t startRep[3] = {1, 4, 8};
-    if (a.dictEntropy) { startRep[0] = a.dictEntropy->rep[0]; startRep[1] = a.dictEntropy->rep[1]; startRep[2] = a.dictEntropy->rep[2]; }
-    const uint32_t total = a.counters[1];
-    const uint32_t nGroups = (total + ZP_K2_LANES - 1) / ZP_K2_LANES;
-    for (;;) {
-        const uint32_t g = zh_first(zh_atomic_add(a.counters + 3, lane == 0 ? 1u : 0u));
-        if (g >= nGroups) break;
-        const uint32_t k = g * ZP_K2_LANES + lane;
-        const bool active = lane < ZP_K2_LANES && k < total;
-        const uint32_t i = active ? a.order[k] : 0xFFFFFFFFu;
-        const uint32_t logs0 = active ? a.meta[i].logs : 0u;
-        zh_sync();
-        // the group's tables, HBM -> LDS, one frame at a time with coalesced dword loads (K1 built them)
-        for (uint32_t j = 0; j < ZP_K2_LANES; j++) {
-            const uint32_t fj = zh_shfl(i, j);
-            if (fj == 0xFFFFFFFFu) break;                                  // active lanes are a prefix
-            const bool sharedT = (zh_shfl(logs0, j) & ZP_LOGS_SHARED) != 0;
-            const uint32_t* src = sharedT ? (const uint32_t*)a.dictTables->fseK2 : (const uint32_t*)(a.fseTables + (size_t)fj * ZP_FSE_CELLS);
-            uint32_t* dstw = (uint32_t*)(L.tab + (size_t)j * ZP_K2_STRIDE);
-            uint32_t r[ZP_FSE_CELLS / 128];                                 // all loads in flight before the first LDS write
-#pragma unroll
-            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) r[q] = src[lane + 64 * q];
-#pragma unroll
-            for (uint32_t q = 0; q < ZP_FSE_CELLS / 128; q++) dstw[lane + 64 * q] = r[q];
-        }
-        zh_sync();
-        if (active) {
-            ZdMeta* m = a.meta + i;
-            const uint32_t f = a.first + i;
-            const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
-            const int err = zp_decode_sequences(src + m->seqOff, src + m->seqEnd, L.tab + (size_t)lane * ZP_K2_STRIDE, L.llInfo, L.mlInfo,
-                                                m->logs, m->nbSeq, a.seqArena + (size_t)i * ZP_SEQ_CAP, L.ring + lane, startRep);
-            if (err == ZE_PARAM_UNSUPPORTED) {                                 // let the generic kernel handle it
-                m->path = 2;
-                const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f;
-            } else if (err) { m->status = err; m->path = 0; a.status[f] = err; a.outSizes[f] = 0; }
-        }
         zh_sync();
     }
 }
@@ -1328,10 +908,8 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #ifndef ZP_ASM_BYTES
 #define ZP_ASM_BYTES ZD_ASM_BYTES       // K3's batch assembly buffer (LDS per wave = this + 1.6 KiB): smaller buffers leave room for a K2 wave beside sixteen K3 waves
 #endif
-#ifndef ZP_K3_R4
 struct ZpExecLDS {
     uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
-    uint8_t cellSeq[(ZP_ASM_BYTES >> 4) + 8];        // round 4: which sequence of the batch holds byte 16 c of the buffer (the need-masks' index, below)
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
     uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
 };
@@ -1394,11 +972,7 @@ ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2
 // the frame at `dst` (MB = false: the frame's only block, position 0). m = the block's record. 0 or a zstd error code.
 // LDS hand-offs inside the batch loop: __syncthreads() also waits for the wave's global stores and loads (s_waitcnt vmcnt(0)); -DZP_K3_LIGHT_SYNC
 // makes them wave-level fences (the LDS executes a wave's instructions in order), as the round-4 form has them
-#ifdef ZP_K3_LIGHT_SYNC
-#define ZP_BSYNC() zh_wave_fence()
-#else
 #define ZP_BSYNC() zh_sync()
-#endif
 template <bool DICT, bool PROF, bool MB>
 ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint8_t* dst, uint32_t cap, uint64_t cap64,
                            uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
@@ -1421,14 +995,8 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
     uint32_t carry = 0;
     const uint32_t nbSeq = m.nbSeq;
     uint64_t qNext = lane < nbSeq ? ZP_SEQ_LD(seqs + lane) : 0;      // the next batch's sequences are requested a batch ahead
-#ifdef ZP_K3_PREFETCH
-    uint32_t pfWord = 0, pfSink = 0;                      // EXPERIMENTAL: one byte of the next batch's far-match source per lane, touched a batch ahead
-#endif
     const uint32_t lane0 = lane;
     while (done < nbSeq) {
-#ifdef ZP_K3_LANE_OPAQUE
-        const uint32_t lane = zh_opaque(lane0);          // nothing derived from the lane id is hoisted out of the batch loop (registers: r03k)
-#endif
         const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
         uint32_t myLL = 0, myML = 0, myOF = 1;
         if (lane < avail) { const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); if (MB) myOF = zp_sym_resolve(myOF, R0, R1, R2); }
@@ -1478,7 +1046,6 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             // loads fly together with the short ones.
             uint64_t rl[4], rm[4];
             const bool shortL = act && myLL > 0 && myLL <= ZP_LIT_SHORT;
-#ifndef ZP_K3_NO_GLD
             // the same economy on the global side where reading past the item cannot leave mapped memory: decoded literals live in our own
             // arena (256 bytes of slack per frame); a match source at least 32 bytes below the end of the frame's output slot stays inside it.
             // Lanes without an item read their frame's first bytes. Raw literals (read from the caller's source) keep the exact form.
@@ -1488,7 +1055,6 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                 rl[0] = ZP_LIT_LD64(q); rl[3] = ZP_LIT_LD64(q + (shortL && myLL >= 8 ? myLL - 8 : 0u));
                 if (ZP_LIT_SHORT > 16) { rl[1] = ZP_LIT_LD64(q + 8); rl[2] = ZP_LIT_LD64(q + 16); } else { rl[1] = 0; rl[2] = 0; }
             } else
-#endif
             if (shortL && !litRLE) zd_ld32(litPtr + litStart, myLL, rl);
             // a near match whose source starts before the batch: that part is global memory too and is fetched here like a far
             // match (byte by byte in the dependency rounds it was a memory round trip per byte). A lane has one or the other, so
@@ -1502,17 +1068,11 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             const bool strad = DICT && (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
             const uint8_t* const mSrc = !DICT || sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
             const bool shortM = (farM || pre) && lenMi <= ZP_FAR_SHORT && !strad;
-#ifndef ZP_K3_NO_GLD
             if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
-#ifdef ZP_K3_DIAG_NOFAR          // DIAGNOSTIC ONLY (wrong output): far matches read the frame's first bytes -- what K3 costs without its random gathers
-                const uint8_t* q = dst + 64 * lane;
-#else
                 const uint8_t* q = shortM ? mSrc : dst;
-#endif
                 rm[0] = ZP_FAR_LD64(q); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
                 if (ZP_FAR_SHORT > 16) { rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); } else { rm[1] = 0; rm[2] = 0; }
             } else
-#endif
             if (shortM) zd_ld32(mSrc, lenMi, rm);
             const bool longL = act && myLL > ZP_LIT_SHORT && !litRLE, longM = (farM || pre) && !shortM && !strad;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
@@ -1546,9 +1106,6 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
 #undef ZP_UNIT
             }
         }
-#ifdef ZP_K3_PREFETCH
-        pfSink |= pfWord;
-#endif
         if (litRLE) {
             for (uint64_t mk = zh_ballot(act && myLL > ZP_LIT_SHORT); mk; mk &= mk - 1) {
                 const uint32_t l = (uint32_t)zh_ctz64(mk);
@@ -1559,7 +1116,6 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         // ---- matches that read this batch's own output. A match may start as soon as every near match whose output
         // it reads is done: `need` = the set of those sequences (contiguous index range found by binary search over the
         // batch-relative match extents), so the number of rounds is the dependency depth, not the batch length.
-#ifndef ZP_K3_NEED_CELLS     // exact need-masks from two binary searches over the batch's match extents (12 dependent LDS reads, ~86 instructions per batch): the default.
                              // -DZP_K3_NEED_CELLS: the 16-byte cell map below -- measured r04p / r04q: K3 10.09-10.13 ms against 9.95-10.06 (its supersets cost a round now and then; the scalar count rose by what the vector count fell)
         L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
         ZP_BSYNC();
@@ -1576,98 +1132,9 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             if (hi > lane) hi = lane;           // only earlier sequences can feed me
             if (lo < hi) need = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
         }
-#else
-        // Round 4: K3's time is its total instruction count, and the two searches were ~86 instructions + 12 dependent LDS reads of every batch.
-        // The sequences of a batch tile its buffer [carry, totB) in order, so "which sequence holds byte 16 c" (cellSeq) answers both ends of
-        // a source range with ONE read each: the sequence holding the 16-byte boundary at or below the range's first byte is the first one
-        // that can reach into it, the one holding the boundary above its last byte is the last. The masks come out as SUPERSETS of the exact
-        // ones (up to a few neighbouring sequences more): a match may wait a round longer than it must, never less.
-        {
-            const uint32_t sEndRel = oRel + myLL + myML;
-            uint32_t c0 = (oRel + 15) >> 4, c1 = (sEndRel + 15) >> 4;            // my boundaries: 16 c in [oRel, sEndRel)
-            if (lane == 0) c0 = 0;                                                // (the carried bytes in front of the first sequence: final, any index does)
-            if (lane + 1 == cnt) c1 += 2;                                         // (reads reach one boundary past the last byte)
-            if (!act) c1 = c0;
-            // (a sequence holds two boundaries at most unless it is longer than 32 bytes: two plain stores, the loop only when some lane needs it.
-            // Written as a plain loop LLVM turns it into a memset -- 8-byte stores, a remainder loop, 40 instructions)
-            if (c0 < c1) L.cellSeq[c0] = (uint8_t)lane;
-            if (c0 + 1 < c1) L.cellSeq[c0 + 1] = (uint8_t)lane;
-            if (zh_ballot(c0 + 2 < c1)) for (uint32_t c = c0 + 2; c < c1; c++) L.cellSeq[zh_opaque(c)] = (uint8_t)lane;
-        }
-        ZP_BSYNC();
-        ZD_TP(P, ZP_EXEC1);
-        bool pending = hasM && !farM;
-        uint64_t need = 0;
-        if (pending) {
-            const uint32_t a0 = sAbs > (int32_t)ob ? (uint32_t)(sAbs - (int32_t)ob) : 0;          // first buffer byte I read
-            uint32_t b0 = (uint32_t)(sAbs + (int32_t)myML - (int32_t)ob);                          // one past the last byte I read
-            if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
-            const uint32_t lo = L.cellSeq[a0 >> 4];
-            uint32_t hi = b0 ? (uint32_t)L.cellSeq[((b0 - 1) >> 4) + 1] + 1 : 0u;                  // (b0 == 0: a match at the buffer's first byte reads nothing of the batch but itself)
-            if (hi > lane) hi = lane;           // only earlier sequences can feed me
-            if (lo < hi) need = ((1ull << hi) - 1) & ~((1ull << lo) - 1);                          // (hi <= lane <= 63)
-        }
-#endif
         const uint64_t nearMask = zh_ballot(pending);
         need &= nearMask;                       // literals and far matches are already in the buffer
         uint64_t doneMask = ~nearMask;
-#ifdef ZP_K3_LONGONE      // round 1 form (one ready long match per dependency round); r02c: the form below is 1.5 % faster
-        for (;;) {
-            const uint64_t pend = zh_ballot(pending);
-            if (!pend) break;
-            const uint64_t longReady = zh_ballot(pending && myML > ZD_COOP_LEN && (need & ~doneMask) == 0);
-            if (longReady) {
-                // whole wave copies one long ready match
-                const uint32_t pf = (uint32_t)zh_ctz64(longReady);
-                const uint32_t Frel = zh_shfl(mRel, pf), fml = zh_shfl(myML, pf), fof = zh_shfl(myOF, pf);
-                const int32_t fs = (int32_t)(ob + Frel) - (int32_t)fof;
-                if (fof >= 64) {
-                    for (uint32_t c = 0; c < fml; c += 64) {
-                        const uint32_t j = c + lane;
-                        if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
-                        if (fof < fml) ZP_BSYNC();
-                    }
-                } else {
-                    uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
-                    for (uint32_t j = lane; j < fml; j += 64) {
-                        const int32_t sp = fs + (int32_t)idx;
-                        asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
-                        idx += adv; if (idx >= fof) idx -= fof;
-                    }
-                }
-                if (lane == pf) pending = false;
-                doneMask |= 1ull << pf;
-            } else {
-                const bool ready = pending && myML <= ZD_COOP_LEN && (need & ~doneMask) == 0;
-                if (ready) {
-                    // what is left of the match lies in the assembly buffer: source nSrc, destination nSrc + myOF, nLen bytes
-                    const uint32_t nLen = myML - nearSkip, nSrc = (uint32_t)(sAbs + (int32_t)nearSkip - (int32_t)ob), nDst = mRel + nearSkip;
-                    if (myOF >= nLen) {
-                        uint64_t rr[4];
-                        zp_ld32_lds(asmb + nSrc, nLen, rr);
-                        zd_st32(asmb + nDst, nLen, rr);
-                    } else {
-                        // the match overlaps its own output (offset < length): the output is periodic with period myOF, so every
-                        // step can copy as much as is already final -- the copied length doubles instead of advancing a byte at a time
-                        // (what has been written is final and periodic, so the source is simply the `span` bytes before the write
-                        // position, span a multiple of the period that doubles while whole spans are copied -- no division)
-                        uint32_t done = 0, span = myOF;
-                        while (done < nLen) {
-                            uint32_t c = span; if (c > nLen - done) c = nLen - done; if (c > 32) c = 32;
-                            uint64_t rr[4];
-                            zp_ld32_lds(asmb + nDst + done - span, c, rr);
-                            zd_st32(asmb + nDst + done, c, rr);
-                            done += c;
-                            if (c == span) span += span;
-                        }
-                    }
-                    pending = false;
-                }
-                doneMask |= zh_ballot(ready);
-            }
-            ZP_BSYNC();
-        }
-#else
         // a round serves its ready short matches AND every ready long match (one after the other by the whole wave): what is ready at
         // the start of a round never depends on anything else that is ready in it.
         for (;;) {
@@ -1728,20 +1195,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             }
             ZP_BSYNC();
         }
-#endif
         ZD_TP(P, ZP_EXEC2);
-#ifdef ZP_K3_PREFETCH
-        {   // the next batch's far matches read output written long ago (HBM / MALL by now): touch their first line now, a batch ahead,
-            // so that the staging loads of the next batch find it in L2. Layout of the next batch as its own scan will compute it,
-            // assuming it takes all 64 sequences (an estimate is enough for a prefetch).
-            const uint64_t qn = qNext;
-            const uint32_t nLL = ZP_SEQ_LL(qn), nML = ZP_SEQ_ML(qn), nOF = ZP_SEQ_OF(qn);
-            const uint32_t nIncT = zh_scan_add(nLL + nML);
-            const int64_t nSrc = (int64_t)op + totT + nIncT - nML - nOF;
-            pfWord = 0;
-            if (nML && nOF && nSrc >= 0 && nSrc < (int64_t)op) pfWord = dst[nSrc];
-        }
-#endif
         // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
         // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
         qNext = zh_opaque64(qNext);
@@ -1773,365 +1227,10 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
     if (op + rest - blockStart > blockMax) return ZE_CORRUPTION;
     if (litRLE) zd_fill_wave(dst + op, rleByte, rest); else zd_copy_wave(dst + op, litPtr + lp, rest);
     op += rest;
-#ifdef ZP_K3_PREFETCH
-    if (pfSink == 0xFFFFFFFFu && op == 0xFFFFFFFFu) dst[0] = 0;          // never: pfSink holds bytes; keeps the prefetch loads alive
-#endif
     opRef = op;
     return 0;
 }
 
-#else
-// ------------------------------------------------------------------------------------------ K3, round-4 form
-// Round 3's batch loop spent 45 % of its instructions on the matches that read the batch's own output (binary searches for the need-masks,
-// ~4.3 dependency rounds per batch on the bench corpus, predicated piece copies) and 25 % on dealing the long items out to the lanes.
-// This form drops both mechanisms:
-//   * items of up to 32 bytes (literal runs, far matches: 99 % / 97 %) are copied by their own lane from two 16-byte loads -- the item's
-//     FIRST 16 bytes and the 16 bytes that END with it -- so every length class is two unconditional stores from the same registers
-//     (1: a byte; 2-3: two 2-byte pieces; 4-7: two dwords; 8-15: two 8-byte pieces; 16-32: two 16-byte pieces), no shifts, no cascade;
-//   * longer items (~2 per batch) are cut into 16-byte units by a SCALAR loop that hands each item a range of lanes: all units of all items
-//     load together, a unit fetches its item's numbers from the owning lane by ds_bpermute;
-//   * matches that read the batch's own output are executed ONE AFTER THE OTHER, in stream order, by the whole wave (lanes = dwords of the
-//     match): everything a match reads is final when its turn comes, so there are no need-masks, no rounds, no LDS index arrays -- per match
-//     two v_readlane, ~5 vector instructions and an LDS read -> write; all control is scalar.
-// 16 bytes of padding precede the assembly buffer: a piece that ends with an item shorter than 16 bytes is addressed from 16 bytes below the item's end.
-struct ZpExecLDS { uint8_t pad[16]; uint8_t asmb[ZP_ASM_BYTES + 64]; uint32_t misc[8]; uint16_t mBeg[64]; uint16_t mEnd[64]; };
-#ifndef ZP_OWN_MAX
-#define ZP_OWN_MAX 32u             // items up to this long are copied by their own lane
-#endif
-#define ZP_SMALL_MAX 1023u          // a sequence of more bytes ends the batch before it and is executed alone (its sums would not fit the packed scan)
-#define ZD_TP(P, i) do { if (PROF) ZD_T(P, i); } while (0)
-ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2)
-{
-    if (v <= ZP_OF_LIMIT) return v;                              // (ZP_OF_LIMIT itself: K2's "too large for the packed form", the caller looks for it)
-    if (v > ZP_SYM_TOP) return 0xFFFFFFFFu;
-    const uint32_t k = (v - (ZP_OF_LIMIT + 1)) >> 23;
-    const uint32_t d = ZP_SYM_REP(k) - v;
-    const uint32_t r = k == 0 ? R0 : k == 1 ? R1 : R2;
-    return r > d ? r - d : 0xFFFFFFFFu;
-}
-struct zh_q4 { uint32_t a, b, c, d; };
-ZH_DEV zh_q4 zp_ldq(const uint8_t* p) { const zh_q4u v = *(const zh_q4u*)p; zh_q4 r; r.a = v.a; r.b = v.b; r.c = v.c; r.d = v.d; return r; }
-// `len` bytes (1 .. 32; 0: nothing) to LDS at q: A = the item's first 16 bytes, Z = the 16 bytes that end with it
-ZH_DEV void zp_put32(uint8_t* q, uint32_t len, const zh_q4& A, const zh_q4& Z)
-{
-    uint8_t* const qe = q + len;                           // (pieces addressed from the end: qe - 16 .. qe, at least q - 15 -> the padding)
-    if (len >= 16) {
-        zh_st64(q, (uint64_t)A.a | ((uint64_t)A.b << 32)); zh_st64(q + 8, (uint64_t)A.c | ((uint64_t)A.d << 32));
-        zh_st64(qe - 16, (uint64_t)Z.a | ((uint64_t)Z.b << 32)); zh_st64(qe - 8, (uint64_t)Z.c | ((uint64_t)Z.d << 32));
-    } else if (len >= 8) {
-        zh_st64(q, (uint64_t)A.a | ((uint64_t)A.b << 32)); zh_st64(qe - 8, (uint64_t)Z.c | ((uint64_t)Z.d << 32));
-    } else if (len >= 4) {
-        zh_st32(q, A.a); zh_st32(qe - 4, Z.d);
-    } else if (len >= 2) {
-        zh_st16(q, (uint16_t)A.a); zh_st16(qe - 2, (uint16_t)(Z.d >> 16));
-    } else if (len) q[0] = (uint8_t)A.a;
-}
-// One match of the sequential pass whose source is not plainly inside the assembly buffer: it starts below the batch (global memory / the
-// dictionary), or overlaps its own output (offset < length), or is longer than 256 bytes. Uniform arguments; d / sR batch-relative.
-template <bool DICT>
-ZH_DEVFN void zp_seq_match_generic(uint8_t* asmb, const uint8_t* dst, const uint8_t* dictEnd, uint32_t ob, uint32_t d, int32_t sR, uint32_t n)
-{
-    const uint32_t lane = zh_lane();
-    const uint32_t ofs = (uint32_t)((int32_t)d - sR);
-    if (ofs >= 64 || ofs >= n) {
-        for (uint32_t c = 0; c < n; c += 64) {
-            const uint32_t j = c + lane;
-            if (j < n) { const int32_t sp = sR + (int32_t)j; asmb[d + j] = sp >= 0 ? asmb[sp] : (uint8_t)zd_hist_byte(dst, dictEnd, (int32_t)ob + sp); }
-            if (ofs < n) zh_wave_fence();                  // the next 64 bytes read these
-        }
-    } else {                                               // period `ofs` < 64: every source byte precedes d
-        uint32_t idx = lane % ofs; const uint32_t adv = 64 % ofs;
-        for (uint32_t j = lane; j < n; j += 64) {
-            const int32_t sp = sR + (int32_t)idx;
-            asmb[d + j] = sp >= 0 ? asmb[sp] : (uint8_t)zd_hist_byte(dst, dictEnd, (int32_t)ob + sp);
-            idx += adv; if (idx >= ofs) idx -= ofs;
-        }
-    }
-}
-
-// One compressed block: the sequences K2 left in slot `t`, the literals of slot `t` (or in place), executed at output position `opRef` of
-// the frame at `dst` (MB = false: the frame's only block, position 0). m = the block's record; srcOff / srcSize: where the frame lies in the
-// caller's source arena (raw literals are read in place). 0 or a zstd error code. Reference semantics: ZSTD_execSequence zstd.c:46634.
-template <bool DICT, bool PROF, bool MB>
-ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint64_t srcOff, uint64_t srcSize, uint8_t* dst,
-                           uint32_t cap, uint64_t cap64, uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
-{
-    const uint32_t lane = zh_lane();
-    const uint64_t* seqs = a.seqArena + (size_t)t * ZP_SEQ_CAP;
-    const bool litRLE = m.litMode == 2, litRaw = m.litMode == 0;
-    const uint32_t rleByte = m.litOff;
-    const uint8_t* litPtr = litRaw ? src + m.litOff : a.litArena + (size_t)t * ZP_LIT_STRIDE;
-    const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
-    const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
-    uint8_t* const asmb = L.asmb;
-    const uint32_t blockStart = MB ? opRef : 0u;
-    uint32_t op = blockStart, lp = 0, done = 0;
-    // The flush writes whole 16-byte units only: the last `carry` (< 16) bytes of a batch stay at the front of the assembly buffer and leave
-    // with the next batch. asmb[0] is the byte at absolute position ob = op - carry; every batch-relative offset below counts from ob.
-    uint32_t carry = 0;
-    const uint32_t nbSeq = m.nbSeq;
-    uint64_t qNext = lane < nbSeq ? *(seqs + lane) : 0;                  // the next batch's sequences are requested a batch ahead
-    zh_q4 rleQ; rleQ.a = rleQ.b = rleQ.c = rleQ.d = 0x01010101u * (rleByte & 255u);
-    while (done < nbSeq) {
-        const uint32_t avail = nbSeq - done < 64 ? nbSeq - done : 64;
-        uint32_t myLL, myML, myOF;
-        {   const uint64_t q = qNext; myLL = ZP_SEQ_LL(q); myML = ZP_SEQ_ML(q); myOF = ZP_SEQ_OF(q); if (MB) myOF = zp_sym_resolve(myOF, R0, R1, R2); }
-        const bool inb = lane < avail;
-        if (MB && zh_ballot(inb && myOF == ZP_OF_LIMIT)) return ZP_RC_FALLBACK;      // an offset K2 could not pack: the generic kernel's frame
-        // a sequence of more than ZP_SMALL_MAX bytes ends the batch in front of it; first in line, it is executed alone, straight in global memory
-        const uint64_t bigMask = zh_ballot(inb && myLL + myML > ZP_SMALL_MAX);
-        const uint32_t n1 = bigMask ? (uint32_t)zh_ctz64(bigMask) : avail;
-        if (n1 == 0) {
-            const uint32_t bll = zh_bcast(myLL, 0), bml = zh_bcast(myML, 0), bof = zh_bcast(myOF, 0);
-            if (lp + bll > m.litSize) return ZE_CORRUPTION;
-            if ((uint64_t)op + bll + bml > cap) return ZE_DST_TOO_SMALL;
-            if (op + bll + bml - blockStart > blockMax) return ZE_CORRUPTION;
-            if (bof - 1 >= op + bll + dictSize) return ZE_CORRUPTION;              // (offset 0: K2's "repeat offset 1 minus one = 0")
-            if (lane < carry) dst[op - carry + lane] = asmb[lane];      // what the last flush held back
-            carry = 0;
-            zd_fence();
-            if (litRLE) zd_fill_wave(dst + op, rleByte, bll); else zd_copy_wave(dst + op, litPtr + lp, bll);
-            zd_fence();
-            zd_match_wave(dst, dictEnd, op + bll, bof, bml);
-            zd_fence();
-            op += bll + bml; lp += bll; done += 1;
-            qNext = done + lane < nbSeq ? *(seqs + done + lane) : 0;
-            continue;
-        }
-        {   const bool a1 = lane < n1; myLL = a1 ? myLL : 0u; myML = a1 ? myML : 0u; }
-        // ONE scan for both running sums: total bytes in the low half, literal bytes in the high half (64 x 1023 < 2^16)
-        const uint32_t pk = zh_scan_add((myLL + myML) | (myLL << 16));
-        const uint32_t incT = pk & 0xFFFFu, incL = pk >> 16;
-        const uint64_t fits = zh_ballot(lane < n1 && incT + carry <= ZP_ASM_BYTES);     // a prefix mask (incT is monotone); its first bit is set
-        const uint32_t cnt = (uint32_t)zh_popc64(fits);
-        qNext = done + cnt + lane < nbSeq ? *(seqs + done + cnt + lane) : 0;
-        const bool act = lane < cnt;
-        if (!act) { myLL = 0; myML = 0; myOF = 1; }
-        const uint32_t totL = zh_bcast(incL, cnt - 1), totT = zh_bcast(incT, cnt - 1);
-        if (lp + totL > m.litSize) return ZE_CORRUPTION;
-        if ((uint64_t)op + totT > cap) return ZE_DST_TOO_SMALL;
-        if (op + totT - blockStart > blockMax) return ZE_CORRUPTION;
-        const uint32_t ob = op - carry;
-        const uint32_t litStart = act ? lp + incL - myLL : lp;
-        const uint32_t oRel = incT - (myLL + myML) + carry, mRel = oRel + myLL;
-        if (zh_ballot(act && myOF - 1 >= ob + mRel + dictSize)) return ZE_CORRUPTION;      // (offset 0 = K2's "repeat offset 1 minus one = 0": wraps to the largest value; ob < 2^31, dictionary < 2^28)
-        ZD_TP(P, ZP_STAGE);
-        const int32_t sRel = (int32_t)mRel - (int32_t)myOF;               // the match source, batch-relative (below 0: before the batch)
-        const int32_t sEnd = sRel + (int32_t)myML;
-        const int32_t sAbs = (int32_t)ob + sRel;                          // frame-relative (below 0: the dictionary)
-        const bool hasM = act && myML > 0;
-        const bool farM = hasM && sEnd <= 0;                              // the whole source lies below the batch: global memory
-        // ---- literal runs of 1 .. ZP_OWN_MAX bytes by their own lanes. Reading 16 bytes around a run is harmless where the memory is ours:
-        // the literal arena (256 bytes of padding on both sides); literals left in the caller's frame only where the batch's runs keep 16
-        // bytes from both ends of the source arena / the frame -- otherwise this batch's runs are copied byte by byte (litOdd)
-        bool litOK = true;
-        if (litRaw) litOK = srcOff + m.litOff + lp >= 16 && (uint64_t)m.litOff + lp + totL + 16 <= srcSize;
-        const bool ownL = myLL > 0 && myLL <= ZP_OWN_MAX;                 // (inactive lanes: myLL == 0)
-        zh_q4 la, lz; la = rleQ; lz = rleQ;
-        if (!litRLE && litOK) { const uint8_t* q = litPtr + litStart; la = zp_ldq(q); lz = zp_ldq(q + myLL - 16); }
-        // ---- far matches of up to ZP_OWN_MAX bytes likewise, where 16 bytes before the match's end and behind its start are this frame's
-        // (or the dictionary's) bytes; the others join the sequential pass below
-        bool ownM;
-        const uint8_t* mp = dst;
-        {
-            bool reg = farM && myML <= ZP_OWN_MAX && sAbs >= 0 && sAbs + (int32_t)myML >= 16 && (uint64_t)(uint32_t)sAbs + 16 <= cap64;
-            if (DICT) {
-                const bool inDict = farM && myML <= ZP_OWN_MAX && sAbs + (int32_t)myML <= 0 && (uint32_t)(-sAbs) + 16 - myML <= dictSize && (uint32_t)(-sAbs) >= 16;
-                if (inDict) mp = dictEnd;
-                reg = reg || inDict;
-            }
-            ownM = reg;
-        }
-        zh_q4 ma, mz;
-        {   const uint8_t* q = ownM ? mp + sAbs : (const uint8_t*)seqs;            // (lanes without such a match read 16 bytes that are always there)
-            ma = zp_ldq(q); mz = zp_ldq(ownM ? q + myML - 16 : q); }
-        // ---- long items: each gets a range of lanes, one 16-byte unit per lane (the last one shifted back to end with the item)
-        const bool longL = myLL > ZP_OWN_MAX;
-        const bool longM = farM && myML > ZP_OWN_MAX && (sAbs >= 0 || (DICT && sAbs + (int32_t)myML <= 0));
-        const uint64_t longLMask = zh_ballot(longL), longMMask = zh_ballot(longM);
-        const bool seqM = hasM && !ownM && !longM;                        // reads the batch's own output, or is irregular: the sequential pass
-        if (longLMask | longMMask) {
-            for (int kind = 0; kind < 2; kind++) {
-                uint64_t mk = kind ? longMMask : longLMask;
-                const uint32_t vLen = kind ? myML : myLL;
-                const uint32_t vSrc = kind ? (uint32_t)sAbs : litStart;
-                const uint32_t vDst = kind ? mRel : oRel;
-                while (mk) {
-                    // hand out lanes: item after item while they fit
-                    uint32_t u0 = 0, owner = 0xFFFFFFFFu, ubase = 0;
-                    while (mk) {
-                        const uint32_t l = (uint32_t)zh_ctz64(mk);
-                        const uint32_t n = (zh_bcast(vLen, l) + 15) >> 4;              // <= 64
-                        if (u0 + n > 64) break;
-                        const bool mine = lane >= u0 && lane < u0 + n;
-                        owner = mine ? l : owner; ubase = mine ? u0 : ubase;
-                        u0 += n; mk &= mk - 1;
-                    }
-                    const bool have = owner != 0xFFFFFFFFu;
-                    const uint32_t ol = have ? owner : lane;
-                    const uint32_t len = zh_shfl(vLen, ol), so = zh_shfl(vSrc, ol), dd = zh_shfl(vDst, ol);
-                    if (have) {
-                        const uint32_t k = lane - ubase;
-                        const uint32_t off = 16 * k + 16 <= len ? 16 * k : len - 16;
-                        zh_q4 v;
-                        if (kind == 0) { if (litRLE) v = rleQ; else v = zp_ldq(litPtr + so + off); }
-                        else { const int32_t sm = (int32_t)so; v = zp_ldq((!DICT || sm >= 0 ? dst + sm : dictEnd + sm) + off); }
-                        uint8_t* q = asmb + dd + off;
-                        zh_st64(q, (uint64_t)v.a | ((uint64_t)v.b << 32)); zh_st64(q + 8, (uint64_t)v.c | ((uint64_t)v.d << 32));
-                    }
-                }
-            }
-        }
-        // ---- the own-lane items into the buffer
-        if (litOK) zp_put32(asmb + oRel, ownL ? myLL : 0u, la, lz);
-        else {                                                             // (rare: raw literals next to the ends of the caller's buffer)
-            for (uint64_t mk = zh_ballot(ownL); mk; mk &= mk - 1) {
-                const uint32_t l = (uint32_t)zh_ctz64(mk);
-                const uint32_t n = zh_bcast(myLL, l), so = zh_bcast(litStart, l), dd = zh_bcast(oRel, l);
-                if (lane < n) asmb[dd + lane] = litPtr[so + lane];
-            }
-        }
-        zp_put32(asmb + mRel, ownM ? myML : 0u, ma, mz);
-        zh_wave_fence();
-        ZD_TP(P, ZP_EXEC1);
-#ifndef ZP_K3_ROUNDS
-        // ---- the matches that read this batch's own output (and the irregular ones), one after the other in stream order: when a match's
-        // turn comes every byte it reads is final. Every instruction of this loop is paid ~14 times per batch, so the common case -- every such
-        // match of the batch lies plainly inside the buffer, does not overlap its own output and is 4 .. 64 bytes long -- is a loop without
-        // branches or exec changes: one v_readlane brings (destination | offset << 13 | length << 26), the wave copies a dword per lane with
-        // the offset clamped to length - 4 (lanes past the match repeat its last dword; sixteen lanes take part).
-        {
-            const bool plainS = seqM && sRel >= 0 && myOF >= myML && myML >= 4 && myML <= 63;
-            const uint64_t seqMask = zh_ballot(seqM);
-            const uint32_t pk3 = mRel | (myOF << 13) | (myML << 26);            // (plain: mRel < 8192, offset <= mRel, length < 64)
-            const uint32_t lane4 = 4 * lane;
-            if (seqMask == zh_ballot(plainS)) {
-                // (sixteen lanes cover 64 bytes; r04e: with all 64 lanes storing, 48 of them the SAME last dword, every store was a 48-way LDS
-                // conflict -- K3 14.2 ms instead of 11.1. On the device the exec mask is set ONCE around the loop -- v_readlane does not care --;
-                // the emulator's collectives want every lane, so there the lane test sits inside)
-#ifndef ZHIP_EMU
-                // (pk3 is pinned HERE, under the full exec mask: left to itself LLVM computes it inside the sixteen-lane region -- for sixteen lanes --
-                // and the v_readlane of a lane above them reads garbage: r04f, wrong bytes on the MI355X only)
-                const uint32_t pk3x = zh_opaque(pk3);
-                if (lane < 16) {
-                    for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
-                        const uint32_t v = zh_bcast(pk3x, (uint32_t)zh_ctz64(mk));
-                        const uint32_t d = v & 0x1FFFu, so = d - ((v >> 13) & 0x1FFFu), n4 = (v >> 26) - 4;
-                        const uint32_t off = lane4 < n4 ? lane4 : n4;
-                        const uint32_t w = zh_ld32(asmb + so + off);
-                        zh_st32(asmb + d + off, w);
-                    }
-                }
-                zh_wave_fence();
-#else
-                for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
-                    const uint32_t v = zh_bcast(pk3, (uint32_t)zh_ctz64(mk));
-                    const uint32_t d = v & 0x1FFFu, so = d - ((v >> 13) & 0x1FFFu), n4 = (v >> 26) - 4;
-                    const uint32_t off = lane4 < n4 ? lane4 : n4;
-                    if (lane < 16) { const uint32_t w = zh_ld32(asmb + so + off); zh_st32(asmb + d + off, w); }
-                    zh_wave_fence();
-                }
-#endif
-            } else {
-                for (uint64_t mk = seqMask; mk; mk &= mk - 1) {
-                    const uint32_t l = (uint32_t)zh_ctz64(mk);
-                    const uint32_t d = zh_shfl(mRel, l), n = zh_shfl(myML, l);
-                    const int32_t sR = (int32_t)zh_shfl((uint32_t)sRel, l);
-                    if (sR >= 0 && (uint32_t)sR + n <= d && n <= 256 && n >= 4) {      // plainly inside the buffer, not overlapping its own output
-                        const uint32_t off = 4 * lane + 4 <= n ? 4 * lane : n - 4;
-                        if (4 * lane < n) { const uint32_t w = zh_ld32(asmb + sR + off); zh_st32(asmb + d + off, w); }
-                    } else zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
-                    zh_wave_fence();
-                }
-            }
-        }
-#else
-        // ---- the matches that read this batch's own output (and the irregular ones). A match may start as soon as every earlier such match
-        // whose output it reads is done: `need` = the set of those (a contiguous index range, found by binary search over the batch-relative
-        // match extents), so the number of rounds is the dependency depth (4.3 on the bench corpus), not the number of matches (14): executed
-        // one after the other by the whole wave (r04a: ~37 instructions per match, 520 per batch) they cost more than the rounds' bookkeeping.
-        // A round serves its ready plain matches of up to ZP_OWN_MAX bytes by their own lanes (two 16-byte LDS reads, the same length classes
-        // as above) and every other ready match -- longer, overlapping its own output, or starting below the batch -- by the whole wave.
-        L.mBeg[lane] = (uint16_t)(act ? mRel : 0xFFFF); L.mEnd[lane] = (uint16_t)(act ? mRel + myML : 0xFFFF);
-        zh_wave_fence();
-        bool pending = seqM;
-        const bool plain = seqM && sRel >= 0 && myML <= ZP_OWN_MAX && myOF >= myML;
-        uint64_t need = 0;
-        if (pending) {
-            const uint32_t a0 = sRel > 0 ? (uint32_t)sRel : 0u;                                    // first buffer byte I read
-            uint32_t b0 = sEnd > 0 ? (uint32_t)sEnd : 0u;                                          // one past the last byte I read
-            if (b0 > mRel) b0 = mRel;                                                              // my own output is handled by me
-            uint32_t lo = 0, hi = 0;            // lo = first j with mEnd[j] > a0 ; hi = first j with mBeg[j] >= b0
-            for (uint32_t stp = 32; stp; stp >>= 1) { if (lo + stp <= 64 && L.mEnd[lo + stp - 1] <= a0) lo += stp; }
-            for (uint32_t stp = 32; stp; stp >>= 1) { if (hi + stp <= 64 && L.mBeg[hi + stp - 1] < b0) hi += stp; }
-            if (hi > lane) hi = lane;           // only earlier sequences can feed me
-            if (lo < hi) need = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
-        }
-        const uint64_t seqMask = zh_ballot(pending);
-        need &= seqMask;                        // literals and staged matches are already in the buffer
-        uint64_t doneMask = ~seqMask;
-        for (;;) {
-            const uint64_t pend = zh_ballot(pending);
-            if (!pend) break;
-            const bool ready = pending && (need & ~doneMask) == 0;
-            const uint64_t waveReady = zh_ballot(ready && !plain);
-            const bool own = ready && plain;
-            {   zh_q4 ra, rz;
-                const uint8_t* q = asmb + (own ? (uint32_t)sRel : 0u);
-                ra = zp_ldq(q); rz = zp_ldq(q + (own ? myML : 16u) - 16);
-                zp_put32(asmb + mRel, own ? myML : 0u, ra, rz); }
-            uint64_t newDone = zh_ballot(own);
-            if (own) pending = false;
-            for (uint64_t lm = waveReady; lm; lm &= lm - 1) {
-                const uint32_t pf = (uint32_t)zh_ctz64(lm);
-                // (ds_bpermute, not v_readlane: a readlane'd value that feeds an LDS address crashes this LLVM)
-                const uint32_t d = zh_shfl(mRel, pf), n = zh_shfl(myML, pf);
-                const int32_t sR = (int32_t)zh_shfl((uint32_t)sRel, pf);
-                zh_wave_fence();
-                zp_seq_match_generic<DICT>(asmb, dst, dictEnd, ob, d, sR, n);
-                if (lane == pf) pending = false;
-                newDone |= 1ull << pf;
-            }
-            doneMask |= newDone;
-            zh_wave_fence();
-        }
-#endif
-        ZD_TP(P, ZP_EXEC2);
-        // vmcnt counts stores as well: the next batch's sequences (requested long ago) are taken into registers HERE, before the flush's
-        // stores are issued -- read at the top of the next batch, the wait for them would also sit out the stores just issued
-        qNext = zh_opaque64(qNext);
-        const uint32_t totB = totT + carry, whole = totB & ~15u;         // bytes in the buffer; the part that leaves now
-        {
-            uint8_t* out = dst + ob;
-            for (uint32_t j = lane * 16; j < whole; j += 1024) {
-                const uint32_t* s4 = (const uint32_t*)(asmb + j);
-                ZdPack16 v; v.a = s4[0]; v.b = s4[1]; v.c = s4[2]; v.d = s4[3];
-                *(ZdPack16*)(out + j) = v;
-            }
-        }
-        carry = totB - whole;
-        zh_wave_fence();
-        if (carry && whole) {                                              // the tail moves to the front (one 16-byte read / write; every flush read is done)
-            uint64_t t0 = 0, t1 = 0;
-            if (lane == 0) { t0 = zh_ld64(asmb + whole); t1 = zh_ld64(asmb + whole + 8); }
-            zh_wave_fence();
-            if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
-        }
-        zh_wave_fence();
-        ZD_TP(P, ZP_FLUSH);
-        op += totT; lp += totL; done += cnt;
-    }
-    if (lane < carry) dst[op - carry + lane] = asmb[lane];               // what the last flush held back
-    zd_fence();
-    const uint32_t rest = m.litSize - lp;
-    if ((uint64_t)op + rest > cap) return ZE_DST_TOO_SMALL;
-    if (op + rest - blockStart > blockMax) return ZE_CORRUPTION;
-    if (litRLE) zd_fill_wave(dst + op, rleByte, rest); else zd_copy_wave(dst + op, litPtr + lp, rest);
-    op += rest;
-    opRef = op;
-    return 0;
-}
-#endif
 
 // what ends a frame: the content size it announced, its checksum (zstd.c:44264-44277). All lanes call.
 ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, uint32_t fcsLo, uint32_t fcsHi, uint32_t hasChecksum, uint32_t checksum)
@@ -2151,6 +1250,9 @@ ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, ui
     return 0;
 }
 
+#ifdef ZP_K3_DIAG_FLOOR
+#include "../../tests/ubench/k3_floor_diag.hpp"
+#endif
 template <bool DICT, bool PROF>
 ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint32_t* pProduced, ZdProf& P)
 {
@@ -2161,10 +1263,10 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     const uint64_t cap64 = a.dstSegs[2 * (size_t)f + 1];
     const uint32_t cap = cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap64;
     uint32_t op = 0;
-#ifndef ZP_K3_R4
-    int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
+#ifdef ZP_K3_DIAG_FLOOR          // DIAGNOSTIC ONLY (wrong bytes): the batch loop reduced to its memory traffic -- tests/ubench/k3_floor_diag.hpp
+    int e = zp_exec_block_floor<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op);
 #else
-    int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
+    int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
 #endif
     if (e) return e;
     e = zp_exec_frame_end(L, dst, op, m.fcsLo, m.fcsHi, m.hasChecksum, m.checksum);
@@ -2202,11 +1304,7 @@ ZH_DEVFN int zp_exec_frame_mb(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, u
             op += size;
             continue;
         }
-#ifndef ZP_K3_R4
         const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
-#else
-        const int e = zp_exec_block<DICT, false, true>(a, L, m, t, src, a.srcSegs[2 * (size_t)f], a.srcSegs[2 * (size_t)f + 1], dst, cap, cap64, rec.blockMax, op, R0, R1, R2, P);
-#endif
         if (e) return e;
         zd_fence();
         if (m.nbSeq) {
@@ -2225,30 +1323,19 @@ template <bool DICT, bool PROF, bool MB = false>
 ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
 {
     const uint32_t lane = zh_lane();
-    // Frames are taken in index order. -DZP_K3_SORTED_ORDER takes them in K2's work order instead (by decreasing sequence count, then the frames
-    // without sequences by index) so that the launch's tail is made of short frames -- MEASURED SLOWER (r03f: 12.95 against 12.18 ms per 65 536
-    // frames): with every wave on a many-sequence frame at the same time the far-match gathers of 4 096 waves peak together (stage phase 758 K ->
-    // 861 K wave-cycles per frame); the corpus' own mix of heavy and light frames spreads them.
-#if !defined(ZP_K3_SORTED_ORDER)
-    const uint32_t ordered = 0;
-#else
-    const uint32_t ordered = MB ? 0u : a.counters[1];
-#endif
+    // Frames are taken in index order (K2's work order -- longest first -- measured slower, r03f: every wave on a many-sequence frame at the same time
+    // makes the far-match gathers of 4 096 waves peak together; the corpus' own mix of heavy and light frames spreads them).
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 2, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
         const uint32_t k = zh_first(L.misc[7]);
         zh_sync();
-        if (k >= ordered + a.count) break;
-        const uint32_t i = k < ordered ? a.order[k] : k - ordered;
+        if (k >= a.count) break;
+        const uint32_t i = k;
         if (MB) { if (a.frameRecs[i].path != 1) continue; }
         else {
-#ifndef ZP_K3_SORTED_ORDER
         if (a.meta[i].path != 1) continue;
-#else
-        if (a.meta[i].path != 1 || (k >= ordered && a.meta[i].nbSeq != 0)) continue;
-#endif
         }
         uint32_t produced = 0;
         ZdProf P; P.on = PROF && a.prof != nullptr;

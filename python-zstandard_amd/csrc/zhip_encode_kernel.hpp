@@ -1279,240 +1279,6 @@ ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSi
 }
 
 
-// ------------------------------------------------------------------------------------------ double-fast without tables: the LINK form (round 4)
-// ze_dfast_flat's bound is the reference's own data structure: every probed position reads a cell and writes a cell in each of two tables
-// (zstd.c:31121), and with a chunk of frames in flight every one of those is a random HBM transaction. The link form asks the
-// same questions without tables. A parallel pre-pass writes one 8-byte RECORD per source position p (position-ordered, so the search reads
-// them as a stream):
-//     bits  0-16  prevL + 1 : the nearest earlier position whose long hash (8 bytes, hashLog bits) equals p's, + 1; 0 = none
-//     bits 17-33  prevS + 1 : the same for the short hash (minMatch bytes, chainLog bits)
-//     bits 34-43  tagL      : ten more bits of p's long-hash product (equal 8 bytes => equal tags)
-//     bits 44-53  tagS      : ten bits of a hash of p's first 4 bytes (the short check compares 4 bytes, zstd.c:31167)
-//     bit  54/55  tmL / tmS : prevL's / prevS's tag equals p's (worth fetching that candidate's bytes together with its record)
-//     bits 56-63  FLAGS, zero after the pre-pass: bit 0 / 1 = the search has written p into the long / short table
-// "What does the long table hold for hash(p)" is then: follow prevL from p to the first position whose long flag is set (the reference's
-// writes are ascending in position, so the nearest flagged position with p's hash IS the cell's last writer -- with one exception, the write
-// of ip1 before curr + 2, handled where the flags are set). No table, no hashing in the search, no random writes: a flag is one byte stored
-// into a record. What it costs instead is the walk: 1.9 random record reads per probed position on the bench corpus against two cell reads
-// and two write-backs (tests/tools/prev_chain_study.py, which also checks a scalar model of this function against the oracle's search).
-//
-// The walks are of uneven length, so the search is a per-lane STATE MACHINE: every trip of the loop issues the same ten loads for every lane
-// -- addresses chosen by the lane's state, a lane with nothing to fetch reads its own first bytes -- waits once, and lets every lane take
-// whatever steps its data allows. A lane never waits for a neighbour's match extension or longer walk, only for the slowest load of the trip.
-#define ZL_PREVL(lo) ((lo) & 0x1FFFFu)
-#define ZL_PREVS(lo, hi) (((lo) >> 17) | (((hi) & 3u) << 15))
-#define ZL_TAGL_EQ(h1, h2) ((((h1) ^ (h2)) & (0x3FFu << 2)) == 0)
-#define ZL_TAGS_EQ(h1, h2) ((((h1) ^ (h2)) & (0x3FFu << 12)) == 0)
-#define ZL_TML(hi) (((hi) >> 22) & 1u)
-#define ZL_TMS(hi) (((hi) >> 23) & 1u)
-#define ZL_FL(hi) (((hi) >> 24) & 1u)
-#define ZL_FS(hi) (((hi) >> 25) & 1u)
-#define ZL_REC_BYTES 8u
-enum { ZL_PROBE = 0, ZL_WALK, ZL_COUNT, ZL_CATCH, ZL_NLWALK, ZL_REPCHK, ZL_DONE };
-enum { ZLK_REP1 = 0, ZLK_LONG, ZLK_SHORT, ZLK_LONG1, ZLK_REPL };
-ZH_DEV uint64_t ze_ldrec(const uint8_t* rec, uint32_t pos) { return *(const uint64_t*)(rec + (size_t)pos * ZL_REC_BYTES); }
-ZH_DEV void ze_flag(uint8_t* rec, uint32_t pos, uint32_t v) { rec[(size_t)pos * ZL_REC_BYTES + 7] = (uint8_t)v; }
-
-// The pre-pass in its plain form, one lane per source with the source's slot of the flat tables as scratch (zeroed by the host): every
-// position is entered into both tables in order, the cell's previous content is the link. Cells: (position + 1) << 10 | tag.
-// (zhip_encode_links_pre_kernel does the same with the tables in LDS; this one is what the emulator and the GPU tests compare it with.)
-ZH_DEV void ze_links_pre_lane(uint8_t* rec, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall)
-{
-    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
-    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
-    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
-    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
-    for (uint32_t p = 0; p + 8 <= srcSize; p++) {
-        const uint64_t w = zh_ld64(src + p);
-        const uint32_t pl = (uint32_t)((w * 0xCF1BBCDCB7A56463ull) >> 32), ps = (uint32_t)(((w << shlS) * primeS) >> 32);
-        const uint32_t tagL = (pl >> (shL - 10)) & 0x3FFu, tagS = ((uint32_t)w * 2654435761u) >> 22;
-        const uint32_t oL = hashLong[pl >> shL], oS = hashSmall[ps >> shS];
-        hashLong[pl >> shL] = ((p + 1) << 10) | tagL; hashSmall[ps >> shS] = ((p + 1) << 10) | tagS;
-        const uint64_t tmL = (oL && (oL & 0x3FFu) == tagL) ? 1u : 0u, tmS = (oS && (oS & 0x3FFu) == tagS) ? 1u : 0u;
-        *(uint64_t*)(rec + (size_t)p * ZL_REC_BYTES) = (uint64_t)(oL >> 10) | ((uint64_t)(oS >> 10) << 17) | ((uint64_t)tagL << 34) | ((uint64_t)tagS << 44) | (tmL << 54) | (tmS << 55);
-    }
-}
-
-// ZSTD_compressBlock_doubleFast_noDict_generic (zstd.c:31039) for one source that is one block, from the records. Sequences only. srcSize in
-// [64, 128 KiB]. Returns nbSeq.
-ZH_DEV uint32_t ze_dfast_links(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, uint8_t* rec)
-{
-    const uint32_t ilimit = srcSize - 8;
-    uint32_t st = ZL_PROBE, ip = 1, anchor = 0, off1 = 1, off2 = 0, step = 1, nextStep = 1 + 256, nseq = 0;   // repcodes 1, 4: 4 reaches before the frame and is parked (zstd.c:31091-31098)
-    uint32_t recLo, recHi, rpP; uint64_t wP;                                   // the probe position's record, its 8 bytes, the 4 bytes at ip + 1 - off1
-    uint32_t recNLo = 0, recNHi = 0, rpN = 0; uint64_t wN = 0;                 // the same for ip + step, fetched while ip's walks run
-    { const uint64_t r = ze_ldrec(rec, 1); recLo = (uint32_t)r; recHi = (uint32_t)(r >> 32); wP = zh_ld64(src + 1); rpP = zh_ld32(src + 1); }
-    uint32_t qL = 0, qS = 0, candL = 0, candS = 0, phL = 2, phS = 2;           // a walk: q = the position (+ 1) whose record is being fetched; ph 0 = record due, 1 = candidate's bytes due, 2 = settled
-    bool mL = false, mS = false, specL = false, specS = false, pfPending = false;
-    uint32_t curr = 0, ipm = 0, mpos = 0, mLength = 0, len = 0, ca = 0, cb = 0, kind = 0, offset = 0, mposS = 0;
-    // the load slots: record positions (A, B, E), source offsets of 8-byte loads (C, D, F, H, I, J) and of 4-byte loads (G, G2)
-    uint32_t oA = 0, oB = 0, oE = 0, oC = 0, oD = 0, oF = 0, oH = 0, oI = 0, oJ = 0, oG = 0, oG2 = 0;
-    while (st != ZL_DONE) {
-        ZE_STAT(10);
-        uint64_t vA = ze_ldrec(rec, oA), vB = ze_ldrec(rec, oB), vE = ze_ldrec(rec, oE);
-        uint64_t vC = zh_ld64(src + oC), vD = zh_ld64(src + oD), vF = zh_ld64(src + oF), vH = zh_ld64(src + oH), vI = zh_ld64(src + oI), vJ = zh_ld64(src + oJ);
-        uint32_t vG = zh_ld32(src + oG), vG2 = zh_ld32(src + oG2);
-        vA = zh_opaque64(vA); vB = zh_opaque64(vB); vE = zh_opaque64(vE); vC = zh_opaque64(vC); vD = zh_opaque64(vD); vF = zh_opaque64(vF);      // no load sinks into a branch
-        vH = zh_opaque64(vH); vI = zh_opaque64(vI); vJ = zh_opaque64(vJ); vG = zh_opaque(vG); vG2 = zh_opaque(vG2);
-        oA = oB = oE = 0; oC = oD = oF = oH = oI = oJ = 0; oG = oG2 = 0;
-        bool finish = false;                                                 // a match is complete: ipm, mLength, kind (and mpos / offset for found >= 2)
-
-        if (st == ZL_REPCHK) {                                               // after a match: the immediate repeat-offset test (zstd.c:31236), else a fresh probe at ip
-            if (off2 > 0 && (uint32_t)vC == vG) { kind = ZLK_REPL; ca = ip + 4; cb = ip + 4 - off2; len = 0; st = ZL_COUNT; }
-            else {
-            recLo = (uint32_t)vE; recHi = (uint32_t)(vE >> 32); wP = vC; rpP = vG2;
-            step = 1; nextStep = ip + 256; st = ZL_PROBE;
-            }
-        }
-        else if (st == ZL_COUNT) {                                           // ZSTD_count (zstd.c:20008), up to 24 bytes a trip
-            const uint32_t room = srcSize - (ca + len);
-            const uint32_t nAvail = room >= 24 ? 3u : room >> 3;
-            uint32_t add = 0; bool ended = false;
-            const uint64_t d0 = vC ^ vD, d1 = vF ^ vH, d2 = vI ^ vJ;
-            if (nAvail >= 1) { if (d0) { add = (uint32_t)(zh_ctz64(d0) >> 3); ended = true; } else add = 8; }
-            if (!ended && nAvail >= 2) { if (d1) { add += (uint32_t)(zh_ctz64(d1) >> 3); ended = true; } else add += 8; }
-            if (!ended && nAvail >= 3) { if (d2) { add += (uint32_t)(zh_ctz64(d2) >> 3); ended = true; } else add += 8; }
-            len += add;
-            if (!ended && nAvail < 3) { while (ca + len < srcSize && src[ca + len] == src[cb + len]) len++; ended = true; }     // the source's last bytes
-            if (ended) {
-                if (kind == ZLK_REP1) { ipm = ip + 1; mLength = len + 4; finish = true; }
-                else if (kind == ZLK_LONG) { mLength = len + 8; st = ZL_CATCH; }
-                else if (kind == ZLK_SHORT) {                                // a short match: is there a long one at ip + step? (zstd.c:31188)
-                    mLength = len + 4;
-                    qL = ZL_PREVL(recNLo); phL = qL ? 0u : 2u; mL = false; candL = 0; specL = qL && ZL_TML(recNHi);
-                    st = ZL_NLWALK;
-                }
-                else if (kind == ZLK_LONG1) {
-                    if (len + 8 > mLength) { ipm = ip + step; mLength = len + 8; mpos = candL - 1; }
-                    offset = ipm - mpos; st = ZL_CATCH;
-                }
-                else {                                                       // an immediate repeat-offset match at ip (zstd.c:31240-31249)
-                    const uint32_t t = off2; off2 = off1; off1 = t;
-                    ze_flag(rec, ip, 3);
-                    seqs[nseq++] = ZE_SEQ_PACK(1, 0, len + 4);
-                    ip += len + 4; anchor = ip;
-                    st = ip <= ilimit ? ZL_REPCHK : ZL_DONE;
-                }
-                if (st == ZL_CATCH && !(ipm > anchor && mpos > 0)) { finish = true; }                   // nothing to catch up
-            }
-        }
-        else if (st == ZL_CATCH) {                                           // catch up (zstd.c:31182, :31204), 8 bytes a trip
-            const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
-            const uint64_t d = vC ^ vD;
-            uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
-            if (k > room) k = room;
-            ipm -= k; mpos -= k; mLength += k;
-            if (k < 8 || !(ipm > anchor && mpos > 0)) finish = true;
-        }
-        else if (st == ZL_NLWALK) {
-            if (phL == 0) {
-                const uint32_t lo = (uint32_t)vA, hi = (uint32_t)(vA >> 32);
-                if (ZL_FL(hi)) {
-                    candL = qL;
-                    if (ZL_TAGL_EQ(hi, recNHi)) { if (specL) { mL = vC == wN; phL = 2; } else phL = 1; }
-                    else phL = 2;
-                } else { qL = ZL_PREVL(lo); specL = false; if (!qL) phL = 2; }
-            } else if (phL == 1) { mL = vC == wN; phL = 2; }
-            if (phL == 2) {
-                ipm = ip; mpos = mposS; offset = ip - mposS;
-                if (mL) { kind = ZLK_LONG1; ca = ip + step + 8; cb = candL - 1 + 8; len = 0; st = ZL_COUNT; }
-                else { st = ZL_CATCH; if (!(ipm > anchor && mpos > 0)) finish = true; }
-            }
-        }
-        else if (st == ZL_WALK) {
-            if (pfPending) { recNLo = (uint32_t)vE; recNHi = (uint32_t)(vE >> 32); wN = vF; rpN = vG; pfPending = false; }
-            if (phL == 0) {
-                const uint32_t lo = (uint32_t)vA, hi = (uint32_t)(vA >> 32);
-                if (ZL_FL(hi)) {                                             // the long table's content for hash(ip)
-                    candL = qL;
-                    if (ZL_TAGL_EQ(hi, recHi)) { if (specL) { mL = vC == wP; phL = 2; } else phL = 1; }
-                    else phL = 2;
-                } else { qL = ZL_PREVL(lo); specL = false; if (!qL) phL = 2; }
-            } else if (phL == 1) { mL = vC == wP; phL = 2; }
-            if (phS == 0) {
-                const uint32_t lo = (uint32_t)vB, hi = (uint32_t)(vB >> 32);
-                if (ZL_FS(hi)) {
-                    candS = qS;
-                    if (ZL_TAGS_EQ(hi, recHi)) { if (specS) { mS = (uint32_t)vD == (uint32_t)wP; phS = 2; } else phS = 1; }
-                    else phS = 2;
-                } else { qS = ZL_PREVS(lo, hi); specS = false; if (!qS) phS = 2; }
-            } else if (phS == 1) { mS = (uint32_t)vD == (uint32_t)wP; phS = 2; }
-            if (phL == 2 && mL) {                                            // zstd.c:31150
-                ZE_STAT(11);
-                ipm = ip; mpos = candL - 1; offset = ip - mpos;
-                kind = ZLK_LONG; ca = ip + 8; cb = mpos + 8; len = 0; st = ZL_COUNT;
-            } else if (phL == 2 && phS == 2) {
-                if (mS) { ZE_STAT(11); mposS = candS - 1; kind = ZLK_SHORT; ca = ip + 4; cb = mposS + 4; len = 0; st = ZL_COUNT; }     // zstd.c:31167
-                else {                                                       // no match here: go on (zstd.c:31203-31211)
-                    const uint32_t ip1 = ip + step;
-                    if (ip1 >= nextStep) { step++; nextStep += 256; }
-                    ip = ip1; recLo = recNLo; recHi = recNHi; wP = wN; rpP = rpN; st = ZL_PROBE;
-                }
-            }
-        }
-
-        if (st == ZL_CATCH && finish == false && mpos < 8) {                // (the match source lies in the frame's first bytes: byte by byte)
-            while (ipm > anchor && mpos > 0 && src[ipm - 1] == src[mpos - 1]) { ipm--; mpos--; mLength++; }
-            finish = true;
-        }
-        if (finish) {
-            uint32_t flag1 = 0; const uint32_t i1 = curr + step;
-            if (kind == ZLK_REP1) seqs[nseq++] = ZE_SEQ_PACK(1, ipm - anchor, mLength);
-            else {
-                off2 = off1; off1 = offset;
-                flag1 = step < 4 ? 1u : 0u;                                  // zstd.c:31213: hashLong[hl1] = ip1
-                seqs[nseq++] = ZE_SEQ_PACK(offset + 3, ipm - anchor, mLength);
-            }
-            ip = ipm + mLength; anchor = ip;
-            if (ip <= ilimit) {
-                // the complementary insertions (zstd.c:31227-31232): curr + 2 in both tables, ip - 2 in the long, ip - 1 in the short one. One flag
-                // byte per position, so positions that coincide are written once with every bit they get. ip1's long write precedes that of
-                // curr + 2: where ip1 == curr + 3 hashes like curr + 2 the cell ends up holding curr + 2, i.e. ip1 is not flagged.
-                const uint32_t ins = curr + 2, e2 = ip - 2, e1 = ip - 1;
-                if (flag1 && i1 == curr + 3 && ZL_PREVL(recNLo) == ins + 1) flag1 = 0;
-                const uint32_t fIns = 3u | (e2 == ins ? 1u : 0u) | (e1 == ins ? 2u : 0u) | ((flag1 && i1 == ins) ? 1u : 0u);
-                const uint32_t fE2 = 1u | (e2 == ins ? 3u : 0u) | ((flag1 && i1 == e2) ? 1u : 0u);
-                const uint32_t fE1 = 2u | (e1 == ins ? 3u : 0u) | ((flag1 && i1 == e1) ? 1u : 0u);
-                if (flag1) ze_flag(rec, i1, 1u | (i1 == ins ? 3u : 0u) | (i1 == e1 ? 2u : 0u));
-                ze_flag(rec, ins, fIns); ze_flag(rec, e2, fE2); ze_flag(rec, e1, fE1);
-                st = ZL_REPCHK;
-            } else { if (flag1) ze_flag(rec, i1, 1); step = 1; nextStep = ip + 256; st = ZL_PROBE; }
-        }
-
-        if (st == ZL_PROBE) {
-            const uint32_t ip1 = ip + step;
-            if (ip1 > ilimit) st = ZL_DONE;
-            else {
-                curr = ip;
-                ze_flag(rec, ip, 3);                                         // zstd.c:31121: hashLong[hl0] = hashSmall[hs0] = curr
-                if (off1 > 0 && rpP == (uint32_t)(wP >> 8)) { ZE_STAT(11); kind = ZLK_REP1; ca = ip + 5; cb = ip + 5 - off1; len = 0; st = ZL_COUNT; }   // zstd.c:31124
-                else {
-                    qL = ZL_PREVL(recLo); qS = ZL_PREVS(recLo, recHi);
-                    phL = qL ? 0u : 2u; phS = qS ? 0u : 2u; mL = mS = false; candL = candS = 0;
-                    specL = qL && ZL_TML(recHi); specS = qS && ZL_TMS(recHi);
-                    pfPending = true; st = ZL_WALK;
-                    oE = ip1; oF = ip1; oG = ip1 + 1 - off1;
-                }
-            }
-        }
-        // the loads of the next trip
-        if (st == ZL_WALK) {
-            if (phL == 0) { oA = qL - 1; if (specL) oC = qL - 1; } else if (phL == 1) oC = candL - 1;
-            if (phS == 0) { oB = qS - 1; if (specS) oD = qS - 1; } else if (phS == 1) oD = candS - 1;
-        } else if (st == ZL_NLWALK) {
-            if (phL == 0) { oA = qL - 1; if (specL) oC = qL - 1; } else if (phL == 1) oC = candL - 1;
-        } else if (st == ZL_COUNT) {
-            const uint32_t room = srcSize - (ca + len);
-            if (room >= 8) { oC = ca + len; oD = cb + len; }
-            if (room >= 16) { oF = ca + len + 8; oH = cb + len + 8; }
-            if (room >= 24) { oI = ca + len + 16; oJ = cb + len + 16; }
-        } else if (st == ZL_CATCH) { oC = ipm - 8; oD = mpos - 8; }
-        else if (st == ZL_REPCHK) { oC = ip; oG = ip - off2; oG2 = ip + 1 - off1; oE = ip; }
-    }
-    return nseq;
-}
-
-
 // ------------------------------------------------------------------------------------------ fast strategy (levels 1-2, negative levels)
 // ZSTD_compressBlock_fast_noDict_generic (zstd.c:31906) for a block that is the whole frame: one hash table of hashLog bits over
 // minMatch bytes, cells hold position + 2. Positions are examined in pairs `step` apart (step grows by one per 128 bytes without a
@@ -3231,8 +2997,8 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
-                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src)
-                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
+                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle)
+                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;
@@ -3240,43 +3006,6 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     a.meta[i] = m;
 }
 
-// E1 links: the double-fast search in its link form (ze_dfast_links). Same frames as the flat kernel takes without a dictionary; what it
-// declines goes to the lane-serial kernel's list as there. The pre-pass kernels write the records first and decide the same way.
-ZH_DEV bool ze_links_takes(const ZhipEncodeArgs& a, uint32_t i, ZePar& cp, uint32_t& srcSize)
-{
-    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)(a.first + i) + 1];
-    srcSize = (uint32_t)srcSize64;
-    if (srcSize64 > ZF_BLOCK_MAX || srcSize < 64 || (size_t)srcSize * ZL_REC_BYTES > a.linkStride) return false;
-    if (ze_get_cparams(cp, a.rows, srcSize) != 0) return false;
-    return cp.strat == 2 && cp.hlog <= 17 && cp.clog <= 17 && cp.hlog >= 10 && cp.clog >= 10;
-}
-ZH_DEVFN void ze_links_pre_lane_body(const ZhipEncodeArgs& a)       // the plain pre-pass: a lane per frame, the flat tables as scratch
-{
-    const uint32_t i = zh_block() * 64 + zh_lane();
-    if (i >= a.count) return;
-    ZePar cp; uint32_t srcSize;
-    if (!ze_links_takes(a, i, cp, srcSize) || (size_t)(4u << cp.hlog) + (4u << cp.clog) > a.tableStride) return;
-    uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)i * a.tableStride);
-    ze_links_pre_lane(a.linkRecs + (size_t)i * a.linkStride, a.src + a.srcSegs[2 * (size_t)(a.first + i)], srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashLong + (1u << cp.hlog));
-}
-ZH_DEVFN void ze_match_links_body(const ZhipEncodeArgs& a)
-{
-    const uint32_t lane = zh_lane();
-    const uint32_t i = zh_block() * a.linkLanes + lane;
-    if (lane >= a.linkLanes || i >= a.count) return;
-    const uint32_t f = a.first + i;
-    ZeMeta m; m.nbSeq = 0; m.litSize = 0; m.mode = 0; m.pad = 0;
-    if (a.srcSegs[2 * (size_t)f + 1] > ZF_BLOCK_MAX) { m.mode = 3; a.meta[i] = m; a.bigList[zh_atomic_add(a.bigCount, 1u)] = f; return; }
-    ZePar cp; uint32_t srcSize;
-    if (!ze_links_takes(a, i, cp, srcSize)) { a.e1List[zh_atomic_add(a.e1Count, 1u)] = i; return; }       // the lane-serial kernel decides (and reports errors)
-    uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    m.nbSeq = ze_dfast_links((uint64_t*)(fr + ZE_ARENA_SEQ), a.src + a.srcSegs[2 * (size_t)f], srcSize, a.linkRecs + (size_t)i * a.linkStride);
-    m.mode = 4;
-#ifdef ZHIP_EMU
-    zd_stat[15]++;
-#endif
-    a.meta[i] = m;
-}
 
 // The flat search on sources of SEVERAL BLOCKS (ZeMbBlock in zhip_format.hpp): one lane per source the split kernel laid out, over all its
 // blocks -- the hash tables (the frame's slot of the flat tables, zeroed by the host) and the repeat offsets carry from block to block as in
@@ -3301,7 +3030,7 @@ ZH_DEVFN void ze_match_flat_mb_body(const ZhipEncodeArgs& a)
         const uint32_t be = blk[j].end;
         // (blocks too small to compress are not searched at all: ZSTD_buildSeqStore, zstd.c:26335)
         const uint32_t ns = be - bs < 7 ? 0u
-                          : a.mbProbes == 4 ? ze_dfast_flat_np<ZE_MB_POS_BITS, true, 4>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep, a.src)
+                          : a.mbProbes == 4 ? ze_dfast_flat_np<ZE_MB_POS_BITS, true, 4>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep, a.idle ? a.idle : src)
                                             : ze_dfast_flat_t<ZE_MB_POS_BITS, true>(sq + start, src, bs, be, cp.hlog, cp.clog, cp.mml, hl, hl + (1u << cp.hlog), rep);
         blk[j].seqStart = start; blk[j].nbSeq = ns; blk[j].rep0 = rep[0]; blk[j].rep1 = rep[1];
         start += ns; bs = be;
@@ -3361,10 +3090,10 @@ ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t 
     if (lane != 0) return;
     if (NPROBE == 4)
         m.nbSeq = staged ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
-                         : ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
+                         : ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
     else
     m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
-                     : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.src);
+                     : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

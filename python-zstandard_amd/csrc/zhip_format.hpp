@@ -130,10 +130,7 @@ struct ZhipEncodeArgs {
     uint32_t mbMaxBlocks, mbSeqCap;
     uint32_t mbLanes;               // sources per wave of the several-block flat search (<= 64)
     uint32_t mbProbes;              // probes per trip of that search: 2, or 4 for batches bound by a source's serial chain (ze_dfast_flat_np)
-    // the link form of the double-fast search (null / 0: the table form): one 8-byte record per source position, written by the pre-pass
-    uint8_t* linkRecs;              // count x linkStride
-    uint32_t linkStride;            // bytes per frame (8 x the largest source of the chunk, rounded)
-    uint32_t linkLanes;             // frames per wave of the link search (<= 64)
+    const uint8_t* idle;            // 16 readable bytes the library owns: where the flat searches' lanes without a plausible candidate point their loads (one address per wave)
     // dictionary compression (null / 0 without a dictionary): digested dictionary + its tagged hash tables, all in HBM
     const struct ZeCDict* cdict;
     const uint8_t* cdictContent;
@@ -232,18 +229,9 @@ struct ZdMeta {
 #define ZP_FSE_ML 512
 #define ZP_FSE_OF 1024
 #define ZP_FSE_CELLS 1280
-#ifndef ZP_K2_LANES
-#define ZP_K2_LANES 60
-#endif
-//      ^                                  // frames decoded per K2 wave (one lane each). 60: one wave fills a CU's LDS; smaller values give
-//                                         // several one-wave workgroups per CU (LDS per workgroup shrinks with it): 30 -> 2, 15 -> 4, 7 -> 8
-#define ZP_K2_LS (ZP_K2_LANES > 32 ? 6 : ZP_K2_LANES > 16 ? 5 : ZP_K2_LANES > 8 ? 4 : 3)   // log2 of the bit-reader ring's lane stride (dwords)
-#define ZP_K2_STRIDE 2564                               // LDS bytes per lane: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
+#define ZP_K2_STRIDE 2564                               // K2: LDS bytes of tANS tables per frame: 1280 2-byte cells + 4 (odd dword stride: equal indices never share a bank)
 #define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
 #define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)
-#if defined(ZP_K1B_R4B) && !defined(ZP_HUF_FRAMES)
-#define ZP_HUF_FRAMES 16                                // the two-level form (768 bytes of tables per frame): a full wave, four lanes per frame
-#endif
 #ifndef ZP_HUF_FRAMES
 #define ZP_HUF_FRAMES 8                                 // frames per K1b wave: 4 lanes (the 4 streams) each; 3 KiB of tables per frame, so 16 -> 3 waves
 #endif                                                  // per CU, 8 -> 6, 4 -> 12 (48 frames per CU either way; r02c: 8 is 7 % faster than 16 alone, 4 is slower)

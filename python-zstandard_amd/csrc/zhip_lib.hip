@@ -20,7 +20,7 @@
 #ifndef ZHIP_E1LDS_PER_CU
 #define ZHIP_E1LDS_PER_CU 4                // batches up to this many frames per CU take the LDS-source match kernel (ZHIP_E1LDS_MAX overrides the frame count); r02zq: 1 024 frames 147 ms against 159-163 with the flat kernel, 512: 89 against 146
 #endif
-static_assert(sizeof(ZpSeqLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufKernelLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
+static_assert(sizeof(ZpSeqQLDS) <= ZHIP_LDS_BYTES && sizeof(ZpHufKernelLDS) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 
 // ------------------------------------------------------------------------------------------ kernels
 ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_frames_kernel(ZhipDecodeArgs a)
@@ -58,11 +58,6 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq_mb_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpSeqQLDS L;
     zp_seqq_body<true>(a, L);
-}
-ZH_GLOBAL __launch_bounds__(64) void zhip_decode_seq1_kernel(ZhipPipeArgs a)          // rounds 1-2 form (a lane per frame, one wave per CU): ZHIP_K2_QUAD=0, A/B only
-{
-    __shared__ ZpSeqLDS L;
-    zp_seq_body(a, L);
 }
 #ifndef ZP_K3_MINWAVES
 #define ZP_K3_MINWAVES 6         // 77 VGPRs: own-lane items <= 16 bytes (zhip_decode_pipeline.hpp: ZP_LIT_SHORT / ZP_FAR_SHORT, r03g: 113 -> 96) and the phase timers
@@ -113,9 +108,6 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArg
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_kernel(ZhipEncodeArgs a) { ze_match_flat_body<3>(a); }      // three probes: launches of up to 65 536 sources
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }
-// the double-fast search in its link form (round 4): the records' pre-pass, then the search that follows them (ze_dfast_links)
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_links_pre_lane_kernel(ZhipEncodeArgs a) { ze_links_pre_lane_body(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_links_kernel(ZhipEncodeArgs a) { ze_match_links_body(a); }
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 template <uint32_t BYTES, int NPROBE> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
 {
@@ -277,47 +269,11 @@ static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed 
 // wraps)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
-    bool contiguous = false;       // experiment (r04v): ask for physically contiguous memory (hipDeviceMallocContiguous); falls back to hipMalloc where that is refused
-    // chunkBytes != 0: a reserved address range backed by separately created physical chunks of that size (hipMemCreate / hipMemMap) instead of
-    // one hipMalloc. For memory that is accessed at RANDOM by a whole chunk of frames -- the flat match kernel's hash tables -- this is worth
-    // 29 % of the access rate on the MI355X (tests/ubench/allocbench, profiles/r04x_allocbench.txt: 25.9 against 20.1 G cells/s for chunks of
-    // 2 - 64 MiB, 23.6 for 1 GiB chunks; hipMalloc's memory behaves like the largest chunks whether the VRAM is fresh, recycled or asked
-    // for as contiguous). Falls back to hipMalloc where the virtual-memory calls are refused.
-    size_t chunkBytes = 0, mapped = 0;      // mapped != 0: p is such a range of `mapped` bytes
-    int map_chunks(size_t want)
-    {
-        int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return -1;
-        hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
-        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
-        size_t gran = 0; if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return -1;
-        size_t chunk = (chunkBytes + gran - 1) / gran * gran;
-        const size_t nChunks = (want + chunk - 1) / chunk, total = nChunks * chunk;
-        void* va = nullptr;
-        if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) return -1;
-        size_t done = 0; bool ok = true;
-        for (; done < nChunks && ok; done++) {
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { ok = false; break; }
-            if (hipMemMap((char*)va + done * chunk, chunk, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); ok = false; break; }
-            (void)hipMemRelease(h);                                   // the mapping keeps the chunk alive
-        }
-        if (ok) {
-            hipMemAccessDesc ad; memset(&ad, 0, sizeof ad); ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
-            ok = hipMemSetAccess(va, total, &ad, 1) == hipSuccess;
-        }
-        if (!ok) { if (done) (void)hipMemUnmap(va, done * chunk); (void)hipMemAddressFree(va, total); (void)hipGetLastError(); return -1; }
-        p = va; cap = total; mapped = total; return 0;
-    }
     int reserve(size_t n) {
         if (n <= cap) return 0;
         release();
         size_t want = n + (n >> 3) + 4096;
         if (want < n) { g_lastError = "allocation size overflow"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
-        if (chunkBytes && want >= chunkBytes && map_chunks(want) == 0) return 0;
-        if (contiguous) {
-            if (hipExtMallocWithFlags(&p, want, hipDeviceMallocContiguous) == hipSuccess) { cap = want; return 0; }
-            (void)hipGetLastError(); p = nullptr;
-        }
         const hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
@@ -325,12 +281,11 @@ struct DevBuf {
     }
     void release()
     {
-        if (p && mapped) { (void)hipMemUnmap(p, mapped); (void)hipMemAddressFree(p, mapped); }
-        else if (p) (void)hipFree(p);
-        p = nullptr; cap = 0; mapped = 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
     }
 };
-#define ZHIP_NTIMER 11
+#define ZHIP_NTIMER 9
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
     std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
@@ -345,7 +300,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
-    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs, encLinkRecs;
+    DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
@@ -367,21 +322,15 @@ struct zhip_ctx {
     DevBuf hSrc, hDst, hSegs, hStatus, hDense;
     void* pinned = nullptr; size_t pinnedCap = 0;
     bool hpReady = false; hipStream_t hpH2D = nullptr, hpCompute = nullptr, hpD2H = nullptr;     // host pipeline: copy-in, kernels, copy-out
-    // compress chunk SLOTS (round 4): the host pipeline's compress chunks run on their own streams, side by side, each in its own part of the
-    // encode arenas -- the match kernel wants every frame of the batch in flight (two launches of 32 768 frames take 2 x 270 ms, one of 65 536
-    // takes 424), and a chunk can start as soon as ITS sources have arrived
-    hipStream_t hpComputeS[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t encSlots = 1, encSlot = 0, encSlotCap = 0;
     void* hpStage[2] = {nullptr, nullptr}; size_t hpStageCap[2] = {0, 0}; hipEvent_t hpStageFree[2] = {nullptr, nullptr}; int hpNextSlot = 0;
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; bool split = false; unsigned packThreads = 0; bool k2quad = true, blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; size_t eslots = 1 /* off: see zhip_compress_batch */, eslotItems = 0 /* 0: the batch divided by the slots */, eslotMin = 49152; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
         int e1lProbes = 2; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
-        int links = 0 /* the double-fast search's link form: 0 off, 1 with the plain pre-pass, 2 with the LDS pre-pass */; unsigned linkLanes = 16;
     } knob;
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
@@ -391,7 +340,7 @@ struct zhip_ctx {
     size_t device_bytes() const
     {
         const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &encWorkspace, &encMeta, &encArena,
-                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &encLinkRecs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
+                               &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
         for (const DevBuf* b : all) n += b->cap;
@@ -415,26 +364,17 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
         if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
-        if (const char* e = getenv("ZHIP_K2_QUAD")) k.k2quad = atol(e) != 0;
-        if (const char* e = getenv("ZHIP_SPLIT")) k.split = atol(e) != 0;
         if (const char* e = getenv("ZHIP_BLOCKS")) k.blocks = atol(e) != 0;        // 0: frames of several blocks go to the generic kernel as in rounds 1-2 (A/B)
         if (const char* e = getenv("ZHIP_MBC_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.mbcLanes = (unsigned)v; }
         if (const char* e = getenv("ZHIP_MBC_MIN")) k.mbcMin = (size_t)atol(e);     // compress: batches of at least this many sources take the flat search for sources of several blocks
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
-        if (const char* e = getenv("ZHIP_ESLOTS")) { const long v = atol(e); if (v >= 1 && v <= 4) k.eslots = (size_t)v; }
-        if (const char* e = getenv("ZHIP_ESLOT_MIN")) { const long v = atol(e); if (v >= 2) k.eslotMin = (size_t)v; }
-        if (const char* e = getenv("ZHIP_ESLOT_ITEMS")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.eslotItems = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
-        if (const char* e = getenv("ZHIP_TABLES_CONTIG")) c->encFlatTables.contiguous = atol(e) != 0;
-        if (const char* e = getenv("ZHIP_TABLES_VMM")) { const long v = atol(e); if (v >= 0 && v <= 4096) c->encFlatTables.chunkBytes = (size_t)v << 20; }      // MiB per physical chunk, 0 = one hipMalloc
         if (const char* e = getenv("ZHIP_E1L_PROBES")) { const long v = atol(e); if (v == 2 || v == 4) k.e1lProbes = (int)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
         if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
-        if (const char* e = getenv("ZHIP_E1LINKS")) { const long v = atol(e); if (v >= 0 && v <= 2) k.links = (int)v; }
-        if (const char* e = getenv("ZHIP_E1LINK_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.linkLanes = (unsigned)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
     zh_resolve_rows(&c->rows, 3, nullptr);
@@ -482,7 +422,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release();
-    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->encLinkRecs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
+    c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -492,7 +432,6 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < 2; i++) { if (c->hpStage[i]) (void)hipHostFree(c->hpStage[i]); if (c->hpStageFree[i]) (void)hipEventDestroy(c->hpStageFree[i]); }
     if (c->hpH2D) (void)hipStreamDestroy(c->hpH2D);
     if (c->hpCompute) (void)hipStreamDestroy(c->hpCompute);
-    for (int i = 0; i < 4; i++) if (c->hpComputeS[i]) (void)hipStreamDestroy(c->hpComputeS[i]);
     if (c->hpD2H) (void)hipStreamDestroy(c->hpD2H);
     delete c;
 }
@@ -500,8 +439,7 @@ extern "C" const char* zhip_kernel_name(int k)
 {
     static const char* names[ZHIP_NTIMER] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
                                    "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
-                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel",
-                                   "zhip_encode_links_pre_kernel", "zhip_encode_match_links_kernel"};
+                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel"};
     return k >= 0 && k < ZHIP_NTIMER ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
@@ -685,7 +623,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // 128 KiB where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
         // they are the generic kernel's)
         const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
-        const bool mb = c->knob.blocks && c->knob.k2quad && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
+        const bool mb = c->knob.blocks && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
         // (the host-buffer API knows every frame's size and says how many slots the batch should need in all -- a batch of mostly small frames
@@ -703,23 +641,17 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
-        // ZHIP_SPLIT=1 (A/B, r03b): the front of the pipeline (K1, KB, K1b, K2: LDS-bound serial chains with idle issue slots) of chunk k + 1 on one
-        // stream, K3 (register- and memory-bound, little LDS) of chunk k on a second one, so that the PAIRING of co-resident kernels is the
-        // complementary one instead of whatever two free-running slot streams drift into; the arenas still alternate over `nslot` slots
-        const bool split = c->knob.split && nslot >= 2;
-        const int nstream = split ? 2 : nslot;
-        std::vector<hipEvent_t> evK3Done;
         if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * slots * ZP_LIT_STRIDE + ZP_LIT_FRONT) ||
             c->pipeSeq.reserve(nslot * slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
                    c->pipeFrameRecs.reserve(nslot * chunk * sizeof(ZpFrameRec)))) return g_reserveRc;
-        for (int sidx = 0; sidx < (nslot > nstream ? nslot : nstream); sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
+        for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
         HIP_TRY(hipMemsetAsync(c->pipeCounters.p, 0, (8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4, stream));
         hipEvent_t evStart; HIP_TRY(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(evStart, stream));
-        for (int sidx = 0; sidx < (nslot > nstream ? nslot : nstream); sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
+        for (int sidx = 0; sidx < nslot; sidx++) HIP_TRY(hipStreamWaitEvent(c->slotStream[sidx], evStart, 0));
         (void)hipEventDestroy(evStart);
         ZhipPipeArgs pa; memset(&pa, 0, sizeof pa);
         pa.src = (const uint8_t*)d_src; pa.srcSegs = (const uint64_t*)d_srcSegs; pa.dst = (uint8_t*)d_dst; pa.dstSegs = (const uint64_t*)d_dstSegs;
@@ -744,9 +676,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         size_t ci = 0;
         for (size_t first = 0; first < n; first += chunk, ci++) {
             const int sidx = (int)(ci % nslot);
-            hipStream_t ss = split ? c->slotStream[0] : c->slotStream[sidx];
-            hipStream_t sx = split ? c->slotStream[1] : ss;                       // K3's stream
-            if (split && ci >= (size_t)nslot) HIP_TRY(hipStreamWaitEvent(ss, evK3Done[ci - nslot], 0));     // the slot's arenas are free again
+            hipStream_t ss = c->slotStream[sidx];
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * slots;
@@ -768,10 +698,8 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             size_t g1m = (size_t)c->numCU * c->k1PerCU, g3m = (size_t)c->numCU * c->k3PerCU;
             if (c->knob.k3PerCU) g3m = (size_t)c->numCU * (size_t)c->knob.k3PerCU;
             if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
-            // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 60 lanes -> 1, 15 -> 4, 7 -> 8)
-            const bool quad = c->knob.k2quad;
-            const size_t perWave = quad ? ZQ_FRAMES : ZP_K2_LANES;
-            const size_t w2 = (items + perWave - 1) / perWave, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / (quad ? sizeof(ZpSeqQLDS) : sizeof(ZpSeqLDS)));
+            // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 15 frames per wave -> 4)
+            const size_t w2 = (items + ZQ_FRAMES - 1) / ZQ_FRAMES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqQLDS));
             const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
@@ -788,34 +716,16 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
             if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
-            hipEvent_t evK2beg = nullptr;
-            if (tm && split) { HIP_TRY(hipEventCreate(&evK2beg)); HIP_TRY(hipEventRecord(evK2beg, ss)); }
             if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            else if (quad) hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            else hipLaunchKernelGGL(zhip_decode_seq1_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            hipEvent_t evK2end = nullptr;
-            if (split) {
-                hipEvent_t evFront; HIP_TRY(hipEventCreateWithFlags(&evFront, hipEventDisableTiming));
-                if (tm) { HIP_TRY(hipEventCreate(&evK2end)); HIP_TRY(hipEventRecord(evK2end, ss)); }
-                HIP_TRY(hipEventRecord(evFront, ss));
-                HIP_TRY(hipStreamWaitEvent(sx, evFront, 0));
-                (void)hipEventDestroy(evFront);
-            }
-            if (tm) HIP_TRY(hipEventRecord(ev[2], sx));
-            if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
-            else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, sx, pa);
-            else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, sx, pa);
-            else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, sx, pa);      // (ZHIP_PROF with a dictionary or frames of several blocks: K3's timers read zero -- said once at context creation)
-            else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, sx, pa);
-            if (tm) HIP_TRY(hipEventRecord(ev[3], sx));
-            if (split) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIP_TRY(hipEventRecord(e, sx)); evK3Done.push_back(e); }
+            else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+            if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
+            if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, ss, pa);      // (ZHIP_PROF with a dictionary or frames of several blocks: K3's timers read zero -- said once at context creation)
+            else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
-            if (tm && split) {
-                c->timer[2].pending.emplace_back(ev[0], evh);
-                c->timer[7].pending.emplace_back(evh2, ev[1]);
-                c->timer[3].pending.emplace_back(evK2beg, evK2end);
-                c->timer[4].pending.emplace_back(ev[2], ev[3]);
-            } else
             if (tm) {
                 // consecutive events bracket one kernel each (same stream, nothing in between). Ownership: K1's timer owns
                 // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
@@ -859,8 +769,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 }
             }
         }
-        for (hipEvent_t e : evK3Done) (void)hipEventDestroy(e);
-        for (int sidx = 0; sidx < nstream; sidx++) {                 // the caller's stream continues after every slot has drained
+        for (int sidx = 0; sidx < nslot; sidx++) {                 // the caller's stream continues after every slot has drained
             hipEvent_t evEnd; HIP_TRY(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(evEnd, c->slotStream[sidx]));
             HIP_TRY(hipStreamWaitEvent(stream, evEnd, 0));
@@ -939,10 +848,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     hipStream_t stream = (hipStream_t)streamv;
     size_t maxBlocks = (size_t)c->numCU * (size_t)c->encBlocksPerCU;
     uint32_t grid = (uint32_t)(n < maxBlocks ? n : maxBlocks);
-    // (chunk slots of the host pipeline: this call's counters and arena parts are slot `encSlot`'s of `encSlots`; 1 / 0 for everybody else)
-    const size_t S = c->encSlots > 1 && !c->hasCDict && !c->knob.noPipeline ? c->encSlots : 1, slot = S > 1 ? c->encSlot : 0;
     if (c->counter.reserve(64 * 8)) return g_reserveRc;
-    uint8_t* const cbase = (uint8_t*)c->counter.p + 64 * slot;
+    uint8_t* const cbase = (uint8_t*)c->counter.p;
     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 4, stream));
     ZhipEncodeArgs a; memset(&a, 0, sizeof a);
     a.src = (const uint8_t*)d_src; a.srcSegs = (const uint64_t*)d_srcSegs; a.dst = (uint8_t*)d_dst;
@@ -1046,8 +953,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const size_t mbSeqCap = mbc ? sizeHint / 4 + mbMaxBlocks + 64 : 0;          // (double-fast matches are four bytes or more: zstd.c:31167 / :31150)
         if (mbc) { const size_t byMem = ((size_t)32 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
-        if (S > 1 && (mbc || n > c->encSlotCap || n > chunkMax)) { g_lastError = "compress chunk slots: a chunk the slots were not sized for"; return ZHIP_ERR_UNSUPPORTED; }
-        const size_t cap = S > 1 ? c->encSlotCap : chunk;                      // items a slot's arena parts are sized for
+        const size_t cap = chunk;                                              // items the arenas are sized for
         const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
         const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;
         a.e1Lanes = (uint32_t)e1Lanes;
@@ -1056,7 +962,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         const size_t w1 = (chunk + e1Lanes - 1) / e1Lanes;
         const uint32_t g1 = (uint32_t)(w1 < g1max ? w1 : g1max);
         size_t g2max = (size_t)c->numCU * (size_t)c->e2PerCU;
-        if (S > 1) g2max = (g2max + S - 1) / S;                                   // the slots' entropy kernels share the chip
         const uint32_t g2 = (uint32_t)(chunk < g2max ? chunk : g2max);
         const size_t w1cap = (cap + e1Lanes - 1) / e1Lanes, g1cap = w1cap < g1max ? w1cap : g1max, g2cap = cap < g2max ? cap : g2max;
         // waves for what the generic kernel takes: inputs above one block, and -- with a dictionary -- inputs above the attach cutoff
@@ -1066,12 +971,12 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // the list is the whole batch and gets the whole chip: 2 048 x 1 MiB took 10.6 s on 64 waves, profiles/r03_multiblock_rate.txt)
         const size_t gBigMax = sizeHint > ZF_BLOCK_MAX ? (size_t)c->numCU * (size_t)c->encBlocksPerCU : c->hasCDict ? (size_t)c->numCU / 2 : 64;
         const uint32_t gBig = (uint32_t)(n < gBigMax ? n : gBigMax);
-        const size_t tabPer = g1cap * e1Lanes * a.tableStride, wsPer = g2cap * ZE_E2_STRIDE + ZHIP_ENC_STRIDE, bigListPer = (S > 1 ? cap : n) * sizeof(uint32_t) + 16,
+        const size_t tabPer = g1cap * e1Lanes * a.tableStride, wsPer = g2cap * ZE_E2_STRIDE + ZHIP_ENC_STRIDE, bigListPer = n * sizeof(uint32_t) + 16,
                      e1ListPer = cap * sizeof(uint32_t) + 16, bigWsPer = (size_t)gBig * ZHIP_ENC_STRIDE;
-        if (c->encMeta.reserve(S * cap * sizeof(ZeMeta)) || c->encArena.reserve(S * cap * (size_t)a.arenaStride) ||
-            c->encTables.reserve(S * tabPer) || c->encWorkspace.reserve(S * wsPer) ||
-            c->encBigList.reserve(S * bigListPer) || c->encE1List.reserve(S * e1ListPer) ||
-            (flat && c->encFlatTables.reserve(S * cap * (size_t)a.tableStride))) return g_reserveRc;
+        if (c->encMeta.reserve(cap * sizeof(ZeMeta)) || c->encArena.reserve(cap * (size_t)a.arenaStride) ||
+            c->encTables.reserve(tabPer) || c->encWorkspace.reserve(wsPer) ||
+            c->encBigList.reserve(bigListPer) || c->encE1List.reserve(e1ListPer) ||
+            (flat && c->encFlatTables.reserve(cap * (size_t)a.tableStride))) return g_reserveRc;
         if (mbc) {
             if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
                 c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
@@ -1079,21 +984,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.mbMaxBlocks = (uint32_t)mbMaxBlocks; a.mbSeqCap = (uint32_t)mbSeqCap; a.mbLanes = c->knob.mbcLanes; a.mbProbes = chunk * ((sizeHint + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) <= c->knob.flat4Max ? 4u : 2u;        // (the traffic in flight is sources x blocks each: 16 384 x 256 KiB 7.9 -> 8.9 GB/s with four probes, 32 768 x 256 KiB 12.0 -> 11.8, r04zj)
             if (c->encBigWs.reserve((size_t)gBig * ZHIP_ENC_STRIDE)) return g_reserveRc;
         }
-        // the link form (ZHIP_E1LINKS): 8 bytes of records per source position instead of -- with the LDS pre-pass -- the tables
-        const bool links = flat && !flatDict && !mbc && c->knob.links != 0 && S == 1;
-        if (links) {
-            const size_t hintL = c->srcMaxHint ? c->srcMaxHint : sizeHint ? sizeHint : (size_t)ZF_BLOCK_MAX;
-            size_t per = ZF_BLOCK_MAX; if (hintL < per) { per = 4096; while (per < hintL) per <<= 1; }
-            a.linkStride = (uint32_t)(per * ZL_REC_BYTES); a.linkLanes = c->knob.linkLanes;
-            if (c->encLinkRecs.reserve(cap * (size_t)a.linkStride)) return g_reserveRc;
-            a.linkRecs = (uint8_t*)c->encLinkRecs.p;
-        }
-        a.workspace = (uint8_t*)c->encWorkspace.p + slot * wsPer;
-        a.meta = (ZeMeta*)c->encMeta.p + slot * cap; a.arena = (uint8_t*)c->encArena.p + slot * cap * (size_t)a.arenaStride; a.laneTables = (uint8_t*)c->encTables.p + slot * tabPer;
-        uint8_t* const flatTables = flat ? (uint8_t*)c->encFlatTables.p + slot * cap * (size_t)a.tableStride : nullptr;
-        a.flatTables = flatTables; a.e1List = (uint32_t*)((uint8_t*)c->encE1List.p + slot * e1ListPer); a.e1Count = (uint32_t*)(cbase + 32);
+        a.workspace = (uint8_t*)c->encWorkspace.p;
+        a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
+        uint8_t* const flatTables = flat ? (uint8_t*)c->encFlatTables.p : nullptr;
+        a.flatTables = flatTables; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)(cbase + 32);
+        a.idle = cbase + 256;                                                       // (the context's own counter block: ADVICE r04 -- the caller's arena base need not be readable)
         a.useE1List = flat ? 1u : 0u;
-        a.bigList = (uint32_t*)((uint8_t*)c->encBigList.p + slot * bigListPer); a.bigCount = (uint32_t*)(cbase + 24);
+        a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)(cbase + 24);
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
             if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
@@ -1106,7 +1003,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream));
             HIP_TRY(hipMemsetAsync(cbase + 32, 0, 4, stream));
             const bool tm = c->timing;
-            hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evL[3] = {nullptr, nullptr, nullptr}; bool usedLinks = false;
+            hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
                 if (!flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
@@ -1133,13 +1030,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                         else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
                     }
                 }
-                else if (links) {
-                    if (tm) { for (int q = 0; q < 3; q++) HIP_TRY(hipEventCreate(&evL[q])); HIP_TRY(hipEventRecord(evL[0], stream)); }
-                    hipLaunchKernelGGL(zhip_encode_links_pre_lane_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, stream, a);
-                    if (tm) { HIP_TRY(hipEventRecord(evL[1], stream)); HIP_TRY(hipEventRecord(evL[2], stream)); }
-                    hipLaunchKernelGGL(zhip_encode_match_links_kernel, dim3((uint32_t)((cnt + a.linkLanes - 1) / a.linkLanes)), dim3(64), 0, stream, a);
-                    usedLinks = true;
-                }
                 else if (!flatDict && !mbc && cnt <= c->knob.flat4Max) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 else if (!flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
@@ -1160,8 +1050,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             }
             HIP_TRY(hipGetLastError());
             if (tm) {
-                if (flat && usedLinks) { c->timer[9].pending.emplace_back(evL[0], evL[1]); c->timer[10].pending.emplace_back(evL[2], ev[1]); (void)hipEventDestroy(ev[0]); }
-                else if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
+                if (flat) c->timer[8].pending.emplace_back(ev[0], ev[1]);
                 else { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); }
                 c->timer[5].pending.emplace_back(ev[2], ev[3]);
                 c->timer[6].pending.emplace_back(ev[4], ev[5]);
@@ -1178,9 +1067,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             a.prof = nullptr;
         }
         if (!mbc) {   // inputs above 128 KiB (multi-block frames): the generic one-wave-per-frame kernel over the list E1 made (usually empty)
-            if (c->encBigWs.reserve(S * bigWsPer)) return g_reserveRc;
+            if (c->encBigWs.reserve(bigWsPer)) return g_reserveRc;
             ZhipEncodeArgs b = a;
-            b.workspace = (uint8_t*)c->encBigWs.p + slot * bigWsPer; b.counter = (uint32_t*)(cbase + 28);
+            b.workspace = (uint8_t*)c->encBigWs.p; b.counter = (uint32_t*)(cbase + 28);
             b.frameList = a.bigList; b.listCount = a.bigCount;
             hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
             HIP_TRY(hipGetLastError());
@@ -1364,7 +1253,6 @@ static int host_pipe_init(zhip_ctx* c)
     if (c->hpReady) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->hpH2D, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->hpCompute, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIP_TRY(hipStreamCreateWithFlags(&c->hpComputeS[i], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->hpD2H, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&c->hpStageFree[i], hipEventDisableTiming));
     c->hpReady = true;
@@ -1425,7 +1313,7 @@ static zhip_ctx* tls_ctx()
 extern "C" size_t zhip_thread_memory_size(void)
 {
     zhip_ctx* c = tls_ctx();
-    if (c) (void)c->counter.reserve(64);
+    if (c) (void)c->counter.reserve(64 * 8);
     return c ? c->device_bytes() : 0;
 }
 static void tls_trim(zhip_ctx* c)
@@ -1617,25 +1505,12 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // the match kernel is a per-frame latency chain (its time barely depends on the batch below ~16 K frames), so compress chunks are
     // large: two of them overlap one's upload with the other's kernels, more would only add chains end to end
-    // Chunk SLOTS (round 4, OFF by default: ZHIP_ESLOTS=2..4 turns them on): a batch of one-block sources without a dictionary -- BASELINE's
-    // shape -- cut into chunks that run side by side on their own streams, each in its own part of the encode arenas, so that a chunk starts as
-    // soon as ITS sources have arrived instead of after the chunk before it. Measured on 65 536 x 128 KiB through Python (profiles/r04h-r04n):
-    // one slot (two serial chunks, round 3's form) 11.6-11.8 GB/s; two slots of half the batch 12.7; four slots of 16 384 12.1-12.3 (HIP drives 4
-    // hardware queues: the fourth slot's queue is the first one's and it waits for it, r04j timeline). But the concurrent form has a SLOW MODE
-    // nobody has explained: three slots 2.4 GB/s, four with GPU_MAX_HW_QUEUES=8 2.3, and TWO slots inside bench.py's process 2.3 -- always
-    // ~3.7 s per call, ~8 x the search's 0.42-0.48 s, while the same three-slot call under rocprofv3's kernel trace takes 0.71 s with the three
-    // searches overlapping as intended (r04m). An intermittent 5 x loss is worse than the 7 % gain: off. The ceiling of this shape is ~14 GB/s
-    // anyway -- the search of 65 536 frames is 424-480 ms of transaction-bound work however it is cut, in front of it the first
-    // chunk's upload, behind it entropy coding, compaction and the copy back.
-    size_t maxItem = 0; for (size_t i = 0; i < n; i++) if (items[i].srcSize > maxItem) maxItem = items[i].srcSize;
-    const size_t S = !c->hasCDict && !c->knob.noPipeline && !c->knob.noFlat && maxItem <= ZF_BLOCK_MAX && c->knob.eslots > 1 && n >= c->knob.eslotMin ? c->knob.eslots : 1;
-    const size_t slotItems = c->knob.eslotItems ? c->knob.eslotItems : (n + S - 1) / S;
-    const std::vector<size_t> cut = S > 1 ? host_chunks(segs.data(), n, (uint64_t)4 << 30, slotItems)
-                                          : host_chunks(segs.data(), n, (uint64_t)4 << 30, c->knob.hchunkE, n > c->knob.hchunkE ? c->knob.hchunkE0 : 0);
+    // (round 4 ran these chunks side by side on their own streams, each in its own part of the encode arenas -- +8 % at best and an unexplained 5 x
+    // slow mode in three of eight configurations; removed in round 5, git tag r04-experiments has it. The ceiling of this shape is the search:
+    // 65 536 frames are 410-480 ms of transaction-bound work however they are cut, with the first chunk's upload in front and entropy coding,
+    // compaction and the copy back behind: DESIGN.md section 3.)
+    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)4 << 30, c->knob.hchunkE, n > c->knob.hchunkE ? c->knob.hchunkE0 : 0);
     const size_t nChunks = cut.size() - 1;
-    struct SlotGuard { zhip_ctx* c; ~SlotGuard() { c->encSlots = 1; c->encSlot = 0; } } slotGuard{c};
-    c->encSlots = S; c->encSlotCap = S > 1 ? slotItems : 0;
-    auto slotStream = [&](size_t q) -> hipStream_t { return q == 0 ? c->hpCompute : q == 1 ? c->hpD2H : c->hpComputeS[q - 2]; };
     // device: sources, slots, dense frames, segment table, [sizes | offsets | chunk totals | status]
     const size_t metaBytes = n * (2 * sizeof(uint64_t) + sizeof(int32_t)) + (nChunks + 1) * sizeof(uint64_t) + 32;
     if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hDense.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment) + 16) ||
@@ -1674,18 +1549,15 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
         uint64_t o = 0;
         for (size_t i = lo; i < hi; i++) { ob[k].segs[i - lo].offset = o; ob[k].segs[i - lo].length = hSizes[i]; o += hSizes[i]; }
         // the compaction finished before evMeta (same stream), so the copy needs no further dependency
-        if (total && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDense.p + segs[n + lo].offset, total, hipMemcpyDeviceToHost, S > 1 ? slotStream(k % S) : c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
+        if (total && hipMemcpyAsync(ob[k].data, (uint8_t*)c->hDense.p + segs[n + lo].offset, total, hipMemcpyDeviceToHost, c->hpD2H) != hipSuccess) return fail(ZHIP_ERR_HIP);
         return 0;
     };
     for (size_t k = 0; k < nChunks; k++) {
         const size_t lo = cut[k], hi = cut[k + 1], cnt = hi - lo;
-        hipStream_t sk = S > 1 ? slotStream(k % S) : c->hpCompute;           // (a slot's next chunk follows its last one in stream order: the arena part is free again)
+        hipStream_t sk = c->hpCompute;
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
-        // (slots: the frames of the chunk that used this slot before travel back on the slot's stream AHEAD of this chunk's kernels)
-        if (S > 1 && k >= S) { const int e = collect(k - S); if (e) return e; }
         if (hipStreamWaitEvent(sk, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
         { size_t mx = 0; for (size_t i = lo; i < hi; i++) if (items[i].srcSize > mx) mx = items[i].srcSize; c->srcMaxHint = mx; }
-        c->encSlot = k % S;
         r = zhip_compress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, sk);
         c->srcMaxHint = 0;
         if (r) return fail(r);
@@ -1699,11 +1571,10 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
             hipMemcpyAsync(hStatus + lo, dStatus + lo, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, sk) != hipSuccess ||
             hipMemcpyAsync(hTotals + k, dTotals + k, sizeof(uint64_t), hipMemcpyDeviceToHost, sk) != hipSuccess ||
             hipEventCreateWithFlags(&evMeta[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(evMeta[k], sk) != hipSuccess) return fail(ZHIP_ERR_HIP);
-        if (S == 1 && k >= 1) { const int e = collect(k - 1); if (e) return e; }
+        if (k >= 1) { const int e = collect(k - 1); if (e) return e; }
     }
-    for (size_t j = nChunks > S ? nChunks - S : 0; j < nChunks; j++) { const int e = collect(j); if (e) return e; }
+    if (nChunks) { const int e = collect(nChunks - 1); if (e) return e; }
     if (hipStreamSynchronize(c->hpD2H) != hipSuccess || hipStreamSynchronize(c->hpCompute) != hipSuccess) return fail(ZHIP_ERR_HIP);
-    for (size_t q = 0; q < S && S > 1; q++) if (hipStreamSynchronize(slotStream(q)) != hipSuccess) return fail(ZHIP_ERR_HIP);
     (void)hipEventDestroy(evUp);
     if (nChunks == 0) empty_outbuf(&ob[0]);
     *out = ob; *nOut = nChunks ? nChunks : 1;

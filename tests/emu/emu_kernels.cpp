@@ -126,15 +126,10 @@ static ZpBinLDS g_binlds;
 static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBits[56];
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
 static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
-static ZpSeqLDS g_seqlds;
 static ZpHufKernelLDS g_huflds;
 static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
-#ifdef ZP_K2_LANEWISE          // the lane-per-frame form kept for A/B (ZHIP_K2_QUAD=0 in the product)
-static void k2_lane(void* p) { zp_seq_body(*(const ZhipPipeArgs*)p, g_seqlds); }
-#else
 static ZpSeqQLDS g_seqqlds;
 static void k2_lane(void* p) { const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p; if (a.itemCap) zp_seqq_body<true>(a, g_seqqlds); else zp_seqq_body<false>(a, g_seqqlds); }
-#endif
 static void k3_lane(void* p)
 {
     const ZhipPipeArgs& a = *(const ZhipPipeArgs*)p;
@@ -204,11 +199,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
         zhemu::run_grid(nBlocks, kh_lane, &a);
-#ifdef ZP_K2_LANEWISE
-        memset(&g_seqlds, 0xA5, sizeof g_seqlds);
-#else
         memset(&g_seqqlds, 0xA5, sizeof g_seqqlds);
-#endif
         zhemu::run_grid(nBlocks, k2_lane, &a);
         zhemu::run_grid(nBlocks, k3_lane, &a);
     }
@@ -235,10 +226,6 @@ extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
 static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
-static void lpre_lane(void* p) { ze_links_pre_lane_body(*(const ZhipEncodeArgs*)p); }
-static void e1k_lane(void* p) { ze_match_links_body(*(const ZhipEncodeArgs*)p); }
-static uint32_t g_links = 0;                    // double-fast batches without dictionary: 0 the table form, 1 the link form with the plain pre-pass, 2 with the LDS pre-pass
-extern "C" void emu_set_links(uint32_t v) { g_links = v; }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
 extern "C" void emu_set_mb_compress(uint32_t v) { g_mbCompress = v; }
 static uint32_t g_dictSlotMax = 0;              // != 0: ZhipEncodeArgs.slotSrcMax of dictionary batches (sources above it are the generic kernel's)
@@ -287,6 +274,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     const bool flat = (anyDfast && !g_hasCD) || flatDict;
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
+    static uint8_t idlePad[64]; a.idle = idlePad;                  // (the product points it at the context's counter block)
     // sources of several blocks in the flat kernel (mirrors zhip_compress_batch_device: the size hint is the batch's largest source)
     const bool mbc = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
     if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] mbc %d flat %d maxSrc %llu\n", (int)mbc, (int)flat, (unsigned long long)maxSrc);
@@ -296,17 +284,10 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
         a.mbBlocks = (ZeMbBlock*)malloc((size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); a.mbCount = (uint32_t*)malloc((size_t)chunk * 4); a.mbSeqs = (uint64_t*)malloc((size_t)chunk * a.mbSeqCap * 8);
         memset(a.mbBlocks, 0xA5, (size_t)chunk * a.mbMaxBlocks * sizeof(ZeMbBlock)); memset(a.mbCount, 0xA5, (size_t)chunk * 4);
     }
-    const bool links = flat && !flatDict && !mbc && g_links;
-    if (links) { a.linkStride = ZL_REC_BYTES * ZF_BLOCK_MAX; a.linkLanes = 16; a.linkRecs = (uint8_t*)malloc((size_t)chunk * a.linkStride); }
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0; e1Count = 0;
-        if (links) {
-            memset(a.flatTables, 0, (size_t)a.count * a.tableStride); memset(a.linkRecs, 0xA5, (size_t)a.count * a.linkStride);
-            zhemu::run_grid((a.count + 63) / 64, lpre_lane, &a);
-            zhemu::run_grid((a.count + a.linkLanes - 1) / a.linkLanes, e1k_lane, &a);
-        }
-        else if (flat) {
+        if (flat) {
             memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
@@ -324,7 +305,6 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             bigCount = 0;
         }
     }
-    free(a.linkRecs);
     free(a.e1List); free(a.flatTables); free(a.mbBlocks); free(a.mbCount); free(a.mbSeqs);
     if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
         ZhipEncodeArgs b = a; uint32_t bc = 0;

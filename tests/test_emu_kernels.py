@@ -207,27 +207,6 @@ def test_emulated_flat_match_kernel_and_wave_entropy_coder(emu, oracle, corpus):
         emu.lib.emu_set_e1lds_max(0); emu.lib.emu_set_e1lds_bytes(131072)
 
 
-def test_emulated_link_form_of_the_double_fast_search(emu, oracle, corpus):
-    """The double-fast search without hash tables (ze_dfast_links, round 4): a pre-pass links every position to the nearest earlier one
-    with the same long / short hash, the search follows the links to the first position it has flagged as written. Same inputs as the
-    flat kernel's test (every branch: repeat offsets, long / short / long-at-the-next-position matches, catch-up, matches into the end
-    of the source, runs, tiny inputs handed to the lane-serial kernel), same frames as the oracle's table search, byte for byte."""
-    import ctypes
-    raws = _flat_search_inputs(corpus) + _flat_search_inputs(corpus, seed=5, count=18)
-    emu.lib.emu_stat.restype = ctypes.c_long
-    emu.lib.emu_set_links(1)
-    try:
-        before = emu.lib.emu_stat(15)
-        for flags, chunk in ((5, 17), (7, 64)):
-            outs, st = emu.compress_batch(raws, level=3, flags=flags, n_blocks=3, pipeline=True, chunk=chunk)
-            assert not any(st)
-            for i, (r, o) in enumerate(zip(raws, outs)):
-                assert o == oracle.compress(r, level=3, flags=flags), (flags, i, len(r))
-        assert emu.lib.emu_stat(15) - before >= 2 * 45, "the link-form kernel did not take these frames"
-    finally:
-        emu.lib.emu_set_links(0)
-
-
 def test_emulated_four_probe_flat_search(emu, oracle, corpus):
     """The flat double-fast search with FOUR probes per trip (ze_dfast_flat_np, round 4: the form chunks of up to 32 768 sources take -- they are bound
     by a source's serial chain, and a trip of four speculative probes consumes 2.95 of them on average instead of 1.8): the same inputs as the
@@ -392,28 +371,6 @@ def test_emulated_decode_pipeline_with_dictionaries(emu, ref, corpus):
         emu.set_ddict(None)
 
 
-def test_experimental_kernel_variants_stay_correct(oracle, corpus, tmp_path):
-    """-DZP_K3_LONGONE (round 1's one-long-match-per-round form of
-    K3; the all-ready-long-matches form became the default after the r02c measurement) are compiled out of the product: keep them
-    bit-exact so that a GPU session can A/B them straight away"""
-    import numpy as np
-    from tests import emulib
-    so = emulib.build_variant(str(tmp_path / "libzhip_emu_exp.so"), ["-DZP_K3_LONGONE"])
-    emu = emulib.Emu(so)
-    rng = np.random.default_rng(11)
-    blk = rng.bytes(600)
-    raws = [corpus.frame_bytes(i)[: 5000 + 21000 * i] for i in range(6)] + [b"ab" * 20000, (blk + rng.bytes(2000) + blk * 4 + rng.bytes(50) + blk) * 12,
-            rng.bytes(30000), b"x" * 7, b"hello " * 11, bytes(rng.integers(0, 4, 50000, dtype=np.uint8))]
-    outs, st = emu.compress_batch(raws, level=3, flags=5, n_blocks=2, pipeline=True)
-    assert not any(st)
-    frames = [oracle.compress(r, level=3) for r in raws]
-    assert outs == frames
-    big = [r for r in raws if len(r) > 100]
-    bigf = [oracle.compress(r, level=3, flags=7) for r in big]
-    dec, st, nfb = emu.decompress_pipeline(bigf, [len(r) for r in big], n_blocks=3, chunk=0)
-    assert not any(st) and dec == big
-
-
 def test_several_block_search_with_an_understated_size_hint(emu, oracle, corpus):
     """the flat search's per-source sequence slices are sized from the caller's size HINT; a source larger than the hint would write
     past its slice. ze_split_body leaves such a source to the generic kernel: frames stay bit-exact, nothing is written out of bounds (the
@@ -433,16 +390,11 @@ def test_several_block_search_with_an_understated_size_hint(emu, oracle, corpus)
     assert emu.stat(8) - s0 >= 2                 # the sources within the hint were still searched by the flat kernel
 
 
-@pytest.mark.parametrize("defines", [["-DZP_K2_LANEWISE", "-DZP_HUF_FRAMES=16"], ["-DZP_K2_LANEWISE", "-DZP_K2_LANES=15", "-DZP_HUF_FRAMES=4"],
-                                     ["-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048", "-DZP_K3_PREFETCH"],
-                                     # round 4's forms (measured slower or neutral on the MI355X, kept selectable -- DESIGN.md 4.1): K3 with own-lane items up to 32
-                                     # bytes + sequential in-batch matches, the lean K1b; the same K3 staging with dependency rounds, the two-level K1b;
-                                     # round 3's K3 with need-masks from the 16-byte cell map and wave-level fences
-                                     ["-DZP_K3_R4", "-DZP_K1B_R4A"], ["-DZP_K3_R4", "-DZP_K3_ROUNDS", "-DZP_K1B_R4B"], ["-DZP_K3_NEED_CELLS", "-DZP_K3_LIGHT_SYNC"]])
+@pytest.mark.parametrize("defines", [["-DZP_HUF_FRAMES=16"], ["-DZP_HUF_FRAMES=4", "-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
-    """the A/B shapes decode the same bytes: K2's lane-per-frame form of rounds 1-2 (ZHIP_K2_QUAD=0 in the product; -DZP_K2_LANEWISE selects it
-    under emulation) with 60 / 15 frames per wave, the quad form with fewer frames per wave, K1b with 16 / 4 frames per wave, K3 with a smaller
-    assembly buffer and the far-match prefetch"""
+    """the build-time shapes decode the same bytes: the quad K2 with fewer frames per wave and other fence placement, K1b with 16 / 4 frames per
+    wave, K3 with a smaller assembly buffer (the losing forms of rounds 1-4 -- lane-per-frame K2, K3 / K1b rewrites -- left the source in round 5:
+    git tag r04-experiments)"""
     import numpy as np
     from tests import emulib
     emu = emulib.Emu(emulib.build_variant(str(tmp_path / "libzhip_emu_shape.so"), defines))

@@ -206,51 +206,10 @@ def test_sources_of_several_blocks_in_the_flat_search(zstd, corpus):
     assert box["back"] == raws
 
 
-def test_host_pipeline_compress_chunk_slots(zstd, corpus):
-    """(off by default, ZHIP_ESLOTS turns it on) multi_compress_to_buffer on host buffers cuts a large batch of one-block sources into chunks that run SIDE BY SIDE on their own streams,
-    each in its own part of the encode arenas (zhip_compress_batch, round 4: the match kernel wants every frame in flight, a chunk starts as
-    soon as its sources have arrived). ZHIP_ESLOT_ITEMS=256 / ZHIP_ESLOT_MIN=512 turn that on for a batch of 1 500 inputs (read when a thread's context is
-    created: fresh thread): every frame against libzstd 1.5.7 (ZSTD_compressStream2(e_end), c-ext/compressor.c:1035-1043), sizes from empty to
-    128 KiB, a second call on the same context (the slots' arenas reused), and a fast-strategy level (the lane-serial match kernel in slots)."""
-    import os
-    import threading
-    from tests import reflib
-    ref = reflib.checker()
-    rng = np.random.default_rng(77)
-    raws = []
-    for i in range(1500):
-        n = int(rng.choice([0, 3, 100, 4096, 30000, 131072], p=[0.01, 0.01, 0.08, 0.3, 0.3, 0.3]))
-        r = corpus.frame_bytes(i % 400)[:n] if i % 7 else rng.bytes(n)
-        raws.append(r)
-    box = {}
-
-    def run():
-        try:
-            c = zstd.ZstdCompressor(level=3)
-            for rep in range(2):
-                res = c.multi_compress_to_buffer(raws)
-                box[rep] = [res[i].tobytes() for i in range(len(raws))]
-            res = zstd.ZstdCompressor(level=1).multi_compress_to_buffer(raws)
-            box["l1"] = [res[i].tobytes() for i in range(len(raws))]
-        except Exception as e:              # noqa: BLE001 -- reported by the assertion below
-            box["error"] = e
-
-    os.environ["ZHIP_ESLOT_ITEMS"] = "256"; os.environ["ZHIP_ESLOT_MIN"] = "512"; os.environ["ZHIP_ESLOTS"] = "3"
-    try:
-        t = threading.Thread(target=run); t.start(); t.join()
-    finally:
-        del os.environ["ZHIP_ESLOT_ITEMS"]; del os.environ["ZHIP_ESLOT_MIN"]; del os.environ["ZHIP_ESLOTS"]
-    assert "error" not in box, box.get("error")
-    want = [ref.compress(r, level=3) for r in raws]
-    assert box[0] == want and box[1] == want
-    assert box["l1"] == [ref.compress(r, level=1) for r in raws]
-
-
-def test_link_form_of_the_double_fast_search(zstd, corpus):
-    """(off by default, ZHIP_E1LINKS=1 turns it on) the double-fast search without hash tables -- a pre-pass links every position to the nearest
-    earlier one with the same long / short hash, the search follows the links to the first position it has flagged as written (ze_dfast_links,
-    DESIGN 4.2, round 4). Kept as the record of a measured experiment; its frames must be libzstd's, byte for byte. ZHIP_E1LDS_MAX=0 keeps the
-    small-batch LDS kernel out of the way so that this batch takes the big-batch path (read when a thread's context is created: fresh thread)."""
+def test_mixed_small_batch_through_the_large_batch_search(zstd, corpus):
+    """A small batch forced onto the large-batch path (ZHIP_E1LDS_MAX=0 keeps the LDS-source kernel out of the way; read when a thread's context is
+    created: fresh thread): sources of 63 ... 131 072 bytes side by side in the flat match kernel, the ones below 64 bytes in the lane-serial
+    kernel with its 512-byte literal area (the slim arena slot of round 5). Frames must be libzstd's, byte for byte."""
     import os
     import threading
     from tests import reflib
@@ -272,11 +231,11 @@ def test_link_form_of_the_double_fast_search(zstd, corpus):
         except Exception as e:              # noqa: BLE001 -- reported by the assertion below
             box["error"] = e
 
-    os.environ["ZHIP_E1LINKS"] = "1"; os.environ["ZHIP_E1LDS_MAX"] = "0"
+    os.environ["ZHIP_E1LDS_MAX"] = "0"
     try:
         t = threading.Thread(target=run); t.start(); t.join()
     finally:
-        del os.environ["ZHIP_E1LINKS"]; del os.environ["ZHIP_E1LDS_MAX"]
+        del os.environ["ZHIP_E1LDS_MAX"]
     assert "error" not in box, box.get("error")
     for i, r in enumerate(raws):
         assert box["out"][i] == ref.compress(r, level=3), (i, len(r))
