@@ -291,6 +291,20 @@ def encode_own_bytes(sec, F, item):
             "zhip_encode_entropy_kernel": F * (8 * sec["nbseq"] + sec["lit"] + sec["rawlit"] + sec["csize"])}
 
 
+def e1f_regime(ctx, ktimes, frames):
+    """The flat match kernel's time for the same launch varies by up to 20 % with where the driver placed the context's hash tables (DESIGN.md 4.2:
+    397 ... 488 ms per 65 536 frames, a property of one allocation, reproducible within a process). The line says which placement THIS process got:
+    the kernel's average launch time scaled to 65 536 frames, against the best and worst the same build has measured (profiles/)."""
+    for k, (ms, launches) in ktimes.items():
+        if ctx.kernel_name(k) == "zhip_encode_match_flat_kernel" and launches:
+            fpl = frames if frames <= 65536 else 131072 if frames >= 131072 else frames          # what one launch holds (zhip_compress_batch_device)
+            per = ms * 65536.0 / fpl
+            return {"match_kernel_ms_per_65536_frames": round(per, 2), "frames_per_launch": int(fpl), "known_range_ms": [397, 488],
+                    "class": "fast" if per <= 425 else "slow" if per >= 455 else "middle",
+                    "note": "placement of the context's tables, not the build: compare compress figures of equal class (launches of 131 072 frames cost ~9 % less per frame)"}
+    return None
+
+
 def kernels_obj(ctx, ktimes):
     return {ctx.kernel_name(k): {"avg_ms": round(v[0], 4), "launches": int(v[1])} for k, v in ktimes.items() if v[1]}
 
@@ -717,6 +731,7 @@ def bench_frames(args, config, rank, world, dev):
                 "dtype": "u8", "data": "synthetic", "config": cfg}
         if rank == 0:
             line["kernels"] = kernels_obj(ctx, ktimes)
+            line["regime"] = e1f_regime(ctx, ktimes, F)
             line["roofline"], _ = roofline(ctx, ktimes, args.steps, F * FRAME + ctotal, ms, F)
             if world == 1 and not args.no_cpu_baseline:
                 offs = np.arange(nsample + 1, dtype=np.uint64) * np.uint64(FRAME)
@@ -771,6 +786,7 @@ def bench_frames(args, config, rank, world, dev):
             c_ms = c_elapsed / 3 * 1e3
             line["compress"] = {"value": round(world * Fc * FRAME * 3 / c_elapsed / 1e9, 3), "unit": "GB/s", "frames_per_gpu": Fc, "steps": 3,
                                 "ms_per_step": round(c_ms, 3), "bit_exact_vs_libzstd": True, "kernels": kernels_obj(ctx, c_k)}
+            line["compress"]["regime"] = e1f_regime(ctx, c_k, Fc)
             line["compress"]["roofline"], _ = roofline(ctx, c_k, 3, Fc * FRAME + c_total, c_ms, Fc)
             line["compress"]["roofline"]["per_kernel"] = per_kernel_roofline(ctx, c_k, 3, encode_own_bytes(sec, Fc, FRAME))
             if world == 1 and not args.no_cpu_baseline:

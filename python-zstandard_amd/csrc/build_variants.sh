@@ -30,8 +30,22 @@ for v in "$@"; do
     k3d2) build k3d2 -DZP_K3D_MINWAVES=2 & ;;
     k3d3) build k3d3 -DZP_K3D_MINWAVES=3 & ;;
     asm2k) build asm2k -DZP_ASM_BYTES=2048 & ;;
+    nt1) build nt1 -DZP_K3_NT=1 & ;;                      # K3: sequences and decoded literals read with streaming (nt) loads
+    nt1w5) build nt1w5 -DZP_K3_NT=1 -DZP_K3_MINWAVES=5 & ;;
+    nt3) build nt3 -DZP_K3_NT=3 & ;;
     own32) build own32 -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32 & ;;
     floor) build floor -DZP_K3_DIAG_FLOOR & ;;
+    floorw4) build floorw4 -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=4 -DZP_FLOOR_LDSPAD=4096 & ;;                                  # the occupancy of an 8 KiB buffer, no window
+    floorw4win) build floorw4win -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=4 -DZP_FLOOR_LDSPAD=4096 -DZP_FLOOR_WIN=8192 -DZP_ASM_BYTES=2048 & ;;
+    floorw5) build floorw5 -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=5 -DZP_FLOOR_LDSPAD=2048 & ;;
+    floorw5win) build floorw5win -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=5 -DZP_FLOOR_LDSPAD=2048 -DZP_FLOOR_WIN=6144 -DZP_FLOOR_KEEP=3072 -DZP_ASM_BYTES=2048 & ;;
+    floorw6win) build floorw6win -DZP_K3_DIAG_FLOOR -DZP_FLOOR_WIN=4096 -DZP_FLOOR_KEEP=2048 -DZP_ASM_BYTES=1536 & ;;
+    floorw3) build floorw3 -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=3 -DZP_FLOOR_LDSPAD=8192 & ;;
+    floorw2) build floorw2 -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=2 -DZP_FLOOR_LDSPAD=14336 & ;;
+    floorw4free) build floorw4free -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=4 -DZP_FLOOR_LDSPAD=4096 -DZP_FLOOR_WIN=8192 -DZP_FLOOR_KEEP=5120 -DZP_FLOOR_FREE & ;;        # an ideal 8 KiB ring: ~5-7 KiB behind the batch, no LDS work of its own
+    floorw6free) build floorw6free -DZP_K3_DIAG_FLOOR -DZP_FLOOR_WIN=8192 -DZP_FLOOR_KEEP=5120 -DZP_FLOOR_FREE & ;;                                                 # the same requests dropped at six waves per SIMD (not buildable: shows what occupancy is worth)
+    floorw3free) build floorw3free -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=3 -DZP_FLOOR_LDSPAD=8192 -DZP_FLOOR_WIN=12288 -DZP_FLOOR_KEEP=9216 -DZP_FLOOR_FREE & ;;
+    floorw2free) build floorw2free -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=2 -DZP_FLOOR_LDSPAD=14336 -DZP_FLOOR_WIN=20480 -DZP_FLOOR_KEEP=17408 -DZP_FLOOR_FREE & ;;
     e1l16) build e1l16 -DZE_E1_LANES=16 & ;;
     e1l32) build e1l32 -DZE_E1_LANES=32 & ;;
     e1l64) build e1l64 -DZE_E1_LANES=64 & ;;

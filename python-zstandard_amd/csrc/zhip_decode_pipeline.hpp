@@ -101,6 +101,23 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
 {
     const uint32_t lane = zh_lane();
     uint8_t* lit = a.litArena + (size_t)t * ZP_LIT_STRIDE;
+    if (a.bases) {
+        // compact literal arena: the section header says how many literals a compressed / treeless section regenerates (RFC 8878 3.1.1.3.1.1; raw
+        // and RLE sections need no room: they are read in place / filled). + 256 bytes: K1b's whole-unit stores and K3's over-reads stay inside
+        uint32_t need16 = 0;
+        if (bs >= 5 && (src[pos] & 3u) >= 2u) {
+            const uint32_t v = zh_ld32(src + pos), fmt = (v >> 2) & 3u;
+            const uint32_t regen = fmt < 2 ? (v >> 4) & 0x3FFu : fmt == 2 ? (v >> 4) & 0x3FFFu : (v >> 4) & 0x3FFFFu;
+            if (regen <= ZF_BLOCK_MAX) need16 = (regen + 256u + 15u) >> 4;                     // (larger: zd_literals refuses the block below)
+        }
+        uint32_t lb = 0;
+        if (need16) {
+            lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? need16 : 0u));
+            if ((uint64_t)lb + need16 > a.litBudget16) return ZP_RC_FALLBACK;                  // the chunk's literal room is used up: the generic kernel's frame
+        }
+        lit = a.litArena + (size_t)lb * 16;
+        if (zh_opaque(lane) == 0) a.bases[2 * (size_t)t + 1] = lb;
+    }
     st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
     const ZhipDictEntropy* const de = a.dictEntropy;
     const int r = zd_literals(L, st, src + pos, bs, lit, blockMax, P, &df);
@@ -256,6 +273,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 else { zh_sync(); for (uint32_t k = lane; k < 256; k += 64) L.weights[k] = de->hufWeights[k]; zh_sync(); }
             }
             err = zp_block_tables(a, L, st, df, src, pos, bs, blockMax, i, m, P, true, false);
+            if (err == (int)ZP_RC_FALLBACK) { err = 0; fallback = true; break; }
             if (err) break;
             if (hasChecksum) {
                 if (pos + bs + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
@@ -645,7 +663,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
         if (active) {
             const uint32_t f = a.first + (a.itemCap ? a.itemFrame[i] : i);
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
-            uint8_t* lit = a.litArena + (size_t)i * ZP_LIT_STRIDE;
+            uint8_t* lit = a.bases ? a.litArena + (size_t)a.bases[2 * (size_t)i + 1] * 16 : a.litArena + (size_t)i * ZP_LIT_STRIDE;
 #define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream(L.sym[slot], L.len[slot], log, pp, sz, oo, nn, L.ring + lane)
             if (!four) { if (strm == 0) ok = ZP_HUF_STREAM(p, streamBytes, lit, litSize); }
             else {
@@ -815,6 +833,23 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         // group is stored at the first trip of the NEXT group; the very first store holds nothing and lands four slots before the
         // frame's -- the previous frame's unused tail, or the arena's front padding.
         ZpVec16* outp = (ZpVec16*)(a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 4);
+        if (!MB) {
+            // compact sequence arena: the group claims room for its frames with ONE atomic add -- every frame the group's longest count, rounded to
+            // whole store groups, + 4 slots in front (the first, empty store) and + 4 behind (where the other lanes' stores are parked and the last
+            // store of a count that is no multiple of four ends): the trips go on to the group's longest frame, so equal rooms need no bound in
+            // the loop, and the work order puts frames of like counts together (bins of 128), so little is wasted
+            const uint32_t per = ((nTrips - 5 + 3) & ~3u) + 8;
+            const uint32_t nAct = (uint32_t)zh_popc64(zh_ballot(active)) >> 2;
+            const uint32_t room = zh_first(zh_atomic_add(a.counters + 7, lane == 0 ? per * nAct : 0u));
+            if ((uint64_t)room + (uint64_t)per * nAct > a.seqBudget) {                      // the chunk's room is used up: the generic kernel's frames
+                if (active && isOF) { m->path = 2; const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f; }
+                zh_sync();
+                continue;
+            }
+            const uint32_t start = room + slot * per + 4;
+            if (active && isOF) a.bases[2 * (size_t)i] = start;
+            outp = (ZpVec16*)(a.seqArena + (isOF && active ? (size_t)start - 4 : (size_t)room + per - 4));
+        }
         const uint32_t outStep = isOF && active ? 2u : 0u;
         uint32_t g1lo = 0, g1hi = 0, g2lo = 0, g2hi = 0, g3lo = 0, g3hi = 0;       // the group's first three packed sequences
         ZpVec16 w0, w1; w0.a = w0.b = w0.c = w0.d = 0; w1 = w0;                       // the group as stored
@@ -910,6 +945,9 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 #endif
 struct ZpExecLDS {
     uint8_t asmb[ZP_ASM_BYTES + 64]; uint16_t mBeg[64]; uint16_t mEnd[64]; uint32_t misc[8];
+#if defined(ZP_K3_DIAG_FLOOR) && defined(ZP_FLOOR_LDSPAD)
+    uint8_t floorPad[ZP_FLOOR_LDSPAD];               // (diagnostic builds: the LDS a window over the recent output would take, i.e. its occupancy)
+#endif
     // the batch's long items (literal runs / far matches above ZD_COOP_LEN bytes), staged together in 16-byte units
     uint16_t uEnd[64], uLit[64], dstL[64], dstM[64], lenL[64], lenM[64]; uint32_t srcL[64], srcM[64];
 };
@@ -978,10 +1016,10 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                            uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
-    const uint64_t* seqs = a.seqArena + (size_t)t * ZP_SEQ_CAP;
+    const uint64_t* seqs = MB ? a.seqArena + (size_t)t * ZP_SEQ_CAP : a.seqArena + a.bases[2 * (size_t)t];
     const bool litRLE = m.litMode == 2;
     const uint32_t rleByte = m.litOff;
-    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)t * ZP_LIT_STRIDE;
+    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : MB ? a.litArena + (size_t)t * ZP_LIT_STRIDE : a.litArena + (size_t)a.bases[2 * (size_t)t + 1] * 16;
     const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
     const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;

@@ -239,8 +239,8 @@ struct ZdMeta {
 #define ZP_LITBIN_SHIFT 9                               // K1b work order: frames binned by litSize >> 9
 #define ZP_BIN_SHIFT 7                                  // K2 work order: frames binned by nbSeq >> 7 (256 bins), longest first
 
-#define ZP_CNT_BINS 8u                                  // counters[8 .. 8 + 512): the 256 + 256 bin counters of the two work orders
-#define ZP_CNT_WORDS (8u + 512u)
+#define ZP_CNT_BINS 16u                                 // counters[16 .. 16 + 512): the 256 + 256 bin counters of the two work orders
+#define ZP_CNT_WORDS (16u + 512u)
 
 // ---- frames of SEVERAL blocks through the same kernels (the chunk's `itemCap` != 0): the work item of K1b / K2 is a BLOCK. K1 (a wave per
 // frame) walks the frame's blocks, claims that many consecutive items and fills one ZdMeta each (offsets still relative to the frame's first
@@ -266,14 +266,20 @@ struct ZhipPipeArgs {
     uint8_t* dst; const uint64_t* dstSegs;
     uint64_t* outSizes; int32_t* status;
     ZdMeta* meta;               // chunk-local
-    uint8_t* litArena;          // chunk x ZP_LIT_STRIDE
-    uint64_t* seqArena;         // chunk x ZP_SEQ_CAP
+    uint8_t* litArena;          // several-block mode: itemCap x ZP_LIT_STRIDE; else COMPACT: litBudget16 x 16 bytes, a frame's literals at bases[2 i + 1] x 16
+    uint64_t* seqArena;         // several-block mode: itemCap x ZP_SEQ_CAP;    else COMPACT: seqBudget sequences, a frame's at bases[2 i]
+    // compact arenas (round 5; null / 0 in the several-block mode): K1 claims a frame's literal room (regenerated size + 256, the section header says it),
+    // K2 a group's sequence room (15 x the group's longest count, rounded, + 8) with one atomic add each on counters[8] / counters[7]; what no
+    // longer fits the chunk's budget is the generic kernel's. 12 GiB of scratch per 65 536-frame chunk instead of 31
+    uint32_t* bases;            // chunk x 2
+    uint32_t seqBudget, litBudget16;
     uint16_t* fseTables;        // chunk x ZP_FSE_CELLS
     uint32_t* order;            // chunk : K2's work list (chunk-local frame indices sorted by decreasing sequence count)
     uint16_t* hufTables;        // chunk x ZP_HUF_CELLS : Huffman decoding tables (symbol | nbBits << 8) for K1b
     uint32_t* orderLit;         // chunk : K1b's work list (frames with Huffman literals, by decreasing literal count)
     uint32_t* counters;         // per chunk slot (ZP_CNT_WORDS words): [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
-                                //                 [4] length of `orderLit`, [5] K1b group counter, [6] items claimed (several-block mode)
+                                //                 [4] length of `orderLit`, [5] K1b group counter, [6] items claimed (several-block mode),
+                                //                 [7] sequences claimed, [8] literal units (16 bytes) claimed (compact arenas)
     uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk

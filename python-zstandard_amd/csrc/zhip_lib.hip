@@ -298,7 +298,7 @@ struct zhip_ctx {
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
-    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs;
+    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
     int e1PerCU = 0, e2PerCU = 0;
@@ -339,7 +339,7 @@ struct zhip_ctx {
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
     size_t device_bytes() const
     {
-        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &encWorkspace, &encMeta, &encArena,
+        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &encWorkspace, &encMeta, &encArena,
                                &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
@@ -421,7 +421,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
-    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release();
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
@@ -641,8 +641,21 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
-        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * slots * ZP_LIT_STRIDE + ZP_LIT_FRONT) ||
-            c->pipeSeq.reserve(nslot * slots * ZP_SEQ_STRIDE + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
+        // the literal and sequence arenas. Several-block mode: a fixed slot per item. Frames of one block (every BASELINE shape): COMPACT -- K1 / K2
+        // claim what a frame's literals / a group's sequences need from a per-chunk budget (ZhipPipeArgs.bases): 60 KiB of literals and 15 360 sequences
+        // per frame on average (the ratio-3 bench corpus needs 45 KiB and 9 600; a block holds at most 128 KiB and 43 690), i.e. 3.75 + 7.5 GiB per
+        // 65 536-frame chunk instead of 8 + 22, with up to 1 024 frames' worth of worst case as the floor so that small batches never run out. What
+        // does not fit goes to the generic kernel (correct, slower): a batch of nothing but frames with more than 15 360 sequences each is that case.
+        const size_t floorFrames = slots < 1024 ? slots : 1024;
+        size_t seqBudget = slots * 15360, litBudget16 = slots * (61440 / 16);
+        if (seqBudget < floorFrames * ZP_SEQ_CAP) seqBudget = floorFrames * ZP_SEQ_CAP;
+        if (litBudget16 < floorFrames * (ZP_LIT_STRIDE / 16 + 1)) litBudget16 = floorFrames * (ZP_LIT_STRIDE / 16 + 1);
+        if (seqBudget > 0xFFFFFFF0u) seqBudget = 0xFFFFFFF0u;
+        if (litBudget16 > 0xFFFFFFF0u) litBudget16 = 0xFFFFFFF0u;
+        const size_t litBytes = mb ? slots * ZP_LIT_STRIDE : litBudget16 * 16 + 256, seqWords = mb ? slots * (size_t)ZP_SEQ_CAP : seqBudget;
+        if (!mb && c->pipeBases.reserve(nslot * slots * 2 * sizeof(uint32_t))) return g_reserveRc;
+        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * litBytes + ZP_LIT_FRONT) ||
+            c->pipeSeq.reserve(nslot * seqWords * 8 + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
@@ -680,8 +693,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * slots;
-            pa.litArena = (uint8_t*)c->pipeLit.p + ZP_LIT_FRONT + (size_t)sidx * slots * ZP_LIT_STRIDE;
-            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * slots * ZP_SEQ_CAP;
+            pa.litArena = (uint8_t*)c->pipeLit.p + ZP_LIT_FRONT + (size_t)sidx * litBytes;
+            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * seqWords;
+            if (!mb) { pa.bases = (uint32_t*)c->pipeBases.p + (size_t)sidx * slots * 2; pa.seqBudget = (uint32_t)seqBudget; pa.litBudget16 = (uint32_t)litBudget16; }
             pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * slots * ZP_FSE_CELLS;
             pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * slots;
             pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * slots * ZP_HUF_CELLS;
@@ -759,9 +773,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 const ZdMeta& m = hm[i];
                 fprintf(stderr, "[pipe] frame %zu status %d path %u seq [%u,%u) lit %u mode %u nbSeq %u logs %06x produced %u order[%zu]=%u\n", i, m.status, m.path,
                         m.seqOff, m.seqEnd, m.litSize, m.litMode, m.nbSeq, m.logs, m.produced, i, ord[i]);
-                if (m.nbSeq) {
-                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8];
-                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + i * ZP_SEQ_CAP, sizeof q, hipMemcpyDeviceToHost));
+                if (m.nbSeq && m.path == 1) {
+                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8]; uint32_t sb = (uint32_t)(i * ZP_SEQ_CAP);
+                    if (!mb) HIP_TRY(hipMemcpy(&sb, (uint32_t*)c->pipeBases.p + 2 * i, 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + sb, sizeof q, hipMemcpyDeviceToHost));
                     HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
                     fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
                             ZP_SEQ_LL(q[0]), ZP_SEQ_ML(q[0]), ZP_SEQ_OF(q[0]),
@@ -1319,7 +1334,7 @@ extern "C" size_t zhip_thread_memory_size(void)
 static void tls_trim(zhip_ctx* c)
 {
     const size_t limit = (size_t)2 << 30;
-    DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeSeq, &c->pipeFse, &c->pipeHuf, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
+    DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeSeq, &c->pipeFse, &c->pipeHuf, &c->pipeBases, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
                        &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst, &c->hDense };
     for (DevBuf* b : bufs) if (b->cap > limit) b->release();
 }

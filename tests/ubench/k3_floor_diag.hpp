@@ -6,15 +6,26 @@
 // assembly, no unit dealing, no need-masks, no dependency rounds: ~150 instructions per batch instead of ~700. Its time is what the memory
 // system (452 M far-match gathers per 65 536-frame step behind the L2) allows with K3's occupancy and access pattern: the floor under ANY
 // rewrite of the batch body, hand-written ISA included. Built with -DZP_K3_DIAG_FLOOR (csrc/build_variants.sh floor).
+// -DZP_FLOOR_WIN=<bytes> models an LDS WINDOW over the frame's recent output (the assembly buffer as a sliding linear buffer of that size: batches
+// are appended, and when the next one might not fit the last ZP_FLOOR_KEEP bytes move to the front): an item whose source starts inside the window
+// is read from LDS instead of global memory -- here: its global loads are dropped and two LDS reads stand in for them. The occupancy such a buffer
+// costs is set with -DZP_FLOOR_LDSPAD=<bytes> (ZpExecLDS grows by it) and -DZP_K3_MINWAVES.
+#ifndef ZP_FLOOR_WIN
+#define ZP_FLOOR_WIN 0
+#endif
+#ifndef ZP_FLOOR_KEEP
+#define ZP_FLOOR_KEEP 4096
+#endif
 template <bool DICT, bool PROF, bool MB>
 ZH_DEVFN int zp_exec_block_floor(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint8_t* dst, uint32_t cap, uint64_t cap64,
                                  uint32_t blockMax, uint32_t& opRef)
 {
     const uint32_t lane = zh_lane();
-    const uint64_t* seqs = a.seqArena + (size_t)t * ZP_SEQ_CAP;
-    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)t * ZP_LIT_STRIDE;
+    const uint64_t* seqs = a.seqArena + a.bases[2 * (size_t)t];
+    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)a.bases[2 * (size_t)t + 1] * 16;
     const uint32_t litSize = m.litSize;
     uint32_t op = 0, lp = 0, done = 0, carry = 0;
+    uint32_t base = 0;                                    // (window model) bytes of earlier output in the buffer in front of the batch
     const uint32_t nbSeq = m.nbSeq;
     uint64_t acc = 0;
     uint64_t qNext = lane < nbSeq ? seqs[lane] : 0;
@@ -39,7 +50,15 @@ ZH_DEVFN int zp_exec_block_floor(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMe
         const bool hasM = act && myML > 0;
         const bool farM = hasM && sAbs + (int32_t)myML <= (int32_t)ob;
         const bool pre = hasM && !farM && sAbs < (int32_t)ob;
-        const uint32_t lenMi = farM ? myML : pre ? (uint32_t)((int32_t)ob - sAbs) : 0u;
+        uint32_t lenMi = farM ? myML : pre ? (uint32_t)((int32_t)ob - sAbs) : 0u;
+        if (ZP_FLOOR_WIN) {                                // items that start inside the window: LDS reads instead of global loads
+            const bool inWin = lenMi > 0 && sAbs >= (int32_t)ob - (int32_t)base;
+#ifndef ZP_FLOOR_FREE          // (-DZP_FLOOR_FREE: the window's own LDS work left out -- the pure effect of the dropped requests)
+            const uint8_t* w = L.asmb + (inWin ? (uint32_t)(sAbs & 1023) : 0u);
+            acc ^= zh_ld64(w) ^ zh_ld64(w + (inWin && lenMi >= 8 && lenMi <= 16 ? lenMi - 8 : 0u));
+#endif
+            if (inWin) lenMi = 0;
+        }
         // own-lane pieces (first + last 8 bytes), as the real kernel addresses them
         const bool shortL = act && myLL > 0 && myLL <= 16, shortM = lenMi > 0 && lenMi <= 16;
         const uint8_t* ql = litPtr + (shortL ? litStart : 0u);
@@ -65,6 +84,19 @@ ZH_DEVFN int zp_exec_block_floor(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMe
         }
         carry = totB - whole;
         zh_sync();
+        if (ZP_FLOOR_WIN) {
+            base += whole;
+            if (base + ZP_ASM_BYTES + 64 > ZP_FLOOR_WIN) {                 // the buffer is full: the last KEEP bytes move to the front
+                if (base > ZP_FLOOR_KEEP) base = ZP_FLOOR_KEEP;
+#ifndef ZP_FLOOR_FREE
+                zh_v16 r[ZP_FLOOR_KEEP / 1024];
+                for (uint32_t k = 0; k < ZP_FLOOR_KEEP / 1024; k++) r[k] = *(const zh_v16*)(L.asmb + (((k + 1) * 1024 + lane * 16) & 4095u));
+                zh_sync();
+                for (uint32_t k = 0; k < ZP_FLOOR_KEEP / 1024; k++) *(zh_v16*)(L.asmb + ((k * 1024 + lane * 16) & 4095u)) = r[k];
+                zh_sync();
+#endif
+            }
+        }
         op += totT; lp += totL; done += cnt;
     }
     const uint32_t rest = litSize - lp;
