@@ -138,7 +138,11 @@ def emit(line):
             for obj in [line] + [v for v in line.values() if isinstance(v, dict)]:
                 if k in obj:
                     obj[k] = None
-    print(json.dumps(line))
+    global PENDING_LINE
+    PENDING_LINE = json.dumps(line)          # printed by main() as the process's LAST output (after the process group is gone: RCCL writes a version banner to stdout)
+
+
+PENDING_LINE = None
 
 
 class Job:
@@ -299,7 +303,9 @@ def e1f_regime(ctx, ktimes, frames):
         if ctx.kernel_name(k) == "zhip_encode_match_flat_kernel" and launches:
             fpl = frames if frames <= 65536 else 131072 if frames >= 131072 else frames          # what one launch holds (zhip_compress_batch_device)
             per = ms * 65536.0 / fpl
+            pick = ctx.table_pick()
             return {"match_kernel_ms_per_65536_frames": round(per, 2), "frames_per_launch": int(fpl), "known_range_ms": [397, 488],
+                    "table_pick": {"candidates_ms": [round(x, 1) for x in pick[0] if x > 0], "kept": pick[1]} if pick[0][0] > 0 else None,
                     "class": "fast" if per <= 425 else "slow" if per >= 455 else "middle",
                     "note": "placement of the context's tables, not the build: compare compress figures of equal class (launches of 131 072 frames cost ~9 % less per frame)"}
     return None
@@ -481,7 +487,8 @@ def bench_roundtrip(args, rank, world, dev, steps=None, warmup=None, quiet=False
                        "verification": "round trip compared in HBM for every frame; %d evenly spaced frames compared byte for byte with libzstd 1.5.7" % ns,
                        "parallelism": "frames sharded by rank; payload all-gatherv over RCCL after the timed steps" if world > 1 else "single GPU"}}
     if rank == 0:
-        line["compress"] = {"value": round(world * F * FRAME * steps / c_el / 1e9, 3), "ms_per_step": round(c_el / steps * 1e3, 3), "kernels": kernels_obj(cctx, c_k)}
+        line["compress"] = {"value": round(world * F * FRAME * steps / c_el / 1e9, 3), "ms_per_step": round(c_el / steps * 1e3, 3), "kernels": kernels_obj(cctx, c_k),
+                            "regime": e1f_regime(cctx, c_k, F)}
         line["decompress"] = {"value": round(world * F * FRAME * steps / d_el / 1e9, 3), "ms_per_step": round(d_el / steps * 1e3, 3), "kernels": kernels_obj(dctx, d_k)}
         allk = dict(c_k)
         line["roofline"], _ = roofline(cctx, allk, steps, 2 * (F * FRAME + ctotal), step_s * 1e3, F)
@@ -692,6 +699,13 @@ def main():
     finally:
         if USE_DIST:
             torch.distributed.destroy_process_group()
+        if PENDING_LINE is not None:
+            sys.stdout.flush()
+            try:
+                C.CDLL(None).fflush(None)                            # whatever native libraries still hold in stdio's buffer goes first
+            except OSError:
+                pass
+            print(PENDING_LINE, flush=True)
 
 
 def bench_frames(args, config, rank, world, dev):

@@ -164,6 +164,9 @@ int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, con
  * over the launches since the last call, measured with HIP events on the launch stream (for bench.py's roofline). */
 const char* zhip_kernel_name(int direction /*0 decompress, 1 compress*/);
 int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
+/* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 49 152 frames or more times the match kernel on
+ * up to three table allocations held side by side and keeps the fastest): ms3[k] = candidate k's time in ms (0 = not tried). Returns the index kept. */
+int         zhip_ctx_table_pick(zhip_ctx*, float* ms3);
 
 #ifdef __cplusplus
 }

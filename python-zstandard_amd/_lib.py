@@ -102,6 +102,7 @@ def lib():
         "zhip_ctx_set_size_hint": (None, [vp, u64]),
         "zhip_kernel_name": (C.c_char_p, [C.c_int]),
         "zhip_ctx_kernel_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "zhip_ctx_table_pick": (C.c_int, [vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in protos.items():
         f = getattr(L, name)
@@ -119,6 +120,7 @@ EXPORTED_SYMBOLS = [
     "zhip_decompress_batch", "zhip_free_outbufs", "zhip_free_payload", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
     "zhip_kernel_name", "zhip_ctx_kernel_time", "zhip_thread_memory_size", "zhip_compact_device", "zhip_ctx_set_size_hint",
+    "zhip_ctx_table_pick",
 ]
 
 

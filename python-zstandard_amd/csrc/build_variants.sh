@@ -31,6 +31,10 @@ for v in "$@"; do
     k3d3) build k3d3 -DZP_K3D_MINWAVES=3 & ;;
     asm2k) build asm2k -DZP_ASM_BYTES=2048 & ;;
     nt1) build nt1 -DZP_K3_NT=1 & ;;                      # K3: sequences and decoded literals read with streaming (nt) loads
+    zqnost) build zqnost -DZQ_DIAG_NOSTORE & ;;             # DIAGNOSTIC: K2 without its sequence stores
+    zqnt) build zqnt -DZQ_NT_STORE & ;;                    # K2: sequences stored with non-temporal stores
+    hufnost) build hufnost -DZP_K1B_DIAG_NOSTORE & ;;      # DIAGNOSTIC: K1b without its literal stores
+    hufnt) build hufnt -DZP_K1B_NT_STORE & ;;
     nt1w5) build nt1w5 -DZP_K3_NT=1 -DZP_K3_MINWAVES=5 & ;;
     nt3) build nt3 -DZP_K3_NT=3 & ;;
     own32) build own32 -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32 & ;;

@@ -602,7 +602,13 @@ ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t
     uint64_t pend = 0;
     while (i + 8 <= count) {                    // two symbols (<= 22 bits) per window, eight per trip and per 8-byte store
         zb_burst(B);
+#if defined(ZP_K1B_DIAG_NOSTORE)    // DIAGNOSTIC ONLY (wrong literals): K1b without its literal stores
+        if (i && pend == 0x0123456789ABCDEFull) zh_st64(out, pend);
+#elif defined(ZP_K1B_NT_STORE)
+        if (i) __builtin_nontemporal_store(pend, (zh_u64u*)(out + i - 8));
+#else
         if (i) zh_st64(out + i - 8, pend);
+#endif
         uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
         ZP_PAIR(s0, s1); ZP_PAIR(s2, s3); ZP_PAIR(s4, s5); ZP_PAIR(s6, s7);
         pend = (uint64_t)(s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) | ((uint64_t)(s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) << 32);
@@ -898,7 +904,15 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
                 {   const uint32_t plo = llv | (mlv << 17), phi = (mlv >> 15) | (offset << 3);
                     if (u == 0) {                                                     // (compile-time: the loop is unrolled)
                         w0.a = g1lo; w0.b = g1hi; w0.c = g2lo; w0.d = g2hi; w1.a = g3lo; w1.b = g3hi; w1.c = plo; w1.d = phi;
+#if defined(ZQ_DIAG_NOSTORE)        // DIAGNOSTIC ONLY (K3 then reads garbage): K2 without its sequence stores -- what their latency costs the chain (vmcnt is in order)
+                        outp += outStep;
+#elif defined(ZQ_NT_STORE)
+                        {   typedef uint32_t zq_v4 __attribute__((ext_vector_type(4)));
+                            zq_v4 t0 = { w0.a, w0.b, w0.c, w0.d }, t1 = { w1.a, w1.b, w1.c, w1.d };
+                            __builtin_nontemporal_store(t0, (zq_v4*)outp); __builtin_nontemporal_store(t1, (zq_v4*)(outp + 1)); outp += outStep; }
+#else
                         outp[0] = w0; outp[1] = w1; outp += outStep;
+#endif
                     } else if (u == 1) { g1lo = plo; g1hi = phi; } else if (u == 2) { g2lo = plo; g2hi = phi; } else { g3lo = plo; g3hi = phi; } }
                 ZQ_F2();
                 // ---- chain. Fields lie in the stream in the order OF, ML, LL extra bits, then LL, ML, OF state bits: inclusive prefix sums over

@@ -330,8 +330,10 @@ struct zhip_ctx {
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
-        int e1lProbes = 2; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
+        bool e1fPick = true; int e1lProbes = 2; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
     } knob;
+    size_t flatMaxCached = 0;                    // frames per launch of the flat match kernel for batches above 65 536 (0: not decided yet)
+    bool e1fPicked = false; float e1fPickMs[3] = {0, 0, 0}; int e1fPickKept = 0;      // the flat match kernel's tables: placement picked once per context (zhip_compress_batch_device)
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
     unsigned long long* profPipe = nullptr;
@@ -374,6 +376,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_E1L_PROBES")) { const long v = atol(e); if (v == 2 || v == 4) k.e1lProbes = (int)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
+        if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
         if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
@@ -454,6 +457,13 @@ extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, u
     if (launches) *launches = t.launches;
     t.totalMs = 0; t.launches = 0;
     return 0;
+}
+
+extern "C" int zhip_ctx_table_pick(zhip_ctx* c, float* ms3)
+{
+    if (!c) return 0;
+    if (ms3) for (int k = 0; k < 3; k++) ms3[k] = c->e1fPickMs[k];
+    return c->e1fPickKept;
 }
 
 static uint64_t dict_fingerprint(const void* p, size_t n, uint64_t salt)
@@ -948,13 +958,21 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // frames per launch of the flat match kernel: the search is a latency chain per frame, so its rate grows with the frames in flight -- 16 384: 204 ms,
         // 32 768: 270, 65 536: 417, 131 072: 760 (r04za: 9 % less per frame than two launches of 65 536, a second wave per SIMD) -- and what it costs
         // is memory, 384 KiB of tables + 196 KiB of arena per frame. Batches above 65 536 take 131 072 per launch where the device has that free.
+        // (the decision is taken once per context -- hipMemGetInfo is not a launch-path call -- and a reservation that fails at 131 072
+        // after all, because another context took the memory in between, falls back to 65 536 below instead of failing the call)
         size_t flatMax = c->knob.echunkMax;
         if (!flatMax) {
             flatMax = 65536;
-            size_t freeB = 0, totalB = 0;
-            if (flat && !c->hasCDict && n > 65536 && hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-                const size_t need = (size_t)131072 * ((size_t)a.tableStride + (size_t)a.arenaStride) / 8 * 9 + ((size_t)4 << 30);
-                if (freeB + c->encFlatTables.cap + c->encArena.cap >= need) flatMax = 131072;
+            if (flat && !c->hasCDict && n > 65536) {
+                if (!c->flatMaxCached) {
+                    size_t freeB = 0, totalB = 0;
+                    c->flatMaxCached = 65536;
+                    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                        const size_t need = (size_t)131072 * ((size_t)a.tableStride + (size_t)a.arenaStride) / 8 * 9 + ((size_t)4 << 30);
+                        if (freeB + c->encFlatTables.cap + c->encArena.cap >= need) c->flatMaxCached = 131072;
+                    }
+                }
+                flatMax = c->flatMaxCached;
             }
         }
         size_t chunkMax = c->hasCDict ? 262144 : flat ? flatMax : 32768;
@@ -991,7 +1009,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         if (c->encMeta.reserve(cap * sizeof(ZeMeta)) || c->encArena.reserve(cap * (size_t)a.arenaStride) ||
             c->encTables.reserve(tabPer) || c->encWorkspace.reserve(wsPer) ||
             c->encBigList.reserve(bigListPer) || c->encE1List.reserve(e1ListPer) ||
-            (flat && c->encFlatTables.reserve(cap * (size_t)a.tableStride))) return g_reserveRc;
+            (flat && c->encFlatTables.reserve(cap * (size_t)a.tableStride))) {
+            if (g_reserveRc == ZHIP_ERR_NO_MEMORY && !c->knob.echunkMax && c->flatMaxCached > 65536) {      // no room for 131 072 per launch after all: 65 536
+                c->flatMaxCached = 65536; c->encArena.release(); c->encFlatTables.release();
+                return zhip_compress_batch_device(c, d_src, d_srcSegs, n, d_dst, d_dstSegs, d_outSizes, d_status, streamv);
+            }
+            return g_reserveRc;
+        }
         if (mbc) {
             if (c->encMbBlocks.reserve(chunk * mbMaxBlocks * sizeof(ZeMbBlock)) || c->encMbCount.reserve(chunk * sizeof(uint32_t) + 16) ||
                 c->encMbSeqs.reserve(chunk * mbSeqCap * 8)) return g_reserveRc;
@@ -1001,11 +1025,55 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         a.workspace = (uint8_t*)c->encWorkspace.p;
         a.meta = (ZeMeta*)c->encMeta.p; a.arena = (uint8_t*)c->encArena.p; a.laneTables = (uint8_t*)c->encTables.p;
-        uint8_t* const flatTables = flat ? (uint8_t*)c->encFlatTables.p : nullptr;
+        uint8_t* flatTables = flat ? (uint8_t*)c->encFlatTables.p : nullptr;
         a.flatTables = flatTables; a.e1List = (uint32_t*)c->encE1List.p; a.e1Count = (uint32_t*)(cbase + 32);
         a.idle = cbase + 256;                                                       // (the context's own counter block: ADVICE r04 -- the caller's arena base need not be readable)
         a.useE1List = flat ? 1u : 0u;
         a.bigList = (uint32_t*)c->encBigList.p; a.bigCount = (uint32_t*)(cbase + 24);
+        // Picking the tables' placement (round 5). The flat match kernel's time for one and the same launch differs by ~14 % with WHERE the driver put
+        // this 25 GiB allocation (397-415 ms or 455-488 per 65 536 frames; sticky for the life of the allocation, not controllable
+        // through the allocator) -- and two allocations held at the same time are different memory. So the first large launch of a context times the
+        // real kernel on its tables, reserves a second set beside them, times that, and keeps the faster (tests/tools/e1f_pick_best.py, r05g: in every
+        // trial at least one of three candidates was the fast kind, and the best stayed the best). Costs two extra launches of the kernel and a transient
+        // second table allocation, once per context; skipped where the second set does not fit. ZHIP_E1F_PICK=0 turns it off.
+        if (flat && !flatDict && !mbc && c->knob.e1fPick && !c->e1fPicked && chunk >= 49152) {
+            c->e1fPicked = true;
+            const size_t cnt0 = chunk, bytes = cnt0 * (size_t)a.tableStride;
+            DevBuf cand;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            struct PickGuard { DevBuf& b; hipEvent_t& x; hipEvent_t& y; ~PickGuard() { b.release(); if (x) (void)hipEventDestroy(x); if (y) (void)hipEventDestroy(y); } } pickGuard{cand, e0, e1};
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                ZhipEncodeArgs pa = a; pa.first = 0; pa.count = (uint32_t)cnt0;
+                auto timeOn = [&](uint8_t* t, float* ms) -> int {
+                    pa.flatTables = t;
+                    HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
+                    HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));
+                    HIP_TRY(hipEventRecord(e0, stream));
+                    if (c->knob.flat3 && cnt0 <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
+                    else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
+                    HIP_TRY(hipEventRecord(e1, stream));
+                    HIP_TRY(hipEventSynchronize(e1));
+                    HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+                    return 0;
+                };
+                // up to three candidates: the context's own tables, then further sets reserved beside the best so far. Two times that differ by 8 % or more
+                // are the two kinds (r05g / r05h: 397-415 against 455-488 ms) -- the faster one is kept and the search ends; alike, a third set is tried
+                float best = 0, worst = 0;
+                if (int rc = timeOn(flatTables, &best)) return rc;
+                worst = best; c->e1fPickMs[0] = best;
+                for (int k = 1; k < 3; k++) {
+                    if (cand.reserve(bytes)) { (void)hipGetLastError(); break; }                 // no room for another set: keep what we have
+                    float ms = 0;
+                    if (int rc = timeOn((uint8_t*)cand.p, &ms)) return rc;
+                    c->e1fPickMs[k] = ms;
+                    if (ms < 0.97f * best) { std::swap(c->encFlatTables.p, cand.p); std::swap(c->encFlatTables.cap, cand.cap); best = ms; c->e1fPickKept = k; }
+                    if (ms > worst) worst = ms;
+                    cand.release();
+                    if (worst > 1.08f * best) break;
+                }
+                flatTables = (uint8_t*)c->encFlatTables.p; a.flatTables = flatTables;
+            } else (void)hipGetLastError();
+        }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
             if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));

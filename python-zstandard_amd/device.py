@@ -103,5 +103,11 @@ class DeviceBatchContext:
         self.L.zhip_ctx_kernel_time(self.ctx, direction, C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def table_pick(self):
+        """(candidate times in ms -- 0 = not tried --, index kept) of the compress direction's table placement pick; zeros while none has happened"""
+        ms = (C.c_float * 3)()
+        kept = self.L.zhip_ctx_table_pick(self.ctx, ms)
+        return [float(x) for x in ms], int(kept)
+
     def kernel_name(self, direction):
         return self.L.zhip_kernel_name(direction).decode()
