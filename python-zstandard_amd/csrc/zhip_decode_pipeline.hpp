@@ -100,9 +100,9 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
                              uint32_t blockMax, uint32_t t, ZdMeta& m, ZdProf& P, bool share, bool dictInLds)
 {
     const uint32_t lane = zh_lane();
-    uint8_t* lit = a.litArena + (size_t)t * ZP_LIT_STRIDE;
-    if (a.bases) {
-        // compact literal arena: the section header says how many literals a compressed / treeless section regenerates (RFC 8878 3.1.1.3.1.1; raw
+    uint8_t* lit;
+    {
+        // compact arena (shared with K2's sequence rooms): the section header says how many literals a compressed / treeless section regenerates (RFC 8878 3.1.1.3.1.1; raw
         // and RLE sections need no room: they are read in place / filled). + 256 bytes: K1b's whole-unit stores and K3's over-reads stay inside
         uint32_t need16 = 0;
         if (bs >= 5 && (src[pos] & 3u) >= 2u) {
@@ -113,10 +113,13 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
         uint32_t lb = 0;
         if (need16) {
             lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? need16 : 0u));
-            if ((uint64_t)lb + need16 > a.litBudget16) return ZP_RC_FALLBACK;                  // the chunk's literal room is used up: the generic kernel's frame
+            if ((uint64_t)lb + need16 > a.arenaBudget16) return ZP_RC_FALLBACK;                // the chunk's room is used up: the generic kernel's frame
         }
-        lit = a.litArena + (size_t)lb * 16;
-        if (zh_opaque(lane) == 0) a.bases[2 * (size_t)t + 1] = lb;
+        // (literal rooms grow DOWN from the arena's end, K2's sequence rooms UP from its start: one budget, and each kind stays packed -- K2's stores
+        // are what feels a wider destination, section 4.1)
+        const uint32_t lpos = need16 ? a.arenaBudget16 - lb - need16 : 0u;
+        lit = a.litArena + (size_t)lpos * 16;
+        if (zh_opaque(lane) == 0) a.bases[2 * (size_t)t + 1] = lpos;
     }
     st.litPtr = lit; st.litSize = 0; st.litRLE = 0; st.rleByte = 0;
     const ZhipDictEntropy* const de = a.dictEntropy;
@@ -390,7 +393,8 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
                     ZdLitDefer df; df.table = a.hufTables + (size_t)t * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
                     df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = prevTable; df.prevLog = prevLog; df.shared = 0; df.shareOK = 0;
                     err = zp_block_tables(a, L, st, df, src, pos, bs, blockMax, t, m, P, false, true);
-                    if (!err) {
+                    if (err == (int)ZP_RC_FALLBACK) { err = 0; fallback = true; }       // the chunk's literal room is used up: the generic kernel's frame (its items stay unused)
+                    else if (!err) {
                         m.path = 1;
                         const uint32_t lt = src[pos] & 3;                      // literals block type: 2 = a Huffman table of its own, 3 = treeless
                         if (lt >= 2) {
@@ -411,6 +415,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
             }
             // the first failing block decides the frame's answer -- K3 meets it in stream order (blocks before it may still be refused by K1b / K2)
             err = 0;
+            if (fallback) break;
             rec.path = 1;
         } while (false);
         if (fallback) rec.path = 2;
@@ -669,7 +674,7 @@ ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
         if (active) {
             const uint32_t f = a.first + (a.itemCap ? a.itemFrame[i] : i);
             const uint8_t* p = a.src + a.srcSegs[2 * (size_t)f] + streamOff;
-            uint8_t* lit = a.bases ? a.litArena + (size_t)a.bases[2 * (size_t)i + 1] * 16 : a.litArena + (size_t)i * ZP_LIT_STRIDE;
+            uint8_t* lit = a.litArena + (size_t)a.bases[2 * (size_t)i + 1] * 16;
 #define ZP_HUF_STREAM(pp, sz, oo, nn) zp_huf_stream(L.sym[slot], L.len[slot], log, pp, sz, oo, nn, L.ring + lane)
             if (!four) { if (strm == 0) ok = ZP_HUF_STREAM(p, streamBytes, lit, litSize); }
             else {
@@ -831,24 +836,26 @@ ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
         // (taken into registers HERE: left pending, the loads made the waitcnt pass put a conservative vmcnt wait at the loop's first use of
         // the history -- behind the ring's block load, whose round trip it then sat out every four steps: 5.6 -> 8.2 ms, r02x)
         rep0 = zh_opaque(rep0); rep1 = zh_opaque(rep1); rep2 = zh_opaque(rep2);
-        // the offset lane resolves the repeat offsets and stores; the other lanes' stores go to the frame's last arena slot (never a sequence:
-        // K1 refuses blocks of more than ZP_SEQ_CAP - 16), so the loop body has no branch. Lanes past their frame's last sequence run on
-        // harmlessly: every LDS access is masked, every fetch clamped, and their stores land in the unused tail of the frame's own arena slot.
+        // the offset lane resolves the repeat offsets and stores; the other lanes' stores are parked in the four slots behind the group's first room,
+        // so the loop body has no branch. Lanes past their frame's last sequence run on harmlessly: every LDS access is masked, every fetch
+        // clamped, and their stores land in the unused tail of the frame's own room (all rooms of a group are the longest frame's size).
         // Sequences leave in groups of four -- 32 aligned bytes, two 16-byte stores (one 8-byte store per step was a partial-sector write
         // each: r02 WRITE_SIZE 242 KB per frame for ~80 KB of sequences). Sequences 4g .. 4g + 3 come out of trips 4g + 1 .. 4g + 4, so a
-        // group is stored at the first trip of the NEXT group; the very first store holds nothing and lands four slots before the
-        // frame's -- the previous frame's unused tail, or the arena's front padding.
-        ZpVec16* outp = (ZpVec16*)(a.seqArena + (size_t)(active ? i : 0u) * ZP_SEQ_CAP + (isOF && active ? 0u : ZP_SEQ_CAP) - 4);
-        if (!MB) {
+        // group is stored at the first trip of the NEXT group; the very first store holds nothing and lands in the four slots in front of the room.
+        ZpVec16* outp;
+        {
             // compact sequence arena: the group claims room for its frames with ONE atomic add -- every frame the group's longest count, rounded to
             // whole store groups, + 4 slots in front (the first, empty store) and + 4 behind (where the other lanes' stores are parked and the last
             // store of a count that is no multiple of four ends): the trips go on to the group's longest frame, so equal rooms need no bound in
             // the loop, and the work order puts frames of like counts together (bins of 128), so little is wasted
             const uint32_t per = ((nTrips - 5 + 3) & ~3u) + 8;
             const uint32_t nAct = (uint32_t)zh_popc64(zh_ballot(active)) >> 2;
-            const uint32_t room = zh_first(zh_atomic_add(a.counters + 7, lane == 0 ? per * nAct : 0u));
-            if ((uint64_t)room + (uint64_t)per * nAct > a.seqBudget) {                      // the chunk's room is used up: the generic kernel's frames
-                if (active && isOF) { m->path = 2; const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f; }
+            const uint32_t need16 = per * nAct / 2;                                          // (per is a multiple of four: whole 16-byte units)
+            const uint32_t room16 = zh_first(zh_atomic_add(a.counters + 7, lane == 0 ? need16 : 0u));      // (sequence rooms grow up from the arena's start ...
+            const uint32_t room = room16 * 2;                                                // in sequences from a.seqArena
+            if ((uint64_t)room16 + need16 + a.counters[8] > a.arenaBudget16) {               //  ... K1's literal rooms, all claimed by now, down from its end)                               // the chunk's room is used up: the generic kernel's frames
+                // (several-block mode: K3 hands the frame over when it meets the item)
+                if (active && isOF) { m->path = 2; if (!MB) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = f; } }
                 zh_sync();
                 continue;
             }
@@ -1030,10 +1037,10 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                            uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
 {
     const uint32_t lane = zh_lane();
-    const uint64_t* seqs = MB ? a.seqArena + (size_t)t * ZP_SEQ_CAP : a.seqArena + a.bases[2 * (size_t)t];
+    const uint64_t* seqs = a.seqArena + a.bases[2 * (size_t)t];
     const bool litRLE = m.litMode == 2;
     const uint32_t rleByte = m.litOff;
-    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : MB ? a.litArena + (size_t)t * ZP_LIT_STRIDE : a.litArena + (size_t)a.bases[2 * (size_t)t + 1] * 16;
+    const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)a.bases[2 * (size_t)t + 1] * 16;
     const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
     const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
     uint8_t* const asmb = L.asmb;

@@ -266,20 +266,23 @@ struct ZhipPipeArgs {
     uint8_t* dst; const uint64_t* dstSegs;
     uint64_t* outSizes; int32_t* status;
     ZdMeta* meta;               // chunk-local
-    uint8_t* litArena;          // several-block mode: itemCap x ZP_LIT_STRIDE; else COMPACT: litBudget16 x 16 bytes, a frame's literals at bases[2 i + 1] x 16
-    uint64_t* seqArena;         // several-block mode: itemCap x ZP_SEQ_CAP;    else COMPACT: seqBudget sequences, a frame's at bases[2 i]
-    // compact arenas (round 5; null / 0 in the several-block mode): K1 claims a frame's literal room (regenerated size + 256, the section header says it),
-    // K2 a group's sequence room (15 x the group's longest count, rounded, + 8) with one atomic add each on counters[8] / counters[7]; what no
-    // longer fits the chunk's budget is the generic kernel's. 12 GiB of scratch per 65 536-frame chunk instead of 31
-    uint32_t* bases;            // chunk x 2
-    uint32_t seqBudget, litBudget16;
+    uint8_t* litArena;          // ONE compact arena of arenaBudget16 x 16 bytes holds literals and sequences (litArena == (uint8_t*)seqArena):
+    uint64_t* seqArena;         // a frame's (several-block mode: an item's) literals at litArena + bases[2 i + 1] x 16, its sequences at seqArena + bases[2 i]
+    // compact arena (round 5): K1 claims a frame's literal room (regenerated size + 256, the section header says it), K2 a group's sequence room
+    // (15 x the group's longest count, rounded, + 8) with one atomic add each (counters[8] / [7]), in 16-byte units of ONE arena -- literals from its
+    // end downwards, sequences from its start upwards, so that each kind stays packed --: a block's literals and
+    // sequences trade off (every sequence costs three bytes of output or more), so a common budget of 160 KiB per frame covers text (45 + 76 KiB),
+    // Huffman-only data (128 KiB + nothing) and match-only data alike; what no longer fits the chunk's budget is the generic kernel's.
+    // ~12 GiB of scratch per 65 536-frame chunk instead of 31
+    uint32_t* bases;            // chunk (several-block mode: itemCap) x 2
+    uint32_t arenaBudget16;
     uint16_t* fseTables;        // chunk x ZP_FSE_CELLS
     uint32_t* order;            // chunk : K2's work list (chunk-local frame indices sorted by decreasing sequence count)
     uint16_t* hufTables;        // chunk x ZP_HUF_CELLS : Huffman decoding tables (symbol | nbBits << 8) for K1b
     uint32_t* orderLit;         // chunk : K1b's work list (frames with Huffman literals, by decreasing literal count)
     uint32_t* counters;         // per chunk slot (ZP_CNT_WORDS words): [0] K1 work, [1] length of `order`, [2] K3 work, [3] K2 group counter,
                                 //                 [4] length of `orderLit`, [5] K1b group counter, [6] items claimed (several-block mode),
-                                //                 [7] sequences claimed, [8] literal units (16 bytes) claimed (compact arenas)
+                                //                 [7] / [8] 16-byte units of the compact arena claimed for sequences (from its start) / for literals (from its end)
     uint32_t* fallbackCount;    // length of the fallback list (shared by every chunk of the batch)
     uint32_t* fallbackList;     // frame indices for the generic kernel
     uint32_t first, count;      // frames [first, first + count) of the batch are this chunk

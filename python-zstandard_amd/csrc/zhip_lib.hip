@@ -298,7 +298,7 @@ struct zhip_ctx {
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
-    DevBuf pipeMeta, pipeLit, pipeSeq, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases;
+    DevBuf pipeMeta, pipeLit, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
     int e1PerCU = 0, e2PerCU = 0;
@@ -330,7 +330,7 @@ struct zhip_ctx {
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
-        bool e1fPick = true; int e1lProbes = 2; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
+        bool e1fPick = true; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
     } knob;
     size_t flatMaxCached = 0;                    // frames per launch of the flat match kernel for batches above 65 536 (0: not decided yet)
     bool e1fPicked = false; float e1fPickMs[3] = {0, 0, 0}; int e1fPickKept = 0;      // the flat match kernel's tables: placement picked once per context (zhip_compress_batch_device)
@@ -341,7 +341,7 @@ struct zhip_ctx {
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
     size_t device_bytes() const
     {
-        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeSeq, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &encWorkspace, &encMeta, &encArena,
+        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &encWorkspace, &encMeta, &encArena,
                                &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
@@ -373,7 +373,6 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
-        if (const char* e = getenv("ZHIP_E1L_PROBES")) { const long v = atol(e); if (v == 2 || v == 4) k.e1lProbes = (int)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
         if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
@@ -424,7 +423,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
-    c->pipeMeta.release(); c->pipeLit.release(); c->pipeSeq.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release();
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
@@ -651,21 +650,19 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         if (slots > 0x7FFFFFFFu) { g_lastError = "frame too large for the block arenas"; return ZHIP_ERR_UNSUPPORTED; }
         const size_t nChunks = (n + chunk - 1) / chunk;
         const int nslot = (int)(nChunks < (size_t)slotMax ? nChunks : (size_t)slotMax);
-        // the literal and sequence arenas. Several-block mode: a fixed slot per item. Frames of one block (every BASELINE shape): COMPACT -- K1 / K2
-        // claim what a frame's literals / a group's sequences need from a per-chunk budget (ZhipPipeArgs.bases): 60 KiB of literals and 15 360 sequences
-        // per frame on average (the ratio-3 bench corpus needs 45 KiB and 9 600; a block holds at most 128 KiB and 43 690), i.e. 3.75 + 7.5 GiB per
-        // 65 536-frame chunk instead of 8 + 22, with up to 1 024 frames' worth of worst case as the floor so that small batches never run out. What
-        // does not fit goes to the generic kernel (correct, slower): a batch of nothing but frames with more than 15 360 sequences each is that case.
+        // ONE compact arena holds literals and sequences (a "frame" below is an ITEM -- a block -- in the several-block mode): K1 claims what a
+        // frame's literals need, K2 what a group's sequences need, from a per-chunk budget (ZhipPipeArgs.bases). A block's literals and sequences
+        // trade off -- every sequence costs at least three bytes of output -- so the budget is common: 160 KiB per frame on average (the ratio-3 bench
+        // corpus needs 45 KiB + 76 KiB, Huffman-only data 128 KiB + nothing, 4-symbol noise 3 + 150 KiB; the worst case, a match every three bytes, 350 KiB):
+        // 10 GiB per 65 536-frame chunk instead of the 8 + 22 GiB of fixed slots, with up to 1 024 frames' worth of worst case as the floor so that small
+        // batches never run out. What does not fit goes to the generic kernel (correct, slower).
         const size_t floorFrames = slots < 1024 ? slots : 1024;
-        size_t seqBudget = slots * 15360, litBudget16 = slots * (61440 / 16);
-        if (seqBudget < floorFrames * ZP_SEQ_CAP) seqBudget = floorFrames * ZP_SEQ_CAP;
-        if (litBudget16 < floorFrames * (ZP_LIT_STRIDE / 16 + 1)) litBudget16 = floorFrames * (ZP_LIT_STRIDE / 16 + 1);
-        if (seqBudget > 0xFFFFFFF0u) seqBudget = 0xFFFFFFF0u;
-        if (litBudget16 > 0xFFFFFFF0u) litBudget16 = 0xFFFFFFF0u;
-        const size_t litBytes = mb ? slots * ZP_LIT_STRIDE : litBudget16 * 16 + 256, seqWords = mb ? slots * (size_t)ZP_SEQ_CAP : seqBudget;
-        if (!mb && c->pipeBases.reserve(nslot * slots * 2 * sizeof(uint32_t))) return g_reserveRc;
-        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * litBytes + ZP_LIT_FRONT) ||
-            c->pipeSeq.reserve(nslot * seqWords * 8 + ZP_SEQ_FRONT * 8) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
+        size_t arenaBudget16 = slots * ((160u << 10) / 16);
+        if (arenaBudget16 < floorFrames * ((ZP_SEQ_STRIDE + ZP_LIT_STRIDE) / 16)) arenaBudget16 = floorFrames * ((ZP_SEQ_STRIDE + ZP_LIT_STRIDE) / 16);
+        if (arenaBudget16 > 0xFFFFFFF0u) arenaBudget16 = 0xFFFFFFF0u;
+        const size_t arenaBytes = arenaBudget16 * 16 + 512;
+        if (c->pipeBases.reserve(nslot * slots * 2 * sizeof(uint32_t))) return g_reserveRc;
+        if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * arenaBytes + ZP_LIT_FRONT) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
@@ -703,9 +700,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             const size_t cnt = n - first < chunk ? n - first : chunk;
             pa.first = (uint32_t)first; pa.count = (uint32_t)cnt;
             pa.meta = (ZdMeta*)c->pipeMeta.p + (size_t)sidx * slots;
-            pa.litArena = (uint8_t*)c->pipeLit.p + ZP_LIT_FRONT + (size_t)sidx * litBytes;
-            pa.seqArena = (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + (size_t)sidx * seqWords;
-            if (!mb) { pa.bases = (uint32_t*)c->pipeBases.p + (size_t)sidx * slots * 2; pa.seqBudget = (uint32_t)seqBudget; pa.litBudget16 = (uint32_t)litBudget16; }
+            pa.litArena = (uint8_t*)c->pipeLit.p + ZP_LIT_FRONT + (size_t)sidx * arenaBytes;     // (ZP_LIT_FRONT = 256 bytes in front: K2's parked / first stores of a room at 0 land there)
+            pa.seqArena = (uint64_t*)pa.litArena;
+            pa.bases = (uint32_t*)c->pipeBases.p + (size_t)sidx * slots * 2; pa.arenaBudget16 = (uint32_t)arenaBudget16;
             pa.fseTables = (uint16_t*)c->pipeFse.p + (size_t)sidx * slots * ZP_FSE_CELLS;
             pa.order = (uint32_t*)c->pipeOrder.p + (size_t)sidx * slots;
             pa.hufTables = (uint16_t*)c->pipeHuf.p + (size_t)sidx * slots * ZP_HUF_CELLS;
@@ -784,9 +781,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 fprintf(stderr, "[pipe] frame %zu status %d path %u seq [%u,%u) lit %u mode %u nbSeq %u logs %06x produced %u order[%zu]=%u\n", i, m.status, m.path,
                         m.seqOff, m.seqEnd, m.litSize, m.litMode, m.nbSeq, m.logs, m.produced, i, ord[i]);
                 if (m.nbSeq && m.path == 1) {
-                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8]; uint32_t sb = (uint32_t)(i * ZP_SEQ_CAP);
-                    if (!mb) HIP_TRY(hipMemcpy(&sb, (uint32_t*)c->pipeBases.p + 2 * i, 4, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(q, (uint64_t*)c->pipeSeq.p + ZP_SEQ_FRONT + sb, sizeof q, hipMemcpyDeviceToHost));
+                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8]; uint32_t sb = 0;
+                    HIP_TRY(hipMemcpy(&sb, (uint32_t*)c->pipeBases.p + 2 * i, 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(q, (uint64_t*)((uint8_t*)c->pipeLit.p + ZP_LIT_FRONT) + sb, sizeof q, hipMemcpyDeviceToHost));
                     HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
                     fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
                             ZP_SEQ_LL(q[0]), ZP_SEQ_ML(q[0]), ZP_SEQ_OF(q[0]),
@@ -1101,17 +1098,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 if (mbc) hipLaunchKernelGGL(zhip_encode_split_kernel, dim3((uint32_t)(cnt < (size_t)c->numCU * 8 ? cnt : (size_t)c->numCU * 8)), dim3(64), 0, stream, a);
                 if (cnt <= ldsMax && !flatDict && !mbc) {
                     const dim3 g((uint32_t)cnt), b(64);
-                    if (c->knob.e1lProbes == 4) {
-                        if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 4>), g, b, 0, stream, a);
-                        else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 4>), g, b, 0, stream, a);
-                        else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 4>), g, b, 0, stream, a);
-                        else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 4>), g, b, 0, stream, a);
-                    } else {
-                        if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 2>), g, b, 0, stream, a);
-                        else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 2>), g, b, 0, stream, a);
-                        else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
-                        else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
-                    }
+                    if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 2>), g, b, 0, stream, a);
+                    else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 2>), g, b, 0, stream, a);
+                    else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
+                    else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
                 }
                 else if (!flatDict && !mbc && cnt <= c->knob.flat4Max) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
                 else if (!flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
@@ -1402,7 +1392,7 @@ extern "C" size_t zhip_thread_memory_size(void)
 static void tls_trim(zhip_ctx* c)
 {
     const size_t limit = (size_t)2 << 30;
-    DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeSeq, &c->pipeFse, &c->pipeHuf, &c->pipeBases, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
+    DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeFse, &c->pipeHuf, &c->pipeBases, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
                        &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst, &c->hDense };
     for (DevBuf* b : bufs) if (b->cap > limit) b->release();
 }

@@ -137,8 +137,8 @@ static void k3_lane(void* p)
     else if (a.dictContent) zp_exec_body<true, false>(a, g_xlds); else zp_exec_body<false, false>(a, g_xlds);
 }
 static void k1mb_lane(void* p) { zp_lit_mb_body(*(const ZhipPipeArgs*)p, g_lds); }
-static uint64_t g_seqBudget = 0, g_litBudget16 = 0;     // compact decode arenas: != 0 overrides the harness' worst-case budgets (what runs out is the generic kernel's)
-extern "C" void emu_set_arena_budget(uint64_t seqs, uint64_t lit16) { g_seqBudget = seqs; g_litBudget16 = lit16; }
+static uint64_t g_arenaBudget16 = 0;                    // compact decode arena: != 0 overrides the harness' worst-case budget, in 16-byte units (what runs out is the generic kernel's)
+extern "C" void emu_set_arena_budget(uint64_t units16) { g_arenaBudget16 = units16; }
 static uint32_t g_mbPerFrame = 0;              // several-block mode of the pipeline harness: item slots per frame (0 = off), mirrors zhip_decompress_batch_device
 extern "C" void emu_set_blocks(uint32_t perFrame) { g_mbPerFrame = perFrame; }
 // decompression dictionary for the pipeline harness (mirrors zhip_ctx_set_ddict): blob, parsed entropy section, ready-made tables
@@ -177,11 +177,10 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     const size_t slots = (size_t)chunk * (mb ? g_mbPerFrame : 1u);
     a.src = src; a.srcSegs = srcSegs; a.dst = dst; a.dstSegs = dstSegs; a.outSizes = outSizes; a.status = status;
     a.meta = (ZdMeta*)calloc(slots, sizeof(ZdMeta));
-    // (frames of one block: the compact arenas with a budget -- worst case by default: every frame a full literal slot, every K2 group its longest possible room)
-    const size_t seqBudget = mb ? 0 : g_seqBudget ? (size_t)g_seqBudget : slots * (size_t)ZP_SEQ_CAP * 2, litBudget16 = mb ? 0 : g_litBudget16 ? (size_t)g_litBudget16 : slots * (ZP_LIT_STRIDE / 16 + 1);
-    uint8_t* const litAlloc = (uint8_t*)malloc((mb ? slots * ZP_LIT_STRIDE : litBudget16 * 16 + 256) + ZP_LIT_FRONT); a.litArena = litAlloc + ZP_LIT_FRONT;
-    uint64_t* const seqAlloc = (uint64_t*)malloc((mb ? slots * ZP_SEQ_STRIDE : seqBudget * 8) + ZP_SEQ_FRONT * 8); a.seqArena = seqAlloc + ZP_SEQ_FRONT;
-    if (!mb) { a.bases = (uint32_t*)malloc(slots * 8); memset(a.bases, 0xA5, slots * 8); a.seqBudget = (uint32_t)seqBudget; a.litBudget16 = (uint32_t)litBudget16; }
+    // (ONE compact arena for literals and sequences with a budget -- worst case by default: every frame a full literal slot and its K2 group's longest possible room)
+    const size_t arenaBudget16 = g_arenaBudget16 ? (size_t)g_arenaBudget16 : slots * ((ZP_SEQ_STRIDE * 2 + ZP_LIT_STRIDE) / 16 + 1);
+    uint8_t* const litAlloc = (uint8_t*)malloc(arenaBudget16 * 16 + 512 + ZP_LIT_FRONT); a.litArena = litAlloc + ZP_LIT_FRONT; a.seqArena = (uint64_t*)a.litArena;
+    a.bases = (uint32_t*)malloc(slots * 8); memset(a.bases, 0xA5, slots * 8); a.arenaBudget16 = (uint32_t)arenaBudget16;
     a.fseTables = (uint16_t*)malloc(slots * ZP_FSE_CELLS * 2);
     a.order = (uint32_t*)calloc(slots, 4);
     a.hufTables = (uint16_t*)malloc(slots * ZP_HUF_CELLS * 2 + 64);
@@ -218,7 +217,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     DecLaunch l = { &g };
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[ZP_CNT_WORDS];
-    free(g.scratch); free(a.meta); free(litAlloc); free(seqAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
+    free(g.scratch); free(a.meta); free(litAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
     free(a.itemFrame); free(a.itemReps); free(a.frameRecs); free(a.bases);
     return nfb;
 }

@@ -335,7 +335,7 @@ def test_emulated_decode_pipeline_on_varied_frames(emu, corpus):
 
 
 def test_compact_decode_arenas_run_out_gracefully(emu, oracle, corpus):
-    """Round 5: frames of one block take their literal / sequence room from per-chunk budgets (ZhipPipeArgs.bases: K1 claims the literals' room,
+    """Round 5: frames take their literal / sequence room from ONE per-chunk arena with a budget (ZhipPipeArgs.bases: K1 claims the literals' room,
     K2 a group's sequences' with one atomic add). A chunk whose budget is used up hands the frames that found no room to the generic kernel:
     every frame still decodes to its bytes, some of them through the fallback list; with room for everybody none does."""
     import ctypes
@@ -344,15 +344,25 @@ def test_compact_decode_arenas_run_out_gracefully(emu, oracle, corpus):
     raws = [corpus.frame_bytes(i)[: 2000 + 5000 * i] for i in range(24)] + [rng.bytes(30000), b"ab" * 30000, bytes(rng.integers(0, 4, 90000, dtype=np.uint8))]
     frames = [oracle.compress(r, level=3, flags=5) for r in raws]
     sizes = [len(r) for r in raws]
-    emu.lib.emu_set_arena_budget.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    emu.lib.emu_set_arena_budget.argtypes = [ctypes.c_uint64]
     try:
-        for seqs, lit16, expect_fallback in ((0, 0, False), (40000, 0, True), (0, 3000, True), (1, 1, True)):
-            emu.lib.emu_set_arena_budget(seqs, lit16)
+        for units16, expect_fallback in ((0, False), (30000, True), (1, True)):                  # (units of 16 bytes: room for everybody / for some / for nobody)
+            emu.lib.emu_set_arena_budget(units16)
             dec, st, nfb = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=0)
-            assert not any(st) and dec == raws, (seqs, lit16)
-            assert (nfb > 0) == expect_fallback, (seqs, lit16, nfb)
+            assert not any(st) and dec == raws, units16
+            assert (nfb > 0) == expect_fallback, (units16, nfb)
+        # the several-block mode claims per ITEM (block): frames of one to three blocks, room for everybody / for some
+        big = [corpus.frame_bytes(40 + i) + corpus.frame_bytes(80 + i)[: 70000 * (i % 3)] for i in range(6)]
+        bframes = [oracle.compress(r, level=3, flags=5) for r in big]
+        emu.set_blocks(4)
+        for units16, expect_fallback in ((0, False), (25000, True)):
+            emu.lib.emu_set_arena_budget(units16)
+            dec, st, nfb = emu.decompress_pipeline(bframes, [len(r) for r in big], n_blocks=3, chunk=0)
+            assert not any(st) and dec == big, units16
+            assert (nfb > 0) == expect_fallback, (units16, nfb)
     finally:
-        emu.lib.emu_set_arena_budget(0, 0)
+        emu.lib.emu_set_arena_budget(0)
+        emu.set_blocks(0)
 
 
 def test_emulated_decode_pipeline_with_dictionaries(emu, ref, corpus):
