@@ -341,21 +341,21 @@ def test_compact_decode_arenas_run_out_gracefully(emu, oracle, corpus):
     import ctypes
     import numpy as np
     rng = np.random.default_rng(23)
-    raws = [corpus.frame_bytes(i)[: 2000 + 5000 * i] for i in range(24)] + [rng.bytes(30000), b"ab" * 30000, bytes(rng.integers(0, 4, 90000, dtype=np.uint8))]
+    raws = [corpus.frame_bytes(i)[: 2000 + 9000 * i] for i in range(12)] + [rng.bytes(30000), b"ab" * 30000, bytes(rng.integers(0, 4, 60000, dtype=np.uint8))]
     frames = [oracle.compress(r, level=3, flags=5) for r in raws]
     sizes = [len(r) for r in raws]
     emu.lib.emu_set_arena_budget.argtypes = [ctypes.c_uint64]
     try:
-        for units16, expect_fallback in ((0, False), (30000, True), (1, True)):                  # (units of 16 bytes: room for everybody / for some / for nobody)
+        for units16, expect_fallback in ((0, False), (20000, True), (1, True)):                  # (units of 16 bytes: room for everybody / for some / for nobody)
             emu.lib.emu_set_arena_budget(units16)
             dec, st, nfb = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=0)
             assert not any(st) and dec == raws, units16
             assert (nfb > 0) == expect_fallback, (units16, nfb)
         # the several-block mode claims per ITEM (block): frames of one to three blocks, room for everybody / for some
-        big = [corpus.frame_bytes(40 + i) + corpus.frame_bytes(80 + i)[: 70000 * (i % 3)] for i in range(6)]
+        big = [corpus.frame_bytes(40 + i) + corpus.frame_bytes(80 + i)[: 70000 * (i % 3)] for i in range(4)]
         bframes = [oracle.compress(r, level=3, flags=5) for r in big]
         emu.set_blocks(4)
-        for units16, expect_fallback in ((0, False), (25000, True)):
+        for units16, expect_fallback in ((0, False), (16000, True)):
             emu.lib.emu_set_arena_budget(units16)
             dec, st, nfb = emu.decompress_pipeline(bframes, [len(r) for r in big], n_blocks=3, chunk=0)
             assert not any(st) and dec == big, units16
