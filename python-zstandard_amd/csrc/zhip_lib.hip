@@ -326,7 +326,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0, hchunkD0 = 2048; long e1LdsMax = -1; size_t e1LdsRounds = 2;
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
@@ -371,6 +371,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_MBC_MIN")) k.mbcMin = (size_t)atol(e);     // compress: batches of at least this many sources take the flat search for sources of several blocks
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
+        if (const char* e = getenv("ZHIP_HCHUNK_D0")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.hchunkD0 = (size_t)v; }      // decompress: items of the host pipeline's first chunk (0: like the others)
         if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
@@ -1479,7 +1480,9 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     if (r) return set_err(err, r, 0, 0);
     if (host_pipe_init(c)) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // the kernels are several times faster than the link here: chunks of ~1 GiB of output keep all three streams busy
-    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)1 << 30, 32768);
+    // (a small FIRST chunk -- ZHIP_HCHUNK_D0 items, default 2 048 for batches above 8 192 -- starts the copy back, which is what the call waits for, a few ms after
+    // the call instead of after a whole chunk's packing, upload and kernels)
+    const std::vector<size_t> cut = host_chunks(segs.data(), n, (uint64_t)1 << 30, 32768, n > 8192 ? c->knob.hchunkD0 : 0);
     const size_t nChunks = cut.size() - 1;
     if (c->hSrc.reserve(srcTotal + 16) || c->hDst.reserve(dstTotal + 16) || c->hSegs.reserve(2 * n * sizeof(zhip_segment) + 16) ||
         c->hStatus.reserve(n * (sizeof(uint64_t) + sizeof(int32_t)) + 16)) return set_err(err, g_reserveRc, 0, 0);

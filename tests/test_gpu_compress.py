@@ -239,3 +239,42 @@ def test_mixed_small_batch_through_the_large_batch_search(zstd, corpus):
     assert "error" not in box, box.get("error")
     for i, r in enumerate(raws):
         assert box["out"][i] == ref.compress(r, level=3), (i, len(r))
+
+
+def test_table_placement_pick_keeps_the_frames(zstd, corpus):
+    """Round 5: the first launch of 49 152 sources or more of a device context times the flat match kernel on up to three table allocations held side by
+    side and keeps the fastest placement (zhip_compress_batch_device). The probes rewrite the chunk's sequences and lists before the real
+    pass runs: every frame must still be libzstd's. 49 152 small sources (1-3 KiB: the launch is what counts, not the bytes), all compared."""
+    import importlib
+    import torch
+    from tests import reflib
+    dev_mod = importlib.import_module("zstandard_amd.device")
+    ref = reflib.checker()
+    dev = torch.device("cuda", 0)
+    F = 49152
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1024, 3073, F).astype(np.int64)
+    offs = np.zeros(F, dtype=np.int64); offs[1:] = np.cumsum(lens)[:-1]
+    pool = np.frombuffer(b"".join(corpus.frame_bytes(i) for i in range(64)), dtype=np.uint8)
+    starts = rng.integers(0, len(pool) - 4096, F)
+    src_np = np.concatenate([pool[s:s + n] for s, n in zip(starts, lens)])
+    bound = 4096
+    def segs(o, n):
+        a = np.zeros((F, 2), dtype=np.int64); a[:, 0] = o; a[:, 1] = n
+        return torch.from_numpy(a).to(dev)
+    src = torch.from_numpy(src_np).to(dev)
+    dst = torch.zeros(F * bound, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev); status = torch.zeros(F, dtype=torch.int32, device=dev)
+    ctx = dev_mod.DeviceBatchContext()
+    try:
+        for _ in range(2):                                         # the second call runs without probes on the tables the first one kept
+            ctx.compress(src, segs(offs, lens), dst, segs(np.arange(F, dtype=np.int64) * bound, np.full(F, bound, dtype=np.int64)), out_sizes, status)
+            torch.cuda.synchronize()
+            assert int(status.abs().max().item()) == 0
+            ms, kept = ctx.table_pick()
+            assert ms[0] > 0 and ms[1] > 0 and 0 <= kept <= 2, (ms, kept)
+            got = dst.view(F, bound).cpu().numpy(); sz = out_sizes.cpu().numpy()
+            for i in list(range(0, F, 97)) + [F - 1]:
+                assert got[i, : sz[i]].tobytes() == ref.compress(src_np[offs[i]: offs[i] + lens[i]].tobytes(), level=3), i
+    finally:
+        ctx.close()
