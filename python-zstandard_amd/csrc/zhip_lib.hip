@@ -333,7 +333,7 @@ struct zhip_ctx {
         bool e1fPick = true; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
     } knob;
     size_t flatMaxCached = 0;                    // frames per launch of the flat match kernel for batches above 65 536 (0: not decided yet)
-    bool e1fPicked = false; float e1fPickMs[3] = {0, 0, 0}; int e1fPickKept = 0;      // the flat match kernel's tables: placement picked once per context (zhip_compress_batch_device)
+    bool e1fPicked = false; float e1fPickMs[3] = {0, 0, 0}; int e1fPickKept = 0; void* e1fPickedPtr = nullptr;      // the flat match kernel's tables: placement picked once per context (zhip_compress_batch_device)
     bool timing = false;                         // per-kernel HIP-event timers: off until zhip_ctx_kernel_time() is first called
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
     unsigned long long* profPipe = nullptr;
@@ -1034,8 +1034,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // real kernel on its tables, reserves a second set beside them, times that, and keeps the faster (tests/tools/e1f_pick_best.py, r05g: in every
         // trial at least one of three candidates was the fast kind, and the best stayed the best). Costs two extra launches of the kernel and a transient
         // second table allocation, once per context; skipped where the second set does not fit. ZHIP_E1F_PICK=0 turns it off.
-        if (flat && !flatDict && !mbc && c->knob.e1fPick && !c->e1fPicked && chunk >= 49152) {
-            c->e1fPicked = true;
+        if (flat && !flatDict && !mbc && c->knob.e1fPick && chunk >= 49152 && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
+            c->e1fPicked = true; c->e1fPickKept = 0; c->e1fPickMs[1] = c->e1fPickMs[2] = 0;
             const size_t cnt0 = chunk, bytes = cnt0 * (size_t)a.tableStride;
             DevBuf cand;
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1072,6 +1072,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 }
                 flatTables = (uint8_t*)c->encFlatTables.p; a.flatTables = flatTables;
             } else (void)hipGetLastError();
+            c->e1fPickedPtr = c->encFlatTables.p;
         }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
