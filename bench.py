@@ -402,6 +402,8 @@ def bench_dict(args, rank, world, dev, steps=None, warmup=None, quiet=False):
     d_elapsed, d_k, _ = run_decompress(job, ctx, frames, csizes, raw, DOC, steps, warmup)
     if rank == 0:
         line["kernels"] = kernels_obj(ctx, ktimes)
+        pick = ctx.table_pick()
+        line["table_pick"] = {"candidates_ms": [round(x, 2) for x in pick[0] if x > 0], "kept": pick[1]} if pick[0][0] > 0 else None
         line["roofline"], _ = roofline(ctx, ktimes, steps, F * DOC + ctotal, ms)
         line["roofline"]["per_kernel"] = per_kernel_roofline(ctx, ktimes, steps, encode_own_bytes(sec, F, DOC))
         d_ms = d_elapsed / steps * 1e3

@@ -326,7 +326,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2, k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0, hchunkD0 = 2048; long e1LdsMax = -1; size_t e1LdsRounds = 2;
+        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2; bool nslotSet = false; int k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0, hchunkD0 = 2048; long e1LdsMax = -1; size_t e1LdsRounds = 2;
         // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
         // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
         // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
@@ -361,7 +361,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         k.noPipeline = getenv("ZHIP_NO_PIPELINE") != nullptr; k.prof = getenv("ZHIP_PROF") != nullptr; k.debug = getenv("ZHIP_DEBUG") != nullptr;
         k.debugPipe = getenv("ZHIP_DEBUG_PIPE") != nullptr; k.watchdog = getenv("ZHIP_WATCHDOG") != nullptr; k.noFlat = getenv("ZHIP_NO_FLAT") != nullptr;
         if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) k.dchunk = (size_t)v; }
-        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) k.nslot = (int)v; }
+        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) { k.nslot = (int)v; k.nslotSet = true; } }
         if (const char* e = getenv("ZHIP_ECHUNK_MAX")) { const long v = atol(e); if (v >= 65536 && v <= 262144) k.echunkMax = (size_t)v; }
         if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
         if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
@@ -627,12 +627,15 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // Chunks of frames flow through K1 -> K2 -> K3 on ZHIP_NSLOT internal streams (slot = chunk % NSLOT, each slot has its own
         // arenas and counters), so that different chunks' kernels overlap on the GPU: each phase is latency-bound with idle issue
         // slots, and their LDS footprints differ, which is exactly when co-residency pays.
-        const size_t chunkMax = c->knob.dchunk; const int slotMax = c->knob.nslot;      // measured on MI355X (profiles/README.md, r01c / r02f / r02zl): 65 536 frames per chunk, 2 slots
+        const size_t chunkMax = c->knob.dchunk; int slotMax = c->knob.nslot;      // measured on MI355X (profiles/README.md, r01c / r02f / r02zl): 65 536 frames per chunk, 2 slots
         // Frames of several blocks (the caller's size hint says so: the host API sets it from the items it sees): the several-block mode --
         // the arenas' slots are per BLOCK, a chunk is as many frames as fit `chunkMax` slots at the estimate below (libzstd cuts a block of
         // 128 KiB where the data changes; frames with more blocks than their share still work while the chunk has slots left, then
         // they are the generic kernel's)
         const uint64_t sizeHint = c->dstMaxHint ? c->dstMaxHint : c->itemHint;
+        // (small frames -- the caller says so -- are short kernels with launch gaps between them: a third chunk slot fills them. 262 144 x 4 KiB with the
+        // shared dictionary: 123 -> 134 GB/s, r05q; frames of 128 KiB: the kernels are long, two slots overlap little as it is)
+        if (!c->knob.nslotSet && sizeHint && sizeHint <= 16384 && slotMax < 3) slotMax = 3;
         const bool mb = c->knob.blocks && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
@@ -658,8 +661,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // 10 GiB per 65 536-frame chunk instead of the 8 + 22 GiB of fixed slots, with up to 1 024 frames' worth of worst case as the floor so that small
         // batches never run out. What does not fit goes to the generic kernel (correct, slower).
         const size_t floorFrames = slots < 1024 ? slots : 1024;
-        size_t arenaBudget16 = slots * ((160u << 10) / 16);
-        if (arenaBudget16 < floorFrames * ((ZP_SEQ_STRIDE + ZP_LIT_STRIDE) / 16)) arenaBudget16 = floorFrames * ((ZP_SEQ_STRIDE + ZP_LIT_STRIDE) / 16);
+        // (frames the caller says are SMALL cannot need more than their own worst case -- literals of the frame's size + 256, a sequence per three bytes in
+        // rooms of the group's longest + 8 --: 4 x the size + 1 KiB; 4 KiB documents get 17 KiB each instead of 160)
+        const size_t smallWorst = !mb && sizeHint && sizeHint < ZF_BLOCK_MAX ? 4 * (size_t)sizeHint + 1024 : (size_t)0;
+        const size_t roomPerFrame = smallWorst && smallWorst < (160u << 10) ? smallWorst : (size_t)(160u << 10);
+        size_t arenaBudget16 = slots * (roomPerFrame / 16);
+        const size_t worstFrame = smallWorst ? smallWorst : (size_t)(ZP_SEQ_STRIDE + ZP_LIT_STRIDE);
+        if (arenaBudget16 < floorFrames * (worstFrame / 16)) arenaBudget16 = floorFrames * (worstFrame / 16);
         if (arenaBudget16 > 0xFFFFFFF0u) arenaBudget16 = 0xFFFFFFF0u;
         const size_t arenaBytes = arenaBudget16 * 16 + 512;
         if (c->pipeBases.reserve(nslot * slots * 2 * sizeof(uint32_t))) return g_reserveRc;
@@ -1034,7 +1042,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // real kernel on its tables, reserves a second set beside them, times that, and keeps the faster (tests/tools/e1f_pick_best.py, r05g: in every
         // trial at least one of three candidates was the fast kind, and the best stayed the best). Costs two extra launches of the kernel and a transient
         // second table allocation, once per context; skipped where the second set does not fit. ZHIP_E1F_PICK=0 turns it off.
-        if (flat && !flatDict && !mbc && c->knob.e1fPick && chunk >= 49152 && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
+        if (flat && !mbc && c->knob.e1fPick && chunk >= 49152 && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
             c->e1fPicked = true; c->e1fPickKept = 0; c->e1fPickMs[1] = c->e1fPickMs[2] = 0;
             const size_t cnt0 = chunk, bytes = cnt0 * (size_t)a.tableStride;
             DevBuf cand;
@@ -1045,9 +1053,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 auto timeOn = [&](uint8_t* t, float* ms) -> int {
                     pa.flatTables = t;
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
-                    HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));
+                    if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: the kernel's waves zero what they use)
                     HIP_TRY(hipEventRecord(e0, stream));
-                    if (c->knob.flat3 && cnt0 <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
+                    if (!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
                     else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
                     HIP_TRY(hipEventSynchronize(e1));
