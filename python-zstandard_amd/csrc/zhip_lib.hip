@@ -1062,21 +1062,19 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     HIP_TRY(hipEventElapsedTime(ms, e0, e1));
                     return 0;
                 };
-                // up to three candidates: the context's own tables, then further sets reserved beside the best so far. Two times that differ by 12 %
-                // or more are the fast and a slow kind (r05g / r05h: 397-415 against 455-488 ms per 65 536 frames; 746-760 against 855-928 per 131 072) -- the faster one is kept and
-                // the search ends; closer together, a third set is tried
-                float best = 0, worst = 0;
+                // three candidates: the context's own tables, then two further sets, each reserved beside the best so far (r05g / r05h: 397-415 or 455-488 ms per
+                // 65 536 frames; 746-764, 805, 855, 928 per 131 072); the fastest is kept
+                float best = 0;
                 if (int rc = timeOn(flatTables, &best)) return rc;
-                worst = best; c->e1fPickMs[0] = best;
+                c->e1fPickMs[0] = best;
                 for (int k = 1; k < 3; k++) {
                     if (cand.reserve(bytes)) { (void)hipGetLastError(); break; }                 // no room for another set: keep what we have
                     float ms = 0;
                     if (int rc = timeOn((uint8_t*)cand.p, &ms)) return rc;
                     c->e1fPickMs[k] = ms;
                     if (ms < 0.97f * best) { std::swap(c->encFlatTables.p, cand.p); std::swap(c->encFlatTables.cap, cand.cap); best = ms; c->e1fPickKept = k; }
-                    if (ms > worst) worst = ms;
                     cand.release();
-                    if (worst > 1.12f * best) break;                                                     // (r05n: 928 against 855 ms at 131 072 frames were two SLOW kinds, 8.6 % apart -- the fast kind is 750)
+                    // (no early stop: at 131 072 frames per launch the kinds are not two but a spread -- 750, 805, 855, 928 ms, r05n / r05u -- so all three are timed)
                 }
                 flatTables = (uint8_t*)c->encFlatTables.p; a.flatTables = flatTables;
             } else (void)hipGetLastError();
