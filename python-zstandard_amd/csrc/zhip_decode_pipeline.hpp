@@ -19,8 +19,10 @@
 //
 // Several-block mode (the caller's size hint exceeds one block): zhip_decode_lit_mb_kernel (K1, a wave per frame over its blocks),
 // zhip_decode_seq_mb_kernel (K2 per block, symbolic repeat-offset history), zhip_decode_exec_mb_kernel (K3, a wave per frame over its blocks).
-// Anything else (sources of 2 GiB and more, frames that find the chunk's block slots used up, offsets the packed form cannot hold in a
-// frame of several blocks, frames of several blocks without the size hint) goes to the generic fused kernel through a fallback list, so
+// Literals (K1b / K1 -> K3) and packed sequences (K2 -> K3) live in ONE compact arena per chunk (round 5; ZhipPipeArgs.bases): K1 claims a frame's
+// literal room from its end, K2 a 15-frame group's sequence room from its start, one atomic add each.
+// Anything else (sources of 2 GiB and more, frames that find the chunk's block slots or the arena's room used up, offsets the packed form cannot hold
+// in a frame of several blocks, frames of several blocks without the size hint) goes to the generic fused kernel through a fallback list, so
 // results are identical on every input.
 #pragma once
 #include "zhip_decode_kernel.hpp"
@@ -754,9 +756,6 @@ template <bool MB>
 ZH_DEVFN void zp_seqq_body(const ZhipPipeArgs& a, ZpSeqQLDS& L)
 {
     const uint32_t lane = zh_lane(), role = lane & 3, slot = lane >> 2;
-#if defined(ZP_K2_PRIO) && !defined(ZHIP_EMU)
-    __builtin_amdgcn_s_setprio(ZP_K2_PRIO);      // co-resident with K3 waves (ZHIP_SPLIT): the serial chain wins issue arbitration
-#endif
     if (lane < 36) L.llInfo[lane] = zc_llBase[lane] | ((uint32_t)zc_llBits[lane] << 24);
     if (lane < 53) L.mlInfo[lane] = zc_mlBase[lane] | ((uint32_t)zc_mlBits[lane] << 24);
     if (lane == 0) L.spare = 512;                    // the spare lane's one-cell "table": symbol 0, x = 512 -> with a 9-bit log no state bits, no extra bits
