@@ -271,3 +271,43 @@ def test_dictionary_frames_through_the_pipeline(zstd, corpus):
     for d in (zstd.ZstdDecompressor(dict_data=zstd.ZstdCompressionDict(other)), zstd.ZstdDecompressor()):
         with pytest.raises(zstd.ZstdError, match="Dictionary mismatch"):
             d.multi_decompress_to_buffer([frame], decompressed_sizes=np.array([4096], dtype=np.uint64).tobytes())
+
+
+def test_understated_size_hint_runs_out_of_room_gracefully(zstd, corpus):
+    """Round 5: the decode pipeline's compact arena is sized from the caller's size HINT (zhip_ctx_set_size_hint: 4 x the hint + 1 KiB of literal + sequence
+    room per frame, three chunk slots for small frames). The hint is advisory: 2 048 frames of 128 KiB behind a hint of 4 KiB overrun that budget many
+    times over -- the frames that find no room must come back from the generic kernel, every byte right, none of the others disturbed."""
+    import importlib
+    import torch
+    dev_mod = importlib.import_module("zstandard_amd.device")
+    enc = _enc()
+    dev = torch.device("cuda", 0)
+    F, item = 2048, 131072
+    raws = [corpus.frame_bytes(i % 600) for i in range(F)]
+    frames = [enc.compress(r) for r in raws[:600]]
+    frames = [frames[i % 600] for i in range(F)]
+    sizes = np.array([len(f) for f in frames], dtype=np.int64)
+    offs = np.zeros(F, dtype=np.int64); offs[1:] = np.cumsum(sizes)[:-1]
+    def segs(o, n):
+        a = np.zeros((F, 2), dtype=np.int64); a[:, 0] = o; a[:, 1] = n
+        return torch.from_numpy(a).to(dev)
+    src = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).to(dev)
+    dst = torch.zeros(F * item, dtype=torch.uint8, device=dev)
+    out_sizes = torch.zeros(F, dtype=torch.int64, device=dev); status = torch.zeros(F, dtype=torch.int32, device=dev)
+    want = torch.from_numpy(np.frombuffer(b"".join(raws[:600]), dtype=np.uint8).copy()).view(600, item).to(dev)
+    for hint in (4096, 0):                                      # understated, then none (the default budget: everybody has room)
+        ctx = dev_mod.DeviceBatchContext()
+        try:
+            ctx.set_size_hint(hint)
+            dst.zero_()
+            ctx.decompress(src, segs(offs, sizes), dst, segs(np.arange(F, dtype=np.int64) * item, np.full(F, item, dtype=np.int64)), out_sizes, status)
+            torch.cuda.synchronize()
+            assert int(status.abs().max().item()) == 0 and bool((out_sizes == item).all().item()), hint
+            got = dst.view(F, item)
+            for a in range(0, F, 600):
+                b = min(F, a + 600)
+                assert torch.equal(got[a:b], want[: b - a]), (hint, a)
+            if hint:
+                assert ctx.kernel_time(0) is not None           # (the generic kernel's timer exists; its share is what the hint cost)
+        finally:
+            ctx.close()
