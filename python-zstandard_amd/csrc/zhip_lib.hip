@@ -325,12 +325,28 @@ struct zhip_ctx {
     void* hpStage[2] = {nullptr, nullptr}; size_t hpStageCap[2] = {0, 0}; hipEvent_t hpStageFree[2] = {nullptr, nullptr}; int hpNextSlot = 0;
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
-        bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false, noFlat = false;
-        size_t dchunk = ZHIP_DCHUNK, echunk = 0, echunkMax = 0 /* frames per launch of the flat match kernel: 0 = 65 536, and 131 072 for larger batches where memory allows (A/B: ZHIP_ECHUNK_MAX) */; int nslot = 2; bool nslotSet = false; int k1PerCU = 0, k3PerCU = 0; unsigned packThreads = 0; bool blocks = true; size_t mbcMin = 8192; unsigned mbcLanes = 32 /* sources per wave of that search: 64 / 32 / 16 / 8 within 10-30 % of each other, r03z */; size_t hchunkE = 32768, hchunkE0 = 0, hchunkD0 = 2048; long e1LdsMax = -1; size_t e1LdsRounds = 2;
-        // probes per trip of the double-fast search. Flat kernel: chunks of up to flat4Max sources take the four-probe form -- 1 024 ... 32 768 sources: 21-25 % less
-        // time (146 -> 110, 173 -> 133, 277 -> 219 ms), 65 536: the same (424 / 422: transaction-bound), r04zd. LDS-source kernel: two (four: one-shot 128 KiB 18 -> 21 ms,
-        // batches of 128-512 8-10 % faster: a single lane's trip is its instruction count, and four probes are 1.8 x the instructions for 1.64 x the probes)
-        bool e1fPick = true; size_t flat4Max = 32768; size_t flat3Max = 65536; bool flat3 = true;       // launches of 32 769 ... 65 536 sources: three probes per trip (r04zg, four rounds in one process: 418 / 415 / 421 / 426 ms with two, 417 / 414 / 408 / 406 with three, 422 / 500 / 496 / 496 with four)
+        // bring-up aids
+        bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false;
+        bool noFlat = false;                // ZHIP_NO_FLAT: every batch through the lane-serial match kernel (A/B)
+        bool blocks = true;                 // ZHIP_BLOCKS=0: frames / sources of several blocks go to the generic kernels as in rounds 1-2 (A/B)
+        // decode pipeline
+        size_t dchunk = ZHIP_DCHUNK;        // frames (several-block mode: block slots) per chunk
+        int nslot = 2; bool nslotSet = false;   // chunk slots on their own streams (small frames get a third unless ZHIP_NSLOT says otherwise)
+        int k1PerCU = 0, k3PerCU = 0;       // waves per CU of K1 / K3 (0: what the occupancy query says)
+        // encode
+        size_t echunk = 0;                  // ZHIP_ECHUNK: sources per chunk, upper bound (0: none)
+        size_t echunkMax = 0;               // ZHIP_ECHUNK_MAX: frames per launch of the flat match kernel (0 = 65 536, and 131 072 for larger batches where memory allows)
+        long e1LdsMax = -1; size_t e1LdsRounds = 2;     // the LDS-source match kernel of small batches: most sources it takes (-1: by the CU count), rounds per CU
+        size_t mbcMin = 8192;               // sources per 256 KiB of size hint from which sources of several blocks take the flat search
+        unsigned mbcLanes = 32;             // sources per wave of that search (64 / 32 / 16 / 8 within 10-30 % of each other, r03z)
+        // probes per trip of the flat double-fast search by launch size: up to flat4Max sources four (bound by one source's serial chain: 21-25 % less time from
+        // 1 024 to 32 768 sources, r04zd), up to flat3Max three, above two (with the placement picked, at 65 536: 421 / 415 / 425 ms for two / three / four, r05w)
+        size_t flat4Max = 32768, flat3Max = 65536; bool flat3 = true;
+        bool e1fPick = true;                // ZHIP_E1F_PICK=0: take the flat tables where the first allocation put them (zhip_compress_batch_device)
+        // host-buffer pipeline
+        size_t hchunkE = 32768, hchunkE0 = 0;   // compress: items per chunk, items of the first chunk (0: like the others)
+        size_t hchunkD0 = 2048;             // decompress: items of the first chunk of batches above 8 192 (0: like the others)
+        unsigned packThreads = 0;           // host threads packing items into the pinned staging slots (0: ZHIP_PACK_THREADS)
     } knob;
     size_t flatMaxCached = 0;                    // frames per launch of the flat match kernel for batches above 65 536 (0: not decided yet)
     bool e1fPicked = false; float e1fPickMs[3] = {0, 0, 0}; int e1fPickKept = 0; void* e1fPickedPtr = nullptr;      // the flat match kernel's tables: placement picked once per context (zhip_compress_batch_device)
