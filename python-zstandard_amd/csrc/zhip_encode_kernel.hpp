@@ -52,7 +52,11 @@ struct ZePrevHuf { const uint8_t* bits; const uint16_t* code; uint32_t maxSym, r
 
 struct ZePar { int wlog, clog, hlog, mml, strat, tlen; };
 // optional per-phase cycle totals of the entropy kernel (ZHIP_PROF tuning aid; lives in registers, null when off)
+#ifdef ZE_PROF_STREAM       // diagnostic build: the sequence stream's rounds split into their four parts (eight bytes of accumulator each: not in the product's registers)
+enum { ZEP_GATHER = 0, ZEP_LITSTAT, ZEP_HUFBUILD, ZEP_HUFENC, ZEP_SEQSTAT, ZEP_SEQTAB, ZEP_SEQENC, ZEP_REST, ZEP_SQ_PRE, ZEP_SQ_CHAIN, ZEP_SQ_PACK, ZEP_SQ_FLUSH, ZEP_N };
+#else
 enum { ZEP_GATHER = 0, ZEP_LITSTAT, ZEP_HUFBUILD, ZEP_HUFENC, ZEP_SEQSTAT, ZEP_SEQTAB, ZEP_SEQENC, ZEP_REST, ZEP_N };
+#endif
 struct ZeProf { uint64_t t0; uint64_t acc[ZEP_N]; };
 #define ZE_T(P, i) do { if (P) { const uint64_t t1_ = zd_clock(); (P)->acc[i] += t1_ - (P)->t0; (P)->t0 = t1_; } } while (0)
 // scratch inside the tree-node area, valid while no tree is being built and disjoint from what ze_scratch users touch at the same time:
@@ -2081,8 +2085,14 @@ ZH_DEV uint32_t ze_ml_bits(uint32_t c) { return c < 32 ? 0u : c < 43 ? (uint32_t
 // to the stream (up to 89 bits) is assembled by its own lane, placed by a wave prefix sum of the bit counts and ORed into an LDS
 // bit buffer that is flushed to the frame in whole bytes (the odd bits carry into the next round). All lanes call.
 // Returns the stream's size, 0 when it does not fit in cap.
-ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq)
+ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, const uint64_t* seqs, uint32_t nbSeq, ZeProf* P = nullptr)
 {
+#ifdef ZE_PROF_STREAM
+    uint64_t sq0 = P ? zd_clock() : 0;
+#define ZE_SQT(i) do { if (P) { const uint64_t t_ = zd_clock(); P->acc[i] += t_ - sq0; sq0 = t_; } } while (0)
+#else
+#define ZE_SQT(i) do { } while (0)
+#endif
     const uint32_t lane = zh_lane();
     uint32_t* const tt = ze_scratch(L);          // per symbol: deltaNbBits, deltaFindState (FSE_symbolCompressionTransform); LL at 0, OF at 36, ML at 68
     uint32_t* const pre = tt + 2 * 121;          // [table][slot] -> the slot's sequence's two constants (3 x 64 x 2)
@@ -2121,6 +2131,7 @@ ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, 
             pre[128 + 2 * lane] = eO[0]; pre[128 + 2 * lane + 1] = eO[1];
             pre[256 + 2 * lane] = eM[0]; pre[256 + 2 * lane + 1] = eM[1]; }
         zh_sync();
+        ZE_SQT(ZEP_SQ_PRE);
         if (zh_opaque(lane) < 3) {
             const uint32_t t = lane;
             const ZeCTab& T = L.tab[t];
@@ -2152,6 +2163,7 @@ ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, 
             }
         }
         zh_sync();
+        ZE_SQT(ZEP_SQ_CHAIN);
         uint64_t lo = 0, up = 0; uint32_t pos = 0;
 #define ZE_ADD(val, nbits) do { const uint32_t n_ = (nbits); const uint64_t v_ = (val); if (n_) { if (pos < 64) { lo |= v_ << pos; if (pos + n_ > 64) up |= v_ >> (64 - pos); } \
                                 else up |= v_ << (pos - 64); pos += n_; } } while (0)
@@ -2174,6 +2186,7 @@ ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, 
             if ((uint32_t)(B >> 32)) zh_lds_atomic_or(w + 3, (uint32_t)(B >> 32));
         }
         zh_sync();
+        ZE_SQT(ZEP_SQ_PACK);
         const uint32_t totalBits = carryBits + tot, nbytes = totalBits >> 3;
         if (bytePos + nbytes > cap) ovf = true;
         if (!ovf) {
@@ -2187,9 +2200,11 @@ ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, 
         for (uint32_t k = lane; k < 196; k += 64) bitbuf[k] = k == 0 ? cb : 0u;
         zh_sync();
         carryBits = rem; bytePos += nbytes;
+        ZE_SQT(ZEP_SQ_FLUSH);
         if (hi < 64) break;
         hi -= 64;
     }
+#undef ZE_SQT
     if (zh_opaque(lane) < 3) L.misc[12 + lane] = v;
     zh_sync();
     if (zh_opaque(lane) == 0) {
@@ -2395,7 +2410,11 @@ ZH_DEVFN uint32_t ze_compress_block(ZeLDS& L, uint8_t* out, uint32_t cap, const 
     ZE_T(P, ZEP_SEQTAB);
     uint32_t r = 1, cSize = seqStart;
     if (nbSeq) {
+#ifdef ZE_PROF_STREAM
+        const uint32_t bs = ze_encode_sequences_wave(L, out + seqStart, cap - seqStart, seqs, nbSeq, P);
+#else
         const uint32_t bs = ze_encode_sequences_wave(L, out + seqStart, cap - seqStart, seqs, nbSeq);
+#endif
         ZE_T(P, ZEP_SEQENC);
         if (bs == 0) r = 0;
         if (lastCount && lastCount + bs < 4) r = 0;

@@ -1158,8 +1158,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             HIP_TRY(hipStreamSynchronize(stream));
             unsigned long long h[16];
             HIP_TRY(hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
-            static const char* nm[ZEP_N] = {"gather literals", "literal stats+decide", "huffman build+table", "huffman encode", "sequence stats", "sequence tables", "sequence stream", "frame assembly"};
-            unsigned long long tot = 0; for (int q = 0; q < ZEP_N; q++) tot += h[q];
+            static const char* nm[12] = {"gather literals", "literal stats+decide", "huffman build+table", "huffman encode", "sequence stats", "sequence tables", "sequence stream", "frame assembly",
+                                          "  stream: constants", "  stream: state chains", "  stream: pack + OR", "  stream: flush"};      // (the last four: -DZE_PROF_STREAM builds only)
+            unsigned long long tot = 0; for (int q = 0; q <= ZEP_REST; q++) tot += h[q];
             fprintf(stderr, "[zhip-prof] E2: %.0f wave-cycles per frame\n", (double)tot / (double)n);
             for (int q = 0; q < ZEP_N; q++) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[q] / (tot ? tot : 1), (double)h[q] / (double)n);
             a.prof = nullptr;
