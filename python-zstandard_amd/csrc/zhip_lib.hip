@@ -1363,7 +1363,7 @@ static int ensure_stage(zhip_ctx* c, int slot, size_t n)
     if (c->hpStage[slot]) (void)hipHostFree(c->hpStage[slot]);
     c->hpStage[slot] = nullptr; c->hpStageCap[slot] = 0;
     const size_t want = n + (n >> 3) + 4096;
-    HIP_TRY(hipHostMalloc(&c->hpStage[slot], want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&c->hpStage[slot], want, hipHostMallocDefault));      // (write-combined / non-coherent staging: no difference, profiles/r05zb_*)
     c->hpStageCap[slot] = want;
     return 0;
 }
