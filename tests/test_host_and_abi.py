@@ -176,3 +176,34 @@ def test_integration_stub_compiles_against_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-c",
                            os.path.join(root, "tests", "abi_stub_check.c"), "-o", str(tmp_path / "abi_stub_check.o")])
+
+
+def test_bench_line_shape_for_the_driver():
+    """bench.py's roofline object keeps every key round-to-round comparisons read (a mid-line comment once swallowed
+    `kernel_ms_per_step` / `algorithmic_bytes_per_step`), and the printed line ends with the flat `summary` -- the driver keeps the TAIL of
+    stdout, so the compress / combined / host-API figures must be the last two KB of the line."""
+    import json
+    import bench
+
+    class FakeCtx:
+        def kernel_name(self, k):
+            return ["zhip_decode_lit_kernel", "zhip_decode_exec_kernel"][k]
+
+    rl, kdom = bench.roofline(FakeCtx(), {0: (2.0, 4), 1: (10.0, 4)}, 4, 11_000_000_000, 12.5, 65536)
+    assert kdom == 1
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_step", "algorithmic_bytes_per_step", "dominant_kernel", "end_to_end"):
+        assert k in rl, k
+    assert rl["kernel_ms_per_step"] == 12.0 and rl["algorithmic_bytes_per_step"] == 11_000_000_000
+    line = {"metric": "m", "value": 350.0, "unit": "GB/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 24.4, "config": {"workload": "w"},
+            "roofline": rl, "cpu_baseline": {"value": 25.0}, "kernels": {"x": {"pad": "y" * 4000}},
+            "compress": {"value": 19.5, "ms_per_step": 440.0, "roofline": {"frac": 0.0033}, "regime": {"class": "fast", "match_kernel_ms_per_65536_frames": 405.7},
+                         "kernels": {"pad": "z" * 4000}},
+            "combined": {"value": 18.5}, "host_api": {"devices": 1, "frames_8192": {"compress": 6.4, "decompress": 28.6}, "frames_65536": {"compress": 14.0, "decompress": 44.8}},
+            "dict": {"value": 26.0, "decompress": {"value": 130.0}}, "roundtrip": {"value": 19.7, "compress": {"value": 20.8}, "decompress": {"value": 358.0}},
+            "blocks": {"value": 152.0, "compress": {"value": 2.1}}, "verified": True}
+    out = bench.ordered_for_the_driver(line)
+    assert set(out) == set(line) | {"summary"} and all(out[k] == line[k] for k in line)
+    assert list(out)[-2:] == ["summary", "verified"]
+    tail = json.dumps(out)[-2000:]
+    for k in ("compress_gbs", "combined_gbs", "host_api_65536_c", "host_api_8192_c", "dict_d_gbs", "roundtrip_c_gbs", "decompress_gbs", "compress_match_kernel_ms"):
+        assert '"%s"' % k in tail, k
