@@ -601,6 +601,12 @@ def bench_host_api(raw_np, frames, csizes, counts=(8192, 65536)):
             del r
         rec["compress"] = round(F * FRAME / best / 1e9, 2)
         out["frames_%d" % F] = rec
+    # the device slots the two calls fan a batch out over inside the call (zhip_compress_batch / zhip_decompress_batch: every visible device, or ZHIP_DEVICES)
+    import ctypes
+    devs = (ctypes.c_int * 64)()
+    nd = pyz._lib.lib().zhip_batch_devices(devs, 64)
+    out["devices"] = nd
+    out["device_slots"] = list(devs[:nd])
     return out
 
 

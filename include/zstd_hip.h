@@ -122,6 +122,15 @@ int  zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, siz
                          zhip_outbuf** out, size_t* nOut, zhip_error* err);
 int  zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
                            zhip_outbuf** out, size_t* nOut, zhip_error* err);
+/* One call, every device (round 6). Both calls fan the batch out over the node's GPUs INSIDE the call, the way the reference fans it out over its worker
+ * threads (c-ext/compressor.c:1127-1298, c-ext/decompressor.c:1237-1455): the item list is cut into contiguous runs of (almost) equal input bytes --
+ * zhip_partition_by_bytes, the reference's rule -- every run goes to a host thread bound to its device (one persistent thread, context and staging area per
+ * device slot), and the devices' zhip_outbufs come back in device order, which is item order; the first failing item (lowest index) is the one reported.
+ * No collective is involved: the collection simply holds the buffers of every device. The environment selects the device slots: ZHIP_DEVICES=0,1,... (a
+ * device may be listed twice: two contexts on one GPU); unset = every visible device, but at least ZHIP_DEVICE_MIN_BYTES (default 256 MiB) of input per
+ * device, so small batches run on the calling thread's current device as they always did. Nothing changes for a caller. */
+size_t zhip_partition_by_bytes(const uint64_t* sizes, size_t n, size_t workers, size_t* bounds /* 2 * workers: [start, end) per worker */);
+int    zhip_batch_devices(int* devices, int cap);   /* the device slots the two calls above fan out over; returns their number */
 void zhip_free_outbufs(zhip_outbuf* bufs, size_t n, int freePayload);
 void zhip_free_payload(void* data);     /* a zhip_outbuf.data pointer: back to the pinned pool, or free() */
 

@@ -120,7 +120,7 @@ EXPORTED_SYMBOLS = [
     "zhip_decompress_batch", "zhip_free_outbufs", "zhip_free_payload", "zhip_ctx_create", "zhip_ctx_destroy", "zhip_ctx_set_ddict",
     "zhip_ctx_set_cparams", "zhip_decompress_batch_device", "zhip_compress_batch_device", "zhip_ctx_sync",
     "zhip_kernel_name", "zhip_ctx_kernel_time", "zhip_thread_memory_size", "zhip_compact_device", "zhip_ctx_set_size_hint",
-    "zhip_ctx_table_pick",
+    "zhip_ctx_table_pick", "zhip_partition_by_bytes", "zhip_batch_devices",
 ]
 
 

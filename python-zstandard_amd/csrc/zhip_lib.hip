@@ -103,10 +103,15 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a) 
     __shared__ ZeLDS L;
     ze_split_body(a, L);
 }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
+// the flat search: every lane's own source bytes come from its LDS window (ze_dfast_flat_w, round 6; 19 KiB per wave, eight waves per CU)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<2>(a, W.b); }
 // four probes per trip: chunks small enough to be bound by a source's serial chain rather than by the memory system (ze_dfast_flat_np)
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_kernel(ZhipEncodeArgs a) { ze_match_flat_body<3>(a); }      // three probes: launches of up to 65 536 sources
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<4>(a, W.b); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<3>(a, W.b); }      // three probes: launches of up to 65 536 sources
+// (A/B: rounds 1-5's form, which re-reads the lane's own bytes from memory every trip -- ZHIP_E1F_WIN=0)
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<3>(a); }
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 template <uint32_t BYTES, int NPROBE> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
@@ -342,6 +347,7 @@ struct zhip_ctx {
         // probes per trip of the flat double-fast search by launch size: up to flat4Max sources four (bound by one source's serial chain: 21-25 % less time from
         // 1 024 to 32 768 sources, r04zd), up to flat3Max three, above two (with the placement picked, at 65 536: 421 / 415 / 425 ms for two / three / four, r05w)
         size_t flat4Max = 32768, flat3Max = 65536; bool flat3 = true;
+        bool e1fWin = false;                // ZHIP_E1F_WIN=0: the flat search of rounds 1-5 (own bytes re-read from memory every trip) -- A/B of round 6's LDS window
         bool e1fPick = true;                // ZHIP_E1F_PICK=0: take the flat tables where the first allocation put them (zhip_compress_batch_device)
         // host-buffer pipeline
         size_t hchunkE = 32768, hchunkE0 = 0;   // compress: items per chunk, items of the first chunk (0: like the others)
@@ -392,6 +398,7 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
+        if (const char* e = getenv("ZHIP_E1F_WIN")) k.e1fWin = atol(e) != 0;
         if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
         if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -885,6 +892,20 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->timer[0].pending.size() > 1024) { HIP_TRY(hipStreamSynchronize(stream)); for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]); for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]); }
     return 0;
 }
+// the flat match kernel at `probes` per trip over `cnt` sources
+static void launch_flat(zhip_ctx* c, int probes, size_t cnt, hipStream_t stream, const ZhipEncodeArgs& a)
+{
+    const dim3 g((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), b(64);
+    if (c->knob.e1fWin) {
+        if (probes == 4) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, g, b, 0, stream, a);
+        else if (probes == 3) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, g, b, 0, stream, a);
+        else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, g, b, 0, stream, a);
+    } else {
+        if (probes == 4) hipLaunchKernelGGL(zhip_encode_match_flat4_nw_kernel, g, b, 0, stream, a);
+        else if (probes == 3) hipLaunchKernelGGL(zhip_encode_match_flat3_nw_kernel, g, b, 0, stream, a);
+        else hipLaunchKernelGGL(zhip_encode_match_flat_nw_kernel, g, b, 0, stream, a);
+    }
+}
 extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
                                           void* d_dst, const zhip_segment* d_dstSegs, uint64_t* d_outSizes,
                                           int32_t* d_status, void* streamv)
@@ -1071,8 +1092,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
                     if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: the kernel's waves zero what they use)
                     HIP_TRY(hipEventRecord(e0, stream));
-                    if (!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
-                    else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt0 + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, pa);
+                    launch_flat(c, !flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
                     HIP_TRY(hipEventSynchronize(e1));
                     HIP_TRY(hipEventElapsedTime(ms, e0, e1));
@@ -1098,8 +1118,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
-            if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
-            HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
+            if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 32 * 8));
+            HIP_TRY(hipMemsetAsync(c->profEncode, 0, 32 * 8, stream));
             a.prof = c->profEncode;
         }
         for (size_t first = 0; first < n; first += chunk) {
@@ -1128,9 +1148,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
                     else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
                 }
-                else if (!flatDict && !mbc && cnt <= c->knob.flat4Max) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
-                else if (!flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
-                else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, dim3((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), dim3(64), 0, stream, a);
+                else launch_flat(c, !flatDict && !mbc && cnt <= c->knob.flat4Max ? 4 : !flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max ? 3 : 2, cnt, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
@@ -1156,8 +1174,13 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         if (a.prof) {
             HIP_TRY(hipStreamSynchronize(stream));
-            unsigned long long h[16];
+            unsigned long long h[32];
             HIP_TRY(hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
+            if (h[16 + 7]) {       // -DZE_PROF_FLAT builds: the flat search's phases (lane 0 of every wave), cycles per trip
+                static const char* fn[7] = {"own bytes + hashing", "round 1 wait", "window / forwarding / round 2 issue", "round 2 wait", "decisions (+ count: old form)", "round 3 wait (old: catch-up)", "match epilogue + loop"};
+                fprintf(stderr, "[zhip-prof] flat search: %llu trips of lane 0 over all waves\n", h[16 + 7]);
+                for (int q = 0; q < 7; q++) fprintf(stderr, "[zhip-prof]    %-38s %8.0f cyc/trip\n", fn[q], (double)h[16 + q] / (double)h[16 + 7]);
+            }
             static const char* nm[12] = {"gather literals", "literal stats+decide", "huffman build+table", "huffman encode", "sequence stats", "sequence tables", "sequence stream", "frame assembly",
                                           "  stream: constants", "  stream: state chains", "  stream: pack + OR", "  stream: flush"};      // (the last four: -DZE_PROF_STREAM builds only)
             unsigned long long tot = 0; for (int q = 0; q <= ZEP_REST; q++) tot += h[q];
@@ -1230,6 +1253,9 @@ extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status
 //   (zhip_free_payload; the CPython extension's BufferWithSegments does that in its deallocator);
 // * compress: the compressBound-sized slots are compacted ON THE DEVICE (scan of the frame sizes + one wave per frame) so that only
 //   the frames cross the link, into a payload allocated once the chunk's total is known (the host learns it one chunk behind).
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -1265,7 +1291,7 @@ struct PinPool {
         }
         void* p = nullptr;
         const size_t cap = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return malloc(n); }     // pageable still works, slower
+        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return malloc(n); }     // pageable still works, slower
         std::lock_guard<std::mutex> g(mu);
         blocks[p] = PinBlock{cap, true};
         return p;
@@ -1472,8 +1498,9 @@ static int upload_items(zhip_ctx* c, const zhip_item* items, const zhip_segment*
 }
 static void empty_outbuf(zhip_outbuf* ob) { ob->data = malloc(1); ob->segs = (zhip_segment*)malloc(sizeof(zhip_segment)); ob->dataSize = 0; ob->nSegs = 0; }
 
-extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
-                                     zhip_outbuf** out, size_t* nOut, zhip_error* err)
+// ONE device (the calling thread's current one): the chunked three-stream pipeline
+static int decompress_batch_one(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
+                                zhip_outbuf** out, size_t* nOut, zhip_error* err)
 {
     const bool allowShort = (requireSizes & 2) != 0;   // dstSize is a capacity (one-shot decompress with max_output_size)
     if (err) memset(err, 0, sizeof *err);
@@ -1572,7 +1599,7 @@ extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item
     return ZHIP_ERR_NONE;
 }
 
-extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, size_t n, zhip_outbuf** out, size_t* nOut, zhip_error* err)
+static int compress_batch_one(const zhip_cparams* params, const zhip_item* items, size_t n, zhip_outbuf** out, size_t* nOut, zhip_error* err)
 {
     if (err) memset(err, 0, sizeof *err);
     *out = nullptr; *nOut = 0;
@@ -1681,4 +1708,176 @@ extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* 
     *out = ob; *nOut = nChunks ? nChunks : 1;
     tls_trim(c);
     return ZHIP_ERR_NONE;
+}
+
+
+// ------------------------------------------------------------------------------------------ one call, every device (round 6)
+// The reference fans a batch out INSIDE multi_compress_to_buffer / multi_decompress_to_buffer: bytesPerWorker = total / workers, a contiguous run of
+// items per worker, one destination buffer set per worker, the collection in worker order, the first failing item reported (c-ext/compressor.c:1127-1298,
+// c-ext/decompressor.c:1237-1455). Here a worker is a DEVICE: zhip_compress_batch / zhip_decompress_batch cut the item list by the same rule, hand every
+// run to a host thread bound to its device (one persistent thread + one context + its own staging per device slot; the pinned payload pool is the process's),
+// and return the devices' zhip_outbufs in device order -- which is item order. No collective: the collection holds one BufferWithSegments per chunk of each
+// device. ZHIP_DEVICES=0,1,... selects the device slots (a device may be listed twice: two contexts on one GPU -- how the split is tested on a
+// one-GPU box); unset = every visible device, but never more devices than ZHIP_DEVICE_MIN_BYTES (default 256 MiB) of input each -- small batches stay on the
+// calling thread's current device, exactly as before.
+extern "C" size_t zhip_partition_by_bytes(const uint64_t* sizes, size_t n, size_t workers, size_t* bounds)
+{
+    // compressor.c:1127-1216: never more workers than items (:1151); walk the items, close a worker's run once its bytes reach total / workers; the
+    // last worker takes the rest. bounds[2w], bounds[2w+1] = [start, end) of worker w; returns the workers that got a run.
+    if (workers < 1) workers = 1;
+    if (n && workers > n) workers = n;
+    if (!n) return 0;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) total += sizes[i];
+    const uint64_t per = total / workers;
+    size_t w = 0, start = 0; uint64_t acc = 0;
+    for (size_t i = 0; i < n; i++) {
+        acc += sizes[i];
+        if (w == workers - 1) continue;
+        if (acc >= per) { bounds[2 * w] = start; bounds[2 * w + 1] = i + 1; w++; start = i + 1; acc = 0; }
+    }
+    if (start < n) { bounds[2 * w] = start; bounds[2 * w + 1] = n; w++; }
+    return w;
+}
+
+namespace {
+struct DevJob { std::function<void()> fn; };
+struct DevWorker {
+    int device = 0;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::thread th;
+    void loop()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<void()> fn;
+            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !q.empty(); }); fn = std::move(q.front()); q.pop_front(); }
+            fn();
+        }
+    }
+    void post(std::function<void()> fn) { { std::lock_guard<std::mutex> l(mu); q.push_back(std::move(fn)); } cv.notify_one(); }
+};
+struct DevPool {
+    std::mutex mu;
+    bool parsed = false, explicitList = false;
+    std::vector<int> slots;                      // device ordinal of every slot
+    std::vector<DevWorker*> workers;             // created on first use, never destroyed (their contexts live as long as the process)
+    uint64_t minBytes = (uint64_t)256 << 20;
+    void parse()
+    {
+        if (parsed) return;
+        parsed = true;
+        if (const char* e = getenv("ZHIP_DEVICE_MIN_BYTES")) minBytes = strtoull(e, nullptr, 10);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+        if (const char* e = getenv("ZHIP_DEVICES")) {
+            explicitList = true;
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                if (v >= 0 && v < count) slots.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+        } else for (int d = 0; d < count; d++) slots.push_back(d);
+        workers.assign(slots.size(), nullptr);
+    }
+    DevWorker* worker(size_t slot)
+    {
+        std::lock_guard<std::mutex> l(mu);
+        if (!workers[slot]) { DevWorker* w = new DevWorker(); w->device = slots[slot]; w->th = std::thread([w] { w->loop(); }); w->th.detach(); workers[slot] = w; }
+        return workers[slot];
+    }
+    // device slots a batch of `n` items / `bytes` input bytes is cut over (0: the calling thread's current device, inline)
+    size_t slotsFor(size_t n, uint64_t bytes)
+    {
+        { std::lock_guard<std::mutex> l(mu); parse(); }
+        size_t d = slots.size();
+        if (!explicitList) {
+            if (d <= 1) return 0;
+            const uint64_t byBytes = minBytes ? bytes / minBytes : d;
+            if (byBytes < d) d = (size_t)byBytes;
+            if (d <= 1) return 0;
+        }
+        if (d > n) d = n;
+        return d;
+    }
+};
+DevPool& dev_pool() { static DevPool* p = new DevPool(); return *p; }
+
+struct DevResult { int rc = 0; zhip_error err; zhip_outbuf* out = nullptr; size_t nOut = 0; std::string text; bool done = false; };
+
+// runs fn(slot, lo, hi, &result) for every run of the partition on its device's thread; gathers the devices' buffers in order
+template <typename F>
+int fan_out(size_t d, const std::vector<uint64_t>& sizes, size_t n, F&& one, zhip_outbuf** out, size_t* nOut, zhip_error* err)
+{
+    std::vector<size_t> bounds(2 * d);
+    const size_t used = zhip_partition_by_bytes(sizes.data(), n, d, bounds.data());
+    std::vector<DevResult> res(used);
+    std::mutex mu; std::condition_variable cv; size_t pending = used;
+    for (size_t w = 0; w < used; w++) {
+        const size_t lo = bounds[2 * w], hi = bounds[2 * w + 1];
+        dev_pool().worker(w)->post([&, w, lo, hi] {
+            DevResult& r = res[w];
+            memset(&r.err, 0, sizeof r.err);
+            r.rc = one(lo, hi, &r.out, &r.nOut, &r.err);
+            if (r.rc) r.text = g_lastError;
+            { std::lock_guard<std::mutex> l(mu); r.done = true; pending--; }
+            cv.notify_one();
+        });
+    }
+    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return pending == 0; }); }
+    // the first failing item (the lowest index: runs are in item order), as the reference reports it (compressor.c:1225-1253)
+    for (size_t w = 0; w < used; w++) if (res[w].rc) {
+        for (size_t v = 0; v < used; v++) if (!res[v].rc) zhip_free_outbufs(res[v].out, res[v].nOut, 1);
+        if (err) { *err = res[w].err; err->index += bounds[2 * w]; }
+        g_lastError = res[w].text;
+        return res[w].rc;
+    }
+    size_t total = 0;
+    for (size_t w = 0; w < used; w++) total += res[w].nOut;
+    zhip_outbuf* all = (zhip_outbuf*)calloc(total ? total : 1, sizeof(zhip_outbuf));
+    if (!all) { for (size_t w = 0; w < used; w++) zhip_free_outbufs(res[w].out, res[w].nOut, 1); if (err) { memset(err, 0, sizeof *err); err->kind = ZHIP_ERR_NO_MEMORY; } return ZHIP_ERR_NO_MEMORY; }
+    size_t k = 0;
+    for (size_t w = 0; w < used; w++) { for (size_t j = 0; j < res[w].nOut; j++) all[k++] = res[w].out[j]; free(res[w].out); }
+    *out = all; *nOut = total;
+    return ZHIP_ERR_NONE;
+}
+}
+
+extern "C" int zhip_batch_devices(int* devices, int cap)
+{
+    DevPool& p = dev_pool();
+    { std::lock_guard<std::mutex> l(p.mu); p.parse(); }
+    for (int i = 0; i < cap && i < (int)p.slots.size(); i++) devices[i] = p.slots[i];
+    return (int)p.slots.size();
+}
+
+extern "C" int zhip_compress_batch(const zhip_cparams* params, const zhip_item* items, size_t n, zhip_outbuf** out, size_t* nOut, zhip_error* err)
+{
+    uint64_t bytes = 0;
+    for (size_t i = 0; i < n; i++) bytes += items[i].srcSize;
+    const size_t d = dev_pool().slotsFor(n, bytes);
+    if (d == 0) return compress_batch_one(params, items, n, out, nOut, err);
+    if (err) memset(err, 0, sizeof *err);
+    *out = nullptr; *nOut = 0;
+    std::vector<uint64_t> sizes(n);
+    for (size_t i = 0; i < n; i++) sizes[i] = items[i].srcSize;
+    return fan_out(d, sizes, n, [&](size_t lo, size_t hi, zhip_outbuf** o, size_t* no, zhip_error* e) { return compress_batch_one(params, items + lo, hi - lo, o, no, e); }, out, nOut, err);
+}
+
+extern "C" int zhip_decompress_batch(const zhip_dparams* params, const zhip_item* items, size_t n, int requireSizes,
+                                     zhip_outbuf** out, size_t* nOut, zhip_error* err)
+{
+    // the reference's decompress dispatcher balances by COMPRESSED bytes (decompressor.c:1237-1320: framePointers' sourceSize)
+    uint64_t bytes = 0, outBytes = 0;
+    for (size_t i = 0; i < n; i++) { bytes += items[i].srcSize; outBytes += items[i].dstSize; }
+    const size_t d = dev_pool().slotsFor(n, outBytes > bytes ? outBytes : bytes);
+    if (d == 0) return decompress_batch_one(params, items, n, requireSizes, out, nOut, err);
+    if (err) memset(err, 0, sizeof *err);
+    *out = nullptr; *nOut = 0;
+    std::vector<uint64_t> sizes(n);
+    for (size_t i = 0; i < n; i++) sizes[i] = items[i].srcSize;
+    return fan_out(d, sizes, n, [&](size_t lo, size_t hi, zhip_outbuf** o, size_t* no, zhip_error* e) { return decompress_batch_one(params, items + lo, hi - lo, requireSizes, o, no, e); }, out, nOut, err);
 }

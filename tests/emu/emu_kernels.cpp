@@ -227,7 +227,57 @@ static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_probes = 2;                   // probes per trip of the flat search (2, or 4: the latency-bound batches' form)
 extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
-static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
+static uint32_t g_e1fWin = 1;                   // the flat search reads the lanes' own bytes from LDS windows (ze_dfast_flat_w, the product's default); 0: rounds 1-5's form
+extern "C" void emu_set_e1f_window(uint32_t v) { g_e1fWin = v; }
+static ZeWinLDS g_winlds;
+static void e1f_lane(void* p)
+{
+    uint8_t* win = g_e1fWin ? g_winlds.b : nullptr;
+    if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p, win); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p, win); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p, win);
+}
+// ---- the flat searches' round log (ZE_RND): per wave and trip, for every kind of dependent memory round, the most any lane needed
+#include <vector>
+static bool g_rndOn = false;
+static uint32_t g_rndTrip[64];
+static std::vector<std::vector<uint8_t>> g_rndLog;          // [block][(trip * 9 + kind) * 64 + lane]
+extern "C" void ze_emu_trip(uint32_t block, uint32_t lane, int reset) { (void)block; if (reset) g_rndTrip[lane & 63] = 0; else g_rndTrip[lane & 63]++; }
+extern "C" void ze_emu_rnd(uint32_t block, uint32_t lane, uint32_t kind)
+{
+    if (!g_rndOn || kind >= 9) return;
+    if (g_rndLog.size() <= block) g_rndLog.resize(block + 1);
+    std::vector<uint8_t>& v = g_rndLog[block];
+    const size_t at = ((size_t)g_rndTrip[lane & 63] * 9 + kind) * 64 + (lane & 63);
+    if (v.size() <= at) v.resize((at + 64 * 9 * 4096) & ~(size_t)63, 0);
+    if (v[at] < 255) v[at]++;
+}
+// trips of every lane of wave `block` (the last trip on which it logged a round, + 1)
+extern "C" void emu_rnd_lane_trips(uint32_t block, uint32_t* out64)
+{
+    for (int l = 0; l < 64; l++) out64[l] = 0;
+    if (block >= g_rndLog.size()) return;
+    const std::vector<uint8_t>& v = g_rndLog[block];
+    const size_t trips = v.size() / (9 * 64);
+    for (size_t t = 0; t < trips; t++) for (int k = 0; k < 9; k++) for (int l = 0; l < 64; l++) if (v[(t * 9 + k) * 64 + l]) out64[l] = (uint32_t)t + 1;
+}
+extern "C" void emu_rnd_log(int on) { g_rndOn = on != 0; g_rndLog.clear(); }
+// out[0..8]: per kind, the rounds the waves paid (sum over trips of the per-trip maximum over lanes); out[9]: trips (of the slowest lane); out[10..18]: per kind, the
+// LANE-trips that needed it (sum over lanes); out[19]: lane-trips
+extern "C" void emu_rnd_report(uint64_t* out)
+{
+    for (int i = 0; i < 20; i++) out[i] = 0;
+    for (const std::vector<uint8_t>& v : g_rndLog) {
+        const size_t trips = v.size() / (9 * 64);
+        for (size_t t = 0; t < trips; t++) {
+            bool any = false; uint64_t lanes = 0;
+            for (int k = 0; k < 9; k++) {
+                uint32_t mx = 0;
+                for (int l = 0; l < 64; l++) { const uint8_t c = v[(t * 9 + k) * 64 + l]; if (c > mx) mx = c; if (c) { out[10 + k]++; lanes |= 1ull << l; } }
+                out[k] += mx; any |= mx != 0;
+            }
+            if (any) { out[9]++; out[19] += (uint64_t)__builtin_popcountll(lanes); }
+        }
+    }
+}
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
@@ -295,7 +345,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
-            else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
+            else { memset(&g_winlds, 0xA5, sizeof g_winlds); zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a); }
             if (mbc) { a.mbLanes = 16; a.mbProbes = g_probes; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);

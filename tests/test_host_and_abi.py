@@ -207,3 +207,48 @@ def test_bench_line_shape_for_the_driver():
     tail = json.dumps(out)[-2000:]
     for k in ("compress_gbs", "combined_gbs", "host_api_65536_c", "host_api_8192_c", "dict_d_gbs", "roundtrip_c_gbs", "decompress_gbs", "compress_match_kernel_ms"):
         assert '"%s"' % k in tail, k
+
+
+def test_c_partition_rule_is_the_references(zstd):
+    """zhip_partition_by_bytes (what zhip_compress_batch / zhip_decompress_batch cut a batch over the node's devices with) against the reference's
+    dispatcher loop restated here line by line (c-ext/compressor.c:1127-1216: bytesPerWorker = total / threadCount, a worker's run closes once its
+    bytes reach it, the last worker takes what is left, never more workers than sources :1151) and against parallel.py's form of the same rule."""
+    import ctypes as C
+    import importlib
+    import random
+    par = importlib.import_module("python-zstandard_amd.parallel")
+    lib = zstd._lib.lib()
+    lib.zhip_partition_by_bytes.restype = C.c_size_t
+    lib.zhip_partition_by_bytes.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
+
+    def reference_rule(sizes, threads):
+        threads = max(1, min(threads, len(sizes)))
+        per = sum(sizes) // threads
+        runs, cur, start, acc = [], 0, 0, 0
+        for i, s in enumerate(sizes):
+            acc += s
+            if cur == threads - 1:
+                continue
+            if acc >= per:
+                runs.append((start, i + 1)); cur += 1; start = i + 1; acc = 0
+        if acc:
+            runs.append((start, len(sizes)))
+        return runs
+
+    def c_rule(sizes, workers):
+        arr = (C.c_uint64 * max(1, len(sizes)))(*sizes)
+        out = (C.c_size_t * (2 * max(1, workers)))()
+        used = lib.zhip_partition_by_bytes(arr, len(sizes), workers, out)
+        return [(out[2 * w], out[2 * w + 1]) for w in range(used)]
+
+    rng = random.Random(6)
+    cases = [([10] * 10, 2), ([10] * 10, 3), ([100, 1, 1, 1], 2), ([5], 4), ([10, 20, 30], 8), (list(range(1, 100)), 8), ([131072] * 65536, 8), ([], 4)]
+    for _ in range(300):
+        n = rng.randint(1, 60)
+        cases.append(([rng.choice([1, 7, 4096, 131072, rng.randint(1, 10 ** 6)]) for _ in range(n)], rng.randint(1, 9)))
+    for sizes, w in cases:
+        got = c_rule(sizes, w)
+        assert got == reference_rule(sizes, w), (sizes[:8], w)
+        assert got == [b for b in par.partition_by_bytes(sizes, w) if b[1] > b[0]], (sizes[:8], w)
+        if sizes:
+            assert got[0][0] == 0 and got[-1][1] == len(sizes) and all(a[1] == b[0] for a, b in zip(got, got[1:]))
