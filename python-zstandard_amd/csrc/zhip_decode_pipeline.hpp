@@ -201,6 +201,84 @@ ZH_DEV void zp_meta_clear(ZdMeta& m)
     m.blockMax = 0; m.fcsLo = m.fcsHi = 0xFFFFFFFFu; m.produced = 0; m.hasChecksum = 0; m.checksum = 0; m.logs = 0; m.pad = 0;
 }
 
+// A LANE's walk over one frame of a dictionary batch (round 6: configs[3]'s 262 144 x 4 KiB documents spent 1.76 ms per launch in K1 with a whole wave per document,
+// although nothing is built for them): a frame of ONE compressed block whose literals are raw, RLE or "treeless" on the dictionary's ready-made Huffman table and
+// whose sequence tables are all "repeat" (the dictionary's, ZhipDictTables.fseK2) is nothing but header arithmetic -- frame header, block header, literals section
+// header (RFC 8878 3.1.1.3.1.1), sequences header (3.1.1.3.2.1). Fills the record zp_lit_one would (same fields, same values) and says how much literal room the
+// frame wants; ANYTHING else -- a table of its own, another block layout, any check that fails -- returns false and the wave takes the frame as before, so every
+// error is found, and worded, by the code that always did. zstd.c:45767 (ZSTD_decodeLiteralsBlock), :46328 (ZSTD_decodeSeqHeaders).
+ZH_DEV bool zp_lit_shared_try(const ZhipPipeArgs& a, uint32_t f, ZdMeta& m, uint32_t& need16)
+{
+    zp_meta_clear(m); need16 = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    if (srcSize64 > 0x7FFFFFFFull) return false;
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    ZpHdr h;
+    if (zp_frame_header(a, src, srcSize, h) || h.skippable) return false;
+    const uint32_t blockMax = h.blockMax;
+    uint32_t pos = h.pos;
+    m.blockMax = blockMax; m.fcsLo = (uint32_t)h.fcs; m.fcsHi = (uint32_t)(h.fcs >> 32);
+    if (pos + 3 > srcSize) return false;
+    const uint32_t bh = zh_ld24(src + pos); pos += 3;
+    const uint32_t bs = bh >> 3;
+    if (!(bh & 1) || ((bh >> 1) & 3) != 2) return false;
+    if (pos + bs > srcSize || bs > blockMax || bs < 2) return false;
+    const ZhipDictEntropy* const de = a.dictEntropy;
+    const uint8_t* const b = src + pos;
+    const uint32_t b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3;
+    uint32_t used, regen;
+    if (lt == 2) return false;                                          // a Huffman table of its own
+    if (lt < 2) {
+        uint32_t hdr;
+        if (fmt == 1) { hdr = 2; regen = zh_ld16(b) >> 4; }            // (bs >= 2)
+        else if (fmt == 3) { if (bs < 3) return false; hdr = 3; regen = zh_ld24(b) >> 4; }
+        else { hdr = 1; regen = b0 >> 3; }
+        if (regen > blockMax) return false;
+        if (lt == 0) { if (hdr + regen > bs) return false; m.litMode = 0; m.litOff = pos + hdr; used = hdr + regen; }
+        else { if (hdr + 1 > bs) return false; m.litMode = 2; m.litOff = b[hdr]; used = hdr + 1; }
+    } else {
+        if (bs < 5) return false;
+        const uint32_t v = zh_ld32(b);
+        uint32_t hdr, four, csize;
+        if (fmt < 2) { hdr = 3; four = fmt; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+        else if (fmt == 2) { hdr = 4; four = 1; regen = (v >> 4) & 0x3FFF; csize = v >> 18; }
+        else { hdr = 5; four = 1; regen = (v >> 4) & 0x3FFFF; csize = (v >> 22) + ((uint32_t)b[4] << 10); }
+        if (regen > blockMax || regen > ZF_BLOCK_MAX) return false;
+        if (four ? regen < 6 : regen == 0) return false;
+        if (hdr + csize > bs) return false;
+        if (four && (csize < 10 || 3 * ((regen + 3) / 4) > regen)) return false;
+        m.litMode = 3u | (a.dictTables->hufLog << 8) | (four << 16) | ZP_LIT_SHARED; m.litOff = pos + hdr; m.produced = csize;
+        need16 = (regen + 256u + 15u) >> 4;
+        used = hdr + csize;
+    }
+    m.litSize = regen;
+    uint32_t sp = pos + used; const uint32_t send = pos + bs;
+    if (sp >= send) return false;
+    uint32_t nbSeq = src[sp++];
+    if (nbSeq > 127) {
+        if (nbSeq == 255) { if (sp + 2 > send) return false; nbSeq = zh_ld16(src + sp) + 0x7F00; sp += 2; }
+        else { if (sp >= send) return false; nbSeq = ((nbSeq - 128) << 8) + src[sp++]; }
+    }
+    m.nbSeq = nbSeq;
+    if (nbSeq == 0) { if (sp != send) return false; }
+    else {
+        if (nbSeq > ZP_SEQ_CAP - 16 || sp >= send) return false;
+        const uint32_t modes = src[sp++];
+        if ((modes & 3) || (modes >> 2) != 0x3F) return false;          // a table of its own (or a reserved bit)
+        if (sp >= send) return false;
+        m.logs = de->llLog | (de->ofLog << 8) | (de->mlLog << 16) | ZP_LOGS_SHARED;
+    }
+    m.seqOff = sp; m.seqEnd = send;
+    if (h.hasChecksum) {
+        if (send + 4 > srcSize) return false;
+        m.hasChecksum = 1; m.checksum = zh_ld32(src + send);
+    }
+    m.path = 1;
+    return true;
+}
+
+ZH_DEVFN void zp_lit_one(const ZhipPipeArgs& a, ZdLDS& L, uint32_t i);
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -208,6 +286,48 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
+    // dictionary batches: k1Lanes frames at a time, a lane each where nothing has to be built (zp_lit_shared_try), the wave for the rest
+    const uint32_t T = a.k1Lanes > 64u ? 64u : a.k1Lanes;
+    if (T > 1 && a.dictEntropy && a.dictEntropy->hufCount && a.dictTables->hufLog <= ZP_HUF_LOGMAX) {
+        for (;;) {
+            const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? T : 0u);
+            if (zh_opaque(lane) == 0) L.misc[7] = got;
+            zh_sync();
+            const uint32_t base = zh_first(L.misc[7]);
+            zh_sync();
+            if (base >= a.count) break;
+            const uint32_t i = base + lane;
+            const bool mine = lane < T && i < a.count;
+            ZdMeta m; uint32_t need16 = 0;
+            const bool done = mine && zp_lit_shared_try(a, a.first + i, m, need16);
+            // the frames' literal rooms: ONE claim for the task (zp_block_tables makes one per frame)
+            const uint32_t n16 = done ? need16 : 0u;
+            const uint32_t incl = zh_scan_add(n16), total = zh_shfl(incl, 63);
+            uint32_t lb = 0;
+            if (total) lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? total : 0u)) + incl - n16;
+            if (done) {
+                if (n16 && (uint64_t)lb + n16 > a.arenaBudget16) {                  // the chunk's room is used up: the generic kernel's frame
+                    const uint32_t bm = m.blockMax, lo = m.fcsLo, hi = m.fcsHi;
+                    zp_meta_clear(m); m.blockMax = bm; m.fcsLo = lo; m.fcsHi = hi; m.path = 2;
+                    a.meta[i] = m;
+                    const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = a.first + i;
+                } else {
+                    a.bases[2 * (size_t)i + 1] = n16 ? a.arenaBudget16 - lb - n16 : 0u;
+                    zp_enter_bins(a, m);
+                    a.meta[i] = m;
+#ifdef ZHIP_EMU
+                    zd_stat[7]++;                                               // (test hook [7]: frames a lane finished)
+#endif
+                }
+            }
+            uint64_t rest = zh_ballot(mine && !done);
+            while (rest) {
+                const uint32_t l = (uint32_t)zh_ctz64(rest); rest &= rest - 1;
+                zp_lit_one(a, L, base + l);
+            }
+        }
+        return;
+    }
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
@@ -215,6 +335,14 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         const uint32_t i = zh_first(L.misc[7]);
         zh_sync();
         if (i >= a.count) break;
+        zp_lit_one(a, L, i);
+    }
+}
+// one frame by the whole wave
+ZH_DEVFN void zp_lit_one(const ZhipPipeArgs& a, ZdLDS& L, uint32_t i)
+{
+    const uint32_t lane = zh_lane();
+    {
         const uint32_t f = a.first + i;
         ZdMeta m;
         zp_meta_clear(m);

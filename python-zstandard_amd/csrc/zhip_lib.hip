@@ -753,7 +753,13 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
             // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 15 frames per wave -> 4)
             const size_t w2 = (items + ZQ_FRAMES - 1) / ZQ_FRAMES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqQLDS));
-            const uint32_t g1 = (uint32_t)(cnt < g1m ? cnt : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
+            // dictionary batches: K1's waves take several frames at a time, a lane each where nothing has to be built (zp_lit_shared_try) -- as many as keep every
+            // resident wave supplied with a task (what a lane cannot finish its wave does one frame after the other: a task is never longer than the share of
+            // frames a wave had before)
+            pa.k1Lanes = 0;
+            if (!mb && c->dictHasEntropy) { uint32_t t = 1; while (t < 64 && (size_t)t * 2 * g1m <= cnt) t *= 2; pa.k1Lanes = t; }
+            const size_t tasks1 = pa.k1Lanes > 1 ? (cnt + pa.k1Lanes - 1) / pa.k1Lanes : cnt;
+            const uint32_t g1 = (uint32_t)(tasks1 < g1m ? tasks1 : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
             const bool tm = c->timing;
@@ -1441,12 +1447,25 @@ extern "C" size_t zhip_thread_memory_size(void)
     if (c) (void)c->counter.reserve(64 * 8);
     return c ? c->device_bytes() : 0;
 }
+// Round 6: a context KEEPS its working set between calls -- the flat search's tables (12 GiB for a 32 768-source chunk), the arenas, the
+// device-side staging -- as long as the whole stays within ZHIP_KEEP_GB (default 64: a BASELINE-sized call of 65 536 x 128 KiB holds ~50 GiB of the GPU's
+// 288), the way the reference keeps one ZSTD_CCtx per worker between calls (c-ext/compressor.c:1129-1168). Rounds 1-5 released every buffer above 2 GiB after
+// every call: the next call re-reserved ~13 GiB of tables (and re-drew their placement). Above the limit the largest buffers go first.
+static size_t tls_keep_bytes()
+{
+    static const size_t keep = [] { const char* e = getenv("ZHIP_KEEP_GB"); return (e ? (size_t)strtoull(e, nullptr, 10) : (size_t)64) << 30; }();
+    return keep;
+}
 static void tls_trim(zhip_ctx* c)
 {
-    const size_t limit = (size_t)2 << 30;
     DevBuf* bufs[] = { &c->pipeMeta, &c->pipeLit, &c->pipeFse, &c->pipeHuf, &c->pipeBases, &c->encArena, &c->encTables, &c->encFlatTables, &c->encWorkspace,
                        &c->encBigWs, &c->scratch, &c->hSrc, &c->hDst, &c->hDense };
-    for (DevBuf* b : bufs) if (b->cap > limit) b->release();
+    while (c->device_bytes() > tls_keep_bytes()) {
+        DevBuf* big = nullptr;
+        for (DevBuf* b : bufs) if (b->cap > ((size_t)64 << 20) && (!big || b->cap > big->cap)) big = b;
+        if (!big) break;
+        big->release();
+    }
 }
 static int set_err(zhip_error* err, int kind, size_t index, int zerr, uint64_t d0 = 0, uint64_t d1 = 0)
 {

@@ -124,6 +124,8 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
 static ZpExecLDS g_xlds;
 static ZpBinLDS g_binlds;
 static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBits[56];
+static uint32_t g_k1Lanes = 16;                  // K1 of dictionary batches: frames per task, a lane each where nothing has to be built (0 / 1: a wave per frame, rounds 1-5)
+extern "C" void emu_set_k1_lanes(uint32_t v) { g_k1Lanes = v; }
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
 static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
 static ZpHufKernelLDS g_huflds;
@@ -189,6 +191,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
               memset(a.itemFrame, 0xA5, slots * 4); memset(a.itemReps, 0xA5, slots * 16); memset(a.frameRecs, 0xA5, (size_t)chunk * sizeof(ZpFrameRec)); }
     a.counters = counters; a.fallbackCount = &counters[ZP_CNT_WORDS]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
+    a.k1Lanes = g_k1Lanes;                       // (the product sets it for dictionary batches: zhip_decompress_batch_device)
     if (g_ddHas) {
         const uint32_t co = g_ddEnt ? g_ddEntropy.contentOffset : 0u;
         a.dictID = g_ddEnt ? g_ddEntropy.dictID : 0u; a.dictContent = g_ddBlob.data() + co; a.dictContentSize = (uint32_t)(g_ddBlob.size() - 64) - co;
