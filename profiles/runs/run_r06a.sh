@@ -1,4 +1,5 @@
 #!/bin/bash
+# (this session's tools -- tests/tools/e1f_window_sweep.py, the ZHIP_E1F_WIN knob, the windowed kernels -- are in git tag r06-e1f-window: the form was measured and removed)
 # round 6, GPU session A: the flat match kernel with the lanes' own bytes in LDS windows (ze_dfast_flat_w) -- parity first (compress tests, every frame against
 # libzstd), then the A/B against rounds 1-5's form at 8 192 ... 131 072 sources per launch
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/r06a && O=gpurun_out/r06a

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (this session's tools -- tests/tools/e1f_window_sweep.py, the ZHIP_E1F_WIN knob, the windowed kernels -- are in git tag r06-e1f-window: the form was measured and removed)
 # round 6, GPU session B: (1) what a trip of the flat match kernel costs in INSTRUCTIONS against waiting, rounds 1-5's form (ZHIP_E1F_WIN=0) against the
 # LDS-window form with long matches counted on by their own lane: SQ counters at 8 192 sources per launch (one wave per 8 SIMDs: the chain-bound end) and at
 # 65 536; (2) the A/B sweep of session A again on this build

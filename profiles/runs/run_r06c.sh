@@ -1,4 +1,5 @@
 #!/bin/bash
+# (this session's tools -- tests/tools/e1f_window_sweep.py, the ZHIP_E1F_WIN knob, the windowed kernels -- are in git tag r06-e1f-window: the form was measured and removed)
 # round 6, GPU session C: (1) where a trip of the flat match kernel spends its cycles (-DZE_PROF_FLAT: s_memtime deltas per phase, lane 0 of every wave), the form
 # of rounds 1-5 against the LDS-window form, at 8 192 and 65 536 sources per launch; (2) the multi-device split of the host-buffer API on two / three
 # device slots of the one GPU (ZHIP_DEVICES=0,0): byte-identical collections, first failing item

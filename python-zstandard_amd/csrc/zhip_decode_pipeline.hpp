@@ -210,6 +210,7 @@ ZH_DEV void zp_meta_clear(ZdMeta& m)
 ZH_DEV bool zp_lit_shared_try(const ZhipPipeArgs& a, uint32_t f, ZdMeta& m, uint32_t& need16)
 {
     zp_meta_clear(m); need16 = 0;
+    if (!a.dictEntropy->hufCount || a.dictTables->hufLog > ZP_HUF_LOGMAX) return false;       // (no ready-made Huffman table to share)
     const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
     const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
     if (srcSize64 > 0x7FFFFFFFull) return false;
@@ -278,7 +279,48 @@ ZH_DEV bool zp_lit_shared_try(const ZhipPipeArgs& a, uint32_t f, ZdMeta& m, uint
     return true;
 }
 
-ZH_DEVFN void zp_lit_one(const ZhipPipeArgs& a, ZdLDS& L, uint32_t i);
+// K1 of dictionary batches, first pass: a wave takes 64 frames, a lane walks each (zp_lit_shared_try); the frames a lane cannot finish are LISTED for K1 proper
+// (zp_lit_body in list mode), which then runs only over them. A kernel of its own: folded into zp_lit_body the per-lane records pushed that kernel into 288 bytes
+// of scratch per lane and made the wave-per-frame path 25 x slower (r06e: 2.2 -> 55 ms per 65 536 frames without any dictionary).
+ZH_DEVFN void zp_lit_lanes_body(const ZhipPipeArgs& a)
+{
+    const uint32_t lane = zh_lane();
+    for (;;) {
+        const uint32_t base = zh_first(zh_atomic_add(a.counters + 9, lane == 0 ? 64u : 0u));
+        if (base >= a.count) break;
+        const uint32_t i = base + lane;
+        const bool mine = i < a.count;
+        ZdMeta m; uint32_t need16 = 0;
+        const bool done = mine && zp_lit_shared_try(a, a.first + i, m, need16);
+        // the frames' literal rooms: ONE claim for the 64 (zp_block_tables makes one per frame)
+        const uint32_t n16 = done ? need16 : 0u;
+        const uint32_t incl = zh_scan_add(n16), total = zh_shfl(incl, 63);
+        uint32_t lb = 0;
+        if (total) lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? total : 0u)) + incl - n16;
+        if (done) {
+            if (n16 && (uint64_t)lb + n16 > a.arenaBudget16) {                  // the chunk's room is used up: the generic kernel's frame
+                const uint32_t bm = m.blockMax, lo = m.fcsLo, hi = m.fcsHi;
+                zp_meta_clear(m); m.blockMax = bm; m.fcsLo = lo; m.fcsHi = hi; m.path = 2;
+                a.meta[i] = m;
+                const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = a.first + i;
+            } else {
+                a.bases[2 * (size_t)i + 1] = n16 ? a.arenaBudget16 - lb - n16 : 0u;
+                zp_enter_bins(a, m);
+                a.meta[i] = m;
+#ifdef ZHIP_EMU
+                zd_stat[7]++;                                               // (test hook [7]: frames a lane finished)
+#endif
+            }
+        }
+        // the others: one list claim for the wave
+        const uint64_t rest = zh_ballot(mine && !done);
+        if (rest) {
+            const uint32_t at = zh_first(zh_atomic_add(a.counters + 10, lane == 0 ? (uint32_t)zh_popc64(rest) : 0u));
+            if (mine && !done) a.order[at + (uint32_t)zh_popc64(rest & zh_lt_mask())] = i;
+        }
+    }
+}
+
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -286,63 +328,15 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
-    // dictionary batches: k1Lanes frames at a time, a lane each where nothing has to be built (zp_lit_shared_try), the wave for the rest
-    const uint32_t T = a.k1Lanes > 64u ? 64u : a.k1Lanes;
-    if (T > 1 && a.dictEntropy && a.dictEntropy->hufCount && a.dictTables->hufLog <= ZP_HUF_LOGMAX) {
-        for (;;) {
-            const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? T : 0u);
-            if (zh_opaque(lane) == 0) L.misc[7] = got;
-            zh_sync();
-            const uint32_t base = zh_first(L.misc[7]);
-            zh_sync();
-            if (base >= a.count) break;
-            const uint32_t i = base + lane;
-            const bool mine = lane < T && i < a.count;
-            ZdMeta m; uint32_t need16 = 0;
-            const bool done = mine && zp_lit_shared_try(a, a.first + i, m, need16);
-            // the frames' literal rooms: ONE claim for the task (zp_block_tables makes one per frame)
-            const uint32_t n16 = done ? need16 : 0u;
-            const uint32_t incl = zh_scan_add(n16), total = zh_shfl(incl, 63);
-            uint32_t lb = 0;
-            if (total) lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? total : 0u)) + incl - n16;
-            if (done) {
-                if (n16 && (uint64_t)lb + n16 > a.arenaBudget16) {                  // the chunk's room is used up: the generic kernel's frame
-                    const uint32_t bm = m.blockMax, lo = m.fcsLo, hi = m.fcsHi;
-                    zp_meta_clear(m); m.blockMax = bm; m.fcsLo = lo; m.fcsHi = hi; m.path = 2;
-                    a.meta[i] = m;
-                    const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = a.first + i;
-                } else {
-                    a.bases[2 * (size_t)i + 1] = n16 ? a.arenaBudget16 - lb - n16 : 0u;
-                    zp_enter_bins(a, m);
-                    a.meta[i] = m;
-#ifdef ZHIP_EMU
-                    zd_stat[7]++;                                               // (test hook [7]: frames a lane finished)
-#endif
-                }
-            }
-            uint64_t rest = zh_ballot(mine && !done);
-            while (rest) {
-                const uint32_t l = (uint32_t)zh_ctz64(rest); rest &= rest - 1;
-                zp_lit_one(a, L, base + l);
-            }
-        }
-        return;
-    }
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
-        const uint32_t i = zh_first(L.misc[7]);
+        const uint32_t got1 = zh_first(L.misc[7]);
         zh_sync();
-        if (i >= a.count) break;
-        zp_lit_one(a, L, i);
-    }
-}
-// one frame by the whole wave
-ZH_DEVFN void zp_lit_one(const ZhipPipeArgs& a, ZdLDS& L, uint32_t i)
-{
-    const uint32_t lane = zh_lane();
-    {
+        // dictionary batches (k1Lanes): the frames the lane-per-frame kernel could not finish, listed in `order` (free until KB fills it)
+        if (got1 >= (a.k1Lanes ? a.counters[10] : a.count)) break;
+        const uint32_t i = a.k1Lanes ? a.order[got1] : got1;
         const uint32_t f = a.first + i;
         ZdMeta m;
         zp_meta_clear(m);
@@ -1159,6 +1153,11 @@ ZH_DEV uint32_t zp_sym_resolve(uint32_t v, uint32_t R0, uint32_t R1, uint32_t R2
 // LDS hand-offs inside the batch loop: __syncthreads() also waits for the wave's global stores and loads (s_waitcnt vmcnt(0)); -DZP_K3_LIGHT_SYNC
 // makes them wave-level fences (the LDS executes a wave's instructions in order), as the round-4 form has them
 #define ZP_BSYNC() zh_sync()
+#ifndef ZP_HIST_KEEP
+#define ZP_HIST_KEEP ((ZP_ASM_BYTES * 5u / 16u) & ~15u)      // bytes of history the buffer keeps when it slides (1 280 of the 4 096) ...
+#define ZP_HIST_SLIDE (2u * ZP_HIST_KEEP + 16u)             // ... once more than this many lie in front of the batch (2 576): a batch always finds ZP_ASM_BYTES - ZP_HIST_SLIDE bytes of room
+#endif
+static_assert((ZP_HIST_SLIDE >= 2 * ZP_HIST_KEEP + 16 || ZP_HIST_KEEP == 0) && ZP_HIST_KEEP % 16 == 0 && ZP_HIST_SLIDE < ZP_ASM_BYTES, "the slide's source and destination must not overlap");      // (-DZP_HIST_KEEP=0u -DZP_HIST_SLIDE=0u: no history, rounds 1-5's form, for A/B)
 template <bool DICT, bool PROF, bool MB>
 ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m, uint32_t t, const uint8_t* src, uint8_t* dst, uint32_t cap, uint64_t cap64,
                            uint32_t blockMax, uint32_t& opRef, uint32_t R0, uint32_t R1, uint32_t R2, ZdProf& P)
@@ -1170,7 +1169,14 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
     const uint8_t* litPtr = m.litMode == 0 ? src + m.litOff : a.litArena + (size_t)a.bases[2 * (size_t)t + 1] * 16;
     const uint8_t* const dictEnd = DICT ? a.dictContent + a.dictContentSize : dst;       // position -k of the frame = dictEnd[-k]
     const uint32_t dictSize = DICT ? a.dictContentSize : 0u;
-    uint8_t* const asmb = L.asmb;
+    // Round 6: the assembly buffer keeps what it flushed. A batch is ~0.9 KiB of the buffer's 4: instead of starting every batch at its front, batches are
+    // APPENDED -- the hOff bytes in front of the current batch are the block's last output, still in LDS -- and a far match (or the part of a near one that
+    // precedes the batch) whose source starts inside that history is staged LDS -> LDS in the staging phase, like a literal run: no memory request, no
+    // dependency round (round 3's window was served by the rounds and lost). K3 sits on the memory system's random-request rate (470 M 64-byte read requests
+    // per 65 536 frames in 10.1 ms = 47 G/s, TCC_EA0_RDREQ, profiles/r06d_*), and a third of its match sources lie within 2 KiB behind the batch. When the
+    // history passes ZP_HIST_SLIDE the last ZP_HIST_KEEP bytes (and the carried tail) move to the buffer's front: two 16-byte copies per lane every other batch.
+    uint32_t hOff = 0;                                               // bytes of history in front of the batch (a multiple of 16; wave-uniform)
+    uint8_t* asmb = L.asmb;                                          // = L.asmb + hOff: asmb[0] is the byte at position ob, asmb[-k] the byte at ob - k for k <= hOff
     const uint32_t blockStart = MB ? opRef : 0u;
     uint32_t op = blockStart, lp = 0, done = 0;
     // The flush writes whole 16-byte units only: the last `carry` (< 16) bytes of a batch stay at the front of the assembly buffer and leave
@@ -1189,7 +1195,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
         if (MB && zh_ballot(lane < avail && myOF == ZP_OF_LIMIT)) return ZP_RC_FALLBACK;      // an offset K2 could not pack: the generic kernel's frame
         uint32_t incL = zh_scan_add(myLL), incT = zh_scan_add(myLL + myML);
         // how many of these fit the assembly buffer (behind the carried bytes)
-        const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES);
+        const uint64_t fits = zh_ballot(lane < avail && incT + carry <= ZP_ASM_BYTES - hOff);
         uint32_t cnt = (uint32_t)zh_popc64(fits);          // fits is a prefix mask (incT is monotone)
         const bool big = cnt == 0;
         if (big) cnt = 1;
@@ -1216,6 +1222,7 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             zd_match_wave(dst, dictEnd, op + bll, bof, bml);
             zd_fence();
             op += totT; lp += totL; done += 1;
+            hOff = 0; asmb = L.asmb;                                            // (the history ends here: this item went straight to memory)
             continue;
         }
         ZD_TP(P, ZP_STAGE);
@@ -1254,12 +1261,14 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             const bool strad = DICT && (farM || pre) && sAbs < 0 && sAbs + (int32_t)lenMi > 0;
             const uint8_t* const mSrc = !DICT || sAbs >= 0 ? dst + sAbs : dictEnd + sAbs;
             const bool shortM = (farM || pre) && lenMi <= ZP_FAR_SHORT && !strad;
-            if (!zh_ballot(shortM && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
-                const uint8_t* q = shortM ? mSrc : dst;
+            const bool inH = (farM || pre) && sAbs >= (int32_t)(ob - hOff);          // the source starts inside the history: staged from LDS (sAbs >= 0 then)
+            if (!zh_ballot(shortM && !inH && sAbs >= 0 && (uint64_t)sAbs + 32 > cap64) && cap64 >= 32) {     // (the dictionary's buffer has its own slack)
+                const uint8_t* q = shortM && !inH ? mSrc : dst;
                 rm[0] = ZP_FAR_LD64(q); rm[3] = ZP_FAR_LD64(q + (shortM && lenMi >= 8 ? lenMi - 8 : 0u));
                 if (ZP_FAR_SHORT > 16) { rm[1] = ZP_FAR_LD64(q + 8); rm[2] = ZP_FAR_LD64(q + 16); } else { rm[1] = 0; rm[2] = 0; }
             } else
-            if (shortM) zd_ld32(mSrc, lenMi, rm);
+            if (shortM && !inH) zd_ld32(mSrc, lenMi, rm);
+            if (shortM && inH) { const uint8_t* hq = asmb + (sAbs - (int32_t)ob); rm[0] = zh_ld64(hq); rm[1] = 0; rm[2] = 0; rm[3] = zh_ld64(hq + (lenMi >= 8 ? lenMi - 8 : 0u)); }
             const bool longL = act && myLL > ZP_LIT_SHORT && !litRLE, longM = (farM || pre) && !shortM && !strad;
             const uint32_t uL = longL ? (myLL + 15) >> 4 : 0u, uM = longM ? (lenMi + 15) >> 4 : 0u;
             const uint32_t ue = zh_scan_add(uL + uM);
@@ -1274,7 +1283,9 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                     uint32_t k_ = (u) - (j_ ? (uint32_t)L.uEnd[j_ - 1] : 0u); const uint32_t nl_ = L.uLit[j_]; const bool isL_ = k_ < nl_; if (!isL_) k_ -= nl_; \
                     const uint32_t len_ = isL_ ? L.lenL[j_] : L.lenM[j_]; const uint32_t off_ = 16 * k_ + 16 <= len_ ? 16 * k_ : len_ - 16; \
                     const int32_t sm_ = (int32_t)L.srcM[j_]; \
-                    uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : (!DICT || sm_ >= 0 ? dst + sm_ : dictEnd + sm_) + off_); udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
+                    if (!isL_ && sm_ >= (int32_t)(ob - hOff)) { const uint8_t* h_ = asmb + (sm_ - (int32_t)ob) + off_; uv.lo = zh_ld64(h_); uv.hi = zh_ld64(h_ + 8); } \
+                    else uv = zh_ld128(isL_ ? litPtr + L.srcL[j_] + off_ : (!DICT || sm_ >= 0 ? dst + sm_ : dictEnd + sm_) + off_); \
+                    udp = asmb + (isL_ ? L.dstL[j_] : L.dstM[j_]) + off_; } while (0)
                 if (lane < U) ZP_UNIT(lane);
             }
             if (litRLE) { for (int k = 0; k < 4; k++) rl[k] = 0x0101010101010101ull * rleByte; }      // (frame-uniform)
@@ -1362,14 +1373,14 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
                     if (fof >= 64) {
                         for (uint32_t c = 0; c < fml; c += 64) {
                             const uint32_t j = c + lane;
-                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
+                            if (j < fml) { const int32_t sp = fs + (int32_t)j; asmb[Frel + j] = sp >= (int32_t)(ob - hOff) ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]); }
                             if (fof < fml) ZP_BSYNC();
                         }
                     } else {
                         uint32_t idx = lane % fof; const uint32_t adv = 64 % fof;
                         for (uint32_t j = lane; j < fml; j += 64) {
                             const int32_t sp = fs + (int32_t)idx;
-                            asmb[Frel + j] = sp >= (int32_t)ob ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
+                            asmb[Frel + j] = sp >= (int32_t)(ob - hOff) ? asmb[sp - (int32_t)ob] : (DICT ? (uint8_t)zd_hist_byte(dst, dictEnd, sp) : dst[sp]);
                             idx += adv; if (idx >= fof) idx -= fof;
                         }
                     }
@@ -1395,14 +1406,15 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
             if (whole > 1024) for (uint32_t j = j0 + 1024; j < whole; j += 1024) { const zh_v16 v = *(const zh_v16*)(asmb + zh_opaque(j)); *(zh_v16*)(out + j) = v; }
         }
         carry = totB - whole;
-        ZP_BSYNC();
-        if (carry && whole) {                                              // the tail moves to the front (one 16-byte read / write; the sync above: every flush read is done)
-            uint64_t t0 = 0, t1 = 0;
-            if (lane == 0) { t0 = zh_ld64(asmb + whole); t1 = zh_ld64(asmb + whole + 8); }
+        hOff += whole;                                                     // what left stays as history; the tail is where the next batch starts: nothing moves
+        ZP_BSYNC();                                                        // (every flush read is done)
+        if (hOff > ZP_HIST_SLIDE) {                                        // the last ZP_HIST_KEEP bytes + the tail to the buffer's front (source and destination do not overlap: ZP_HIST_SLIDE >= 2 * ZP_HIST_KEEP + 16)
+            const uint32_t s0 = hOff - ZP_HIST_KEEP, n = ZP_HIST_KEEP + carry;
+            for (uint32_t j = lane * 16; j < n; j += 1024) { const zh_v16 v = *(const zh_v16*)(L.asmb + s0 + j); *(zh_v16*)(L.asmb + j) = v; }
+            hOff = ZP_HIST_KEEP;
             ZP_BSYNC();
-            if (lane == 0) { zh_st64(asmb, t0); zh_st64(asmb + 8, t1); }
         }
-        ZP_BSYNC();
+        asmb = L.asmb + hOff;
         ZD_TP(P, ZP_FLUSH);
         op += totT; lp += totL; done += cnt;
     }

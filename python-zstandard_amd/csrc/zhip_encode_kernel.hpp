@@ -1038,31 +1038,8 @@ ZH_DEV uint32_t ze_dfast(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const ui
 // the reference's comparisons against the lowest prefix index (2) keep their meaning. srcSize in [16, 128 KiB]; tables zeroed.
 #ifdef ZHIP_EMU
 #define ZE_STAT(i) (zd_stat[i]++)
-// the flat searches' dependent memory rounds, logged per (wave, trip, kind, lane) for tests/tools/e1f_round_model.py: what a WAVE pays for a trip is,
-// for every kind of round, the most any of its lanes needed (kinds: 0 own bytes from memory, 1 cells, 2 candidates, 3 count, 4 count goes on,
-// 5 catch-up goes on, 6 own bytes the window did not hold / insertion bytes, 7 repeat-offset bytes, 8 a trip that only fetched)
-extern "C" void ze_emu_rnd(uint32_t block, uint32_t lane, uint32_t kind);
-extern "C" void ze_emu_trip(uint32_t block, uint32_t lane, int reset);
-#define ZE_RND(kind) ze_emu_rnd(zh_block(), zh_lane(), kind)
-#define ZE_TRIP_RESET ze_emu_trip(zh_block(), zh_lane(), 1)
-#define ZE_TRIP_NEXT ze_emu_trip(zh_block(), zh_lane(), 0)
 #else
 #define ZE_STAT(i) ((void)0)
-#define ZE_RND(kind) ((void)0)
-#define ZE_TRIP_RESET ((void)0)
-#define ZE_TRIP_NEXT ((void)0)
-#endif
-// -DZE_PROF_FLAT (diagnostic builds, ZHIP_PROF=1): where a trip of the flat searches spends its cycles -- s_memtime deltas per phase, summed by lane 0 of every wave
-#if defined(ZE_PROF_FLAT) && !defined(ZHIP_EMU)
-#define ZE_FT_DECL uint64_t ze_ft0 = zd_clock(); unsigned long long ze_fta[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define ZE_FT(i) do { const uint64_t t_ = zd_clock(); ze_fta[i] += t_ - ze_ft0; ze_ft0 = t_; } while (0)
-#define ZE_FT_TRIP (ze_fta[7]++)
-#define ZE_FT_END(prof) do { if ((prof) && zh_lane() == 0) for (int q_ = 0; q_ < 8; q_++) zh_atomic_add64((prof) + 16 + q_, ze_fta[q_]); } while (0)
-#else
-#define ZE_FT_DECL ((void)0)
-#define ZE_FT(i) ((void)0)
-#define ZE_FT_TRIP ((void)0)
-#define ZE_FT_END(prof) ((void)0)
 #endif
 ZH_DEV uint32_t ze_hl8(uint64_t u, uint32_t sh) { return (uint32_t)((u * 0xCF1BBCDCB7A56463ull) >> 32) >> sh; }
 ZH_DEV uint32_t ze_hsx(uint64_t u, uint32_t shl, uint64_t prime, uint32_t sh) { return (uint32_t)(((u << shl) * prime) >> 32) >> sh; }
@@ -1070,7 +1047,7 @@ ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_
 {
     uint32_t len = 0;
     while (a + len + 32 <= srcSize) {                                  // 32 bytes a round: most matches end inside the first
-        ZE_STAT(12); ZE_RND(4);
+        ZE_STAT(12);
         const zh_v16 x0 = zh_ld128(src + a + len), y0 = zh_ld128(src + b + len), x1 = zh_ld128(src + a + len + 16), y1 = zh_ld128(src + b + len + 16);
         const uint64_t d0 = x0.lo ^ y0.lo, d1 = x0.hi ^ y0.hi, d2 = x1.lo ^ y1.lo, d3 = x1.hi ^ y1.hi;
         if (d0) return len + (uint32_t)(zh_ctz64(d0) >> 3);
@@ -1105,10 +1082,8 @@ ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_
 // (r04zd / r04zg). The function was written for two probes in round 1 and generalised in round 4; at NP = 2 it compiles to the same kernel (4 573 against
 // 4 569 instructions, 85 against 84 VGPRs).
 template <int PB, bool BLK, int NP>
-ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle,
-                                 unsigned long long* prof = nullptr)
+ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle)
 {
-    ZE_FT_DECL;
     constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
 #undef ZE_CELL_IDX
 #define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
@@ -1131,8 +1106,7 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
     }
     uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
     bool fresh = true;
-    ZE_TRIP_RESET;
-    for (;; ZE_TRIP_NEXT) {
+    for (;;) {
         if (fresh) { step = 1; nextStep = ip + 256; }
         // the trip's positions: probe k at pos[k], with the step a failed probe k - 1 leaves behind (zstd.c:31207); pos[NP] is where the search goes on
         uint32_t pos[NP + 1], st[NP + 1], nx[NP + 1];
@@ -1147,8 +1121,7 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
         uint32_t R = 1;
 #pragma unroll
         for (int k = 1; k < NP; k++) if (R == (uint32_t)k && pos[k + 1] <= ilimit) R = (uint32_t)k + 1;
-        ZE_STAT(10); ZE_FT_TRIP; ZE_FT(6);
-        ZE_RND(0); ZE_RND(1); ZE_RND(2);
+        ZE_STAT(10);
         // round 0: the probes' own bytes (positions beyond the last real one read the last valid position: ignored)
         uint64_t w[NP + 1]; uint32_t rp[NP], pL[NP + 1], hl[NP + 1], hs[NP];
 #pragma unroll
@@ -1159,7 +1132,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
         for (int k = 0; k <= NP; k++) { pL[k] = ZE_PL(w[k]); hl[k] = pL[k] >> shL; }
 #pragma unroll
         for (int k = 0; k < NP; k++) hs[k] = ZE_PS(w[k]) >> shS;
-        ZE_FT(0);
         // round 1: the table cells, all in flight together. The long cell of probe 0 was read one trip earlier unless the trip is fresh.
         uint32_t cL[NP + 1], cS[NP], newL[NP + 1], newS[NP];
         const uint32_t tA = hashLong[fresh ? hl[0] : hl[1]];
@@ -1182,7 +1154,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
                 if (k < NP && hs[k < NP ? k : 0] == hs[j]) cS[k < NP ? k : 0] = newS[j];
             }
         }
-        ZE_FT(1);
         hashLong[hl[0]] = newL[0]; hashSmall[hs[0]] = newS[0];
         uint32_t idxl[NP + 1], idxs[NP], pl[NP + 1]; bool psv[NP];
 #pragma unroll
@@ -1200,7 +1171,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
         for (int k = 0; k <= NP; k++) xl[k] = zh_opaque64(xl[k]);                 // no load sinks into a branch
 #pragma unroll
         for (int k = 0; k < NP; k++) cs[k] = zh_opaque(cs[k]);
-        ZE_FT(2);
         if (!fresh) xl[0] = cl0;
         int fnd[NP];
 #pragma unroll
@@ -1212,7 +1182,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
         // the table writes of the probes that really happened: 1 .. P (a match at P) or 1 .. R - 1 (none), in the reference's order
 #pragma unroll
         for (int k = 1; k < NP; k++) if ((uint32_t)k <= P && (uint32_t)k < R) { hashLong[hl[k]] = newL[k]; hashSmall[hs[k]] = newS[k]; }
-        ZE_FT(3);
         if (found) {
             ZE_STAT(11);
             uint32_t ipP = pos[0], ipP1 = pos[1], stepP = st[0], idxlP = idxl[0], idxsP = idxs[0], idxl1 = idxl[1], pl1 = pl[1], hl1 = hl[1], newL1 = newL[1];
@@ -1226,16 +1195,14 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
             uint32_t mLength = ze_count_fwd(src, ca, cb, srcSize) + add;
             if (found == 3 && pl1 && idxl1 > 2 && cl1 == w1) {          // a long match one step ahead beats a shorter short match (zstd.c:31192-31201)
                 const uint32_t m1 = idxl1 - 2;
-                ZE_RND(3);
                 const uint32_t l1 = ze_count_fwd(src, ipP1 + 8, m1 + 8, srcSize) + 8;
                 if (l1 > mLength) { ipm = ipP1; mLength = l1; mpos = m1; }
             }
-            ZE_FT(4);
             uint32_t offBase = 1;
             if (found >= 2) {
                 const uint32_t offset = ipm - mpos;
                 while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204), 8 bytes a round
-                    ZE_STAT(13); ZE_RND(5);
+                    ZE_STAT(13);
                     const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
                     if (mpos >= 8) {
                         const uint64_t d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8);
@@ -1252,12 +1219,10 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
                 if (stepP < 4) hashLong[hl1] = newL1;
                 offBase = offset + 3;
             }
-            ZE_FT(5);
             seqs[nseq++] = ZE_SEQ_PACK(offBase, ipm - anchor, mLength);
             const uint32_t pI = ipP + 2;
             ip = ipm + mLength; anchor = ip;
             if (ip <= ilimit) {
-                ZE_RND(6);
                 const uint64_t wI = zh_ld64(src + pI), wE2 = zh_ld64(src + ip - 2), wE1 = zh_ld64(src + ip - 1);
                 uint64_t wr = zh_ld64(src + ip); uint32_t r2 = zh_ld32(src + ip - off2);
                 const uint32_t qI = ZE_PL(wI), qE = ZE_PL(wE2);
@@ -1275,7 +1240,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
                     seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
                     ip += r; anchor = ip;
                     if (ip > ilimit) break;
-                    ZE_RND(7);
                     wr = zh_ld64(src + ip); r2 = zh_ld32(src + ip - off2);
                 }
             }
@@ -1293,7 +1257,6 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
 #undef ZE_TS
 #undef ZE_CELL_IDX
 #define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
-    ZE_FT_END(prof);
     if (BLK) {                                                        // zstd.c:31252-31258
         saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
         rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
@@ -1317,384 +1280,6 @@ ZH_DEV uint32_t ze_dfast_flat4(uint64_t* seqs, const uint8_t* src, uint32_t srcS
 ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
 {
     return ze_dfast_flat_t<18, false>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle);
-}
-
-
-// ------------------------------------------------------------------------------------------ E1, flat form, the lane's own bytes from an LDS window (round 6)
-// ze_dfast_flat_np above spends the first of a trip's three dependent memory rounds re-reading the lane's OWN source bytes -- with 65 536 sources in flight
-// a line does not survive in the L2 from one trip to the next, so every 64-byte source line was fetched a dozen times -- and its match epilogue is three more
-// rounds (count, catch-up, the insertions' bytes), which the whole wave waits out on every trip because some lane of 64 always has a match. This form keeps
-// ZE_WIN_BYTES of every lane's source in LDS and arranges a trip as a per-lane state machine over at most THREE global rounds:
-//   (LDS)    the probes' own bytes w[k] from the window (three aligned dwords + v_alignbit each);
-//   round 1  the table cells, the repeat-offset candidates' bytes, the bytes of the pending "second repeat offset" test that follows a match
-//            (zstd.c:31236: made at the START of the next trip, speculatively beside that trip's cell reads -- if it hits, the trip becomes that match),
-//            and the window's next 32 bytes (consumed ~2.5 bytes a trip: mostly idle);
-//   round 2  the plausible candidates' bytes -- or, for a lane whose pending repeat test hit, the first 8 * NB bytes of that match's source in the same slots;
-//   round 3  (lanes with a match) 32 bytes of the match's source, the 8 bytes in front of it for the catch-up, and both again for the long match one position
-//            ahead that may replace a short one (zstd.c:31192) -- all at once; the lane's own side of every comparison comes from the window.
-// A lane whose window does not reach its probes yet (after a match longer than the window holds) spends one trip fetching and nothing else: its cost is its
-// own, not the wave's. Lanes whose probes spread wider than the window holds (steps > ~16: incompressible data, which is searched quickly anyway) and the
-// last 16 bytes of a source read memory directly as before. Decisions, table contents and sequences are ze_dfast_flat_np's -- the reference's.
-// Window: ZE_WIN_BYTES circular per lane + a mirror of its first ZE_WIN_MIRROR bytes behind it, so that reads of up to 36 bytes never wrap.
-#define ZE_WIN_BYTES 256u
-#define ZE_WIN_MIRROR 48u
-#define ZE_WIN_STRIDE (ZE_WIN_BYTES + ZE_WIN_MIRROR)
-#define ZE_WIN_AHEAD 128u
-struct __attribute__((aligned(16))) ZeWinLDS { uint8_t b[ZE_FLAT_LANES * ZE_WIN_STRIDE]; };      // 19 456 bytes per wave: eight waves per CU
-struct __attribute__((aligned(16))) zh_v16a { uint64_t lo, hi; };
-struct ZeWin { uint8_t* w; uint32_t lo, hi; };                          // this lane's window holds the source positions [lo, hi), both multiples of 16
-ZH_DEV bool ze_win_has(const ZeWin& W, uint32_t p, uint32_t n) { return p >= W.lo && p + n <= W.hi; }
-ZH_DEV uint64_t ze_win_ld64(const ZeWin& W, uint32_t p)
-{
-    const uint32_t o = p & (ZE_WIN_BYTES - 1u), s = (o & 3u) * 8u;
-    const uint32_t* d = (const uint32_t*)(W.w + (o & ~3u));
-    const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
-    return (uint64_t)zh_alignbit(d1, d0, s) | ((uint64_t)zh_alignbit(d2, d1, s) << 32);
-}
-ZH_DEV void ze_win_ld256(const ZeWin& W, uint32_t p, uint64_t* out)
-{
-    const uint32_t o = p & (ZE_WIN_BYTES - 1u), s = (o & 3u) * 8u;
-    const uint32_t* d = (const uint32_t*)(W.w + (o & ~3u));
-    uint32_t v[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) v[j] = d[j];
-#pragma unroll
-    for (int j = 0; j < 4; j++) out[j] = (uint64_t)zh_alignbit(v[2 * j + 1], v[2 * j], s) | ((uint64_t)zh_alignbit(v[2 * j + 2], v[2 * j + 1], s) << 32);
-}
-ZH_DEV void ze_win_put(const ZeWin& W, uint32_t p, const zh_v16& v)        // p a multiple of 16
-{
-    const uint32_t o = p & (ZE_WIN_BYTES - 1u);
-    zh_v16a t; t.lo = v.lo; t.hi = v.hi;
-    *(zh_v16a*)(W.w + o) = t;
-    *(zh_v16a*)(W.w + (o < ZE_WIN_MIRROR ? o + ZE_WIN_BYTES : o)) = t;
-}
-// first differing byte of two 32-byte strings (32: none)
-ZH_DEV uint32_t ze_cmp32(const uint64_t* a, const uint64_t* b)
-{
-    const uint64_t d0 = a[0] ^ b[0], d1 = a[1] ^ b[1], d2 = a[2] ^ b[2], d3 = a[3] ^ b[3];
-    if (d0) return (uint32_t)(zh_ctz64(d0) >> 3);
-    if (d1) return 8 + (uint32_t)(zh_ctz64(d1) >> 3);
-    if (d2) return 16 + (uint32_t)(zh_ctz64(d2) >> 3);
-    if (d3) return 24 + (uint32_t)(zh_ctz64(d3) >> 3);
-    return 32;
-}
-template <int PB, bool BLK, int NP>
-ZH_DEV uint32_t ze_dfast_flat_w(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep,
-                                const uint8_t* idle, uint8_t* winLane, unsigned long long* prof = nullptr)
-{
-    ZE_FT_DECL;
-    constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
-    constexpr int NB = NP + 1 < 4 ? NP + 1 : 4;                       // eight-byte pieces of a repeat match's source that ride in round 2's candidate slots
-#undef ZE_CELL_IDX
-#define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
-    const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
-    const int mls = mml <= 4 ? 4 : mml >= 7 ? 7 : mml;
-    const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
-    const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
-#define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))
-#define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))
-#define ZE_TL(ph) ((((ph) >> (shL - TB)) & TM) << PB)
-#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB)
-    // the lane's own bytes: from the window where it holds them, from memory otherwise (rare by construction: counted under emulation)
-#define ZE_OWN64(p) (ze_win_has(W, (p), 8) ? ze_win_ld64(W, (p)) : (ZE_RND(6), zh_ld64(src + (p))))
-    const uint32_t ilimit = be - 8, srcSize = be, hiMax = be & ~15u;
-    uint32_t ip = BLK ? bs + (bs == 0 ? 1u : 0u) : 1u, anchor = BLK ? bs : 0u, off1 = 1, off2 = 0, nseq = 0;
-    uint32_t saved1 = 0, saved2 = 0;
-    if (BLK) {                                                        // one block [bs, be) of a larger frame, repeat offsets in and out (as ze_dfast_flat_np)
-        off1 = rep[0]; off2 = rep[1];
-        if (off2 > ip) { saved2 = off2; off2 = 0; }
-        if (off1 > ip) { saved1 = off1; off1 = 0; }
-        if (be < bs + 8) { return 0; }
-    }
-    ZeWin W; W.w = winLane; W.lo = W.hi = ip & ~15u;
-    uint32_t step = 1, nextStep = 0, cellL0 = 0, pl0 = 0; uint64_t cl0 = 0;
-    bool fresh = true, chk = false;                                   // chk: the repeat-offset test that follows a match (zstd.c:31236) is still to be made at ip
-    // a match longer than round 3 (or, for a repeat match, round 2) covers is counted on over the following trips, 8 * NB bytes a trip, by ITS lane alone -- its
-    // own side from the window, which follows cA, the other side in round 2's candidate slots -- while the wave's other lanes go on probing: cont
-    bool cont = false, cMatch = false; uint32_t cA = 0, cB = 0, cML = 0, cLL = 0, cOff = 0, cPI = 0; uint64_t cWI = 0;
-    // what follows a match (zstd.c:31223-31233): the sequence, the four insertions, the repeat-offset test left to the next trip
-    auto finishMatch = [&](uint32_t offBase, uint32_t ll, uint32_t mLength, uint32_t ipEnd, uint32_t pI, uint64_t wI) {
-        seqs[nseq++] = ZE_SEQ_PACK(offBase, ll, mLength);
-        ip = ipEnd; anchor = ip;
-        if (ip <= ilimit) {
-            const uint64_t wE2 = ZE_OWN64(ip - 2), wE1 = ZE_OWN64(ip - 1);
-            const uint32_t qI = ZE_PL(wI), qE = ZE_PL(wE2);
-            hashLong[qI >> shL] = (pI + 2) | ZE_TL(qI);
-            hashLong[qE >> shL] = ip | ZE_TL(qE);
-            hashSmall[ZE_PS(wI) >> shS] = (pI + 2) | ZE_TS(wI);
-            hashSmall[ZE_PS(wE1) >> shS] = (ip + 1) | ZE_TS(wE1);
-            chk = true;                                                 // the repeat-offset test at ip rides on the next trip's round 1
-        }
-        fresh = true;
-    };
-    auto finishRep = [&](uint32_t r, uint32_t ipEnd) {
-        seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
-        ip = ipEnd; anchor = ip;
-        fresh = true; chk = ip <= ilimit;
-    };
-    ZE_TRIP_RESET;
-    for (;; ZE_TRIP_NEXT) {
-        if (fresh) { step = 1; nextStep = ip + 256; }
-        uint32_t pos[NP + 1], st[NP + 1], nx[NP + 1];
-        pos[0] = ip; st[0] = step; nx[0] = nextStep;
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            pos[k + 1] = pos[k] + st[k]; st[k + 1] = st[k]; nx[k + 1] = nx[k];
-            if (pos[k + 1] >= nx[k]) { st[k + 1]++; nx[k + 1] += 256; }
-        }
-        // R = the probes of this trip that are real if all before them fail (probe k needs pos[k + 1] <= ilimit); none when only the pending repeat test is left
-        uint32_t R = 0;
-        if (pos[1] <= ilimit) {
-            R = 1;
-#pragma unroll
-            for (int k = 1; k < NP; k++) if (R == (uint32_t)k && pos[k + 1] <= ilimit) R = (uint32_t)k + 1;
-        } else if (!cont && !(chk && ip <= ilimit)) break;
-        ZE_STAT(10); ZE_FT_TRIP; ZE_FT(6);
-        // q: where the trip's own bytes are read (a lane that is counting a long match on: the next 8 * NB bytes of its side of the match)
-        uint32_t q[NP + 1];
-#pragma unroll
-        for (int k = 0; k <= NP; k++) q[k] = cont ? cA + (k < NB ? 8u * k : 0u) : pos[k] <= ilimit ? pos[k] : ilimit;
-        // ---- the window: where the probes' bytes come from this trip
-        if (q[0] < W.lo || q[0] >= W.hi) W.lo = W.hi = q[0] & ~15u;                  // left behind by a long match: it starts again here
-        uint32_t need = cont ? cA + 8u * NB : q[NP] + 9; if (need > be) need = be;   // (+ 1: the insertion at probe position + 2 reads one byte further)
-        const bool glob = need - q[0] > 80u || need > hiMax;                         // wide steps / the source's last bytes: straight from memory, as before
-        const bool stall = !glob && need > W.hi;                                     // not here yet: this trip only fetches
-        const bool live = !stall;
-        const bool want0 = W.hi < q[0] + ZE_WIN_AHEAD && W.hi + 16 <= be, want1 = want0 && W.hi + 32 <= be;
-        uint64_t w[NP + 1];
-        if (glob) {
-            ZE_RND(0);
-#pragma unroll
-            for (int k = 0; k <= NP; k++) w[k] = zh_ld64(src + q[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k <= NP; k++) w[k] = ze_win_ld64(W, q[k]);
-        }
-        uint64_t A[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) A[k] = w[k];
-        if (stall || cont) {
-            if (stall) ZE_RND(8);
-#pragma unroll
-            for (int k = 0; k <= NP; k++) w[k] = 0;                                  // (its table reads share one line)
-        }
-        uint32_t pL[NP + 1], hl[NP + 1], hs[NP];
-#pragma unroll
-        for (int k = 0; k <= NP; k++) { pL[k] = ZE_PL(w[k]); hl[k] = pL[k] >> shL; }
-#pragma unroll
-        for (int k = 0; k < NP; k++) hs[k] = ZE_PS(w[k]) >> shS;
-        // ---- round 1
-        ZE_RND(1);
-        uint32_t cL[NP + 1], cS[NP], newL[NP + 1], newS[NP], rp[NP];
-        uint32_t tA = hashLong[fresh ? hl[0] : hl[1]];
-#pragma unroll
-        for (int k = 0; k < NP; k++) cS[k] = hashSmall[hs[k]];
-#pragma unroll
-        for (int k = 1; k <= NP; k++) cL[k] = hashLong[hl[k]];
-#pragma unroll
-        for (int k = 0; k < NP; k++) rp[k] = zh_ld32(src + q[k] + 1 - off1);
-        uint32_t r2 = zh_ld32((chk && off2 > 0) ? src + q[0] - off2 : idle);
-        zh_v16 pf0 = zh_ld128(want0 ? src + W.hi : idle), pf1 = zh_ld128(want1 ? src + W.hi + 16 : idle);
-        ZE_FT(0);
-        tA = zh_opaque(tA); r2 = zh_opaque(r2);                                    // the round's loads are issued together: none sinks to where it is used
-#pragma unroll
-        for (int k = 0; k < NP; k++) { cS[k] = zh_opaque(cS[k]); rp[k] = zh_opaque(rp[k]); }
-#pragma unroll
-        for (int k = 1; k <= NP; k++) cL[k] = zh_opaque(cL[k]);
-        pf0.lo = zh_opaque64(pf0.lo); pf0.hi = zh_opaque64(pf0.hi); pf1.lo = zh_opaque64(pf1.lo); pf1.hi = zh_opaque64(pf1.hi);
-        ZE_FT(1);
-        if (want0) {
-            ze_win_put(W, W.hi, pf0); W.hi += 16;
-            if (want1) { ze_win_put(W, W.hi, pf1); W.hi += 16; }
-            if (W.hi - W.lo > ZE_WIN_BYTES) W.lo = W.hi - ZE_WIN_BYTES;
-        }
-        if (stall) continue;                                                       // (nothing of the search's state was touched)
-        const bool repHit = !cont && chk && off2 > 0 && (uint32_t)w[0] == r2;      // the pending test (zstd.c:31236-31250)
-        chk = false;
-        if (fresh) cellL0 = tA;
-        cL[0] = cellL0;
-#pragma unroll
-        for (int k = 0; k <= NP; k++) newL[k] = (pos[k] + 2) | ZE_TL(pL[k]);
-#pragma unroll
-        for (int k = 0; k < NP; k++) newS[k] = (pos[k] + 2) | ZE_TS(w[k]);
-        // what the reference's later reads see after its earlier writes of this trip (zstd.c:31121 then :31163): the latest earlier probe with the same cell wins
-#pragma unroll
-        for (int k = 1; k <= NP; k++) {
-#pragma unroll
-            for (int j = 0; j < k; j++) {
-                if (hl[k] == hl[j]) cL[k] = newL[j];
-                if (k < NP && hs[k < NP ? k : 0] == hs[j]) cS[k < NP ? k : 0] = newS[j];
-            }
-        }
-        const bool probing = R >= 1 && !repHit && !cont;
-        if ((R >= 1 || repHit) && !cont) { hashLong[hl[0]] = newL[0]; hashSmall[hs[0]] = newS[0]; }      // (a repeat match at ip inserts ip into both tables too: the same two cells)
-        uint32_t idxl[NP + 1], idxs[NP], pl[NP + 1]; bool psv[NP];
-#pragma unroll
-        for (int k = 0; k <= NP; k++) { idxl[k] = ZE_CELL_IDX(cL[k]); pl[k] = (probing && idxl[k] >= 2 && (cL[k] >> PB) == (ZE_TL(pL[k]) >> PB)) ? 1u : 0u; }
-#pragma unroll
-        for (int k = 0; k < NP; k++) { idxs[k] = ZE_CELL_IDX(cS[k]); psv[k] = probing && idxs[k] >= 2 && (cS[k] >> PB) == (ZE_TS(w[k]) >> PB); }
-        if (!fresh) pl[0] = pl0;
-        // ---- round 2: the bytes of the plausible candidates (the others read one address the whole wave shares); a lane whose repeat test hit reads that match's source
-        ZE_RND(2);
-        const bool repFast = repHit && ip + 4 + 8 * NB <= srcSize;
-        uint64_t xl[NP + 1]; uint32_t cs[NP];
-#pragma unroll
-        for (int k = 0; k <= NP; k++)
-            xl[k] = zh_ld64(cont ? (k < NB ? src + (cB + 8 * k) : idle) : repHit ? ((repFast && k < NB) ? src + (ip + 4 - off2 + 8 * k) : idle) : (pl[k] && (k > 0 || fresh)) ? src + (idxl[k] - 2) : idle);
-#pragma unroll
-        for (int k = 0; k < NP; k++) cs[k] = zh_ld32(psv[k] ? src + (idxs[k] - 2) : idle);
-        ZE_FT(2);
-#pragma unroll
-        for (int k = 0; k <= NP; k++) xl[k] = zh_opaque64(xl[k]);                 // no load sinks into a branch
-#pragma unroll
-        for (int k = 0; k < NP; k++) cs[k] = zh_opaque(cs[k]);
-        ZE_FT(3);
-        if (cont) {                                                                // 8 * NB more bytes of a long match
-            uint32_t c = 0; bool open = true;
-#pragma unroll
-            for (int k = 0; k < NB; k++) if (open) {
-                const uint64_t d = A[k] ^ xl[k];
-                if (d) { c += (uint32_t)(zh_ctz64(d) >> 3); open = false; } else c += 8;
-            }
-            if (open && cA + 16u * NB <= srcSize) { cA += 8u * NB; cB += 8u * NB; cML += 8u * NB; continue; }
-            if (open) c += ze_count_fwd(src, cA + 8u * NB, cB + 8u * NB, srcSize);   // (the source's last bytes)
-            cont = false;
-            if (cMatch) finishMatch(cOff, cLL, cML + c, cA + c, cPI, cWI); else finishRep(cML + c, cA + c);
-            continue;
-        }
-        if (repHit) {
-            ZE_STAT(14);
-            uint32_t len = 0; bool on = false;
-            if (repFast) {
-                bool open = true;
-#pragma unroll
-                for (int k = 0; k < NB; k++) if (open) {
-                    const uint64_t d = ZE_OWN64(ip + 4 + 8 * k) ^ xl[k];
-                    if (d) { len += (uint32_t)(zh_ctz64(d) >> 3); open = false; } else len += 8;
-                }
-                if (open) {
-                    if (ip + 4 + 16u * NB <= srcSize) on = true;
-                    else len += ze_count_fwd(src, ip + 4 + 8 * NB, ip + 4 - off2 + 8 * NB, srcSize);
-                }
-            } else { len = ze_count_fwd(src, ip + 4, ip + 4 - off2, srcSize); }
-            if (on) { cont = true; cMatch = false; cA = ip + 4 + 8u * NB; cB = ip + 4 - off2 + 8u * NB; cML = 4 + 8u * NB; }
-            const uint32_t t = off2; off2 = off1; off1 = t;
-            if (!on) finishRep(len + 4, ip + len + 4);
-            continue;
-        }
-        if (R == 0) break;                                                         // the last position's repeat test failed: the search is over
-        if (!fresh) xl[0] = cl0;
-        int fnd[NP];
-#pragma unroll
-        for (int k = 0; k < NP; k++)
-            fnd[k] = (off1 > 0 && rp[k] == (uint32_t)(w[k] >> 8)) ? 1 : (pl[k] && xl[k] == w[k]) ? 2 : (psv[k] && cs[k] == (uint32_t)w[k]) ? 3 : 0;
-        uint32_t P = NP; int found = 0;                                            // the first real probe that matched
-#pragma unroll
-        for (int k = NP - 1; k >= 0; k--) if ((uint32_t)k < R && fnd[k]) { P = (uint32_t)k; found = fnd[k]; }
-        // the table writes of the probes that really happened: 1 .. P (a match at P) or 1 .. R - 1 (none), in the reference's order
-#pragma unroll
-        for (int k = 1; k < NP; k++) if ((uint32_t)k <= P && (uint32_t)k < R) { hashLong[hl[k]] = newL[k]; hashSmall[hs[k]] = newS[k]; }
-        if (found) {
-            ZE_STAT(11);
-            uint32_t ipP = pos[0], ipP1 = pos[1], stepP = st[0], idxlP = idxl[0], idxsP = idxs[0], idxl1 = idxl[1], pl1 = pl[1], hl1 = hl[1], newL1 = newL[1];
-            uint64_t w1 = w[1], cl1 = xl[1];
-#pragma unroll
-            for (int k = 1; k < NP; k++) if (P == (uint32_t)k) { ipP = pos[k]; ipP1 = pos[k + 1]; stepP = st[k]; idxlP = idxl[k]; idxsP = idxs[k]; idxl1 = idxl[k + 1]; pl1 = pl[k + 1]; hl1 = hl[k + 1]; newL1 = newL[k + 1]; w1 = w[k + 1]; cl1 = xl[k + 1]; }
-            uint32_t ipm = ipP, mpos = 0, ca, cb, add;
-            if (found == 1) { ipm = ipP + 1; ca = ipP + 5; cb = ipP + 5 - off1; add = 4; }
-            else if (found == 2) { mpos = idxlP - 2; ca = ipP + 8; cb = mpos + 8; add = 8; }
-            else { mpos = idxsP - 2; ca = ipP + 4; cb = mpos + 4; add = 4; }
-            // ---- round 3: 32 bytes of the match's source behind what was compared, the 8 bytes in front of it (catch-up), and both for the long match one
-            // position ahead that beats a shorter short match (zstd.c:31192-31201) -- everything at once, the lane's own side from the window
-            ZE_RND(3);
-            const bool two = found == 3 && pl1 && idxl1 > 2 && cl1 == w1;
-            const uint32_t m1 = two ? idxl1 - 2 : 0u;
-            const bool f0 = ca + 32 <= srcSize, f1 = two && ipP1 + 40 <= srcSize;
-            const bool cu0 = found >= 2 && mpos >= 8, cu1 = two && m1 >= 8;
-            zh_v16 b0 = zh_ld128(f0 ? src + cb : idle), b1 = zh_ld128(f0 ? src + cb + 16 : idle);
-            zh_v16 e0 = zh_ld128(f1 ? src + m1 + 8 : idle), e1 = zh_ld128(f1 ? src + m1 + 24 : idle);
-            uint64_t pb = zh_ld64(cu0 ? src + mpos - 8 : idle), pe = zh_ld64(cu1 ? src + m1 - 8 : idle);
-            ZE_FT(4);
-            b0.lo = zh_opaque64(b0.lo); b0.hi = zh_opaque64(b0.hi); b1.lo = zh_opaque64(b1.lo); b1.hi = zh_opaque64(b1.hi);
-            e0.lo = zh_opaque64(e0.lo); e0.hi = zh_opaque64(e0.hi); e1.lo = zh_opaque64(e1.lo); e1.hi = zh_opaque64(e1.hi);
-            pb = zh_opaque64(pb); pe = zh_opaque64(pe);
-            ZE_FT(5);
-            uint32_t mLength = add; bool on = false;
-            if (f0) {
-                uint64_t M[4]; const uint64_t B[4] = { b0.lo, b0.hi, b1.lo, b1.hi };
-                if (ze_win_has(W, ca, 32)) ze_win_ld256(W, ca, M);
-                else { ZE_RND(6); const zh_v16 a0 = zh_ld128(src + ca), a1 = zh_ld128(src + ca + 16); M[0] = a0.lo; M[1] = a0.hi; M[2] = a1.lo; M[3] = a1.hi; }
-                const uint32_t c = ze_cmp32(M, B);
-                mLength += c;
-                if (c == 32) {
-                    if (!two && ca + 32 + 8u * NB <= srcSize) on = true;            // counted on over the next trips
-                    else mLength += ze_count_fwd(src, ca + 32, cb + 32, srcSize);
-                }
-            } else { mLength += ze_count_fwd(src, ca, cb, srcSize); }
-            uint64_t pa = cu0 ? ZE_OWN64(ipP - 8) : 0;                              // (mpos >= 8 and the match lies before ipP: ipP - 8 >= 0)
-            if (two) {
-                uint32_t l1 = 8;
-                if (f1) {
-                    uint64_t M[4]; const uint64_t B[4] = { e0.lo, e0.hi, e1.lo, e1.hi };
-                    if (ze_win_has(W, ipP1 + 8, 32)) ze_win_ld256(W, ipP1 + 8, M);
-                    else { ZE_RND(6); const zh_v16 a0 = zh_ld128(src + ipP1 + 8), a1 = zh_ld128(src + ipP1 + 24); M[0] = a0.lo; M[1] = a0.hi; M[2] = a1.lo; M[3] = a1.hi; }
-                    const uint32_t c = ze_cmp32(M, B);
-                    l1 += c;
-                    if (c == 32) { l1 += ze_count_fwd(src, ipP1 + 40, m1 + 40, srcSize); }
-                } else { l1 += ze_count_fwd(src, ipP1 + 8, m1 + 8, srcSize); }
-                if (l1 > mLength) { ipm = ipP1; mLength = l1; mpos = m1; pb = pe; pa = cu1 ? ZE_OWN64(ipP1 - 8) : 0; }
-            }
-            uint32_t offBase = 1;
-            if (found >= 2) {
-                const uint32_t offset = ipm - mpos;
-                bool first = true;
-                while (ipm > anchor && mpos > 0) {                      // catch up (zstd.c:31182, :31204), 8 bytes a round, the first from round 3
-                    ZE_STAT(13);
-                    const uint32_t room = ipm - anchor < mpos ? ipm - anchor : mpos;
-                    if (mpos >= 8) {
-                        uint64_t d;
-                        if (first) d = pa ^ pb;
-                        else { ZE_RND(5); d = zh_ld64(src + ipm - 8) ^ zh_ld64(src + mpos - 8); }
-                        first = false;
-                        uint32_t k = d ? (uint32_t)(zh_clz64(d) >> 3) : 8u;
-                        if (k > room) k = room;
-                        ipm -= k; mpos -= k; mLength += k;
-                        if (k < 8) break;
-                    } else {
-                        ZE_RND(5);
-                        first = false;
-                        if (src[ipm - 1] != src[mpos - 1]) break;
-                        ipm--; mpos--; mLength++;
-                    }
-                }
-                off2 = off1; off1 = offset;
-                if (stepP < 4) hashLong[hl1] = newL1;
-                offBase = offset + 3;
-            }
-            const uint32_t pI = ipP + 2;
-            const uint64_t wI = pI + 8 <= srcSize ? ZE_OWN64(pI) : 0;   // (read before the window moves on; beyond the source only when no insertion follows: ip >= ipP + 4)
-            if (on) { cont = true; cMatch = true; cA = ca + 32; cB = cb + 32; cML = mLength; cLL = ipm - anchor; cOff = offBase; cPI = pI; cWI = wI; fresh = true; }
-            else finishMatch(offBase, ipm - anchor, mLength, ipm + mLength, pI, wI);
-        } else {                                                        // every real probe failed: go on from pos[R] with its long cell and candidate in hand
-            ip = pos[1]; step = st[1]; nextStep = nx[1]; cellL0 = cL[1]; pl0 = pl[1]; cl0 = xl[1];
-#pragma unroll
-            for (int k = 2; k <= NP; k++) if (R == (uint32_t)k) { ip = pos[k]; step = st[k]; nextStep = nx[k]; cellL0 = cL[k]; pl0 = pl[k]; cl0 = xl[k]; }
-            fresh = false;
-        }
-    }
-#undef ZE_OWN64
-#undef ZE_PL
-#undef ZE_PS
-#undef ZE_TL
-#undef ZE_TS
-#undef ZE_CELL_IDX
-#define ZE_CELL_IDX(c) ((c) & 0x3FFFFu)
-    ZE_FT_END(prof);
-    if (BLK) {                                                        // zstd.c:31252-31258
-        saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
-        rep[0] = off1 ? off1 : saved1; rep[1] = off2 ? off2 : saved2;
-    }
-    return nseq;
 }
 
 
@@ -3383,9 +2968,8 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
 
 // E1 flat: one lane per frame, statically assigned, every frame of the chunk in flight (ze_dfast_flat). Frames it does not cover are
 // listed for the lane-serial kernel above (chunk-local index) or, above one block, for the generic kernel.
-// win: the wave's ZeWinLDS (every lane's window of its own source bytes, ze_dfast_flat_w), or nullptr: the form of rounds 1-5 that re-reads them from memory
 template <int NPROBE = 2>
-ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a, uint8_t* win = nullptr)
+ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
 {
     const uint32_t lane = zh_lane();
     const uint32_t i = zh_block() * ZE_FLAT_LANES + lane;
@@ -3432,8 +3016,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a, uint8_t* win = nullptr
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
-                   : win ? ze_dfast_flat_w<18, false, NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, 0, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, nullptr, a.idle ? a.idle : src, win + lane * ZE_WIN_STRIDE, a.prof)
-                   : NPROBE > 2 ? ze_dfast_flat_np<18, false, NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, 0, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, nullptr, a.idle ? a.idle : src, a.prof)
+                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle)
                                  : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
     m.mode = 4;
 #ifdef ZHIP_EMU

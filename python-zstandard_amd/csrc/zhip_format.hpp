@@ -293,8 +293,9 @@ struct ZhipPipeArgs {
     ZpFrameRec* frameRecs;      // count
     uint64_t maxWindowSize;
     uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
-    uint32_t k1Lanes;           // > 1 (dictionary batches, round 6): K1's waves take this many frames at a time and a LANE walks a frame whose tables are all the
-                                // dictionary's ("treeless" literals, every sequence table "repeat": nothing to build); what a lane cannot finish the wave does as before
+    uint32_t k1Lanes;           // != 0 (dictionary batches, round 6): zhip_decode_lit_lanes_kernel ran first -- a LANE walked every frame whose tables are all the
+                                // dictionary's ("treeless" literals, every sequence table "repeat": nothing to build) -- and K1 takes only the frames it listed in `order`
+                                // (counters[10] of them; counters[9] is that kernel's work counter)
     unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases
     // dictionary (all null / 0 without one): id, raw content (match sources before the frame's first byte), parsed entropy section, its tables
     uint32_t dictID, dictContentSize;

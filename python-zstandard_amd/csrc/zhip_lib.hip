@@ -33,6 +33,7 @@ ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_kernel(ZhipPipeArgs a)
     __shared__ ZdLDS L;
     zp_lit_body(a, L);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_lit_lanes_kernel(ZhipPipeArgs a) { zp_lit_lanes_body(a); }      // K1's lane-per-frame pass over dictionary batches
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_bin_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpBinLDS L;
@@ -103,15 +104,10 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a) 
     __shared__ ZeLDS L;
     ze_split_body(a, L);
 }
-// the flat search: every lane's own source bytes come from its LDS window (ze_dfast_flat_w, round 6; 19 KiB per wave, eight waves per CU)
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<2>(a, W.b); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
 // four probes per trip: chunks small enough to be bound by a source's serial chain rather than by the memory system (ze_dfast_flat_np)
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<4>(a, W.b); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_kernel(ZhipEncodeArgs a) { __shared__ ZeWinLDS W; ze_match_flat_body<3>(a, W.b); }      // three probes: launches of up to 65 536 sources
-// (A/B: rounds 1-5's form, which re-reads the lane's own bytes from memory every trip -- ZHIP_E1F_WIN=0)
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
-ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_nw_kernel(ZhipEncodeArgs a) { ze_match_flat_body<3>(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat3_kernel(ZhipEncodeArgs a) { ze_match_flat_body<3>(a); }      // three probes: launches of up to 65 536 sources
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_mb_kernel(ZhipEncodeArgs a) { ze_match_flat_mb_body(a); }
 static_assert(sizeof(ZeSrcLDS<ZF_BLOCK_MAX>) <= ZHIP_LDS_BYTES, "a workgroup's LDS must fit a CU");
 template <uint32_t BYTES, int NPROBE> __global__ __launch_bounds__(64) void zhip_encode_match_lds_kernel(ZhipEncodeArgs a)
@@ -347,7 +343,6 @@ struct zhip_ctx {
         // probes per trip of the flat double-fast search by launch size: up to flat4Max sources four (bound by one source's serial chain: 21-25 % less time from
         // 1 024 to 32 768 sources, r04zd), up to flat3Max three, above two (with the placement picked, at 65 536: 421 / 415 / 425 ms for two / three / four, r05w)
         size_t flat4Max = 32768, flat3Max = 65536; bool flat3 = true;
-        bool e1fWin = false;                // ZHIP_E1F_WIN=0: the flat search of rounds 1-5 (own bytes re-read from memory every trip) -- A/B of round 6's LDS window
         bool e1fPick = true;                // ZHIP_E1F_PICK=0: take the flat tables where the first allocation put them (zhip_compress_batch_device)
         // host-buffer pipeline
         size_t hchunkE = 32768, hchunkE0 = 0;   // compress: items per chunk, items of the first chunk (0: like the others)
@@ -398,7 +393,6 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
         if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
-        if (const char* e = getenv("ZHIP_E1F_WIN")) k.e1fWin = atol(e) != 0;
         if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
         if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
         if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
@@ -753,12 +747,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             if (c->knob.k1PerCU) g1m = (size_t)c->numCU * (size_t)c->knob.k1PerCU;
             // K2 and K1b are sized by LDS: as many one-wave workgroups per CU as their table sets fit (K2: 15 frames per wave -> 4)
             const size_t w2 = (items + ZQ_FRAMES - 1) / ZQ_FRAMES, g2m = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpSeqQLDS));
-            // dictionary batches: K1's waves take several frames at a time, a lane each where nothing has to be built (zp_lit_shared_try) -- as many as keep every
-            // resident wave supplied with a task (what a lane cannot finish its wave does one frame after the other: a task is never longer than the share of
-            // frames a wave had before)
-            pa.k1Lanes = 0;
-            if (!mb && c->dictHasEntropy) { uint32_t t = 1; while (t < 64 && (size_t)t * 2 * g1m <= cnt) t *= 2; pa.k1Lanes = t; }
-            const size_t tasks1 = pa.k1Lanes > 1 ? (cnt + pa.k1Lanes - 1) / pa.k1Lanes : cnt;
+            // dictionary batches: a lane-per-frame pass first (zhip_decode_lit_lanes_kernel: frames whose tables are all the dictionary's are nothing but header
+            // arithmetic), K1 then only over the frames that pass listed
+            pa.k1Lanes = !mb && c->dictHasEntropy ? 1u : 0u;
+            const size_t tasks1 = cnt;
             const uint32_t g1 = (uint32_t)(tasks1 < g1m ? tasks1 : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
             const uint32_t gh = (uint32_t)(wh < ghm ? wh : ghm);
@@ -770,7 +762,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 HIP_TRY(hipEventRecord(ev[0], ss));
             }
             if (mb) hipLaunchKernelGGL(zhip_decode_lit_mb_kernel, dim3(g1), dim3(64), 0, ss, pa);
-            else hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            else {
+                if (pa.k1Lanes) { const size_t w = (cnt + 63) / 64; hipLaunchKernelGGL(zhip_decode_lit_lanes_kernel, dim3((uint32_t)(w < g1m ? w : g1m)), dim3(64), 0, ss, pa); }
+                hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
+            }
             hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2 * (items < 4096 ? 1u : 64u)), dim3(64), 0, ss, pa);      // tiny; timed with K1
             if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
             hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
@@ -899,18 +894,12 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     return 0;
 }
 // the flat match kernel at `probes` per trip over `cnt` sources
-static void launch_flat(zhip_ctx* c, int probes, size_t cnt, hipStream_t stream, const ZhipEncodeArgs& a)
+static void launch_flat(int probes, size_t cnt, hipStream_t stream, const ZhipEncodeArgs& a)
 {
     const dim3 g((uint32_t)((cnt + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES)), b(64);
-    if (c->knob.e1fWin) {
-        if (probes == 4) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, g, b, 0, stream, a);
-        else if (probes == 3) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, g, b, 0, stream, a);
-        else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, g, b, 0, stream, a);
-    } else {
-        if (probes == 4) hipLaunchKernelGGL(zhip_encode_match_flat4_nw_kernel, g, b, 0, stream, a);
-        else if (probes == 3) hipLaunchKernelGGL(zhip_encode_match_flat3_nw_kernel, g, b, 0, stream, a);
-        else hipLaunchKernelGGL(zhip_encode_match_flat_nw_kernel, g, b, 0, stream, a);
-    }
+    if (probes == 4) hipLaunchKernelGGL(zhip_encode_match_flat4_kernel, g, b, 0, stream, a);
+    else if (probes == 3) hipLaunchKernelGGL(zhip_encode_match_flat3_kernel, g, b, 0, stream, a);
+    else hipLaunchKernelGGL(zhip_encode_match_flat_kernel, g, b, 0, stream, a);
 }
 extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const zhip_segment* d_srcSegs, size_t n,
                                           void* d_dst, const zhip_segment* d_dstSegs, uint64_t* d_outSizes,
@@ -1098,7 +1087,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
                     if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: the kernel's waves zero what they use)
                     HIP_TRY(hipEventRecord(e0, stream));
-                    launch_flat(c, !flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
+                    launch_flat(!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
                     HIP_TRY(hipEventSynchronize(e1));
                     HIP_TRY(hipEventElapsedTime(ms, e0, e1));
@@ -1124,8 +1113,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
-            if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 32 * 8));
-            HIP_TRY(hipMemsetAsync(c->profEncode, 0, 32 * 8, stream));
+            if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
+            HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
             a.prof = c->profEncode;
         }
         for (size_t first = 0; first < n; first += chunk) {
@@ -1154,7 +1143,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
                     else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
                 }
-                else launch_flat(c, !flatDict && !mbc && cnt <= c->knob.flat4Max ? 4 : !flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max ? 3 : 2, cnt, stream, a);
+                else launch_flat(!flatDict && !mbc && cnt <= c->knob.flat4Max ? 4 : !flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max ? 3 : 2, cnt, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
                 if (tm) HIP_TRY(hipEventRecord(ev[1], stream));
             }
@@ -1180,13 +1169,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         }
         if (a.prof) {
             HIP_TRY(hipStreamSynchronize(stream));
-            unsigned long long h[32];
+            unsigned long long h[16];
             HIP_TRY(hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
-            if (h[16 + 7]) {       // -DZE_PROF_FLAT builds: the flat search's phases (lane 0 of every wave), cycles per trip
-                static const char* fn[7] = {"own bytes + hashing", "round 1 wait", "window / forwarding / round 2 issue", "round 2 wait", "decisions (+ count: old form)", "round 3 wait (old: catch-up)", "match epilogue + loop"};
-                fprintf(stderr, "[zhip-prof] flat search: %llu trips of lane 0 over all waves\n", h[16 + 7]);
-                for (int q = 0; q < 7; q++) fprintf(stderr, "[zhip-prof]    %-38s %8.0f cyc/trip\n", fn[q], (double)h[16 + q] / (double)h[16 + 7]);
-            }
             static const char* nm[12] = {"gather literals", "literal stats+decide", "huffman build+table", "huffman encode", "sequence stats", "sequence tables", "sequence stream", "frame assembly",
                                           "  stream: constants", "  stream: state chains", "  stream: pack + OR", "  stream: flush"};      // (the last four: -DZE_PROF_STREAM builds only)
             unsigned long long tot = 0; for (int q = 0; q <= ZEP_REST; q++) tot += h[q];

@@ -124,7 +124,8 @@ extern "C" int emu_compress_batch(const uint8_t* src, const uint64_t* srcSegs, u
 static ZpExecLDS g_xlds;
 static ZpBinLDS g_binlds;
 static uint32_t g_llBase[36], g_mlBase[53]; static uint8_t g_llBits[36], g_mlBits[56];
-static uint32_t g_k1Lanes = 16;                  // K1 of dictionary batches: frames per task, a lane each where nothing has to be built (0 / 1: a wave per frame, rounds 1-5)
+static uint32_t g_k1Lanes = 1;                   // dictionary batches: K1's lane-per-frame pass first (zp_lit_lanes_body), K1 over what it listed (0: a wave per frame, rounds 1-5)
+static void k1lanes_lane(void* p) { zp_lit_lanes_body(*(const ZhipPipeArgs*)p); }
 extern "C" void emu_set_k1_lanes(uint32_t v) { g_k1Lanes = v; }
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
 static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
@@ -191,17 +192,19 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
               memset(a.itemFrame, 0xA5, slots * 4); memset(a.itemReps, 0xA5, slots * 16); memset(a.frameRecs, 0xA5, (size_t)chunk * sizeof(ZpFrameRec)); }
     a.counters = counters; a.fallbackCount = &counters[ZP_CNT_WORDS]; a.fallbackList = (uint32_t*)calloc(n ? n : 1, 4);
     a.maxWindowSize = (1ull << 27) + 1; a.magicless = g_magicless;
-    a.k1Lanes = g_k1Lanes;                       // (the product sets it for dictionary batches: zhip_decompress_batch_device)
     if (g_ddHas) {
         const uint32_t co = g_ddEnt ? g_ddEntropy.contentOffset : 0u;
         a.dictID = g_ddEnt ? g_ddEntropy.dictID : 0u; a.dictContent = g_ddBlob.data() + co; a.dictContentSize = (uint32_t)(g_ddBlob.size() - 64) - co;
         a.dictEntropy = g_ddEnt ? &g_ddEntropy : nullptr; a.dictTables = g_ddEnt ? &g_ddTables : nullptr;
     }
+    a.k1Lanes = g_k1Lanes && a.dictEntropy ? 1u : 0u;       // (mirrors zhip_decompress_batch_device; cleared below in the several-block mode)
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (uint32_t q = 0; q < ZP_CNT_WORDS; q++) counters[q] = 0;
         memset(&g_lds, 0xA5, sizeof g_lds); memset(&g_xlds, 0xA5, sizeof g_xlds); memset(&g_binlds, 0xA5, sizeof g_binlds);   // LDS is not zeroed on hardware
         a.itemCap = mb ? a.count * g_mbPerFrame : 0u;
+        if (mb) a.k1Lanes = 0;
+        if (a.k1Lanes) zhemu::run_grid(nBlocks, k1lanes_lane, &a);
         zhemu::run_grid(nBlocks, mb ? k1mb_lane : k1_lane, &a);
         zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
@@ -230,57 +233,7 @@ static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_probes = 2;                   // probes per trip of the flat search (2, or 4: the latency-bound batches' form)
 extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
-static uint32_t g_e1fWin = 1;                   // the flat search reads the lanes' own bytes from LDS windows (ze_dfast_flat_w, the product's default); 0: rounds 1-5's form
-extern "C" void emu_set_e1f_window(uint32_t v) { g_e1fWin = v; }
-static ZeWinLDS g_winlds;
-static void e1f_lane(void* p)
-{
-    uint8_t* win = g_e1fWin ? g_winlds.b : nullptr;
-    if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p, win); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p, win); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p, win);
-}
-// ---- the flat searches' round log (ZE_RND): per wave and trip, for every kind of dependent memory round, the most any lane needed
-#include <vector>
-static bool g_rndOn = false;
-static uint32_t g_rndTrip[64];
-static std::vector<std::vector<uint8_t>> g_rndLog;          // [block][(trip * 9 + kind) * 64 + lane]
-extern "C" void ze_emu_trip(uint32_t block, uint32_t lane, int reset) { (void)block; if (reset) g_rndTrip[lane & 63] = 0; else g_rndTrip[lane & 63]++; }
-extern "C" void ze_emu_rnd(uint32_t block, uint32_t lane, uint32_t kind)
-{
-    if (!g_rndOn || kind >= 9) return;
-    if (g_rndLog.size() <= block) g_rndLog.resize(block + 1);
-    std::vector<uint8_t>& v = g_rndLog[block];
-    const size_t at = ((size_t)g_rndTrip[lane & 63] * 9 + kind) * 64 + (lane & 63);
-    if (v.size() <= at) v.resize((at + 64 * 9 * 4096) & ~(size_t)63, 0);
-    if (v[at] < 255) v[at]++;
-}
-// trips of every lane of wave `block` (the last trip on which it logged a round, + 1)
-extern "C" void emu_rnd_lane_trips(uint32_t block, uint32_t* out64)
-{
-    for (int l = 0; l < 64; l++) out64[l] = 0;
-    if (block >= g_rndLog.size()) return;
-    const std::vector<uint8_t>& v = g_rndLog[block];
-    const size_t trips = v.size() / (9 * 64);
-    for (size_t t = 0; t < trips; t++) for (int k = 0; k < 9; k++) for (int l = 0; l < 64; l++) if (v[(t * 9 + k) * 64 + l]) out64[l] = (uint32_t)t + 1;
-}
-extern "C" void emu_rnd_log(int on) { g_rndOn = on != 0; g_rndLog.clear(); }
-// out[0..8]: per kind, the rounds the waves paid (sum over trips of the per-trip maximum over lanes); out[9]: trips (of the slowest lane); out[10..18]: per kind, the
-// LANE-trips that needed it (sum over lanes); out[19]: lane-trips
-extern "C" void emu_rnd_report(uint64_t* out)
-{
-    for (int i = 0; i < 20; i++) out[i] = 0;
-    for (const std::vector<uint8_t>& v : g_rndLog) {
-        const size_t trips = v.size() / (9 * 64);
-        for (size_t t = 0; t < trips; t++) {
-            bool any = false; uint64_t lanes = 0;
-            for (int k = 0; k < 9; k++) {
-                uint32_t mx = 0;
-                for (int l = 0; l < 64; l++) { const uint8_t c = v[(t * 9 + k) * 64 + l]; if (c > mx) mx = c; if (c) { out[10 + k]++; lanes |= 1ull << l; } }
-                out[k] += mx; any |= mx != 0;
-            }
-            if (any) { out[9]++; out[19] += (uint64_t)__builtin_popcountll(lanes); }
-        }
-    }
-}
+static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
 static void e1fmb_lane(void* p) { ze_match_flat_mb_body(*(const ZhipEncodeArgs*)p); }
 static void split_lane(void* p) { ze_split_body(*(const ZhipEncodeArgs*)p, g_elds); }
 static uint32_t g_mbCompress = 1;               // sources of several blocks in the flat match kernel: 0 off, 1 on, > 1 on with that many block slots per frame
@@ -348,7 +301,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
-            else { memset(&g_winlds, 0xA5, sizeof g_winlds); zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a); }
+            else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
             if (mbc) { a.mbLanes = 16; a.mbProbes = g_probes; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);

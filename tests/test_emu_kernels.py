@@ -742,9 +742,9 @@ def test_sources_of_several_blocks_in_the_flat_search(emu, ref, corpus):
 def test_k1_lane_per_frame_for_dictionary_batches(emu, ref, corpus):
     """Round 6: in dictionary batches K1's waves take several frames at a time and a LANE walks a frame whose tables are all the
     dictionary's (zp_lit_shared_try: treeless / raw / RLE literals, every sequence table "repeat"); what a lane cannot finish -- a table of the frame's own,
-    another layout, any failing check -- its wave does as before. The wave-per-frame form (k1Lanes = 0) and the lane forms (4, 16, 64 frames per task) must
-    agree on every output byte and every status, on good frames, on frames that need the wave, and on damaged ones; and the lanes must in fact finish the
-    4 KiB documents of BASELINE configs[3]'s shape."""
+    another layout, any failing check -- is listed for K1 proper, which does it as before. The wave-per-frame form alone (k1Lanes = 0) and the two-pass form
+    must agree on every output byte and every status, on good frames, on frames that need the wave, and on damaged ones; and the lanes must in fact finish
+    the 4 KiB documents of BASELINE configs[3]'s shape."""
     import ctypes as C
     import numpy as np
     rng = np.random.default_rng(23)
@@ -769,18 +769,18 @@ def test_k1_lane_per_frame_for_dictionary_batches(emu, ref, corpus):
     try:
         assert emu.set_ddict(trained) == 0
         res = {}
-        for lanes in (0, 4, 16, 64):
+        for lanes in (0, 1):
             emu.lib.emu_set_k1_lanes(C.c_uint32(lanes))
             before = emu.stat(7)
             outs, st, nfb = emu.decompress_pipeline(allf, alls, n_blocks=3, chunk=0)
             res[lanes] = (outs, st, nfb, emu.stat(7) - before)
-        for lanes in (4, 16, 64):
+        for lanes in (1,):
             assert res[lanes][1] == res[0][1], (lanes, [(i, a, b) for i, (a, b) in enumerate(zip(res[lanes][1], res[0][1])) if a != b][:5])
             assert all(a == b for a, b, s in zip(res[lanes][0], res[0][0], res[0][1]) if s == 0), lanes
             assert res[lanes][2] == res[0][2]
-        outs, st = res[16][0], res[16][1]
+        outs, st = res[1][0], res[1][1]
         assert not any(st[:len(frames)]) and all(o == r for o, r in zip(outs, raws + [docs[0], docs[1], docs[2]]))
-        assert res[0][3] == 0 and res[16][3] >= 30 and res[64][3] == res[16][3], (res[0][3], res[16][3], res[64][3])  # (corpus slices often carry tables of their own)
+        assert res[0][3] == 0 and res[1][3] >= 30, (res[0][3], res[1][3])              # (corpus slices often carry tables of their own)
         assert any(st[len(frames):])                                                                                  # (and the damage was noticed)
         # BASELINE configs[3]'s own shape: JSON-like 4 KiB documents on the 112 640-byte trained dictionary -- every frame is header arithmetic
         import os
@@ -790,12 +790,12 @@ def test_k1_lane_per_frame_for_dictionary_batches(emu, ref, corpus):
         jdocs = [jraw[i].tobytes() for i in range(96)]
         jframes = [ref.compress(d, level=3, dict_data=jd) for d in jdocs]
         assert emu.set_ddict(jd) == 0
-        for lanes in (0, 16):
+        for lanes in (0, 1):
             emu.lib.emu_set_k1_lanes(C.c_uint32(lanes))
             before = emu.stat(7)
             outs, st, nfb = emu.decompress_pipeline(jframes, [4096] * 96, n_blocks=3, chunk=0)
             assert not any(st) and nfb == 0 and outs == jdocs
             assert emu.stat(7) - before == (96 if lanes else 0)
     finally:
-        emu.lib.emu_set_k1_lanes(C.c_uint32(16))
+        emu.lib.emu_set_k1_lanes(C.c_uint32(1))
         emu.set_ddict(None)
