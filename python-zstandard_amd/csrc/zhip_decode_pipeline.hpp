@@ -115,7 +115,11 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
         uint32_t lb = 0;
         if (need16) {
             lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? need16 : 0u));
-            if ((uint64_t)lb + need16 > a.arenaBudget16) return ZP_RC_FALLBACK;                // the chunk's room is used up: the generic kernel's frame
+            if ((uint64_t)lb + need16 > a.arenaBudget16) {                                     // the chunk's room is used up: the generic kernel's frame
+                // (the refused claim is taken back: K2's room check adds this counter to its own, and a claim that got nothing must not shut every K2 group of the chunk out -- ADVICE r05)
+                if (zh_opaque(lane) == 0) zh_atomic_add(a.counters + 8, 0u - need16);
+                return ZP_RC_FALLBACK;
+            }
         }
         // (literal rooms grow DOWN from the arena's end, K2's sequence rooms UP from its start: one budget, and each kind stays packed -- K2's stores
         // are what feels a wider destination, section 4.1)
@@ -194,6 +198,30 @@ ZH_DEV void zp_enter_bins(const ZhipPipeArgs& a, ZdMeta& m)
     const uint32_t kl = (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
     if (ks) m.pad = zh_atomic_add(a.counters + ZP_CNT_BINS + (256 - (ks > 256 ? 256u : ks)), 1u);
     if (kl) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + (256 - (kl > 256 ? 256u : kl)), 1u) << 1;
+}
+// the same for a wave whose every lane holds a frame of its own (zp_lit_lanes_body; all lanes call, `on` = this lane has a record to enter): the lanes that enter the same
+// bin claim their ranks with ONE atomic -- 262 144 four-KiB documents of one shape are two bins, and a per-lane atomic on one address is what the pass would then wait for
+ZH_DEV void zp_enter_bins_wave(const ZhipPipeArgs& a, ZdMeta& m, bool on)
+{
+    const uint32_t lane = zh_lane();
+    const uint32_t ks = on && m.nbSeq ? 1u + (m.nbSeq >> ZP_BIN_SHIFT) : 0u;
+    const uint32_t kl = on && (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
+    const uint32_t bS = ks ? 256u - (ks > 256u ? 256u : ks) : 0xFFFFu, bL = kl ? 256u + (256u - (kl > 256u ? 256u : kl)) : 0xFFFFu;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const uint32_t mine = which ? bL : bS;
+        uint64_t todo = zh_ballot(mine != 0xFFFFu);
+        while (todo) {
+            const uint32_t leader = (uint32_t)zh_ctz64(todo);
+            const uint32_t b = zh_shfl(mine, leader);
+            const uint64_t same = zh_ballot(mine == b);
+            uint32_t base = 0;
+            if (lane == leader) base = zh_atomic_add(a.counters + ZP_CNT_BINS + b, (uint32_t)zh_popc64(same));
+            base = zh_shfl(base, leader);
+            if (mine == b) { const uint32_t rank = base + (uint32_t)zh_popc64(same & zh_lt_mask()); if (which) m.hasChecksum |= rank << 1; else m.pad = rank; }
+            todo &= ~same;
+        }
+    }
 }
 ZH_DEV void zp_meta_clear(ZdMeta& m)
 {
@@ -297,15 +325,16 @@ ZH_DEVFN void zp_lit_lanes_body(const ZhipPipeArgs& a)
         const uint32_t incl = zh_scan_add(n16), total = zh_shfl(incl, 63);
         uint32_t lb = 0;
         if (total) lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? total : 0u)) + incl - n16;
+        const bool noRoom = done && n16 && (uint64_t)lb + n16 > a.arenaBudget16;    // the chunk's room is used up: the generic kernel's frame
+        zp_enter_bins_wave(a, m, done && !noRoom);
         if (done) {
-            if (n16 && (uint64_t)lb + n16 > a.arenaBudget16) {                  // the chunk's room is used up: the generic kernel's frame
+            if (noRoom) {
                 const uint32_t bm = m.blockMax, lo = m.fcsLo, hi = m.fcsHi;
                 zp_meta_clear(m); m.blockMax = bm; m.fcsLo = lo; m.fcsHi = hi; m.path = 2;
                 a.meta[i] = m;
                 const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = a.first + i;
             } else {
                 a.bases[2 * (size_t)i + 1] = n16 ? a.arenaBudget16 - lb - n16 : 0u;
-                zp_enter_bins(a, m);
                 a.meta[i] = m;
 #ifdef ZHIP_EMU
                 zd_stat[7]++;                                               // (test hook [7]: frames a lane finished)
@@ -507,7 +536,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
                 ZdMeta m; zp_meta_clear(m);
                 const uint32_t bh = zh_ld24(src + pos); pos += 3;
                 const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
-                if (err) { /* a block before this one failed: the item stays unused */ }
+                if (err || fallback) { /* a block before this one failed, or the frame already goes to the generic kernel: the item stays unused (and claims nothing) */ }
                 else if (type < 2) {
                     if (bs > blockMax && !onePass) err = ZE_CORRUPTION;
                     else { m.path = type == 0 ? 3u : 4u; m.litSize = bs; m.litOff = type == 0 ? pos : (uint32_t)src[pos]; }

@@ -327,9 +327,7 @@ struct zhip_ctx {
     // bring-up / tuning knobs, read from the environment ONCE when the context is created (never in a launch path)
     struct Knobs {
         // bring-up aids
-        bool noPipeline = false, prof = false, debug = false, debugPipe = false, watchdog = false;
-        bool noFlat = false;                // ZHIP_NO_FLAT: every batch through the lane-serial match kernel (A/B)
-        bool blocks = true;                 // ZHIP_BLOCKS=0: frames / sources of several blocks go to the generic kernels as in rounds 1-2 (A/B)
+        bool prof = false;                  // ZHIP_PROF: the kernels' phase timers (a separate instantiation of K3; printed to stderr)
         // decode pipeline
         size_t dchunk = ZHIP_DCHUNK;        // frames (several-block mode: block slots) per chunk
         int nslot = 2; bool nslotSet = false;   // chunk slots on their own streams (small frames get a third unless ZHIP_NSLOT says otherwise)
@@ -375,27 +373,14 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { g_lastError = "hipGetDeviceProperties failed"; delete c; return nullptr; }
     c->numCU = prop.multiProcessorCount;
     {   zhip_ctx::Knobs& k = c->knob;
-        k.noPipeline = getenv("ZHIP_NO_PIPELINE") != nullptr; k.prof = getenv("ZHIP_PROF") != nullptr; k.debug = getenv("ZHIP_DEBUG") != nullptr;
-        k.debugPipe = getenv("ZHIP_DEBUG_PIPE") != nullptr; k.watchdog = getenv("ZHIP_WATCHDOG") != nullptr; k.noFlat = getenv("ZHIP_NO_FLAT") != nullptr;
-        if (const char* e = getenv("ZHIP_DCHUNK")) { const long v = atol(e); if (v >= 64 && v <= (1 << 20)) k.dchunk = (size_t)v; }
-        if (const char* e = getenv("ZHIP_NSLOT")) { const long v = atol(e); if (v >= 1 && v <= ZHIP_NSLOT) { k.nslot = (int)v; k.nslotSet = true; } }
-        if (const char* e = getenv("ZHIP_ECHUNK_MAX")) { const long v = atol(e); if (v >= 65536 && v <= 262144) k.echunkMax = (size_t)v; }
-        if (const char* e = getenv("ZHIP_ECHUNK")) { const long v = atol(e); if (v >= 64) k.echunk = (size_t)v; }
-        if (const char* e = getenv("ZHIP_K3_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k3PerCU = (int)v; }
-        if (const char* e = getenv("ZHIP_K1_PER_CU")) { const long v = atol(e); if (v >= 1 && v <= 32) k.k1PerCU = (int)v; }
-        if (const char* e = getenv("ZHIP_BLOCKS")) k.blocks = atol(e) != 0;        // 0: frames of several blocks go to the generic kernel as in rounds 1-2 (A/B)
-        if (const char* e = getenv("ZHIP_MBC_LANES")) { const long v = atol(e); if (v >= 1 && v <= 64) k.mbcLanes = (unsigned)v; }
+        // Run-time knobs (round 6: eight, each exercised by a GPU test or a resource policy; rounds 1-5's other twenty-two -- chunk shapes, probe counts, waves per CU,
+        // bring-up aids -- are the constants of this struct, and what lost its A/B is in DESIGN.md with its measurements): ZHIP_PROF (phase timers), ZHIP_E1F_PICK,
+        // ZHIP_E1LDS_MAX, ZHIP_MBC_MIN here; ZHIP_DEVICES / ZHIP_DEVICE_MIN_BYTES (the in-call device fan-out), ZHIP_KEEP_GB, ZHIP_PIN_POOL_KEEP_MB (memory kept between
+        // calls) where they are used.
+        k.prof = getenv("ZHIP_PROF") != nullptr;
         if (const char* e = getenv("ZHIP_MBC_MIN")) k.mbcMin = (size_t)atol(e);     // compress: batches of at least this many sources take the flat search for sources of several blocks
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
-        if (const char* e = getenv("ZHIP_E1LDS_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.e1LdsRounds = (size_t)v; }
-        if (const char* e = getenv("ZHIP_HCHUNK_D0")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.hchunkD0 = (size_t)v; }      // decompress: items of the host pipeline's first chunk (0: like the others)
-        if (const char* e = getenv("ZHIP_HCHUNK_E0")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE0 = (size_t)v; }
-        if (const char* e = getenv("ZHIP_HCHUNK_E")) { const long v = atol(e); if (v >= 256 && v <= 65536) k.hchunkE = (size_t)v; }
-        if (const char* e = getenv("ZHIP_FLAT3_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat3Max = (size_t)v; }
-        if (const char* e = getenv("ZHIP_FLAT3")) k.flat3 = atol(e) != 0;          // 0: launches above flat4Max keep two probes per trip (A/B)
         if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
-        if (const char* e = getenv("ZHIP_FLAT4_MAX")) { const long v = atol(e); if (v >= 0 && v <= 262144) k.flat4Max = (size_t)v; }
-        if (const char* e = getenv("ZHIP_PACK_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) k.packThreads = (unsigned)v; }
     }
     zh_resolve_rows(&c->rows, 3, nullptr);
     int nb = 0;
@@ -637,7 +622,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
     if (c->counter.reserve(64)) return g_reserveRc;
     HIP_TRY(hipMemsetAsync(c->counter.p, 0, 4, stream));
     const uint32_t* d_fallbackList = nullptr; const uint32_t* d_fallbackCount = nullptr;
-    const bool usePipeline = !c->knob.noPipeline;
+    const bool usePipeline = true;
     if (usePipeline) {
         // phase-split fast path for single-block, dictionary-less frames (zhip_decode_pipeline.hpp); everything it declines
         // lands in the fallback list consumed by the generic kernel below.
@@ -653,7 +638,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // (small frames -- the caller says so -- are short kernels with launch gaps between them: a third chunk slot fills them. 262 144 x 4 KiB with the
         // shared dictionary: 123 -> 134 GB/s, r05q; frames of 128 KiB: the kernels are long, two slots overlap little as it is)
         if (!c->knob.nslotSet && sizeHint && sizeHint <= 16384 && slotMax < 3) slotMax = 3;
-        const bool mb = c->knob.blocks && sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
+        const bool mb = sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
         // (the host-buffer API knows every frame's size and says how many slots the batch should need in all -- a batch of mostly small frames
@@ -801,29 +786,6 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 for (int q = 0; q < 10; q++) if (h[16 * k + q]) fprintf(stderr, "[zhip-prof]    %-22s %6.2f%% %10.0f cyc/frame\n", nm[q], 100.0 * h[16 * k + q] / (tot ? tot : 1), (double)h[16 * k + q] / (double)n);
             }
         }
-        if (c->knob.debugPipe) {          // bring-up aid: per-frame records of the first chunk, after the pipeline drained
-            HIP_TRY(hipDeviceSynchronize());
-            const size_t cnt = n < chunk ? n : chunk;
-            std::vector<ZdMeta> hm(cnt); std::vector<uint32_t> ord(cnt); uint32_t hc[16];
-            HIP_TRY(hipMemcpy(hm.data(), c->pipeMeta.p, cnt * sizeof(ZdMeta), hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(ord.data(), c->pipeOrder.p, cnt * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(hc, c->pipeCounters.p, sizeof hc, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[pipe] counters: fallback %u | slot0 k1 %u order %u k3 %u\n", hc[0], hc[4], hc[5], hc[6]);
-            for (size_t i = 0; i < cnt && i < 64; i++) {
-                const ZdMeta& m = hm[i];
-                fprintf(stderr, "[pipe] frame %zu status %d path %u seq [%u,%u) lit %u mode %u nbSeq %u logs %06x produced %u order[%zu]=%u\n", i, m.status, m.path,
-                        m.seqOff, m.seqEnd, m.litSize, m.litMode, m.nbSeq, m.logs, m.produced, i, ord[i]);
-                if (m.nbSeq && m.path == 1) {
-                    uint64_t q[4] = {0, 0, 0, 0}; uint16_t cells[8]; uint32_t sb = 0;
-                    HIP_TRY(hipMemcpy(&sb, (uint32_t*)c->pipeBases.p + 2 * i, 4, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(q, (uint64_t*)((uint8_t*)c->pipeLit.p + ZP_LIT_FRONT) + sb, sizeof q, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(cells, (uint16_t*)c->pipeFse.p + i * ZP_FSE_CELLS + ZP_FSE_ML, sizeof cells, hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[pipe]    seq0 ll %u ml %u off %u | seq1 ll %u ml %u off %u | ml cells %04x %04x %04x %04x\n",
-                            ZP_SEQ_LL(q[0]), ZP_SEQ_ML(q[0]), ZP_SEQ_OF(q[0]),
-                            ZP_SEQ_LL(q[1]), ZP_SEQ_ML(q[1]), ZP_SEQ_OF(q[1]), cells[0], cells[1], cells[2], cells[3]);
-                }
-            }
-        }
         for (int sidx = 0; sidx < nslot; sidx++) {                 // the caller's stream continues after every slot has drained
             hipEvent_t evEnd; HIP_TRY(hipEventCreateWithFlags(&evEnd, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(evEnd, c->slotStream[sidx]));
@@ -847,40 +809,17 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         a.dictContentSize = c->dictSize - c->dictContentOffset;
         a.dictEntropy = c->dictHasEntropy ? (const ZhipDictEntropy*)c->dictEntropy.p : nullptr;
     }
-    const bool debug = c->knob.debug, watchdog = c->knob.watchdog, prof = c->knob.prof;
+    const bool prof = c->knob.prof;
     if (prof) {
         if (!c->profDecode) HIP_TRY(hipMalloc((void**)&c->profDecode, ZP_N * 8));
         HIP_TRY(hipMemsetAsync(c->profDecode, 0, ZP_N * 8, stream));
         a.prof = c->profDecode;
-    }
-    uint32_t* dbg = nullptr;
-    if (debug) {
-        HIP_TRY(hipHostMalloc((void**)&dbg, 64, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(dbg, 0, 64);
-        a.dbg = dbg;
-        fprintf(stderr, "[zhip] launch decode grid=%u n=%u scratch=%p counter=%p\n", grid, a.n, (void*)a.scratch, (void*)a.counter);
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, stream)); }
     hipLaunchKernelGGL(zhip_decode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
     HIP_TRY(hipGetLastError());
     if (c->timing) HIP_TRY(hipEventRecord(e1, stream));
-    if (watchdog && !debug) {
-        for (int it = 0; it < 5000; it++) {                  // 1 ms polls: the aid must not quantise what a caller times
-            if (hipStreamQuery(stream) == hipSuccess) break;
-            struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
-            if (it == 4999) { fprintf(stderr, "[zhip] WATCHDOG: kernel did not finish in 5 s; aborting process\n"); abort(); }
-        }
-    }
-    if (debug) {
-        for (int it = 0; it < 12; it++) {
-            hipError_t q = hipStreamQuery(stream);
-            fprintf(stderr, "[zhip] t=%dms query=%d dbg=%x %x %x %x %x %x %x\n", it * 50, (int)q, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
-            if (q == hipSuccess) break;
-            struct timespec ts = {0, 50 * 1000 * 1000}; nanosleep(&ts, nullptr);
-            if (it == 11) { fprintf(stderr, "[zhip] kernel did not finish in 5 s; aborting process\n"); abort(); }
-        }
-    }
     if (c->timing) c->timer[0].pending.emplace_back(e0, e1);
     if (prof) {
         unsigned long long h[ZP_N];
@@ -928,7 +867,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         a.cdictHashLong = (const uint32_t*)c->cdictTables.p;
         a.cdictHashSmall = (const uint32_t*)c->cdictTables.p + cells;
     }
-    if (!c->knob.noPipeline) {
+    {
         // two kernels: E1 searches with one LANE per frame (frames in flight hide the probe latency), E2 entropy-codes with one
         // wave per frame. Frames are processed in chunks so that the per-frame sequence/literal arena stays bounded.
         // table bytes of the largest one-block source of the two size classes these kernels serve (<= 128 KiB, <= 16 KiB), after the
@@ -951,7 +890,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // 50 % at 512 KiB+). r03u / r03v, flat against generic: 2 048 x 1 MiB 2.5 s / 1.04 s, 4 096 x 512 KiB 1.31 / 0.85, 4 096 x 256 KiB
         // 0.44 / 0.42, 8 192 x 256 KiB 0.47 / 0.68, 16 384 x 256 KiB 0.51 / 1.24, 8 192 x 1 MiB 3.3 / ~2.1: the longer the sources the more
         // rounds of the generic kernel it takes to lose, hence the threshold grows with the size hint -- ZHIP_MBC_MIN sources per 256 KiB of it)
-        const bool mbcWanted = anyDfast && !c->hasCDict && !c->knob.noFlat && c->knob.blocks && n >= c->knob.mbcMin * ((sizeHint + (256u << 10) - 1) / (256u << 10)) && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
+        const bool mbcWanted = anyDfast && !c->hasCDict && n >= c->knob.mbcMin * ((sizeHint + (256u << 10) - 1) / (256u << 10)) && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
         if (mbcWanted) for (int t = 0; t < 2; t++) {
             const int32_t* r = a.rows.r[t];
             if (r[6] != 2) continue;
@@ -986,8 +925,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // memset) takes every double-fast frame; what it declines goes to the lane-serial kernel through a list. Fast strategy
         // and dictionary batches use the lane-serial kernel for the whole chunk.
         // (r03: dictionary batches whose dictionary row is double-fast take the flat kernel too -- ze_dfast_dict_flat; its waves zero the tables)
-        const bool flatDict = c->hasCDict && c->cdictStrat == 2 && !c->knob.noFlat;
-        const bool flat = (anyDfast && !c->hasCDict && !c->knob.noFlat) || flatDict;
+        const bool flatDict = c->hasCDict && c->cdictStrat == 2;
+        const bool flat = (anyDfast && !c->hasCDict) || flatDict;
         // (round 5) every row double-fast, no dictionary: the flat kernel takes every one-block source of 64 bytes and more and writes sequences only, and what
         // it declines -- sources below 64 bytes, parameter errors -- needs a literal area of its own size at most: the slot is the sequence area + 512 bytes
         // instead of + 128 KiB (21.4 GiB of arena per 65 536 sources instead of 30; it is what lets 262 144 sources be one launch, 88 + 96 GiB)
@@ -1186,13 +1125,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(gBig), dim3(64), 0, stream, b);
             HIP_TRY(hipGetLastError());
         }
-        if (c->knob.watchdog) {
-            for (int it = 0; it < 120000; it++) {
-                if (hipStreamQuery(stream) == hipSuccess) break;
-                struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
-                if (it == 119999) { fprintf(stderr, "[zhip] WATCHDOG: encode kernels did not finish in 120 s; aborting process\n"); abort(); }
-            }
-        }
         return 0;
     }
     if (c->encWorkspace.reserve((size_t)grid * ZHIP_ENC_STRIDE)) return g_reserveRc;
@@ -1202,13 +1134,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
     hipLaunchKernelGGL(zhip_encode_frames_kernel, dim3(grid), dim3(64), 0, stream, a);
     HIP_TRY(hipGetLastError());
     if (c->timing) { HIP_TRY(hipEventRecord(e1, stream)); c->timer[1].pending.emplace_back(e0, e1); }
-    if (c->knob.watchdog) {
-        for (int it = 0; it < 60000; it++) {
-            if (hipStreamQuery(stream) == hipSuccess) break;
-            struct timespec ts = {0, 1000 * 1000}; nanosleep(&ts, nullptr);
-            if (it == 59999) { fprintf(stderr, "[zhip] WATCHDOG: encode kernel did not finish in 60 s; aborting process\n"); abort(); }
-        }
-    }
     if (c->timer[1].pending.size() > 4096) { HIP_TRY(hipStreamSynchronize(stream)); drain_timer(c->timer[1]); }
     return 0;
 }
@@ -1243,6 +1168,7 @@ extern "C" int zhip_ctx_sync(zhip_ctx* c, void* streamv, const int32_t* d_status
 //   (zhip_free_payload; the CPython extension's BufferWithSegments does that in its deallocator);
 // * compress: the compressBound-sized slots are compacted ON THE DEVICE (scan of the frame sizes + one wave per frame) so that only
 //   the frames cross the link, into a payload allocated once the chunk's total is known (the host learns it one chunk behind).
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -1264,6 +1190,7 @@ static size_t pin_pool_keep()
 }
 #define ZHIP_PIN_POOL_KEEP pin_pool_keep()
 
+static std::atomic<bool> g_pinPortable{false};      // set when the host-buffer calls have more than one device slot to fan out over (DevPool::parse)
 namespace {
 struct PinBlock { size_t cap; bool busy; };
 struct PinPool {
@@ -1281,7 +1208,8 @@ struct PinPool {
         }
         void* p = nullptr;
         const size_t cap = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return malloc(n); }     // pageable still works, slower
+        // (portable -- pinned for every device's copy engines -- only where the in-call fan-out can hand a block to another device: fan_out sets the flag)
+        if (hipHostMalloc(&p, cap, g_pinPortable.load() ? hipHostMallocPortable : hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return malloc(n); }     // pageable still works, slower
         std::lock_guard<std::mutex> g(mu);
         blocks[p] = PinBlock{cap, true};
         return p;
@@ -1785,6 +1713,7 @@ struct DevPool {
             }
         } else for (int d = 0; d < count; d++) slots.push_back(d);
         workers.assign(slots.size(), nullptr);
+        if (slots.size() > 1) g_pinPortable.store(true);       // payload blocks serve any device's copy engines from the first one on
     }
     DevWorker* worker(size_t slot)
     {

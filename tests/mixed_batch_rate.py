@@ -1,6 +1,6 @@
 """A batch of mostly small frames with a few large ones through the host-buffer API (PCIe inclusive): python tests/mixed_batch_rate.py [small] [large] [MiB].
 The large frames put the decode kernels in their several-block mode; the pool of block slots is sized from ALL the frames' sizes, so the small
-ones are not cut into chunks sized for the large ones (ZHIP_BLOCKS=0: the large frames go to the generic kernel, one wave each)."""
+ones are not cut into chunks sized for the large ones."""
 import json
 import os
 import sys
@@ -26,7 +26,7 @@ for j, b in enumerate(big): frames.insert((j + 1) * (S // (B + 1)), ref.compress
 raws = list(small)
 for j, b in enumerate(big): raws.insert((j + 1) * (S // (B + 1)), b)
 d = pyz.ZstdDecompressor()
-out = {"small_frames": S, "large_frames": B, "large_MiB": MIB, "blocks_mode": os.environ.get("ZHIP_BLOCKS", "1")}
+out = {"small_frames": S, "large_frames": B, "large_MiB": MIB}
 d.multi_decompress_to_buffer(frames)
 best = 1e9
 for _ in range(3):

@@ -1,5 +1,5 @@
 """Throughput of MULTI-BLOCK frames (inputs above 128 KiB), device-resident. Decompression: the phase-split kernels in their several-block
-mode (ZHIP_BLOCKS=0: one wave per frame in the generic kernel, as in rounds 1-2); compression: the generic kernel (DESIGN.md 4.1 / 4.2,
+mode (rounds 1-2: one wave per frame in the generic kernel); compression: the generic kernel (DESIGN.md 4.1 / 4.2,
 VERDICT r02 "missing" 3). 1 MiB inputs = BASELINE configs[0]'s size, built from 8 consecutive
 128 KiB corpus frames; frames compared with libzstd's (compress) and with the inputs (decompress).
 Usage: python tests/multiblock_rate.py [frames] [KiB per frame]"""

@@ -51,7 +51,7 @@ for n in (16, 256):
         t0 = time.perf_counter(); r = d.multi_decompress_to_buffer(frames[:n]); best = min(best, time.perf_counter() - t0)
     assert all(r[i].tobytes() == items[i] for i in range(n))
     out["decompress_batch_%d_ms" % n] = round(best * 1e3, 2)
-# one large frame (several blocks): the several-block mode of the decode kernels (ZHIP_BLOCKS=0: the generic kernel, one wave)
+# one large frame (several blocks): the several-block mode of the decode kernels
 for mib in (1, 8):
     big = b"".join(items[: 8 * mib])
     fb = ref.compress(big)

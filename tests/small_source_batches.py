@@ -1,6 +1,6 @@
 """Batches of SMALL sources (no dictionary) through the host-buffer API: the LDS-source match kernel with its LDS area sized for the
 batch's largest source (more frames per CU) against the flat kernel (ZHIP_E1LDS_MAX=0). ms per multi_compress_to_buffer call, a sample
-of the frames checked against libzstd 1.5.7.   Usage: python tests/small_source_batches.py   (once per ZHIP_E1LDS_* setting)"""
+of the frames checked against libzstd 1.5.7.   Usage: python tests/small_source_batches.py   (once per ZHIP_E1LDS_MAX setting)"""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ corpus = Corpus(device=torch.device("cuda", 0))
 ref = reflib.RefZstd()
 raw = corpus.frames(0, 2048, chunk=256).cpu().numpy()
 c = pyz.ZstdCompressor(level=3)
-out = {"ZHIP_E1LDS_MAX": os.environ.get("ZHIP_E1LDS_MAX", "default"), "ZHIP_E1LDS_ROUNDS": os.environ.get("ZHIP_E1LDS_ROUNDS", "default")}
+out = {"ZHIP_E1LDS_MAX": os.environ.get("ZHIP_E1LDS_MAX", "default")}
 for size, counts in ((4096, (1024, 8192, 16384, 32768)), (16384, (1024, 4608, 9216)), (65536, (512, 1024, 2048))):
     per = 131072 // size
     items = [raw[i // per][(i % per) * size:(i % per + 1) * size].tobytes() for i in range(max(counts))]
