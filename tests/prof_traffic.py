@@ -32,13 +32,18 @@ for direction in ("decode", "compress", "dict"):              # dict: kernel tra
     for r in rows_of(direction + "_kt", "*kernel_trace.csv"):
         if "zhip_" in r.get("Kernel_Name", ""):
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    # (the compress trace's average mixed in the table pick's probe launches -- the first launches of the flat match kernel in a fresh
+    # context, up to three, on candidate allocations of which only the fastest is kept. They are dropped here: what is left is the steady state the bench times)
+    k_ = "zhip_encode_match_flat_kernel"
+    if direction == "compress" and len(dur.get(k_, [])) > 4:
+        dur[k_] = dur[k_][3:]
     if dur:
         with open(os.path.join(out_dir, "%s_%s_kt_zhip_kernels_summary.csv" % (tag, direction)), "w", newline="") as fh:
             w = csv.writer(fh)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
             for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v)])
-    for kind in ("fetch", "write", "sq", "sq2", "sq3"):
+    for kind in ("fetch", "write", "sq", "sq2", "sq3", "tcc"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows_of("%s_%s" % (direction, kind), "*counter_collection.csv"):
             if "zhip_" in r.get("Kernel_Name", ""):

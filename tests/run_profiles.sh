@@ -15,7 +15,9 @@ run decode_write --pmc WRITE_SIZE --output-format csv -d $P/decode_write -- $B -
 run decode_sq --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $P/decode_sq -- $B --steps 1 --compress-frames 0
 run decode_sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $P/decode_sq2 -- $B --steps 1 --compress-frames 0
 run decode_sq3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU --output-format csv -d $P/decode_sq3 -- $B --steps 1 --compress-frames 0
-run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- $B --steps 2 --config compress
+run decode_tcc --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $P/decode_tcc -- $B --steps 1 --compress-frames 0
+run compress_kt --kernel-trace --stats --output-format csv -d $P/compress_kt -- $B --steps 4 --config compress
+run compress_tcc --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $P/compress_tcc -- $B --steps 1 --warmup 0 --config compress
 run compress_fetch --pmc FETCH_SIZE --output-format csv -d $P/compress_fetch -- $B --steps 1 --warmup 0 --config compress
 run compress_write --pmc WRITE_SIZE --output-format csv -d $P/compress_write -- $B --steps 1 --warmup 0 --config compress
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/dict_kt -- python bench.py --config dict --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $P/dict_kt.err; echo "dict_kt rc $?"
