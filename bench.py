@@ -255,11 +255,27 @@ def roofline(ctx, ktimes, steps, algo_bytes_per_step, ms_per_step, frames_per_st
         except (OSError, ValueError, KeyError):
             pass
     e2e = algo_bytes_per_step / (ms_per_step * 1e-3) / 1e9
+    # what the dominant kernel asks of the memory system in REQUESTS (the L2's memory-side counters TCC_EA0_RDREQ / WRREQ, one rocprofv3 --pmc pass, profiles/traffic.json):
+    # the two kernels that bound this codec sit on request-rate walls the bandwidth fraction does not show -- random 64-byte reads top out at ~50 G/s, random partial
+    # (32-byte) write-backs at ~22 G/s (tests/ubench/membench.hip, tablebench.hip)
+    req = None
+    if frames_per_step:
+        try:
+            rq = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("requests_per_frame", {}).get(ctx.kernel_name(kdom))
+            if rq and kernel_ms > 0:
+                n = frames_per_step / launches_per_step
+                rd, wr = rq["read"] * n / (kernel_ms * 1e-3), rq["write"] * n / (kernel_ms * 1e-3)
+                req = {"kernel": ctx.kernel_name(kdom), "read_requests_per_s": round(rd / 1e9, 2), "write_requests_per_s": round(wr / 1e9, 2), "unit": "G/s",
+                       "write_requests_of_64_bytes": rq.get("write64_share"), "read_ceiling": 50.0, "partial_write_ceiling": 22.0,
+                       "frac_of_ceiling": round(max(rd / 50e9, (wr / 22e9) if (rq.get("write64_share") or 0) < 0.5 else 0.0), 3),
+                       "measured_in_run": False, "note": "requests per frame from profiles/traffic.json (separate --pmc pass) over this run's kernel time; ceilings from the microbenchmarks"}
+        except (OSError, ValueError, KeyError):
+            pass
     return {"bound": "hbm", "kernel": "pipeline: " + " + ".join(ctx.kernel_name(k) for k, v in ktimes.items() if v[1] and v[0] >= 0.05),
             "achieved": round(pipe, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBS, 5),
             # traffic: read from profiles/traffic.json (separate rocprofv3 --pmc passes), scaled to the step
             "traffic": traffic, "traffic_source": tsrc, "traffic_measured_in_run": False,
-            "kernel_ms_per_step": round(pipe_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes_per_step),
+            "kernel_ms_per_step": round(pipe_ms, 4), "algorithmic_bytes_per_step": int(algo_bytes_per_step), "memory_requests": req,
             "dominant_kernel": {"kernel": ctx.kernel_name(kdom), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": ktraffic,
                                 "kernel_ms": round(kernel_ms, 4), "launches": int(launches), "algorithmic_bytes_per_launch": int(algo_bytes),
                                 "note": "the step's whole algorithmic bytes over ONE kernel's duration (the prescribed formula): it credits this kernel with bytes the other kernels move"},

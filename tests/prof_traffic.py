@@ -26,6 +26,7 @@ def rows_of(sub, pattern):
 
 
 traffic = collections.defaultdict(float)
+requests = collections.defaultdict(dict)
 for direction in ("decode", "compress", "dict"):              # dict: kernel trace only (bench.py --config dict, 262 144 x 4 KiB)
     # kernel trace -> durations
     dur = collections.defaultdict(list)
@@ -59,8 +60,14 @@ for direction in ("decode", "compress", "dict"):              # dict: kernel tra
                     w.writerow([k, c, len(v), round(sum(v) / len(v), 3)])
                     if c in ("FETCH_SIZE", "WRITE_SIZE"):               # KiB per launch (rocprofv3's unit) -> bytes per frame
                         traffic[k] += sum(v) / len(v) * 1024.0 / frames
+                    if c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):      # the L2's memory-side requests per frame
+                        requests[k][{"TCC_EA0_RDREQ_sum": "read", "TCC_EA0_WRREQ_sum": "write", "TCC_EA0_WRREQ_64B_sum": "write64"}[c]] = sum(v) / len(v) / frames
 json.dump({"round": tag, "frames_per_launch": frames,
            "source": "profiles/%s_{decode,compress}_{fetch,write}_counters.csv: FETCH_SIZE + WRITE_SIZE (KiB per launch of %d frames, one rocprofv3 --pmc pass each, "
                      "tests/run_profiles.sh); FETCH_SIZE uncorrected (the guide's x2 applies to wide coalesced reads; these kernels' reads are narrow)" % (tag, frames),
-           "bytes_per_frame": {k: round(v, 1) for k, v in sorted(traffic.items())}}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+           "bytes_per_frame": {k: round(v, 1) for k, v in sorted(traffic.items())},
+           "requests_per_frame": {k: {"read": round(v.get("read", 0.0), 1), "write": round(v.get("write", 0.0), 1),
+                                      "write64_share": round(v.get("write64", 0.0) / v["write"], 4) if v.get("write") else None}
+                                  for k, v in sorted(requests.items()) if v.get("read", 0) + v.get("write", 0) >= 1.0}},
+          open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(out_dir, "traffic.json")).read())
