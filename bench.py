@@ -619,10 +619,13 @@ def bench_host_api(raw_np, frames, csizes, counts=(8192, 65536)):
         out["frames_%d" % F] = rec
     # the device slots the two calls fan a batch out over inside the call (zhip_compress_batch / zhip_decompress_batch: every visible device, or ZHIP_DEVICES)
     import ctypes
-    devs = (ctypes.c_int * 64)()
-    nd = pyz._lib.lib().zhip_batch_devices(devs, 64)
-    out["devices"] = nd
-    out["device_slots"] = list(devs[:nd])
+    try:
+        devs = (ctypes.c_int * 64)()
+        nd = pyz._lib.lib().zhip_batch_devices(devs, 64)
+        out["devices"] = nd
+        out["device_slots"] = list(devs[:nd])
+    except AttributeError:                                          # (an older library under ZHIP_LIB, for A/B runs: one device, the current one)
+        out["devices"] = 1
     return out
 
 
