@@ -9,6 +9,7 @@
 #   k3d{2,3}    -DZP_K3D_MINWAVES=n  K3's dictionary instantiation (default 4)
 #   asm2k       -DZP_ASM_BYTES=2048  K3: 2 KiB batch assembly buffer
 #   own32       -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32   K3: own-lane items up to 32 bytes (round 2's shape)
+#   nohist      -DZP_HIST_KEEP=0u -DZP_HIST_SLIDE=0u  K3 without the LDS history in front of the batch (round 6 A/B)
 #   e1l{16,32,64} -DZE_E1_LANES=n    lane-serial match kernel (fast-strategy batches): n frames per wave instead of 8
 # Emulator-verified shapes: tests/test_emu_kernels.py::test_decode_shape_variants_stay_correct.
 # usage: build_variants.sh name [name ...]
@@ -38,6 +39,7 @@ for v in "$@"; do
     nt1w5) build nt1w5 -DZP_K3_NT=1 -DZP_K3_MINWAVES=5 & ;;
     nt3) build nt3 -DZP_K3_NT=3 & ;;
     own32) build own32 -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32 & ;;
+    nohist) build nohist -DZP_HIST_KEEP=0u -DZP_HIST_SLIDE=0u & ;;   # K3 without the LDS history of its flushed output (rounds 1-5's form; A/B of round 6: profiles/r06g_k3_history_*)
     floor) build floor -DZP_K3_DIAG_FLOOR & ;;
     floorw4) build floorw4 -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=4 -DZP_FLOOR_LDSPAD=4096 & ;;                                  # the occupancy of an 8 KiB buffer, no window
     floorw4win) build floorw4win -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=4 -DZP_FLOOR_LDSPAD=4096 -DZP_FLOOR_WIN=8192 -DZP_ASM_BYTES=2048 & ;;
