@@ -171,6 +171,9 @@ def ordered_for_the_driver(line):
          "host_api_8192_c": _dig(line, "host_api", "frames_8192", "compress"), "host_api_8192_d": _dig(line, "host_api", "frames_8192", "decompress"),
          "host_api_65536_c": _dig(line, "host_api", "frames_65536", "compress"), "host_api_65536_d": _dig(line, "host_api", "frames_65536", "decompress"),
          "host_api_devices": _dig(line, "host_api", "devices"),
+         "host_api_all_devices": _dig(line, "host_api", "all_devices", "devices"),
+         "host_api_all_devices_c": _dig(line, "host_api", "all_devices", "frames_%d" % (_dig(line, "config", "frames_per_gpu") or 65536), "compress"),
+         "host_api_all_devices_d": _dig(line, "host_api", "all_devices", "frames_%d" % (_dig(line, "config", "frames_per_gpu") or 65536), "decompress"),
          "dict_c_gbs": _dig(line, "dict", "value"), "dict_d_gbs": _dig(line, "dict", "decompress", "value"),
          "roundtrip_gbs": _dig(line, "roundtrip", "value"), "roundtrip_c_gbs": _dig(line, "roundtrip", "compress", "value"),
          "roundtrip_d_gbs": _dig(line, "roundtrip", "decompress", "value"),
@@ -629,6 +632,38 @@ def bench_host_api(raw_np, frames, csizes, counts=(8192, 65536)):
     return out
 
 
+def host_api_child(args):
+    """`python bench.py --host-api-child SLOTS`: the host-buffer calls (multi_compress_to_buffer / multi_decompress_to_buffer through Python) with the batch cut over
+    several device slots INSIDE the call (zhip_compress_batch / zhip_decompress_batch: DESIGN.md section 6). A process of its own: the device list is read once per
+    process, and a first run on real multi-GPU hardware must not be able to take the parent's line down. Prints one JSON object."""
+    if args.host_api_child == "all":
+        os.environ.pop("ZHIP_DEVICES", None)
+    else:
+        os.environ["ZHIP_DEVICES"] = args.host_api_child
+    from tests.corpus import Corpus
+    F = args.frames
+    dev = torch.device("cuda", 0)
+    raw_np = Corpus(device=dev, mix=args.mix).frames(0, F, chunk=256).cpu().numpy()
+    torch.cuda.empty_cache()
+    frames, csizes = compress_on_host(raw_np, FRAME)
+    out = bench_host_api(raw_np, frames, csizes, counts=(F,))
+    print(json.dumps(out), flush=True)
+
+
+def host_api_over_slots(slots, frames, timeout=420):
+    """the child above, with a time limit; its object, or what went wrong"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-api-child", slots, "--frames", str(frames)], capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            return {"error": "exit code %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else "")}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s" % timeout}
+    except (ValueError, IndexError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def bench_blocks(args, rank, world, dev, steps=None, warmup=None, quiet=False):
     """Frames of SEVERAL blocks (inputs above 128 KiB; not a BASELINE.json config -- configs[0]'s 1 MiB size as a batch): 2 048 x 1 MiB per GPU,
     each source eight consecutive 128 KiB corpus pieces. Decompression runs the phase-split kernels' several-block mode; compression of a batch
@@ -733,7 +768,11 @@ def main():
     ap.add_argument("--mix", choices=["silesia", "default"], default="silesia", help="class mix of the 128 KiB corpus (tests/corpus.py)")
     ap.add_argument("--direction", choices=["decompress", "compress"], default=None, help="older spelling of --config")
     ap.add_argument("--dry-launch", action="store_true", help="form the process group, agree on the partition, exit (no kernels; gloo where there is no GPU)")
+    ap.add_argument("--host-api-child", default=None, metavar="SLOTS",
+                    help="(internal) measure the host-buffer calls over these device slots ('all' = every visible device, or a ZHIP_DEVICES list) in this process and print the object")
     args = ap.parse_args()
+    if args.host_api_child:
+        return host_api_child(args)
     config = args.config or args.direction or "decompress"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -751,6 +790,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # this process's host-buffer calls stay on its own device (the library would otherwise fan a large batch out over every visible device: measured in a process of
+    # its own, host_api_child, so that nothing a first multi-device run may do can take the headline with it)
+    os.environ.setdefault("ZHIP_DEVICES", str(local_rank))
     global USE_DIST
     # ZHIP_BENCH_FORCE_DIST=1: take the process-group path (RCCL init, barriers, max over ranks, the payload all-gatherv) with ONE rank too --
     # the only way to exercise it on a single-GPU box
@@ -897,6 +939,11 @@ def bench_frames(args, config, rank, world, dev):
             line["host_api"]["wall_s"] = round(time.time() - t0, 1)
         except Exception as e:                                      # noqa: BLE001 -- keep the headline
             line["host_api"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the same two calls with the batch cut over every device of the node inside the call -- where there is more than one (ZHIP_BENCH_HOST_API_SLOTS=0,0 forces
+        # two slots on one GPU: the plumbing's price where it cannot help)
+        slots = os.environ.get("ZHIP_BENCH_HOST_API_SLOTS") or ("all" if torch.cuda.device_count() > 1 else None)
+        if slots and isinstance(line.get("host_api"), dict):
+            line["host_api"]["all_devices"] = host_api_over_slots(slots, F)
     if not args.no_extra and F >= 65536 and (world == 1 or args.extra):
         # BASELINE.json configs[3] and configs[4] ride on the default line as sub-objects (each with its own roofline and cpu_baseline), so
         # that the driver's one run records every config; their own timed regions start after this line's is over. A failure there is
