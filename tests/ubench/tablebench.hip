@@ -4,6 +4,7 @@
 //                                        xchg : one atomic exchange per cell (the same reads and writes as 4 requests instead of 8)
 //                                        ld   : the loads alone                          st : the stores alone
 //                                        + nontemporal forms of the stores / loads, and 2-byte cells (same cell count, half the bytes)
+//                                        + round 6: the stores as whole 64-byte lines / 32-byte sectors, and the load-line / change-one-cell / store-line form
 // Usage: tablebench [lanes = 65536] [table KiB = 384] [trips = 2000]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -49,6 +50,37 @@ __global__ __launch_bounds__(64) void tb(uint32_t* tab, uint32_t cells, uint32_t
             for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(t + ix[k]);
 #pragma unroll
             for (int k = 0; k < 4; k++) __builtin_nontemporal_store(i + k, t + ix[k]);
+        } else if (MODE == 8) {                         // round 6: the stores as WHOLE 64-byte lines (4 x 16 bytes to the cell's line): no partial write-back
+#pragma unroll
+            for (int k = 0; k < 4; k++) { uint4* q = (uint4*)(t + (ix[k] & ~15u)); const uint4 w = make_uint4(i, k, i, k); q[0] = w; q[1] = w; q[2] = w; q[3] = w; }
+        } else if (MODE == 9) {                         // whole 32-byte sectors
+#pragma unroll
+            for (int k = 0; k < 4; k++) { uint4* q = (uint4*)(t + (ix[k] & ~7u)); const uint4 w = make_uint4(i, k, i, k); q[0] = w; q[1] = w; }
+        } else if (MODE == 10) {                        // what a search with line-wide cells would do: load the cell's 64-byte line, change one cell, store the line
+            uint4 ln[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint4* q = (const uint4*)(t + (ix[k] & ~15u)); ln[k][0] = q[0]; ln[k][1] = q[1]; ln[k][2] = q[2]; ln[k][3] = q[3]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = ln[k][0].x ^ ln[k][1].y ^ ln[k][2].z ^ ln[k][3].w; uint4* q = (uint4*)(t + (ix[k] & ~15u)); ln[k][ix[k] & 3].x = i + k; q[0] = ln[k][0]; q[1] = ln[k][1]; q[2] = ln[k][2]; q[3] = ln[k][3]; }
+        } else if (MODE == 11) {                        // the 64-byte loads alone
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint4* q = (const uint4*)(t + (ix[k] & ~15u)); const uint4 a = q[0], b = q[1], c = q[2], d = q[3]; v[k] = a.x ^ b.y ^ c.z ^ d.w; }
+        } else if (MODE == 12) {                        // 4-byte loads + whole-line stores (isolates the write side of mode 10)
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = t[ix[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { uint4* q = (uint4*)(t + (ix[k] & ~15u)); const uint4 w = make_uint4(i, k, i, k); q[0] = w; q[1] = w; q[2] = w; q[3] = w; }
+        } else if (MODE >= 13 && MODE <= 16) {          // load the line / change one cell / store the line, with the cache policy varied: 13 loads nt, 14 stores nt, 15 both nt, 16 loads nt + DEPENDENT only through one dword
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 ln[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const u4* q = (const u4*)(t + (ix[k] & ~15u));
+#pragma unroll
+                for (int j = 0; j < 4; j++) ln[k][j] = (MODE == 14) ? q[j] : __builtin_nontemporal_load(q + j); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = ln[k][0].x ^ ln[k][1].y ^ ln[k][2].z ^ ln[k][3].w; u4* q = (u4*)(t + (ix[k] & ~15u)); ln[k][ix[k] & 3].x = i + k;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { if (MODE == 13 || MODE == 16) q[j] = ln[k][j]; else __builtin_nontemporal_store(ln[k][j], q + j); } }
         } else {                                        // 2-byte cells: loads + stores of half the width
             uint16_t* t2 = (uint16_t*)t;
 #pragma unroll
@@ -75,8 +107,10 @@ int main(int argc, char** argv)
     const uint32_t cells = kib * 256;
     uint32_t* tab; uint32_t* sink; CHECK(hipMalloc(&tab, (size_t)lanes * cells * 4)); CHECK(hipMemset(tab, 0, (size_t)lanes * cells * 4)); CHECK(hipMalloc(&sink, 64));
     const dim3 g((lanes + 63) / 64), b(64);
-    const char* names[8] = {"ldst (4 loads + 4 stores)", "xchg (4 atomic exchanges)", "ld   (4 loads)", "st   (4 stores)", "st nontemporal", "ld + st nontemporal", "ld nt + st nt", "ldst, 2-byte cells (half the table)"};
-    for (int m = 0; m < 8; m++) {
+    const char* names[17] = {"ldst (4 loads + 4 stores)", "xchg (4 atomic exchanges)", "ld   (4 loads)", "st   (4 stores)", "st nontemporal", "ld + st nontemporal", "ld nt + st nt", "ldst, 2-byte cells (half the table)",
+                             "st   whole 64-byte lines", "st   whole 32-byte sectors", "ldst whole 64-byte lines", "ld   whole 64-byte lines", "ld 4 bytes + st whole lines",
+                             "ldst whole lines, loads nt", "ldst whole lines, stores nt", "ldst whole lines, both nt", "(as 13)"};
+    for (int m = 0; m < 16; m++) {
         float ms = 0;
         if (m == 0) ms = timed([&] { hipLaunchKernelGGL(tb<0>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
         if (m == 1) ms = timed([&] { hipLaunchKernelGGL(tb<1>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
@@ -86,6 +120,14 @@ int main(int argc, char** argv)
         if (m == 5) ms = timed([&] { hipLaunchKernelGGL(tb<5>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
         if (m == 6) ms = timed([&] { hipLaunchKernelGGL(tb<6>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
         if (m == 7) ms = timed([&] { hipLaunchKernelGGL(tb<7>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 8) ms = timed([&] { hipLaunchKernelGGL(tb<8>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 9) ms = timed([&] { hipLaunchKernelGGL(tb<9>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 10) ms = timed([&] { hipLaunchKernelGGL(tb<10>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 11) ms = timed([&] { hipLaunchKernelGGL(tb<11>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 12) ms = timed([&] { hipLaunchKernelGGL(tb<12>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 13) ms = timed([&] { hipLaunchKernelGGL(tb<13>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 14) ms = timed([&] { hipLaunchKernelGGL(tb<14>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
+        if (m == 15) ms = timed([&] { hipLaunchKernelGGL(tb<15>, g, b, 0, 0, tab, cells, lanes, trips, sink); });
         const double cellsTouched = (double)lanes * trips * 4;
         printf("%-28s %u lanes x %u KiB tables, %u trips: %8.2f ms   %6.1f G cells/s\n", names[m], lanes, kib, trips, ms, cellsTouched / ms / 1e6);
     }
