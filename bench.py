@@ -166,6 +166,8 @@ def ordered_for_the_driver(line):
     s = {"decompress_gbs": line.get("value"), "decompress_ms": line.get("ms_per_step"), "decompress_hbm_frac": _dig(line, "roofline", "frac"),
          "compress_gbs": _dig(line, "compress", "value"), "compress_ms": _dig(line, "compress", "ms_per_step"),
          "compress_hbm_frac": _dig(line, "compress", "roofline", "frac"),
+         "decompress_line_transfer_frac": _dig(line, "roofline", "memory_requests", "frac_of_ceiling"),
+         "compress_line_transfer_frac": _dig(line, "compress", "roofline", "memory_requests", "frac_of_ceiling"),
          "compress_match_kernel_ms": _dig(line, "compress", "regime", "match_kernel_ms_per_65536_frames"),
          "compress_regime": _dig(line, "compress", "regime", "class"), "combined_gbs": _dig(line, "combined", "value"),
          "host_api_8192_c": _dig(line, "host_api", "frames_8192", "compress"), "host_api_8192_d": _dig(line, "host_api", "frames_8192", "decompress"),
