@@ -1116,20 +1116,12 @@ ZH_DEVFN int zd_frame(const ZhipDecodeArgs& a, ZdLDS& L, uint32_t f, uint8_t* li
     return ZE_OK;
 }
 
-#if !defined(ZHIP_EMU) && !defined(ZD_NO_DBG)
-#define ZD_DBG(slot, val) do { if (a.dbg && zh_block() == 0) { a.dbg[slot] = (uint32_t)(val); __threadfence_system(); } } while (0)
-#else
-#define ZD_DBG(slot, val) do { } while (0)
-#endif
-
 ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
-    ZD_DBG(0, 1);
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
-    ZD_DBG(0, 2);
     uint8_t* lit = a.scratch + (size_t)zh_block() * ZHIP_LIT_STRIDE;
     for (;;) {
         // NOTE (compiler hazard, found on hardware): never write `x = c; if (lane == 0) x = ...; x = readfirstlane(x)`.
@@ -1143,7 +1135,6 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
         zh_sync();
         uint32_t f = zh_first(L.misc[7]);
         zh_sync();
-        ZD_DBG(2, 0x200 + f);
         const uint32_t limit = a.listCount ? *a.listCount : a.n;
         if (f >= limit) break;
         if (a.frameList) f = a.frameList[f];
@@ -1155,11 +1146,9 @@ ZH_DEVFN void zd_kernel_body(const ZhipDecodeArgs& a, ZdLDS& L)
             ZD_T(P, ZP_HEADER);
             if (zh_opaque(lane) == 0) for (int i = 0; i < ZP_N; i++) zh_atomic_add64(a.prof + i, (unsigned long long)P.acc[i]);
         }
-        ZD_DBG(3, 0x300 + err);
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
     }
-    ZD_DBG(0, 9);
 }
 
 // Parses the entropy section of a zstd-format dictionary (magic, dictID, Huffman table, OF/ML/LL distributions,

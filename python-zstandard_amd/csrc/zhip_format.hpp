@@ -67,7 +67,6 @@ struct ZhipDecodeArgs {
     const uint32_t* frameList;      // optional indirection: process frameList[0 .. *listCount) instead of 0 .. n (pipeline fallback)
     const uint32_t* listCount;
     unsigned long long* prof;       // optional: per-phase cycle totals (ZHIP_PROF bring-up / tuning aid), else null
-    volatile uint32_t* dbg;         // optional host-visible progress words (ZHIP_DEBUG bring-up aid), else null
 };
 
 // ------------------------------------------------------------------------------------------------ encode side

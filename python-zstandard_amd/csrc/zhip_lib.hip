@@ -1353,11 +1353,14 @@ static zhip_ctx* tls_ctx()
 // the host-buffer API keeps its scratch between calls (allocation is slow), but not the tens of GiB a 65 536-frame batch needs
 // what memory_size() reports. The reference's contexts exist from the constructor on (ZSTD_sizeof_CCtx > 0 right away, its tests expect that):
 // the calling thread's device context is created here if it is not there yet, with the launch counters every call needs.
+static std::atomic<size_t> g_slotBytes[64];         // device bytes the device slots' contexts hold (each slot's thread updates its own after a job: fan_out)
 extern "C" size_t zhip_thread_memory_size(void)
 {
     zhip_ctx* c = tls_ctx();
     if (c) (void)c->counter.reserve(64 * 8);
-    return c ? c->device_bytes() : 0;
+    size_t n = c ? c->device_bytes() : 0;
+    for (int i = 0; i < 64; i++) n += g_slotBytes[i].load();     // (what the in-call fan-out keeps on the node's devices belongs to the caller's picture too)
+    return n;
 }
 // Round 6: a context KEEPS its working set between calls -- the flat search's tables (12 GiB for a 32 768-source chunk), the arenas, the
 // device-side staging -- as long as the whole stays within ZHIP_KEEP_GB (default 64: a BASELINE-sized call of 65 536 x 128 KiB holds ~50 GiB of the GPU's
@@ -1755,6 +1758,7 @@ int fan_out(size_t d, const std::vector<uint64_t>& sizes, size_t n, F&& one, zhi
             memset(&r.err, 0, sizeof r.err);
             r.rc = one(lo, hi, &r.out, &r.nOut, &r.err);
             if (r.rc) r.text = g_lastError;
+            if (w < 64 && g_tls.c) g_slotBytes[w].store(g_tls.c->device_bytes());
             { std::lock_guard<std::mutex> l(mu); r.done = true; pending--; }
             cv.notify_one();
         });
