@@ -286,7 +286,7 @@ struct DevBuf {
         p = nullptr; cap = 0;
     }
 };
-#define ZHIP_NTIMER 9
+#define ZHIP_NTIMER 10
 struct KTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // owned: destroyed after reading
     std::vector<std::pair<hipEvent_t, hipEvent_t>> shared;    // borrowed: another timer owns the events
@@ -301,6 +301,7 @@ struct zhip_ctx {
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
     DevBuf pipeMeta, pipeLit, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
+    hipStream_t sideStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
@@ -353,7 +354,7 @@ struct zhip_ctx {
     unsigned long long* profDecode = nullptr;    // ZHIP_PROF phase-timer accumulators, owned by the context (one context == one caller)
     unsigned long long* profPipe = nullptr;
     unsigned long long* profEncode = nullptr;
-    KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams
+    KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams, 8 the flat match kernel, 9 the decode pipeline of a chunk from K1's start to K3's end (K1b runs beside K2)
     size_t device_bytes() const
     {
         const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &encWorkspace, &encMeta, &encArena,
@@ -414,7 +415,7 @@ static void drain_timer(KTimer& t)
     drain_shared(t);
     for (auto& pr : t.pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.totalMs += ms; t.launches++; }
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.totalMs += ms > 0 ? ms : 0; t.launches++; }
         (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
     }
     t.pending.clear();
@@ -426,6 +427,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_shared(c->timer[i]);
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
+    for (int i = 0; i < ZHIP_NSLOT; i++) if (c->sideStream[i]) (void)hipStreamDestroy(c->sideStream[i]);
     c->pipeMeta.release(); c->pipeLit.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
@@ -444,7 +446,7 @@ extern "C" const char* zhip_kernel_name(int k)
 {
     static const char* names[ZHIP_NTIMER] = {"zhip_decode_frames_kernel", "zhip_encode_frames_kernel", "zhip_decode_lit_kernel",
                                    "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", "zhip_encode_match_kernel",
-                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel"};
+                                   "zhip_encode_entropy_kernel", "zhip_decode_huf_kernel", "zhip_encode_match_flat_kernel", "zhip_decode_pipeline_span"};
     return k >= 0 && k < ZHIP_NTIMER ? names[k] : "";
 }
 extern "C" int zhip_ctx_kernel_time(zhip_ctx* c, int direction, double* avgMs, uint64_t* launches)
@@ -639,6 +641,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // shared dictionary: 123 -> 134 GB/s, r05q; frames of 128 KiB: the kernels are long, two slots overlap little as it is)
         if (!c->knob.nslotSet && sizeHint && sizeHint <= 16384 && slotMax < 3) slotMax = 3;
         const bool mb = sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
+        // K1b beside K2 on a side stream (below) -- not for batches of small frames: their kernels are short, the three chunk slots overlap them already, and the
+        // side streams only added queues (262 144 x 4 KiB with the dictionary: 199 -> 187 GB/s, r06p)
+        const bool side = !(sizeHint && sizeHint <= 16384);
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
         // (the host-buffer API knows every frame's size and says how many slots the batch should need in all -- a batch of mostly small frames
@@ -752,12 +757,36 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
             }
             hipLaunchKernelGGL(zhip_decode_bin_kernel, dim3(2 * (items < 4096 ? 1u : 64u)), dim3(64), 0, ss, pa);      // tiny; timed with K1
-            if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
-            hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
-            if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
-            if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
-            if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
+            hipEvent_t evS0 = nullptr, evS1 = nullptr;
+            if (side) {
+                // K1b and K2 need nothing of each other: both follow K1 and the bins, K3 follows both. K2's 15-frame groups are long (~1.9 ms at 128 KiB) and a wave gets 4.27 of
+                // them at 65 536 frames, so K2 ends with three quarters of its waves gone for a group's time, and K1b then starts on an empty chip. K1b goes to a side stream BEHIND
+                // K2's launch instead: K2's one-wave workgroups are all resident at once, K1b's land where K2's have drained (two K2 waves' LDS make room for one of K1b's).
+                // 65 536 x 128 KiB: 24.35 -> 23.3 ms (K1b's 3.35 ms cost 2.4 beyond K2's end), frames of several blocks 150 -> 158 GB/s (r06p). The other order (K1b first)
+                // LOSES, 26.2 ms: K1b's short groups keep handing LDS to K2 piecemeal and the mix holds three waves per CU where K2 alone holds four.
+                if (!c->sideStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->sideStream[sidx], hipStreamNonBlocking));
+                hipStream_t sd = c->sideStream[sidx];
+                hipEvent_t evBin, evSide; HIP_TRY(hipEventCreateWithFlags(&evBin, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&evSide, hipEventDisableTiming));
+                if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); HIP_TRY(hipEventCreate(&evS0)); HIP_TRY(hipEventCreate(&evS1)); }
+                HIP_TRY(hipEventRecord(evBin, ss));
+                HIP_TRY(hipStreamWaitEvent(sd, evBin, 0));
+                if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
+                else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+                if (tm) { HIP_TRY(hipEventRecord(ev[1], ss)); HIP_TRY(hipEventRecord(evS0, ss)); }       // (two events at K2's end: one closes K2's pair, one opens K1b's)
+                hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, sd, pa);
+                if (tm) HIP_TRY(hipEventRecord(evS1, sd));
+                HIP_TRY(hipEventRecord(evSide, sd));
+                HIP_TRY(hipStreamWaitEvent(ss, evSide, 0));
+                (void)hipEventDestroy(evBin); (void)hipEventDestroy(evSide);
+                if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
+            } else {
+                if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
+                hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
+                if (tm) HIP_TRY(hipEventRecord(ev[1], ss));
+                if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
+                else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
+                if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
+            }
             if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
@@ -770,8 +799,16 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 // (ev[0], evh), K1b's (evh2, ev[1]), K3's (ev[2], ev[3]); K2's pair (ev[1], ev[2]) is borrowed and always drained
                 // before any destroy.
                 c->timer[2].pending.emplace_back(ev[0], evh);          // K1 (+ the two bin waves)
-                c->timer[7].pending.emplace_back(evh2, ev[1]);         // K1b
-                c->timer[3].shared.emplace_back(ev[1], ev[2]);
+                if (side) {
+                    // K2's pair is its own now; K1b's is what it costs the step: from K2's END (on the main stream) to its own end on the side stream -- its first part
+                    // runs inside K2's tail --, so that the kernels' times still add up to the step (a K1b that ends before K2 counts zero)
+                    c->timer[3].pending.emplace_back(evh2, ev[1]);
+                    c->timer[7].pending.emplace_back(evS0, evS1);
+                } else {
+                    c->timer[7].pending.emplace_back(evh2, ev[1]);         // K1b
+                    c->timer[3].shared.emplace_back(ev[1], ev[2]);
+                }
+                c->timer[9].shared.emplace_back(ev[0], ev[3]);             // the chunk's pipeline, K1's start to K3's end: what the step costs now that two of its kernels overlap
                 c->timer[4].pending.emplace_back(ev[2], ev[3]);
             }
         }

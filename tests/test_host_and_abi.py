@@ -194,6 +194,16 @@ def test_bench_line_shape_for_the_driver():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_step", "algorithmic_bytes_per_step", "dominant_kernel", "end_to_end"):
         assert k in rl, k
     assert rl["kernel_ms_per_step"] == 12.0 and rl["algorithmic_bytes_per_step"] == 11_000_000_000
+
+    class SpanCtx:          # K1b beside K2: the kernels' durations overlap, the library's span of the chunk's pipeline is the step's kernel time
+        def kernel_name(self, k):
+            return ["zhip_decode_frames_kernel", "zhip_decode_huf_kernel", "zhip_decode_seq_kernel", "zhip_decode_exec_kernel", bench.SPAN_NAME][k]
+
+    kt = {0: (0.5, 4), 1: (2.4, 4), 2: (8.5, 4), 3: (10.0, 4), 4: (21.0, 4)}
+    rl2, kdom2 = bench.roofline(SpanCtx(), kt, 4, 11_000_000_000, 22.0, 65536)
+    assert kdom2 == 3 and rl2["kernel_ms_per_step"] == 21.5 and bench.SPAN_NAME not in rl2["kernel"]
+    ko = bench.kernels_obj(SpanCtx(), kt)
+    assert "note" in ko[bench.SPAN_NAME] and "note" in ko["zhip_decode_huf_kernel"]
     line = {"metric": "m", "value": 350.0, "unit": "GB/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 24.4, "config": {"workload": "w"},
             "roofline": rl, "cpu_baseline": {"value": 25.0}, "kernels": {"x": {"pad": "y" * 4000}},
             "compress": {"value": 19.5, "ms_per_step": 440.0, "roofline": {"frac": 0.0033}, "regime": {"class": "fast", "match_kernel_ms_per_65536_frames": 405.7},
