@@ -644,6 +644,10 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // K1b beside K2 on a side stream (below) -- not for batches of small frames: their kernels are short, the three chunk slots overlap them already, and the
         // side streams only added queues (262 144 x 4 KiB with the dictionary: 199 -> 187 GB/s, r06p)
         const bool side = !(sizeHint && sizeHint <= 16384);
+        // (with the side stream a batch of several chunks runs them one after the other on ONE slot stream: two slots' kernels side by side mix K3 with the next chunk's
+        // K2 -- each slows the other, section 4.1 of DESIGN.md -- and the side stream has taken the tail the second slot used to fill. 131 072 x 128 KiB: 360 GB/s on two
+        // slots with or without the side stream, 365-366 on one slot with it, and half the scratch (r06s). A single 128 KiB frame: 3.6 -> 2.4 ms, its two chains run together)
+        if (side) slotMax = 1;
         // (two slots per 128 KiB decide how many frames make a chunk -- the slots are a pool, a frame may take more than its share; a chunk of
         // FEW frames has no pool to lean on and gets four: 64 x 128 KiB of changing data in one frame came as 235 blocks, r03x)
         // (the host-buffer API knows every frame's size and says how many slots the batch should need in all -- a batch of mostly small frames
