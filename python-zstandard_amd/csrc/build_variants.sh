@@ -10,6 +10,7 @@
 #   asm2k       -DZP_ASM_BYTES=2048  K3: 2 KiB batch assembly buffer
 #   own32       -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32   K3: own-lane items up to 32 bytes (round 2's shape)
 #   nohist      -DZP_HIST_KEEP=0u -DZP_HIST_SLIDE=0u  K3 without the LDS history in front of the batch (round 6 A/B)
+#   nok0        -DZHIP_K0=0          decode pipeline without K0 (the lane-per-frame parser pass in front of K1)
 #   dchunk32k   -DZHIP_DCHUNK=32768  decode pipeline in chunks of 32 768 frames (two slot streams) instead of one of 65 536
 #   e1l{16,32,64} -DZE_E1_LANES=n    lane-serial match kernel (fast-strategy batches): n frames per wave instead of 8
 # Emulator-verified shapes: tests/test_emu_kernels.py::test_decode_shape_variants_stay_correct.
@@ -56,6 +57,7 @@ for v in "$@"; do
     e2prof) build e2prof -DZE_PROF_STREAM & ;;             # E2 with its sequence-stream rounds timed in four parts (ZHIP_PROF=1)
     e2w3) build e2w3 -DZE_E2_MINWAVES=3 & ;;               # E2 (entropy stage) at three / five waves per SIMD (default 4: 127 VGPRs + 160 bytes of scratch)
     e2w5) build e2w5 -DZE_E2_MINWAVES=5 & ;;
+    nok0) build nok0 -DZHIP_K0=0 & ;;                    # decode without K0: K1's lane 0 parses the Huffman weights and the sequence distributions itself (rounds 1-5; A/B of round 6: profiles/r06w_*)
     dchunk32k) build dchunk32k -DZHIP_DCHUNK=32768 & ;;    # decode: chunks of 32 768 frames on the slot streams (round 6 A/B with K1b beside K2: profiles/r06q_*)
     e1l16) build e1l16 -DZE_E1_LANES=16 & ;;
     e1l32) build e1l32 -DZE_E1_LANES=32 & ;;

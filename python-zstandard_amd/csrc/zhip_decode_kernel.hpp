@@ -164,9 +164,10 @@ ZH_DEV uint32_t zd_fwd_peek(ZdFwd& f, uint32_t n)                     // n <= 16
     return (uint32_t)(f.w >> off) & ((1u << n) - 1);
 }
 
-// lane 0 only. Parses an FSE distribution (RFC 8878 4.1.1) into L.norm[]. Returns bytes used or -err.
+// One lane. Parses an FSE distribution (RFC 8878 4.1.1) into norm[0 .. 64). Returns bytes used or -err.
 // *pMax in: alphabet limit, out: last symbol present. *pLog out.
-ZH_DEVFN int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, uint32_t* pMax, uint32_t* pLog)
+// (K1 calls it on lane 0 with the wave's L.norm; K0 -- zp_pre_body -- on every lane with the lane's own record)
+ZH_DEVFN int zd_read_ncount_to(int16_t* norm, const uint8_t* src, const uint8_t* end, uint32_t* pMax, uint32_t* pLog)
 {
     if (src >= end) return -ZE_SRC_SIZE_WRONG;
     ZdFwd f; zd_fwd_init(f, src, end);
@@ -181,7 +182,7 @@ ZH_DEVFN int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, ui
         if (prev0) {
             for (;;) {
                 uint32_t r = zd_fwd_peek(f, 2); f.bitpos += 2;
-                for (uint32_t k = 0; k < r && sym <= maxS; k++) L.norm[sym++] = 0;
+                for (uint32_t k = 0; k < r && sym <= maxS; k++) norm[sym++] = 0;
                 if (r != 3) break;
                 if (f.bitpos > srcBits) return -ZE_CORRUPTION;
             }
@@ -199,16 +200,17 @@ ZH_DEVFN int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, ui
         count--;
         remaining -= count < 0 ? -count : count;
         if (remaining < 1) return -ZE_CORRUPTION;
-        L.norm[sym++] = (int16_t)count;
+        norm[sym++] = (int16_t)count;
         prev0 = (count == 0);
         while (remaining < threshold) { nbBits--; threshold >>= 1; }
         if (((f.bitpos + 7) >> 3) > (uint32_t)(end - src)) return -ZE_CORRUPTION;
     }
     if (remaining != 1) return -ZE_CORRUPTION;
-    for (uint32_t s = sym; s < 64; s++) L.norm[s] = 0;
+    for (uint32_t s = sym; s < 64; s++) norm[s] = 0;
     *pMax = sym - 1;
     return (int)((f.bitpos + 7) >> 3);
 }
+ZH_DEV int zd_read_ncount(ZdLDS& L, const uint8_t* src, const uint8_t* end, uint32_t* pMax, uint32_t* pLog) { return zd_read_ncount_to(L.norm, src, end, pMax, pLog); }
 
 // Wave-parallel construction of an FSE decoding table from L.norm[0..maxSym] (all lanes call).
 // One lane per symbol for the bookkeeping, one lane per cell for spreading and state numbering.
@@ -349,7 +351,8 @@ ZH_DEV bool zd_pb_done(const ZdPBits& b) { return b.ptr == b.start && b.used == 
 
 // ------------------------------------------------------------------------------------------ Huffman
 // Reads a tree description into L.weights (all lanes call). Returns bytes used or -err; *pCount = #weights incl. last.
-ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize, uint32_t* pCount, uint32_t* pLog)
+// `pre` (K1 of the pipeline, round 6): K0's record of the frame -- when it holds the weights of the description at block offset `at`, they are copied and nothing is parsed
+ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize, uint32_t* pCount, uint32_t* pLog, const ZpPre* pre = nullptr, uint32_t at = 0)
 {
     const uint32_t lane = zh_lane();
     if (srcSize < 1) return -ZE_CORRUPTION;
@@ -364,6 +367,14 @@ ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize,
     } else {
         used = 1 + hb;
         if (used > srcSize || hb < 2) return -ZE_CORRUPTION;
+        if (pre && pre->wCount && pre->wAt == at) {
+            n = pre->wCount;
+            zh_sync();
+            ((uint32_t*)L.weights)[lane] = ((const uint32_t*)pre->weights)[lane];       // (all 256 bytes: what lies past the count is never read)
+#ifdef ZHIP_EMU
+            if (lane == 0) zd_stat[10]++;                                                // (test hook [10]: Huffman weights taken from K0's record)
+#endif
+        } else {
         // Round 4: the description (< 128 bytes) is copied to LDS by the whole wave and lane 0 parses THAT. Parsed in place, every field of the
         // distribution and every refill of the weights' bit reader below was a dependent global-memory round trip (~300 of them per frame with
         // the three sequence tables, ~500 cycles each): K1's time is frames per resident wave x the latency of ONE frame's chain (210 K cycles).
@@ -413,6 +424,7 @@ ZH_DEVFN int zd_read_huf_weights(ZdLDS& L, const uint8_t* src, uint32_t srcSize,
         zh_sync();
         n = L.misc[0];
         if (n == 0xFFFFFFFFu || n == 0) return -ZE_CORRUPTION;
+        }
     }
     zh_sync();
     // implied last weight: the sum of 2^(w-1) must complete to a power of two
@@ -513,7 +525,8 @@ ZH_DEVFN bool zd_huf_stream(const uint16_t* huf, uint32_t log, const uint8_t* sr
 // `defer` (pipeline K1 only): instead of decoding Huffman streams here, hand the table and the stream location to K1b.
 struct ZdLitDefer { uint16_t* table; uint32_t maxLog; uint32_t taken, log, four, streamBytes; const uint8_t* streams;
                     const uint16_t* prevTable; uint32_t prevLog;      // prevTable: the "previous" table of a treeless block, ready-made (a dictionary's)
-                    uint32_t shared, shareOK; };                      // shareOK: the caller reads prevTable where it lies (no copy into `table`); shared: that happened
+                    uint32_t shared, shareOK;                         // shareOK: the caller reads prevTable where it lies (no copy into `table`); shared: that happened
+                    const ZpPre* pre; };                              // K0's record of the frame or null (zd_read_huf_weights)
 ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t srcSize, uint8_t* lit, uint32_t blockMax, ZdProf& P,
                          ZdLitDefer* defer = nullptr)
 {
@@ -551,7 +564,7 @@ ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t src
         if (st.hufCount == 0) return -ZE_DICT_CORRUPTED;
     } else {
         uint32_t cnt = 0, lg = 0;
-        int r = zd_read_huf_weights(L, p, left, &cnt, &lg);
+        int r = zd_read_huf_weights(L, p, left, &cnt, &lg, defer ? defer->pre : nullptr, hdr);
         if (r < 0) return -ZE_CORRUPTION;
         p += r; left -= (uint32_t)r; st.hufCount = cnt;
     }
@@ -612,7 +625,8 @@ ZH_DEVFN int zd_literals(ZdLDS& L, ZdState& st, const uint8_t* src, uint32_t src
 
 // ------------------------------------------------------------------------------------------ sequence tables
 // one of the three symbol-compression modes (RFC 8878 3.1.1.3.2.1). All lanes call. Returns bytes used or -err.
-ZH_DEVFN int zd_seq_table(ZdLDS& L, uint32_t mode, int kind, uint32_t* pLog, const uint8_t* p, const uint8_t* end)
+// `pre`: K0's record of the frame or null -- a distribution it parsed is taken from there (zp_block_tables hands the record over only for the block it was made from)
+ZH_DEVFN int zd_seq_table(ZdLDS& L, uint32_t mode, int kind, uint32_t* pLog, const uint8_t* p, const uint8_t* end, const ZpPre* pre = nullptr)
 {
     const uint32_t lane = zh_lane();
     uint32_t* table = L.fse + (kind == ZD_KIND_LL ? ZD_FSE_LL : kind == ZD_KIND_ML ? ZD_FSE_ML : ZD_FSE_OF);
@@ -642,13 +656,22 @@ ZH_DEVFN int zd_seq_table(ZdLDS& L, uint32_t mode, int kind, uint32_t* pLog, con
     }
     if (mode == 2) {
         zh_sync();
-        if (lane == 0) {
-            uint32_t ms = maxSym, tl = 0;
-            int r = zd_read_ncount(L, p, end, &ms, &tl);
-            L.misc[0] = (uint32_t)r; L.misc[1] = ms; L.misc[2] = tl;
+        int r; uint32_t ms, tl;
+        if (pre && pre->t[kind].valid) {
+            L.norm[lane] = pre->norm[kind][lane];
+            r = (int)pre->t[kind].used; ms = pre->t[kind].maxSym; tl = pre->t[kind].log;
+#ifdef ZHIP_EMU
+            if (lane == 0) zd_stat[11]++;                                                // (test hook [11]: sequence distributions taken from K0's record)
+#endif
+        } else {
+            if (lane == 0) {
+                uint32_t ms0 = maxSym, tl0 = 0;
+                int r0 = zd_read_ncount(L, p, end, &ms0, &tl0);
+                L.misc[0] = (uint32_t)r0; L.misc[1] = ms0; L.misc[2] = tl0;
+            }
+            zh_sync();
+            r = (int)L.misc[0]; ms = L.misc[1]; tl = L.misc[2];
         }
-        zh_sync();
-        int r = (int)L.misc[0]; uint32_t ms = L.misc[1], tl = L.misc[2];
         if (r < 0 || tl > maxLog) return -ZE_CORRUPTION;
         if (zd_build_fse(L, table, ms, tl, kind) < 0) return -ZE_CORRUPTION;
         *pLog = tl; return r;

@@ -175,9 +175,11 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
             zd_stage_wave(stg, sp, hn);
             zh_sync();
             const uint8_t* lp = stg; const uint8_t* const lend = stg + hn;
-            int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
-            q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
-            q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, lp, lend); if (q < 0) return -q; sp += q; lp += q;
+            // (K0's record, where one was made from THIS block's descriptions: the distributions come parsed, lane 0 walks nothing)
+            const ZpPre* const spre = df.pre && df.pre->seqAt == (uint32_t)(sp - (src + pos)) ? df.pre : nullptr;
+            int q = zd_seq_table(L, modes >> 6, ZD_KIND_LL, &st.llLog, lp, lend, spre); if (q < 0) return -q; sp += q; lp += q;
+            q = zd_seq_table(L, (modes >> 4) & 3, ZD_KIND_OF, &st.ofLog, lp, lend, spre); if (q < 0) return -q; sp += q; lp += q;
+            q = zd_seq_table(L, (modes >> 2) & 3, ZD_KIND_ML, &st.mlLog, lp, lend, spre); if (q < 0) return -q; sp += q; lp += q;
             if (sp >= send) return ZE_CORRUPTION;
             zh_sync();
             // LDS cells (base | nbBits << 10 | ...) -> 2-byte cells (symbol << 10 | x), x = (base + size) >> nbBits, two per store
@@ -350,6 +352,153 @@ ZH_DEVFN void zp_lit_lanes_body(const ZhipPipeArgs& a)
     }
 }
 
+// ------------------------------------------------------------------------------------------ K0 (a LANE per frame: K1's serial parsers, 64 frames at a time)
+// K1 gives a frame a whole wave, and 41 % of that wave's time was ONE lane walking bit fields: the Huffman weights' description (a distribution, a 64-cell FSE
+// table, ~100 weights decoded by two interleaved states) and the three sequence distributions (`profiles/r06v_k1_fine_phase_timers.txt`). Those walks need no wave:
+// here every lane does them for a frame of its own and leaves the results in the frame's ZpPre record; K1 then copies weights and counts and goes straight to its
+// wave-parallel table builders. K0 checks what it needs to find the descriptions and to trust its own results, and on ANYTHING else -- a check that fails, a layout
+// it does not know, a description that does not parse -- leaves that part of the record empty: K1 parses it itself and finds, and words, the error as it always
+// did. Frames of one compressed block (the single-block pipeline's); RFC 8878 3.1.1.3.1 / 3.1.1.3.2 / 4.1.1 / 4.2.1, zstd.c:45767, :46328.
+struct ZpPreLane { int16_t wnorm[64]; uint16_t cell[64]; uint8_t symAt[64]; uint8_t next[16]; uint32_t pad; };      // 340 bytes = 85 dwords: the lanes' arrays start in different banks
+struct ZpPreLDS { ZpPreLane lane[64]; };
+
+// the weights: distribution -> FSE decoding table (FSE_buildDTable's serial form: low-probability symbols from the top, the spread walk, states numbered in table order --
+// cell for cell what zd_build_fse makes wave-parallel) -> the two-state decode of zd_read_huf_weights, over the description where it lies
+ZH_DEV void zp_pre_weights(ZpPre& R, ZpPreLane& S, const uint8_t* desc, uint32_t hb, uint32_t at)
+{
+    uint32_t maxS = 63, tl = 0;
+    const int r = zd_read_ncount_to(S.wnorm, desc, desc + hb, &maxS, &tl);
+    if (r < 0 || tl > 6 || maxS > 12) return;
+    const uint32_t size = 1u << tl, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint32_t high = size - 1, total = 0;
+    for (uint32_t q = 0; q <= maxS; q++) {
+        const int n = S.wnorm[q];
+        if (n == -1) { S.symAt[high--] = (uint8_t)q; S.next[q] = 1; total++; }
+        else { S.next[q] = (uint8_t)n; total += (uint32_t)n; }
+    }
+    if (total != size) return;
+    uint32_t pos = 0;
+    for (uint32_t q = 0; q <= maxS; q++) {
+        const int n = S.wnorm[q];
+        for (int k = 0; k < n; k++) {
+            S.symAt[pos] = (uint8_t)q;
+            do pos = (pos + step) & mask; while (pos > high);
+        }
+    }
+    for (uint32_t u = 0; u < size; u++) {
+        const uint32_t q = S.symAt[u], x = S.next[q];
+        S.next[q] = (uint8_t)(x + 1);
+        const uint32_t nb = tl - (uint32_t)zh_highbit32(x);
+        S.cell[u] = (uint16_t)(((x << nb) - size) | (nb << 6) | (q << 9));
+    }
+    ZdBits b; uint32_t cnt = 0;
+    if (!zd_bits_init(b, desc + r, hb - (uint32_t)r)) return;
+    zd_bits_reload(b);
+    uint32_t s1 = zd_bits_peek(b, tl); b.used += tl;
+    uint32_t s2 = zd_bits_peek(b, tl); b.used += tl;
+    if (tl == 0) { s1 = s2 = 0; }
+    int64_t left;
+    for (;;) {
+        if (b.used >= 32) zd_bits_reload(b);
+        left = (int64_t)(b.ptr - b.start) * 8 + 64 - (int64_t)b.used;
+        const uint32_t e1 = S.cell[s1], nb1 = (e1 >> 6) & 7;
+        if (cnt > 253) return;
+        R.weights[cnt++] = (uint8_t)(e1 >> 9);
+        const uint32_t v1 = nb1 ? zd_bits_peek(b, nb1) : 0; b.used += nb1; left -= nb1;
+        s1 = (e1 & 63) + v1;
+        const uint32_t e2 = S.cell[s2], nb2 = (e2 >> 6) & 7;
+        if (left < 0) { R.weights[cnt++] = (uint8_t)(e2 >> 9); break; }
+        if (cnt > 253) return;
+        R.weights[cnt++] = (uint8_t)(e2 >> 9);
+        const uint32_t v2 = nb2 ? zd_bits_peek(b, nb2) : 0; b.used += nb2; left -= nb2;
+        s2 = (e2 & 63) + v2;
+        if (left < 0) { R.weights[cnt++] = (uint8_t)(S.cell[s1] >> 9); break; }
+    }
+    R.wAt = at; R.wCount = cnt;
+}
+
+ZH_DEV void zp_pre_one(const ZhipPipeArgs& a, uint32_t f, ZpPre& R, ZpPreLane& S)
+{
+    R.wCount = 0; R.wAt = 0; R.seqAt = 0; R.t[0].valid = 0; R.t[1].valid = 0; R.t[2].valid = 0;
+    const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+    const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
+    if (srcSize64 > 0x7FFFFFFFull) return;
+    const uint32_t srcSize = (uint32_t)srcSize64;
+    ZpHdr h;
+    if (zp_frame_header(a, src, srcSize, h) || h.skippable) return;
+    uint32_t pos = h.pos;
+    if (pos + 3 > srcSize) return;
+    const uint32_t bh = zh_ld24(src + pos); pos += 3;
+    const uint32_t bs = bh >> 3;
+    if (!(bh & 1) || ((bh >> 1) & 3) != 2) return;                      // one block, compressed
+    if (pos + bs > srcSize || bs > h.blockMax || bs < 2) return;
+    const uint8_t* const b = src + pos;
+    const uint32_t b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3;
+    uint32_t used, regen;
+    if (lt < 2) {
+        uint32_t hdr;
+        if (fmt == 1) { hdr = 2; regen = zh_ld16(b) >> 4; }
+        else if (fmt == 3) { if (bs < 3) return; hdr = 3; regen = zh_ld24(b) >> 4; }
+        else { hdr = 1; regen = b0 >> 3; }
+        if (regen > h.blockMax) return;
+        if (lt == 0) { if (hdr + regen > bs) return; used = hdr + regen; }
+        else { if (hdr + 1 > bs) return; used = hdr + 1; }
+    } else {
+        if (bs < 5) return;
+        const uint32_t v = zh_ld32(b);
+        uint32_t hdr, four, csize;
+        if (fmt < 2) { hdr = 3; four = fmt; regen = (v >> 4) & 0x3FF; csize = (v >> 14) & 0x3FF; }
+        else if (fmt == 2) { hdr = 4; four = 1; regen = (v >> 4) & 0x3FFF; csize = v >> 18; }
+        else { hdr = 5; four = 1; regen = (v >> 4) & 0x3FFFF; csize = (v >> 22) + ((uint32_t)b[4] << 10); }
+        if (regen > h.blockMax || regen > ZF_BLOCK_MAX) return;
+        if (four ? regen < 6 : regen == 0) return;
+        if (hdr + csize > bs) return;
+        used = hdr + csize;
+        if (lt == 2 && csize >= 1) {                                    // a Huffman table of its own; FSE-compressed weights are the serial kind (4-bit ones K1 unpacks by the wave)
+            const uint32_t hb = b[hdr];
+            if (hb >= 2 && hb < 128 && 1 + hb <= csize) zp_pre_weights(R, S, b + hdr + 1, hb, hdr);
+        }
+    }
+    uint32_t sp = used; const uint32_t send = bs;                        // (relative to the block's first byte)
+    if (sp >= send) return;
+    uint32_t nbSeq = b[sp++];
+    if (nbSeq > 127) {
+        if (nbSeq == 255) { if (sp + 2 > send) return; nbSeq = zh_ld16(b + sp) + 0x7F00; sp += 2; }
+        else { if (sp >= send) return; nbSeq = ((nbSeq - 128) << 8) + b[sp++]; }
+    }
+    if (nbSeq == 0 || nbSeq > ZP_SEQ_CAP - 16 || sp >= send) return;
+    const uint32_t modes = b[sp++];
+    if (modes & 3) return;
+    // (K1 parses the three descriptions from an LDS copy of at most 256 bytes: the same bound here, so both read the same bytes)
+    const uint32_t hn = send - sp < 256u ? send - sp : 256u;
+    const uint8_t* lp = b + sp; const uint8_t* const lend = lp + hn;
+    R.seqAt = sp;
+#pragma unroll
+    for (int kind = 0; kind < 3; kind++) {
+        const uint32_t mode = kind == ZD_KIND_LL ? modes >> 6 : kind == ZD_KIND_OF ? (modes >> 4) & 3 : (modes >> 2) & 3;
+        if (mode == 3) return;                                          // "repeat" without a dictionary: K1's to refuse
+        if (mode == 1) { if (lp >= lend) return; lp += 1; }
+        if (mode == 2) {
+            uint32_t ms = kind == ZD_KIND_LL ? ZF_MAXLL : kind == ZD_KIND_ML ? ZF_MAXML : ZF_MAXOFF, tl = 0;
+            const int r = zd_read_ncount_to(R.norm[kind], lp, lend, &ms, &tl);
+            if (r < 0) return;
+            R.t[kind].maxSym = ms; R.t[kind].log = tl; R.t[kind].used = (uint32_t)r; R.t[kind].valid = 1;
+            lp += r;
+        }
+    }
+}
+
+ZH_DEVFN void zp_pre_body(const ZhipPipeArgs& a, ZpPreLDS& L)
+{
+    const uint32_t lane = zh_lane();
+    for (;;) {
+        const uint32_t base = zh_first(zh_atomic_add(a.counters + 11, lane == 0 ? 64u : 0u));
+        if (base >= a.count) break;
+        const uint32_t i = base + lane;
+        if (i < a.count) zp_pre_one(a, a.first + i, a.pre[i], L.lane[lane]);
+    }
+}
+
 ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
 {
     const uint32_t lane = zh_lane();
@@ -422,6 +571,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             ZD_T(P, ZP_HEADER);
             ZdLitDefer df; df.table = a.hufTables + (size_t)i * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
             df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = nullptr; df.prevLog = 0; df.shared = 0; df.shareOK = 1;
+            df.pre = a.pre ? a.pre + i : nullptr;
             const ZhipDictEntropy* const de = a.dictEntropy;
             if (de) {                                                       // a dictionary with entropy tables: they are the block's "previous" tables
                 st.hufCount = de->hufCount;
@@ -544,7 +694,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
                 else if (bs < 2) err = ZE_CORRUPTION;
                 else {
                     ZdLitDefer df; df.table = a.hufTables + (size_t)t * ZP_HUF_CELLS; df.maxLog = ZP_HUF_LOGMAX; df.taken = 0;
-                    df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = prevTable; df.prevLog = prevLog; df.shared = 0; df.shareOK = 0;
+                    df.log = 0; df.four = 0; df.streamBytes = 0; df.streams = src; df.prevTable = prevTable; df.prevLog = prevLog; df.shared = 0; df.shareOK = 0; df.pre = nullptr;
                     err = zp_block_tables(a, L, st, df, src, pos, bs, blockMax, t, m, P, false, true);
                     if (err == (int)ZP_RC_FALLBACK) { err = 0; fallback = true; }       // the chunk's literal room is used up: the generic kernel's frame (its items stay unused)
                     else if (!err) {

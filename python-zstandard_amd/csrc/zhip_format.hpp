@@ -260,6 +260,19 @@ struct ZpFrameRec {
 #define ZP_SYM_TOP ZP_SYM_REP(2)                          // values above it (K2's "no such offset" = 0xFFFFFFFF cut to 29 bits) are refused
 #define ZP_MB_MAXBLOCKS 4096u                             // frames of more blocks are the generic kernel's
 #define ZP_RC_FALLBACK 0x7FFF0002                         // K3's "hand this frame to the generic kernel"
+// K0's record of a frame (round 6; zp_pre_body in zhip_decode_pipeline.hpp): what K1's two SERIAL parsers leave behind -- lane 0's walk over the Huffman weights' description
+// (distribution, 64-cell FSE table, the weights' two-state decode) and over the three sequence distributions -- made by a LANE per frame one kernel earlier, 64 frames per
+// wave, so that K1's wave only builds tables. A part that K0 did not finish (an error, an unusual layout, a table mode that needs no parse) has its count / valid flag at 0
+// and K1 parses it itself, as it always did: every error is still found, and worded, by K1's own code.
+struct alignas(16) ZpPre {
+    uint8_t weights[256];               // the FSE-decoded Huffman weights (zd_read_huf_weights' L.weights[0 .. wCount), before the implied last weight)
+    int16_t norm[3][64];                // [ZD_KIND_LL / ZD_KIND_OF / ZD_KIND_ML]: zd_read_ncount's L.norm[0 .. 64)
+    uint32_t wCount;                    // 0: weights not made here; else their count
+    uint32_t wAt;                       // where the weights' description lies, relative to the block's first byte (K1 uses the record only for THAT description)
+    struct { uint32_t valid, maxSym, log, used; } t[3];     // by kind: the distribution's last symbol, table log, bytes used (zd_read_ncount's results)
+    uint32_t seqAt;                     // where the first distribution lies, relative to the block's first byte
+    uint32_t pad;
+};
 struct ZhipPipeArgs {
     const uint8_t* src; const uint64_t* srcSegs;
     uint8_t* dst; const uint64_t* dstSegs;
@@ -292,6 +305,7 @@ struct ZhipPipeArgs {
     ZpFrameRec* frameRecs;      // count
     uint64_t maxWindowSize;
     uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
+    ZpPre* pre;                 // chunk : K0's records (null: no K0 ran -- the several-block mode, dictionary batches -- and K1 parses everything itself); counters[11] is K0's work counter
     uint32_t k1Lanes;           // != 0 (dictionary batches, round 6): zhip_decode_lit_lanes_kernel ran first -- a LANE walked every frame whose tables are all the
                                 // dictionary's ("treeless" literals, every sequence table "repeat": nothing to build) -- and K1 takes only the frames it listed in `order`
                                 // (counters[10] of them; counters[9] is that kernel's work counter)

@@ -34,6 +34,11 @@ ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_kernel(ZhipPipeArgs a)
     zp_lit_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_lit_lanes_kernel(ZhipPipeArgs a) { zp_lit_lanes_body(a); }      // K1's lane-per-frame pass over dictionary batches
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_pre_kernel(ZhipPipeArgs a)           // K0: a lane per frame walks what K1's lane 0 used to (Huffman weights, sequence distributions)
+{
+    __shared__ ZpPreLDS L;
+    zp_pre_body(a, L);
+}
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_bin_kernel(ZhipPipeArgs a)
 {
     __shared__ ZpBinLDS L;
@@ -261,6 +266,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_NSLOT
 #define ZHIP_NSLOT 3
 #endif
+#ifndef ZHIP_K0
+#define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
+#endif
 #ifndef ZHIP_DCHUNK
 #define ZHIP_DCHUNK 65536        // frames per chunk of the decode pipeline (r02zl: 301 GB/s in one 65 536-frame chunk against 297 in two of 32 768: longer launches amortise their tails, and the two chunk slots overlap little anyway)
 #endif
@@ -299,7 +307,7 @@ struct zhip_ctx {
     int decBlocksPerCU = 0;
     int encBlocksPerCU = 0;
     int k1PerCU = 0, k2PerCU = 0, k3PerCU = 0;
-    DevBuf pipeMeta, pipeLit, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases;
+    DevBuf pipeMeta, pipeLit, pipeCounters, pipeFallback, pipeFse, pipeOrder, pipeHuf, pipeOrderLit, pipeItemFrame, pipeItemReps, pipeFrameRecs, pipeBases, pipePre;
     hipStream_t slotStream[ZHIP_NSLOT] = {};
     hipStream_t sideStream[ZHIP_NSLOT] = {};
     DevBuf encWorkspace, encMeta, encArena, encTables, encBigList, encBigWs, encFlatTables, encE1List, encMbBlocks, encMbCount, encMbSeqs;
@@ -357,7 +365,7 @@ struct zhip_ctx {
     KTimer timer[ZHIP_NTIMER];   // 0 fused decode, 1 fused encode, 2 K1 literals, 3 K2 sequences, 4 K3 execution, 5 E1 match, 6 E2 entropy, 7 K1b Huffman streams, 8 the flat match kernel, 9 the decode pipeline of a chunk from K1's start to K3's end (K1b runs beside K2)
     size_t device_bytes() const
     {
-        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &encWorkspace, &encMeta, &encArena,
+        const DevBuf* all[] = {&pipeMeta, &pipeLit, &pipeCounters, &pipeFallback, &pipeFse, &pipeOrder, &pipeHuf, &pipeOrderLit, &pipeItemFrame, &pipeItemReps, &pipeFrameRecs, &pipeBases, &pipePre, &encWorkspace, &encMeta, &encArena,
                                &encTables, &encBigList, &encBigWs, &encFlatTables, &encE1List, &encMbBlocks, &encMbCount, &encMbSeqs, &scratch, &counter, &cdictBlob, &cdictEntropy, &cdictDigest, &cdictTables,
                                &dictBlob, &dictEntropy, &dictTables, &hSrc, &hDst, &hSegs, &hStatus, &hDense};
         size_t n = 0;
@@ -428,7 +436,7 @@ extern "C" void zhip_ctx_destroy(zhip_ctx* c)
     for (int i = 0; i < ZHIP_NTIMER; i++) drain_timer(c->timer[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->slotStream[i]) (void)hipStreamDestroy(c->slotStream[i]);
     for (int i = 0; i < ZHIP_NSLOT; i++) if (c->sideStream[i]) (void)hipStreamDestroy(c->sideStream[i]);
-    c->pipeMeta.release(); c->pipeLit.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release();
+    c->pipeMeta.release(); c->pipeLit.release(); c->pipeCounters.release(); c->pipeFallback.release(); c->pipeFse.release(); c->pipeOrder.release(); c->pipeHuf.release(); c->pipeOrderLit.release(); c->pipeItemFrame.release(); c->pipeItemReps.release(); c->pipeFrameRecs.release(); c->pipeBases.release(); c->pipePre.release();
     c->scratch.release(); c->counter.release(); c->encWorkspace.release(); c->encMeta.release(); c->encArena.release(); c->encTables.release(); c->encBigList.release(); c->encBigWs.release(); c->encFlatTables.release(); c->encE1List.release(); c->encMbBlocks.release(); c->encMbCount.release(); c->encMbSeqs.release(); c->dictBlob.release(); c->dictEntropy.release(); c->dictTables.release();
     c->cdictBlob.release(); c->cdictEntropy.release(); c->cdictDigest.release(); c->cdictTables.release();
     c->hSrc.release(); c->hDst.release(); c->hSegs.release(); c->hStatus.release(); c->hDense.release();
@@ -685,6 +693,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         if (c->pipeMeta.reserve(nslot * slots * sizeof(ZdMeta)) || c->pipeLit.reserve(nslot * arenaBytes + ZP_LIT_FRONT) || c->pipeCounters.reserve((8 + (size_t)ZHIP_NSLOT * ZP_CNT_WORDS) * 4) || c->pipeFallback.reserve(n * 4 + 16) ||
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
+        // K0's records (one per frame; not in the several-block mode, whose K1 walks a frame's blocks in order, nor for dictionary batches, whose lane pass finishes what has no table of its own)
+        const bool pre = ZHIP_K0 && !mb && !c->dictHasEntropy;
+        if (pre && c->pipePre.reserve(nslot * slots * sizeof(ZpPre))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
                    c->pipeFrameRecs.reserve(nslot * chunk * sizeof(ZpFrameRec)))) return g_reserveRc;
         for (int sidx = 0; sidx < nslot; sidx++) if (!c->slotStream[sidx]) HIP_TRY(hipStreamCreateWithFlags(&c->slotStream[sidx], hipStreamNonBlocking));
@@ -744,6 +755,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             // dictionary batches: a lane-per-frame pass first (zhip_decode_lit_lanes_kernel: frames whose tables are all the dictionary's are nothing but header
             // arithmetic), K1 then only over the frames that pass listed
             pa.k1Lanes = !mb && c->dictHasEntropy ? 1u : 0u;
+            pa.pre = pre ? (ZpPre*)c->pipePre.p + (size_t)sidx * slots : nullptr;
             const size_t tasks1 = cnt;
             const uint32_t g1 = (uint32_t)(tasks1 < g1m ? tasks1 : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
@@ -757,6 +769,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             }
             if (mb) hipLaunchKernelGGL(zhip_decode_lit_mb_kernel, dim3(g1), dim3(64), 0, ss, pa);
             else {
+                if (pa.pre) { const size_t w = (cnt + 63) / 64, gm = (size_t)c->numCU * 7; hipLaunchKernelGGL(zhip_decode_pre_kernel, dim3((uint32_t)(w < gm ? w : gm)), dim3(64), 0, ss, pa); }      // (7 waves of 21.3 KiB of LDS per CU)
                 if (pa.k1Lanes) { const size_t w = (cnt + 63) / 64; hipLaunchKernelGGL(zhip_decode_lit_lanes_kernel, dim3((uint32_t)(w < g1m ? w : g1m)), dim3(64), 0, ss, pa); }
                 hipLaunchKernelGGL(zhip_decode_lit_kernel, dim3(g1), dim3(64), 0, ss, pa);
             }

@@ -128,6 +128,10 @@ static uint32_t g_k1Lanes = 1;                   // dictionary batches: K1's lan
 static void k1lanes_lane(void* p) { zp_lit_lanes_body(*(const ZhipPipeArgs*)p); }
 extern "C" void emu_set_k1_lanes(uint32_t v) { g_k1Lanes = v; }
 static void k1_lane(void* p) { zp_lit_body(*(const ZhipPipeArgs*)p, g_lds); }
+static ZpPreLDS g_prelds;
+static uint32_t g_k0 = 1;                        // K0 (zp_pre_body: a lane per frame walks K1's serial descriptions) before K1 -- as zhip_decompress_batch_device runs it; 0: K1 parses everything itself
+static void k0_lane(void* p) { zp_pre_body(*(const ZhipPipeArgs*)p, g_prelds); }
+extern "C" void emu_set_k0(uint32_t v) { g_k0 = v; }
 static void kb_lane(void* p) { zp_bin_body(*(const ZhipPipeArgs*)p, g_binlds); }
 static ZpHufKernelLDS g_huflds;
 static void kh_lane(void* p) { zp_huf_body(*(const ZhipPipeArgs*)p, g_huflds); }
@@ -198,6 +202,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         a.dictEntropy = g_ddEnt ? &g_ddEntropy : nullptr; a.dictTables = g_ddEnt ? &g_ddTables : nullptr;
     }
     a.k1Lanes = g_k1Lanes && a.dictEntropy ? 1u : 0u;       // (mirrors zhip_decompress_batch_device; cleared below in the several-block mode)
+    ZpPre* pre = nullptr;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (uint32_t q = 0; q < ZP_CNT_WORDS; q++) counters[q] = 0;
@@ -205,6 +210,13 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         a.itemCap = mb ? a.count * g_mbPerFrame : 0u;
         if (mb) a.k1Lanes = 0;
         if (a.k1Lanes) zhemu::run_grid(nBlocks, k1lanes_lane, &a);
+        a.pre = nullptr;
+        if (g_k0 && !mb && !a.dictEntropy) {          // (mirrors zhip_decompress_batch_device)
+            if (!pre) pre = (ZpPre*)malloc(slots * sizeof(ZpPre));
+            memset(pre, 0xA5, slots * sizeof(ZpPre)); memset(&g_prelds, 0xA5, sizeof g_prelds);
+            a.pre = pre;
+            zhemu::run_grid(nBlocks, k0_lane, &a);
+        }
         zhemu::run_grid(nBlocks, mb ? k1mb_lane : k1_lane, &a);
         zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
@@ -224,7 +236,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     zhemu::run_grid(nBlocks, dec_lane, &l);
     int nfb = (int)counters[ZP_CNT_WORDS];
     free(g.scratch); free(a.meta); free(litAlloc); free(a.fallbackList); free(a.fseTables); free(a.order); free(a.hufTables); free(a.orderLit);
-    free(a.itemFrame); free(a.itemReps); free(a.frameRecs); free(a.bases);
+    free(a.itemFrame); free(a.itemReps); free(a.frameRecs); free(a.bases); free(pre);
     return nfb;
 }
 

@@ -180,3 +180,11 @@ Emu.set_mb_compress = _emu_set_mb_compress
 Emu.set_mb_hint = _emu_set_mb_hint
 Emu.set_dict_slot_max = _emu_set_dict_slot_max
 Emu.stat = _emu_stat
+
+
+def _emu_set_k0(self, v):
+    """1 (default, as the product): K0 -- a lane per frame walks K1's serial descriptions -- runs before K1; 0: K1 parses everything itself"""
+    self.lib.emu_set_k0(C.c_uint32(v))
+
+
+Emu.set_k0 = _emu_set_k0

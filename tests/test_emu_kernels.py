@@ -799,3 +799,57 @@ def test_k1_lane_per_frame_for_dictionary_batches(emu, ref, corpus):
     finally:
         emu.lib.emu_set_k1_lanes(C.c_uint32(1))
         emu.set_ddict(None)
+
+
+def test_k0_lane_per_frame_parsers_agree_with_k1s_own(emu, ref, corpus):
+    """Round 6: K0 (zp_pre_body) -- a LANE per frame walks what K1's lane 0 used to: the Huffman weights' description (distribution, 64-cell FSE table, two-state
+    decode) and the three sequence distributions -- and K1 takes weights and counts from its record. With and without K0 the pipeline must give the same bytes AND the
+    same status for every frame: good ones of every class and level, frames whose descriptions are damaged (bit flips confined to the description regions, the tail cut),
+    frames with 4-bit weights, RLE / predefined tables, raw / RLE literals; and K1 must in fact have taken the records (test hooks [10] / [11])."""
+    import numpy as np
+    rng = np.random.default_rng(31)
+    raws = []
+    for i in range(40):
+        base = corpus.frame_bytes(int(rng.integers(0, 4000)))
+        n = int(rng.integers(300, 20000)) if i % 5 else 131072
+        k = i % 6
+        if k == 0: r = base[:n]
+        elif k == 1: r = bytes(rng.integers(0, 12, n, dtype=np.uint8))                      # few symbols: 4-bit weights, short tables
+        elif k == 2: r = (base[:300] + bytes(rng.integers(97, 105, 80, dtype=np.uint8))) * (n // 380 + 1)
+        elif k == 3: r = bytes((np.frombuffer(base[:n], dtype=np.uint8) & 0x3F).tobytes())
+        elif k == 4: r = rng.bytes(n // 8) + base[:n]
+        else: r = base[:n // 2] + bytes(n // 2)
+        raws.append(r[:n])
+    levels = [3, 1, 3, 5, 3, 9, 3, -1]
+    frames = [ref.compress(r, level=levels[i % len(levels)]) for i, r in enumerate(raws)]
+    sizes = [len(r) for r in raws]
+    bad, bsz = [], []
+    for k in range(120):
+        j = k % len(frames)
+        if len(raws[j]) > 20000:
+            continue
+        f = bytearray(frames[j])
+        if k % 10 == 9:
+            f = f[:max(6, len(f) - 1 - k % 7)]
+        else:
+            hi = min(len(f), 200)
+            for _ in range(1 + k % 2):
+                f[int(rng.integers(5, hi))] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(f)); bsz.append(sizes[j])
+    allf, alls = frames + bad, sizes + bsz
+    try:
+        res = {}
+        for k0 in (0, 1):
+            emu.set_k0(k0)
+            b10, b11 = emu.stat(10), emu.stat(11)
+            outs, st, nfb = emu.decompress_pipeline(allf, alls, n_blocks=3, chunk=0)
+            res[k0] = (outs, st, nfb, emu.stat(10) - b10, emu.stat(11) - b11)
+        assert res[1][1] == res[0][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[0][1])) if a != b][:8]
+        assert all(a == b for a, b, s in zip(res[1][0], res[0][0], res[0][1]) if s == 0)
+        assert res[1][2] == res[0][2]
+        assert not any(res[1][1][:len(frames)]) and all(o == r for o, r in zip(res[1][0], raws))
+        assert any(res[1][1][len(frames):])                                     # (the damage was noticed)
+        assert res[0][3] == 0 and res[0][4] == 0
+        assert res[1][3] >= 10 and res[1][4] >= 30, (res[1][3], res[1][4])       # weights of >= 10 frames, >= 30 distributions came from K0's records
+    finally:
+        emu.set_k0(1)
