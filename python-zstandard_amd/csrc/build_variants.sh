@@ -54,6 +54,7 @@ for v in "$@"; do
     floorw6free) build floorw6free -DZP_K3_DIAG_FLOOR -DZP_FLOOR_WIN=8192 -DZP_FLOOR_KEEP=5120 -DZP_FLOOR_FREE & ;;                                                 # the same requests dropped at six waves per SIMD (not buildable: shows what occupancy is worth)
     floorw3free) build floorw3free -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=3 -DZP_FLOOR_LDSPAD=8192 -DZP_FLOOR_WIN=12288 -DZP_FLOOR_KEEP=9216 -DZP_FLOOR_FREE & ;;
     floorw2free) build floorw2free -DZP_K3_DIAG_FLOOR -DZP_K3_MINWAVES=2 -DZP_FLOOR_LDSPAD=14336 -DZP_FLOOR_WIN=20480 -DZP_FLOOR_KEEP=17408 -DZP_FLOOR_FREE & ;;
+    chain1) build chain1 -DZE_CHAIN_UNROLL=0 & ;;          # E2's state chains one step per loop trip (rounds 2-5: 17 instructions per step; round 6 unrolls a full round: 11.5)
     e2prof) build e2prof -DZE_PROF_STREAM & ;;             # E2 with its sequence-stream rounds timed in four parts (ZHIP_PROF=1)
     e2w3) build e2w3 -DZE_E2_MINWAVES=3 & ;;               # E2 (entropy stage) at three / five waves per SIMD (default 4: 127 VGPRs + 160 bytes of scratch)
     e2w5) build e2w5 -DZE_E2_MINWAVES=5 & ;;

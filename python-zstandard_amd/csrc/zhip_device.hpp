@@ -24,6 +24,9 @@
 #define ZH_GLOBAL extern "C" __global__
 #define ZH_SHARED __shared__
 #define ZH_CONST __device__ const
+// a pointer the caller KNOWS points into LDS, typed so: reads through it are ds_read, not flat loads (a noinline routine sees its LDS arguments as generic pointers, and where the
+// compiler cannot infer the address space back it emits flat_load, which waits on both counters)
+#define ZH_LDS_CPTR(type, p) ((const __attribute__((address_space(3))) type*)(p))
 
 ZH_DEV uint32_t zh_lane() { return threadIdx.x; }
 ZH_DEV uint32_t zh_block() { return blockIdx.x; }

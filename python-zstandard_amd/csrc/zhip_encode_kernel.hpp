@@ -2079,6 +2079,9 @@ ZH_DEV uint32_t ze_ll_bits(uint32_t c) { return c < 16 ? 0u : c < 25 ? (uint32_t
 ZH_DEV uint32_t ze_ml_bits(uint32_t c) { return c < 32 ? 0u : c < 43 ? (uint32_t)((0x54433221111ull >> (4 * (c - 32))) & 15) : c - 36; }
 
 // ------------------------------------------------------------------------------------------ sequences bitstream, wave-parallel
+#ifndef ZE_CHAIN_UNROLL
+#define ZE_CHAIN_UNROLL 1
+#endif
 // ZSTD_encodeSequences_body (zstd.c:21386): sequences last to first; per sequence the OF, ML, LL state transitions
 // (FSE_encodeSymbol :2785) then the LL, ML, OF extra bits; finally the three states and the end mark. The only serial part is the
 // three state chains -- one lane per table walks them, 64 sequences per round, through LDS -- while what each sequence contributes
@@ -2151,6 +2154,27 @@ ZH_COLD uint32_t ze_encode_sequences_wave(ZeLDS& L, uint8_t* out, uint32_t cap, 
                 // the chain: add, shift, shift, add, one table read per step; the next slot's two constants are requested right
                 // behind that read (LDS answers in order), so their latency is not on the chain
                 uint64_t c = *(const uint64_t*)(pt + 2 * (j < cnt ? j : 0));
+#if ZE_CHAIN_UNROLL
+                // (a full round -- every round but a frame's first and last -- in steps of eight with constant offsets: the loop's counter, bound check and
+                // address arithmetic are 4 of its 15 instructions, and three busy lanes pay for every one of them)
+                if (cnt == 64 && j == 0) {
+                    const auto nx = ZH_LDS_CPTR(uint16_t, T.next);
+#pragma nounroll
+                    for (uint32_t j4 = 0; j4 < 64; j4 += 8) {                  // (eight steps per trip and no further: the whole round unrolled is 733 instructions that 4 KiB documents run three times each -- E2 4.8 -> 5.6 ms per dictionary batch, r06x)
+                        const uint32_t* p4 = pt + 2 * j4; uint32_t* r4 = rt + j4;
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) {
+                            const uint32_t dnb = (uint32_t)c, dfs = (uint32_t)(c >> 32);
+                            const uint32_t nb = (v + dnb) >> 16;
+                            r4[u] = v | (nb << 16);
+                            const uint32_t vn = nx[(v >> nb) + dfs];
+                            c = *(const uint64_t*)(p4 + 2 * (u + 1 < 8 || j4 + 8 < 64 ? u + 1 : 0));
+                            v = vn;
+                        }
+                    }
+                    j = 64;
+                }
+#endif
                 while (j < cnt) {
                     const uint32_t dnb = (uint32_t)c, dfs = (uint32_t)(c >> 32);
                     const uint32_t nb = (v + dnb) >> 16;

@@ -9,6 +9,7 @@
 #define ZH_GLOBAL extern "C"
 #define ZH_SHARED static
 #define ZH_CONST static const
+#define ZH_LDS_CPTR(type, p) ((const type*)(p))
 
 namespace zhemu {
 void collective_wait();                 // rendezvous of all live lanes of the current wave
