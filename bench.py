@@ -261,7 +261,9 @@ def roofline(ctx, ktimes, steps, algo_bytes_per_step, ms_per_step, frames_per_st
             per = tj["bytes_per_frame"]
             names = [ctx.kernel_name(k) for k, v in ktimes.items() if v[1]]
             if all(nm in per for nm in names if "frames_kernel" not in nm):
-                traffic = int(sum(per.get(nm, 0) for nm in names) * frames_per_step)
+                # (K0, the lane-per-frame parser pass, runs inside K1's timer -- it has no timer of its own -- so its traffic rides with K1's)
+                extra = per.get("zhip_decode_pre_kernel", 0) if "zhip_decode_lit_kernel" in names else 0
+                traffic = int((sum(per.get(nm, 0) for nm in names) + extra) * frames_per_step)
                 ktraffic = int(per[ctx.kernel_name(kdom)] * frames_per_step / launches_per_step) if ctx.kernel_name(kdom) in per else None
                 tsrc = tj.get("round")
         except (OSError, ValueError, KeyError):

@@ -694,7 +694,9 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             c->pipeFse.reserve(nslot * slots * ZP_FSE_CELLS * sizeof(uint16_t)) || c->pipeOrder.reserve(nslot * slots * sizeof(uint32_t)) ||
             c->pipeHuf.reserve(nslot * slots * ZP_HUF_CELLS * sizeof(uint16_t)) || c->pipeOrderLit.reserve(nslot * slots * sizeof(uint32_t))) return g_reserveRc;
         // K0's records (one per frame; not in the several-block mode, whose K1 walks a frame's blocks in order, nor for dictionary batches, whose lane pass finishes what has no table of its own)
-        const bool pre = ZHIP_K0 && !mb && !c->dictHasEntropy;
+        // (... nor for small batches: K0 is a lane-serial walk of ~0.1 ms whatever the batch, which pays from ~6 000 frames on -- 2 048 frames 3.53 -> 3.62 ms with it, 8 192
+        // 4.66 -> 4.62, 16 384 7.17 -> 6.96, 32 768 12.5 -> 12.0, 65 536 23.4 -> 22.4; `profiles/r06z2_k0_by_batch_size.txt`)
+        const bool pre = ZHIP_K0 && !mb && !c->dictHasEntropy && chunk >= 6144;
         if (pre && c->pipePre.reserve(nslot * slots * sizeof(ZpPre))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
                    c->pipeFrameRecs.reserve(nslot * chunk * sizeof(ZpFrameRec)))) return g_reserveRc;
