@@ -174,7 +174,8 @@ int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, con
 const char* zhip_kernel_name(int direction /*0 decompress, 1 compress*/);
 int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
 /* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 49 152 frames or more times the match kernel on
- * up to three table allocations held side by side and keeps the fastest): ms3[k] = candidate k's time in ms (0 = not tried). Returns the index kept. */
+ * up to three table allocations held side by side and keeps the fastest; where a probe is cheap -- dictionary batches -- and the three came out alike, up to three more):
+ * ms3[k] = candidate k's time in ms for the first three (0 = not tried). Returns the index kept (3..5: one of the further candidates). */
 int         zhip_ctx_table_pick(zhip_ctx*, float* ms3);
 
 #ifdef __cplusplus
