@@ -169,9 +169,11 @@ int zhip_ctx_sync(zhip_ctx*, void* stream, const int32_t* d_status, size_t n, zh
 int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, const uint64_t* d_outSizes, const int32_t* d_status,
                         const uint64_t* d_offsets, size_t n, void* d_dense, void* stream);
 
-/* name of the dominant kernel of each direction as it appears in rocprofv3 traces, and its average duration (ms)
- * over the launches since the last call, measured with HIP events on the launch stream (for bench.py's roofline). */
-const char* zhip_kernel_name(int direction /*0 decompress, 1 compress*/);
+/* name of a kernel as it appears in rocprofv3 traces ("" past the last one), and its average duration (ms) over the launches since the last call, measured with HIP events
+ * on the stream it is launched on (for bench.py's roofline). k: 0 / 1 the generic decode / encode kernels, 2 K1 (with K0 and the bin pass in front of / behind it), 3 K2,
+ * 4 K3, 5 / 6 the lane-serial match and the entropy kernels, 7 K1b -- which runs BESIDE K2 on a side stream: timed from K2's end to its own end, what it adds to the step --,
+ * 8 the flat match kernel, 9 "zhip_decode_pipeline_span": not a kernel, a chunk's decode pipeline from K1's start to K3's end (what the overlapping kernels cost together). */
+const char* zhip_kernel_name(int k);
 int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
 /* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 49 152 frames or more times the match kernel on
  * up to three table allocations held side by side and keeps the fastest; where a probe is cheap -- dictionary batches -- and the three came out alike, up to three more):
