@@ -1549,8 +1549,12 @@ ZH_DEVFN uint32_t ze_dfast_dict(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, c
 // that consults it (:31391). Sequences only -- the entropy stage gathers the literals from the source (ze_gather_literals).
 // Index space as in ze_dfast_dict: dictionary content byte k is index 2 + k, the source starts at CE = 2 + contentSize.
 ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, const ZePar& cp, const ZeCDict& cd, const uint8_t* content,
-                                   const uint32_t* dHashLong, const uint32_t* dHashSmall, uint32_t* hashLong, uint32_t* hashSmall)
+                                   const uint32_t* dHashLong, const uint32_t* dHashSmall, uint32_t* hashLong, uint32_t* hashSmall, uint32_t epoch = 0, uint32_t epochShift = 31)
 {
+    // own cells: index | launch number << ES (ZhipEncodeArgs.tabEpoch); a cell of another launch -- or, with epoch 0, a zeroed one -- reads as 0 = empty (own candidates are >= CE)
+    const uint32_t ES = epoch ? epochShift : 31u, EW = epoch << ES, IM = (1u << ES) - 1u;
+#define ZE_OWN_RD(x) ((((x) >> ES) == epoch) ? ((x) & IM) : 0u)
+#define ZE_OWN_WR(i) ((i) | EW)
     const int mls = cp.mml <= 4 ? 4 : cp.mml >= 7 ? 7 : cp.mml;
     const uint32_t shL = 64u - (uint32_t)cp.hlog, shDL = 64u - (uint32_t)(cd.hlog + 8);
     const uint32_t shlS = mls == 4 ? 32u : (uint32_t)(64 - 8 * mls);
@@ -1580,10 +1584,12 @@ ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t 
         const uint32_t h2 = (uint32_t)(pL >> shL), h = (uint32_t)(pS >> shS), hl3 = (uint32_t)(pL1 >> shL);
         const uint32_t dTagL = (uint32_t)(pL >> shDL), dTagS = (uint32_t)(pS >> shDS), dTagL3 = (uint32_t)(pL1 >> shDL);
         // ---- round 1
-        const uint32_t mIdxL = hashLong[h2], mIdxS0 = hashSmall[h], dEntL = dHashLong[dTagL >> 8], dEntS = dHashSmall[dTagS >> 8];
-        uint32_t mIdxL3 = hashLong[hl3]; const uint32_t dEntL3 = dHashLong[dTagL3 >> 8];
+        const uint32_t rawL = hashLong[h2], rawS = hashSmall[h], dEntL = dHashLong[dTagL >> 8], dEntS = dHashSmall[dTagS >> 8];
+        const uint32_t rawL3 = hashLong[hl3]; const uint32_t dEntL3 = dHashLong[dTagL3 >> 8];
+        const uint32_t mIdxL = ZE_OWN_RD(rawL), mIdxS0 = ZE_OWN_RD(rawS);
+        uint32_t mIdxL3 = ZE_OWN_RD(rawL3);
         if (hl3 == h2) mIdxL3 = curr;                                           // what the reference's later read sees after its write below
-        hashLong[h2] = curr; hashSmall[h] = curr;
+        hashLong[h2] = ZE_OWN_WR(curr); hashSmall[h] = ZE_OWN_WR(curr);
         const bool tagL = (dEntL & 255) == (dTagL & 255), tagS = (dEntS & 255) == (dTagS & 255), tagL3 = (dEntL3 & 255) == (dTagL3 & 255);
         const uint32_t dL = dEntL >> 8, dS = dEntS >> 8, dL3 = dEntL3 >> 8;
         const bool ownL = mIdxL >= CE, ownS = mIdxS0 > CE, ownL3 = mIdxL3 >= CE;
@@ -1626,7 +1632,7 @@ ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t 
                 const bool shortCand = (ownS || dctS) && cS == (uint32_t)w;
                 if (!shortCand) { ip += ((ip - anchor) >> 8) + 1; continue; }
                 const uint32_t mIdxS = ownS ? mIdxS0 : dS;
-                hashLong[hl3] = curr + 1;                                       // the long table is consulted -- and written -- one position ahead
+                hashLong[hl3] = ZE_OWN_WR(curr + 1);                            // the long table is consulted -- and written -- one position ahead
                 if (ownL3 && cL3 == w1) {
                     uint32_t m = mIdxL3;
                     mLength = ze_sp_count(sp, ip + 9, m + 8) + 8;
@@ -1654,10 +1660,10 @@ ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t 
         if (ip <= ilimit) {
             const uint32_t ins = curr + 2;
             const uint64_t wI = zh_ld64(ZE_SRC(ins)), wE2 = zh_ld64(ZE_SRC(ip - 2)), wE1 = zh_ld64(ZE_SRC(ip - 1));
-            hashLong[(uint32_t)((wI * 0xCF1BBCDCB7A56463ull) >> shL)] = ins;
-            hashLong[(uint32_t)((wE2 * 0xCF1BBCDCB7A56463ull) >> shL)] = ip - 2;
-            hashSmall[(uint32_t)(((wI << shlS) * primeS) >> shS)] = ins;
-            hashSmall[(uint32_t)(((wE1 << shlS) * primeS) >> shS)] = ip - 1;
+            hashLong[(uint32_t)((wI * 0xCF1BBCDCB7A56463ull) >> shL)] = ZE_OWN_WR(ins);
+            hashLong[(uint32_t)((wE2 * 0xCF1BBCDCB7A56463ull) >> shL)] = ZE_OWN_WR(ip - 2);
+            hashSmall[(uint32_t)(((wI << shlS) * primeS) >> shS)] = ZE_OWN_WR(ins);
+            hashSmall[(uint32_t)(((wE1 << shlS) * primeS) >> shS)] = ZE_OWN_WR(ip - 1);
             while (ip <= ilimit) {
                 const uint32_t rep2 = ip - off2;
                 if (!((uint32_t)((CE - 1) - rep2) >= 3 && ze_sp_rd32(sp, rep2) == zh_ld32(ZE_SRC(ip)))) break;
@@ -1665,12 +1671,14 @@ ZH_DEV uint32_t ze_dfast_dict_flat(uint64_t* seqs, const uint8_t* src, uint32_t 
                 const uint32_t t = off2; off2 = off1; off1 = t;
                 seqs[nseq++] = ZE_SEQ_PACK(1, 0, r);
                 const uint64_t wr = zh_ld64(ZE_SRC(ip));
-                hashSmall[(uint32_t)(((wr << shlS) * primeS) >> shS)] = ip;
-                hashLong[(uint32_t)((wr * 0xCF1BBCDCB7A56463ull) >> shL)] = ip;
+                hashSmall[(uint32_t)(((wr << shlS) * primeS) >> shS)] = ZE_OWN_WR(ip);
+                hashLong[(uint32_t)((wr * 0xCF1BBCDCB7A56463ull) >> shL)] = ZE_OWN_WR(ip);
                 ip += r; anchor = ip;
             }
         }
     }
+#undef ZE_OWN_RD
+#undef ZE_OWN_WR
 #undef ZE_BACK
 #undef ZE_SPP
 #undef ZE_SRC
@@ -3022,9 +3030,9 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     }
     uint32_t* hashLong = (uint32_t*)(a.flatTables + (size_t)(mine ? i : 0u) * a.tableStride);
     uint32_t* hashSmall = hashLong + (take ? (1u << cp.hlog) : 0u);
-    if (dict) {
-        // dictionary batches: the wave zeroes its documents' tables itself, only the part each one uses (the slots are sized for the attach
-        // cutoff: a host-side memset of whole slots would write four times what 4 KiB documents need)
+    if (dict && a.tabEpoch == 0) {
+        // dictionary batches without launch numbers in the cells (ZhipEncodeArgs.tabEpoch): the wave zeroes its documents' tables itself, only the part each one uses (the
+        // slots are sized for the attach cutoff: a host-side memset of whole slots would write four times what 4 KiB documents need)
         const uint32_t myUnits = take ? ((4u << cp.hlog) + (4u << cp.clog)) / 16u : 0u;
         for (uint32_t l = 0; l < ZE_FLAT_LANES; l++) {
             const uint32_t units = zh_shfl(myUnits, l);
@@ -3039,7 +3047,7 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     }
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall)
+    m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall, a.tabEpoch, a.tabEpochShift)
                    : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle)
                                  : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
     m.mode = 4;

@@ -113,6 +113,11 @@ struct ZhipEncodeArgs {
     uint32_t e1Lanes;               // frames per wave of the lane-serial match kernel: ZE_E1_LANES (8), ZE_E1_LANES_DICT (32) for dictionary batches
     uint32_t tableStride;
     uint32_t slotSrcMax;            // != 0: table and arena slots of a dictionary batch are sized for sources up to this (the caller's size hint); larger ones are the generic kernel's
+    // flat search with an attached dictionary (round 6): its per-document tables are not zeroed any more -- 48 KiB of whole-line stores per 4 KiB document were a seventh of the
+    // kernel's line transfers -- but carry the LAUNCH's number above the index: a cell written by an earlier launch reads as empty. tabEpoch == 0: cells are plain indices and
+    // the kernel's waves zero the tables first (the emulator's default; dictionaries whose index space leaves fewer than 6 bits); else cell = index | tabEpoch << tabEpochShift,
+    // the host zeroes the allocation once and whenever the numbers run out or the index width changes (zhip_compress_batch_device)
+    uint32_t tabEpoch, tabEpochShift;
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
     // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
     uint32_t* bigList; uint32_t* bigCount;

@@ -4,6 +4,7 @@
 // (c-ext/compressor.c:1083, c-ext/decompressor.c:1185): instead of partitioning frames over a pthread pool
 // (POOL_*, zstd.c:7537-7975) it stages them in HBM and launches persistent one-wave workgroups that pull frame
 // indices from an atomic counter.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <time.h>
@@ -266,6 +267,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_NSLOT
 #define ZHIP_NSLOT 3
 #endif
+#ifndef ZHIP_DICT_EPOCHS
+#define ZHIP_DICT_EPOCHS 1       // launch numbers in the cells of the flat dictionary search's tables; 0: the kernel's waves zero the tables every launch (A/B build)
+#endif
 #ifndef ZHIP_K0
 #define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
 #endif
@@ -278,6 +282,7 @@ static thread_local int g_reserveRc = ZHIP_ERR_HIP;      // why the last failed 
 // wraps)
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    uint64_t gen = 0;            // which allocation this is, process-wide (a released buffer's address may come back with other contents: whoever remembers something ABOUT the contents remembers this too)
     int reserve(size_t n) {
         if (n <= cap) return 0;
         release();
@@ -286,7 +291,8 @@ struct DevBuf {
         const hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; g_lastError = "out of device memory"; return g_reserveRc = ZHIP_ERR_NO_MEMORY; }
         if (e != hipSuccess) { p = nullptr; return g_reserveRc = hip_fail(e, "hipMalloc"); }
-        cap = want; return 0;
+        static std::atomic<uint64_t> g_gen{0};
+        cap = want; gen = ++g_gen; return 0;
     }
     void release()
     {
@@ -322,6 +328,10 @@ struct zhip_ctx {
     // dictionary (compress side): raw bytes, parsed entropy section, digested form and its tagged tables
     DevBuf cdictBlob, cdictEntropy, cdictDigest, cdictTables;
     bool hasCDict = false; uint32_t cdictContentOffset = 0, cdictAttachMax = ZE_DICT_ATTACH_MAX; int cdictHlog = 0, cdictClog = 0, cdictStrat = 2;
+    uint32_t cdictContentSize = 0;
+    // launch numbers in the cells of the flat dictionary search's tables (ZhipEncodeArgs.tabEpoch): the last one used on the allocation at encEpochPtr, the index width and
+    // dictionary it was counted for -- any of them changing, or the numbers running out, zeroes the allocation and starts again at 1
+    uint32_t encEpoch = 0, encEpochShift = 0; void* encEpochPtr = nullptr; uint64_t encEpochKey = 0, encEpochGen = 0;
     uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy, dictTables;
@@ -611,7 +621,7 @@ extern "C" int zhip_ctx_set_cparams(zhip_ctx* c, const zhip_cparams* p)
         if (cd.status) return cd.status == ZE_DICT_CORRUPTED || cd.status == ZE_DICT_WRONG ? -ZE_MEMORY : -cd.status;
         c->hasCDict = true; c->cdictContentOffset = de.hufCount ? de.contentOffset : 0u;
         c->cdictAttachMax = cd.strat == 1 ? ZE_DICT_ATTACH_MAX_FAST : ZE_DICT_ATTACH_MAX;
-        c->cdictHlog = cd.hlog; c->cdictClog = cd.clog; c->cdictStrat = cd.strat;
+        c->cdictHlog = cd.hlog; c->cdictClog = cd.clog; c->cdictStrat = cd.strat; c->cdictContentSize = cd.contentSize;
     }
     c->cparams = *p; c->cparams.dict = nullptr; c->cparams.dictSize = 0; c->rows = rows;
     return 0;
@@ -1069,6 +1079,23 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // real kernel on its tables, reserves a second set beside them, times that, and keeps the faster (tests/tools/e1f_pick_best.py, r05g: in every
         // trial at least one of three candidates was the fast kind, and the best stayed the best). Costs two extra launches of the kernel and a transient
         // second table allocation, once per context; skipped where the second set does not fit. ZHIP_E1F_PICK=0 turns it off.
+        // The dictionary search's tables are not zeroed per launch: a cell carries its launch's number above the index and reads as empty under any other number.
+        // The index space is 2 + the dictionary's content + a source (+ slack): what is left of 32 bits counts launches, at least 6 bits or the kernel zeroes as before.
+        auto nextEpoch = [&](ZhipEncodeArgs& args, uint8_t* tables, uint64_t gen) -> int {
+            args.tabEpoch = 0; args.tabEpochShift = 31;
+            if (!flatDict || !ZHIP_DICT_EPOCHS) return 0;
+            const uint64_t span = 2ull + c->cdictContentSize + (a.slotSrcMax ? a.slotSrcMax : c->cdictAttachMax) + 64;
+            uint32_t es = 1; while ((1ull << es) < span) es++;
+            if (es > 26) return 0;
+            const uint32_t maxE = (1u << (32 - es)) - 1;
+            const uint64_t key = c->cdictKey ^ ((uint64_t)a.tableStride << 40);
+            if (tables != c->encEpochPtr || gen != c->encEpochGen || es != c->encEpochShift || key != c->encEpochKey || c->encEpoch >= maxE) {
+                HIP_TRY(hipMemsetAsync(tables, 0, cap * (size_t)a.tableStride, stream));
+                c->encEpoch = 0; c->encEpochPtr = tables; c->encEpochGen = gen; c->encEpochShift = es; c->encEpochKey = key;
+            }
+            args.tabEpoch = ++c->encEpoch; args.tabEpochShift = es;
+            return 0;
+        };
         if (flat && !mbc && c->knob.e1fPick && chunk >= 49152 && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
             c->e1fPicked = true; c->e1fPickKept = 0; c->e1fPickMs[1] = c->e1fPickMs[2] = 0;
             const size_t cnt0 = chunk, bytes = cnt0 * (size_t)a.tableStride;
@@ -1080,7 +1107,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 auto timeOn = [&](uint8_t* t, float* ms) -> int {
                     pa.flatTables = t;
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
-                    if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: the kernel's waves zero what they use)
+                    if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: launch numbers in the cells -- a candidate allocation is zeroed once, by nextEpoch)
+                    else if (int rc = nextEpoch(pa, t, t == (uint8_t*)cand.p ? cand.gen : c->encFlatTables.gen)) return rc;
                     HIP_TRY(hipEventRecord(e0, stream));
                     launch_flat(!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
@@ -1104,7 +1132,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     if (int rc = timeOn((uint8_t*)cand.p, &ms)) return rc;
                     if (k < 3) c->e1fPickMs[k] = ms;
                     if (ms > worst) worst = ms;
-                    if (ms < 0.97f * best) { std::swap(c->encFlatTables.p, cand.p); std::swap(c->encFlatTables.cap, cand.cap); best = ms; c->e1fPickKept = k; }
+                    if (ms < 0.97f * best) { std::swap(c->encFlatTables.p, cand.p); std::swap(c->encFlatTables.cap, cand.cap); std::swap(c->encFlatTables.gen, cand.gen); best = ms; c->e1fPickKept = k; }
                     cand.release();
                     // (no early stop among the first three: at 131 072 frames per launch the kinds are not two but a spread -- 750, 805, 855, 928 ms, r05n / r05u -- so all three are timed)
                 }
@@ -1113,6 +1141,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             c->e1fPickedPtr = c->encFlatTables.p;
         }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
+        if (flatDict) { if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen)) return rc; }          // (one launch number per batch: chunks of a larger batch take the next ones in the loop)
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
             if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
             HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
@@ -1121,6 +1150,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
+            if (flatDict && first) { if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen)) return rc; }      // (the tables serve other documents now)
             HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream));
             HIP_TRY(hipMemsetAsync(cbase + 32, 0, 4, stream));
             const bool tm = c->timing;

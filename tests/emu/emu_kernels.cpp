@@ -254,6 +254,8 @@ static uint32_t g_dictSlotMax = 0;              // != 0: ZhipEncodeArgs.slotSrcM
 extern "C" void emu_set_dict_slot_max(uint32_t v) { g_dictSlotMax = v; }
 static uint64_t g_mbHint = 0;                   // != 0: the several-block arenas are sized from this size HINT instead of the batch's largest source (a device-API caller's stale hint)
 extern "C" void emu_set_mb_hint(uint64_t v) { g_mbHint = v; }
+static uint32_t g_dictEpochs = 0, g_epoch = 0, g_epochShift = 0; static uint8_t* g_epochTables = nullptr; static size_t g_epochCap = 0;
+extern "C" void emu_set_dict_epochs(uint32_t v) { g_dictEpochs = v; }        // 1: the flat dictionary search's tables carry launch numbers and persist between calls (the product's way); 0: zeroed by the kernel
 static ZeSrcLDS<ZF_BLOCK_MAX> g_srclds;
 static uint32_t g_e1LdsBytes = ZF_BLOCK_MAX;       // the LDS shape under emulation (the product picks it from the batch's largest source)
 static void e1l_lane(void* p) { if (g_probes == 4) ze_match_lds_body<4>(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); else ze_match_lds_body<2>(*(const ZhipEncodeArgs*)p, g_srclds.b, g_e1LdsBytes); }
@@ -295,6 +297,16 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     const bool flatDict = g_hasCD && a.cdict && a.cdict->strat == 2;      // mirrors zhip_compress_batch_device
     const bool flat = (anyDfast && !g_hasCD) || flatDict;
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
+    // launch numbers in the dictionary search's cells (ZhipEncodeArgs.tabEpoch; mirrors zhip_compress_batch_device): the tables persist from call to call, zeroed when they are
+    // (re)made, and every launch on them takes the next number -- earlier launches' cells must read as empty
+    const bool epochs = flatDict && g_dictEpochs;
+    if (epochs) {
+        const size_t need = (size_t)chunk * a.tableStride;
+        const uint64_t span = 2ull + a.cdict->contentSize + (a.slotSrcMax ? a.slotSrcMax : (uint32_t)ZE_DICT_ATTACH_MAX) + 64;
+        uint32_t es = 1; while ((1ull << es) < span) es++;
+        if (need > g_epochCap || es != g_epochShift || g_epoch + 8 >= (1u << (32 - es))) { free(g_epochTables); g_epochTables = (uint8_t*)calloc(need, 1); g_epochCap = need; g_epochShift = es; g_epoch = 0; }
+        a.flatTables = g_epochTables; a.tabEpochShift = es;
+    } else
     a.flatTables = flat ? (uint8_t*)malloc((size_t)chunk * a.tableStride) : nullptr;
     static uint8_t idlePad[64]; a.idle = idlePad;                  // (the product points it at the context's counter block)
     // sources of several blocks in the flat kernel (mirrors zhip_compress_batch_device: the size hint is the batch's largest source)
@@ -310,7 +322,8 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         counters[0] = counters[1] = 0; e1Count = 0;
         if (flat) {
-            memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
+            if (epochs) a.tabEpoch = ++g_epoch;
+            else memset(a.flatTables, flatDict ? 0xA5 : 0, (size_t)a.count * a.tableStride);      // (dictionary batches: the kernel's waves zero what they use)
             if (mbc) { memset(&g_elds, 0xA5, sizeof g_elds); zhemu::run_grid(a.count < 3 ? a.count : 3, split_lane, &a); if (getenv("ZHIP_EMU_DEBUG")) fprintf(stderr, "[emu] split: count[0] = %u stride %u\n", a.mbCount[0], a.tableStride); }
             if (a.count <= g_e1LdsMax && !flatDict && !mbc) { memset(&g_srclds, 0xA5, sizeof g_srclds); zhemu::run_grid(a.count, e1l_lane, &a); }
             else zhemu::run_grid((a.count + ZE_FLAT_LANES - 1) / ZE_FLAT_LANES, e1f_lane, &a);
@@ -327,7 +340,7 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             bigCount = 0;
         }
     }
-    free(a.e1List); free(a.flatTables); free(a.mbBlocks); free(a.mbCount); free(a.mbSeqs);
+    free(a.e1List); if (!epochs) free(a.flatTables); free(a.mbBlocks); free(a.mbCount); free(a.mbSeqs);
     if (bigCount) {                              // inputs above one block: generic kernel over the list (mirrors zhip_compress_batch_device)
         ZhipEncodeArgs b = a; uint32_t bc = 0;
         b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;

@@ -188,3 +188,11 @@ def _emu_set_k0(self, v):
 
 
 Emu.set_k0 = _emu_set_k0
+
+
+def _emu_set_dict_epochs(self, v):
+    """1: the flat dictionary search's tables persist between calls and carry launch numbers in their cells (the product's way); 0 (default): the kernel's waves zero them"""
+    self.lib.emu_set_dict_epochs(C.c_uint32(v))
+
+
+Emu.set_dict_epochs = _emu_set_dict_epochs

@@ -853,3 +853,33 @@ def test_k0_lane_per_frame_parsers_agree_with_k1s_own(emu, ref, corpus):
         assert res[1][3] >= 10 and res[1][4] >= 30, (res[1][3], res[1][4])       # weights of >= 10 frames, >= 30 distributions came from K0's records
     finally:
         emu.set_k0(1)
+
+
+def test_flat_dictionary_search_with_launch_numbers_in_the_cells(emu, ref, corpus):
+    """Round 6: the flat dictionary search's per-document tables are not zeroed per launch any more -- a cell carries its launch's number above the index
+    (ZhipEncodeArgs.tabEpoch) and a cell of any other launch reads as empty. Six launches over the SAME persistent tables with the documents shuffled from launch to
+    launch (so every slot holds another document's cells from the launch before), two dictionaries in turn (the index width changes: the tables start over): every
+    frame libzstd's, every time."""
+    import numpy as np
+    from tests.corpus import Corpus
+    rng = np.random.default_rng(47)
+    here = os.path.dirname(os.path.abspath(__file__))
+    big = open(os.path.join(here, "golden", "dict_json4k.bin"), "rb").read()
+    small = open(os.path.join(here, "golden", "dict_json4k_16k.bin"), "rb").read()
+    docs = Corpus(frame_size=4096).json_docs(0, 48).numpy()
+    raws = [docs[i].tobytes() for i in range(48)]
+    raws += [big[-3000:] + raws[0][:1000], big[5000:6500] + raws[1][:2000] + big[60000:61000], (big[-700:] * 30)[:16384], raws[5] * 4, raws[6] * 3 + b"zz"]
+    raws += [corpus.frame_bytes(i)[: int(rng.integers(100, 16385))] for i in range(6)]
+    want = {id(dd): {r: ref.compress(r, level=3, dict_data=dd) for r in set(raws)} for dd in (big, small)}
+    try:
+        emu.set_dict_epochs(1)
+        for launch, dd in enumerate((big, big, big, small, small, big)):
+            order = list(rng.permutation(len(raws)))
+            batch = [raws[i] for i in order]
+            before = emu.lib.emu_stat(15)
+            outs, st = emu.compress_batch(batch, level=3, flags=5, pipeline=True, dict_data=dd)
+            assert not any(st), launch
+            assert outs == [want[id(dd)][r] for r in batch], launch
+            assert emu.lib.emu_stat(15) - before >= 50
+    finally:
+        emu.set_dict_epochs(0)
