@@ -1082,9 +1082,13 @@ ZH_DEV uint32_t ze_count_fwd(const uint8_t* src, uint32_t a, uint32_t b, uint32_
 // (r04zd / r04zg). The function was written for two probes in round 1 and generalised in round 4; at NP = 2 it compiles to the same kernel (4 573 against
 // 4 569 instructions, 85 against 84 VGPRs).
 template <int PB, bool BLK, int NP>
-ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle)
+ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs, uint32_t be, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, uint32_t* rep, const uint8_t* idle, uint32_t epoch = 0)
 {
-    constexpr uint32_t TB = 32 - PB, TM = (1u << TB) - 1;
+    // (round 6) sources of one block: the top EB = 6 of the 14 bits above the position hold the LAUNCH's number (ZhipEncodeArgs.tabEpoch, 0 .. 63), the 8 below them the tag. A cell
+    // another launch wrote fails the tag comparison like any cell of other bytes -- "cannot match", what a zeroed cell says too -- so the tables need no zeroing between launches
+    // (the host zeroes an allocation once and every 63 launches); an 8-bit tag still keeps 255 of 256 foreign candidates from being fetched. Number 0 = tables zeroed per launch, as before.
+    constexpr uint32_t TBA = 32 - PB, EB = PB == 18 ? 6u : 0u, TB = TBA - EB, TM = (1u << TB) - 1;
+    const uint32_t EPW = EB ? (epoch & ((1u << EB) - 1u)) << (PB + TB) : 0u;
 #undef ZE_CELL_IDX
 #define ZE_CELL_IDX(c) ((c) & ((1u << PB) - 1))
     const uint32_t shL = 32u - (uint32_t)hlog, shS = 32u - (uint32_t)clog;
@@ -1093,8 +1097,8 @@ ZH_DEV uint32_t ze_dfast_flat_np(uint64_t* seqs, const uint8_t* src, uint32_t bs
     const uint64_t primeS = mls == 4 ? 2654435761ull : mls == 5 ? 889523592379ull : mls == 6 ? 227718039650203ull : 58295818150454627ull;
 #define ZE_PL(u) ((uint32_t)(((u) * 0xCF1BBCDCB7A56463ull) >> 32))
 #define ZE_PS(u) ((uint32_t)((((u) << shlS) * primeS) >> 32))
-#define ZE_TL(ph) ((((ph) >> (shL - TB)) & TM) << PB)
-#define ZE_TS(u) (((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB)
+#define ZE_TL(ph) (((((ph) >> (shL - TB)) & TM) << PB) | EPW)
+#define ZE_TS(u) ((((((uint32_t)(u) * 2654435761u) >> (shS - TB)) & TM) << PB) | EPW)
     const uint32_t ilimit = be - 8, srcSize = be;
     uint32_t ip = BLK ? bs + (bs == 0 ? 1u : 0u) : 1u, anchor = BLK ? bs : 0u, off1 = 1, off2 = 0, nseq = 0;
     uint32_t saved1 = 0, saved2 = 0;
@@ -1269,17 +1273,17 @@ ZH_DEV uint32_t ze_dfast_flat_t(uint64_t* seqs, const uint8_t* src, uint32_t bs,
     return ze_dfast_flat_np<PB, BLK, 2>(seqs, src, bs, be, hlog, clog, mml, hashLong, hashSmall, rep, idle ? idle : src);
 }
 template <int NP>
-ZH_DEV uint32_t ze_dfast_flatn(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
+ZH_DEV uint32_t ze_dfast_flatn(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr, uint32_t epoch = 0)
 {
-    return ze_dfast_flat_np<18, false, NP>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src);
+    return ze_dfast_flat_np<18, false, NP>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src, epoch);
 }
-ZH_DEV uint32_t ze_dfast_flat4(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
+ZH_DEV uint32_t ze_dfast_flat4(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr, uint32_t epoch = 0)
 {
-    return ze_dfast_flatn<4>(seqs, src, srcSize, hlog, clog, mml, hashLong, hashSmall, idle);
+    return ze_dfast_flatn<4>(seqs, src, srcSize, hlog, clog, mml, hashLong, hashSmall, idle, epoch);
 }
-ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr)
+ZH_DEV uint32_t ze_dfast_flat(uint64_t* seqs, const uint8_t* src, uint32_t srcSize, int hlog, int clog, int mml, uint32_t* hashLong, uint32_t* hashSmall, const uint8_t* idle = nullptr, uint32_t epoch = 0)
 {
-    return ze_dfast_flat_t<18, false>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle);
+    return ze_dfast_flat_np<18, false, 2>(seqs, src, 0, srcSize, hlog, clog, mml, hashLong, hashSmall, nullptr, idle ? idle : src, epoch);
 }
 
 
@@ -3048,8 +3052,8 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall, a.tabEpoch, a.tabEpochShift)
-                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle)
-                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
+                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch)
+                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;
@@ -3140,11 +3144,11 @@ ZH_DEVFN void ze_match_lds_body(const ZhipEncodeArgs& a, uint8_t* lds, uint32_t 
     // little more than half the round trips and pays shuffles, ballots and a wave-wide match extension for each.)
     if (lane != 0) return;
     if (NPROBE == 4)
-        m.nbSeq = staged ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
-                         : ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
+        m.nbSeq = staged ? ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, nullptr, a.tabEpoch)
+                         : ze_dfast_flat4((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
     else
-    m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall)
-                     : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle);
+    m.nbSeq = staged ? ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), lds, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, nullptr, a.tabEpoch)
+                     : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

@@ -267,8 +267,8 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_NSLOT
 #define ZHIP_NSLOT 3
 #endif
-#ifndef ZHIP_DICT_EPOCHS
-#define ZHIP_DICT_EPOCHS 1       // launch numbers in the cells of the flat dictionary search's tables; 0: the kernel's waves zero the tables every launch (A/B build)
+#ifndef ZHIP_TABLE_EPOCHS
+#define ZHIP_TABLE_EPOCHS 1      // launch numbers in the cells of the flat searches' tables; 0: the tables are zeroed every launch -- a memset, the dictionary search's own waves -- (A/B build)
 #endif
 #ifndef ZHIP_K0
 #define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
@@ -1081,16 +1081,22 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // second table allocation, once per context; skipped where the second set does not fit. ZHIP_E1F_PICK=0 turns it off.
         // The dictionary search's tables are not zeroed per launch: a cell carries its launch's number above the index and reads as empty under any other number.
         // The index space is 2 + the dictionary's content + a source (+ slack): what is left of 32 bits counts launches, at least 6 bits or the kernel zeroes as before.
-        auto nextEpoch = [&](ZhipEncodeArgs& args, uint8_t* tables, uint64_t gen) -> int {
-            args.tabEpoch = 0; args.tabEpochShift = 31;
-            if (!flatDict || !ZHIP_DICT_EPOCHS) return 0;
-            const uint64_t span = 2ull + c->cdictContentSize + (a.slotSrcMax ? a.slotSrcMax : c->cdictAttachMax) + 64;
-            uint32_t es = 1; while ((1ull << es) < span) es++;
+        // (the dictionary-less flat search of one-block sources does the same with six fixed bits: its cells are position 18 | tag 8 | launch number 6, ze_dfast_flat_np. `zeroed`
+        // comes back false when the tables carry no launch numbers -- the several-block search, an index space too wide -- and the caller zeroes them as before.)
+        auto nextEpoch = [&](ZhipEncodeArgs& args, uint8_t* tables, uint64_t gen, size_t bytes, bool* zeroed) -> int {
+            args.tabEpoch = 0; args.tabEpochShift = 31; *zeroed = false;
+            if (!ZHIP_TABLE_EPOCHS || !flat || mbc) return 0;
+            uint32_t es = 26;
+            if (flatDict) {
+                const uint64_t span = 2ull + c->cdictContentSize + (a.slotSrcMax ? a.slotSrcMax : c->cdictAttachMax) + 64;
+                es = 1; while ((1ull << es) < span) es++;
+            }
             if (es > 26) return 0;
+            *zeroed = true;
             const uint32_t maxE = (1u << (32 - es)) - 1;
-            const uint64_t key = c->cdictKey ^ ((uint64_t)a.tableStride << 40);
+            const uint64_t key = (flatDict ? c->cdictKey : 0x9E3779B97F4A7C15ull) ^ ((uint64_t)a.tableStride << 40);
             if (tables != c->encEpochPtr || gen != c->encEpochGen || es != c->encEpochShift || key != c->encEpochKey || c->encEpoch >= maxE) {
-                HIP_TRY(hipMemsetAsync(tables, 0, cap * (size_t)a.tableStride, stream));
+                HIP_TRY(hipMemsetAsync(tables, 0, bytes, stream));
                 c->encEpoch = 0; c->encEpochPtr = tables; c->encEpochGen = gen; c->encEpochShift = es; c->encEpochKey = key;
             }
             args.tabEpoch = ++c->encEpoch; args.tabEpochShift = es;
@@ -1107,8 +1113,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 auto timeOn = [&](uint8_t* t, float* ms) -> int {
                     pa.flatTables = t;
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
-                    if (!flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream));           // (dictionary batches: launch numbers in the cells -- a candidate allocation is zeroed once, by nextEpoch)
-                    else if (int rc = nextEpoch(pa, t, t == (uint8_t*)cand.p ? cand.gen : c->encFlatTables.gen)) return rc;
+                    {   bool z = false;                                                    // (launch numbers in the cells: a candidate allocation is zeroed once, by nextEpoch)
+                        if (int rc = nextEpoch(pa, t, t == (uint8_t*)cand.p ? cand.gen : c->encFlatTables.gen, bytes, &z)) return rc;
+                        if (!z && !flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream)); }
                     HIP_TRY(hipEventRecord(e0, stream));
                     launch_flat(!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
@@ -1141,7 +1148,6 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             c->e1fPickedPtr = c->encFlatTables.p;
         }
         HIP_TRY(hipMemsetAsync(cbase + 24, 0, 8, stream));
-        if (flatDict) { if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen)) return rc; }          // (one launch number per batch: chunks of a larger batch take the next ones in the loop)
         if (c->knob.prof) {                                                         // tuning aid: per-phase cycle totals of the entropy kernel
             if (!c->profEncode) HIP_TRY(hipMalloc((void**)&c->profEncode, 16 * 8));
             HIP_TRY(hipMemsetAsync(c->profEncode, 0, 16 * 8, stream));
@@ -1150,14 +1156,16 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         for (size_t first = 0; first < n; first += chunk) {
             const size_t cnt = n - first < chunk ? n - first : chunk;
             a.first = (uint32_t)first; a.count = (uint32_t)cnt;
-            if (flatDict && first) { if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen)) return rc; }      // (the tables serve other documents now)
             HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream));
             HIP_TRY(hipMemsetAsync(cbase + 32, 0, 4, stream));
             const bool tm = c->timing;
             hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             if (tm) for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&ev[i]));
             if (flat) {
-                if (!flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
+                // every launch its own number in the tables' cells (the tables serve other sources now), or -- where the cells carry none -- zeroed tables
+                bool z = false;
+                if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen, cap * (size_t)a.tableStride, &z)) return rc;
+                if (!z && !flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
                 // (the LDS area follows the batch's largest source where the caller told us -- the host-buffer API does: more frames per CU)

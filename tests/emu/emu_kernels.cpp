@@ -299,11 +299,12 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
     uint32_t e1Count = 0; a.e1List = (uint32_t*)calloc(chunk, 4); a.e1Count = &e1Count; a.useE1List = flat ? 1u : 0u;
     // launch numbers in the dictionary search's cells (ZhipEncodeArgs.tabEpoch; mirrors zhip_compress_batch_device): the tables persist from call to call, zeroed when they are
     // (re)made, and every launch on them takes the next number -- earlier launches' cells must read as empty
-    const bool epochs = flatDict && g_dictEpochs;
+    const bool mbcWanted = flat && !flatDict && g_mbCompress && maxSrc > ZF_BLOCK_MAX && maxSrc < (1ull << ZE_MB_POS_BITS) - 8;
+    const bool epochs = flat && !mbcWanted && g_dictEpochs;
     if (epochs) {
         const size_t need = (size_t)chunk * a.tableStride;
-        const uint64_t span = 2ull + a.cdict->contentSize + (a.slotSrcMax ? a.slotSrcMax : (uint32_t)ZE_DICT_ATTACH_MAX) + 64;
-        uint32_t es = 1; while ((1ull << es) < span) es++;
+        uint32_t es = 26;                                      // (the dictionary-less search: six fixed bits, ze_dfast_flat_np)
+        if (flatDict) { const uint64_t span = 2ull + a.cdict->contentSize + (a.slotSrcMax ? a.slotSrcMax : (uint32_t)ZE_DICT_ATTACH_MAX) + 64; es = 1; while ((1ull << es) < span) es++; }
         if (need > g_epochCap || es != g_epochShift || g_epoch + 8 >= (1u << (32 - es))) { free(g_epochTables); g_epochTables = (uint8_t*)calloc(need, 1); g_epochCap = need; g_epochShift = es; g_epoch = 0; }
         a.flatTables = g_epochTables; a.tabEpochShift = es;
     } else

@@ -883,3 +883,27 @@ def test_flat_dictionary_search_with_launch_numbers_in_the_cells(emu, ref, corpu
             assert emu.lib.emu_stat(15) - before >= 50
     finally:
         emu.set_dict_epochs(0)
+
+
+def test_flat_search_with_launch_numbers_in_the_cells(emu, ref, corpus):
+    """The dictionary-less flat search of one-block sources the same way (round 6): cells are position 18 | tag 8 | launch number 6 bits, the tables persist and are zeroed once per 63
+    launches. 70 launches over the same persistent tables (so the numbers wrap and the tables start over once), sources shuffled and of changing kinds from launch to launch, two, three
+    and four probes per trip and the LDS-source kernel in turn: every frame libzstd's."""
+    import ctypes as C
+    import numpy as np
+    rng = np.random.default_rng(53)
+    pool = [corpus.frame_bytes(200 + i)[: int(rng.integers(2000, 40000))] for i in range(10)]
+    pool += [bytes(rng.integers(0, 5, 9000, dtype=np.uint8)), (corpus.frame_bytes(3)[:700] * 40)[:25000], corpus.frame_bytes(77), b"ab" * 3000]
+    want = {r: ref.compress(r, level=3) for r in pool}
+    try:
+        emu.set_dict_epochs(1)
+        for launch in range(70):
+            emu.lib.emu_set_probes(C.c_uint32((2, 3, 4)[launch % 3]))
+            emu.lib.emu_set_e1lds_max(C.c_uint32(64 if launch % 5 == 4 else 0))
+            k = 3 if launch not in (0, 33, 69) else len(pool)                      # (most launches small -- the emulator is slow --, three of them the whole pool)
+            batch = [pool[i] for i in rng.permutation(len(pool))[:k]]
+            outs, st = emu.compress_batch(batch, level=3, flags=5, pipeline=True)
+            assert not any(st), launch
+            assert outs == [want[r] for r in batch], launch
+    finally:
+        emu.set_dict_epochs(0); emu.lib.emu_set_probes(C.c_uint32(2)); emu.lib.emu_set_e1lds_max(C.c_uint32(0))
