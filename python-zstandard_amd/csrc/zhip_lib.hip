@@ -267,6 +267,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_NSLOT
 #define ZHIP_NSLOT 3
 #endif
+#ifndef ZHIP_E1LDS_PROBES
+#define ZHIP_E1LDS_PROBES 2       // probes per trip of the LDS-source match kernel (small batches: one source per CU)
+#endif
 #ifndef ZHIP_TABLE_EPOCHS
 #define ZHIP_TABLE_EPOCHS 1      // launch numbers in the cells of the flat searches' tables; 0: the tables are zeroed every launch -- a memset, the dictionary search's own waves -- (A/B build)
 #endif
@@ -1177,10 +1180,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 if (mbc) hipLaunchKernelGGL(zhip_encode_split_kernel, dim3((uint32_t)(cnt < (size_t)c->numCU * 8 ? cnt : (size_t)c->numCU * 8)), dim3(64), 0, stream, a);
                 if (cnt <= ldsMax && !flatDict && !mbc) {
                     const dim3 g((uint32_t)cnt), b(64);
-                    if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, 2>), g, b, 0, stream, a);
-                    else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, 2>), g, b, 0, stream, a);
-                    else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, 2>), g, b, 0, stream, a);
-                    else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, 2>), g, b, 0, stream, a);
+                    if (shape == 0) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<4096, ZHIP_E1LDS_PROBES>), g, b, 0, stream, a);
+                    else if (shape == 1) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<16384, ZHIP_E1LDS_PROBES>), g, b, 0, stream, a);
+                    else if (shape == 2) hipLaunchKernelGGL((zhip_encode_match_lds_kernel<65536, ZHIP_E1LDS_PROBES>), g, b, 0, stream, a);
+                    else hipLaunchKernelGGL((zhip_encode_match_lds_kernel<ZF_BLOCK_MAX, ZHIP_E1LDS_PROBES>), g, b, 0, stream, a);
                 }
                 else launch_flat(!flatDict && !mbc && cnt <= c->knob.flat4Max ? 4 : !flatDict && !mbc && c->knob.flat3 && cnt <= c->knob.flat3Max ? 3 : 2, cnt, stream, a);
                 if (mbc) hipLaunchKernelGGL(zhip_encode_match_flat_mb_kernel, dim3((uint32_t)((cnt + a.mbLanes - 1) / a.mbLanes)), dim3(64), 0, stream, a);
