@@ -334,7 +334,7 @@ struct zhip_ctx {
     uint32_t cdictContentSize = 0;
     // launch numbers in the cells of the flat dictionary search's tables (ZhipEncodeArgs.tabEpoch): the last one used on the allocation at encEpochPtr, the index width and
     // dictionary it was counted for -- any of them changing, or the numbers running out, zeroes the allocation and starts again at 1
-    uint32_t encEpoch = 0, encEpochShift = 0; void* encEpochPtr = nullptr; uint64_t encEpochKey = 0, encEpochGen = 0;
+    uint32_t encEpoch = 0, encEpochShift = 0; void* encEpochPtr = nullptr; uint64_t encEpochKey = 0, encEpochGen = 0; size_t encEpochBytes = 0;      // (encEpochBytes: how much of the allocation has been zeroed -- a larger batch that still fits the allocation reaches slots that never were)
     uint64_t cdictKey = 0, ddictKey = 0;     // fingerprint of the dictionary currently digested (skip re-digesting per call)
     // dictionary (decode side)
     DevBuf dictBlob, dictEntropy, dictTables;
@@ -1098,9 +1098,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             *zeroed = true;
             const uint32_t maxE = (1u << (32 - es)) - 1;
             const uint64_t key = (flatDict ? c->cdictKey : 0x9E3779B97F4A7C15ull) ^ ((uint64_t)a.tableStride << 40);
-            if (tables != c->encEpochPtr || gen != c->encEpochGen || es != c->encEpochShift || key != c->encEpochKey || c->encEpoch >= maxE) {
+            if (tables != c->encEpochPtr || gen != c->encEpochGen || es != c->encEpochShift || key != c->encEpochKey || c->encEpoch >= maxE || bytes > c->encEpochBytes) {
                 HIP_TRY(hipMemsetAsync(tables, 0, bytes, stream));
-                c->encEpoch = 0; c->encEpochPtr = tables; c->encEpochGen = gen; c->encEpochShift = es; c->encEpochKey = key;
+                c->encEpoch = 0; c->encEpochPtr = tables; c->encEpochGen = gen; c->encEpochShift = es; c->encEpochKey = key; c->encEpochBytes = bytes;
             }
             args.tabEpoch = ++c->encEpoch; args.tabEpochShift = es;
             return 0;
@@ -1118,7 +1118,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
                     {   bool z = false;                                                    // (launch numbers in the cells: a candidate allocation is zeroed once, by nextEpoch)
                         if (int rc = nextEpoch(pa, t, t == (uint8_t*)cand.p ? cand.gen : c->encFlatTables.gen, bytes, &z)) return rc;
-                        if (!z && !flatDict) HIP_TRY(hipMemsetAsync(t, 0, bytes, stream)); }
+                        if (!z && !flatDict) { HIP_TRY(hipMemsetAsync(t, 0, bytes, stream)); c->encEpochPtr = nullptr; } }
                     HIP_TRY(hipEventRecord(e0, stream));
                     launch_flat(!flatDict && c->knob.flat3 && cnt0 <= c->knob.flat3Max ? 3 : 2, cnt0, stream, pa);
                     HIP_TRY(hipEventRecord(e1, stream));
@@ -1168,7 +1168,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 // every launch its own number in the tables' cells (the tables serve other sources now), or -- where the cells carry none -- zeroed tables
                 bool z = false;
                 if (int rc = nextEpoch(a, flatTables, c->encFlatTables.gen, cap * (size_t)a.tableStride, &z)) return rc;
-                if (!z && !flatDict) HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream));
+                if (!z && !flatDict) { HIP_TRY(hipMemsetAsync(flatTables, 0, cnt * (size_t)a.tableStride, stream)); c->encEpochPtr = nullptr; }      // (cells without numbers in the tables now: the next numbered launch starts from zeroed tables)
                 if (tm) HIP_TRY(hipEventRecord(ev[0], stream));
                 // a few frames: nothing hides the search's round trips, so each frame gets a CU and its source goes to LDS (ze_match_lds_body)
                 // (the LDS area follows the batch's largest source where the caller told us -- the host-buffer API does: more frames per CU)

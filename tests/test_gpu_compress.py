@@ -278,3 +278,45 @@ def test_table_placement_pick_keeps_the_frames(zstd, corpus):
                 assert got[i, : sz[i]].tobytes() == ref.compress(src_np[offs[i]: offs[i] + lens[i]].tobytes(), level=3), i
     finally:
         ctx.close()
+
+
+def test_launch_numbers_in_the_tables_across_calls(zstd, corpus):
+    """Round 6: the flat searches' tables are not zeroed per launch -- a cell carries its launch's number and the context zeroes the allocation when it must (new allocation, numbers used
+    up, a batch that reaches slots never zeroed, tables last used WITHOUT numbers: the several-block search). One thread's context through a sequence that meets each of those, every frame
+    of every call against libzstd: a batch, a slightly larger one (inside the allocation's headroom), the same sources shuffled (other sources' cells in every slot), sources of several
+    blocks through the flat search (ZHIP_MBC_MIN=0; un-numbered cells), one-block sources again, another level's strategy in between, a dictionary batch twice (its own numbering), and
+    plain sources once more."""
+    import os
+    import threading
+    from tests import reflib
+    from tests.stress_emu_encode_blocks import make
+    ref = reflib.checker()
+    rng = np.random.default_rng(77)
+    small = [corpus.frame_bytes(500 + i)[: int(rng.integers(64, 131073))] for i in range(420)]
+    blocks = [make(rng, corpus) for _ in range(24)]
+    docs = [corpus.frame_bytes(900 + i)[i * 37: i * 37 + 4096] for i in range(300)]
+    dd = ref.train_dictionary(16384, [corpus.frame_bytes(950 + i)[:4096] for i in range(200)]) if hasattr(ref, "train_dictionary") else corpus.frame_bytes(960)[:16384]
+    steps = [("a", small[:380], 3, None), ("b", small, 3, None), ("c", [small[i] for i in rng.permutation(len(small))], 3, None), ("d", blocks + small[:40], 3, None),
+             ("e", small[:400], 3, None), ("f", small[:100], 1, None), ("g", [small[i] for i in rng.permutation(400)], 3, None),
+             ("h", docs, 3, dd), ("i", [docs[i] for i in rng.permutation(len(docs))], 3, dd), ("j", small[:410], 3, None)]
+    box = {}
+
+    def run():
+        try:
+            for name, raws, level, dict_bytes in steps:
+                kw = {"dict_data": zstd.ZstdCompressionDict(dict_bytes)} if dict_bytes else {}
+                res = zstd.ZstdCompressor(level=level, **kw).multi_compress_to_buffer(raws)
+                box[name] = [res[i].tobytes() for i in range(len(raws))]
+        except Exception as e:              # noqa: BLE001 -- reported by the assertion below
+            box["error"] = e
+
+    os.environ["ZHIP_MBC_MIN"] = "0"; os.environ["ZHIP_E1LDS_MAX"] = "0"
+    try:
+        t = threading.Thread(target=run); t.start(); t.join()
+    finally:
+        del os.environ["ZHIP_MBC_MIN"]; del os.environ["ZHIP_E1LDS_MAX"]
+    assert "error" not in box, box.get("error")
+    for name, raws, level, dict_bytes in steps:
+        for i, r in enumerate(raws):
+            want = ref.compress(r, level=level, dict_data=dict_bytes) if dict_bytes else ref.compress(r, level=level)
+            assert box[name][i] == want, (name, i, len(r))
