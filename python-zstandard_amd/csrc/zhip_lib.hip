@@ -273,6 +273,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_TABLE_EPOCHS
 #define ZHIP_TABLE_EPOCHS 1      // launch numbers in the cells of the flat searches' tables; 0: the tables are zeroed every launch -- a memset, the dictionary search's own waves -- (A/B build)
 #endif
+#ifndef ZHIP_SIDE
+#define ZHIP_SIDE 1              // K1b beside K2 on a side stream; 0: the decode kernels one after the other on one stream, two chunk slots (rounds 1-5; A/B build)
+#endif
 #ifndef ZHIP_K0
 #define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
 #endif
@@ -323,6 +326,9 @@ struct zhip_ctx {
     int e1PerCU = 0, e2PerCU = 0;
     size_t srcMaxHint = 0;             // largest source of the batch being launched when the caller knows it (host-buffer API), else 0
     size_t dstMaxHint = 0;             // the same for the decode direction: largest announced content size of the batch (host-buffer API), else 0
+    bool hostPipe = false;             // the host-buffer pipeline is the caller (decompress_batch_one): its chunks' kernels are far from its bound -- the copies over the link -- and it
+                                       // already keeps three streams busy; the decode step's side stream only added a queue for those copies to share (65 536 x 128 KiB inside a process
+                                       // with other streams: 46-48 -> 38-43 GB/s with it, r06zl), so K1b stays on the chunk's stream there
     size_t dstSlotsHint = 0;           // decode, host-buffer API: block slots the frames of the batch being launched are expected to need (1 per frame of one block, 2 per 128 KiB + 2 above), else 0
     size_t itemHint = 0;               // zhip_ctx_set_size_hint: what a device-API caller says about its items' uncompressed sizes (0 = nothing)
     zhip_cparams cparams = {3, 1, 0, 1, nullptr, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
@@ -664,7 +670,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         const bool mb = sizeHint > ZF_BLOCK_MAX && sizeHint <= 0x7FFFFFFFull;     // (larger frames are the generic kernel's anyway)
         // K1b beside K2 on a side stream (below) -- not for batches of small frames: their kernels are short, the three chunk slots overlap them already, and the
         // side streams only added queues (262 144 x 4 KiB with the dictionary: 199 -> 187 GB/s, r06p)
-        const bool side = !(sizeHint && sizeHint <= 16384);
+        const bool side = ZHIP_SIDE && !c->hostPipe && !(sizeHint && sizeHint <= 16384);
         // (with the side stream a batch of several chunks runs them one after the other on ONE slot stream: two slots' kernels side by side mix K3 with the next chunk's
         // K2 -- each slows the other, section 4.1 of DESIGN.md -- and the side stream has taken the tail the second slot used to fill. 131 072 x 128 KiB: 360 GB/s on two
         // slots with or without the side stream, 365-366 on one slot with it, and half the scratch (r06s). A single 128 KiB frame: 3.6 -> 2.4 ms, its two chains run together)
@@ -1606,8 +1612,9 @@ static int decompress_batch_one(const zhip_dparams* params, const zhip_item* ite
                 slotsWanted += len <= ZF_BLOCK_MAX ? 1 : 2 * ((len + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2;
             }
             c->dstMaxHint = (size_t)mx; c->dstSlotsHint = (size_t)slotsWanted; }
+        c->hostPipe = true;
         r = zhip_decompress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);
-        c->dstMaxHint = 0; c->dstSlotsHint = 0;
+        c->hostPipe = false; c->dstMaxHint = 0; c->dstSlotsHint = 0;
         if (r) return fail(r);
         if (hipEventRecord(evK, c->hpCompute) != hipSuccess || hipStreamWaitEvent(c->hpD2H, evK, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
         // the chunk's output goes straight into its (pinned) result payload
