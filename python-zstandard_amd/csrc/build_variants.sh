@@ -2,7 +2,7 @@
 # builds kernel variants next to the product library, for A/B measurement on the GPU with ZHIP_LIB=<path>. What is left to vary at build time
 # after round 5's pruning (the forms that lost in rounds 1-4 -- lane-per-frame K2, co-resident K2 + K3, K3 / K1b rewrites, the link search --
 # are in git tag r04-experiments, with their measurements in DESIGN.md section 4 and profiles/):
-#   huf{16,4}   -DZP_HUF_FRAMES=n    K1b: n frames per wave -> 3 / 12 workgroups per CU instead of 6
+#   huf{16,10,8,4} -DZP_HUF_FRAMES=n K1b: n frames per wave -> 3 / 4 / 6 / 12 workgroups per CU instead of the product's 4 of 12 frames (rounds 2-5: 8)
 #   zqf{1,0}    -DZQ_FENCES=n        K2: fewer / no scheduling fences around the hand-placed pipeline sections
 #   zq{9,12}    -DZQ_FRAMES=n        K2: n frames per wave
 #   k3w{4,5}    -DZP_K3_MINWAVES=n   K3 at n waves per SIMD (default 6)
@@ -24,6 +24,8 @@ for v in "$@"; do
   case $v in
     huf16) build huf16 -DZP_HUF_FRAMES=16 & ;;
     huf4) build huf4 -DZP_HUF_FRAMES=4 & ;;
+    huf8) build huf8 -DZP_HUF_FRAMES=8 & ;;
+    huf10) build huf10 -DZP_HUF_FRAMES=10 & ;;
     zqf1) build zqf1 -DZQ_FENCES=1 & ;;
     zqf0) build zqf0 -DZQ_FENCES=0 & ;;
     zq9) build zq9 -DZQ_FRAMES=9 & ;;

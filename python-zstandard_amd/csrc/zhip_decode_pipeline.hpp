@@ -892,7 +892,7 @@ typedef ZpBits<ZP_HUF_RING, 2, ZP_HUF_LS> ZpHufBits;
 // A decoding cell is 12 bits of information (symbol, code length <= 11): kept as a byte array of symbols and a nibble array of lengths,
 // a frame's table is 3 KiB instead of 4, a wave's 16 tables 48 KiB (+ 4 KiB of rings), and THREE waves fit a CU's LDS instead of two --
 // the kernel is a latency-bound lookup chain, so residency is throughput.
-struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; uint32_t ring[ZP_HUF_RING << ZP_HUF_LS]; };
+struct ZpHufLDS { alignas(16) uint8_t sym[ZP_HUF_FRAMES][ZP_HUF_CELLS]; alignas(16) uint8_t len[ZP_HUF_FRAMES][ZP_HUF_CELLS / 2]; uint32_t ring[((ZP_HUF_RING - 1) << ZP_HUF_LS) + 4 * ZP_HUF_FRAMES]; };      // (ring word w of lane l at [w << LS | l], lanes 0 .. 4 x frames - 1: the last row ends with the last lane in use)
 
 ZH_DEV bool zp_huf_stream(const uint8_t* symTab, const uint8_t* lenTab, uint32_t log, const uint8_t* p, uint32_t size, uint8_t* out, uint32_t count,
                           uint32_t* ringCol)

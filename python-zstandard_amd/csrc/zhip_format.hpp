@@ -237,8 +237,10 @@ struct ZdMeta {
 #define ZP_HUF_LOGMAX 11                                // K1b's table slots hold 2^11 2-byte cells (libzstd never emits more; log 12 decodes inside K1)
 #define ZP_HUF_CELLS (1u << ZP_HUF_LOGMAX)
 #ifndef ZP_HUF_FRAMES
-#define ZP_HUF_FRAMES 8                                 // frames per K1b wave: 4 lanes (the 4 streams) each; 3 KiB of tables per frame, so 16 -> 3 waves
-#endif                                                  // per CU, 8 -> 6, 4 -> 12 (48 frames per CU either way; r02c: 8 is 7 % faster than 16 alone, 4 is slower)
+#define ZP_HUF_FRAMES 12                                // frames per K1b wave: 4 lanes (the 4 streams) each; 3 KiB of tables per frame, so 16 -> 3 waves
+#endif                                                  // per CU, 12 -> 4, 8 -> 6, 4 -> 12 (48 frames per CU either way; r02c: 8 is 7 % faster than 16 alone, 4 is slower).
+                                                        // Round 6: 12 -- ONE wave per SIMD instead of 8's six waves on four SIMDs, and (with the ring trimmed to the lanes in use)
+                                                        // 40 896 bytes of LDS, which the 40 932 ONE leaving K2 wave frees still hold: K1b's part beyond K2's end 2.40 -> 1.85 ms (r06zn)
 #define ZP_HUF_LS (ZP_HUF_FRAMES > 8 ? 6 : ZP_HUF_FRAMES > 4 ? 5 : 4)     // log2 of the K1b ring's lane stride (dwords): 4 lanes per frame
 #define ZP_LITBIN_SHIFT 9                               // K1b work order: frames binned by litSize >> 9
 #define ZP_BIN_SHIFT 7                                  // K2 work order: frames binned by nbSeq >> 7 (256 bins), longest first

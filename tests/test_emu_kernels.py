@@ -421,7 +421,7 @@ def test_several_block_search_with_an_understated_size_hint(emu, oracle, corpus)
     assert emu.stat(8) - s0 >= 2                 # the sources within the hint were still searched by the flat kernel
 
 
-@pytest.mark.parametrize("defines", [["-DZP_HUF_FRAMES=16"], ["-DZP_HUF_FRAMES=4", "-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048"]])
+@pytest.mark.parametrize("defines", [["-DZP_HUF_FRAMES=16"], ["-DZP_HUF_FRAMES=8"], ["-DZP_HUF_FRAMES=4", "-DZQ_FRAMES=9", "-DZQ_FENCES=2", "-DZP_ASM_BYTES=2048"]])
 def test_decode_shape_variants_stay_correct(oracle, corpus, tmp_path, defines):
     """the build-time shapes decode the same bytes: the quad K2 with fewer frames per wave and other fence placement, K1b with 16 / 4 frames per
     wave, K3 with a smaller assembly buffer (the losing forms of rounds 1-4 -- lane-per-frame K2, K3 / K1b rewrites -- left the source in round 5:
