@@ -356,6 +356,7 @@ struct zhip_ctx {
     struct Knobs {
         // bring-up aids
         bool prof = false;                  // ZHIP_PROF: the kernels' phase timers (a separate instantiation of K3; printed to stderr)
+        size_t k0Min = 6144;                // ZHIP_K0_MIN: frames per chunk from which K0 runs in front of K1 (a GPU test sets 0: K0 on every batch)
         // decode pipeline
         size_t dchunk = ZHIP_DCHUNK;        // frames (several-block mode: block slots) per chunk
         int nslot = 2; bool nslotSet = false;   // chunk slots on their own streams (small frames get a third unless ZHIP_NSLOT says otherwise)
@@ -401,11 +402,12 @@ extern "C" zhip_ctx* zhip_ctx_create(void)
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { g_lastError = "hipGetDeviceProperties failed"; delete c; return nullptr; }
     c->numCU = prop.multiProcessorCount;
     {   zhip_ctx::Knobs& k = c->knob;
-        // Run-time knobs (round 6: eight, each exercised by a GPU test or a resource policy; rounds 1-5's other twenty-two -- chunk shapes, probe counts, waves per CU,
-        // bring-up aids -- are the constants of this struct, and what lost its A/B is in DESIGN.md with its measurements): ZHIP_PROF (phase timers), ZHIP_E1F_PICK,
+        // Run-time knobs (round 6: nine, each exercised by a GPU test or a resource policy; rounds 1-5's other twenty-two -- chunk shapes, probe counts, waves per CU,
+        // bring-up aids -- are the constants of this struct, and what lost its A/B is in DESIGN.md with its measurements): ZHIP_PROF (phase timers), ZHIP_K0_MIN, ZHIP_E1F_PICK,
         // ZHIP_E1LDS_MAX, ZHIP_MBC_MIN here; ZHIP_DEVICES / ZHIP_DEVICE_MIN_BYTES (the in-call device fan-out), ZHIP_KEEP_GB, ZHIP_PIN_POOL_KEEP_MB (memory kept between
         // calls) where they are used.
         k.prof = getenv("ZHIP_PROF") != nullptr;
+        if (const char* e = getenv("ZHIP_K0_MIN")) k.k0Min = (size_t)atol(e);
         if (const char* e = getenv("ZHIP_MBC_MIN")) k.mbcMin = (size_t)atol(e);     // compress: batches of at least this many sources take the flat search for sources of several blocks
         if (const char* e = getenv("ZHIP_E1LDS_MAX")) { const long v = atol(e); if (v >= 0 && v <= 65536) k.e1LdsMax = v; }
         if (const char* e = getenv("ZHIP_E1F_PICK")) k.e1fPick = atol(e) != 0;    // 0: take the tables where the first allocation put them (A/B)
@@ -715,7 +717,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
         // K0's records (one per frame; not in the several-block mode, whose K1 walks a frame's blocks in order, nor for dictionary batches, whose lane pass finishes what has no table of its own)
         // (... nor for small batches: K0 is a lane-serial walk of ~0.1 ms whatever the batch, which pays from ~6 000 frames on -- 2 048 frames 3.53 -> 3.62 ms with it, 8 192
         // 4.66 -> 4.62, 16 384 7.17 -> 6.96, 32 768 12.5 -> 12.0, 65 536 23.4 -> 22.4; `profiles/r06z2_k0_by_batch_size.txt`)
-        const bool pre = ZHIP_K0 && !mb && !c->dictHasEntropy && chunk >= 6144;
+        const bool pre = ZHIP_K0 && !mb && !c->dictHasEntropy && chunk >= c->knob.k0Min;
         if (pre && c->pipePre.reserve(nslot * slots * sizeof(ZpPre))) return g_reserveRc;
         if (mb && (c->pipeItemFrame.reserve(nslot * slots * sizeof(uint32_t)) || c->pipeItemReps.reserve(nslot * slots * 4 * sizeof(uint32_t)) ||
                    c->pipeFrameRecs.reserve(nslot * chunk * sizeof(ZpFrameRec)))) return g_reserveRc;
