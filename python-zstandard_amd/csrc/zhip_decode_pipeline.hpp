@@ -315,9 +315,11 @@ ZH_DEV bool zp_lit_shared_try(const ZhipPipeArgs& a, uint32_t f, ZdMeta& m, uint
 ZH_DEVFN void zp_lit_lanes_body(const ZhipPipeArgs& a)
 {
     const uint32_t lane = zh_lane();
+    bool anyCk = false;                                  // a frame this wave finished carries a content checksum: said ONCE, when the wave leaves (counters[12]; per-frame stores
+                                                         // or atomics on that one word cost K1 0.5-3 ms per 65 536 frames, r06zs / r06zt)
     for (;;) {
         const uint32_t base = zh_first(zh_atomic_add(a.counters + 9, lane == 0 ? 64u : 0u));
-        if (base >= a.count) break;
+        if (base >= a.count) { if (anyCk && lane == 0) *(volatile uint32_t*)(a.counters + 12) = 1u; break; }
         const uint32_t i = base + lane;
         const bool mine = i < a.count;
         ZdMeta m; uint32_t need16 = 0;
@@ -329,6 +331,10 @@ ZH_DEVFN void zp_lit_lanes_body(const ZhipPipeArgs& a)
         if (total) lb = zh_first(zh_atomic_add(a.counters + 8, lane == 0 ? total : 0u)) + incl - n16;
         const bool noRoom = done && n16 && (uint64_t)lb + n16 > a.arenaBudget16;    // the chunk's room is used up: the generic kernel's frame
         zp_enter_bins_wave(a, m, done && !noRoom);
+        if (a.ckLater) {                                                            // (frames that carry a checksum: KX's count)
+            const uint32_t nck = (uint32_t)zh_popc64(zh_ballot(done && !noRoom && (m.hasChecksum & 1u)));
+            anyCk |= nck != 0;
+        }
         if (done) {
             if (noRoom) {
                 const uint32_t bm = m.blockMax, lo = m.fcsLo, hi = m.fcsHi;
@@ -506,6 +512,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
+    bool anyCk = false;                                  // (as zp_lit_lanes_body: KX's word is written once, when the wave leaves)
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
@@ -513,7 +520,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         const uint32_t got1 = zh_first(L.misc[7]);
         zh_sync();
         // dictionary batches (k1Lanes): the frames the lane-per-frame kernel could not finish, listed in `order` (free until KB fills it)
-        if (got1 >= (a.k1Lanes ? a.counters[10] : a.count)) break;
+        if (got1 >= (a.k1Lanes ? a.counters[10] : a.count)) { if (anyCk && zh_opaque(lane) == 0) *(volatile uint32_t*)(a.counters + 12) = 1u; break; }
         const uint32_t i = a.k1Lanes ? a.order[got1] : got1;
         const uint32_t f = a.first + i;
         ZdMeta m;
@@ -550,7 +557,12 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
                 if (type == 0) zd_copy_wave(dst, src + pos, bs); else zd_fill_wave(dst, src[pos], bs);
                 if (fcs != ~0ull && fcs != bs) { err = ZE_CORRUPTION; break; }
                 m.produced = bs;
-                if (hasChecksum) {
+                if (hasChecksum && a.ckLater) {                             // KX verifies it (a lane per frame; here one lane hashed 128 KiB while 63 waited)
+                    const uint32_t cpos = pos + (type == 0 ? bs : 1);
+                    if (cpos + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
+                    m.hasChecksum = 1; m.checksum = zh_ld32(src + cpos);
+                    anyCk = true;
+                } else if (hasChecksum) {
                     const uint32_t cpos = pos + (type == 0 ? bs : 1);
                     if (cpos + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
                     zd_fence();
@@ -584,6 +596,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (hasChecksum) {
                 if (pos + bs + 4 > srcSize) { err = ZE_CHECKSUM_WRONG; break; }
                 m.hasChecksum = 1; m.checksum = zh_ld32(src + pos + bs);
+                anyCk = anyCk || a.ckLater != 0;
             }
             m.path = 1;
         } while (false);
@@ -614,13 +627,14 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
     if (lane < 36) { L.llBase[lane] = zc_llBase[lane]; L.llBits[lane] = zc_llBits[lane]; }
     if (lane < 53) { L.mlBase[lane] = zc_mlBase[lane]; L.mlBits[lane] = zc_mlBits[lane]; }
     zh_sync();
+    bool anyCk = false;
     for (;;) {
         const uint32_t got = zh_atomic_add(a.counters + 0, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
         const uint32_t i = zh_first(L.misc[7]);
         zh_sync();
-        if (i >= a.count) break;
+        if (i >= a.count) { if (anyCk && zh_opaque(lane) == 0) *(volatile uint32_t*)(a.counters + 12) = 1u; break; }
         const uint32_t f = a.first + i;
         const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
         const uint64_t srcSize64 = a.srcSegs[2 * (size_t)f + 1];
@@ -652,6 +666,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
             if (h.hasChecksum) {
                 if (end + 4 > srcSize) { fallback = true; break; }
                 rec.hasChecksum = 1; rec.checksum = zh_ld32(src + end);
+                anyCk = anyCk || a.ckLater != 0;
             }
             // ---- nb consecutive items (a frame that does not get them is the generic kernel's; a partly granted range is marked unused)
             zh_sync();
@@ -1610,12 +1625,12 @@ ZH_DEVFN int zp_exec_block(const ZhipPipeArgs& a, ZpExecLDS& L, const ZdMeta& m,
 
 
 // what ends a frame: the content size it announced, its checksum (zstd.c:44264-44277). All lanes call.
-ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, uint32_t fcsLo, uint32_t fcsHi, uint32_t hasChecksum, uint32_t checksum)
+ZH_DEVFN int zp_exec_frame_end(ZpExecLDS& L, const uint8_t* dst, uint32_t op, uint32_t fcsLo, uint32_t fcsHi, uint32_t hasChecksum, uint32_t checksum, uint32_t ckLater)
 {
     const uint32_t lane = zh_lane();
     const uint64_t fcs = (uint64_t)fcsLo | ((uint64_t)fcsHi << 32);
     if (fcs != ~0ull && fcs != op) return ZE_CORRUPTION;
-    if (hasChecksum & 1) {
+    if ((hasChecksum & 1) && !ckLater) {                            // (ckLater: KX hashes the frame, a lane per frame -- here ONE lane walked 128 KiB while the wave's other 63 waited: K3 3.1 -> 9.7 ms per 16 384 frames, r06zr)
         zd_fence();
         zh_sync();
         if (zh_opaque(lane) == 0) L.misc[0] = (uint32_t)ze_xxh64(dst, op);
@@ -1646,7 +1661,7 @@ ZH_DEVFN int zp_exec_frame(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, uint
     int e = zp_exec_block<DICT, PROF, false>(a, L, m, i, src, dst, cap, cap64, m.blockMax, op, 1, 4, 8, P);
 #endif
     if (e) return e;
-    e = zp_exec_frame_end(L, dst, op, m.fcsLo, m.fcsHi, m.hasChecksum, m.checksum);
+    e = zp_exec_frame_end(L, dst, op, m.fcsLo, m.fcsHi, m.hasChecksum, m.checksum, a.ckLater);
     if (e) return e;
     *pProduced = op;
     return 0;
@@ -1690,7 +1705,7 @@ ZH_DEVFN int zp_exec_frame_mb(const ZhipPipeArgs& a, ZpExecLDS& L, uint32_t i, u
             R0 = n0; R1 = n1; R2 = n2;
         }
     }
-    const int e = zp_exec_frame_end(L, dst, op, rec.fcsLo, rec.fcsHi, rec.hasChecksum, rec.checksum);
+    const int e = zp_exec_frame_end(L, dst, op, rec.fcsLo, rec.fcsHi, rec.hasChecksum, rec.checksum, a.ckLater);
     if (e) return e;
     *pProduced = op;
     return 0;
@@ -1723,8 +1738,31 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
         if (PROF && P.on) { ZD_T(P, ZP_RAW); if (lane == 0) for (int q = 0; q < ZP_N; q++) if (P.acc[q]) zh_atomic_add64(a.prof + 16 + q, P.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) {
-            if (MB && err == ZP_RC_FALLBACK) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = a.first + i; }
+            if (MB && err == ZP_RC_FALLBACK) { const uint32_t q = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[q] = a.first + i;
+                                               a.status[a.first + i] = ZE_CORRUPTION; a.outSizes[a.first + i] = 0; }      // (a placeholder the generic kernel overwrites: KX must not take the frame for a finished one)
             else { a.status[a.first + i] = err; a.outSizes[a.first + i] = err ? 0 : produced; }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ KX (a LANE per frame: content checksums)
+// A frame's content checksum is XXH64 over its output (zstd.c:44270-44277) -- four accumulators over 32-byte stripes, a serial chain of 4 096 steps for 128 KiB. K3 (and K1 for raw / RLE
+// frames) ran it on ONE lane at the frame's end while the wave's other 63 lanes waited: a batch of checksummed frames took K3 3.1 -> 9.7 ms and K1 0.33 -> 2.4 ms per 16 384 frames
+// (`profiles/r06zr_decode_checksum_cost.txt`). Here every lane hashes a frame of its own, after K3: frames that carry a checksum (K1 noted the trailer in the record), were finished by
+// the pipeline (path 2 is the generic kernel's, which checks for itself) and decoded without error. A mismatch is the frame's answer, as libzstd's (checksum_wrong, nothing produced).
+ZH_DEVFN void zp_check_body(const ZhipPipeArgs& a)
+{
+    if (a.counters[12] == 0) return;                                // no frame of the chunk carries a checksum
+    const uint32_t lane = zh_lane();
+    for (uint32_t i = zh_block() * 64 + lane; i < a.count; i += zh_nblocks() * 64) {
+        uint32_t has, want, path;
+        if (a.itemCap) { const ZpFrameRec& r = a.frameRecs[i]; has = r.hasChecksum & 1u; want = r.checksum; path = r.path; }
+        else { const ZdMeta& m = a.meta[i]; has = m.hasChecksum & 1u; want = m.checksum; path = m.path; }
+        if (!has || path == 2) continue;
+        const uint32_t f = a.first + i;
+        if (a.status[f] != 0) continue;
+        const uint8_t* dst = a.dst + a.dstSegs[2 * (size_t)f];
+        const uint64_t n = a.outSizes[f];
+        if ((uint32_t)ze_xxh64(dst, (uint32_t)n) != want) { a.status[f] = ZE_CHECKSUM_WRONG; a.outSizes[f] = 0; }
     }
 }

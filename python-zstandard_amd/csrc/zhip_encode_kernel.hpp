@@ -2689,7 +2689,7 @@ ZH_DEVFN int ze_frame_multi_impl(const ZhipEncodeArgs& a, ZeLDS& L, ZeLDSMulti* 
         zh_sync();
     }
     if (checksum) {
-        if (zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));
+        if (!a.xxLater && zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));     // (xxLater: EX fills the trailer -- one lane hashing the source while 63 wait is a fifth of this kernel's time per frame)
         pos += 4;
     }
     ze_fence();
@@ -2779,7 +2779,7 @@ ZH_DEVFN int ze_frame(const ZhipEncodeArgs& a, ZeLDS& L, uint32_t f, uint8_t* ws
         }
     }
     if (checksum) {
-        if (zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));
+        if (!a.xxLater && zh_opaque(lane) == 0) zh_st32(dst + pos, (uint32_t)ze_xxh64(src, srcSize));     // (xxLater: EX fills the trailer -- one lane hashing the source while 63 wait is a fifth of this kernel's time per frame)
         pos += 4;
     }
     ze_fence();
@@ -3181,5 +3181,25 @@ ZH_DEVFN void ze_entropy_body(const ZhipEncodeArgs& a, ZeLDS& L)
         if (P) { ZE_T(P, ZEP_REST); if (zh_opaque(lane) == 0) for (int q = 0; q < ZEP_N; q++) zh_atomic_add64(a.prof + q, (unsigned long long)prof.acc[q]); }
         zh_sync();
         if (zh_opaque(lane) == 0) { a.status[f] = err; a.outSizes[f] = err ? 0 : produced; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ EX (a LANE per frame: the frames' checksum trailers)
+// write_checksum frames end with the low 32 bits of XXH64 of the SOURCE (zstd.c:28325-28329): a serial chain of 4 096 steps per 128 KiB that the entropy kernel ran on one lane
+// of the frame's wave. With ZhipEncodeArgs.xxLater the entropy kernel only reserves the 4 bytes; here every lane hashes a source of its own and stores the trailer at the end
+// of the frame that kernel produced. Frames listed for the generic kernel (modes 3 / 5) keep its own hashing.
+ZH_DEVFN void ze_trailer_body(const ZhipEncodeArgs& a)
+{
+    const uint32_t lane = zh_lane();
+    for (uint32_t i = zh_block() * 64 + lane; i < a.count; i += zh_nblocks() * 64) {
+        const uint32_t mode = a.meta[i].mode;
+        if (mode == 3 || mode == 5) continue;
+        const uint32_t f = a.first + i;
+        if (a.status[f] != 0) continue;
+        const uint64_t n = a.outSizes[f];
+        if (n < 4) continue;
+        const uint8_t* src = a.src + a.srcSegs[2 * (size_t)f];
+        const uint64_t srcSize = a.srcSegs[2 * (size_t)f + 1];
+        zh_st32(a.dst + a.dstSegs[2 * (size_t)f] + n - 4, (uint32_t)ze_xxh64(src, (uint32_t)srcSize));
     }
 }

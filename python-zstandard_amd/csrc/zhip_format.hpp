@@ -118,6 +118,7 @@ struct ZhipEncodeArgs {
     // the kernel's waves zero the tables first (the emulator's default; dictionaries whose index space leaves fewer than 6 bits); else cell = index | tabEpoch << tabEpochShift,
     // the host zeroes the allocation once and whenever the numbers run out or the index width changes (zhip_compress_batch_device)
     uint32_t tabEpoch, tabEpochShift;
+    uint32_t xxLater;               // != 0: frames leave the entropy kernel with their 4 checksum bytes reserved, not computed -- EX (ze_trailer_body: a LANE per frame) hashes the sources after it
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk
     // inputs above one block (multi-block frames) are listed by E1 for the generic kernel, which also honours an explicit list
     uint32_t* bigList; uint32_t* bigCount;
@@ -312,6 +313,8 @@ struct ZhipPipeArgs {
     ZpFrameRec* frameRecs;      // count
     uint64_t maxWindowSize;
     uint32_t magicless;         // 1: frames carry no magic number (ZSTD_f_zstd1_magicless)
+    uint32_t ckLater;           // != 0: content checksums are verified AFTER K3 by KX (zp_check_body: a lane per frame) -- K1's raw / RLE frames and K3's frame end only note the trailer;
+                                // counters[12] != 0 once a frame of the chunk carries one (KX returns at once on 0)
     ZpPre* pre;                 // chunk : K0's records (null: no K0 ran -- the several-block mode, dictionary batches -- and K1 parses everything itself); counters[11] is K0's work counter
     uint32_t k1Lanes;           // != 0 (dictionary batches, round 6): zhip_decode_lit_lanes_kernel ran first -- a LANE walked every frame whose tables are all the
                                 // dictionary's ("treeless" literals, every sequence table "repeat": nothing to build) -- and K1 takes only the frames it listed in `order`

@@ -35,6 +35,7 @@ ZH_GLOBAL __launch_bounds__(64, 2) void zhip_decode_lit_kernel(ZhipPipeArgs a)
     zp_lit_body(a, L);
 }
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_lit_lanes_kernel(ZhipPipeArgs a) { zp_lit_lanes_body(a); }      // K1's lane-per-frame pass over dictionary batches
+ZH_GLOBAL __launch_bounds__(64) void zhip_decode_check_kernel(ZhipPipeArgs a) { zp_check_body(a); }      // KX: content checksums, a lane per frame, after K3
 ZH_GLOBAL __launch_bounds__(64) void zhip_decode_pre_kernel(ZhipPipeArgs a)           // K0: a lane per frame walks what K1's lane 0 used to (Huffman weights, sequence distributions)
 {
     __shared__ ZpPreLDS L;
@@ -110,6 +111,7 @@ ZH_GLOBAL __launch_bounds__(64) void zhip_encode_split_kernel(ZhipEncodeArgs a) 
     __shared__ ZeLDS L;
     ze_split_body(a, L);
 }
+ZH_GLOBAL __launch_bounds__(64) void zhip_encode_trailer_kernel(ZhipEncodeArgs a) { ze_trailer_body(a); }      // EX: checksum trailers, a lane per frame, after E2
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat_kernel(ZhipEncodeArgs a) { ze_match_flat_body<2>(a); }
 // four probes per trip: chunks small enough to be bound by a source's serial chain rather than by the memory system (ze_dfast_flat_np)
 ZH_GLOBAL __launch_bounds__(64) void zhip_encode_match_flat4_kernel(ZhipEncodeArgs a) { ze_match_flat_body<4>(a); }
@@ -272,6 +274,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #endif
 #ifndef ZHIP_TABLE_EPOCHS
 #define ZHIP_TABLE_EPOCHS 1      // launch numbers in the cells of the flat searches' tables; 0: the tables are zeroed every launch -- a memset, the dictionary search's own waves -- (A/B build)
+#endif
+#ifndef ZHIP_TRAILER_LATER
+#define ZHIP_TRAILER_LATER 1     // compress: checksum trailers by EX after the entropy kernel; 0: by the entropy kernel on one lane per frame (A/B build)
 #endif
 #ifndef ZHIP_SIDE
 #define ZHIP_SIDE 1              // K1b beside K2 on a side stream; 0: the decode kernels one after the other on one stream, two chunk slots (rounds 1-5; A/B build)
@@ -778,6 +783,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             // dictionary batches: a lane-per-frame pass first (zhip_decode_lit_lanes_kernel: frames whose tables are all the dictionary's are nothing but header
             // arithmetic), K1 then only over the frames that pass listed
             pa.k1Lanes = !mb && c->dictHasEntropy ? 1u : 0u;
+            pa.ckLater = 1;
             pa.pre = pre ? (ZpPre*)c->pipePre.p + (size_t)sidx * slots : nullptr;
             const size_t tasks1 = cnt;
             const uint32_t g1 = (uint32_t)(tasks1 < g1m ? tasks1 : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
@@ -832,6 +838,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, ss, pa);      // (ZHIP_PROF with a dictionary or frames of several blocks: K3's timers read zero -- said once at context creation)
             else hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            { const size_t w = (cnt + 63) / 64, gm = (size_t)c->numCU * 8; hipLaunchKernelGGL(zhip_decode_check_kernel, dim3((uint32_t)(w < gm ? w : gm)), dim3(64), 0, ss, pa); }      // KX (returns at once when no frame carries a checksum; timed with K3)
             if (tm) HIP_TRY(hipEventRecord(ev[3], ss));
             HIP_TRY(hipGetLastError());
             if (tm) {
@@ -1200,7 +1207,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             if (tm) HIP_TRY(hipEventRecord(ev[2], stream));
             hipLaunchKernelGGL(zhip_encode_match_kernel, dim3(g1), dim3(64), 0, stream, a);
             if (tm) { HIP_TRY(hipEventRecord(ev[3], stream)); HIP_TRY(hipEventRecord(ev[4], stream)); }
+            a.xxLater = ZHIP_TRAILER_LATER && a.checksumFlag ? 1u : 0u;
             hipLaunchKernelGGL(zhip_encode_entropy_kernel, dim3(g2), dim3(64), 0, stream, a);
+            if (a.xxLater) { const size_t w = (cnt + 63) / 64, gm = (size_t)c->numCU * 8; hipLaunchKernelGGL(zhip_encode_trailer_kernel, dim3((uint32_t)(w < gm ? w : gm)), dim3(64), 0, stream, a); }      // EX (timed with E2)
+            a.xxLater = 0;
             if (tm) HIP_TRY(hipEventRecord(ev[5], stream));
             if (mbc) {      // this chunk's sources of several blocks: the generic kernel over the list the flat kernel just made (it reads the chunk's arenas)
                 ZhipEncodeArgs b = a;

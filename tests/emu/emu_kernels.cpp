@@ -143,6 +143,9 @@ static void k3_lane(void* p)
     if (a.itemCap) { if (a.dictContent) zp_exec_body<true, false, true>(a, g_xlds); else zp_exec_body<false, false, true>(a, g_xlds); }
     else if (a.dictContent) zp_exec_body<true, false>(a, g_xlds); else zp_exec_body<false, false>(a, g_xlds);
 }
+static void kx_lane(void* p) { zp_check_body(*(const ZhipPipeArgs*)p); }
+static uint32_t g_ckLater = 1;                  // content checksums verified by KX after K3 (a lane per frame), as the product does; 0: by K1 / K3 on one lane (rounds 1-5)
+extern "C" void emu_set_check_later(uint32_t v) { g_ckLater = v; }
 static void k1mb_lane(void* p) { zp_lit_mb_body(*(const ZhipPipeArgs*)p, g_lds); }
 static uint64_t g_arenaBudget16 = 0;                    // compact decode arena: != 0 overrides the harness' worst-case budget, in 16-byte units (what runs out is the generic kernel's)
 extern "C" void emu_set_arena_budget(uint64_t units16) { g_arenaBudget16 = units16; }
@@ -203,6 +206,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
     }
     a.k1Lanes = g_k1Lanes && a.dictEntropy ? 1u : 0u;       // (mirrors zhip_decompress_batch_device; cleared below in the several-block mode)
     ZpPre* pre = nullptr;
+    a.ckLater = g_ckLater;
     for (uint32_t first = 0; first < n; first += chunk) {
         a.first = first; a.count = n - first < chunk ? n - first : chunk;
         for (uint32_t q = 0; q < ZP_CNT_WORDS; q++) counters[q] = 0;
@@ -224,6 +228,7 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
         memset(&g_seqqlds, 0xA5, sizeof g_seqqlds);
         zhemu::run_grid(nBlocks, k2_lane, &a);
         zhemu::run_grid(nBlocks, k3_lane, &a);
+        if (a.ckLater) zhemu::run_grid(nBlocks, kx_lane, &a);
     }
     // generic kernel for everything the fast path declined
     ZhipDecodeArgs g; memset(&g, 0, sizeof(g));
@@ -243,6 +248,9 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
 // ---- two-kernel encoder under emulation
 static void e1_lane(void* p) { ze_match_body(*(const ZhipEncodeArgs*)p); }
 static void e2_lane(void* p) { ze_entropy_body(*(const ZhipEncodeArgs*)p, g_elds); }
+static void ex_lane(void* p) { ze_trailer_body(*(const ZhipEncodeArgs*)p); }
+static uint32_t g_xxLater = 1;                  // checksum trailers by EX after the entropy kernel (a lane per frame), as the product does; 0: by the entropy kernel on one lane
+extern "C" void emu_set_trailer_later(uint32_t v) { g_xxLater = v; }
 static uint32_t g_probes = 2;                   // probes per trip of the flat search (2, or 4: the latency-bound batches' form)
 extern "C" void emu_set_probes(uint32_t v) { g_probes = v; }
 static void e1f_lane(void* p) { if (g_probes == 4) ze_match_flat_body<4>(*(const ZhipEncodeArgs*)p); else if (g_probes == 3) ze_match_flat_body<3>(*(const ZhipEncodeArgs*)p); else ze_match_flat_body<2>(*(const ZhipEncodeArgs*)p); }
@@ -331,7 +339,10 @@ extern "C" int emu_compress_pipeline(const uint8_t* src, const uint64_t* srcSegs
             if (mbc) { a.mbLanes = 16; a.mbProbes = g_probes; zhemu::run_grid((a.count + a.mbLanes - 1) / a.mbLanes, e1fmb_lane, &a); }
         }
         zhemu::run_grid(nBlocks, e1_lane, &a);
+        a.xxLater = g_xxLater && a.checksumFlag ? 1u : 0u;
         zhemu::run_grid(nBlocks, e2_lane, &a);
+        if (a.xxLater) zhemu::run_grid(nBlocks, ex_lane, &a);
+        a.xxLater = 0;
         if (mbc && bigCount) {                   // the chunk's sources of several blocks: the generic kernel right away (it reads the chunk's arenas)
             ZhipEncodeArgs b = a; uint32_t bc = 0;
             b.workspace = (uint8_t*)malloc((size_t)nBlocks * ZHIP_ENC_STRIDE); b.counter = &bc; b.frameList = a.bigList; b.listCount = &bigCount;

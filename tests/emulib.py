@@ -196,3 +196,11 @@ def _emu_set_dict_epochs(self, v):
 
 
 Emu.set_dict_epochs = _emu_set_dict_epochs
+
+
+def _emu_set_check_later(self, v):
+    """1 (default, as the product): content checksums are verified by KX after K3, a lane per frame; 0: by K1 / K3 on one lane at the frame's end"""
+    self.lib.emu_set_check_later(C.c_uint32(v))
+
+
+Emu.set_check_later = _emu_set_check_later

@@ -907,3 +907,77 @@ def test_flat_search_with_launch_numbers_in_the_cells(emu, ref, corpus):
             assert outs == [want[r] for r in batch], launch
     finally:
         emu.set_dict_epochs(0); emu.lib.emu_set_probes(C.c_uint32(2)); emu.lib.emu_set_e1lds_max(C.c_uint32(0))
+
+
+def test_content_checksums_verified_by_a_lane_per_frame(emu, ref, corpus):
+    """Round 6: KX (zp_check_body) verifies content checksums after K3, a lane per frame -- K3 and K1 (raw / RLE frames) used to hash 128 KiB on ONE lane. Frames with and without
+    checksums side by side: compressible, incompressible (raw block: K1 finishes them), byte runs (RLE), empty, frames of several blocks (the several-block mode), dictionary frames
+    that the lane pass finishes -- each also with its checksum trailer or a content byte damaged. Both forms must agree on every status and byte, wrong checksums must be refused as
+    checksum_wrong (22), right ones accepted."""
+    import numpy as np
+    from tests import reflib
+    rng = np.random.default_rng(61)
+    raws = [corpus.frame_bytes(700 + i)[: int(rng.integers(100, 131073))] for i in range(10)] + [rng.bytes(50000), rng.bytes(131072), b"z" * 70000, b"", b"ab" * 9, bytes(4000)]
+    F = reflib.DEFAULT_FLAGS | reflib.F_CHECKSUM
+    frames = [ref.compress(r, level=3, flags=F) for r in raws] + [ref.compress(r, level=3) for r in raws[:4]]
+    sizes = [len(r) for r in raws] + [len(r) for r in raws[:4]]
+    bad = []
+    for k in range(len(raws)):
+        f = bytearray(frames[k])
+        if len(f) < 12: continue
+        f[-1 - (k % 4)] ^= 0x40                                  # the trailer itself
+        bad.append((bytes(f), sizes[k]))
+    allf = frames + [b for b, _ in bad]; alls = sizes + [n for _, n in bad]
+    try:
+        res = {}
+        for later in (0, 1):
+            emu.set_check_later(later)
+            res[later] = emu.decompress_pipeline(allf, alls, n_blocks=3, chunk=0)
+        assert res[1][1] == res[0][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[1][1], res[0][1])) if a != b][:8]
+        assert all(a == b for a, b, s in zip(res[1][0], res[0][0], res[0][1]) if s == 0) and res[1][2] == res[0][2]
+        st = res[1][1]
+        assert not any(st[:len(frames)]) and all(o == r for o, r in zip(res[1][0], raws + raws[:4]))
+        assert all(s == 22 for s in st[len(frames):]), st[len(frames):]
+        # frames of several blocks
+        big = [corpus.frame_bytes(40 + k)[:90000] + rng.bytes(3000) + corpus.frame_bytes(80 + k) for k in range(4)]
+        bf = [ref.compress(r, level=3, flags=F) for r in big]
+        wrong = bytearray(bf[1]); wrong[-2] ^= 1
+        emu.set_blocks(6)
+        for later in (0, 1):
+            emu.set_check_later(later)
+            outs, st, nfb = emu.decompress_pipeline(bf + [bytes(wrong)], [len(r) for r in big] + [len(big[1])], n_blocks=3, chunk=0)
+            assert st[:4] == [0, 0, 0, 0] and outs[:4] == big and st[4] == 22, (later, st)
+        emu.set_blocks(0)
+        # dictionary frames the lane pass finishes, with checksums
+        docs = [corpus.frame_bytes(900 + i)[i * 31: i * 31 + 4096] for i in range(70)]
+        dd = ref.train_dictionary(16384, [corpus.frame_bytes(950 + i)[:4096] for i in range(120)])
+        df = [ref.compress(d, level=3, flags=F, dict_data=dd) for d in docs]
+        w2 = bytearray(df[5]); w2[-1] ^= 0x80
+        assert emu.set_ddict(dd) == 0
+        for later in (0, 1):
+            emu.set_check_later(later)
+            outs, st, nfb = emu.decompress_pipeline(df + [bytes(w2)], [4096] * 71, n_blocks=3, chunk=0)
+            assert not any(st[:70]) and outs[:70] == docs and st[70] == 22, (later, st[60:])
+    finally:
+        emu.set_check_later(1); emu.set_blocks(0); emu.set_ddict(None)
+
+
+def test_checksum_trailers_written_by_a_lane_per_frame(emu, ref, corpus):
+    """Round 6: EX (ze_trailer_body) fills the frames' checksum trailers after the entropy kernel, a lane per frame (that kernel hashed the source on ONE lane of the frame's wave).
+    write_checksum frames of compressible, incompressible (raw block), run (RLE block), tiny and empty sources, with and without a dictionary, with the trailer written either way:
+    libzstd's frames, byte for byte."""
+    import ctypes as C
+    import numpy as np
+    rng = np.random.default_rng(67)
+    raws = [corpus.frame_bytes(800 + i)[: int(rng.integers(64, 131073))] for i in range(12)] + [rng.bytes(40000), b"r" * 30000, b"xyz", b"", corpus.frame_bytes(3)[:63]]
+    dd = corpus.frame_bytes(990)[:20000]
+    docs = [corpus.frame_bytes(990)[i * 50: i * 50 + 3000] + raws[i % 12][:1000] for i in range(20)]
+    try:
+        for later in (1, 0):
+            emu.lib.emu_set_trailer_later(C.c_uint32(later))
+            outs, st = emu.compress_batch(raws, level=3, flags=7, pipeline=True)
+            assert not any(st) and outs == [ref.compress(r, level=3, flags=7) for r in raws], later
+            outs, st = emu.compress_batch(docs, level=3, flags=7, pipeline=True, dict_data=dd)
+            assert not any(st) and outs == [ref.compress(r, level=3, flags=7, dict_data=dd) for r in docs], later
+    finally:
+        emu.lib.emu_set_trailer_later(C.c_uint32(1))
