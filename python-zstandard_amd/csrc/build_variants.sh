@@ -62,6 +62,7 @@ for v in "$@"; do
     e2w5) build e2w5 -DZE_E2_MINWAVES=5 & ;;
     e1lds4) build e1lds4 -DZHIP_E1LDS_PROBES=4 & ;;        # the LDS-source match kernel (small batches) with four probes per trip
     noepoch) build noepoch -DZHIP_TABLE_EPOCHS=0 & ;;      # the flat searches with their tables zeroed every launch (rounds 1-5; A/B of round 6: profiles/r06ze_*, r06zg_*)
+    nofastwide) build nofastwide -DZHIP_FAST_WIDE=0 & ;;   # fast-strategy batches in chunks of 32 768 at eight sources per wave (rounds 2-5)
     notrailer) build notrailer -DZHIP_TRAILER_LATER=0 & ;;   # compress with write_checksum: the entropy kernel hashes the source on one lane (rounds 1-5; A/B of round 6: profiles/r06zt_*)
     noside) build noside -DZHIP_SIDE=0 -DZHIP_K0=0 & ;;    # the decode step as rounds 1-5 ran it: one stream, no K0
     nok0) build nok0 -DZHIP_K0=0 & ;;                    # decode without K0: K1's lane 0 parses the Huffman weights and the sequence distributions itself (rounds 1-5; A/B of round 6: profiles/r06w_*)

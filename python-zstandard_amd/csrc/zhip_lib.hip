@@ -275,6 +275,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_TABLE_EPOCHS
 #define ZHIP_TABLE_EPOCHS 1      // launch numbers in the cells of the flat searches' tables; 0: the tables are zeroed every launch -- a memset, the dictionary search's own waves -- (A/B build)
 #endif
+#ifndef ZHIP_FAST_WIDE
+#define ZHIP_FAST_WIDE 1          // fast-strategy batches above 32 768 sources: 65 536 per chunk at sixteen sources per wave; 0: chunks of 32 768 at eight (A/B build)
+#endif
 #ifndef ZHIP_TRAILER_LATER
 #define ZHIP_TRAILER_LATER 1     // compress: checksum trailers by EX after the entropy kernel; 0: by the entropy kernel on one lane per frame (A/B build)
 #endif
@@ -1036,7 +1039,10 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 flatMax = c->flatMaxCached;
             }
         }
-        size_t chunkMax = c->hasCDict ? 262144 : flat ? flatMax : 32768;
+        // (the fast strategy -- levels 1, 2, negative -- runs in the lane-serial match kernel, whose time is ONE source's chain of dependent round trips: every source in flight at once
+        // is one chain's time, two chunks of 32 768 are two. ZHIP_FAST_WIDE: 65 536 per chunk, sixteen sources per wave -- the kernel's 111 VGPRs hold 4 096 waves)
+        const bool fastWide = ZHIP_FAST_WIDE && !flat && !c->hasCDict && n > 32768;
+        size_t chunkMax = c->hasCDict ? 262144 : flat ? flatMax : fastWide ? 65536 : 32768;
         if (flat) { const size_t byMem = ((size_t)(flatMax > 65536 ? 96 : 32) << 30) / a.tableStride; if (chunkMax > byMem) chunkMax = byMem; }
         if (c->knob.echunk && c->knob.echunk < chunkMax) chunkMax = c->knob.echunk;
         // Sources of several blocks (the caller's size hint says so) in a double-fast batch without dictionary: the flat kernel searches them
@@ -1048,8 +1054,8 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         if (mbc) { const size_t byMem = ((size_t)32 << 30) / (mbSeqCap * 8); if (chunkMax > byMem) chunkMax = byMem ? byMem : 1; }
         const size_t chunk = n < chunkMax ? n : chunkMax;
         const size_t cap = chunk;                                              // items the arenas are sized for
-        const size_t laneCap = c->hasCDict ? 262144 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
-        const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : ZE_E1_LANES;
+        const size_t laneCap = c->hasCDict ? 262144 : fastWide ? 65536 : 32768;          // lanes of the lane-serial match kernel in flight (each owns tableStride bytes of tables)
+        const size_t e1Lanes = c->hasCDict ? ZE_E1_LANES_DICT : fastWide ? 16 : ZE_E1_LANES;
         a.e1Lanes = (uint32_t)e1Lanes;
         size_t g1max = (size_t)c->numCU * (size_t)c->e1PerCU; if (g1max * e1Lanes > laneCap) g1max = laneCap / e1Lanes;
         if (flat && g1max > 256) g1max = 256;                                      // only the frames the flat kernel declines

@@ -320,3 +320,22 @@ def test_launch_numbers_in_the_tables_across_calls(zstd, corpus):
         for i, r in enumerate(raws):
             want = ref.compress(r, level=level, dict_data=dict_bytes) if dict_bytes else ref.compress(r, level=level)
             assert box[name][i] == want, (name, i, len(r))
+
+
+def test_fast_strategy_batches_above_32768_sources(zstd, corpus):
+    """Round 6: fast-strategy batches (levels 1, 2, negative) above 32 768 sources run 65 536 per chunk at sixteen sources per wave of the lane-serial match kernel -- every source in
+    flight at once -- instead of chunks of 32 768 at eight. 34 000 small sources (64 bytes ... 6 KiB, a few of a whole block) at levels 1 and -3: every frame libzstd's."""
+    from tests import reflib
+    ref = reflib.checker()
+    rng = np.random.default_rng(83)
+    pool = [corpus.frame_bytes(1200 + i) for i in range(40)]
+    raws = []
+    for i in range(34000):
+        b = pool[i % 40]; o = int(rng.integers(0, 120000)); n = int(rng.integers(64, 6145)) if i % 500 else 131072
+        raws.append(b[o:o + n] if n < 131072 else b)
+    for level in (1, -3):
+        res = zstd.ZstdCompressor(level=level).multi_compress_to_buffer(raws)
+        assert len(res) == len(raws)
+        for i in range(0, len(raws), 7):
+            assert res[i].tobytes() == ref.compress(raws[i], level=level), (level, i, len(raws[i]))
+        del res
