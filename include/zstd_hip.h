@@ -148,7 +148,9 @@ int       zhip_ctx_set_cparams(zhip_ctx*, const zhip_cparams* params);          
  * Items above one block (128 KiB) are frames of several blocks. Told so, decompression runs the phase-split kernels in their several-block
  * mode (a block is the work item) and compression gives the generic kernel the whole chip -- or, in batches of thousands of such sources, the
  * flat match kernel searches them too. Untold, they are decoded / encoded one wave per frame by a token grid of the generic kernels: correct,
- * slow (the reference has no equivalent: its workers take any size, c-ext/compressor.c:1035). */
+ * slow (the reference has no equivalent: its workers take any size, c-ext/compressor.c:1035). Frames of ONE block's size may also be frames of several
+ * blocks -- libzstd's block splitter (levels 16 and up) cuts a 128 KiB source into many --: a decompress caller whose frames come from such levels
+ * should say 131 073 or more here (the host-buffer API counts every frame's blocks itself and does). */
 void      zhip_ctx_set_size_hint(zhip_ctx*, uint64_t maxItemBytes);
 
 /* d_src: concatenated frames; d_srcSegs[i] = (offset,length) of frame i in d_src.

@@ -236,6 +236,26 @@ static int host_frame_header(HostFrameHeader* h, const uint8_t* src, size_t n, i
     h->headerSize = (uint32_t)mg + hs; h->hasChecksum = (fhd >> 2) & 1;
     return 0;
 }
+// how many blocks a frame has (0: not a frame this walk can follow -- the kernels will say what is wrong with it). The host-buffer decompress call uses it to tell frames of
+// SEVERAL blocks from frames of one: libzstd's block splitter (levels 16 and up) cuts even a 128 KiB source into many, and those belong to the pipeline's several-block mode,
+// not -- one wave each -- to the generic kernel (round 6: 2 048 level-19 frames of 128 KiB took 44 ms there, 6 GB/s)
+static uint32_t host_count_blocks(const uint8_t* src, size_t n, int format)
+{
+    HostFrameHeader h;
+    if (host_frame_header(&h, src, n, format) < 0 || h.skippable) return 0;
+    size_t pos = h.headerSize; uint32_t nb = 0;
+    for (;;) {
+        if (pos + 3 > n) return 0;
+        const uint32_t bh = rd24(src + pos); pos += 3;
+        const uint32_t type = (bh >> 1) & 3, bs = bh >> 3;
+        if (type == 3) return 0;
+        const size_t body = type == 1 ? 1 : bs;
+        if (pos + body > n) return 0;
+        pos += body; nb++;
+        if (bh & 1) return nb;
+        if (nb > 65535) return 0;
+    }
+}
 extern "C" uint64_t zhip_frame_content_size_format(const void* src, size_t n, int format)
 {
     HostFrameHeader h;
@@ -1570,6 +1590,7 @@ static int decompress_batch_one(const zhip_dparams* params, const zhip_item* ite
     if (!c) return set_err(err, ZHIP_ERR_HIP, 0, 0);
     // pass 1 (decompress_worker pass 1, decompressor.c:981-1014): every frame needs a known decompressed size
     std::vector<zhip_segment> segs(2 * n);           // [0,n) source, [n,2n) destination
+    std::vector<uint32_t> nBlocks(n);                // blocks per frame (0: unknown), from the block headers (host_count_blocks)
     const int format = params ? params->format : ZHIP_FORMAT_ZSTD1;
     uint64_t srcTotal = 0, dstTotal = 0;
     for (size_t i = 0; i < n; i++) {
@@ -1584,6 +1605,7 @@ static int decompress_batch_one(const zhip_dparams* params, const zhip_item* ite
         if (ds > ((uint64_t)1 << 46) || dstTotal + ds > ((uint64_t)1 << 46)) return set_err(err, ZHIP_ERR_NO_MEMORY, i, 0);
         segs[i].offset = srcTotal; segs[i].length = items[i].srcSize; srcTotal += items[i].srcSize;
         segs[n + i].offset = dstTotal; segs[n + i].length = ds; dstTotal += ds;
+        nBlocks[i] = host_count_blocks((const uint8_t*)items[i].src, items[i].srcSize, format);
     }
     int r = zhip_ctx_set_dformat(c, format, params ? params->maxWindowSize : 0);
     if (r) return set_err(err, r, 0, 0);
@@ -1623,12 +1645,17 @@ static int decompress_batch_one(const zhip_dparams* params, const zhip_item* ite
         const uint64_t outBytes = segs[n + hi - 1].offset + segs[n + hi - 1].length - segs[n + lo].offset;
         if (upload_items(c, items, segs.data(), lo, hi, evUp)) return fail(ZHIP_ERR_HIP);
         if (hipStreamWaitEvent(c->hpCompute, evUp, 0) != hipSuccess) return fail(ZHIP_ERR_HIP);
-        {   uint64_t mx = 0, slotsWanted = 0;
+        {   uint64_t mx = 0, slotsWanted = 0; size_t several = 0;
             for (size_t i = lo; i < hi; i++) {
                 const uint64_t len = segs[n + i].length;
                 if (len > mx) mx = len;
-                slotsWanted += len <= ZF_BLOCK_MAX ? 1 : 2 * ((len + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2;
+                // (a frame's block count is known where its block headers could be walked: the slots it will take; else the estimate from its size)
+                slotsWanted += nBlocks[i] > 1 ? (uint64_t)nBlocks[i] + 1 : len <= ZF_BLOCK_MAX ? 1 : 2 * ((len + ZF_BLOCK_MAX - 1) / ZF_BLOCK_MAX) + 2;
+                several += nBlocks[i] > 1 && len <= ZF_BLOCK_MAX;
             }
+            // frames of one block's size cut into SEVERAL blocks (the block splitter of levels 16+): from one in sixteen on the chunk takes the several-block mode -- a size hint just
+            // above a block says so --, below that the few go to the generic kernel as before
+            if (several * 16 >= cnt && mx <= ZF_BLOCK_MAX) mx = ZF_BLOCK_MAX + 1;
             c->dstMaxHint = (size_t)mx; c->dstSlotsHint = (size_t)slotsWanted; }
         c->hostPipe = true;
         r = zhip_decompress_batch_device(c, c->hSrc.p, dSegs + lo, cnt, c->hDst.p, dSegs + n + lo, dSizes + lo, dStatus + lo, c->hpCompute);

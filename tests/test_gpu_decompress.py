@@ -381,3 +381,27 @@ def test_k0_on_small_and_unusual_batches(zstd, corpus):
             assert want is not None and got == want, i
             good += 1
     assert good >= 70 and int((st1 != 0).sum()) >= 30, (good, int((st1 != 0).sum()))
+
+
+def test_frames_cut_by_the_block_splitter_take_the_several_block_mode(zstd, corpus):
+    """libzstd's block splitter (levels 16 and up) cuts even a 128 KiB source into many blocks: such frames are frames of several blocks although no larger than one. The host-buffer
+    call counts every frame's blocks from its block headers and gives a chunk with enough of them to the pipeline's several-block mode (round 6: one wave each in the generic kernel,
+    they decoded at 6 GB/s). Level-19 and level-17 frames, alone, mixed with level-3 frames, and a few among many level-3 frames (those few stay the generic kernel's): every byte back."""
+    from tests import reflib
+    ref = reflib.checker()
+    raws = [corpus.frame_bytes(1300 + i)[: 131072 - 997 * (i % 5)] for i in range(96)]
+    hi = [ref.compress(r, level=19 if i % 2 else 17) for i, r in enumerate(raws)]
+    lo = [ref.compress(r, level=3) for r in raws]
+    blocks = []
+    for f in hi[:8]:
+        fhd = f[4]; single = (fhd >> 5) & 1; pos = 5 + (0 if single else 1) + [0, 1, 2, 4][fhd & 3] + ([1 if single else 0, 2, 4, 8][fhd >> 6]); nb = 0
+        while True:
+            bh = int.from_bytes(f[pos:pos + 3], "little"); nb += 1; pos += 3 + (1 if (bh >> 1) & 3 == 1 else bh >> 3)
+            if bh & 1: break
+        blocks.append(nb)
+    assert max(blocks) > 1, blocks                       # (the splitter did cut them)
+    d = zstd.ZstdDecompressor()
+    for batch, want in ((hi, raws), (hi[:40] + lo[:40], raws[:40] + raws[:40]), (lo + hi[:3], raws + raws[:3]), ([hi[5]], [raws[5]])):
+        res = d.multi_decompress_to_buffer(batch)
+        assert len(res) == len(batch) and all(res[i].tobytes() == want[i] for i in range(len(batch)))
+    assert d.decompress(hi[7]) == raws[7]
