@@ -1311,7 +1311,9 @@ ZH_DEVFN uint32_t ze_fast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const
         if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
         if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }
     uint32_t nseq = 0; uint8_t* lp = lits;
-#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; \
+    // (lits == nullptr: sequences only -- the entropy kernel gathers the literals from the source, wave-parallel, as for the flat search; this lane's byte-by-byte copy of ~45 KB per
+    // 128 KiB source was a good part of the lane-serial kernel's time on fast-strategy batches)
+#define ZE_STORE(LL, OFFBASE, ML) do { const uint32_t ll_ = (uint32_t)(LL); if (lits) { for (uint32_t i_ = 0; i_ < ll_; i_++) lp[i_] = anchor[i_]; lp += ll_; } \
         seqs[nseq] = ZE_SEQ_PACK(OFFBASE, ll_, (uint32_t)(ML)); nseq++; } while (0)
 #define ZE_IDX(p) ((uint32_t)((p) - base))
     if (srcSize >= 8) for (;;) {
@@ -1371,8 +1373,8 @@ ZH_DEVFN uint32_t ze_fast_g(uint64_t* seqs, uint8_t* lits, uint32_t* pLit, const
     }
 #undef ZE_IDX
 #undef ZE_STORE
-    {   const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
-    *pLit = (uint32_t)(lp - lits);
+    if (lits) { const uint32_t lastLL = (uint32_t)(iend - anchor); for (uint32_t i = 0; i < lastLL; i++) lp[i] = anchor[i]; lp += lastLL; }
+    *pLit = lits ? (uint32_t)(lp - lits) : 0u;
     if (saved1 != 0 && rep1 != 0) saved2 = saved1;
     rep[0] = rep1 ? rep1 : saved1; rep[1] = rep2 ? rep2 : saved2;
     return nseq;
@@ -2986,7 +2988,7 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
         if (srcSize < 7) { m.mode = 1; a.meta[i] = m; continue; }
         uint32_t* hashLong = (uint32_t*)tables;
         uint32_t* hashSmall = (uint32_t*)(tables + (4u << cp.hlog));
-        { uint64_t* z = (uint64_t*)tables; const uint32_t nz = ((4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u)) / 8; for (uint32_t k = 0; k < nz; k++) z[k] = 0; }
+        { ZdPack16* z = (ZdPack16*)tables; const uint32_t nz = ((4u << cp.hlog) + (cp.strat == 2 ? (4u << cp.clog) : 0u)) / 16; ZdPack16 zero; zero.a = zero.b = zero.c = zero.d = 0; for (uint32_t k = 0; k < nz; k++) z[k] = zero; }
         uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
         uint32_t litSize = 0;
         // a dictionary without content (shorter than 8 bytes: nothing of it is loaded, zstd.c:28167) is not attached
@@ -2995,9 +2997,10 @@ ZH_DEVFN void ze_match_body(const ZhipEncodeArgs& a)
                                                                                    a.cdictHashLong, hashLong)
                                                                       : ze_dfast_dict((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, *a.cdict, a.cdictContent,
                                                                                       a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall))
-                          : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, hashLong)
+                          : cp.strat == 1 ? ze_fast((uint64_t*)(fr + ZE_ARENA_SEQ), nullptr, &litSize, src, srcSize, cp, hashLong)
                           : ze_dfast((uint64_t*)(fr + ZE_ARENA_SEQ), fr + a.arenaLit, &litSize, src, srcSize, cp, hashLong, hashSmall);
         m.litSize = litSize;
+        if (!(a.cdict && a.cdict->contentSize) && cp.strat == 1) m.mode = 4;                  // sequences only: the entropy kernel gathers the literals
         a.meta[i] = m;
     }
 }
