@@ -393,7 +393,7 @@ struct zhip_ctx {
         size_t echunk = 0;                  // ZHIP_ECHUNK: sources per chunk, upper bound (0: none)
         size_t echunkMax = 0;               // ZHIP_ECHUNK_MAX: frames per launch of the flat match kernel (0 = 65 536, and 131 072 for larger batches where memory allows)
         long e1LdsMax = -1; size_t e1LdsRounds = 2;     // the LDS-source match kernel of small batches: most sources it takes (-1: by the CU count), rounds per CU
-        size_t mbcMin = 8192;               // sources per 256 KiB of size hint from which sources of several blocks take the flat search
+        size_t mbcMin = 4096;               // sources per 256 KiB of size hint from which sources of several blocks take the flat search (8 192 until r06zzi)
         unsigned mbcLanes = 32;             // sources per wave of that search (64 / 32 / 16 / 8 within 10-30 % of each other, r03z)
         // probes per trip of the flat double-fast search by launch size: up to flat4Max sources four (bound by one source's serial chain: 21-25 % less time from
         // 1 024 to 32 768 sources, r04zd), up to flat3Max three, above two (with the placement picked, at 65 536: 421 / 415 / 425 ms for two / three / four, r05w)
@@ -996,7 +996,9 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
         // (64 per wave, whose every trip waits for the slowest of 64 requests and runs every lane's branch: ~10 % slower per round at 256 KiB,
         // 50 % at 512 KiB+). r03u / r03v, flat against generic: 2 048 x 1 MiB 2.5 s / 1.04 s, 4 096 x 512 KiB 1.31 / 0.85, 4 096 x 256 KiB
         // 0.44 / 0.42, 8 192 x 256 KiB 0.47 / 0.68, 16 384 x 256 KiB 0.51 / 1.24, 8 192 x 1 MiB 3.3 / ~2.1: the longer the sources the more
-        // rounds of the generic kernel it takes to lose, hence the threshold grows with the size hint -- ZHIP_MBC_MIN sources per 256 KiB of it)
+        // rounds of the generic kernel it takes to lose, hence the threshold grows with the size hint -- ZHIP_MBC_MIN sources per 256 KiB of it.
+        // Round 6's kernels, flat / generic (r06zzi): 3 072 x 256 KiB 340 / 325 ms, 4 096 x 256 KiB 351 / 420, 6 144 x 384 KiB 810 / 846, 4 096 x 512 KiB 1 075 / 860,
+        // 8 192 x 512 KiB 1 191 / 1 417, 12 288 x 512 KiB 1 639 / 1 965, 2 048 x 1 MiB 1 950 / 1 034: the flat search wins from 4 096 per 256 KiB on, was 8 192)
         const bool mbcWanted = anyDfast && !c->hasCDict && n >= c->knob.mbcMin * ((sizeHint + (256u << 10) - 1) / (256u << 10)) && sizeHint > ZF_BLOCK_MAX && sizeHint < ((size_t)1 << ZE_MB_POS_BITS) - 8;
         if (mbcWanted) for (int t = 0; t < 2; t++) {
             const int32_t* r = a.rows.r[t];
