@@ -10,7 +10,6 @@
 #   asm2k       -DZP_ASM_BYTES=2048  K3: 2 KiB batch assembly buffer
 #   own32       -DZP_LIT_SHORT=32 -DZP_FAR_SHORT=32   K3: own-lane items up to 32 bytes (round 2's shape)
 #   nohist      -DZP_HIST_KEEP=0u -DZP_HIST_SLIDE=0u  K3 without the LDS history in front of the batch (round 6 A/B)
-#   nohalves    -DZHIP_HALVES=0      decode pipeline without the chunk in halves (K3's first half beside K1b's second)
 #   nok0        -DZHIP_K0=0          decode pipeline without K0 (the lane-per-frame parser pass in front of K1)
 #   dchunk32k   -DZHIP_DCHUNK=32768  decode pipeline in chunks of 32 768 frames (two slot streams) instead of one of 65 536
 #   e1l{16,32,64} -DZE_E1_LANES=n    lane-serial match kernel (fast-strategy batches): n frames per wave instead of 8
@@ -66,9 +65,6 @@ for v in "$@"; do
     nofastwide) build nofastwide -DZHIP_FAST_WIDE=0 & ;;   # fast-strategy batches in chunks of 32 768 at eight sources per wave (rounds 2-5)
     notrailer) build notrailer -DZHIP_TRAILER_LATER=0 & ;;   # compress with write_checksum: the entropy kernel hashes the source on one lane (rounds 1-5; A/B of round 6: profiles/r06zt_*)
     noside) build noside -DZHIP_SIDE=0 -DZHIP_K0=0 & ;;    # the decode step as rounds 1-5 ran it: one stream, no K0
-    halvesb2) build halvesb2 -DZHIP_HALVES_BDIV=2 & ;;
-    halvesb4) build halvesb4 -DZHIP_HALVES_BDIV=4 & ;;
-    nohalves) build nohalves -DZHIP_HALVES=0 & ;;          # decode: K1b, then K3, each over the whole chunk (round 6 until its last session; A/B: profiles/r06zzl_*)
     nok0) build nok0 -DZHIP_K0=0 & ;;                    # decode without K0: K1's lane 0 parses the Huffman weights and the sequence distributions itself (rounds 1-5; A/B of round 6: profiles/r06w_*)
     dchunk32k) build dchunk32k -DZHIP_DCHUNK=32768 & ;;    # decode: chunks of 32 768 frames on the slot streams (round 6 A/B with K1b beside K2: profiles/r06q_*)
     e1l16) build e1l16 -DZE_E1_LANES=16 & ;;

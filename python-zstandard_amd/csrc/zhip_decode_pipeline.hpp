@@ -193,21 +193,13 @@ ZH_DEVFN int zp_block_tables(const ZhipPipeArgs& a, ZdLDS& L, ZdState& st, ZdLit
     return 0;
 }
 
-// K1b's bin of a frame with Huffman literals, longest first; with the chunk in halves (ZhipPipeArgs.split) the half is the key's top bit and the size bins are twice as wide:
-// bins 0..127 hold the frames below `split`, 128..255 the rest
-ZH_DEV uint32_t zp_lit_bin(const ZhipPipeArgs& a, uint32_t i, uint32_t litSize)
-{
-    const uint32_t kl = 1u + (litSize >> ZP_LITBIN_SHIFT);
-    if (!a.split) return 256u - (kl > 256u ? 256u : kl);
-    const uint32_t k2 = (kl + 1u) >> 1;
-    return (i >= a.split ? 128u : 0u) + (128u - (k2 > 128u ? 128u : k2));
-}
 // the item's place in K2's and K1b's work orders (KB below): its bin, and its rank inside the bin -- the atomic's return value (lane 0 calls)
-ZH_DEV void zp_enter_bins(const ZhipPipeArgs& a, ZdMeta& m, uint32_t i)
+ZH_DEV void zp_enter_bins(const ZhipPipeArgs& a, ZdMeta& m)
 {
     const uint32_t ks = m.nbSeq ? 1u + (m.nbSeq >> ZP_BIN_SHIFT) : 0u;
+    const uint32_t kl = (m.litMode & 255u) == 3u ? 1u + (m.litSize >> ZP_LITBIN_SHIFT) : 0u;
     if (ks) m.pad = zh_atomic_add(a.counters + ZP_CNT_BINS + (256 - (ks > 256 ? 256u : ks)), 1u);
-    if ((m.litMode & 255u) == 3u) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + zp_lit_bin(a, i, m.litSize), 1u) << 1;
+    if (kl) m.hasChecksum |= zh_atomic_add(a.counters + ZP_CNT_BINS + 256 + (256 - (kl > 256 ? 256u : kl)), 1u) << 1;
 }
 // the same for a wave whose every lane holds a frame of its own (zp_lit_lanes_body; all lanes call, `on` = this lane has a record to enter): the lanes that enter the same
 // bin claim their ranks with ONE atomic -- 262 144 four-KiB documents of one shape are two bins, and a per-lane atomic on one address is what the pass would then wait for
@@ -612,7 +604,7 @@ ZH_DEVFN void zp_lit_body(const ZhipPipeArgs& a, ZdLDS& L)
         if (err) { m.status = err; m.path = 0; }
         zh_sync();
         if (zh_opaque(lane) == 0) {
-            if (m.path == 1) zp_enter_bins(a, m, i);
+            if (m.path == 1) zp_enter_bins(a, m);
             a.meta[i] = m;
             if (m.path == 2) { const uint32_t k = zh_atomic_add(a.fallbackCount, 1u); a.fallbackList[k] = f; }
             if (m.path == 0) { a.status[f] = m.status; a.outSizes[f] = m.status ? 0 : m.produced; }
@@ -734,7 +726,7 @@ ZH_DEVFN void zp_lit_mb_body(const ZhipPipeArgs& a, ZdLDS& L)
                 pos += type == 1 ? 1u : bs;
                 zh_sync();
                 if (zh_opaque(lane) == 0) {
-                    if (m.path == 1) zp_enter_bins(a, m, t);
+                    if (m.path == 1) zp_enter_bins(a, m);
                     a.meta[t] = m; a.itemFrame[t] = i;
                 }
                 zh_sync();
@@ -810,14 +802,12 @@ ZH_DEVFN void zp_bin_body(const ZhipPipeArgs& a, ZpBinLDS& L)
         L.base[4 * lane] = b0; L.base[4 * lane + 1] = b0 + h0; L.base[4 * lane + 2] = b0 + h0 + h1; L.base[4 * lane + 3] = b0 + h0 + h1 + h2;
         if (blk == 0 && lane == 63) a.counters[lit ? 4 : 1] = incl; }
     zh_sync();
-    if (lit && a.split && blk == 0 && lane == 0) a.counters[13] = L.base[128];          // the chunk in halves: K1b's order holds this many frames of the first half, in front
     const uint32_t nItems = !a.itemCap ? a.count : a.counters[6] < a.itemCap ? a.counters[6] : a.itemCap;      // several-block mode: the items K1 claimed
     for (uint32_t i = blk * 64 + lane; i < nItems; i += half * 64) {
         const ZdMeta* m = a.meta + i;
         const uint32_t path = m->path, ns = m->nbSeq, lm = m->litMode, ls = m->litSize, rs = m->pad, rl = m->hasChecksum >> 1;
-        if (path != 1) continue;
-        if (lit) { if ((lm & 255u) == 3u) order[L.base[zp_lit_bin(a, i, ls)] + rl] = i; }
-        else if (ns) { const uint32_t k = 1u + (ns >> ZP_BIN_SHIFT); order[L.base[256 - (k > 256 ? 256u : k)] + rs] = i; }
+        const uint32_t k = path != 1 ? 0u : lit ? ((lm & 255u) == 3u ? 1u + (ls >> ZP_LITBIN_SHIFT) : 0u) : (ns ? 1u + (ns >> ZP_BIN_SHIFT) : 0u);
+        if (k) order[L.base[256 - (k > 256 ? 256u : k)] + (lit ? rl : rs)] = i;
     }
     zd_fence();
 }
@@ -965,14 +955,12 @@ typedef ZpHufLDS ZpHufKernelLDS;
 ZH_DEVFN void zp_huf_body(const ZhipPipeArgs& a, ZpHufKernelLDS& L)
 {
     const uint32_t lane = zh_lane(), slot = lane >> 2, strm = lane & 3;
-    // (the chunk in halves: part 1 takes the work order's first counters[13] entries -- the frames below `split` --, part 2 the rest, each with a group counter of its own)
-    const uint32_t kLo = a.part == 2 ? a.counters[13] : 0u, total = a.part == 1 ? a.counters[13] : a.counters[4];
-    const uint32_t nGroups = (total - kLo + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES;
-    uint32_t* const cursor = a.counters + (a.part == 2 ? 14 : 5);
+    const uint32_t total = a.counters[4];
+    const uint32_t nGroups = (total + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES;
     for (;;) {
-        const uint32_t g = zh_first(zh_atomic_add(cursor, lane == 0 ? 1u : 0u));
+        const uint32_t g = zh_first(zh_atomic_add(a.counters + 5, lane == 0 ? 1u : 0u));
         if (g >= nGroups) break;
-        const uint32_t k = kLo + g * ZP_HUF_FRAMES + slot;
+        const uint32_t k = g * ZP_HUF_FRAMES + slot;
         const bool active = slot < ZP_HUF_FRAMES && k < total;
         const uint32_t i = active ? a.orderLit[k] : 0xFFFFFFFFu;
         uint32_t mode = 0, litSize = 0, streamOff = 0, streamBytes = 0;
@@ -1729,16 +1717,13 @@ ZH_DEVFN void zp_exec_body(const ZhipPipeArgs& a, ZpExecLDS& L)
     const uint32_t lane = zh_lane();
     // Frames are taken in index order (K2's work order -- longest first -- measured slower, r03f: every wave on a many-sequence frame at the same time
     // makes the far-match gathers of 4 096 waves peak together; the corpus' own mix of heavy and light frames spreads them).
-    // (the chunk in halves: part 1 the frames below `split`, part 2 the rest, each with a work counter of its own)
-    const uint32_t iLo = a.part == 2 ? a.split : 0u, iHi = a.part == 1 ? a.split : a.count;
-    uint32_t* const cursor = a.counters + (a.part == 2 ? 15 : 2);
     for (;;) {
-        const uint32_t got = zh_atomic_add(cursor, lane == 0 ? 1u : 0u);
+        const uint32_t got = zh_atomic_add(a.counters + 2, lane == 0 ? 1u : 0u);
         if (zh_opaque(lane) == 0) L.misc[7] = got;
         zh_sync();
-        const uint32_t k = iLo + zh_first(L.misc[7]);
+        const uint32_t k = zh_first(L.misc[7]);
         zh_sync();
-        if (k >= iHi) break;
+        if (k >= a.count) break;
         const uint32_t i = k;
         if (MB) { if (a.frameRecs[i].path != 1) continue; }
         else {

@@ -319,9 +319,6 @@ struct ZhipPipeArgs {
     uint32_t k1Lanes;           // != 0 (dictionary batches, round 6): zhip_decode_lit_lanes_kernel ran first -- a LANE walked every frame whose tables are all the
                                 // dictionary's ("treeless" literals, every sequence table "repeat": nothing to build) -- and K1 takes only the frames it listed in `order`
                                 // (counters[10] of them; counters[9] is that kernel's work counter)
-    uint32_t split, part;       // round 6, "halves": split != 0 -- K1b's work order holds the frames below index `split` first (counters[13] of them) and K1b / K3 are launched
-                                // twice, part 1 over the frames below `split`, part 2 over the rest (work counters [14] / [15]), so that K3's first half starts while K1b's second half
-                                // still runs beside it (zhip_decompress_batch_device); part 0: the whole chunk
     unsigned long long* prof;   // optional per-phase cycle totals (ZHIP_PROF tuning aid): [0..9] K1 phases, [16..25] K3 phases
     // dictionary (all null / 0 without one): id, raw content (match sources before the frame's first byte), parsed entropy section, its tables
     uint32_t dictID, dictContentSize;

@@ -304,12 +304,6 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_SIDE
 #define ZHIP_SIDE 1              // K1b beside K2 on a side stream; 0: the decode kernels one after the other on one stream, two chunk slots (rounds 1-5; A/B build)
 #endif
-#ifndef ZHIP_HALVES
-#define ZHIP_HALVES 1            // large chunks in halves: K3's first half beside K1b's second (zhip_decompress_batch_device); 0: K1b, then K3, whole (A/B build)
-#endif
-#ifndef ZHIP_HALVES_BDIV
-#define ZHIP_HALVES_BDIV 1       // K1b's second launch on 1 / n of the workgroups its LDS allows (room for K3's first half beside it)
-#endif
 #ifndef ZHIP_K0
 #define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
 #endif
@@ -814,9 +808,6 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
             pa.k1Lanes = !mb && c->dictHasEntropy ? 1u : 0u;
             pa.ckLater = 1;
             pa.pre = pre ? (ZpPre*)c->pipePre.p + (size_t)sidx * slots : nullptr;
-            // (the chunk in halves -- see the launches below: large dictionary-less single-block chunks with the side stream)
-            const bool halves = ZHIP_HALVES && side && !mb && !pa.dictContent && !pa.dictEntropy && !pa.prof && cnt >= 16384;
-            pa.split = halves ? (uint32_t)(cnt / 2) : 0u; pa.part = 0;
             const size_t tasks1 = cnt;
             const uint32_t g1 = (uint32_t)(tasks1 < g1m ? tasks1 : g1m), g2 = (uint32_t)(w2 < g2m ? w2 : g2m), g3 = (uint32_t)(cnt < g3m ? cnt : g3m);
             const size_t wh = (items + ZP_HUF_FRAMES - 1) / ZP_HUF_FRAMES, ghm = (size_t)c->numCU * (ZHIP_LDS_BYTES / sizeof(ZpHufKernelLDS));
@@ -851,35 +842,12 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 if (mb) hipLaunchKernelGGL(zhip_decode_seq_mb_kernel, dim3(g2), dim3(64), 0, ss, pa);
                 else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
                 if (tm) { HIP_TRY(hipEventRecord(ev[1], ss)); HIP_TRY(hipEventRecord(evS0, ss)); }       // (two events at K2's end: one closes K2's pair, one opens K1b's)
-                if (halves) {
-                    // The chunk in halves (round 6's last find): K3 needs ALL of K2 but only its own frames' literals, and K1b's last part (1.85 ms at 65 536 frames) ran with nothing
-                    // beside it. K1b's work order holds the frames of the chunk's first half in front (KB), K1b runs as two launches on the side stream, K3's first half starts on the main
-                    // stream once K2 and K1b's first launch are done -- beside K1b's second --, K3's second half follows K1b's second launch on the side stream and takes the slots the
-                    // first half's waves leave.
-                    hipEvent_t evA, evK2; HIP_TRY(hipEventCreateWithFlags(&evA, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&evK2, hipEventDisableTiming));
-                    HIP_TRY(hipEventRecord(evK2, ss));
-                    ZhipPipeArgs pA = pa, pB = pa; pA.part = 1; pB.part = 2;
-                    hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, sd, pA);
-                    HIP_TRY(hipEventRecord(evA, sd));
-                    hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh / ZHIP_HALVES_BDIV ? gh / ZHIP_HALVES_BDIV : 1u), dim3(64), 0, sd, pB);
-                    if (tm) HIP_TRY(hipEventRecord(evS1, sd));
-                    HIP_TRY(hipStreamWaitEvent(sd, evK2, 0));
-                    HIP_TRY(hipStreamWaitEvent(ss, evA, 0));
-                    if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
-                    const uint32_t gA = (uint32_t)(pa.split < g3m ? pa.split : g3m), gB = (uint32_t)(cnt - pa.split < g3m ? cnt - pa.split : g3m);
-                    hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(gA), dim3(64), 0, ss, pA);
-                    hipLaunchKernelGGL(zhip_decode_exec_kernel, dim3(gB), dim3(64), 0, sd, pB);
-                    HIP_TRY(hipEventRecord(evSide, sd));
-                    HIP_TRY(hipStreamWaitEvent(ss, evSide, 0));
-                    (void)hipEventDestroy(evA); (void)hipEventDestroy(evK2);
-                } else {
                 hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, sd, pa);
                 if (tm) HIP_TRY(hipEventRecord(evS1, sd));
                 HIP_TRY(hipEventRecord(evSide, sd));
                 HIP_TRY(hipStreamWaitEvent(ss, evSide, 0));
-                }
                 (void)hipEventDestroy(evBin); (void)hipEventDestroy(evSide);
-                if (tm && !halves) HIP_TRY(hipEventRecord(ev[2], ss));
+                if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
             } else {
                 if (tm) { HIP_TRY(hipEventRecord(evh, ss)); HIP_TRY(hipEventRecord(evh2, ss)); }
                 hipLaunchKernelGGL(zhip_decode_huf_kernel, dim3(gh), dim3(64), 0, ss, pa);
@@ -888,8 +856,7 @@ extern "C" int zhip_decompress_batch_device(zhip_ctx* c, const void* d_src, cons
                 else hipLaunchKernelGGL(zhip_decode_seq_kernel, dim3(g2), dim3(64), 0, ss, pa);
                 if (tm) HIP_TRY(hipEventRecord(ev[2], ss));
             }
-            if (halves) { }                                                   // (K3 went out above, in two parts)
-            else if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
+            if (mb && pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_mb_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (mb) hipLaunchKernelGGL(zhip_decode_exec_mb_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (pa.dictContent) hipLaunchKernelGGL(zhip_decode_exec_dict_kernel, dim3(g3), dim3(64), 0, ss, pa);
             else if (pa.prof) hipLaunchKernelGGL(zhip_decode_exec_prof_kernel, dim3(g3), dim3(64), 0, ss, pa);      // (ZHIP_PROF with a dictionary or frames of several blocks: K3's timers read zero -- said once at context creation)

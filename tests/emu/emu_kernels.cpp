@@ -146,8 +146,6 @@ static void k3_lane(void* p)
 static void kx_lane(void* p) { zp_check_body(*(const ZhipPipeArgs*)p); }
 static uint32_t g_ckLater = 1;                  // content checksums verified by KX after K3 (a lane per frame), as the product does; 0: by K1 / K3 on one lane (rounds 1-5)
 extern "C" void emu_set_check_later(uint32_t v) { g_ckLater = v; }
-static uint32_t g_halves = 0;                   // != 0: the chunk in halves (ZhipPipeArgs.split / part) -- K1b and K3 run twice, as zhip_decompress_batch_device launches them for large chunks
-extern "C" void emu_set_halves(uint32_t v) { g_halves = v; }
 static void k1mb_lane(void* p) { zp_lit_mb_body(*(const ZhipPipeArgs*)p, g_lds); }
 static uint64_t g_arenaBudget16 = 0;                    // compact decode arena: != 0 overrides the harness' worst-case budget, in 16-byte units (what runs out is the generic kernel's)
 extern "C" void emu_set_arena_budget(uint64_t units16) { g_arenaBudget16 = units16; }
@@ -223,26 +221,13 @@ extern "C" int emu_decompress_pipeline(const uint8_t* src, const uint64_t* srcSe
             a.pre = pre;
             zhemu::run_grid(nBlocks, k0_lane, &a);
         }
-        const bool halves = g_halves && !mb && !a.dictContent && !a.dictEntropy && a.count >= 2;      // (the product: chunks of 16 384 frames and more)
-        a.split = halves ? a.count / 2 : 0u; a.part = 0;
         zhemu::run_grid(nBlocks, mb ? k1mb_lane : k1_lane, &a);
         zhemu::run_grid(2 * (a.count < 8 ? 1u : 3u), kb_lane, &a);
         memset(&g_huflds, 0xA5, sizeof g_huflds);
-        if (halves) {                                 // in the order the streams allow at the earliest: K1b's first half, K2, K3's first half, K1b's second half, K3's second half
-            ZhipPipeArgs pA = a, pB = a; pA.part = 1; pB.part = 2;
-            zhemu::run_grid(nBlocks, kh_lane, &pA);
-            memset(&g_seqqlds, 0xA5, sizeof g_seqqlds);
-            zhemu::run_grid(nBlocks, k2_lane, &a);
-            zhemu::run_grid(nBlocks, k3_lane, &pA);
-            memset(&g_huflds, 0xA5, sizeof g_huflds);
-            zhemu::run_grid(nBlocks, kh_lane, &pB);
-            zhemu::run_grid(nBlocks, k3_lane, &pB);
-        } else {
         zhemu::run_grid(nBlocks, kh_lane, &a);
         memset(&g_seqqlds, 0xA5, sizeof g_seqqlds);
         zhemu::run_grid(nBlocks, k2_lane, &a);
         zhemu::run_grid(nBlocks, k3_lane, &a);
-        }
         if (a.ckLater) zhemu::run_grid(nBlocks, kx_lane, &a);
     }
     // generic kernel for everything the fast path declined

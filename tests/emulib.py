@@ -204,12 +204,3 @@ def _emu_set_check_later(self, v):
 
 
 Emu.set_check_later = _emu_set_check_later
-
-
-def _emu_set_halves(self, v):
-    """1: the chunk in halves -- K1b's work order holds the first half's frames in front, K1b and K3 run twice (K3's first half BEFORE K1b's second), as the product launches
-    large dictionary-less single-block chunks; 0 (default): K1b, K2, K3 once each"""
-    self.lib.emu_set_halves(C.c_uint32(v))
-
-
-Emu.set_halves = _emu_set_halves

@@ -981,49 +981,3 @@ def test_checksum_trailers_written_by_a_lane_per_frame(emu, ref, corpus):
             assert not any(st) and outs == [ref.compress(r, level=3, flags=7, dict_data=dd) for r in docs], later
     finally:
         emu.lib.emu_set_trailer_later(C.c_uint32(1))
-
-
-def test_chunk_in_halves_k3_beside_k1b(emu, ref, corpus):
-    """Round 6's last find: K3 needs all of K2 but only its own frames' literals, so large chunks run K1b and K3 in two parts -- KB puts the first half's frames in front of K1b's
-    work order (the half is the top bit of the literal bin), part 1 of K1b / K3 takes the frames below `split`, part 2 the rest (zhip_decompress_batch_device). The emulator runs
-    K3's first half BEFORE K1b's second, the earliest the streams allow: frames of several levels and shapes (Huffman, raw, RLE and treeless literals, no sequences, odd counts so
-    that a K1b group straddles nothing it should not), damaged copies and short slots -- whole and in halves must agree on every status and byte, and whole frames are their sources."""
-    import numpy as np
-    rng = np.random.default_rng(77)
-    raws = []
-    for i in range(45):
-        base = corpus.frame_bytes(1200 + i); n = int(rng.integers(50, 131073)); k = i % 7
-        r = (base[:n] if k in (0, 1) else bytes(rng.integers(0, 9, n, dtype=np.uint8)) if k == 2 else rng.bytes(n // 3) if k == 3 else b"q" * n if k == 4
-             else (base[:500] + rng.bytes(40)) * (n // 540 + 1) if k == 5 else bytes((np.frombuffer(base[:n], dtype=np.uint8) & 0x1F).tobytes()))
-        raws.append(r[:n])
-    levels = [3, 1, 3, 5, -1, 3, 7]
-    frames = [ref.compress(r, level=levels[i % 7], flags=7 if i % 4 == 0 else 5) for i, r in enumerate(raws)]
-    sizes = [len(r) for r in raws]
-    for k in range(30):
-        f = bytearray(frames[k])
-        if k % 5 == 4: f = f[: max(6, len(f) - 2 - k % 7)]
-        else:
-            for _ in range(1 + k % 2): f[int(rng.integers(5, len(f)))] ^= 1 << int(rng.integers(0, 8))
-        frames.append(bytes(f)); sizes.append(sizes[k])
-    frames.append(frames[3]); sizes.append(max(0, sizes[3] - 9))           # a whole frame whose slot is too small
-    order = rng.permutation(len(frames))
-    frames = [frames[j] for j in order]; sizes = [sizes[j] for j in order]
-    res = {}
-    try:
-        for h in (0, 1):
-            emu.set_halves(h)
-            res[h] = emu.decompress_pipeline(frames, sizes, n_blocks=3, chunk=0)
-        # and in chunks of 20 frames: every chunk is cut in halves of its own
-        emu.set_halves(1)
-        res[2] = emu.decompress_pipeline(frames, sizes, n_blocks=2, chunk=20)
-    finally:
-        emu.set_halves(0)
-    for h in (1, 2):
-        assert res[h][1] == res[0][1], [(i, a, b) for i, (a, b) in enumerate(zip(res[h][1], res[0][1])) if a != b][:8]
-        assert all(a == b for a, b, s in zip(res[h][0], res[0][0], res[0][1]) if s == 0) and res[h][2] == res[0][2]
-    good = 0
-    for pos, j in enumerate(order):
-        if j < 45:
-            assert res[1][1][pos] == 0 and res[1][0][pos] == raws[j], (pos, j)
-            good += 1
-    assert good == 45 and sum(1 for s in res[1][1] if s != 0) >= 15
