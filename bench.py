@@ -383,7 +383,8 @@ def e1f_regime(ctx, ktimes, frames):
             per = ms * 65536.0 / fpl
             pick = ctx.table_pick()
             return {"match_kernel_ms_per_65536_frames": round(per, 2), "frames_per_launch": int(fpl), "known_range_ms": [397, 488],
-                    "table_pick": {"candidates_ms": [round(x, 1) for x in pick[0] if x > 0], "kept": pick[1]} if pick[0][0] > 0 else None,
+                    "table_pick": {"candidates_ms": [round(x, 1) for x in pick[0] if x > 0], "kept": pick[1],
+                                   "candidates_are": "probe launches over the first 8 KiB of every source (they rank the allocations like whole launches: profiles/r06zzr_pick_study.txt)"} if pick[0][0] > 0 else None,
                     "class": "fast" if per <= 425 else "slow" if per >= 455 else "middle",
                     "note": "placement of the context's tables, not the build: compare compress figures of equal class (launches of 131 072 frames cost ~9 % less per frame)"}
     return None

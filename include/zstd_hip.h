@@ -179,7 +179,8 @@ const char* zhip_kernel_name(int k);
 int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
 /* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 49 152 frames or more times the match kernel on
  * up to three table allocations held side by side and keeps the fastest; where a probe is cheap -- dictionary batches -- and the three came out alike, up to three more):
- * ms3[k] = candidate k's time in ms for the first three (0 = not tried). Returns the index kept (3..5: one of the further candidates). */
+ * ms3[k] = candidate k's PROBE time in ms for the first three (0 = not tried) -- since round 6's last session a probe launch searches the first 8 KiB of every source only, which ranks the
+ * allocations like the whole launch does at a thirteenth of the time (30 against 36 ms per 65 536 sources of 128 KiB where the whole launches take 407 against 470). Returns the index kept (3..5: one of the further candidates). */
 int         zhip_ctx_table_pick(zhip_ctx*, float* ms3);
 
 #ifdef __cplusplus

@@ -3054,9 +3054,11 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     }
     if (!take) return;
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
-    m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall, a.tabEpoch, a.tabEpochShift)
-                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch)
-                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, srcSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
+    // (a probe launch of the placement pick searches the sources' first bytes only -- same tables, same parameters, the same scatter over the allocation, a fraction of the time)
+    const uint32_t searchSize = a.probeCap && srcSize > a.probeCap ? a.probeCap : srcSize;
+    m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall, a.tabEpoch, a.tabEpochShift)
+                   : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch)
+                                 : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;

@@ -304,6 +304,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_SIDE
 #define ZHIP_SIDE 1              // K1b beside K2 on a side stream; 0: the decode kernels one after the other on one stream, two chunk slots (rounds 1-5; A/B build)
 #endif
+#ifndef ZHIP_PICK_STUDY
+#define ZHIP_PICK_STUDY 0        // 1: DIAGNOSTIC build -- the placement pick also times eight candidate allocations whole and over the sources' first bytes, and prints them
+#endif
 #ifndef ZHIP_K0
 #define ZHIP_K0 1                // K0 (zhip_decode_pre_kernel) in front of K1; 0: K1 parses every description itself (A/B build)
 #endif
@@ -1156,6 +1159,11 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             struct PickGuard { DevBuf& b; hipEvent_t& x; hipEvent_t& y; ~PickGuard() { b.release(); if (x) (void)hipEventDestroy(x); if (y) (void)hipEventDestroy(y); } } pickGuard{cand, e0, e1};
             if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
                 ZhipEncodeArgs pa = a; pa.first = 0; pa.count = (uint32_t)cnt0;
+                // (round 6, last session: a probe searches the first 8 KiB of every source only. What makes an allocation the slow kind shows in any stretch of the launch -- eight
+                // candidates in each of six processes, whole launch / first 8 KiB: 405-412 ms / 30.1-30.5 or 468-485 / 35.7-36.4, never out of order (profiles/r06zzr_pick_study.txt) --
+                // so a candidate costs ~35 ms instead of ~450, the first large launch of a context 0.1-0.2 s instead of 1.3, and three slow candidates in a row (one time in eleven
+                // at this box's 4 in 9) get three more tries by the rule below instead of a slow context)
+                pa.probeCap = flatDict ? 0u : 8192u;
                 auto timeOn = [&](uint8_t* t, float* ms) -> int {
                     pa.flatTables = t;
                     HIP_TRY(hipMemsetAsync(cbase + 8, 0, 8, stream)); HIP_TRY(hipMemsetAsync(cbase + 24, 0, 12, stream));
@@ -1171,6 +1179,21 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 };
                 // three candidates: the context's own tables, then two further sets, each reserved beside the best so far (r05g / r05h: 397-415 or 455-488 ms per
                 // 65 536 frames; 746-764, 805, 855, 928 per 131 072); the fastest is kept
+#if ZHIP_PICK_STUDY
+                // DIAGNOSTIC build: does a probe over the sources' first bytes rank the candidates like the whole launch? Eight allocations, each timed whole and capped
+                {   static const uint32_t caps[4] = {0, 32768, 16384, 8192};
+                    const uint32_t cap0 = pa.probeCap;
+                    for (int k = 0; k < 8; k++) {
+                        uint8_t* t = flatTables;
+                        if (k) { if (cand.reserve(bytes)) { (void)hipGetLastError(); break; } t = (uint8_t*)cand.p; }
+                        float ms[4] = {0, 0, 0, 0};
+                        for (int q = 0; q < 4; q++) { pa.probeCap = caps[q]; if (int rc = timeOn(t, &ms[q])) return rc; }
+                        pa.probeCap = cap0;
+                        fprintf(stderr, "[zhip-pick-study] candidate %d %p whole %.1f ms, first 32 KiB %.1f, 16 KiB %.1f, 8 KiB %.1f\n", k, (void*)t, ms[0], ms[1], ms[2], ms[3]);
+                        if (k) cand.release();
+                    }
+                }
+#endif
                 float best = 0;
                 if (int rc = timeOn(flatTables, &best)) return rc;
                 c->e1fPickMs[0] = best;
