@@ -177,7 +177,7 @@ int zhip_compact_device(const void* d_slots, const zhip_segment* d_slotSegs, con
  * 8 the flat match kernel, 9 "zhip_decode_pipeline_span": not a kernel, a chunk's decode pipeline from K1's start to K3's end (what the overlapping kernels cost together). */
 const char* zhip_kernel_name(int k);
 int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64_t* launches);
-/* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 49 152 frames or more times the match kernel on
+/* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 16 384 frames or more -- 49 152 until round 6's last session -- times the match kernel on
  * up to three table allocations held side by side and keeps the fastest; where a probe is cheap -- dictionary batches -- and the three came out alike, up to three more):
  * ms3[k] = candidate k's PROBE time in ms for the first three (0 = not tried) -- since round 6's last session a probe launch searches the first 8 KiB of every source only, which ranks the
  * allocations like the whole launch does at a thirteenth of the time (30 against 36 ms per 65 536 sources of 128 KiB where the whole launches take 407 against 470). Returns the index kept (3..5: one of the further candidates). */

@@ -304,6 +304,10 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #ifndef ZHIP_SIDE
 #define ZHIP_SIDE 1              // K1b beside K2 on a side stream; 0: the decode kernels one after the other on one stream, two chunk slots (rounds 1-5; A/B build)
 #endif
+#ifndef ZHIP_PICK_MIN
+#define ZHIP_PICK_MIN 16384       // sources per launch from which a context's first flat-search launch picks its tables' placement (49 152 while a probe was a whole launch: with probes at ~9 ms per
+                                  // 16 384 sources the host-buffer API's chunks of 32 768 pick too -- multi_compress_to_buffer of 65 536 x 128 KiB 12.4-13.5 -> 13.5-13.9 GB/s in five alternating pairs, r06zzt)
+#endif
 #ifndef ZHIP_PICK_STUDY
 #define ZHIP_PICK_STUDY 0        // 1: DIAGNOSTIC build -- the placement pick also times eight candidate allocations whole and over the sources' first bytes, and prints them
 #endif
@@ -1151,7 +1155,7 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
             args.tabEpoch = ++c->encEpoch; args.tabEpochShift = es;
             return 0;
         };
-        if (flat && !mbc && c->knob.e1fPick && chunk >= 49152 && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
+        if (flat && !mbc && c->knob.e1fPick && chunk >= ZHIP_PICK_MIN && (!c->e1fPicked || c->e1fPickedPtr != c->encFlatTables.p)) {      // (again when a larger batch made the context reallocate its tables)
             c->e1fPicked = true; c->e1fPickKept = 0; c->e1fPickMs[1] = c->e1fPickMs[2] = 0;
             const size_t cnt0 = chunk, bytes = cnt0 * (size_t)a.tableStride;
             DevBuf cand;

@@ -242,7 +242,7 @@ def test_mixed_small_batch_through_the_large_batch_search(zstd, corpus):
 
 
 def test_table_placement_pick_keeps_the_frames(zstd, corpus):
-    """Round 5: the first launch of 49 152 sources or more of a device context times the flat match kernel on up to three table allocations held side by
+    """Round 5: the first launch of 49 152 sources or more (16 384 since round 6's last session) of a device context times the flat match kernel on up to three table allocations held side by
     side and keeps the fastest placement (zhip_compress_batch_device); round 6: up to six when the probes are cheap and the first three are
     alike, which is this batch's case on some boxes (kept = 5 seen in r06zzc / r06zzd). The probes rewrite the chunk's sequences and lists before the real
     pass runs: every frame must still be libzstd's. 49 152 small sources (1-3 KiB: the launch is what counts, not the bytes), every one compared, both calls."""
