@@ -180,7 +180,7 @@ int         zhip_ctx_kernel_time(zhip_ctx*, int direction, double* avgMs, uint64
 /* the compress direction's table placement pick (zhip_compress_batch_device: the first launch of 16 384 frames or more -- 49 152 until round 6's last session -- times the match kernel on
  * up to three table allocations held side by side and keeps the fastest; where a probe is cheap -- dictionary batches -- and the three came out alike, up to three more):
  * ms3[k] = candidate k's PROBE time in ms for the first three (0 = not tried) -- since round 6's last session a probe launch searches the first 8 KiB of every source only, which ranks the
- * allocations like the whole launch does at a thirteenth of the time (30 against 36 ms per 65 536 sources of 128 KiB where the whole launches take 407 against 470). Returns the index kept (3..5: one of the further candidates). */
+ * allocations like the whole launch does at a thirteenth of the time (30 against 36 ms per 65 536 sources of 128 KiB where the whole launches take 407 against 470). Returns the index kept (0..7: eight candidates are probed since round 6's last session -- one allocation in eight was a third, faster kind, 388-392 ms where the usual fast kind takes 406-417). */
 int         zhip_ctx_table_pick(zhip_ctx*, float* ms3);
 
 #ifdef __cplusplus

@@ -65,6 +65,7 @@ for v in "$@"; do
     nofastwide) build nofastwide -DZHIP_FAST_WIDE=0 & ;;   # fast-strategy batches in chunks of 32 768 at eight sources per wave (rounds 2-5)
     notrailer) build notrailer -DZHIP_TRAILER_LATER=0 & ;;   # compress with write_checksum: the entropy kernel hashes the source on one lane (rounds 1-5; A/B of round 6: profiles/r06zt_*)
     noside) build noside -DZHIP_SIDE=0 -DZHIP_K0=0 & ;;    # the decode step as rounds 1-5 ran it: one stream, no K0
+    pick3) build pick3 -DZHIP_PICK_CANDIDATES=3 & ;;       # the placement pick over three candidates (rounds 5-6 until r06zzv)
     pick48k) build pick48k -DZHIP_PICK_MIN=49152 & ;;      # the placement pick from 49 152 sources per launch on only (rounds 5-6 until r06zzt: the host-buffer API's chunks of 32 768 never picked)
     pickstudy) build pickstudy -DZHIP_PICK_STUDY=1 & ;;   # DIAGNOSTIC: the placement pick prints eight candidates' times, whole launches and probes over the sources' first bytes
     nok0) build nok0 -DZHIP_K0=0 & ;;                    # decode without K0: K1's lane 0 parses the Huffman weights and the sequence distributions itself (rounds 1-5; A/B of round 6: profiles/r06w_*)

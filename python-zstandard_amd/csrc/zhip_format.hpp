@@ -118,6 +118,7 @@ struct ZhipEncodeArgs {
     // the kernel's waves zero the tables first (the emulator's default; dictionaries whose index space leaves fewer than 6 bits); else cell = index | tabEpoch << tabEpochShift,
     // the host zeroes the allocation once and whenever the numbers run out or the index width changes (zhip_compress_batch_device)
     uint32_t tabEpoch, tabEpochShift;
+    unsigned long long* waveClock;   // DIAGNOSTIC (null in the product): the flat match kernel's waves leave their duration here, one word per workgroup (-DZHIP_PICK_STUDY=1 reads them)
     uint32_t probeCap;          // != 0: a PROBE launch of the table placement pick (zhip_compress_batch_device) -- the flat search stops after this many bytes of every source; what it leaves is overwritten by the real pass
     uint32_t xxLater;               // != 0: frames leave the entropy kernel with their 4 checksum bytes reserved, not computed -- EX (ze_trailer_body: a LANE per frame) hashes the sources after it
     uint32_t first, count;          // frames [first, first + count) of the batch form this chunk

@@ -308,6 +308,9 @@ extern "C" void zhip_get_cparams(int level, uint64_t srcSizeHint, size_t dictSiz
 #define ZHIP_PICK_MIN 16384       // sources per launch from which a context's first flat-search launch picks its tables' placement (49 152 while a probe was a whole launch: with probes at ~9 ms per
                                   // 16 384 sources the host-buffer API's chunks of 32 768 pick too -- multi_compress_to_buffer of 65 536 x 128 KiB 12.4-13.5 -> 13.5-13.9 GB/s in five alternating pairs, r06zzt)
 #endif
+#ifndef ZHIP_PICK_CANDIDATES
+#define ZHIP_PICK_CANDIDATES 8     // table allocations the placement pick probes (3, up to 6 when alike, until r06zzv)
+#endif
 #ifndef ZHIP_PICK_STUDY
 #define ZHIP_PICK_STUDY 0        // 1: DIAGNOSTIC build -- the placement pick also times eight candidate allocations whole and over the sources' first bytes, and prints them
 #endif
@@ -1184,18 +1187,28 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 // three candidates: the context's own tables, then two further sets, each reserved beside the best so far (r05g / r05h: 397-415 or 455-488 ms per
                 // 65 536 frames; 746-764, 805, 855, 928 per 131 072); the fastest is kept
 #if ZHIP_PICK_STUDY
-                // DIAGNOSTIC build: does a probe over the sources' first bytes rank the candidates like the whole launch? Eight allocations, each timed whole and capped
-                {   static const uint32_t caps[4] = {0, 32768, 16384, 8192};
-                    const uint32_t cap0 = pa.probeCap;
+                // DIAGNOSTIC build: eight candidate allocations, each timed whole and over the sources' first 8 KiB; the probe's waves leave their durations (wall clock, 10 ns units), printed
+                // as the mean of each sixteenth of the allocation -- is a slow allocation slow everywhere?
+                {   const uint32_t cap0 = pa.probeCap;
+                    const size_t nw = (cnt0 + 63) / 64;
+                    unsigned long long* dClock = nullptr; HIP_TRY(hipMalloc((void**)&dClock, nw * 8));
+                    std::vector<unsigned long long> hClock(nw);
                     for (int k = 0; k < 8; k++) {
                         uint8_t* t = flatTables;
                         if (k) { if (cand.reserve(bytes)) { (void)hipGetLastError(); break; } t = (uint8_t*)cand.p; }
-                        float ms[4] = {0, 0, 0, 0};
-                        for (int q = 0; q < 4; q++) { pa.probeCap = caps[q]; if (int rc = timeOn(t, &ms[q])) return rc; }
-                        pa.probeCap = cap0;
-                        fprintf(stderr, "[zhip-pick-study] candidate %d %p whole %.1f ms, first 32 KiB %.1f, 16 KiB %.1f, 8 KiB %.1f\n", k, (void*)t, ms[0], ms[1], ms[2], ms[3]);
+                        float whole = 0, probe = 0;
+                        pa.probeCap = 0; if (int rc = timeOn(t, &whole)) return rc;
+                        HIP_TRY(hipMemsetAsync(dClock, 0, nw * 8, stream));
+                        pa.probeCap = 8192; pa.waveClock = dClock; if (int rc = timeOn(t, &probe)) return rc;
+                        pa.waveClock = nullptr; pa.probeCap = cap0;
+                        HIP_TRY(hipMemcpy(hClock.data(), dClock, nw * 8, hipMemcpyDeviceToHost));
+                        char line[512]; int o = 0; unsigned long long mn = ~0ull, mx = 0;
+                        for (int q = 0; q < 16; q++) { double sum = 0; size_t lo = nw * q / 16, hi = nw * (q + 1) / 16; for (size_t w = lo; w < hi; w++) { sum += (double)hClock[w]; if (hClock[w] < mn) mn = hClock[w]; if (hClock[w] > mx) mx = hClock[w]; }
+                                                       o += snprintf(line + o, sizeof line - o, " %.2f", sum / (double)(hi - lo ? hi - lo : 1) / 1e5); }
+                        fprintf(stderr, "[zhip-pick-study] candidate %d %p whole %.1f ms, first 8 KiB %.1f; waves' ms by sixteenth of the allocation:%s (min %.2f max %.2f)\n", k, (void*)t, whole, probe, line, mn / 1e5, mx / 1e5);
                         if (k) cand.release();
                     }
+                    (void)hipFree(dClock);
                 }
 #endif
                 float best = 0;
@@ -1204,9 +1217,11 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 // (round 6: where a probe is cheap -- dictionary batches: ~40 ms and 12 GiB a candidate -- and the first three came out ALIKE, which says they are one kind but not
                 // which, up to three more are tried until one is clearly faster: a dictionary batch's candidates are the fast kind one time in three, 35.4 ms against 41-42
                 // (r06u: [35.6, 42.1, 42.1], [42.3, 35.3, 42.1]; r06z: [41.1, 40.9, 41.2] -- all slow, 23.2 GB/s instead of 26.5), so three of them are all slow three runs in ten)
+                // (round 6, last session: EIGHT candidates, always. With probes at ~35 ms there is no reason to stop at the first fast one, and there is a third kind: the wave-clock study
+                // (profiles/r06zzv_wave_clocks.txt) found allocations at 388-392 ms per 65 536 sources beside the 406-417 and 467-473 ones -- one candidate in eight, the eighth in each of
+                // three processes; an allocation's kind is the same over all of its sixteenths, so there is nothing to pick INSIDE one)
                 float worst = best;
-                for (int k = 1; k < 6; k++) {
-                    if (k >= 3 && !(best < 100.0f && best > 0.95f * worst)) break;
+                for (int k = 1; k < ZHIP_PICK_CANDIDATES; k++) {
                     if (cand.reserve(bytes)) { (void)hipGetLastError(); break; }                 // no room for another set: keep what we have
                     float ms = 0;
                     if (int rc = timeOn((uint8_t*)cand.p, &ms)) return rc;

@@ -244,7 +244,7 @@ def test_mixed_small_batch_through_the_large_batch_search(zstd, corpus):
 def test_table_placement_pick_keeps_the_frames(zstd, corpus):
     """Round 5: the first launch of 49 152 sources or more (16 384 since round 6's last session) of a device context times the flat match kernel on up to three table allocations held side by
     side and keeps the fastest placement (zhip_compress_batch_device); round 6: up to six when the probes are cheap and the first three are
-    alike, which is this batch's case on some boxes (kept = 5 seen in r06zzc / r06zzd). The probes rewrite the chunk's sequences and lists before the real
+    alike, which is this batch's case on some boxes (kept = 5 seen in r06zzc / r06zzd); since the round's last session eight, always (the probes are short). The probes rewrite the chunk's sequences and lists before the real
     pass runs: every frame must still be libzstd's. 49 152 small sources (1-3 KiB: the launch is what counts, not the bytes), every one compared, both calls."""
     import importlib
     import torch
@@ -273,7 +273,7 @@ def test_table_placement_pick_keeps_the_frames(zstd, corpus):
             torch.cuda.synchronize()
             assert int(status.abs().max().item()) == 0
             ms, kept = ctx.table_pick()
-            assert ms[0] > 0 and ms[1] > 0 and 0 <= kept <= 5, (ms, kept)
+            assert ms[0] > 0 and ms[1] > 0 and 0 <= kept <= 7, (ms, kept)
             got = dst.view(F, bound).cpu().numpy(); sz = out_sizes.cpu().numpy()
             for i in range(F):                                      # ALL of them (the probes rewrite every list up to three times; it costs seconds)
                 assert got[i, : sz[i]].tobytes() == ref.compress(src_np[offs[i]: offs[i] + lens[i]].tobytes(), level=3), i
