@@ -67,6 +67,7 @@ for v in "$@"; do
     noside) build noside -DZHIP_SIDE=0 -DZHIP_K0=0 & ;;    # the decode step as rounds 1-5 ran it: one stream, no K0
     pick3) build pick3 -DZHIP_PICK_CANDIDATES=3 & ;;       # the placement pick over three candidates (rounds 5-6 until r06zzv)
     pick48k) build pick48k -DZHIP_PICK_MIN=49152 & ;;      # the placement pick from 49 152 sources per launch on only (rounds 5-6 until r06zzt: the host-buffer API's chunks of 32 768 never picked)
+    pickstudy24) build pickstudy24 -DZHIP_PICK_STUDY=24 & ;;   # the same over 24 candidates (whole launches for the first eight)
     pickstudy) build pickstudy -DZHIP_PICK_STUDY=1 & ;;   # DIAGNOSTIC: the placement pick prints eight candidates' times, whole launches and probes over the sources' first bytes
     nok0) build nok0 -DZHIP_K0=0 & ;;                    # decode without K0: K1's lane 0 parses the Huffman weights and the sequence distributions itself (rounds 1-5; A/B of round 6: profiles/r06w_*)
     dchunk32k) build dchunk32k -DZHIP_DCHUNK=32768 & ;;    # decode: chunks of 32 768 frames on the slot streams (round 6 A/B with K1b beside K2: profiles/r06q_*)

@@ -1193,11 +1193,11 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                     const size_t nw = (cnt0 + 63) / 64;
                     unsigned long long* dClock = nullptr; HIP_TRY(hipMalloc((void**)&dClock, nw * 8));
                     std::vector<unsigned long long> hClock(nw);
-                    for (int k = 0; k < 8; k++) {
+                    for (int k = 0; k < (ZHIP_PICK_STUDY > 1 ? ZHIP_PICK_STUDY : 8); k++) {            // (-DZHIP_PICK_STUDY=n, n > 1: n candidates, whole launches for the first eight only)
                         uint8_t* t = flatTables;
                         if (k) { if (cand.reserve(bytes)) { (void)hipGetLastError(); break; } t = (uint8_t*)cand.p; }
                         float whole = 0, probe = 0;
-                        pa.probeCap = 0; if (int rc = timeOn(t, &whole)) return rc;
+                        pa.probeCap = 0; if (k < 8) if (int rc = timeOn(t, &whole)) return rc;
                         HIP_TRY(hipMemsetAsync(dClock, 0, nw * 8, stream));
                         pa.probeCap = 8192; pa.waveClock = dClock; if (int rc = timeOn(t, &probe)) return rc;
                         pa.waveClock = nullptr; pa.probeCap = cap0;
