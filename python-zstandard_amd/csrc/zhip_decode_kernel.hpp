@@ -90,8 +90,10 @@ enum { ZP_HEADER = 0, ZP_HUFTAB, ZP_HUFDEC, ZP_SEQTAB, ZP_STAGE, ZP_SEQDEC, ZP_E
 struct ZdProf { bool on; uint64_t t0; uint64_t acc[ZP_N]; };
 #ifndef ZHIP_EMU
 ZH_DEV uint64_t zd_clock() { return __builtin_readcyclecounter(); }
+ZH_DEV uint64_t zd_wall_clock() { return (uint64_t)wall_clock64(); }          // constant 100 MHz: comparable across waves and CUs (the pick study's per-wave durations)
 #else
 ZH_DEV uint64_t zd_clock() { return 0; }
+ZH_DEV uint64_t zd_wall_clock() { return 0; }
 #endif
 #define ZD_T(P, i) do { if ((P).on) { uint64_t t1_ = zd_clock(); (P).acc[i] += t1_ - (P).t0; (P).t0 = t1_; } } while (0)
 

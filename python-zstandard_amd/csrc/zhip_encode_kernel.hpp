@@ -3056,11 +3056,11 @@ ZH_DEVFN void ze_match_flat_body(const ZhipEncodeArgs& a)
     uint8_t* fr = a.arena + (size_t)i * a.arenaStride;
     // (a probe launch of the placement pick searches the sources' first bytes only -- same tables, same parameters, the same scatter over the allocation, a fraction of the time)
     const uint32_t searchSize = a.probeCap && srcSize > a.probeCap ? a.probeCap : srcSize;
-    const uint64_t wc0 = a.waveClock ? (uint64_t)wall_clock64() : 0ull;
+    const uint64_t wc0 = a.waveClock ? zd_wall_clock() : 0ull;
     m.nbSeq = dict ? ze_dfast_dict_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp, *a.cdict, a.cdictContent, a.cdictHashLong, a.cdictHashSmall, hashLong, hashSmall, a.tabEpoch, a.tabEpochShift)
                    : NPROBE > 2 ? ze_dfast_flatn<NPROBE>((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch)
                                  : ze_dfast_flat((uint64_t*)(fr + ZE_ARENA_SEQ), src, searchSize, cp.hlog, cp.clog, cp.mml, hashLong, hashSmall, a.idle, a.tabEpoch);
-    if (a.waveClock && lane == 0) a.waveClock[zh_block()] = (uint64_t)wall_clock64() - wc0;
+    if (a.waveClock && lane == 0) a.waveClock[zh_block()] = zd_wall_clock() - wc0;
     m.mode = 4;
 #ifdef ZHIP_EMU
     zd_stat[15]++;
