@@ -35,9 +35,12 @@ for direction in ("decode", "compress", "dict"):              # dict: kernel tra
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     # (the compress trace's average mixed in the table pick's probe launches -- the first launches of the flat match kernel in a fresh
     # context, up to three, on candidate allocations of which only the fastest is kept. They are dropped here: what is left is the steady state the bench times)
+    # Since round 6's last session the probes are SHORT launches (the first 8 KiB of every source, eight of them): they are told from the real launches by their size --
+    # anything below half the longest launch (kernel trace) / half the largest count (counter passes, below) is a probe.
     k_ = "zhip_encode_match_flat_kernel"
-    if direction == "compress" and len(dur.get(k_, [])) > 4:
-        dur[k_] = dur[k_][3:]
+    if direction in ("compress", "dict") and dur.get(k_):
+        top = max(dur[k_]); dur[k_] = [d for d in dur[k_] if d >= 0.5 * top]
+        if direction == "dict" and len(dur[k_]) > 8: dur[k_] = dur[k_][8:]      # (a dictionary batch's probes are whole launches -- its documents are shorter than a probe's 8 KiB: the first eight launches of the context)
     if dur:
         with open(os.path.join(out_dir, "%s_%s_kt_zhip_kernels_summary.csv" % (tag, direction)), "w", newline="") as fh:
             w = csv.writer(fh)
@@ -57,6 +60,7 @@ for direction in ("decode", "compress", "dict"):              # dict: kernel tra
             for k in sorted(acc):
                 for c in sorted(acc[k]):
                     v = acc[k][c]
+                    if k == k_ and v and max(v) > 0: v = [x for x in v if x >= 0.5 * max(v)]          # (the pick's probe launches: see above)
                     w.writerow([k, c, len(v), round(sum(v) / len(v), 3)])
                     if c in ("FETCH_SIZE", "WRITE_SIZE"):               # KiB per launch (rocprofv3's unit) -> bytes per frame
                         traffic[k] += sum(v) / len(v) * 1024.0 / frames
