@@ -5,6 +5,7 @@
 // (POOL_*, zstd.c:7537-7975) it stages them in HBM and launches persistent one-wave workgroups that pull frame
 // indices from an atomic counter.
 #include <atomic>
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <time.h>
@@ -1220,11 +1221,22 @@ extern "C" int zhip_compress_batch_device(zhip_ctx* c, const void* d_src, const 
                 // (round 6, last session: EIGHT candidates, always. With probes at ~35 ms there is no reason to stop at the first fast one, and there is a third kind: the wave-clock study
                 // (profiles/r06zzv_wave_clocks.txt) found allocations at 388-392 ms per 65 536 sources beside the 406-417 and 467-473 ones -- one candidate in eight, the eighth in each of
                 // three processes; an allocation's kind is the same over all of its sixteenths, so there is nothing to pick INSIDE one)
+                // (a released candidate's memory does not come back at once: the EIGHTH 28 GiB reservation of a 65 536-source context, with ~70 GiB of the process's own in use, waited
+                // 4.7 s for the driver to reclaim what the earlier candidates had left -- profiles/r06zzz6_pick_candidates_cost.txt -- where every other one took 0.3 ms. So the candidates'
+                // reservations together stay inside what was free when the pick began, less one more set and 8 GiB: seven candidates there, two at 131 072 sources per launch)
                 float worst = best;
+                size_t free0 = 0, total0 = 0;
+                if (hipMemGetInfo(&free0, &total0) != hipSuccess) { (void)hipGetLastError(); free0 = 0; }
+                const size_t want = bytes + (bytes >> 3) + 4096;
                 for (int k = 1; k < ZHIP_PICK_CANDIDATES; k++) {
+                    if ((size_t)k * want + want + ((size_t)8 << 30) > free0) break;
+                    const auto tc0 = std::chrono::steady_clock::now();
                     if (cand.reserve(bytes)) { (void)hipGetLastError(); break; }                 // no room for another set: keep what we have
+                    const auto tc1 = std::chrono::steady_clock::now();
                     float ms = 0;
                     if (int rc = timeOn((uint8_t*)cand.p, &ms)) return rc;
+                    if (c->knob.prof) fprintf(stderr, "[zhip-prof] pick candidate %d: reserve %.1f ms, zero + probe %.1f ms (the probe launch %.1f)\n", k,
+                                              std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count(), ms);
                     if (k < 3) c->e1fPickMs[k] = ms;
                     if (ms > worst) worst = ms;
                     if (ms < 0.97f * best) { std::swap(c->encFlatTables.p, cand.p); std::swap(c->encFlatTables.cap, cand.cap); std::swap(c->encFlatTables.gen, cand.gen); best = ms; c->e1fPickKept = k; }
